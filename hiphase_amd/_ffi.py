@@ -1,0 +1,194 @@
+"""ctypes bindings for include/hiphase_gpu.h (the drop-in C ABI).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950) as
+``hiphase_amd/libhiphase_gpu.so``. Loading fails loudly when it is missing — there is no fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhiphase_gpu.so")
+
+
+class HpError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"hiphase_gpu status {code}: {msg}")
+        self.code = code
+
+
+class BlockView(C.Structure):
+    _fields_ = [
+        ("n_variants", C.c_uint32),
+        ("n_reads", C.c_uint32),
+        ("read_start", C.POINTER(C.c_uint32)),
+        ("read_end", C.POINTER(C.c_uint32)),
+        ("row_off", C.POINTER(C.c_uint64)),
+        ("alleles_2bit", C.POINTER(C.c_uint8)),
+        ("quals", C.POINTER(C.c_uint8)),
+        ("var_flags", C.POINTER(C.c_uint8)),
+    ]
+
+
+class AstarParams(C.Structure):
+    _fields_ = [
+        ("min_queue_size", C.c_uint64),
+        ("queue_increment", C.c_uint64),
+        ("max_segment_size", C.c_uint64),
+        ("block_index", C.c_uint64),
+    ]
+
+
+class PhaseStats(C.Structure):
+    _fields_ = [
+        ("pruned_solutions", C.c_uint64),
+        ("estimated_cost", C.c_uint64),
+        ("actual_cost", C.c_uint64),
+        ("phased_variants", C.c_uint64),
+        ("phased_snvs", C.c_uint64),
+        ("homozygous_variants", C.c_uint64),
+        ("skipped_variants", C.c_uint64),
+    ]
+
+    def as_tuple(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+class WorkCounters(C.Structure):
+    _fields_ = [
+        ("sub_pops", C.c_uint64),
+        ("main_pops", C.c_uint64),
+        ("evals", C.c_uint64),
+        ("cells", C.c_uint64),
+        ("nodes_created", C.c_uint64),
+        ("reserved", C.c_uint64 * 3),
+    ]
+
+    def as_tuple(self):
+        return (self.sub_pops, self.main_pops, self.evals, self.cells, self.nodes_created)
+
+
+class SynthSpec(C.Structure):
+    _fields_ = [
+        ("n_variants", C.c_uint32),
+        ("coverage", C.c_uint32),
+        ("span", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("error_rate", C.c_double),
+        ("ambig_rate", C.c_double),
+        ("seed", C.c_uint64),
+    ]
+
+
+class WfaVariant(C.Structure):
+    _fields_ = [
+        ("position", C.c_int64),
+        ("ref_len", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("allele0", C.POINTER(C.c_uint8)),
+        ("allele0_len", C.c_uint32),
+        ("allele1_len", C.c_uint32),
+        ("allele1", C.POINTER(C.c_uint8)),
+    ]
+
+
+class WfaJob(C.Structure):
+    _fields_ = [
+        ("reference", C.POINTER(C.c_uint8)),
+        ("ref_base", C.c_uint64),
+        ("ref_start", C.c_uint64),
+        ("ref_end", C.c_uint64),
+        ("hets", C.POINTER(WfaVariant)),
+        ("n_hets", C.c_uint32),
+        ("n_homs", C.c_uint32),
+        ("homs", C.POINTER(WfaVariant)),
+        ("read", C.POINTER(C.c_uint8)),
+        ("read_len", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class WfaResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_nodes", C.c_uint32), ("score", C.c_uint64)]
+
+
+class EdPair(C.Structure):
+    _fields_ = [
+        ("a", C.POINTER(C.c_uint8)),
+        ("b", C.POINTER(C.c_uint8)),
+        ("a_len", C.c_uint32),
+        ("b_len", C.c_uint32),
+    ]
+
+
+# Every symbol include/hiphase_gpu.h declares; tests check the library exports all of them.
+EXPORTS = [
+    "hp_astar_solve",
+    "hp_astar_solve_batch",
+    "hp_batch_create",
+    "hp_batch_solve",
+    "hp_batch_results",
+    "hp_batch_destroy",
+    "hp_wfa_assign_batch",
+    "hp_edit_distance_batch",
+    "hp_device_count",
+    "hp_default_device",
+    "hp_last_error",
+    "hp_version",
+    "hp_synth_block_size",
+    "hp_synth_block",
+]
+
+
+def declare_common(dll):
+    """argtypes/restype for the symbols shared by libhiphase_gpu.so and (synth only) liboracle.so."""
+    dll.hp_synth_block_size.restype = C.c_uint32
+    dll.hp_synth_block_size.argtypes = [C.POINTER(SynthSpec), C.POINTER(C.c_uint64)]
+    dll.hp_synth_block.restype = C.c_int
+    dll.hp_synth_block.argtypes = [C.POINTER(SynthSpec)] + [C.c_void_p] * 7
+
+
+_lib = None
+
+
+def lib():
+    """Load libhiphase_gpu.so (once). Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HpError(-1, f"{LIB_PATH} not found — run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                          "there is no CPU fallback")
+    dll = C.CDLL(LIB_PATH)
+    declare_common(dll)
+    dll.hp_astar_solve.restype = C.c_int
+    dll.hp_astar_solve.argtypes = [C.POINTER(BlockView), C.POINTER(AstarParams), C.c_void_p, C.c_void_p,
+                                   C.POINTER(PhaseStats)]
+    dll.hp_astar_solve_batch.restype = C.c_int
+    dll.hp_astar_solve_batch.argtypes = [C.c_size_t, C.POINTER(BlockView), C.POINTER(AstarParams),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(PhaseStats), C.c_int]
+    dll.hp_batch_create.restype = C.c_void_p
+    dll.hp_batch_create.argtypes = [C.c_size_t, C.POINTER(BlockView), C.POINTER(AstarParams), C.c_int,
+                                    C.POINTER(C.c_int)]
+    dll.hp_batch_solve.restype = C.c_int
+    dll.hp_batch_solve.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    dll.hp_batch_results.restype = C.c_int
+    dll.hp_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    dll.hp_batch_destroy.restype = None
+    dll.hp_batch_destroy.argtypes = [C.c_void_p]
+    dll.hp_wfa_assign_batch.restype = C.c_int
+    dll.hp_wfa_assign_batch.argtypes = [C.POINTER(WfaJob), C.c_size_t, C.c_uint64, C.c_uint64,
+                                        C.POINTER(WfaResult), C.POINTER(C.c_void_p), C.c_int]
+    dll.hp_edit_distance_batch.restype = C.c_int
+    dll.hp_edit_distance_batch.argtypes = [C.POINTER(EdPair), C.c_size_t, C.POINTER(C.c_uint64), C.c_int]
+    dll.hp_device_count.restype = C.c_int
+    dll.hp_default_device.restype = C.c_int
+    dll.hp_last_error.restype = C.c_char_p
+    dll.hp_version.restype = C.c_char_p
+    _lib = dll
+    return dll
+
+
+def check(code):
+    if code < 0:
+        raise HpError(code, lib().hp_last_error().decode())
+    return code

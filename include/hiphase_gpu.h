@@ -1,0 +1,200 @@
+/*
+ * hiphase_gpu.h — C ABI of libhiphase_gpu.so: the MI355X (gfx950) phasing core that drops in
+ * behind HiPhase's per-block entry point (reference src/phaser.rs:406 `solve_block`).
+ *
+ * The reference has no FFI for this path; the seams this ABI replaces are the Rust call sites
+ *   - src/phaser.rs:541-543            astar_phaser::astar_solver(...)            -> hp_astar_solve*
+ *   - src/read_parsing.rs:769-780      WFAGraph::from_reference_variants_with_hom + edit_distance_with_pruning
+ *                                                                                  -> hp_wfa_assign_batch
+ *   - src/data_types/variants.rs:627   sequence_alignment::edit_distance           -> hp_edit_distance_batch
+ *   - src/phaser.rs:546,614-623        get_solution_span_counts / haplotag_reads   -> hp_block_postprocess
+ * INTEGRATION.md shows the `extern "C"` block + call-site patch a HiPhase maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, caller owns every buffer, no pointer outlives a call
+ * (except opaque hp_batch handles). All entry points are re-entrant (called from HiPhase's
+ * `--threads` pool, src/main.rs:332,385). Return value: 0 = OK, >0 = per-item soft status,
+ * <0 = fatal (HIP error / OOM / violated invariant) — the Rust side maps <0 onto its existing
+ * `error!` + `exit(SOFTWARE)` path (src/main.rs:401-405).
+ */
+#ifndef HIPHASE_GPU_H
+#define HIPHASE_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define HP_OK                 0
+#define HP_WFA_MAX_ED         1   /* per-job: WFAGraphError::MaxEditDistance (wfa_graph.rs:13-17,645-648) */
+#define HP_ERR_HIP           -1   /* HIP runtime error / no device / kernel image missing */
+#define HP_ERR_OOM           -2   /* host or device allocation failed */
+#define HP_ERR_INVARIANT     -3   /* an `assert!`/`panic!` of the reference would have fired */
+#define HP_ERR_ARG           -4   /* malformed view (row_off not monotone, N==0, ...) */
+#define HP_ERR_UNSUPPORTED   -5   /* outside the packed-key limits documented in DESIGN.md */
+
+/* ---- AlleleType (src/data_types/read_segments.rs:5-16) ----------------------------------- */
+#define HP_ALLELE_REFERENCE 0
+#define HP_ALLELE_ALTERNATE 1
+#define HP_ALLELE_AMBIGUOUS 2
+#define HP_ALLELE_NOOVERLAP 3
+
+/* ---- per-variant flags (what astar_solver reads from `Variant`, astar_phaser.rs:438,446,606) */
+#define HP_VAR_IGNORED 0x1   /* Variant::is_ignored() */
+#define HP_VAR_SNV     0x2   /* Variant::get_type() == VariantType::Snv */
+
+/*
+ * One phase block's read x variant allele matrix = the IntervalTree<usize, ReadSegment> that
+ * phaser.rs:514-533 hands to astar_solver, flattened to CSR. Row r is ReadSegment r:
+ *   region()  = [read_start[r], read_end[r])            (read_segments.rs:29,52)
+ *   allele(i) = 2-bit code at cell  row_off[r] + (i - read_start[r])
+ *   qual(i)   = quals[ row_off[r] + (i - read_start[r]) ]
+ * Cell c of alleles_2bit lives in byte c/4, bits [2*(c%4), 2*(c%4)+2).
+ * Rows may come in any order (the library sorts by start). A row with start==end is legal and inert.
+ */
+typedef struct hp_block_view {
+    uint32_t        n_variants;    /* N  = variants.len()  (astar_phaser.rs:431) */
+    uint32_t        n_reads;       /* R  = rows in the solver tree */
+    const uint32_t* read_start;    /* [R] */
+    const uint32_t* read_end;      /* [R] exclusive */
+    const uint64_t* row_off;       /* [R+1] cell offsets, row_off[r+1]-row_off[r] == end-start */
+    const uint8_t*  alleles_2bit;  /* ceil(row_off[R]/4) bytes */
+    const uint8_t*  quals;         /* row_off[R] bytes */
+    const uint8_t*  var_flags;     /* [N] HP_VAR_* */
+} hp_block_view;
+
+/* Solver parameters (cli.rs:217,224; astar_phaser.rs:466). */
+typedef struct hp_astar_params {
+    uint64_t min_queue_size;    /* --phase-min-queue-size, default 1000 */
+    uint64_t queue_increment;   /* --phase-queue-increment, default 3   */
+    uint64_t max_segment_size;  /* hard-coded 40 in the reference (astar_phaser.rs:466); 0 => 40 */
+    uint64_t block_index;       /* PhaseBlock::get_block_index(), diagnostics only */
+} hp_astar_params;
+
+/* PhaseStats as filled by astar_solver (astar_phaser.rs:599-621, phase_stats.rs:131-173). */
+typedef struct hp_phase_stats {
+    uint64_t pruned_solutions;
+    uint64_t estimated_cost;
+    uint64_t actual_cost;
+    uint64_t phased_variants;
+    uint64_t phased_snvs;
+    uint64_t homozygous_variants;
+    uint64_t skipped_variants;
+} hp_phase_stats;
+
+/* Work counters: the roofline numerator of SURVEY.md §8(d). Deterministic properties of the input
+ * (the search trajectory is a total order), so oracle and device must agree exactly. */
+typedef struct hp_work_counters {
+    uint64_t sub_pops;      /* nodes popped by astar_subsolver over the whole heuristic chain */
+    uint64_t main_pops;     /* nodes popped by the main search (incl. pruned ones) */
+    uint64_t evals;         /* (child node, read) pairs scored in new_extended_node */
+    uint64_t cells;         /* sum over evals of the overlap length l (cells touched per haplotype) */
+    uint64_t nodes_created; /* children created (sub + main) */
+    uint64_t reserved[3];
+} hp_work_counters;
+
+/* ---- A* MEC solver ------------------------------------------------------------------------ */
+
+/* Replaces astar_phaser::astar_solver (astar_phaser.rs:426-633) for one block.
+ * h1/h2: N bytes each, AlleleType codes 0/1/2. Runs on device `hp_default_device()`. */
+int hp_astar_solve(const hp_block_view* blk, const hp_astar_params* p,
+                   uint8_t* h1, uint8_t* h2, hp_phase_stats* out);
+
+/* Batch form used by the multi-GPU block queue: n_blocks independent blocks, one params struct
+ * shared by all (HiPhase passes the same CLI values to every block, main.rs:385-399).
+ * device_id >= 0: that device; device_id == -1: shard over every visible device with a host-side
+ * LPT work queue (one worker thread per device, no collective). h1[i]/h2[i] -> N_i bytes. */
+int hp_astar_solve_batch(size_t n_blocks, const hp_block_view* blks, const hp_astar_params* p,
+                         uint8_t* const* h1, uint8_t* const* h2, hp_phase_stats* out, int device_id);
+
+/* Resident form: pack + upload once, solve many times (what bench.py times: inputs already in HBM). */
+typedef struct hp_batch hp_batch;
+hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_astar_params* p,
+                          int device_id, int* status);
+/* Launches the solve on `stream` (a hipStream_t passed as void*; NULL = the batch's own stream) and
+ * waits for it. kernel_ms (may be NULL) receives the HIP-event time of the solve kernel(s). */
+int  hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms);
+/* Copies results of the last solve to host. Any pointer may be NULL. h1/h2: concatenated over blocks
+ * (sum N_i bytes); stats/counters: [n_blocks]. */
+int  hp_batch_results(hp_batch* b, uint8_t* h1, uint8_t* h2, hp_phase_stats* stats,
+                      hp_work_counters* counters, uint64_t* heuristics /* sum (N_i+1) or NULL */);
+void hp_batch_destroy(hp_batch* b);
+
+/* ---- graph-WFA allele assignment ---------------------------------------------------------- */
+
+/* One variant as WFAGraph::from_reference_variants_with_hom reads it (wfa_graph.rs:146-251):
+ * position(), get_ref_len(), get_truncated_allele0/1(), convert_index(Reference) != 0, is_ignored(). */
+typedef struct hp_wfa_variant {
+    int64_t        position;        /* 0-based, chromosome coordinates */
+    uint32_t       ref_len;
+    uint32_t       flags;           /* bit0: ignored; bit1: allele0 is itself an ALT (index_allele0 != 0) */
+    const uint8_t* allele0;         /* truncated allele0 (variants.rs:581-585); unused unless flags&2 */
+    uint32_t       allele0_len;
+    uint32_t       allele1_len;
+    const uint8_t* allele1;         /* truncated allele1 (variants.rs:587-591) */
+} hp_wfa_variant;
+
+/* One BAM record's re-alignment job (read_parsing.rs:738-780). `reference` points at the chromosome
+ * sequence such that reference[x - ref_base] is base x for x in [ref_start, ref_end). */
+typedef struct hp_wfa_job {
+    const uint8_t*        reference;
+    uint64_t              ref_base;      /* chromosome coordinate of reference[0] */
+    uint64_t              ref_start;     /* min_position (inclusive) */
+    uint64_t              ref_end;       /* max_position + 1 (exclusive) */
+    const hp_wfa_variant* hets;          /* variant_calls[first_overlap..last_overlap) */
+    uint32_t              n_hets;
+    uint32_t              n_homs;
+    const hp_wfa_variant* homs;          /* hom_calls[first_hom_overlap..last_hom_overlap) */
+    const uint8_t*        read;          /* read_align = seq[read_start..=read_end] */
+    uint32_t              read_len;
+    uint32_t              reserved;
+} hp_wfa_job;
+
+typedef struct hp_wfa_result {
+    int32_t  status;       /* HP_OK or HP_WFA_MAX_ED */
+    uint32_t n_nodes;      /* WFAGraph::get_num_nodes() */
+    uint64_t score;        /* WFAResult::score(); max_edit_distance when status == HP_WFA_MAX_ED */
+} hp_wfa_result;
+
+/* Replaces graph build + edit_distance_with_pruning + the node->allele mapping of
+ * read_parsing.rs:790-800 for n jobs. alleles[i] must hold jobs[i].n_hets bytes and receives one
+ * AlleleType per het of the job (NoOverlap / Reference / Alternate / Ambiguous).
+ * prune_distance: GlobalRealignmentConfig::wfa_prune_distance (UINT64_MAX disables pruning).
+ * max_ed: GlobalRealignmentConfig::max_edit_distance. */
+int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
+                        hp_wfa_result* out, uint8_t* const* alleles, int device_id);
+
+/* ---- Levenshtein (sequence_alignment.rs:7-38) --------------------------------------------- */
+typedef struct hp_ed_pair { const uint8_t* a; const uint8_t* b; uint32_t a_len; uint32_t b_len; } hp_ed_pair;
+int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_t* out, int device_id);
+
+/* ---- misc --------------------------------------------------------------------------------- */
+int         hp_device_count(void);
+int         hp_default_device(void);
+const char* hp_last_error(void);        /* thread-local, never NULL */
+const char* hp_version(void);
+
+/* Deterministic synthetic block generator of SURVEY.md §8(d) (splitmix64). Fills caller-provided
+ * buffers sized via hp_synth_block_size(). Used by tests and bench.py on both legs. */
+typedef struct hp_synth_spec {
+    uint32_t n_variants;  /* N */
+    uint32_t coverage;    /* C */
+    uint32_t span;        /* S */
+    uint32_t reserved;
+    double   error_rate;  /* e */
+    double   ambig_rate;  /* a */
+    uint64_t seed;
+} hp_synth_spec;
+/* returns R; *n_cells = upper bound on cells (R * min(N, ceil(1.5*S)+1)) */
+uint32_t hp_synth_block_size(const hp_synth_spec* s, uint64_t* n_cells);
+/* returns 0; fills arrays (read_start/end [R], row_off [R+1], alleles_2bit, quals, var_flags [N],
+ * truth [N] may be NULL). Rows that end up with no set allele keep start==end (inert). */
+int hp_synth_block(const hp_synth_spec* s, uint32_t* read_start, uint32_t* read_end, uint64_t* row_off,
+                   uint8_t* alleles_2bit, uint8_t* quals, uint8_t* var_flags, uint8_t* truth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPHASE_GPU_H */

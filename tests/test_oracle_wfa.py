@@ -1,0 +1,107 @@
+"""Pins the WFA oracle against the reference's 19 wfa_graph tests (wfa_graph.rs:677-1208): exact
+(score, traversed_nodes) and exact node_to_alleles, plus hash-iteration-order independence."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from hiphase_amd import _ffi
+from hiphase_amd.wfa_graph import make_jobs
+from oracle_ffi import OracleGraph, oracle
+from wfa_util import spec_from_golden, synth_wfa_job
+
+G = load_golden("wfa_graph.json")
+
+
+@pytest.mark.parametrize("case", G["hand_built"], ids=lambda c: c["name"])
+def test_hand_built(case):
+    g = OracleGraph()
+    for i, n in enumerate(case["nodes"]):
+        assert g.add_node(n["seq"], n["parents"]) == i
+    for q in case["queries"]:
+        for seed in (0, 1, 7, 12345):
+            st, score, nodes = g.edit_distance(q["seq"], shuffle_seed=seed)
+            assert st == 0 and score == q["score"], (case["name"], q)
+            if q["nodes"] is not None:
+                assert nodes == q["nodes"], (case["name"], q)
+
+
+def test_add_node_errors():
+    g = OracleGraph()
+    assert g.add_node([1], [0]) < 0          # first node must have no parents (wfa_graph.rs:302-306)
+    assert g.add_node([1], []) == 0
+    assert g.add_node([2], []) < 0           # later nodes need a parent (:309-311)
+    assert g.add_node([2], [1]) < 0          # parent must precede (:313-317)
+    assert g.add_node([2], [0]) == 1
+
+
+@pytest.mark.parametrize("case", G["variant_built"], ids=lambda c: c["name"])
+def test_variant_built(case):
+    d = oracle()
+    spec = spec_from_golden(case)
+    jobs, keep = make_jobs([spec])
+    status = C.c_int(0)
+    h = d.hpo_graph_from_job(C.byref(jobs[0]), 1000, C.byref(status))
+    assert h and status.value == 0
+    g = OracleGraph(handle=h)
+    assert g.num_nodes() == case["num_nodes"]
+    for node, exp in case["node_to_alleles"].items():
+        assert g.node_alleles(int(node)) == [tuple(e) for e in exp], (case["name"], node)
+    for q in case["queries"]:
+        for seed in (0, 3, 99):
+            st, score, nodes = g.edit_distance(q["seq"], shuffle_seed=seed)
+            assert st == 0 and score == q["score"] and nodes == q["nodes"], (case["name"], q, score, nodes)
+
+
+def test_overlapping_variants_structure():
+    """wfa_graph.rs:919-923 picture: REF 0->2->4->5->6, ALT 1 rejoins at 5, ALT 3 rejoins at 6."""
+    case = next(c for c in G["variant_built"] if c["name"] == "test_overlapping_variants")
+    d = oracle()
+    jobs, keep = make_jobs([spec_from_golden(case)])
+    st = C.c_int(0)
+    g = OracleGraph(handle=d.hpo_graph_from_job(C.byref(jobs[0]), 1000, C.byref(st)))
+    assert [g.node_seq(i) for i in range(7)] == [b"A", b"C", b"C", b"G", b"G", b"T", b"A"]
+    assert [g.node_parents(i) for i in range(7)] == [[], [0], [0], [2], [2], [1, 4], [3, 5]]
+    assert g.node_edges(0) == [1, 2] and g.node_edges(2) == [3, 4]
+
+
+def test_max_edit_distance_error():
+    """wfa_graph.rs:645-648: Err(MaxEditDistance) once edit_distance > max."""
+    g = OracleGraph(max_edit_distance=2)
+    g.add_node(list(b"AAAAAAAA"), [])
+    st, score, _ = g.edit_distance(list(b"CCCCCCCC"))
+    assert st == 1 and score == 2
+    st, score, _ = g.edit_distance(list(b"AACCAAAA"))
+    assert st == 0 and score == 2     # largest returnable score == max_edit_distance
+
+
+def test_pruning_changes_nothing_when_wide():
+    spec, _ = synth_wfa_job(5, ref_len=1500, n_vars=6)
+    d = oracle()
+    jobs, keep = make_jobs([spec])
+    out = _ffi.WfaResult()
+    a1 = np.zeros(len(spec.hets), np.uint8)
+    a2 = np.zeros(len(spec.hets), np.uint8)
+    assert d.hpo_wfa_assign(C.byref(jobs[0]), 2 ** 64 - 1, 500, C.byref(out), a1.ctypes.data) == 0
+    s1 = out.score
+    assert d.hpo_wfa_assign(C.byref(jobs[0]), 500, 500, C.byref(out), a2.ctypes.data) == 0
+    assert out.score == s1 and (a1 == a2).all()
+
+
+@pytest.mark.parametrize("seed", range(1, 9))
+def test_synthetic_recovers_haplotype(seed):
+    """On low-noise synthetic reads the assigned allele equals the planted one or is Ambiguous/NoOverlap
+    (never the opposite allele) for variants well inside the window."""
+    spec, chosen = synth_wfa_job(seed, ref_len=3000, n_vars=10, noise=0.002)
+    d = oracle()
+    jobs, keep = make_jobs([spec])
+    out = _ffi.WfaResult()
+    al = np.zeros(max(1, len(spec.hets)), np.uint8)
+    assert d.hpo_wfa_assign(C.byref(jobs[0]), 500, 500, C.byref(out), al.ctypes.data) == 0
+    assert out.status == 0
+    wrong = 0
+    for i, (v, pick) in enumerate(chosen):
+        if al[i] in (0, 1) and al[i] != pick:
+            wrong += 1
+    assert wrong <= 1, (al[:len(chosen)].tolist(), [p for _, p in chosen])
