@@ -1,0 +1,447 @@
+// hp_astar.hip — host side of the A* solver: packs hp_block_view matrices into the bit-sliced HBM layout,
+// owns the device pools/scratch, launches hp_astar_kernel and implements the hp_astar_* / hp_batch_* C ABI.
+//
+// Boundary: replaces reference src/astar_phaser.rs:426-429 `astar_solver(...)` as called from
+// reference src/phaser.rs:541-543. See include/hiphase_gpu.h for the contract.
+#include "hp_astar_kernel.hip"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+namespace hp {
+
+namespace {
+
+struct HostPack {
+    std::vector<BlockDesc> desc;
+    std::vector<uint32_t> vlo, vhi;
+    std::vector<uint8_t> vflags;
+    std::vector<uint32_t> rstart, rend, rword;
+    std::vector<uint32_t> words;
+    std::vector<uint64_t> work;  // LPT estimate per block
+    uint64_t h_total = 0;
+    uint32_t max_n = 0;
+};
+
+inline uint8_t cell_allele(const hp_block_view* v, uint64_t cell) {
+    return (v->alleles_2bit[cell >> 2] >> (2 * (cell & 3))) & 3;
+}
+
+// Packs one block: sorts rows by start, drops inert rows, builds per-variant candidate ranges and the
+// bit-sliced plane words. Returns HP_OK or an HP_ERR_* code (message in hp_last_error()).
+int pack_block(const hp_block_view* v, HostPack& hpk) {
+    const uint32_t N = v->n_variants, R = v->n_reads;
+    if (N == 0) { set_error("block with 0 variants (phaser.rs:415-434 short-circuits those before the solver)"); return HP_ERR_ARG; }
+    if (N >= (1u << 24)) { set_error("N=%u >= 2^24 exceeds the packed priority-key limit", N); return HP_ERR_UNSUPPORTED; }
+    if (R && (!v->read_start || !v->read_end || !v->row_off || !v->alleles_2bit || !v->quals)) {
+        set_error("null array in hp_block_view"); return HP_ERR_ARG;
+    }
+    if (!v->var_flags) { set_error("null var_flags"); return HP_ERR_ARG; }
+    std::vector<uint32_t> idx;
+    idx.reserve(R);
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t s = v->read_start[r], e = v->read_end[r];
+        if (s > e || e > N || v->row_off[r + 1] < v->row_off[r] || v->row_off[r + 1] - v->row_off[r] != (uint64_t)(e - s)) {
+            set_error("row %u: inconsistent region [%u,%u) / row_off", r, s, e); return HP_ERR_ARG;
+        }
+        if (e > s) idx.push_back(r);
+    }
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+        if (v->read_start[a] != v->read_start[b]) return v->read_start[a] < v->read_start[b];
+        if (v->read_end[a] != v->read_end[b]) return v->read_end[a] < v->read_end[b];
+        return a < b;
+    });
+    BlockDesc d{};
+    d.n_vars = N;
+    d.n_reads = (uint32_t)idx.size();
+    d.var_off = hpk.vlo.size();
+    d.read_off = hpk.rstart.size();
+    d.word_off = hpk.words.size() / WORD_DWORDS;
+    d.h_off = hpk.h_total;
+    hpk.h_total += (uint64_t)N + 1;
+
+    const size_t v0 = hpk.vlo.size();
+    hpk.vlo.resize(v0 + N, 0xFFFFFFFFu);
+    hpk.vhi.resize(v0 + N, 0);
+    hpk.vflags.insert(hpk.vflags.end(), v->var_flags, v->var_flags + N);
+
+    uint64_t n_words = 0, cells = 0, max_row_qual = 0;
+    for (uint32_t i = 0; i < idx.size(); ++i) {
+        const uint32_t r = idx[i];
+        const uint32_t s = v->read_start[r], e = v->read_end[r];
+        const uint64_t ro = v->row_off[r];
+        const uint32_t k0 = s >> 5, k1 = (e - 1) >> 5;
+        if (n_words > 0xFFFFFFF0ull) { set_error("block too large (plane words)"); return HP_ERR_UNSUPPORTED; }
+        hpk.rstart.push_back(s);
+        hpk.rend.push_back(e);
+        hpk.rword.push_back((uint32_t)n_words);
+        const size_t w0 = hpk.words.size();
+        hpk.words.resize(w0 + (size_t)(k1 - k0 + 1) * WORD_DWORDS, 0);
+        uint32_t* W = hpk.words.data() + w0;
+        for (uint32_t k = k0; k <= k1; ++k) {  // default: NoOverlap (3), qual 0
+            W[(size_t)(k - k0) * WORD_DWORDS + 0] = 0xFFFFFFFFu;
+            W[(size_t)(k - k0) * WORD_DWORDS + 1] = 0xFFFFFFFFu;
+        }
+        uint64_t row_qual = 0;
+        for (uint32_t p = s; p < e; ++p) {
+            const uint64_t cell = ro + (p - s);
+            const uint8_t a = cell_allele(v, cell), q = v->quals[cell];
+            if ((v->var_flags[p] & HP_VAR_IGNORED) && a != HP_ALLELE_NOOVERLAP) {
+                set_error("row %u has allele %u at ignored variant %u (astar_phaser.rs:435-442 assert)", r, a, p);
+                return HP_ERR_INVARIANT;
+            }
+            uint32_t* w = W + (size_t)((p >> 5) - k0) * WORD_DWORDS;
+            const uint32_t bit = 1u << (p & 31);
+            if (!(a & 1)) w[0] &= ~bit;
+            if (!(a & 2)) w[1] &= ~bit;
+            for (int b = 0; b < 8; ++b) if ((q >> b) & 1) w[2 + b] |= bit;
+            row_qual += q;
+            uint32_t& lo = hpk.vlo[v0 + p];
+            if (lo == 0xFFFFFFFFu) lo = i;  // rows are visited in sorted order: the first one covering p is the min
+        }
+        max_row_qual = std::max(max_row_qual, row_qual);
+        n_words += k1 - k0 + 1;
+        cells += e - s;
+    }
+    // vhi[p] = number of rows with start <= p
+    {
+        uint32_t j = 0;
+        for (uint32_t p = 0; p < N; ++p) {
+            while (j < idx.size() && v->read_start[idx[j]] <= p) ++j;
+            hpk.vhi[v0 + p] = j;
+            if (hpk.vlo[v0 + p] == 0xFFFFFFFFu) hpk.vlo[v0 + p] = j;  // no row covers p: empty range
+        }
+    }
+    uint32_t max_cov = 0;
+    for (uint32_t p = 0; p < N; ++p) max_cov = std::max(max_cov, hpk.vhi[v0 + p] - hpk.vlo[v0 + p]);
+    if (max_row_qual * (uint64_t)std::max(max_cov, 1u) >= (1ull << 32)) {
+        set_error("row quality mass x coverage overflows the u32 score accumulators"); return HP_ERR_UNSUPPORTED;
+    }
+    d.max_cov = max_cov;
+    d.n_words = (uint32_t)n_words;
+    hpk.desc.push_back(d);
+    hpk.work.push_back(cells * 8 + N);
+    hpk.max_n = std::max(hpk.max_n, N);
+    return HP_OK;
+}
+
+template <class T> int upload(DevBuf& buf, const std::vector<T>& v, hipStream_t s) {
+    int rc = buf.alloc(v.size() * sizeof(T));
+    if (rc != HP_OK) return rc;
+    if (!v.empty()) HP_HIP_CHECK(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return HP_OK;
+}
+
+}  // namespace
+
+}  // namespace hp
+
+using namespace hp;
+
+struct hp_batch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t n_blocks = 0;
+    hp_astar_params params{};
+    SolveParams prm{};
+    std::vector<BlockDesc> desc;
+    std::vector<uint32_t> order;  // LPT
+    uint64_t sum_n = 0, sum_h = 0;
+    uint32_t max_n = 0;
+    int n_cu = 256;
+    // device inputs
+    DevBuf d_desc, d_order, d_vlo, d_vhi, d_vflags, d_rstart, d_rend, d_rword, d_words, d_head;
+    // device outputs
+    DevBuf d_H, d_h1, d_h2, d_stats, d_counters, d_status;
+    // scratch (sized on first solve, kept)
+    DevBuf s_sub_pool, s_main_pool, s_sub_heap, s_main_heap, s_tracker;
+    uint32_t scratch_slots = 0, scratch_cap_main = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    ~hp_batch() {
+        (void)hipSetDevice(device);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+constexpr uint32_t LDS_SUB_HEAP_MAX_BYTES = 24 * 1024;  // keep >= 6 waves per CU resident (160 KiB LDS)
+
+int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items, uint32_t cap_main,
+                DevBuf& main_pool, DevBuf& main_heap, DevBuf& sub_pool, DevBuf& sub_heap, DevBuf& tracker,
+                uint32_t& have_slots, uint32_t& have_cap, DevBuf& d_items) {
+    SolveParams prm = b->prm;
+    prm.cap_main = cap_main;
+    prm.jcap_main = (cap_main + 63) / 64 + 1;
+    uint32_t max_n = 0;
+    for (uint32_t i : items) max_n = std::max(max_n, b->desc[i].n_vars);
+    prm.max_n_vars = max_n;
+    const size_t lds_bytes = 64 * sizeof(uint64_t) + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(Key) : 0);
+    // resident waves per CU limited by LDS; one wave per workgroup
+    uint32_t per_cu = (uint32_t)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
+    if (per_cu == 0) per_cu = 1;
+    const size_t per_slot = (size_t)cap_main * sizeof(NodeRec) + (size_t)prm.jcap_main * 64 * sizeof(Key) +
+                            (size_t)prm.cap_sub * sizeof(NodeRec) + ((size_t)max_n + 1) * 4 +
+                            (prm.sub_heap_in_lds ? 0 : (size_t)prm.jcap_sub * 64 * sizeof(Key));
+    size_t free_b = 0, total_b = 0;
+    HP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = free_b / 2 + main_pool.bytes + main_heap.bytes + sub_pool.bytes + tracker.bytes;
+    uint32_t slots = (uint32_t)std::min<size_t>({(size_t)items.size(), (size_t)b->n_cu * per_cu, std::max<size_t>(1, budget / per_slot)});
+    if (slots == 0) slots = 1;
+    if (per_slot > budget) { set_error("a single block needs %zu bytes of solver scratch; only %zu available", per_slot, budget); return HP_ERR_OOM; }
+    if (have_slots < slots || have_cap != cap_main || tracker.bytes < (size_t)slots * ((size_t)max_n + 1) * 4) {
+        int rc;
+        if ((rc = main_pool.alloc((size_t)slots * cap_main * sizeof(NodeRec))) != HP_OK) return rc;
+        if ((rc = main_heap.alloc((size_t)slots * prm.jcap_main * 64 * sizeof(Key))) != HP_OK) return rc;
+        if ((rc = sub_pool.alloc((size_t)slots * prm.cap_sub * sizeof(NodeRec))) != HP_OK) return rc;
+        if ((rc = tracker.alloc((size_t)slots * ((size_t)max_n + 1) * 4)) != HP_OK) return rc;
+        if (!prm.sub_heap_in_lds && (rc = sub_heap.alloc((size_t)slots * prm.jcap_sub * 64 * sizeof(Key))) != HP_OK) return rc;
+        have_slots = slots;
+        have_cap = cap_main;
+    }
+    slots = std::min(slots, have_slots);
+    int rc = upload(d_items, items, st);
+    if (rc != HP_OK) return rc;
+    HP_HIP_CHECK(hipMemsetAsync(b->d_head.p, 0, sizeof(uint32_t), st));
+
+    BatchDev B{};
+    B.desc = b->d_desc.as<BlockDesc>();
+    B.order = d_items.as<uint32_t>();
+    B.n_items = (uint32_t)items.size();
+    B.queue_head = b->d_head.as<uint32_t>();
+    B.vlo = b->d_vlo.as<uint32_t>(); B.vhi = b->d_vhi.as<uint32_t>(); B.vflags = b->d_vflags.as<uint8_t>();
+    B.rstart = b->d_rstart.as<uint32_t>(); B.rend = b->d_rend.as<uint32_t>(); B.rword = b->d_rword.as<uint32_t>();
+    B.words = b->d_words.as<uint32_t>();
+    B.H = b->d_H.as<uint64_t>(); B.h1 = b->d_h1.as<uint8_t>(); B.h2 = b->d_h2.as<uint8_t>();
+    B.stats = b->d_stats.as<hp_phase_stats>(); B.counters = b->d_counters.as<hp_work_counters>();
+    B.status = b->d_status.as<int32_t>();
+    B.sub_pool = sub_pool.as<NodeRec>(); B.main_pool = main_pool.as<NodeRec>();
+    B.sub_heap_g = sub_heap.as<Key>(); B.main_heap = main_heap.as<Key>(); B.tracker = tracker.as<uint32_t>();
+    B.prm = prm;
+    if (prm.sub_heap_in_lds)
+        hipLaunchKernelGGL(hp_astar_kernel<true>, dim3(slots), dim3(64), lds_bytes, st, B);
+    else
+        hipLaunchKernelGGL(hp_astar_kernel<false>, dim3(slots), dim3(64), lds_bytes, st, B);
+    HP_HIP_CHECK(hipGetLastError());
+    return HP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_astar_params* p, int device_id, int* status) {
+    auto fail = [&](int code) { if (status) *status = code; return (hp_batch*)nullptr; };
+    if (!blks || !p || n_blocks == 0 || n_blocks > 0x7FFFFFFFull) { set_error("bad arguments to hp_batch_create"); return fail(HP_ERR_ARG); }
+    const uint64_t max_seg = p->max_segment_size ? p->max_segment_size : 40;
+    if (max_seg < 2 || max_seg > 62) { set_error("max_segment_size %llu outside [2,62]", (unsigned long long)max_seg); return fail(HP_ERR_UNSUPPORTED); }
+    if (p->min_queue_size > (1u << 26) || p->queue_increment > (1u << 20)) { set_error("queue parameters too large"); return fail(HP_ERR_UNSUPPORTED); }
+
+    HostPack hpk;
+    for (size_t i = 0; i < n_blocks; ++i) {
+        int rc = pack_block(&blks[i], hpk);
+        if (rc != HP_OK) return fail(rc);
+    }
+    // host-side validation/packing is done; from here on a GPU is mandatory
+    if (device_id < 0) device_id = hp_default_device();
+    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return fail(HP_ERR_HIP); }
+    std::unique_ptr<hp_batch> b(new hp_batch());
+    b->device = device_id;
+    b->n_blocks = n_blocks;
+    b->params = *p;
+    b->desc = hpk.desc;
+    b->max_n = hpk.max_n;
+    b->sum_h = hpk.h_total;
+    b->sum_n = hpk.vlo.size();
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) b->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(HP_ERR_HIP); }
+    if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { set_error("hipEventCreate failed"); return fail(HP_ERR_HIP); }
+
+    SolveParams& prm = b->prm;
+    prm.minq_main = (uint32_t)p->min_queue_size;
+    prm.minq_sub = (uint32_t)(p->min_queue_size / 10);
+    prm.qinc = (uint32_t)p->queue_increment;
+    prm.max_seg = (uint32_t)max_seg;
+    const uint64_t max_visits = (uint64_t)prm.minq_sub + (uint64_t)prm.qinc * max_seg;
+    prm.cap_sub = (uint32_t)(4 * max_visits + 8);
+    prm.jcap_sub = (prm.cap_sub + 63) / 64 + 1;
+    prm.sub_heap_in_lds = ((size_t)prm.jcap_sub * 64 * sizeof(Key) <= LDS_SUB_HEAP_MAX_BYTES) ? 1 : 0;
+
+    b->order.resize(n_blocks);
+    std::iota(b->order.begin(), b->order.end(), 0u);
+    std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t a, uint32_t c) { return hpk.work[a] > hpk.work[c]; });
+
+    hipStream_t s = b->stream;
+    int rc;
+#define UP(buf, vec) if ((rc = upload(b->buf, hpk.vec, s)) != HP_OK) return fail(rc)
+    UP(d_desc, desc); UP(d_vlo, vlo); UP(d_vhi, vhi); UP(d_vflags, vflags);
+    UP(d_rstart, rstart); UP(d_rend, rend); UP(d_rword, rword); UP(d_words, words);
+#undef UP
+    if ((rc = b->d_head.alloc(16)) != HP_OK) return fail(rc);
+    if ((rc = b->d_H.alloc(b->sum_h * 8)) != HP_OK) return fail(rc);
+    if ((rc = b->d_h1.alloc(b->sum_n)) != HP_OK) return fail(rc);
+    if ((rc = b->d_h2.alloc(b->sum_n)) != HP_OK) return fail(rc);
+    if ((rc = b->d_stats.alloc(n_blocks * sizeof(hp_phase_stats))) != HP_OK) return fail(rc);
+    if ((rc = b->d_counters.alloc(n_blocks * sizeof(hp_work_counters))) != HP_OK) return fail(rc);
+    if ((rc = b->d_status.alloc(n_blocks * sizeof(int32_t))) != HP_OK) return fail(rc);
+    if (hipStreamSynchronize(s) != hipSuccess) { set_error("upload failed"); return fail(HP_ERR_HIP); }
+    if (status) *status = HP_OK;
+    return b.release();
+}
+
+int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
+    if (!b) { set_error("null batch"); return HP_ERR_ARG; }
+    HP_HIP_CHECK(hipSetDevice(b->device));
+    hipStream_t st = stream ? (hipStream_t)stream : b->stream;
+    std::vector<int32_t> status(b->n_blocks, ST_PENDING);
+    HP_HIP_CHECK(hipMemcpyAsync(b->d_status.p, status.data(), status.size() * 4, hipMemcpyHostToDevice, st));
+    HP_HIP_CHECK(hipEventRecord(b->ev0, st));
+
+    // pass 0: every block, scratch sized for the clean-data bound (<= 4N+1 nodes); blocks whose frontier
+    // outgrows it (noisy data) are re-solved with 4x the capacity until they fit (or memory runs out).
+    uint32_t cap_main = 4 * b->max_n + 64;
+    int rc = launch_pass(b, st, b->order, cap_main, b->s_main_pool, b->s_main_heap, b->s_sub_pool, b->s_sub_heap,
+                         b->s_tracker, b->scratch_slots, b->scratch_cap_main, b->d_order);
+    if (rc != HP_OK) return rc;
+    HP_HIP_CHECK(hipEventRecord(b->ev1, st));
+    HP_HIP_CHECK(hipStreamSynchronize(st));
+    float ms_total = 0.f;
+    HP_HIP_CHECK(hipEventElapsedTime(&ms_total, b->ev0, b->ev1));
+    HP_HIP_CHECK(hipMemcpy(status.data(), b->d_status.p, status.size() * 4, hipMemcpyDeviceToHost));
+
+    std::vector<uint32_t> retry;
+    for (uint32_t i : b->order) if (status[i] == ST_OVERFLOW) retry.push_back(i);
+    DevBuf r_main_pool, r_main_heap, r_sub_pool, r_sub_heap, r_tracker, r_items;
+    uint32_t r_slots = 0, r_cap = 0;
+    uint64_t cap64 = cap_main;
+    while (!retry.empty()) {
+        cap64 *= 4;
+        if (cap64 > 0xF0000000ull) { set_error("search frontier exceeds 2^32 nodes"); return HP_ERR_OOM; }
+        uint32_t rmax = 0;
+        for (uint32_t i : retry) rmax = std::max(rmax, b->desc[i].n_vars);
+        HP_HIP_CHECK(hipEventRecord(b->ev0, st));
+        rc = launch_pass(b, st, retry, (uint32_t)cap64, r_main_pool, r_main_heap, r_sub_pool, r_sub_heap, r_tracker, r_slots,
+                         r_cap, r_items);
+        if (rc != HP_OK) return rc;
+        HP_HIP_CHECK(hipEventRecord(b->ev1, st));
+        HP_HIP_CHECK(hipStreamSynchronize(st));
+        float ms = 0.f;
+        HP_HIP_CHECK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+        ms_total += ms;
+        HP_HIP_CHECK(hipMemcpy(status.data(), b->d_status.p, status.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> again;
+        for (uint32_t i : retry) if (status[i] == ST_OVERFLOW) again.push_back(i);
+        retry.swap(again);
+    }
+    if (kernel_ms) *kernel_ms = ms_total;
+    for (size_t i = 0; i < status.size(); ++i) {
+        if (status[i] == ST_INVARIANT) {
+            set_error("block %zu: solver invariant violated (the reference would panic/assert, astar_phaser.rs:268,284,360,529,631)", i);
+            return HP_ERR_INVARIANT;
+        }
+        if (status[i] != ST_OK) { set_error("block %zu: unexpected device status %d", i, status[i]); return HP_ERR_HIP; }
+    }
+    return HP_OK;
+}
+
+int hp_batch_results(hp_batch* b, uint8_t* h1, uint8_t* h2, hp_phase_stats* stats, hp_work_counters* counters, uint64_t* heuristics) {
+    if (!b) { set_error("null batch"); return HP_ERR_ARG; }
+    HP_HIP_CHECK(hipSetDevice(b->device));
+    if (h1) HP_HIP_CHECK(hipMemcpy(h1, b->d_h1.p, b->sum_n, hipMemcpyDeviceToHost));
+    if (h2) HP_HIP_CHECK(hipMemcpy(h2, b->d_h2.p, b->sum_n, hipMemcpyDeviceToHost));
+    if (stats) HP_HIP_CHECK(hipMemcpy(stats, b->d_stats.p, b->n_blocks * sizeof(hp_phase_stats), hipMemcpyDeviceToHost));
+    if (counters) HP_HIP_CHECK(hipMemcpy(counters, b->d_counters.p, b->n_blocks * sizeof(hp_work_counters), hipMemcpyDeviceToHost));
+    if (heuristics) HP_HIP_CHECK(hipMemcpy(heuristics, b->d_H.p, b->sum_h * 8, hipMemcpyDeviceToHost));
+    return HP_OK;
+}
+
+void hp_batch_destroy(hp_batch* b) { delete b; }
+
+static int solve_on_device(size_t n, const hp_block_view* blks, const hp_astar_params* p, uint8_t* const* h1,
+                           uint8_t* const* h2, hp_phase_stats* out, int device_id) {
+    int status = HP_OK;
+    hp_batch* b = hp_batch_create(n, blks, p, device_id, &status);
+    if (!b) return status;
+    std::unique_ptr<hp_batch> guard(b);
+    int rc = hp_batch_solve(b, nullptr, nullptr);
+    if (rc != HP_OK) return rc;
+    std::vector<uint8_t> a1(b->sum_n), a2(b->sum_n);
+    rc = hp_batch_results(b, a1.data(), a2.data(), out, nullptr, nullptr);
+    if (rc != HP_OK) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        const BlockDesc& d = b->desc[i];
+        if (h1 && h1[i]) std::memcpy(h1[i], a1.data() + d.var_off, d.n_vars);
+        if (h2 && h2[i]) std::memcpy(h2[i], a2.data() + d.var_off, d.n_vars);
+    }
+    return HP_OK;
+}
+
+int hp_astar_solve_batch(size_t n_blocks, const hp_block_view* blks, const hp_astar_params* p, uint8_t* const* h1,
+                         uint8_t* const* h2, hp_phase_stats* out, int device_id) {
+    if (n_blocks == 0) return HP_OK;
+    if (!blks || !p) { set_error("null argument"); return HP_ERR_ARG; }
+    if (device_id >= 0) return solve_on_device(n_blocks, blks, p, h1, h2, out, device_id);
+
+    // device_id == -1: host-side work queue over every visible GPU: blocks sorted by
+    // estimated work (LPT), cut into chunks, one worker thread per device pulls chunks. No collective.
+    const int ndev = hp_device_count();
+    if (ndev <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return HP_ERR_HIP; }
+    if (ndev == 1) return solve_on_device(n_blocks, blks, p, h1, h2, out, 0);
+    std::vector<uint32_t> order(n_blocks);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
+        const uint64_t wa = blks[a].row_off ? blks[a].row_off[blks[a].n_reads] : 0, wc = blks[c].row_off ? blks[c].row_off[blks[c].n_reads] : 0;
+        return wa > wc;
+    });
+    // interleave so that every chunk carries a similar mix of large and small blocks
+    const size_t n_chunks = std::min<size_t>(n_blocks, (size_t)ndev * 4);
+    std::vector<std::vector<uint32_t>> chunks(n_chunks);
+    for (size_t i = 0; i < n_blocks; ++i) chunks[i % n_chunks].push_back(order[i]);
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_err{HP_OK};
+    std::vector<std::string> errs(ndev);
+    std::vector<std::thread> workers;
+    for (int dev = 0; dev < ndev; ++dev) {
+        workers.emplace_back([&, dev]() {
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= n_chunks || first_err.load() != HP_OK) break;
+                const auto& ids = chunks[c];
+                std::vector<hp_block_view> v(ids.size());
+                std::vector<uint8_t*> p1(ids.size()), p2(ids.size());
+                std::vector<hp_phase_stats> st(ids.size());
+                for (size_t k = 0; k < ids.size(); ++k) { v[k] = blks[ids[k]]; p1[k] = h1 ? h1[ids[k]] : nullptr; p2[k] = h2 ? h2[ids[k]] : nullptr; }
+                int rc = solve_on_device(ids.size(), v.data(), p, p1.data(), p2.data(), st.data(), dev);
+                if (rc != HP_OK) { int exp = HP_OK; if (first_err.compare_exchange_strong(exp, rc)) errs[dev] = hp_last_error(); break; }
+                if (out) for (size_t k = 0; k < ids.size(); ++k) out[ids[k]] = st[k];
+            }
+        });
+    }
+    for (auto& t : workers) t.join();
+    if (first_err.load() != HP_OK) {
+        for (auto& e : errs) if (!e.empty()) { set_error("%s", e.c_str()); break; }
+        return first_err.load();
+    }
+    return HP_OK;
+}
+
+int hp_astar_solve(const hp_block_view* blk, const hp_astar_params* p, uint8_t* h1, uint8_t* h2, hp_phase_stats* out) {
+    if (!blk || !p) { set_error("null argument"); return HP_ERR_ARG; }
+    uint8_t* a1[1] = {h1};
+    uint8_t* a2[1] = {h2};
+    hp_phase_stats st{};
+    int rc = solve_on_device(1, blk, p, a1, a2, &st, hp_default_device());
+    if (rc == HP_OK && out) *out = st;
+    return rc;
+}
+
+}  // extern "C"

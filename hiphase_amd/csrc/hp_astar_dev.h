@@ -1,0 +1,107 @@
+// hp_astar_dev.h — device-side data layout of the A* MEC solver (shared by host packer and kernel).
+//
+// HBM layout of one batch (all blocks concatenated, see DESIGN.md "Data layout in HBM"):
+//   desc[n_blocks]                      BlockDesc
+//   vlo/vhi[sum N]    u32               per variant p: candidate rows are [vlo[p], vhi[p]) in start-sorted
+//                                       order (the IntervalTree::find(p..p+1) replacement, astar_phaser.rs:92)
+//   vflags[sum N]     u8                HP_VAR_*
+//   rstart/rend/rword[sum R] u32        rows sorted by start; rword = index of the row's first plane word
+//   words[sum W][12]  u32               bit-sliced matrix: one "plane word" covers 32 consecutive variants
+//                                       (aligned to absolute variant index / 32) of one row:
+//                                       [0] allele bit0, [1] allele bit1, [2..9] qual bit-planes 0..7, [10..11] pad.
+//                                       Cells outside the row's region are allele 3 (NoOverlap), qual 0.
+//   H[sum (N+1)]      u64               heuristic array (output, astar_phaser.rs:252)
+//   h1/h2[sum N]      u8                haplotypes (output)
+//   stats/counters/status per block
+#pragma once
+#include <stdint.h>
+
+#include "../../include/hiphase_gpu.h"
+
+namespace hp {
+
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr int WORD_DWORDS = 12;  // 48 B per plane word -> three 16-B loads
+
+struct BlockDesc {
+    uint32_t n_vars;
+    uint32_t n_reads;
+    uint64_t var_off;   // into vlo/vhi/vflags/h1/h2
+    uint64_t read_off;  // into rstart/rend/rword
+    uint64_t word_off;  // into words (units of plane words)
+    uint64_t h_off;     // into H
+    uint32_t max_cov;   // max over p of vhi-vlo
+    uint32_t n_words;
+};
+
+// Priority key (astar_phaser.rs:131-133): min total cost, then MORE hets, then OLDER node.
+//   hi = cost << 24 | (0xFFFFFF - num_hets)      cost < 2^40 (sum of all quals of a block < 2^40)
+//   lo = node_index << 24 | depth                node_index < 2^40, depth <= N < 2^24
+// Lexicographic (hi, lo) order == the reference's pop order; node_index is unique so it is total.
+// depth rides in the low bits so the full prune (astar_phaser.rs:576-581) needs no node lookup.
+struct Key {
+    uint64_t hi, lo;
+};
+
+struct Win {  // haplotype window over one 32-variant chunk
+    uint32_t h1, h2;  // allele bit of each haplotype (valid where nv == 0)
+    uint32_t nv;      // 1 = not assigned yet, before the sub-problem offset, or (2,2)
+};
+
+// Search-tree node as stored in the pool: O(1) state instead of the reference's O(len) Vec copies
+// (astar_phaser.rs:79-82). The haplotype is a chain of 32-variant chunks: w0 = chunk of the last
+// assigned position, w1 = the chunk before it; anc1/anc2 = pool slots of the ancestors that hold the
+// complete chunks ck-1 / ck-2 (their w0), so any look-back costs one hop per two chunks.
+struct NodeRec {  // 48 B
+    uint64_t frozen;
+    uint32_t depth;
+    uint32_t hets;
+    uint32_t anc1, anc2;
+    Win w0, w1;
+};
+static_assert(sizeof(NodeRec) == 48, "NodeRec must be 48 bytes");
+
+struct SolveParams {
+    uint32_t minq_main;   // min_queue_size
+    uint32_t minq_sub;    // min_queue_size / 10 (astar_phaser.rs:266)
+    uint32_t qinc;        // queue_increment
+    uint32_t max_seg;     // 40 (astar_phaser.rs:466)
+    uint32_t cap_sub;     // node capacity of the sub-solver pool/heap
+    uint32_t jcap_sub;    // per-lane heap capacity (sub)
+    uint32_t cap_main;    // node capacity of the main pool/heap
+    uint32_t jcap_main;   // per-lane heap capacity (main)
+    uint32_t sub_heap_in_lds;
+    uint32_t max_n_vars;  // largest N among the blocks of this launch (tracker stride)
+    uint32_t pad0, pad1;
+};
+
+// block status written by the kernel
+constexpr int32_t ST_OK = 0;
+constexpr int32_t ST_OVERFLOW = 1;        // pool/heap capacity exceeded -> host retries with more scratch
+constexpr int32_t ST_INVARIANT = -3;      // a reference assert!/panic! would have fired
+constexpr int32_t ST_PENDING = 7;
+
+struct BatchDev {
+    const BlockDesc* desc;
+    const uint32_t* order;   // LPT work list: indices of the blocks this launch solves
+    uint32_t n_items;
+    uint32_t* queue_head;
+    const uint32_t *vlo, *vhi;
+    const uint8_t* vflags;
+    const uint32_t *rstart, *rend, *rword;
+    const uint32_t* words;
+    uint64_t* H;
+    uint8_t *h1, *h2;
+    hp_phase_stats* stats;
+    hp_work_counters* counters;
+    int32_t* status;
+    // per-workgroup-slot scratch
+    NodeRec* sub_pool;    // [slots][cap_sub]
+    NodeRec* main_pool;   // [slots][cap_main]
+    Key* sub_heap_g;      // [slots][jcap_sub*64] (only when the sub heap does not fit LDS)
+    Key* main_heap;       // [slots][jcap_main*64]
+    uint32_t* tracker;    // [slots][max_n_vars+1]
+    SolveParams prm;
+};
+
+}  // namespace hp

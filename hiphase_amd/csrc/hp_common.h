@@ -1,0 +1,47 @@
+// hp_common.h — shared host-side helpers for libhiphase_gpu.so (error slots, HIP checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/hiphase_gpu.h"
+
+namespace hp {
+
+void set_error(const char* fmt, ...);  // thread-local message returned by hp_last_error()
+
+#define HP_HIP_CHECK(expr)                                                                         \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            hp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return (_e == hipErrorOutOfMemory) ? HP_ERR_OOM : HP_ERR_HIP;                          \
+        }                                                                                          \
+    } while (0)
+
+// RAII device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        HP_HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+        return HP_OK;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace hp

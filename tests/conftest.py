@@ -23,9 +23,8 @@ def oracle_lib():
 def hp_lib():
     """The product library; built in-tree by __graft_entry__.build()."""
     from hiphase_amd import _ffi
-    if not os.path.exists(_ffi.LIB_PATH):
-        import __graft_entry__
-        __graft_entry__.build()
+    import __graft_entry__
+    __graft_entry__.build()   # no-op when libhiphase_gpu.so is newer than its sources
     return _ffi.lib()
 
 

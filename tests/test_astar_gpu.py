@@ -1,0 +1,170 @@
+"""Parity of the HIP A* solver (through the C ABI) with the CPU oracle: byte-equal h1/h2, equal
+PhaseStats, equal heuristic arrays and equal work counters (the search trajectory is a total order)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from hiphase_amd import BlockMatrix, ReadSegment, ResidentBatch, astar_solver, astar_solve_batch, synth_block
+from oracle_ffi import oracle, oracle_solve
+
+pytestmark = pytest.mark.gpu
+
+
+def check_block(blk, **kw):
+    got = astar_solver(0, blk, **kw)
+    h1, h2, st, ctr = oracle_solve(blk, **kw)
+    assert np.array_equal(got.haplotype_1, h1), (got.haplotype_1.tolist(), h1.tolist())
+    assert np.array_equal(got.haplotype_2, h2)
+    assert got.statistics.as_tuple() == st
+    return got
+
+
+def check_batch(blocks, **kw):
+    rb = ResidentBatch(blocks, **kw)
+    ms = rb.solve()
+    res, ctrs, heur = rb.results(want_heuristics=True)
+    rb.close()
+    for blk, r, c, h in zip(blocks, res, ctrs, heur):
+        h1, h2, st, octr, oh = oracle_solve(blk, want_heuristics=True, **kw)
+        assert np.array_equal(r.haplotype_1, h1) and np.array_equal(r.haplotype_2, h2)
+        assert r.statistics.as_tuple() == st
+        assert np.array_equal(h, oh), "heuristic arrays differ"
+        assert c.as_tuple() == octr, (c.as_tuple(), octr)
+    return ms
+
+
+def test_golden_simple_reads():
+    """get_simple_reads of astar_phaser.rs:642-660 (the reads behind test_astarnode): all-0 row qual 2,
+    all-1 row qual 3 -> the optimum is the het path with cost 0."""
+    g = load_golden("astar_phaser.json")["astarnode"]
+    blk = BlockMatrix.from_rows([(r["alleles"], r["quals"]) for r in g["reads"]])
+    got = check_block(blk)
+    assert got.statistics.actual_cost == 0 and got.statistics.phased_variants == 4
+    assert got.haplotype_1.tolist() == [0, 0, 0, 0] and got.haplotype_2.tolist() == [1, 1, 1, 1]
+
+
+def test_golden_collapse_row_scores():
+    """read_segments.rs:278-308 rows (with 2/3 cells inside the region) as a 1-read + 1-read block."""
+    g = load_golden("read_segments.json")["collapse"]
+    rows = [(r["alleles"], r["quals"]) for r in g["rows"]] + [(g["expect_alleles"], g["expect_quals"])]
+    check_block(BlockMatrix.from_rows(rows))
+
+
+def test_c1_plumbing():
+    blk, _ = synth_block(50, 8, 20, 0.01, 0.02, 1)
+    check_batch([blk])
+
+
+@pytest.mark.parametrize("seed", range(1, 9))
+def test_bruteforce_sized(seed):
+    blk, _ = synth_block(7, 6, 4, 0.1, 0.05, seed)
+    got = check_block(blk)
+    v = blk.view()
+    assert oracle().hpo_bruteforce_mec(C.byref(v)) == got.statistics.actual_cost
+
+
+def test_single_variant_and_tiny():
+    for n in (1, 2, 3):
+        blk, _ = synth_block(n, 5, 2, 0.0, 0.0, 5 + n)
+        check_block(blk)
+
+
+def test_uncovered_variants_and_empty_rows():
+    rows = [
+        ([0, 1, 3, 3, 3, 3, 3, 3], [10, 10, 0, 0, 0, 0, 0, 0]),
+        ([3, 3, 3, 3, 3, 3, 1, 0], [0, 0, 0, 0, 0, 0, 7, 9]),
+        ([3, 3, 3, 3, 3, 3, 3, 3], [0] * 8),   # no set allele: inert row (start == end)
+        ([1, 0, 3, 3, 3, 3, 0, 1], [5, 5, 0, 0, 0, 0, 5, 5]),
+    ]
+    check_block(BlockMatrix.from_rows(rows))
+
+
+def test_ambiguous_with_quality():
+    """Local-mode rows may carry qual > 0 on Ambiguous cells (read_parsing.rs:281-285,327):
+    the mismatch predicate is on the haplotype allele, not the row allele."""
+    rows = [
+        ([0, 2, 1, 0, 2, 1], [9, 4, 9, 9, 3, 9]),
+        ([1, 2, 0, 1, 1, 0], [8, 6, 8, 8, 8, 8]),
+        ([0, 0, 2, 2, 1, 1], [7, 7, 5, 5, 7, 7]),
+    ]
+    check_block(BlockMatrix.from_rows(rows))
+
+
+def test_ignored_variants():
+    blk, _ = synth_block(120, 20, 12, 0.02, 0.02, 7, ignored_permille=80)
+    got = check_block(blk)
+    assert got.statistics.skipped_variants == int((blk.var_flags & 1).sum()) > 0
+
+
+def test_long_rows_chain_walk():
+    """Rows spanning > 96 variants force the haplotype-window chain walk (look-back beyond 3 chunks)."""
+    blk, _ = synth_block(400, 12, 150, 0.03, 0.02, 9)
+    check_batch([blk])
+
+
+def test_high_coverage_batches():
+    """Coverage > 64 rows per variant: several 64-lane batches per expansion."""
+    blk, _ = synth_block(150, 150, 16, 0.05, 0.02, 10)
+    check_batch([blk])
+
+
+@pytest.mark.parametrize("minq,qinc,e", [(20, 1, 0.30), (50, 3, 0.25), (10, 0, 0.35)])
+def test_pruning_dynamics(minq, qinc, e):
+    """Small queues + noisy data: threshold reset at the first prune, min_progress, full prune
+    (astar_phaser.rs:497-585)."""
+    blk, _ = synth_block(150, 30, 10, e, 0.02, 11)
+    got = check_block(blk, min_queue_size=minq, queue_increment=qinc)
+    assert got.statistics.pruned_solutions > 0
+
+
+def test_noisy_default_params_overflow_retry():
+    """C2-noisy shape, small: the frontier outgrows the 4N+64 node pool and the host retries."""
+    blk, _ = synth_block(300, 60, 20, 0.30, 0.02, 13)
+    check_batch([blk])
+
+
+def test_batch_many_blocks_mixed():
+    blocks = [synth_block(n, c, s, e, 0.02, 100 + i)[0]
+              for i, (n, c, s, e) in enumerate([(15, 30, 20, 0.01), (220, 30, 20, 0.01), (63, 10, 20, 0.05),
+                                                (500, 30, 20, 0.02), (5, 4, 3, 0.1), (90, 60, 20, 0.15),
+                                                (33, 30, 40, 0.0), (64, 30, 20, 0.01), (65, 30, 20, 0.01)] * 3)]
+    check_batch(blocks)
+    res = astar_solve_batch(blocks[:5])
+    for blk, r in zip(blocks[:5], res):
+        h1, h2, st, _ = oracle_solve(blk)
+        assert np.array_equal(r.haplotype_1, h1) and r.statistics.as_tuple() == st
+
+
+def test_c2_full_size():
+    """BASELINE.json configs[1]: N=5000, C=30, S=20, e=0.01, a=0.02, seed=20250509 (R=7500)."""
+    blk, _ = synth_block(5000, 30, 20, 0.01, 0.02, 20250509)
+    assert blk.n_reads == 7500
+    check_batch([blk])
+
+
+def test_many_c2_blocks_properties():
+    """Full-size property checks without the oracle: determinism across solves and the MEC identity
+    actual_cost == sum_r min(score(h1), score(h2)) recomputed on the host from the returned haplotypes."""
+    blocks = [synth_block(2000, 30, 20, 0.01, 0.02, 7000 + i)[0] for i in range(24)]
+    rb = ResidentBatch(blocks)
+    rb.solve()
+    r1, c1, _ = rb.results()
+    rb.solve()
+    r2, c2, _ = rb.results()
+    rb.close()
+    for a, b in zip(r1, r2):
+        assert np.array_equal(a.haplotype_1, b.haplotype_1) and a.statistics.as_tuple() == b.statistics.as_tuple()
+    for blk, r in zip(blocks[:6], r1):
+        tot = 0
+        for seg in blk.segments():
+            al = np.asarray(seg.alleles)
+            q = np.asarray(seg.quals, dtype=np.int64)
+            sl = slice(seg.start, seg.end)
+            s = []
+            for h in (r.haplotype_1[sl], r.haplotype_2[sl]):
+                s.append(int(q[(h < 2) & (al != h)].sum()))
+            tot += min(s)
+        assert tot == r.statistics.actual_cost
+        assert r.statistics.actual_cost >= r.statistics.estimated_cost
