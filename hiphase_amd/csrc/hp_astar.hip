@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -184,6 +185,9 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     uint32_t max_n = 0;
     for (uint32_t i : items) max_n = std::max(max_n, b->desc[i].n_vars);
     prm.max_n_vars = max_n;
+    const char* dbg = std::getenv("HP_DEBUG_STAGE");
+    prm.pad0 = dbg ? (uint32_t)std::atoi(dbg) : 0;
+    const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const size_t lds_bytes = 64 * sizeof(uint64_t) + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(Key) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup
     uint32_t per_cu = (uint32_t)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
@@ -226,6 +230,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     B.sub_pool = sub_pool.as<NodeRec>(); B.main_pool = main_pool.as<NodeRec>();
     B.sub_heap_g = sub_heap.as<Key>(); B.main_heap = main_heap.as<Key>(); B.tracker = tracker.as<uint32_t>();
     B.prm = prm;
+    if (verbose) { fprintf(stderr, "[hp] launch items=%zu slots=%u cap_main=%u cap_sub=%u jcap_sub=%u lds=%zu stage=%u\n", items.size(), slots, cap_main, prm.cap_sub, prm.jcap_sub, lds_bytes, prm.pad0); fflush(stderr); }
     if (prm.sub_heap_in_lds)
         hipLaunchKernelGGL(hp_astar_kernel<true>, dim3(slots), dim3(64), lds_bytes, st, B);
     else
@@ -313,7 +318,9 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
                          b->s_tracker, b->scratch_slots, b->scratch_cap_main, b->d_order);
     if (rc != HP_OK) return rc;
     HP_HIP_CHECK(hipEventRecord(b->ev1, st));
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] waiting for kernel\n"); fflush(stderr); }
     HP_HIP_CHECK(hipStreamSynchronize(st));
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] kernel done\n"); fflush(stderr); }
     float ms_total = 0.f;
     HP_HIP_CHECK(hipEventElapsedTime(&ms_total, b->ev0, b->ev1));
     HP_HIP_CHECK(hipMemcpy(status.data(), b->d_status.p, status.size() * 4, hipMemcpyDeviceToHost));

@@ -502,20 +502,18 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
         hq.jcap = prm.jcap_main;
         hq.ovf = 0;
         heap_reset(hq);
-        for (uint32_t i = lane; i <= N; i += 64) tracker[i] = 0;
-        // PQueueHapTracker (astar_phaser.rs:171-231): counts live in global scratch (lane 0 only), the running
-        // total in a register
+        // PQueueHapTracker (astar_phaser.rs:171-231): per-length counts live in global scratch and are only
+        // ever touched by lane 0 (plain same-thread read-modify-write); the running total is a register.
+        if (lane == 0) for (uint32_t i = 0; i <= N; ++i) tracker[i] = 0;
         uint32_t trk_total = 0, trk_thr = 0;
-        auto trk_add = [&](uint32_t len) {
-            if (lane == 0) __hip_atomic_fetch_add(&tracker[len], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (len >= trk_thr) trk_total += 1;
+        auto trk_add = [&](uint32_t len, uint32_t n) {
+            if (lane == 0) tracker[len] = tracker[len] + n;
+            if (len >= trk_thr) trk_total += n;
         };
         auto trk_remove = [&](uint32_t len) {
-            if (lane == 0) __hip_atomic_fetch_add(&tracker[len], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) tracker[len] = tracker[len] - 1u;
             if (len >= trk_thr) trk_total -= 1;
         };
-        // the zeroing above was done by all lanes; make it visible to lane 0's atomics (same wave, L2 atomics)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 
         uint64_t thr = prm.minq_main;                      // curr_queue_size_threshold
         const uint64_t max_q = 10ull * prm.minq_main;      // max_queue_size
@@ -523,7 +521,7 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
         uint64_t pruned = 0, next_idx = 1, qlen = 1;
         const uint64_t h0 = bcast64(lane == 0 ? H[0] : 0);
         Cur cur = root_node(h0);
-        trk_add(0);
+        trk_add(0, 1);
 
         while (cur.depth < N) {
             wc.main_pops += 1;
@@ -556,8 +554,8 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
                 if (key_less(k, kbest)) { kbest = k; best = c; }
             }
             // push every child except the best one, which is held in registers (it is logically queued)
+            trk_add(ch.depth, (uint32_t)ch.n);
             for (int c = 0; c < ch.n; ++c) {
-                trk_add(ch.depth);
                 if (c == best) continue;
                 store_child(main_pool, ch, c, next_idx + c);
                 heap_push(hq, make_key(ch.total[c], ch.hets[c], next_idx + c, ch.depth));
@@ -568,7 +566,7 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
                 min_progress += 1;
                 {   // increase_threshold(min_progress)
                     uint32_t c = 0;
-                    if (lane == 0) c = __hip_atomic_load(&tracker[min_progress - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) c = tracker[min_progress - 1];
                     trk_total -= bcast32(c);
                     trk_thr = min_progress;
                 }
@@ -671,12 +669,14 @@ __global__ void __launch_bounds__(64) hp_astar_kernel(BatchDev B) {
     uint64_t* ring = reinterpret_cast<uint64_t*>(smem);            // 64 x u64
     Key* lds_heap = reinterpret_cast<Key*>(smem + 64 * sizeof(uint64_t));
     const uint32_t slot = blockIdx.x;
-    for (;;) {
-        uint32_t i = 0;
-        if (lane_id() == 0) i = atomicAdd(B.queue_head, 1u);
-        i = bcast32(i);
-        if (i >= B.n_items) break;
-        solve_block<SUB_LDS>(B, B.order[i], slot, lds_heap, ring);
+    const uint32_t G = gridDim.x;
+    // Static "snake" assignment over the LPT-sorted work list: workgroup w takes ranks w, 2G-1-w, 2G+w, ...
+    // (uniform control flow, no atomics; every workgroup gets a similar mix of large and small blocks).
+    for (uint32_t round = 0;; ++round) {
+        const uint32_t base = round * G;
+        if (base >= B.n_items) break;
+        const uint32_t i = base + ((round & 1u) ? (G - 1u - slot) : slot);
+        if (i < B.n_items) solve_block<SUB_LDS>(B, B.order[i], slot, lds_heap, ring);
     }
 }
 
