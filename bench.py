@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py — het variants phased / sec through the HIP A* solver (BASELINE.json metric).
+
+One "step" = one pass of the hot path (hp_batch_solve: heuristic chain + pruned A* for every block)
+over one resident batch of synthetic read x variant allele matrices. Default workload = BASELINE.json
+configs[1] shape: blocks of N=5000 hets, coverage 30, span 20 (R=7500), e=0.01, a=0.02,
+seeds 20250509+i, `--blocks` of them per GPU (independent blocks, weak scaling, no collective).
+
+Prints ONE JSON line (rank 0). See DESIGN.md §Measurement for the roofline accounting.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_CELL = 1.75  # l x (2-bit allele + 8-bit qual) + 2 x l x 2-bit haplotype
+
+
+def make_blocks(args, rank):
+    from hiphase_amd import synth_block
+    blocks = []
+    if args.workload == "c2":
+        for i in range(args.blocks):
+            blocks.append(synth_block(args.hets, args.coverage, args.span, args.error, 0.02,
+                                      20250509 + rank * 1000003 + i)[0])
+    else:  # "wgs": heavy-tailed block sizes (docs/user_guide.md:257: median 15, mean ~220, max ~4000)
+        import numpy as np
+        rng = np.random.default_rng(12345 + rank)
+        sizes = np.clip(np.exp(rng.normal(np.log(15.0), 2.2, args.blocks)).astype(int), 2, 4000)
+        for i, n in enumerate(sizes):
+            blocks.append(synth_block(int(n), args.coverage, args.span, args.error, 0.02, 777 + rank * 1000003 + i)[0])
+    return blocks
+
+
+def cpu_baseline(args, blocks):
+    """The line-faithful C++ restatement of the reference algorithm (oracle, kind='port'), one thread,
+    on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi
+    budget_s = args.cpu_seconds
+    t0 = time.perf_counter()
+    hets = 0
+    used = 0
+    counters = []
+    results = []
+    for blk in blocks:
+        h1, h2, st, ctr = oracle_ffi.oracle_solve(blk)
+        hets += blk.n_variants
+        used += 1
+        counters.append(ctr)
+        results.append((h1, h2, st))
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": hets / dt, "unit": "hets/s", "cores": 1, "kind": "port",
+            "sample": f"first {used} block(s) of the same batch ({hets} hets), single thread, {dt:.1f}s"}, counters, results
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["c2", "wgs"], default="c2")
+    ap.add_argument("--blocks", type=int, default=1024, help="blocks per GPU")
+    ap.add_argument("--hets", type=int, default=5000)
+    ap.add_argument("--coverage", type=int, default=30)
+    ap.add_argument("--span", type=int, default=20)
+    ap.add_argument("--error", type=float, default=0.01)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from hiphase_amd import ResidentBatch, _ffi
+    lib = _ffi.lib()
+    if lib.hp_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libhiphase_gpu.so has no CPU fallback")
+
+    blocks = make_blocks(args, rank)
+    hets_per_step = sum(b.n_variants for b in blocks)
+    t_pack = time.perf_counter()
+    rb = ResidentBatch(blocks, device_id=local_rank)   # pack + upload: inputs resident in HBM from here on
+    t_pack = time.perf_counter() - t_pack
+
+    def sync_all():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        rb.solve()
+    sync_all()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        kernel_ms.append(rb.solve())       # launches on the batch stream and waits for it (HIP events inside)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    res, ctrs, _ = rb.results()
+    cells_per_step = sum(c.cells for c in ctrs)
+    evals_per_step = sum(c.evals for c in ctrs)
+    out = None
+    if rank == 0:
+        kavg_ms = sum(kernel_ms) / len(kernel_ms)
+        b_alg = BYTES_PER_CELL * cells_per_step
+        achieved = b_alg / (kavg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "het variants phased/sec (A* MEC solver, synthetic read-allele matrices)",
+            "value": hets_per_step * world * args.steps / elapsed,
+            "unit": "hets/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": (f"C2 x {args.blocks} blocks/GPU: N={args.hets} hets x R={blocks[0].n_reads} reads "
+                                    f"(C={args.coverage}, S={args.span}, e={args.error}, a=0.02), seeds 20250509+i"
+                                    if args.workload == "c2" else
+                                    f"WGS-like: {args.blocks} blocks/GPU, lognormal sizes (median 15, max 4000), C={args.coverage}"),
+                       "min_queue_size": 1000, "queue_increment": 3, "hets_per_step_per_gpu": hets_per_step,
+                       "pack_upload_s": round(t_pack, 3)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "hp::hp_astar_kernel", "kernel_ms": kavg_ms,
+                         "algorithmic_bytes_per_launch": b_alg, "cells_per_het": cells_per_step / hets_per_step,
+                         "evals_per_het": evals_per_step / hets_per_step},
+        }
+        if not args.no_cpu:
+            cb, octr, ores = cpu_baseline(args, blocks)
+            out["cpu_baseline"] = cb
+            # the oracle doubles as a live parity check on the sampled blocks
+            ok = all((r.haplotype_1 == o[0]).all() and (r.haplotype_2 == o[1]).all() and r.statistics.as_tuple() == o[2]
+                     for r, o in zip(res, ores))
+            ok = ok and all(c.as_tuple() == o for c, o in zip(ctrs, octr))
+            out["parity"] = {"blocks_compared": len(ores), "bit_identical": bool(ok)}
+        print(json.dumps(out), flush=True)
+    rb.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,7 +71,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     hpk.vhi.resize(v0 + N, 0);
     hpk.vflags.insert(hpk.vflags.end(), v->var_flags, v->var_flags + N);
 
-    uint64_t n_words = 0, cells = 0, max_row_qual = 0;
+    uint64_t n_words = 0, cells = 0, max_row_qual = 0, total_qual = 0;
     for (uint32_t i = 0; i < idx.size(); ++i) {
         const uint32_t r = idx[i];
         const uint32_t s = v->read_start[r], e = v->read_end[r];
@@ -106,6 +106,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
             if (lo == 0xFFFFFFFFu) lo = i;  // rows are visited in sorted order: the first one covering p is the min
         }
         max_row_qual = std::max(max_row_qual, row_qual);
+        total_qual += row_qual;
         n_words += k1 - k0 + 1;
         cells += e - s;
     }
@@ -123,6 +124,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     if (max_row_qual * (uint64_t)std::max(max_cov, 1u) >= (1ull << 32)) {
         set_error("row quality mass x coverage overflows the u32 score accumulators"); return HP_ERR_UNSUPPORTED;
     }
+    if (total_qual >= (1ull << 37)) { set_error("total quality mass of the block exceeds the packed key range"); return HP_ERR_UNSUPPORTED; }
     d.max_cov = max_cov;
     d.n_words = (uint32_t)n_words;
     hpk.desc.push_back(d);
@@ -188,13 +190,13 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     const char* dbg = std::getenv("HP_DEBUG_STAGE");
     prm.pad0 = dbg ? (uint32_t)std::atoi(dbg) : 0;
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
-    const size_t lds_bytes = 64 * sizeof(uint64_t) + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(Key) : 0);
+    const size_t lds_bytes = LDS_HEAP_OFF + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup
     uint32_t per_cu = (uint32_t)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
     if (per_cu == 0) per_cu = 1;
     const size_t per_slot = (size_t)cap_main * sizeof(NodeRec) + (size_t)prm.jcap_main * 64 * sizeof(Key) +
                             (size_t)prm.cap_sub * sizeof(NodeRec) + ((size_t)max_n + 1) * 4 +
-                            (prm.sub_heap_in_lds ? 0 : (size_t)prm.jcap_sub * 64 * sizeof(Key));
+                            (prm.sub_heap_in_lds ? 0 : (size_t)prm.jcap_sub * 64 * sizeof(uint64_t));
     size_t free_b = 0, total_b = 0;
     HP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     size_t budget = free_b / 2 + main_pool.bytes + main_heap.bytes + sub_pool.bytes + tracker.bytes;
@@ -207,7 +209,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
         if ((rc = main_heap.alloc((size_t)slots * prm.jcap_main * 64 * sizeof(Key))) != HP_OK) return rc;
         if ((rc = sub_pool.alloc((size_t)slots * prm.cap_sub * sizeof(NodeRec))) != HP_OK) return rc;
         if ((rc = tracker.alloc((size_t)slots * ((size_t)max_n + 1) * 4)) != HP_OK) return rc;
-        if (!prm.sub_heap_in_lds && (rc = sub_heap.alloc((size_t)slots * prm.jcap_sub * 64 * sizeof(Key))) != HP_OK) return rc;
+        if (!prm.sub_heap_in_lds && (rc = sub_heap.alloc((size_t)slots * prm.jcap_sub * 64 * sizeof(uint64_t))) != HP_OK) return rc;
         have_slots = slots;
         have_cap = cap_main;
     }
@@ -228,7 +230,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     B.stats = b->d_stats.as<hp_phase_stats>(); B.counters = b->d_counters.as<hp_work_counters>();
     B.status = b->d_status.as<int32_t>();
     B.sub_pool = sub_pool.as<NodeRec>(); B.main_pool = main_pool.as<NodeRec>();
-    B.sub_heap_g = sub_heap.as<Key>(); B.main_heap = main_heap.as<Key>(); B.tracker = tracker.as<uint32_t>();
+    B.sub_heap_g = sub_heap.as<uint64_t>(); B.main_heap = main_heap.as<Key>(); B.tracker = tracker.as<uint32_t>();
     B.prm = prm;
     if (verbose) { fprintf(stderr, "[hp] launch items=%zu slots=%u cap_main=%u cap_sub=%u jcap_sub=%u lds=%zu stage=%u\n", items.size(), slots, cap_main, prm.cap_sub, prm.jcap_sub, lds_bytes, prm.pad0); fflush(stderr); }
     if (prm.sub_heap_in_lds)
@@ -279,7 +281,8 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     const uint64_t max_visits = (uint64_t)prm.minq_sub + (uint64_t)prm.qinc * max_seg;
     prm.cap_sub = (uint32_t)(4 * max_visits + 8);
     prm.jcap_sub = (prm.cap_sub + 63) / 64 + 1;
-    prm.sub_heap_in_lds = ((size_t)prm.jcap_sub * 64 * sizeof(Key) <= LDS_SUB_HEAP_MAX_BYTES) ? 1 : 0;
+    prm.sub_heap_in_lds = ((size_t)prm.jcap_sub * 64 * sizeof(uint64_t) <= LDS_SUB_HEAP_MAX_BYTES) ? 1 : 0;
+    if (prm.cap_sub >= (1u << 14)) { set_error("min_queue_size/10 + queue_increment*max_segment_size = %llu visits exceeds the packed sub-key limit (4093)", (unsigned long long)max_visits); return fail(HP_ERR_UNSUPPORTED); }
 
     b->order.resize(n_blocks);
     std::iota(b->order.begin(), b->order.end(), 0u);
@@ -311,9 +314,10 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     HP_HIP_CHECK(hipMemcpyAsync(b->d_status.p, status.data(), status.size() * 4, hipMemcpyHostToDevice, st));
     HP_HIP_CHECK(hipEventRecord(b->ev0, st));
 
-    // pass 0: every block, scratch sized for the clean-data bound (<= 4N+1 nodes); blocks whose frontier
-    // outgrows it (noisy data) are re-solved with 4x the capacity until they fit (or memory runs out).
-    uint32_t cap_main = 4 * b->max_n + 64;
+    // pass 0: every block, scratch sized generously above the clean-data bound (<= 4N+1 nodes); blocks whose
+    // frontier outgrows it (noisy data) keep their finished heuristic and only their main search is re-run
+    // with 4x the capacity until it fits (or memory runs out).
+    uint32_t cap_main = 6 * b->max_n + 2048;
     int rc = launch_pass(b, st, b->order, cap_main, b->s_main_pool, b->s_main_heap, b->s_sub_pool, b->s_sub_heap,
                          b->s_tracker, b->scratch_slots, b->scratch_cap_main, b->d_order);
     if (rc != HP_OK) return rc;
@@ -326,7 +330,7 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     HP_HIP_CHECK(hipMemcpy(status.data(), b->d_status.p, status.size() * 4, hipMemcpyDeviceToHost));
 
     std::vector<uint32_t> retry;
-    for (uint32_t i : b->order) if (status[i] == ST_OVERFLOW) retry.push_back(i);
+    for (uint32_t i : b->order) if (status[i] == ST_OVERFLOW_MAIN) retry.push_back(i);
     DevBuf r_main_pool, r_main_heap, r_sub_pool, r_sub_heap, r_tracker, r_items;
     uint32_t r_slots = 0, r_cap = 0;
     uint64_t cap64 = cap_main;
@@ -346,7 +350,7 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
         ms_total += ms;
         HP_HIP_CHECK(hipMemcpy(status.data(), b->d_status.p, status.size() * 4, hipMemcpyDeviceToHost));
         std::vector<uint32_t> again;
-        for (uint32_t i : retry) if (status[i] == ST_OVERFLOW) again.push_back(i);
+        for (uint32_t i : retry) if (status[i] == ST_OVERFLOW_MAIN) again.push_back(i);
         retry.swap(again);
     }
     if (kernel_ms) *kernel_ms = ms_total;

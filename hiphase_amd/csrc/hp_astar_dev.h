@@ -77,7 +77,8 @@ struct SolveParams {
 
 // block status written by the kernel
 constexpr int32_t ST_OK = 0;
-constexpr int32_t ST_OVERFLOW = 1;        // pool/heap capacity exceeded -> host retries with more scratch
+constexpr int32_t ST_OVERFLOW = 1;        // sub-solver pool/heap capacity exceeded (cannot happen with the host's sizing)
+constexpr int32_t ST_OVERFLOW_MAIN = 2;   // main-search scratch exceeded: H[] is complete, host re-launches with 4x scratch
 constexpr int32_t ST_INVARIANT = -3;      // a reference assert!/panic! would have fired
 constexpr int32_t ST_PENDING = 7;
 
@@ -98,7 +99,7 @@ struct BatchDev {
     // per-workgroup-slot scratch
     NodeRec* sub_pool;    // [slots][cap_sub]
     NodeRec* main_pool;   // [slots][cap_main]
-    Key* sub_heap_g;      // [slots][jcap_sub*64] (only when the sub heap does not fit LDS)
+    uint64_t* sub_heap_g; // [slots][jcap_sub*64] packed sub keys (only when the sub heap does not fit LDS)
     Key* main_heap;       // [slots][jcap_main*64]
     uint32_t* tracker;    // [slots][max_n_vars+1]
     SolveParams prm;

@@ -1,19 +1,25 @@
 // hp_astar_kernel.hip — the A* MEC phasing solver for gfx950 (MI355X), one wavefront per phase block.
 //
 // Replaces, bit-identically, reference src/astar_phaser.rs:
-//   new_extended_node (:69-119)  -> score_children(): lanes = rows covering the new variant; each lane scores
+//   new_extended_node (:69-119)  -> expand(): lanes = rows covering the new variant; each lane scores
 //                                   its row against both haplotype windows with bit-sliced AND/popcount
-//                                   (v_bcnt_u32_b32) over 32-variant plane words, then wave reductions.
+//                                   (v_bcnt_u32_b32) over 32-variant plane words; the 4 children share the
+//                                   O(overlap) part; 8 partial sums are reduced with a DPP transpose-butterfly.
 //   PriorityQueue (:316,460)     -> 64-way sharded binary heap (one private heap per lane, wave arg-min over
-//                                   the 64 tops); the priority is a total order so any heap gives the same pops.
+//                                   the 64 tops by DPP); the priority is a total order so any heap pops alike.
+//                                   Sub-solver heap: packed 64-bit keys in LDS; main heap: 128-bit keys in HBM.
 //   astar_subsolver (:311-405), calculate_astar_heuristic (:246-292), astar_solver (:426-633)
 //                                -> subsolve()/solve_block(), same statement order, same `<`/`<=`.
 // Integer-only (u32 per-row scores, u64 costs); no MFMA (there is no dense contraction on this path).
 // Node state is O(1): a chain of 32-variant haplotype windows (see hp_astar_dev.h), not O(len) copies.
 //
-// Memory-ordering rule used throughout: every global/LDS location is written and later read by the SAME
-// lane (lane 0 for node records / H / tracker, the owning lane for its private heap), then broadcast with
-// v_readfirstlane / v_readlane — so no cross-lane visibility fences are needed inside the wave.
+// Rules learnt on hardware (see DESIGN.md "Bring-up notes"):
+//  * no atomics under a lane-0 branch: hipcc's atomic optimiser + the structuriser produced a wave that never
+//    left the work-queue loop on gfx950 -> blocks are assigned statically (snake order over the LPT list);
+//  * every global/LDS location is written and later read by the SAME lane (lane 0 for node records / H /
+//    tracker, the owning lane for its private heap) and then broadcast with v_readfirstlane / v_readlane,
+//    so no cross-lane visibility fences are needed inside the wave;
+//  * no dynamically indexed private arrays (they become scratch memory = global-latency accesses).
 #include "hp_astar_dev.h"
 #include "hp_common.h"
 
@@ -21,28 +27,84 @@ namespace hp {
 
 #define DEVINL __device__ __forceinline__
 
-DEVINL bool key_less(const Key& a, const Key& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
-DEVINL Key key_inf() { return Key{~0ull, ~0ull}; }
-DEVINL bool key_is_inf(const Key& k) { return (k.hi & k.lo) == ~0ull; }
+// LDS layout (bytes): [0,512) H ring (64 x u64) | [512,1536) variant ring (64 x uint4) | [1536,...) sub heap
+constexpr uint32_t LDS_HRING_OFF = 0;
+constexpr uint32_t LDS_VRING_OFF = 512;
+constexpr uint32_t LDS_HEAP_OFF = 1536;
+extern __shared__ __attribute__((aligned(16))) unsigned char hp_smem[];
 
+DEVINL uint32_t lane_id() { return __lane_id(); }
 DEVINL uint32_t bcast32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 DEVINL uint64_t bcast64(uint64_t v) {
-    uint32_t lo = bcast32((uint32_t)v), hi = bcast32((uint32_t)(v >> 32));
+    const uint32_t lo = bcast32((uint32_t)v), hi = bcast32((uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
-DEVINL uint32_t lane_id() { return __lane_id(); }
+DEVINL uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
-DEVINL uint32_t wave_sum_u32(uint32_t v) {
+// ---- DPP helpers -----------------------------------------------------------------------------------------
+// quad_perm [1,0,3,2] = 0xB1 (lane^1), [2,3,0,1] = 0x4E (lane^2), row_ror:8 = 0x128 (lane^8 inside a 16-lane
+// row), row_shr:4 = 0x114, row_shl:4 = 0x104, row_half_mirror = 0x141, row_mirror = 0x140.
+template <int CTRL> DEVINL uint32_t dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+DEVINL uint32_t dpp_xor4(uint32_t v) {  // lanes with bit2 set take lane-4 (banks 1,3), the others lane+4 (banks 0,2)
+    int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xF, 0xA, false);
+    t = __builtin_amdgcn_update_dpp(t, (int)v, 0x104, 0xF, 0x5, false);
+    return (uint32_t)t;
+}
+
+// Sum of 8 per-lane values over the 64 lanes -> 8 uniform results. Transpose-butterfly: three halving
+// exchanges (lane^1, lane^2, lane^8) leave one value per lane (index = b0*4 + b1*2 + b3), one more exchange
+// (lane^4) completes the 16-lane row, and the four rows are combined through v_readlane into SGPRs.
+DEVINL void wave_sum8(const uint32_t (&a)[8], uint32_t (&out)[8]) {
+    const uint32_t lane = lane_id();
+    const bool b0 = (lane & 1u) != 0, b1 = (lane & 2u) != 0, b3 = (lane & 8u) != 0;
+    uint32_t b[4], c[2];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t keep = b0 ? a[k + 4] : a[k], send = b0 ? a[k] : a[k + 4];
+        b[k] = keep + dpp<0xB1>(send);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t keep = b1 ? b[k + 2] : b[k], send = b1 ? b[k] : b[k + 2];
+        c[k] = keep + dpp<0x4E>(send);
+    }
+    const uint32_t keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
+    const uint32_t d = keep + dpp<0x128>(send);
+    const uint32_t e = d + dpp_xor4(d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int L = (j >> 2) | (((j >> 1) & 1) << 1) | ((j & 1) << 3);
+        out[j] = rdlane(e, L) + rdlane(e, L + 16) + rdlane(e, L + 32) + rdlane(e, L + 48);
+    }
 }
 DEVINL uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
-DEVINL Key wave_min_key(Key k) {
+template <int CTRL> DEVINL uint64_t dpp64(uint64_t v) {
+    return ((uint64_t)dpp<CTRL>((uint32_t)(v >> 32)) << 32) | dpp<CTRL>((uint32_t)v);
+}
+DEVINL uint64_t rdlane64(uint64_t v, int l) { return ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l); }
+DEVINL uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+// minimum of a u64 over the wave, uniform result
+DEVINL uint64_t wave_min_u64(uint64_t v) {
+    v = umin64(v, dpp64<0xB1>(v));
+    v = umin64(v, dpp64<0x4E>(v));
+    v = umin64(v, dpp64<0x141>(v));
+    v = umin64(v, dpp64<0x140>(v));
+    return umin64(umin64(rdlane64(v, 0), rdlane64(v, 16)), umin64(rdlane64(v, 32), rdlane64(v, 48)));
+}
+
+// ---- keys ------------------------------------------------------------------------------------------------
+DEVINL bool key_less(const Key& a, const Key& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+DEVINL Key key_inf() { return Key{~0ull, ~0ull}; }
+DEVINL Key make_key(uint64_t total, uint32_t hets, uint64_t idx, uint32_t depth) {
+    return Key{(total << 24) | (uint64_t)(0xFFFFFFu - hets), (idx << 24) | (uint64_t)depth};
+}
+DEVINL Key wave_min_key(Key k) {  // 128-bit lexicographic minimum (main heap; slow path only)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         Key o;
@@ -50,16 +112,24 @@ DEVINL Key wave_min_key(Key k) {
         o.lo = __shfl_xor(k.lo, m);
         if (key_less(o, k)) k = o;
     }
-    return k;
+    return Key{bcast64(k.hi), bcast64(k.lo)};
 }
+// Sub-solver key, one u64 (astar_phaser.rs:131-133 restricted to a <= 62-variant sub-problem):
+//   cost:38 | (63 - hets):6 | node_index:14 | depth:6      (host checks cost < 2^38, nodes < 2^14)
+DEVINL uint64_t make_subkey(uint64_t total, uint32_t hets, uint32_t idx, uint32_t depth) {
+    return (total << 26) | ((uint64_t)(63u - hets) << 20) | ((uint64_t)idx << 6) | (uint64_t)depth;
+}
+DEVINL uint64_t subkey_total(uint64_t k) { return k >> 26; }
+DEVINL uint32_t subkey_idx(uint64_t k) { return (uint32_t)(k >> 6) & 0x3FFFu; }
 
-// ---- node record I/O: lane 0 writes, lane 0 reads, broadcast ------------------------------------
-DEVINL void store_rec(NodeRec* dst, const NodeRec& r) {
+// ---- node record I/O: lane 0 writes, lane 0 reads, broadcast -----------------------------------------------
+DEVINL void store_rec(NodeRec* dst, uint64_t frozen, uint32_t depth, uint32_t hets, uint32_t anc1, uint32_t anc2,
+                      const Win& w0, const Win& w1) {
     if (lane_id() == 0) {
         uint4* d = reinterpret_cast<uint4*>(dst);
-        d[0] = make_uint4((uint32_t)r.frozen, (uint32_t)(r.frozen >> 32), r.depth, r.hets);
-        d[1] = make_uint4(r.anc1, r.anc2, r.w0.h1, r.w0.h2);
-        d[2] = make_uint4(r.w0.nv, r.w1.h1, r.w1.h2, r.w1.nv);
+        d[0] = make_uint4((uint32_t)frozen, (uint32_t)(frozen >> 32), depth, hets);
+        d[1] = make_uint4(anc1, anc2, w0.h1, w0.h2);
+        d[2] = make_uint4(w0.nv, w1.h1, w1.h2, w1.nv);
     }
 }
 DEVINL NodeRec load_rec(const NodeRec* src) {
@@ -85,132 +155,198 @@ DEVINL NodeRec load_rec(const NodeRec* src) {
     return r;
 }
 
-// ---- 64-way sharded heap: lane l owns elements base[j*64 + l] --------------------------------------
-struct Heap {
-    Key* base;          // uniform
-    uint32_t jcap;      // uniform: per-lane capacity
+// ---- 64-way sharded heaps: lane l owns elements [j*64 + l] -------------------------------------------------
+// (a) sub-solver heap: u64 keys, in LDS (or in HBM when the queue parameters make it too large for LDS)
+template <bool LDS> struct SubHeap {
+    uint64_t* gbase;    // used when !LDS
+    uint32_t jcap;      // per-lane capacity
     uint32_t cnt;       // per lane
-    Key top;            // uniform cache of the global minimum (inf when empty)
+    uint64_t top;       // uniform cache of the global minimum (~0 when empty)
     uint32_t top_lane;  // uniform
     uint32_t ovf;       // per lane
-};
-
-DEVINL void heap_reset(Heap& h) {
-    h.cnt = 0;
-    h.top = key_inf();
-    h.top_lane = 0;
-}
-DEVINL void lane_sift_up(Key* hp, uint32_t j, Key k) {
-    while (j > 0) {
-        uint32_t pj = (j - 1) >> 1;
-        Key pk = hp[(size_t)pj * 64];
-        if (key_less(k, pk)) {
-            hp[(size_t)j * 64] = pk;
-            j = pj;
-        } else
-            break;
+    DEVINL uint64_t ld(uint32_t j) const {
+        if (LDS) return reinterpret_cast<const uint64_t*>(hp_smem + LDS_HEAP_OFF)[j * 64 + lane_id()];
+        return gbase[(size_t)j * 64 + lane_id()];
     }
-    hp[(size_t)j * 64] = k;
-}
-DEVINL void lane_sift_down(Key* hp, uint32_t i, uint32_t n, Key k) {
-    for (;;) {
-        uint32_t c = 2 * i + 1;
-        if (c >= n) break;
-        Key ck = hp[(size_t)c * 64];
-        if (c + 1 < n) {
-            Key c2 = hp[(size_t)(c + 1) * 64];
-            if (key_less(c2, ck)) {
-                ck = c2;
-                c = c + 1;
+    DEVINL void st(uint32_t j, uint64_t k) {
+        if (LDS) reinterpret_cast<uint64_t*>(hp_smem + LDS_HEAP_OFF)[j * 64 + lane_id()] = k;
+        else gbase[(size_t)j * 64 + lane_id()] = k;
+    }
+    DEVINL void reset() { cnt = 0; top = ~0ull; top_lane = 0; }
+    DEVINL void push(uint64_t k) {  // uniform key; lane (node_index % 64) inserts it
+        const uint32_t tgt = subkey_idx(k) & 63u;
+        if (lane_id() == tgt) {
+            if (cnt >= jcap) ovf = 1;
+            else {
+                uint32_t j = cnt;
+                while (j > 0) {
+                    const uint32_t pj = (j - 1) >> 1;
+                    const uint64_t pk = ld(pj);
+                    if (k < pk) { st(j, pk); j = pj; } else break;
+                }
+                st(j, k);
+                cnt += 1;
             }
         }
-        if (key_less(ck, k)) {
-            hp[(size_t)i * 64] = ck;
-            i = c;
-        } else
-            break;
+        if (k < top) { top = k; top_lane = tgt; }
     }
-    hp[(size_t)i * 64] = k;
-}
-DEVINL void heap_recompute_top(Heap& h) {
-    Key mine = key_inf();
-    if (h.cnt > 0) mine = h.base[lane_id()];
-    Key m = wave_min_key(mine);
-    h.top.hi = bcast64(m.hi);
-    h.top.lo = bcast64(m.lo);
-    uint64_t who = __ballot(h.cnt > 0 && mine.hi == m.hi && mine.lo == m.lo);
-    h.top_lane = who ? (uint32_t)__builtin_ctzll(who) : 0;
-}
-// uniform key; the lane (node_index % 64) inserts it into its private heap
-DEVINL void heap_push(Heap& h, Key k) {
-    uint32_t tgt = (uint32_t)(k.lo >> 24) & 63u;
-    if (lane_id() == tgt) {
-        if (h.cnt >= h.jcap) {
-            h.ovf = 1;
-        } else {
-            lane_sift_up(h.base + lane_id(), h.cnt, k);
-            h.cnt += 1;
+    DEVINL void pop() {  // removes the global minimum (caller copied `top` first)
+        if (lane_id() == top_lane) {
+            cnt -= 1;
+            if (cnt > 0) {
+                const uint64_t k = ld(cnt);
+                uint32_t i = 0;
+                for (;;) {
+                    uint32_t c = 2 * i + 1;
+                    if (c >= cnt) break;
+                    uint64_t ck = ld(c);
+                    if (c + 1 < cnt) {
+                        const uint64_t c2 = ld(c + 1);
+                        if (c2 < ck) { ck = c2; c += 1; }
+                    }
+                    if (ck < k) { st(i, ck); i = c; } else break;
+                }
+                st(i, k);
+            }
         }
+        const uint64_t mine = cnt > 0 ? ld(0) : ~0ull;
+        top = wave_min_u64(mine);
+        const uint64_t who = __ballot(cnt > 0 && mine == top);
+        top_lane = who ? (uint32_t)__builtin_ctzll(who) : 0u;
     }
-    if (key_less(k, h.top)) {
-        h.top = k;
-        h.top_lane = tgt;
-    }
-}
-// removes the global minimum (h.top); caller copied it first
-DEVINL void heap_pop(Heap& h) {
-    if (lane_id() == h.top_lane) {
-        h.cnt -= 1;
-        if (h.cnt > 0) {
-            Key last = h.base[(size_t)h.cnt * 64 + lane_id()];
-            lane_sift_down(h.base + lane_id(), 0, h.cnt, last);
-        }
-    }
-    heap_recompute_top(h);
-}
-DEVINL bool heap_empty(const Heap& h) { return key_is_inf(h.top); }
+};
 
-// ---- search node held in (uniform) registers -------------------------------------------------------
+// (b) main heap: 128-bit keys in HBM scratch
+struct MainHeap {
+    Key* base;
+    uint32_t jcap, cnt;
+    Key top;
+    uint32_t top_lane, ovf;
+    DEVINL Key ld(uint32_t j) const { return base[(size_t)j * 64 + lane_id()]; }
+    DEVINL void st(uint32_t j, const Key& k) { base[(size_t)j * 64 + lane_id()] = k; }
+    DEVINL void reset() { cnt = 0; top = key_inf(); top_lane = 0; }
+    DEVINL bool empty() const { return (top.hi & top.lo) == ~0ull; }
+    DEVINL void sift_down(uint32_t i, Key k) {
+        for (;;) {
+            uint32_t c = 2 * i + 1;
+            if (c >= cnt) break;
+            Key ck = ld(c);
+            if (c + 1 < cnt) {
+                const Key c2 = ld(c + 1);
+                if (key_less(c2, ck)) { ck = c2; c += 1; }
+            }
+            if (key_less(ck, k)) { st(i, ck); i = c; } else break;
+        }
+        st(i, k);
+    }
+    DEVINL void push(const Key& k) {
+        const uint32_t tgt = (uint32_t)(k.lo >> 24) & 63u;
+        if (lane_id() == tgt) {
+            if (cnt >= jcap) ovf = 1;
+            else {
+                uint32_t j = cnt;
+                while (j > 0) {
+                    const uint32_t pj = (j - 1) >> 1;
+                    const Key pk = ld(pj);
+                    if (key_less(k, pk)) { st(j, pk); j = pj; } else break;
+                }
+                st(j, k);
+                cnt += 1;
+            }
+        }
+        if (key_less(k, top)) { top = k; top_lane = tgt; }
+    }
+    DEVINL void recompute_top() {
+        Key mine = key_inf();
+        if (cnt > 0) mine = ld(0);
+        top = wave_min_key(mine);
+        const uint64_t who = __ballot(cnt > 0 && mine.hi == top.hi && mine.lo == top.lo);
+        top_lane = who ? (uint32_t)__builtin_ctzll(who) : 0;
+    }
+    DEVINL void pop() {
+        if (lane_id() == top_lane) {
+            cnt -= 1;
+            if (cnt > 0) sift_down(0, ld(cnt));
+        }
+        recompute_top();
+    }
+};
+
+// ---- search node held in (uniform) registers ---------------------------------------------------------------
 struct Cur {
     uint64_t frozen, total, idx;
     uint32_t depth, hets, anc1, anc2;
     Win w0, w1;
 };
-
-DEVINL Key make_key(uint64_t total, uint32_t hets, uint64_t idx, uint32_t depth) {
-    Key k;
-    k.hi = (total << 24) | (uint64_t)(0xFFFFFFu - hets);
-    k.lo = (idx << 24) | (uint64_t)depth;
-    return k;
-}
 DEVINL Win fresh_win() { return Win{0u, 0u, 0xFFFFFFFFu}; }
+DEVINL Cur root_node(uint64_t heur) {
+    Cur n;
+    n.frozen = 0; n.total = heur; n.idx = 0; n.depth = 0; n.hets = 0; n.anc1 = NONE32; n.anc2 = NONE32;
+    n.w0 = fresh_win(); n.w1 = fresh_win();
+    return n;
+}
+DEVINL Cur cur_from_rec(const NodeRec& r, uint64_t total, uint64_t idx) {
+    Cur n;
+    n.frozen = r.frozen; n.total = total; n.idx = idx; n.depth = r.depth; n.hets = r.hets;
+    n.anc1 = r.anc1; n.anc2 = r.anc2; n.w0 = r.w0; n.w1 = r.w1;
+    return n;
+}
 
 struct Ctx {
-    const uint32_t *vlo, *vhi;
-    const uint8_t* vflags;
     const uint32_t *rstart, *rend, *rword;
     const uint32_t* words;
     uint32_t N;
-    // per-lane work counters
-    uint64_t evals, cells;
+    uint64_t evals, cells;  // per-lane work counters
 };
 
-struct Children {
-    int n;
-    uint32_t a1[4], a2[4];
-    uint64_t frozen[4], total[4];
-    uint32_t hets[4];
-    Win w0[4];
-    // shared by all children
-    uint32_t depth, anc1, anc2;
-    Win w1;
+// The children of one expansion, fixed slots in the reference's hap_order (astar_phaser.rs:367-372):
+//   slot 0 = (0,1)   slot 1 = (1,0)   slot 2 = (0,0)   slot 3 = (1,1);   an ignored variant: slot 0 = (2,2) only.
+struct Kids {
+    bool bad, has1;        // has1: the (1,0) child exists (parent haplotypes differ <=> hets != 0)
+    uint32_t n;            // number of children created
+    uint64_t frozen0, frozen1, frozen2, frozen3;
+    uint64_t total0, total1, total2, total3;
+    uint32_t depth, anc1, anc2, hets_het, hets_hom;
+    Win base, w1;          // base = parent's window in the child's chunk (fresh when a new chunk opens)
+    uint32_t bit;          // 1 << (p & 31)
 };
+template <int S> DEVINL uint64_t kid_total(const Kids& k) { return S == 0 ? k.total0 : S == 1 ? k.total1 : S == 2 ? k.total2 : k.total3; }
+template <int S> DEVINL uint64_t kid_frozen(const Kids& k) { return S == 0 ? k.frozen0 : S == 1 ? k.frozen1 : S == 2 ? k.frozen2 : k.frozen3; }
+template <int S> DEVINL bool kid_valid(const Kids& k) { return S == 0 ? true : k.bad ? false : (S == 1 ? k.has1 : true); }
+template <int S> DEVINL uint32_t kid_hets(const Kids& k) { return (S <= 1 && !k.bad) ? k.hets_het : k.hets_hom; }
+// creation rank of slot S among the children of this expansion (node_index = next_idx + rank)
+template <int S> DEVINL uint32_t kid_rank(const Kids& k) { return S == 0 ? 0u : S == 1 ? 1u : (S == 2 ? (k.has1 ? 2u : 1u) : (k.has1 ? 3u : 2u)); }
+template <int S> DEVINL Win kid_win(const Kids& k) {
+    Win w = k.base;
+    if (!k.bad) {
+        w.nv &= ~k.bit;
+        if (S == 1 || S == 3) w.h1 |= k.bit;   // a1 == 1
+        if (S == 0 || S == 3) w.h2 |= k.bit;   // a2 == 1
+    }
+    return w;
+}
+template <int S> DEVINL Cur kid_as_cur(const Kids& k, uint64_t next_idx) {
+    Cur n;
+    n.frozen = kid_frozen<S>(k); n.total = kid_total<S>(k); n.idx = next_idx + kid_rank<S>(k);
+    n.depth = k.depth; n.hets = kid_hets<S>(k); n.anc1 = k.anc1; n.anc2 = k.anc2;
+    n.w0 = kid_win<S>(k); n.w1 = k.w1;
+    return n;
+}
+template <int S> DEVINL void kid_store(NodeRec* pool, const Kids& k, uint64_t next_idx) {
+    store_rec(pool + (next_idx + kid_rank<S>(k)), kid_frozen<S>(k), k.depth, kid_hets<S>(k), k.anc1, k.anc2, kid_win<S>(k), k.w1);
+}
 
 // weighted popcount: sum_b popc(M & Q_b) << b   (Horner over the 8 quality bit-planes)
-DEVINL uint32_t wpop(uint32_t M, const uint32_t* Q) {
-    uint32_t s = 0;
-#pragma unroll
-    for (int b = 7; b >= 0; --b) s = (s << 1) + (uint32_t)__popc(M & Q[b]);
+DEVINL uint32_t wpop(uint32_t M, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t q4, uint32_t q5,
+                     uint32_t q6, uint32_t q7) {
+    uint32_t s = (uint32_t)__popc(M & q7);
+    s = (s << 1) + (uint32_t)__popc(M & q6);
+    s = (s << 1) + (uint32_t)__popc(M & q5);
+    s = (s << 1) + (uint32_t)__popc(M & q4);
+    s = (s << 1) + (uint32_t)__popc(M & q3);
+    s = (s << 1) + (uint32_t)__popc(M & q2);
+    s = (s << 1) + (uint32_t)__popc(M & q1);
+    s = (s << 1) + (uint32_t)__popc(M & q0);
     return s;
 }
 
@@ -218,17 +354,20 @@ DEVINL uint32_t wpop(uint32_t M, const uint32_t* Q) {
 // Row r covering p contributes min(score(h1'), score(h2')) where h' = parent prefix + child allele:
 //   score(h') = S(parent prefix over [max(start_r, off), p)) + (allele_r[p] != a ? qual_r[p] : 0)
 // so the O(overlap) part is shared by the children; it is evaluated bit-parallel per 32-variant word.
-DEVINL void score_children(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, const NodeRec* pool, Children& ch,
-                           uint32_t (&sumF)[4], uint32_t (&sumL)[4]) {
+// [lo, hi) = candidate rows of variant p (start-sorted), bad = variant ignored.
+DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t lo, uint32_t hi, bool bad,
+                   uint64_t h_next, NodeRec* pool, Kids& kd) {
     const uint32_t lane = lane_id();
     const uint32_t kp = p >> 5, bp = p & 31u;
     const uint32_t ck = cur.depth ? ((off + cur.depth - 1) >> 5) : (off >> 5);
     const bool trans = (ck != kp);  // the child opens a new 32-variant chunk
+    if (trans)  // cur becomes the holder of a complete chunk that its descendants link to: persist it
+        store_rec(pool + cur.idx, cur.frozen, cur.depth, cur.hets, cur.anc1, cur.anc2, cur.w0, cur.w1);
     const Win W0 = trans ? fresh_win() : cur.w0;
     const Win W1 = trans ? cur.w0 : cur.w1;
     const Win W2 = cur.w1;  // only meaningful when trans
-    uint32_t accF[4] = {0, 0, 0, 0}, accL[4] = {0, 0, 0, 0};
-    const uint32_t lo = cx.vlo[p], hi = cx.vhi[p];
+    const uint32_t nkids = bad ? 1u : (cur.hets != 0 ? 4u : 3u);
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0..3] frozen per slot, [4..7] fluid per slot
 
     for (uint32_t base = lo; base < hi; base += 64) {
         const uint32_t r = base + lane;
@@ -256,7 +395,7 @@ DEVINL void score_children(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, co
             else {
                 if (chain_phase == 0) {
                     if (chain_slot == NONE32 || ++guard > (cx.N >> 6) + 4) break;  // nothing older: zero cost
-                    NodeRec a = load_rec(pool + chain_slot);
+                    const NodeRec a = load_rec(pool + chain_slot);
                     w = a.w0;
                     cw1 = a.w1;
                     chain_next = a.anc2;
@@ -271,134 +410,86 @@ DEVINL void score_children(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, co
                 const uint4* pw = reinterpret_cast<const uint4*>(cx.words + (size_t)(rw + (kp - j - kr)) * WORD_DWORDS);
                 const uint4 x0 = pw[0], x1 = pw[1], x2 = pw[2];
                 const uint32_t aLo = x0.x, aHi = x0.y;
-                const uint32_t Q[8] = {x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y};
                 const uint32_t M1 = ~w.nv & ((aLo ^ w.h1) | aHi);
                 const uint32_t M2 = ~w.nv & ((aLo ^ w.h2) | aHi);
-                s1 += wpop(M1, Q);
-                s2 += wpop(M2, Q);
+                s1 += wpop(M1, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
+                s2 += wpop(M2, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
                 if (j == 0) {
                     ap = ((aLo >> bp) & 1u) | (((aHi >> bp) & 1u) << 1);
-                    qp = 0;
-#pragma unroll
-                    for (int b = 7; b >= 0; --b) qp = (qp << 1) | ((Q[b] >> bp) & 1u);
+                    qp = ((x0.z >> bp) & 1u) | (((x0.w >> bp) & 1u) << 1) | (((x1.x >> bp) & 1u) << 2) |
+                         (((x1.y >> bp) & 1u) << 3) | (((x1.z >> bp) & 1u) << 4) | (((x1.w >> bp) & 1u) << 5) |
+                         (((x2.x >> bp) & 1u) << 6) | (((x2.y >> bp) & 1u) << 7);
                 }
             }
         }
         if (valid) {
-            const bool frozen = (re == p + 1);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c < ch.n) {
-                    const uint32_t m1 = (ch.a1[c] < 2 && ap != ch.a1[c]) ? qp : 0u;
-                    const uint32_t m2 = (ch.a2[c] < 2 && ap != ch.a2[c]) ? qp : 0u;
-                    const uint32_t cost = min(s1 + m1, s2 + m2);
-                    if (frozen) accF[c] += cost; else accL[c] += cost;
-                }
-            }
-            cx.evals += (uint64_t)ch.n;
-            cx.cells += (uint64_t)ch.n * (uint64_t)(p + 1 - max(rs, off));
+            const uint32_t x0 = (!bad && ap != 0u) ? qp : 0u;  // cost of giving a haplotype allele 0 here
+            const uint32_t x1 = (!bad && ap != 1u) ? qp : 0u;  // ... allele 1
+            const uint32_t c0 = min(s1 + x0, s2 + x1);  // (0,1)  [== min(s1, s2) for the (2,2) child]
+            const uint32_t c1 = min(s1 + x1, s2 + x0);  // (1,0)
+            const uint32_t c2 = min(s1 + x0, s2 + x0);  // (0,0)
+            const uint32_t c3 = min(s1 + x1, s2 + x1);  // (1,1)
+            const bool frozen = (re == p + 1);           // rs.region().end <= hap_len (astar_phaser.rs:101)
+            acc[0] += frozen ? c0 : 0u; acc[4] += frozen ? 0u : c0;
+            acc[1] += frozen ? c1 : 0u; acc[5] += frozen ? 0u : c1;
+            acc[2] += frozen ? c2 : 0u; acc[6] += frozen ? 0u : c2;
+            acc[3] += frozen ? c3 : 0u; acc[7] += frozen ? 0u : c3;
+            cx.evals += (uint64_t)nkids;
+            cx.cells += (uint64_t)nkids * (uint64_t)(p + 1 - max(rs, off));
         }
     }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        sumF[c] = bcast32(wave_sum_u32(accF[c]));
-        sumL[c] = bcast32(wave_sum_u32(accL[c]));
-    }
-}
+    uint32_t sum[8];
+    wave_sum8(acc, sum);
 
-// Builds the children of `cur` (astar_phaser.rs:348-392 / :517-561): order (0,1),(1,0),(0,0),(1,1);
-// (1,0) skipped iff the parent haplotypes are identical (<=> hets == 0); an ignored variant yields one (2,2).
-DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint64_t h_next, NodeRec* pool, Children& ch) {
-    const bool bad = (cx.vflags[p] & HP_VAR_IGNORED) != 0;
-    ch.n = 0;
-    if (bad) {
-        ch.a1[0] = 2; ch.a2[0] = 2; ch.n = 1;
-    } else {
-        ch.a1[ch.n] = 0; ch.a2[ch.n] = 1; ch.n++;
-        if (cur.hets != 0) { ch.a1[ch.n] = 1; ch.a2[ch.n] = 0; ch.n++; }
-        ch.a1[ch.n] = 0; ch.a2[ch.n] = 0; ch.n++;
-        ch.a1[ch.n] = 1; ch.a2[ch.n] = 1; ch.n++;
-    }
-    const uint32_t kp = p >> 5, bp = p & 31u;
-    const uint32_t ck = cur.depth ? ((off + cur.depth - 1) >> 5) : (off >> 5);
-    const bool trans = (ck != kp);
-    if (trans) {
-        // cur becomes the holder of a complete chunk that its descendants link to: persist it
-        NodeRec r;
-        r.frozen = cur.frozen; r.depth = cur.depth; r.hets = cur.hets; r.anc1 = cur.anc1; r.anc2 = cur.anc2;
-        r.w0 = cur.w0; r.w1 = cur.w1;
-        store_rec(pool + cur.idx, r);
-    }
-    uint32_t sumF[4], sumL[4];
-    score_children(cx, cur, off, p, pool, ch, sumF, sumL);
-    ch.depth = cur.depth + 1;
-    ch.anc1 = trans ? (uint32_t)cur.idx : cur.anc1;
-    ch.anc2 = trans ? cur.anc1 : cur.anc2;
-    ch.w1 = trans ? cur.w0 : cur.w1;
-    const Win basew = trans ? fresh_win() : cur.w0;
-    for (int c = 0; c < ch.n; ++c) {
-        ch.frozen[c] = cur.frozen + sumF[c];
-        ch.total[c] = ch.frozen[c] + sumL[c] + h_next;
-        ch.hets[c] = cur.hets + (ch.a1[c] != ch.a2[c] ? 1u : 0u);
-        Win w = basew;
-        if (ch.a1[c] < 2) {
-            w.nv &= ~(1u << bp);
-            w.h1 |= ch.a1[c] << bp;
-            w.h2 |= ch.a2[c] << bp;
-        }
-        ch.w0[c] = w;
-    }
-}
-
-DEVINL Cur child_as_cur(const Children& ch, int c, uint64_t idx) {
-    Cur n;
-    n.frozen = ch.frozen[c]; n.total = ch.total[c]; n.idx = idx;
-    n.depth = ch.depth; n.hets = ch.hets[c]; n.anc1 = ch.anc1; n.anc2 = ch.anc2;
-    n.w0 = ch.w0[c]; n.w1 = ch.w1;
-    return n;
-}
-DEVINL void store_child(NodeRec* pool, const Children& ch, int c, uint64_t idx) {
-    NodeRec r;
-    r.frozen = ch.frozen[c]; r.depth = ch.depth; r.hets = ch.hets[c]; r.anc1 = ch.anc1; r.anc2 = ch.anc2;
-    r.w0 = ch.w0[c]; r.w1 = ch.w1;
-    store_rec(pool + idx, r);
-}
-DEVINL Cur cur_from_pool(const NodeRec* pool, Key k) {
-    const uint64_t idx = k.lo >> 24;
-    NodeRec r = load_rec(pool + idx);
-    Cur n;
-    n.frozen = r.frozen; n.total = k.hi >> 24; n.idx = idx;
-    n.depth = r.depth; n.hets = r.hets; n.anc1 = r.anc1; n.anc2 = r.anc2;
-    n.w0 = r.w0; n.w1 = r.w1;
-    return n;
-}
-DEVINL Cur root_node(uint64_t heur) {
-    Cur n;
-    n.frozen = 0; n.total = heur; n.idx = 0; n.depth = 0; n.hets = 0; n.anc1 = NONE32; n.anc2 = NONE32;
-    n.w0 = fresh_win(); n.w1 = fresh_win();
-    return n;
+    kd.bad = bad;
+    kd.has1 = !bad && cur.hets != 0;
+    kd.n = nkids;
+    kd.depth = cur.depth + 1;
+    kd.anc1 = trans ? (uint32_t)cur.idx : cur.anc1;
+    kd.anc2 = trans ? cur.anc1 : cur.anc2;
+    kd.w1 = W1;
+    kd.base = W0;
+    kd.bit = 1u << bp;
+    kd.hets_het = cur.hets + 1;
+    kd.hets_hom = cur.hets;
+    kd.frozen0 = cur.frozen + sum[0]; kd.total0 = kd.frozen0 + sum[4] + h_next;
+    kd.frozen1 = cur.frozen + sum[1]; kd.total1 = kd.frozen1 + sum[5] + h_next;
+    kd.frozen2 = cur.frozen + sum[2]; kd.total2 = kd.frozen2 + sum[6] + h_next;
+    kd.frozen3 = cur.frozen + sum[3]; kd.total3 = kd.frozen3 + sum[7] + h_next;
 }
 
 struct WaveCounters {
     uint64_t sub_pops, main_pops, nodes;
 };
 
-// LDS ring of the last 64 heuristic values: H[x] lives at ring[x & 63] while x in [v, v+64)
-DEVINL uint64_t ring_get(const uint64_t* ring, uint32_t x) {
+// LDS rings, indexed by (variant & 63): H[x] and the per-variant (lo, hi, flags) triple. Written and read by
+// lane 0 only, then broadcast.
+DEVINL uint64_t ringH_get(uint32_t x) {
     uint64_t v = 0;
-    if (lane_id() == 0) v = ring[x & 63u];
+    if (lane_id() == 0) v = reinterpret_cast<const uint64_t*>(hp_smem + LDS_HRING_OFF)[x & 63u];
     return bcast64(v);
 }
-DEVINL void ring_set(uint64_t* ring, uint32_t x, uint64_t v) {
-    if (lane_id() == 0) ring[x & 63u] = v;
+DEVINL void ringH_set(uint32_t x, uint64_t v) {
+    if (lane_id() == 0) reinterpret_cast<uint64_t*>(hp_smem + LDS_HRING_OFF)[x & 63u] = v;
+}
+DEVINL void ringV_set(uint32_t x, uint32_t lo, uint32_t hi, uint32_t flags) {
+    if (lane_id() == 0) reinterpret_cast<uint4*>(hp_smem + LDS_VRING_OFF)[x & 63u] = make_uint4(lo, hi, flags, 0);
+}
+DEVINL void ringV_get(uint32_t x, uint32_t& lo, uint32_t& hi, uint32_t& flags) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (lane_id() == 0) v = reinterpret_cast<const uint4*>(hp_smem + LDS_VRING_OFF)[x & 63u];
+    lo = bcast32(v.x);
+    hi = bcast32(v.y);
+    flags = bcast32(v.z);
 }
 
 // astar_subsolver (astar_phaser.rs:311-405). Returns status; outputs (max_cost_so_far, farthest).
-DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t ps, Heap& heap, NodeRec* pool,
-                        const uint64_t* ring, WaveCounters& wc, uint64_t& est, uint32_t& solved) {
-    heap_reset(heap);
-    uint64_t next_idx = 1;
-    Cur cur = root_node(ring_get(ring, off + 1));  // initial_estimate = H[off+1] (astar_phaser.rs:322)
+template <bool SUB_LDS>
+DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t ps, SubHeap<SUB_LDS>& heap,
+                        NodeRec* pool, WaveCounters& wc, uint64_t& est, uint32_t& solved) {
+    heap.reset();
+    uint32_t next_idx = 1;
+    Cur cur = root_node(ringH_get(off + 1));  // initial_estimate = H[off+1] (astar_phaser.rs:322)
     uint32_t next_expected = 0, visited = 0;
     uint64_t max_cost = 0;
     const uint32_t max_visits = prm.minq_sub + prm.qinc * ps;
@@ -411,31 +502,37 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
             next_expected += 1;
         }
         const uint32_t p = off + cur.depth;
-        Children ch;
-        expand(cx, cur, off, p, ring_get(ring, p + 1), pool, ch);
-        wc.nodes += ch.n;
-        if (next_idx + ch.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
-        if (ch.a1[0] == 2 && ch.total[0] != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
-        int best = 0;
-        Key kbest = make_key(ch.total[0], ch.hets[0], next_idx, ch.depth);
-        for (int c = 1; c < ch.n; ++c) {
-            Key k = make_key(ch.total[c], ch.hets[c], next_idx + c, ch.depth);
-            if (key_less(k, kbest)) { kbest = k; best = c; }
-        }
-        const bool take_child = key_less(kbest, heap.top);  // top is inf when the heap is empty
-        for (int c = 0; c < ch.n; ++c) {
-            if (take_child && c == best) continue;
-            store_child(pool, ch, c, next_idx + c);
-            heap_push(heap, make_key(ch.total[c], ch.hets[c], next_idx + c, ch.depth));
-        }
+        uint32_t lo, hi, flags;
+        ringV_get(p, lo, hi, flags);
+        Kids kd;
+        expand(cx, cur, off, p, lo, hi, (flags & HP_VAR_IGNORED) != 0, ringH_get(p + 1), pool, kd);
+        wc.nodes += kd.n;
+        if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
+        if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
+        // keys of the (up to 4) children; invalid slots get the infinite key
+        const uint64_t k0 = make_subkey(kd.total0, kid_hets<0>(kd), next_idx + kid_rank<0>(kd), kd.depth);
+        const uint64_t k1 = kid_valid<1>(kd) ? make_subkey(kd.total1, kid_hets<1>(kd), next_idx + kid_rank<1>(kd), kd.depth) : ~0ull;
+        const uint64_t k2 = kid_valid<2>(kd) ? make_subkey(kd.total2, kid_hets<2>(kd), next_idx + kid_rank<2>(kd), kd.depth) : ~0ull;
+        const uint64_t k3 = kid_valid<3>(kd) ? make_subkey(kd.total3, kid_hets<3>(kd), next_idx + kid_rank<3>(kd), kd.depth) : ~0ull;
+        const uint64_t kbest = umin64(umin64(k0, k1), umin64(k2, k3));
+        // If the best child beats everything queued it is the next pop: keep it in registers (push + pop elided;
+        // the priority is a total order, so this is exactly what the reference's queue would return).
+        const bool take_child = kbest < heap.top;
+        if (!(take_child && k0 == kbest)) { kid_store<0>(pool, kd, next_idx); heap.push(k0); }
+        if (k1 != ~0ull && !(take_child && k1 == kbest)) { kid_store<1>(pool, kd, next_idx); heap.push(k1); }
+        if (k2 != ~0ull && !(take_child && k2 == kbest)) { kid_store<2>(pool, kd, next_idx); heap.push(k2); }
+        if (k3 != ~0ull && !(take_child && k3 == kbest)) { kid_store<3>(pool, kd, next_idx); heap.push(k3); }
         if (take_child) {
-            cur = child_as_cur(ch, best, next_idx + best);
+            if (k0 == kbest) cur = kid_as_cur<0>(kd, next_idx);
+            else if (k1 == kbest) cur = kid_as_cur<1>(kd, next_idx);
+            else if (k2 == kbest) cur = kid_as_cur<2>(kd, next_idx);
+            else cur = kid_as_cur<3>(kd, next_idx);
         } else {
-            Key t = heap.top;
-            heap_pop(heap);
-            cur = cur_from_pool(pool, t);
+            const uint64_t t = heap.top;
+            heap.pop();
+            cur = cur_from_rec(load_rec(pool + subkey_idx(t)), subkey_total(t), subkey_idx(t));
         }
-        next_idx += ch.n;
+        next_idx += kd.n;
         if (__any(heap.ovf)) { st = ST_OVERFLOW; break; }
     }
     if (cur.depth == ps) {  // astar_phaser.rs:395-399 (peek, not pop)
@@ -448,13 +545,15 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
 }
 
 template <bool SUB_LDS>
-DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* lds_heap, uint64_t* ring) {
+DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
     const SolveParams& prm = B.prm;
     const BlockDesc d = B.desc[blk];
     const uint32_t N = d.n_vars;
     const uint32_t lane = lane_id();
     Ctx cx;
-    cx.vlo = B.vlo + d.var_off; cx.vhi = B.vhi + d.var_off; cx.vflags = B.vflags + d.var_off;
+    const uint32_t* vlo = B.vlo + d.var_off;
+    const uint32_t* vhi = B.vhi + d.var_off;
+    const uint8_t* vflags = B.vflags + d.var_off;
     cx.rstart = B.rstart + d.read_off; cx.rend = B.rend + d.read_off; cx.rword = B.rword + d.read_off;
     cx.words = B.words + d.word_off * WORD_DWORDS;
     cx.N = N; cx.evals = 0; cx.cells = 0;
@@ -464,44 +563,64 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
     uint32_t* tracker = B.tracker + (size_t)slot * ((size_t)prm.max_n_vars + 1);
     WaveCounters wc{0, 0, 0};
     int32_t st = ST_OK;
+    const bool resume = bcast32(lane == 0 ? (uint32_t)B.status[blk] : 0u) == (uint32_t)ST_OVERFLOW_MAIN;
 
-    Heap sub;
-    sub.base = SUB_LDS ? lds_heap : (B.sub_heap_g + (size_t)slot * prm.jcap_sub * 64);
-    sub.jcap = prm.jcap_sub;
-    sub.ovf = 0;
-
-    // ---- calculate_astar_heuristic (astar_phaser.rs:246-292) -------------------------------------------
-    if (lane == 0) H[N] = 0;
-    ring_set(ring, N, 0);
-    uint32_t clip = 1;
-    for (uint32_t v = N; v-- > 0;) {
-        ring_set(ring, v, 0);  // heuristic_costs[problem_offset] is still 0 (astar_phaser.rs:320)
-        uint64_t est = 0;
-        uint32_t solved = 0;
-        st = subsolve(cx, prm, v, clip, sub, sub_pool, ring, wc, est, solved);
-        if (st != ST_OK) break;
-        if (solved < min(clip, 2u)) { st = ST_INVARIANT; break; }  // astar_phaser.rs:268
-        const bool bad = (cx.vflags[v] & HP_VAR_IGNORED) != 0;
-        const uint64_t hnext = ring_get(ring, v + 1);
-        uint64_t hv;
-        if (bad) hv = hnext;
-        else {
-            if (est < hnext) { st = ST_INVARIANT; break; }  // astar_phaser.rs:284
-            hv = est;
+    if (!resume) {
+        // ---- calculate_astar_heuristic (astar_phaser.rs:246-292) ---------------------------------------
+        SubHeap<SUB_LDS> sub;
+        sub.gbase = SUB_LDS ? nullptr : reinterpret_cast<uint64_t*>(B.sub_heap_g) + (size_t)slot * prm.jcap_sub * 64;
+        sub.jcap = prm.jcap_sub;
+        sub.ovf = 0;
+        if (lane == 0) H[N] = 0;
+        ringH_set(N, 0);
+        uint32_t clip = 1;
+        for (uint32_t v = N; v-- > 0;) {
+            ringH_set(v, 0);  // heuristic_costs[problem_offset] is still 0 (astar_phaser.rs:320)
+            uint32_t fl = 0, l = 0, h = 0;
+            if (lane == 0) { fl = vflags[v]; l = vlo[v]; h = vhi[v]; }
+            fl = bcast32(fl);
+            ringV_set(v, l, h, fl);
+            uint64_t est = 0;
+            uint32_t solved = 0;
+            st = subsolve<SUB_LDS>(cx, prm, v, clip, sub, sub_pool, wc, est, solved);
+            if (st != ST_OK) break;
+            if (solved < min(clip, 2u)) { st = ST_INVARIANT; break; }  // astar_phaser.rs:268
+            const bool bad = (fl & HP_VAR_IGNORED) != 0;
+            const uint64_t hnext = ringH_get(v + 1);
+            uint64_t hv;
+            if (bad) hv = hnext;
+            else {
+                if (est < hnext) { st = ST_INVARIANT; break; }  // astar_phaser.rs:284
+                hv = est;
+            }
+            ringH_set(v, hv);
+            if (lane == 0) H[v] = hv;
+            clip = min(solved + 1, prm.max_seg);
         }
-        ring_set(ring, v, hv);
-        if (lane == 0) H[v] = hv;
-        clip = min(solved + 1, prm.max_seg);
+    } else {
+        // the heuristic of this block was completed by an earlier launch whose main-search scratch overflowed
+        uint64_t a = 0, b2 = 0, c2 = 0, d2 = 0;
+        if (lane == 0) {
+            const hp_work_counters c = B.counters[blk];
+            a = c.sub_pops; b2 = c.nodes_created; c2 = c.evals; d2 = c.cells;
+            cx.evals = c2; cx.cells = d2;
+        }
+        wc.sub_pops = bcast64(a);
+        wc.nodes = bcast64(b2);
     }
+    // counters of the heuristic phase, kept in case the main search has to be re-run with more scratch
+    const uint64_t h_evals = wave_sum_u64(cx.evals), h_cells = wave_sum_u64(cx.cells);
+    const uint64_t h_nodes = wc.nodes;
+    cx.evals = 0; cx.cells = 0;
 
     // ---- main pruned search (astar_phaser.rs:451-633) ---------------------------------------------------
     hp_phase_stats stats{};
     if (st == ST_OK) {
-        Heap hq;
+        MainHeap hq;
         hq.base = B.main_heap + (size_t)slot * prm.jcap_main * 64;
         hq.jcap = prm.jcap_main;
         hq.ovf = 0;
-        heap_reset(hq);
+        hq.reset();
         // PQueueHapTracker (astar_phaser.rs:171-231): per-length counts live in global scratch and are only
         // ever touched by lane 0 (plain same-thread read-modify-write); the running total is a register.
         if (lane == 0) for (uint32_t i = 0; i <= N; ++i) tracker[i] = 0;
@@ -515,8 +634,8 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
             if (len >= trk_thr) trk_total -= 1;
         };
 
-        uint64_t thr = prm.minq_main;                      // curr_queue_size_threshold
-        const uint64_t max_q = 10ull * prm.minq_main;      // max_queue_size
+        uint64_t thr = prm.minq_main;                  // curr_queue_size_threshold
+        const uint64_t max_q = 10ull * prm.minq_main;  // max_queue_size
         uint32_t min_progress = 0, next_expected = 0;
         uint64_t pruned = 0, next_idx = 1, qlen = 1;
         const uint64_t h0 = bcast64(lane == 0 ? H[0] : 0);
@@ -534,33 +653,38 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
             if (cur.depth < min_progress) {  // astar_phaser.rs:507-515
                 if (pruned == 0) thr = prm.minq_main;
                 pruned += 1;
-                if (heap_empty(hq)) { st = ST_INVARIANT; break; }
-                Key t = hq.top;
-                heap_pop(hq);
-                cur = cur_from_pool(main_pool, t);
+                if (hq.empty()) { st = ST_INVARIANT; break; }
+                const Key t = hq.top;
+                hq.pop();
+                cur = cur_from_rec(load_rec(main_pool + (t.lo >> 24)), t.hi >> 24, t.lo >> 24);
                 continue;
             }
             const uint32_t p = cur.depth;
-            const uint64_t hn = bcast64(lane == 0 ? H[p + 1] : 0);
-            Children ch;
-            expand(cx, cur, 0, p, hn, main_pool, ch);
-            wc.nodes += ch.n;
-            if (next_idx + ch.n > prm.cap_main) { st = ST_OVERFLOW; break; }
-            if (ch.a1[0] == 2 && ch.total[0] != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:529
+            uint32_t fl = 0, l = 0, h = 0;
+            uint64_t hn = 0;
+            if (lane == 0) { fl = vflags[p]; l = vlo[p]; h = vhi[p]; hn = H[p + 1]; }
+            fl = bcast32(fl); l = bcast32(l); h = bcast32(h); hn = bcast64(hn);
+            Kids kd;
+            expand(cx, cur, 0, p, l, h, (fl & HP_VAR_IGNORED) != 0, hn, main_pool, kd);
+            wc.nodes += kd.n;
+            if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; break; }
+            if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:529
+            const Key k0 = make_key(kd.total0, kid_hets<0>(kd), next_idx + kid_rank<0>(kd), kd.depth);
+            const Key k1 = kid_valid<1>(kd) ? make_key(kd.total1, kid_hets<1>(kd), next_idx + kid_rank<1>(kd), kd.depth) : key_inf();
+            const Key k2 = kid_valid<2>(kd) ? make_key(kd.total2, kid_hets<2>(kd), next_idx + kid_rank<2>(kd), kd.depth) : key_inf();
+            const Key k3 = kid_valid<3>(kd) ? make_key(kd.total3, kid_hets<3>(kd), next_idx + kid_rank<3>(kd), kd.depth) : key_inf();
             int best = 0;
-            Key kbest = make_key(ch.total[0], ch.hets[0], next_idx, ch.depth);
-            for (int c = 1; c < ch.n; ++c) {
-                Key k = make_key(ch.total[c], ch.hets[c], next_idx + c, ch.depth);
-                if (key_less(k, kbest)) { kbest = k; best = c; }
-            }
+            Key kbest = k0;
+            if (key_less(k1, kbest)) { kbest = k1; best = 1; }
+            if (key_less(k2, kbest)) { kbest = k2; best = 2; }
+            if (key_less(k3, kbest)) { kbest = k3; best = 3; }
             // push every child except the best one, which is held in registers (it is logically queued)
-            trk_add(ch.depth, (uint32_t)ch.n);
-            for (int c = 0; c < ch.n; ++c) {
-                if (c == best) continue;
-                store_child(main_pool, ch, c, next_idx + c);
-                heap_push(hq, make_key(ch.total[c], ch.hets[c], next_idx + c, ch.depth));
-            }
-            qlen += ch.n;
+            trk_add(kd.depth, kd.n);
+            if (best != 0) { kid_store<0>(main_pool, kd, next_idx); hq.push(k0); }
+            if (kid_valid<1>(kd) && best != 1) { kid_store<1>(main_pool, kd, next_idx); hq.push(k1); }
+            if (kid_valid<2>(kd) && best != 2) { kid_store<2>(main_pool, kd, next_idx); hq.push(k2); }
+            if (kid_valid<3>(kd) && best != 3) { kid_store<3>(main_pool, kd, next_idx); hq.push(k3); }
+            qlen += kd.n;
             // astar_phaser.rs:564-585
             while (trk_total > thr && min_progress < next_expected) {
                 min_progress += 1;
@@ -573,31 +697,36 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
                 if (qlen > max_q) {
                     // full prune: every queued node shorter than min_progress gets the cleared priority
                     // (cost 0, same hets, same index); each lane rewrites and re-heapifies its private heap
-                    Key* hp = hq.base + lane;
                     for (uint32_t j = 0; j < hq.cnt; ++j) {
-                        Key k = hp[(size_t)j * 64];
+                        Key k = hq.ld(j);
                         if ((uint32_t)(k.lo & 0xFFFFFFu) < min_progress) {
                             k.hi &= 0xFFFFFFull;
-                            hp[(size_t)j * 64] = k;
+                            hq.st(j, k);
                         }
                     }
-                    for (uint32_t i = hq.cnt / 2; i-- > 0;) lane_sift_down(hp, i, hq.cnt, hp[(size_t)i * 64]);
-                    heap_recompute_top(hq);
-                    if (ch.depth < min_progress) kbest.hi &= 0xFFFFFFull;
+                    for (uint32_t i = hq.cnt / 2; i-- > 0;) hq.sift_down(i, hq.ld(i));
+                    hq.recompute_top();
+                    if (kd.depth < min_progress) kbest.hi &= 0xFFFFFFull;
                 }
             }
             if (key_less(kbest, hq.top)) {
-                cur = child_as_cur(ch, best, next_idx + best);
+                if (best == 0) cur = kid_as_cur<0>(kd, next_idx);
+                else if (best == 1) cur = kid_as_cur<1>(kd, next_idx);
+                else if (best == 2) cur = kid_as_cur<2>(kd, next_idx);
+                else cur = kid_as_cur<3>(kd, next_idx);
                 cur.total = kbest.hi >> 24;
             } else {
-                store_child(main_pool, ch, best, next_idx + best);
-                heap_push(hq, kbest);
-                Key t = hq.top;
-                heap_pop(hq);
-                cur = cur_from_pool(main_pool, t);
+                if (best == 0) kid_store<0>(main_pool, kd, next_idx);
+                else if (best == 1) kid_store<1>(main_pool, kd, next_idx);
+                else if (best == 2) kid_store<2>(main_pool, kd, next_idx);
+                else kid_store<3>(main_pool, kd, next_idx);
+                hq.push(kbest);
+                const Key t = hq.top;
+                hq.pop();
+                cur = cur_from_rec(load_rec(main_pool + (t.lo >> 24)), t.hi >> 24, t.lo >> 24);
             }
-            next_idx += ch.n;
-            if (__any(hq.ovf)) { st = ST_OVERFLOW; break; }
+            next_idx += kd.n;
+            if (__any(hq.ovf)) { st = ST_OVERFLOW_MAIN; break; }
         }
 
         if (st == ST_OK) {
@@ -605,8 +734,7 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
             uint8_t* o1 = B.h1 + d.var_off;
             uint8_t* o2 = B.h2 + d.var_off;
             uint64_t phased = 0, snvs = 0, skipped = 0;
-            const uint32_t last_ck = (N - 1) >> 5;
-            uint32_t chunk = last_ck;
+            uint32_t chunk = (N - 1) >> 5;
             Win w = cur.w0, wn = cur.w1;
             uint32_t slot_next = cur.anc2;
             bool have_wn = true;
@@ -619,11 +747,9 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
                     o1[pos] = nvb ? 2 : (uint8_t)b1;
                     o2[pos] = nvb ? 2 : (uint8_t)b2;
                 }
-                const uint64_t m_in = __ballot(inb);
                 const uint64_t m_het = __ballot(inb && !nvb && b1 != b2);
                 const uint64_t m_skip = __ballot(inb && nvb);
-                const uint64_t m_snv = __ballot(inb && (cx.vflags[inb ? pos : 0] & HP_VAR_SNV));
-                (void)m_in;
+                const uint64_t m_snv = __ballot(inb && (vflags[inb ? pos : 0] & HP_VAR_SNV));
                 phased += __popcll(m_het);
                 skipped += __popcll(m_skip);
                 snvs += __popcll(m_het & m_snv);
@@ -634,7 +760,7 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
                     have_wn = false;
                 } else {
                     if (slot_next == NONE32) { st = ST_INVARIANT; break; }
-                    NodeRec a = load_rec(main_pool + slot_next);
+                    const NodeRec a = load_rec(main_pool + slot_next);
                     w = a.w0;
                     wn = a.w1;
                     slot_next = a.anc2;
@@ -652,22 +778,23 @@ DEVINL int32_t solve_block(const BatchDev& B, uint32_t blk, uint32_t slot, Key* 
         }
     }
 
-    const uint64_t evals = wave_sum_u64(cx.evals), cells = wave_sum_u64(cx.cells);
+    const uint64_t m_evals = wave_sum_u64(cx.evals), m_cells = wave_sum_u64(cx.cells);
     if (lane == 0) {
         B.stats[blk] = stats;
         hp_work_counters c{};
-        c.sub_pops = wc.sub_pops; c.main_pops = wc.main_pops; c.evals = evals; c.cells = cells; c.nodes_created = wc.nodes;
+        c.sub_pops = wc.sub_pops;
+        if (st == ST_OVERFLOW_MAIN) {  // keep only the heuristic phase; the main search will be redone
+            c.evals = h_evals; c.cells = h_cells; c.nodes_created = h_nodes;
+        } else {
+            c.main_pops = wc.main_pops; c.evals = h_evals + m_evals; c.cells = h_cells + m_cells; c.nodes_created = wc.nodes;
+        }
         B.counters[blk] = c;
         B.status[blk] = st;
     }
-    return st;
 }
 
 template <bool SUB_LDS>
 __global__ void __launch_bounds__(64) hp_astar_kernel(BatchDev B) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* ring = reinterpret_cast<uint64_t*>(smem);            // 64 x u64
-    Key* lds_heap = reinterpret_cast<Key*>(smem + 64 * sizeof(uint64_t));
     const uint32_t slot = blockIdx.x;
     const uint32_t G = gridDim.x;
     // Static "snake" assignment over the LPT-sorted work list: workgroup w takes ranks w, 2G-1-w, 2G+w, ...
@@ -676,11 +803,10 @@ __global__ void __launch_bounds__(64) hp_astar_kernel(BatchDev B) {
         const uint32_t base = round * G;
         if (base >= B.n_items) break;
         const uint32_t i = base + ((round & 1u) ? (G - 1u - slot) : slot);
-        if (i < B.n_items) solve_block<SUB_LDS>(B, B.order[i], slot, lds_heap, ring);
+        if (i < B.n_items) solve_block<SUB_LDS>(B, B.order[i], slot);
     }
 }
 
-// explicit instantiations used by the host code
 template __global__ void hp_astar_kernel<true>(BatchDev);
 template __global__ void hp_astar_kernel<false>(BatchDev);
 

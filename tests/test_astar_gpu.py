@@ -110,13 +110,27 @@ def test_high_coverage_batches():
     check_batch([blk])
 
 
-@pytest.mark.parametrize("minq,qinc,e", [(20, 1, 0.30), (50, 3, 0.25), (10, 0, 0.35)])
+@pytest.mark.parametrize("minq,qinc,e", [(20, 1, 0.30), (50, 3, 0.25), (10, 1, 0.35), (100, 0, 0.30)])
 def test_pruning_dynamics(minq, qinc, e):
     """Small queues + noisy data: threshold reset at the first prune, min_progress, full prune
     (astar_phaser.rs:497-585)."""
     blk, _ = synth_block(150, 30, 10, e, 0.02, 11)
     got = check_block(blk, min_queue_size=minq, queue_increment=qinc)
     assert got.statistics.pruned_solutions > 0
+
+
+def test_reference_assert_is_reported():
+    """min_queue_size=10, queue_increment=0 gives the sub-solver a single visit, so the reference's
+    `assert!(solve_size >= max_clip_size.min(2))` (astar_phaser.rs:268) fires; the ABI reports it as
+    HP_ERR_INVARIANT (-3) instead of returning a wrong answer — and the oracle agrees."""
+    from hiphase_amd._ffi import HpError
+    blk, _ = synth_block(150, 30, 10, 0.35, 0.02, 11)
+    with pytest.raises(HpError) as e1:
+        astar_solver(0, blk, min_queue_size=10, queue_increment=0)
+    assert e1.value.code == -3
+    with pytest.raises(HpError) as e2:
+        oracle_solve(blk, min_queue_size=10, queue_increment=0)
+    assert e2.value.code == -3
 
 
 def test_noisy_default_params_overflow_retry():
