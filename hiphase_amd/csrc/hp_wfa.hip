@@ -1,0 +1,340 @@
+// hp_wfa.hip — host side of the graph-WFA allele assignment: builds each read's variant graph
+// (reference src/wfa_graph.rs:119-284 `from_reference_variants_with_hom`, restated over sequence SPANS
+// instead of copies), lays out the per-node diagonal bands, launches hp_wfa_kernel and maps the
+// traversed nodes to per-het AlleleTypes (reference src/read_parsing.rs:790-800).
+//
+// Boundary: hp_wfa_assign_batch replaces the two calls at reference src/read_parsing.rs:769-780.
+#include "hp_wfa_kernel.hip"
+
+#include <algorithm>
+#include <array>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <set>
+#include <vector>
+
+namespace hp {
+namespace {
+
+struct HostNode {
+    uint32_t seq_off, seq_len;
+    std::vector<uint32_t> parents;   // sorted (wfa_graph.rs:36)
+    std::vector<uint32_t> children;  // creation order (wfa_graph.rs:321-323)
+    int64_t emin = 0, emax = 0;      // shortest / longest path length from the root to this node's first base
+};
+
+struct HostJob {
+    std::vector<HostNode> nodes;
+    std::vector<uint8_t> seq;                 // [ref slice][alt alleles...][read][pad]
+    uint32_t read_off = 0, read_len = 0;
+    // node_to_alleles (wfa_graph.rs:19): (node, het index, allele)
+    std::vector<std::array<uint32_t, 3>> tags;
+};
+
+// WFAGraph::add_node (wfa_graph.rs:298-331)
+int add_node(HostJob& g, uint32_t seq_off, uint32_t seq_len, std::vector<uint32_t> parents) {
+    const uint32_t idx = (uint32_t)g.nodes.size();
+    if (idx == 0) { if (!parents.empty()) return -1; }
+    else {
+        if (parents.empty()) return -1;
+        for (uint32_t p : parents) if (idx <= p) return -1;
+    }
+    for (uint32_t p : parents) g.nodes[p].children.push_back(idx);
+    std::sort(parents.begin(), parents.end());
+    HostNode n;
+    n.seq_off = seq_off;
+    n.seq_len = seq_len;
+    n.parents = std::move(parents);
+    g.nodes.push_back(std::move(n));
+    return (int)idx;
+}
+
+// from_reference_variants_with_hom (wfa_graph.rs:119-284). Reference nodes are spans of the copied
+// reference slice; allele nodes are spans of the appended allele bytes.
+int build_graph(const hp_wfa_job* job, HostJob& g) {
+    if (job->ref_end < job->ref_start || job->ref_start < job->ref_base) { set_error("bad reference window"); return HP_ERR_ARG; }
+    const size_t ref_len = (size_t)(job->ref_end - job->ref_start);
+    g.seq.assign(job->reference + (job->ref_start - job->ref_base), job->reference + (job->ref_start - job->ref_base) + ref_len);
+    auto ref_span = [&](uint64_t a) { return (uint32_t)(a - job->ref_start); };
+    const uint64_t ref_start = job->ref_start, ref_end = job->ref_end;
+    uint64_t previous_end = ref_start;
+    std::vector<uint32_t> reference_reconnect;
+    std::vector<std::pair<uint32_t, uint32_t>> reference_alleles;  // (het index, 0)
+    std::set<std::pair<uint64_t, uint32_t>> reconnect_queue;       // (reconnect position, alt node); ties in any order
+
+    struct VarRef { const hp_wfa_variant* v; int64_t index; };
+    std::vector<VarRef> all;
+    all.reserve((size_t)job->n_hets + job->n_homs);
+    for (uint32_t i = 0; i < job->n_hets; ++i) all.push_back({&job->hets[i], (int64_t)i});
+    for (uint32_t i = 0; i < job->n_homs; ++i) all.push_back({&job->homs[i], -1});
+    std::stable_sort(all.begin(), all.end(), [](const VarRef& a, const VarRef& b) { return a.v->position < b.v->position; });
+
+    auto flush_ref_alleles = [&](int node) {
+        for (auto& ra : reference_alleles) g.tags.push_back({(uint32_t)node, ra.first, ra.second});
+        reference_alleles.clear();
+    };
+    auto drain_one = [&]() -> bool {  // wfa_graph.rs:168-189 and :256-272
+        auto it = reconnect_queue.begin();
+        const uint64_t alt_reconnect = it->first;
+        const uint32_t alt_index = it->second;
+        reconnect_queue.erase(it);
+        if (!(alt_reconnect > previous_end)) return false;  // assert!(alt_reconnect > previous_end)
+        int ri = add_node(g, ref_span(previous_end), (uint32_t)(alt_reconnect - previous_end), reference_reconnect);
+        if (ri < 0) return false;
+        flush_ref_alleles(ri);
+        previous_end = alt_reconnect;
+        reference_reconnect = {(uint32_t)ri, alt_index};
+        while (!reconnect_queue.empty() && reconnect_queue.begin()->first == alt_reconnect) {
+            reference_reconnect.push_back(reconnect_queue.begin()->second);
+            reconnect_queue.erase(reconnect_queue.begin());
+        }
+        return true;
+    };
+    auto add_allele = [&](const uint8_t* bytes, uint32_t len) -> int {
+        const uint32_t off = (uint32_t)g.seq.size();
+        g.seq.insert(g.seq.end(), bytes, bytes + len);
+        return add_node(g, off, len, reference_reconnect);
+    };
+
+    for (auto& vr : all) {
+        const hp_wfa_variant* v = vr.v;
+        if (v->flags & 1u) continue;                                     // is_ignored (wfa_graph.rs:147-150)
+        if (v->position < (int64_t)ref_start) continue;                  // :155-159
+        const uint64_t pos = (uint64_t)v->position;
+        if (pos + v->ref_len > ref_end) continue;                        // :160-164
+        while (!reconnect_queue.empty() && reconnect_queue.begin()->first <= pos)
+            if (!drain_one()) { set_error("graph construction assert (alt_reconnect > previous_end)"); return HP_ERR_INVARIANT; }
+        if (previous_end < pos || g.nodes.empty()) {                     // :196-209
+            int ri = add_node(g, ref_span(previous_end), (uint32_t)(pos - previous_end), reference_reconnect);
+            if (ri < 0) { set_error("graph construction: add_node failed"); return HP_ERR_INVARIANT; }
+            flush_ref_alleles(ri);
+            reference_reconnect = {(uint32_t)ri};
+            previous_end = pos;
+        } else if (previous_end != pos) {
+            set_error("graph construction assert (previous_end == variant_pos)");
+            return HP_ERR_INVARIANT;
+        }
+        if (v->flags & 2u) {                                             // allele0 is itself an ALT (:217-231)
+            int ai = add_allele(v->allele0, v->allele0_len);
+            if (ai < 0) { set_error("graph construction: add_node failed"); return HP_ERR_INVARIANT; }
+            if (vr.index >= 0) g.tags.push_back({(uint32_t)ai, (uint32_t)vr.index, 0u});
+            reconnect_queue.insert({pos + v->ref_len, (uint32_t)ai});
+        } else if (vr.index >= 0) {
+            reference_alleles.push_back({(uint32_t)vr.index, 0u});       // tags the NEXT reference node (:233-237)
+        }
+        int ai = add_allele(v->allele1, v->allele1_len);                  // :240-251
+        if (ai < 0) { set_error("graph construction: add_node failed"); return HP_ERR_INVARIANT; }
+        if (vr.index >= 0) g.tags.push_back({(uint32_t)ai, (uint32_t)vr.index, 1u});
+        reconnect_queue.insert({pos + v->ref_len, (uint32_t)ai});
+    }
+    while (!reconnect_queue.empty())
+        if (!drain_one()) { set_error("graph construction assert (alt_reconnect > previous_end)"); return HP_ERR_INVARIANT; }
+    if (!(previous_end <= ref_end)) { set_error("graph construction assert (previous_end <= ref_end)"); return HP_ERR_INVARIANT; }
+    if (add_node(g, ref_span(previous_end), (uint32_t)(ref_end - previous_end), reference_reconnect) < 0) {
+        set_error("graph construction: add_node failed"); return HP_ERR_INVARIANT;
+    }
+    if (!reference_alleles.empty()) { set_error("graph construction assert (dangling reference alleles)"); return HP_ERR_INVARIANT; }
+
+    g.read_off = (uint32_t)g.seq.size();
+    g.read_len = job->read_len;
+    g.seq.insert(g.seq.end(), job->read, job->read + job->read_len);
+    g.seq.resize(g.seq.size() + 16, 0);  // 8-byte compares may read past the last base
+    while (g.seq.size() & 15) g.seq.push_back(0);
+    // path-length range to every node (band placement)
+    for (size_t n = 1; n < g.nodes.size(); ++n) {
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (uint32_t q : g.nodes[n].parents) {
+            lo = std::min(lo, g.nodes[q].emin + (int64_t)g.nodes[q].seq_len);
+            hi = std::max(hi, g.nodes[q].emax + (int64_t)g.nodes[q].seq_len);
+        }
+        g.nodes[n].emin = lo;
+        g.nodes[n].emax = hi;
+    }
+    return HP_OK;
+}
+
+struct WfaPack {
+    std::vector<WfaJobDesc> jobs;
+    std::vector<WfaNode> nodes;
+    std::vector<WfaEdge> edges;
+    std::vector<uint8_t> seq;
+    uint64_t out_set_words = 0;
+    uint64_t max_scratch = 0;
+    uint32_t max_nodes = 0;
+};
+
+// lays the jobs `ids` out for edit-distance capacity `band`
+int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, uint32_t band, WfaPack& pk) {
+    for (uint32_t id : ids) {
+        const HostJob& g = hj[id];
+        WfaJobDesc jd{};
+        jd.node_off = pk.nodes.size();
+        jd.edge_off = pk.edges.size();
+        jd.seq_off = pk.seq.size();
+        jd.n_nodes = (uint32_t)g.nodes.size();
+        jd.set_words = (jd.n_nodes + 31) / 32;
+        jd.read_off = g.read_off;
+        jd.read_len = g.read_len;
+        jd.band = band;
+        jd.out_set_off = pk.out_set_words;
+        pk.out_set_words += jd.set_words;
+        if (jd.n_nodes > WFA_MAX_NODES) { set_error("read overlaps a graph of %u nodes (> %u supported)", jd.n_nodes, WFA_MAX_NODES); return HP_ERR_UNSUPPORTED; }
+        uint64_t entry_off = 0;
+        for (uint32_t n = 0; n < jd.n_nodes; ++n) {
+            const HostNode& hn = g.nodes[n];
+            WfaNode dn{};
+            dn.seq_off = hn.seq_off;
+            dn.seq_len = hn.seq_len;
+            dn.child_off = (uint32_t)(pk.edges.size() - jd.edge_off);
+            dn.n_children = (uint16_t)hn.children.size();
+            const uint32_t np = n == 0 ? 1u : (uint32_t)hn.parents.size();
+            if (np > 32 || hn.children.size() > 65535) { set_error("graph node with %u parents (> 32 supported)", np); return HP_ERR_UNSUPPORTED; }
+            dn.n_parents = (uint16_t)np;
+            const int64_t width = (hn.emax - hn.emin) + 2 * (int64_t)band + 3;
+            if (width > 65535) { set_error("diagonal band of %lld exceeds 65535", (long long)width); return HP_ERR_UNSUPPORTED; }
+            dn.dbase = (int32_t)(hn.emin - (int64_t)band - 1);
+            dn.width = (uint32_t)width;
+            dn.entry_stride = 5 + 2 * jd.set_words + np * jd.set_words;
+            dn.entry_off = (uint32_t)entry_off;
+            entry_off += (uint64_t)dn.width * dn.entry_stride;
+            if (entry_off > 0xFFFFFFF0ull) { set_error("WFA scratch of one read exceeds 16 GiB"); return HP_ERR_UNSUPPORTED; }
+            for (uint32_t c : hn.children) {
+                const auto& cp = g.nodes[c].parents;
+                const uint32_t ord = (uint32_t)(std::lower_bound(cp.begin(), cp.end(), n) - cp.begin());
+                pk.edges.push_back(WfaEdge{c, ord});
+            }
+            pk.nodes.push_back(dn);
+        }
+        jd.scratch_dwords = (uint32_t)entry_off;
+        pk.max_scratch = std::max<uint64_t>(pk.max_scratch, entry_off);
+        pk.max_nodes = std::max(pk.max_nodes, jd.n_nodes);
+        pk.seq.insert(pk.seq.end(), g.seq.begin(), g.seq.end());
+        pk.jobs.push_back(jd);
+    }
+    return HP_OK;
+}
+
+template <class T> int up(DevBuf& buf, const std::vector<T>& v) {
+    int rc = buf.alloc(v.size() * sizeof(T));
+    if (rc != HP_OK) return rc;
+    if (!v.empty()) HP_HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return HP_OK;
+}
+
+// one launch over `ids` with capacity `band`; fills status/score/sets for those jobs
+int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, uint32_t band, uint64_t prune, uint64_t max_ed,
+             int n_cu, std::vector<int32_t>& status, std::vector<uint64_t>& score, std::vector<std::vector<uint32_t>>& sets) {
+    WfaPack pk;
+    int rc = pack_jobs(hj, ids, band, pk);
+    if (rc != HP_OK) return rc;
+    const size_t n = ids.size();
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pk.jobs[a].read_len > pk.jobs[b].read_len; });
+    DevBuf d_jobs, d_order, d_nodes, d_edges, d_seq, d_sets, d_score, d_status, d_scratch;
+    if ((rc = up(d_jobs, pk.jobs)) || (rc = up(d_order, order)) || (rc = up(d_nodes, pk.nodes)) || (rc = up(d_edges, pk.edges)) ||
+        (rc = up(d_seq, pk.seq)))
+        return rc;
+    if ((rc = d_sets.alloc(pk.out_set_words * 4 + 16)) || (rc = d_score.alloc(n * 8)) || (rc = d_status.alloc(n * 4))) return rc;
+    std::vector<int32_t> st0(n, WFA_ST_PENDING);
+    HP_HIP_CHECK(hipMemcpy(d_status.p, st0.data(), n * 4, hipMemcpyHostToDevice));
+    const size_t lds = (size_t)pk.max_nodes * WFA_NODE_STATE_BYTES;
+    uint32_t per_cu = (uint32_t)std::min<size_t>(12, (160 * 1024) / std::max<size_t>(lds, 1024));
+    if (per_cu == 0) per_cu = 1;
+    size_t free_b = 0, total_b = 0;
+    HP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t stride = (pk.max_scratch + 63) & ~63ull;
+    const size_t per_slot = (size_t)stride * 4;
+    uint32_t slots = (uint32_t)std::min<size_t>({n, (size_t)n_cu * per_cu, std::max<size_t>(1, (free_b / 2) / std::max<size_t>(per_slot, 1))});
+    if (slots == 0) slots = 1;
+    if ((rc = d_scratch.alloc((size_t)slots * per_slot)) != HP_OK) return rc;
+    HP_HIP_CHECK(hipMemset(d_scratch.p, 0, (size_t)slots * per_slot));
+    WfaBatchDev B{};
+    B.jobs = d_jobs.as<WfaJobDesc>(); B.order = d_order.as<uint32_t>(); B.n_items = (uint32_t)n;
+    B.nodes = d_nodes.as<WfaNode>(); B.edges = d_edges.as<WfaEdge>(); B.seq = d_seq.as<uint8_t>();
+    B.out_sets = d_sets.as<uint32_t>(); B.out_score = d_score.as<uint64_t>(); B.status = d_status.as<int32_t>();
+    B.scratch = d_scratch.as<uint32_t>(); B.scratch_stride = stride; B.prune_distance = prune; B.max_ed = max_ed;
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa launch jobs=%zu band=%u slots=%u lds=%zu scratch/slot=%zu B\n", n, band, slots, lds, per_slot); fflush(stderr); }
+    hipLaunchKernelGGL(hp_wfa_kernel, dim3(slots), dim3(64), lds, 0, B);
+    HP_HIP_CHECK(hipGetLastError());
+    HP_HIP_CHECK(hipDeviceSynchronize());
+    std::vector<int32_t> st(n);
+    std::vector<uint64_t> sc(n);
+    std::vector<uint32_t> all_sets(pk.out_set_words + 4);
+    HP_HIP_CHECK(hipMemcpy(st.data(), d_status.p, n * 4, hipMemcpyDeviceToHost));
+    HP_HIP_CHECK(hipMemcpy(sc.data(), d_score.p, n * 8, hipMemcpyDeviceToHost));
+    HP_HIP_CHECK(hipMemcpy(all_sets.data(), d_sets.p, pk.out_set_words * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+        status[ids[i]] = st[i];
+        score[ids[i]] = sc[i];
+        sets[ids[i]].assign(all_sets.begin() + pk.jobs[i].out_set_off, all_sets.begin() + pk.jobs[i].out_set_off + pk.jobs[i].set_words);
+    }
+    return HP_OK;
+}
+
+}  // namespace
+}  // namespace hp
+
+using namespace hp;
+
+extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
+                                   hp_wfa_result* out, uint8_t* const* alleles, int device_id) {
+    if (n == 0) return HP_OK;
+    if (!jobs || !out) { set_error("null argument"); return HP_ERR_ARG; }
+    if (n > 0x7FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
+    if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
+    std::vector<HostJob> hj(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (!jobs[i].reference || (!jobs[i].read && jobs[i].read_len)) { set_error("job %zu: null sequence", i); return HP_ERR_ARG; }
+        int rc = build_graph(&jobs[i], hj[i]);
+        if (rc != HP_OK) return rc;
+    }
+    // host-side work is done; from here on a GPU is mandatory (no CPU fallback)
+    if (device_id < 0) device_id = hp_default_device();
+    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
+    int n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) n_cu = prop.multiProcessorCount;
+
+    std::vector<int32_t> status(n, WFA_ST_PENDING);
+    std::vector<uint64_t> score(n, 0);
+    std::vector<std::vector<uint32_t>> sets(n);
+    std::vector<uint32_t> ids(n);
+    std::iota(ids.begin(), ids.end(), 0u);
+    // pass 1 with a narrow band (most reads finish within a few dozen edits); the rest re-run at full width
+    const char* benv = std::getenv("HP_WFA_BAND");
+    uint32_t band = (uint32_t)std::min<uint64_t>(max_ed, benv ? (uint64_t)std::atoi(benv) : 96);
+    for (;;) {
+        int rc = run_pass(hj, ids, band, prune_distance, max_ed, n_cu, status, score, sets);
+        if (rc != HP_OK) return rc;
+        std::vector<uint32_t> again;
+        for (uint32_t id : ids) if (status[id] == WFA_ST_NEED_BAND) again.push_back(id);
+        if (again.empty()) break;
+        if (band >= max_ed) { set_error("WFA band overflow at full width (internal)"); return HP_ERR_INVARIANT; }
+        band = (uint32_t)std::min<uint64_t>(max_ed, (uint64_t)band * 6);
+        ids.swap(again);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (status[i] != WFA_ST_OK && status[i] != WFA_ST_MAX_ED) { set_error("job %zu: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
+        out[i].status = status[i] == WFA_ST_OK ? HP_OK : HP_WFA_MAX_ED;
+        out[i].n_nodes = (uint32_t)hj[i].nodes.size();
+        out[i].score = score[i];
+        if (alleles && alleles[i]) {
+            uint8_t* a = alleles[i];
+            for (uint32_t k = 0; k < jobs[i].n_hets; ++k) a[k] = HP_ALLELE_NOOVERLAP;
+            if (status[i] == WFA_ST_OK) {
+                // read_parsing.rs:790-800: traversed nodes ascending; first assignment wins, a different one -> Ambiguous
+                std::vector<std::array<uint32_t, 3>> tags = hj[i].tags;
+                std::stable_sort(tags.begin(), tags.end(), [](const std::array<uint32_t, 3>& x, const std::array<uint32_t, 3>& y) { return x[0] < y[0]; });
+                for (auto& t : tags) {
+                    if (!((sets[i][t[0] >> 5] >> (t[0] & 31)) & 1u)) continue;
+                    if (a[t[1]] == HP_ALLELE_NOOVERLAP) a[t[1]] = (uint8_t)t[2];
+                    else if (a[t[1]] != (uint8_t)t[2]) a[t[1]] = HP_ALLELE_AMBIGUOUS;
+                }
+            }
+        }
+    }
+    return HP_OK;
+}

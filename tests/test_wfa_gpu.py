@@ -1,0 +1,150 @@
+"""Parity of the HIP graph-WFA allele assignment and the HIP Levenshtein kernel (through the C ABI) with
+the CPU oracle and the reference's own known-answer vectors (wfa_graph.rs:842-1208, sequence_alignment.rs:45-76,
+variants.rs:838-845)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from hiphase_amd import _ffi
+from hiphase_amd.sequence_alignment import closest_allele_clip, edit_distance_batch
+from hiphase_amd.wfa_graph import make_jobs, wfa_assign_batch
+from oracle_ffi import oracle
+from wfa_util import spec_from_golden, synth_wfa_job, _Rng
+
+pytestmark = pytest.mark.gpu
+G = load_golden("wfa_graph.json")
+
+
+def oracle_assign(spec, prune, max_ed):
+    d = oracle()
+    jobs, keep = make_jobs([spec])
+    out = _ffi.WfaResult()
+    al = np.full(max(1, len(spec.hets)), 3, np.uint8)
+    rc = d.hpo_wfa_assign(C.byref(jobs[0]), (2 ** 64 - 1) if prune in (0, None) else prune, max_ed, C.byref(out), al.ctypes.data)
+    assert rc == 0
+    return out.status, out.score, out.n_nodes, al[:len(spec.hets)]
+
+
+def check_specs(specs, prune=500, max_ed=500):
+    got = wfa_assign_batch(specs, prune_distance=prune, max_edit_distance=max_ed)
+    for i, (spec, g) in enumerate(zip(specs, got)):
+        st, score, nn, al = oracle_assign(spec, prune, max_ed)
+        assert (g[0], g[1], g[2]) == (st, score, nn), (i, g[:3], (st, score, nn))
+        assert np.array_equal(g[3], al), (i, g[3].tolist(), al.tolist())
+    return got
+
+
+@pytest.mark.parametrize("case", [c for c in G["variant_built"] if c["queries"]], ids=lambda c: c["name"])
+def test_golden_variant_graphs(case):
+    """Exact (score, traversed nodes) of the reference's tests, observed through the allele mapping of
+    read_parsing.rs:790-800 applied to the expected node sets and node_to_alleles table."""
+    specs = [spec_from_golden(case, read=bytes(q["seq"])) for q in case["queries"]]
+    got = wfa_assign_batch(specs, prune_distance=0, max_edit_distance=1000)
+    n_hets = len(case["variants"])
+    for q, g in zip(case["queries"], got):
+        exp = [3] * n_hets
+        for node in q["nodes"]:
+            for vi, a in case["node_to_alleles"][str(node)]:
+                if exp[vi] == 3:
+                    exp[vi] = a
+                elif exp[vi] != a:
+                    exp[vi] = 2
+        assert g[0] == 0 and g[1] == q["score"] and g[2] == case["num_nodes"], (case["name"], q, g)
+        assert g[3].tolist() == exp, (case["name"], q, g[3].tolist(), exp)
+    check_specs(specs, prune=0, max_ed=1000)
+
+
+def test_golden_graph_shapes():
+    for name in ("test_variant_before_start", "test_span_ref_end"):
+        case = next(c for c in G["variant_built"] if c["name"] == name)
+        spec = spec_from_golden(case, read=case["reference"][case["ref_start"]:case["ref_end"]].encode())
+        (st, score, nn, al), = wfa_assign_batch([spec], prune_distance=0, max_edit_distance=1000)
+        assert (st, score, nn) == (0, 0, case["num_nodes"])
+        check_specs([spec], prune=0, max_ed=1000)
+
+
+def test_synthetic_batch_default_params():
+    specs = [synth_wfa_job(seed, ref_len=3000 + 37 * seed, n_vars=6 + seed % 9, noise=0.003 + 0.001 * (seed % 5))[0]
+             for seed in range(1, 49)]
+    check_specs(specs)
+
+
+def test_synthetic_long_reads():
+    specs = [synth_wfa_job(100 + s, ref_len=17000, n_vars=24, n_homs=8, noise=0.004)[0] for s in range(6)]
+    check_specs(specs)
+
+
+def test_noisy_reads_and_band_retry(monkeypatch):
+    """Reads whose edit distance exceeds the first-pass band are re-run with a wider one."""
+    monkeypatch.setenv("HP_WFA_BAND", "6")
+    specs = [synth_wfa_job(200 + s, ref_len=2500, n_vars=8, noise=0.02)[0] for s in range(12)]
+    got = check_specs(specs)
+    assert max(g[1] for g in got) > 6
+
+
+def test_max_edit_distance_fallback_status():
+    """Err(MaxEditDistance) (wfa_graph.rs:645-648): status 1, score == max_ed, alleles all NoOverlap; the largest
+    returnable score equals max_edit_distance."""
+    spec, _ = synth_wfa_job(300, ref_len=2000, n_vars=6, noise=0.05)
+    full = check_specs([spec], max_ed=500)[0]
+    assert full[0] == 0 and full[1] > 10
+    capped = check_specs([spec], max_ed=full[1] - 1)[0]
+    assert capped[0] == 1 and capped[1] == full[1] - 1 and (capped[3] == 3).all()
+    exact = check_specs([spec], max_ed=full[1])[0]
+    assert exact[0] == 0 and exact[1] == full[1]
+
+
+@pytest.mark.parametrize("prune", [0, 30, 150])
+def test_prune_distance(prune):
+    specs = [synth_wfa_job(400 + s, ref_len=4000, n_vars=10, noise=0.01)[0] for s in range(8)]
+    check_specs(specs, prune=prune)
+
+
+def test_edge_reads():
+    spec, _ = synth_wfa_job(500, ref_len=1200, n_vars=5)
+    from dataclasses import replace
+    specs = [replace(spec, read=b""), replace(spec, read=b"ACGT"), replace(spec, read=spec.read[:300]),
+             replace(spec, read=b"N" * 50)]
+    check_specs(specs, prune=0, max_ed=2000)
+
+
+def test_ignored_and_multiallelic():
+    spec, _ = synth_wfa_job(600, ref_len=3000, n_vars=14, multiallelic=0.6)
+    spec.hets[2].is_ignored = True
+    check_specs([spec])
+
+
+# ---- Levenshtein -------------------------------------------------------------------------------------------
+
+def test_edit_distance_golden():
+    g = load_golden("sequence_alignment.json")
+    pairs = [(bytes(a), bytes(b)) for a, b, _ in g["edit_distance"]]
+    assert edit_distance_batch(pairs) == [e for _, _, e in g["edit_distance"]]
+    ca = g["closest_allele"]
+    for obs, exp_allele, dmin, dother in ca["cases"]:
+        assert closest_allele_clip(obs.encode(), ca["allele0"].encode(), ca["allele1"].encode()) == (exp_allele, dmin, dother)
+    # clipping = comparing against the allele without part of its padding (variants.rs:624-628)
+    assert closest_allele_clip(b"AGGC", ca["allele0"].encode(), ca["allele1"].encode(), head_clip=2) == (0, 0, 2)
+
+
+def test_edit_distance_random_vs_oracle():
+    r = _Rng(7)
+    d = oracle()
+    pairs = []
+    for i in range(200):
+        la, lb = r.randint(0, 90), r.randint(0, 90)
+        a = r.dna(la)
+        b = bytearray(a[:lb]) if r.u01() < 0.5 else bytearray(r.dna(lb))
+        for _ in range(r.randint(0, 6)):
+            if b:
+                b[r.randint(0, len(b) - 1)] = b"ACGT"[r.next() & 3]
+        pairs.append((a, bytes(b)))
+    pairs += [(r.dna(3000), r.dna(2500)), (r.dna(130), r.dna(4000)), (b"", r.dna(70)), (r.dna(64), r.dna(64)), (r.dna(65), r.dna(63))]
+    got = edit_distance_batch(pairs)
+    for (a, b), g in zip(pairs, got):
+        A = np.frombuffer(a, np.uint8) if a else np.zeros(1, np.uint8)
+        Bv = np.frombuffer(b, np.uint8) if b else np.zeros(1, np.uint8)
+        assert g == d.hpo_edit_distance(A.ctypes.data, len(a), Bv.ctypes.data, len(b)), (len(a), len(b))
