@@ -259,10 +259,11 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                 {
                     const bool nA = has && oA >= 0 && oA < omax, nB = has && oB >= 0 && oB < omax, nC = has && oC >= 0 && oC < omax;
                     const bool nD = has && inj_mask != 0 && omax > 0;
-                    if (__any(nA)) { const uint32_t g = (uint32_t)(omax - oA); tA = tA || (nA && match_run(nseq + (nA ? oA : 0), read + (nA ? (int64_t)d + oA : 0), nA ? g : 0) == g); }
-                    if (__any(nB)) { const uint32_t g = (uint32_t)(omax - oB); tB = tB || (nB && match_run(nseq + (nB ? oB : 0), read + (nB ? (int64_t)d + oB : 0), nB ? g : 0) == g); }
-                    if (__any(nC)) { const uint32_t g = (uint32_t)(omax - oC); tC = tC || (nC && match_run(nseq + (nC ? oC : 0), read + (nC ? (int64_t)d + oC : 0), nC ? g : 0) == g); }
-                    if (__any(nD)) { const uint32_t g = (uint32_t)omax; tD = tD || (nD && match_run(nseq, read + (nD ? (int64_t)d : 0), nD ? g : 0) == g); }
+                    // match_run is a wave-collective: every lane must call it (no short-circuit around the call)
+                    if (__any(nA)) { const uint32_t g = (uint32_t)(omax - oA); const uint32_t mr = match_run(nseq + (nA ? oA : 0), read + (nA ? (int64_t)d + oA : 0), nA ? g : 0u); tA = tA || (nA && mr == g); }
+                    if (__any(nB)) { const uint32_t g = (uint32_t)(omax - oB); const uint32_t mr = match_run(nseq + (nB ? oB : 0), read + (nB ? (int64_t)d + oB : 0), nB ? g : 0u); tB = tB || (nB && mr == g); }
+                    if (__any(nC)) { const uint32_t g = (uint32_t)(omax - oC); const uint32_t mr = match_run(nseq + (nC ? oC : 0), read + (nC ? (int64_t)d + oC : 0), nC ? g : 0u); tC = tC || (nC && mr == g); }
+                    if (__any(nD)) { const uint32_t g = (uint32_t)omax; const uint32_t mr = match_run(nseq, read + (nD ? (int64_t)d : 0), nD ? g : 0u); tD = tD || (nD && mr == g); }
                 }
                 // ---- decide (wfa_graph.rs:463-474) -----------------------------------------------------------
                 const uint64_t pos_end = has ? (uint64_t)((int64_t)d + (int64_t)E) : 0;

@@ -7,7 +7,6 @@
  *   - src/read_parsing.rs:769-780      WFAGraph::from_reference_variants_with_hom + edit_distance_with_pruning
  *                                                                                  -> hp_wfa_assign_batch
  *   - src/data_types/variants.rs:627   sequence_alignment::edit_distance           -> hp_edit_distance_batch
- *   - src/phaser.rs:546,614-623        get_solution_span_counts / haplotag_reads   -> hp_block_postprocess
  * INTEGRATION.md shows the `extern "C"` block + call-site patch a HiPhase maintainer would add.
  *
  * Conventions: plain pointers and sizes, caller owns every buffer, no pointer outlives a call
