@@ -134,6 +134,7 @@ EXPORTS = [
     "hp_default_device",
     "hp_last_error",
     "hp_version",
+    "hp_last_kernel_ms",
     "hp_synth_block_size",
     "hp_synth_block",
 ]
@@ -184,6 +185,7 @@ def lib():
     dll.hp_default_device.restype = C.c_int
     dll.hp_last_error.restype = C.c_char_p
     dll.hp_version.restype = C.c_char_p
+    dll.hp_last_kernel_ms.restype = C.c_double
     _lib = dll
     return dll
 

@@ -5,6 +5,7 @@
 
 namespace hp {
 static thread_local std::string g_err;
+thread_local double g_last_kernel_ms = 0.0;
 void set_error(const char* fmt, ...) {
     char buf[1024];
     va_list ap;
@@ -19,6 +20,7 @@ extern "C" {
 
 const char* hp_last_error(void) { return hp::g_err.c_str(); }
 const char* hp_version(void) { return "hiphase_gpu 0.1.0 (gfx950)"; }
+double hp_last_kernel_ms(void) { return hp::g_last_kernel_ms; }
 
 int hp_device_count(void) {
     int n = 0;

@@ -192,7 +192,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const size_t lds_bytes = LDS_HEAP_OFF + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup
-    uint32_t per_cu = (uint32_t)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
+    uint32_t per_cu = (uint32_t)std::min<size_t>(20, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
     if (per_cu == 0) per_cu = 1;
     const size_t per_slot = (size_t)cap_main * sizeof(NodeRec) + (size_t)prm.jcap_main * 64 * sizeof(Key) +
                             (size_t)prm.cap_sub * sizeof(NodeRec) + ((size_t)max_n + 1) * 4 +
@@ -354,6 +354,7 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
         retry.swap(again);
     }
     if (kernel_ms) *kernel_ms = ms_total;
+    g_last_kernel_ms = ms_total;
     for (size_t i = 0; i < status.size(); ++i) {
         if (status[i] == ST_INVARIANT) {
             set_error("block %zu: solver invariant violated (the reference would panic/assert, astar_phaser.rs:268,284,360,529,631)", i);

@@ -10,7 +10,8 @@
 
 namespace hp {
 
-void set_error(const char* fmt, ...);  // thread-local message returned by hp_last_error()
+void set_error(const char* fmt, ...);
+extern thread_local double g_last_kernel_ms;  // see hp_last_kernel_ms()  // thread-local message returned by hp_last_error()
 
 #define HP_HIP_CHECK(expr)                                                                         \
     do {                                                                                           \

@@ -147,9 +147,19 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
     B.pairs = d_pairs.as<EdPairDev>(); B.order = d_order.as<uint32_t>(); B.n_items = (uint32_t)n;
     B.bytes = d_bytes.as<uint8_t>(); B.out = d_out.as<uint64_t>(); B.scratch = d_scratch.as<uint32_t>();
     B.row_stride = row_stride; B.lds_row_cap = lds_row_cap;
+    hipEvent_t e0, e1;
+    HP_HIP_CHECK(hipEventCreate(&e0));
+    HP_HIP_CHECK(hipEventCreate(&e1));
+    HP_HIP_CHECK(hipEventRecord(e0, 0));
     hipLaunchKernelGGL(hp_edit_kernel, dim3(slots), dim3(64), (size_t)lds_row_cap * 2 * 4, 0, B);
     HP_HIP_CHECK(hipGetLastError());
+    HP_HIP_CHECK(hipEventRecord(e1, 0));
     HP_HIP_CHECK(hipDeviceSynchronize());
+    float kms = 0.f;
+    HP_HIP_CHECK(hipEventElapsedTime(&kms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    g_last_kernel_ms = kms;
     HP_HIP_CHECK(hipMemcpy(out, d_out.p, n * 8, hipMemcpyDeviceToHost));
     return HP_OK;
 }

@@ -10,6 +10,7 @@
 #include <array>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <memory>
 #include <numeric>
 #include <set>
@@ -155,6 +156,22 @@ int build_graph(const hp_wfa_job* job, HostJob& g) {
     return HP_OK;
 }
 
+
+// Per-(thread, device) scratch that survives across calls: the kernel leaves its band scratch zeroed, so the
+// (large) allocation + memset is paid once per worker thread, not once per block.
+struct WfaContext {
+    int device = -1;
+    DevBuf scratch;
+    bool dirty = true;     // needs a memset before use
+};
+thread_local WfaContext g_ctx;
+
+double now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 struct WfaPack {
     std::vector<WfaJobDesc> jobs;
     std::vector<WfaNode> nodes;
@@ -233,7 +250,9 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pk.jobs[a].read_len > pk.jobs[b].read_len; });
-    DevBuf d_jobs, d_order, d_nodes, d_edges, d_seq, d_sets, d_score, d_status, d_scratch;
+    const bool verbose = std::getenv("HP_DEBUG") != nullptr;
+    const double t_pack = now_ms();
+    DevBuf d_jobs, d_order, d_nodes, d_edges, d_seq, d_sets, d_score, d_status;
     if ((rc = up(d_jobs, pk.jobs)) || (rc = up(d_order, order)) || (rc = up(d_nodes, pk.nodes)) || (rc = up(d_edges, pk.edges)) ||
         (rc = up(d_seq, pk.seq)))
         return rc;
@@ -249,17 +268,38 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     const size_t per_slot = (size_t)stride * 4;
     uint32_t slots = (uint32_t)std::min<size_t>({n, (size_t)n_cu * per_cu, std::max<size_t>(1, (free_b / 2) / std::max<size_t>(per_slot, 1))});
     if (slots == 0) slots = 1;
-    if ((rc = d_scratch.alloc((size_t)slots * per_slot)) != HP_OK) return rc;
-    HP_HIP_CHECK(hipMemset(d_scratch.p, 0, (size_t)slots * per_slot));
+    int cur_dev = 0;
+    HP_HIP_CHECK(hipGetDevice(&cur_dev));
+    if (g_ctx.device != cur_dev) { g_ctx.scratch.release(); g_ctx.device = cur_dev; g_ctx.dirty = true; }
+    if (g_ctx.scratch.bytes < (size_t)slots * per_slot) {
+        if ((rc = g_ctx.scratch.alloc((size_t)slots * per_slot)) != HP_OK) return rc;
+        g_ctx.dirty = true;
+    }
+    if (g_ctx.dirty) {
+        HP_HIP_CHECK(hipMemset(g_ctx.scratch.p, 0, g_ctx.scratch.bytes));
+        g_ctx.dirty = false;
+    }
+    const double t_up = now_ms();
     WfaBatchDev B{};
     B.jobs = d_jobs.as<WfaJobDesc>(); B.order = d_order.as<uint32_t>(); B.n_items = (uint32_t)n;
     B.nodes = d_nodes.as<WfaNode>(); B.edges = d_edges.as<WfaEdge>(); B.seq = d_seq.as<uint8_t>();
     B.out_sets = d_sets.as<uint32_t>(); B.out_score = d_score.as<uint64_t>(); B.status = d_status.as<int32_t>();
-    B.scratch = d_scratch.as<uint32_t>(); B.scratch_stride = stride; B.prune_distance = prune; B.max_ed = max_ed;
+    B.scratch = g_ctx.scratch.as<uint32_t>(); B.scratch_stride = stride; B.prune_distance = prune; B.max_ed = max_ed;
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa launch jobs=%zu band=%u slots=%u lds=%zu scratch/slot=%zu B\n", n, band, slots, lds, per_slot); fflush(stderr); }
+    hipEvent_t e0, e1;
+    HP_HIP_CHECK(hipEventCreate(&e0));
+    HP_HIP_CHECK(hipEventCreate(&e1));
+    HP_HIP_CHECK(hipEventRecord(e0, 0));
     hipLaunchKernelGGL(hp_wfa_kernel, dim3(slots), dim3(64), lds, 0, B);
     HP_HIP_CHECK(hipGetLastError());
-    HP_HIP_CHECK(hipDeviceSynchronize());
+    HP_HIP_CHECK(hipEventRecord(e1, 0));
+    if (hipDeviceSynchronize() != hipSuccess) { g_ctx.dirty = true; set_error("WFA kernel failed"); return HP_ERR_HIP; }
+    float kms = 0.f;
+    HP_HIP_CHECK(hipEventElapsedTime(&kms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    g_last_kernel_ms += kms;
+    if (verbose) { fprintf(stderr, "[hp] wfa pack+upload %.2f ms, alloc/memset %.2f ms, kernel %.3f ms\n", t_up - t_pack, now_ms() - t_up - kms, kms); fflush(stderr); }
     std::vector<int32_t> st(n);
     std::vector<uint64_t> sc(n);
     std::vector<uint32_t> all_sets(pk.out_set_words + 4);
@@ -286,11 +326,14 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
     if (n > 0x7FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
     if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
     std::vector<HostJob> hj(n);
+    g_last_kernel_ms = 0.0;
+    const double t_build = now_ms();
     for (size_t i = 0; i < n; ++i) {
         if (!jobs[i].reference || (!jobs[i].read && jobs[i].read_len)) { set_error("job %zu: null sequence", i); return HP_ERR_ARG; }
         int rc = build_graph(&jobs[i], hj[i]);
         if (rc != HP_OK) return rc;
     }
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa graph build %.2f ms for %zu jobs\n", now_ms() - t_build, n); fflush(stderr); }
     // host-side work is done; from here on a GPU is mandatory (no CPU fallback)
     if (device_id < 0) device_id = hp_default_device();
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }

@@ -174,6 +174,9 @@ int         hp_device_count(void);
 int         hp_default_device(void);
 const char* hp_last_error(void);        /* thread-local, never NULL */
 const char* hp_version(void);
+/* HIP-event time (ms) of the kernel(s) launched by the last hp_wfa_assign_batch / hp_edit_distance_batch /
+ * hp_astar_solve* call made on this thread (diagnostics for bench/roofline reporting). */
+double      hp_last_kernel_ms(void);
 
 /* Deterministic synthetic block generator of SURVEY.md §8(d) (splitmix64). Fills caller-provided
  * buffers sized via hp_synth_block_size(). Used by tests and bench.py on both legs. */
