@@ -23,11 +23,11 @@ BYTES_PER_CELL = 1.75  # l x (2-bit allele + 8-bit qual) + 2 x
 
 def make_blocks(args, rank):
     from hiphase_amd import synth_block
+    from hiphase_amd.shard import rank_seeds
     blocks = []
     if args.workload == "c2":
-        for i in range(args.blocks):
-            blocks.append(synth_block(args.hets, args.coverage, args.span, args.error, 0.02,
-                                      20250509 + rank * 1000003 + i)[0])
+        for seed in rank_seeds(20250509, rank, args.blocks):   # disjoint seed ranges per rank (weak scaling)
+            blocks.append(synth_block(args.hets, args.coverage, args.span, args.error, 0.02, seed)[0])
     else:  # "wgs": heavy-tailed block sizes (docs/user_guide.md:257: median 15, mean ~220, max ~4000)
         import numpy as np
         rng = np.random.default_rng(12345 + rank)
@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["c2", "wgs"], default="c2")
-    ap.add_argument("--blocks", type=int, default=1024, help="blocks per GPU")
+    ap.add_argument("--blocks", type=int, default=4096, help="blocks per GPU (16 resident wavefronts per CU x 256 CUs)")
     ap.add_argument("--hets", type=int, default=5000)
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--span", type=int, default=20)
@@ -113,10 +113,8 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from hiphase_amd.shard import max_over_ranks
+        elapsed = max_over_ranks(dist, elapsed, device="cuda")   # timing only; no block data crosses ranks
 
     res, ctrs, _ = rb.results()
     cells_per_step = sum(c.cells for c in ctrs)

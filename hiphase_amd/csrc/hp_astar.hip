@@ -192,7 +192,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const size_t lds_bytes = LDS_HEAP_OFF + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup
-    uint32_t per_cu = (uint32_t)std::min<size_t>(20, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
+    uint32_t per_cu = (uint32_t)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
     if (per_cu == 0) per_cu = 1;
     const size_t per_slot = (size_t)cap_main * sizeof(NodeRec) + (size_t)prm.jcap_main * 64 * sizeof(Key) +
                             (size_t)prm.cap_sub * sizeof(NodeRec) + ((size_t)max_n + 1) * 4 +

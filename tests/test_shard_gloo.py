@@ -1,0 +1,70 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard a global list of phase blocks (no block data is
+exchanged), solve their shard (with the CPU oracle here — the GPU path is covered by -m gpu tests), and reduce
+only the result counts/timings, exactly as bench.py does under torch.distributed.run."""
+import os
+import socket
+import sys
+
+import pytest
+
+from hiphase_amd.shard import rank_seeds, shard_lpt
+
+
+def test_shard_lpt_properties():
+    work = [5000, 3, 40, 40, 999, 1, 17, 2500, 2500, 8]
+    for ws in (1, 2, 3, 8):
+        shards = shard_lpt(work, ws)
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(len(work)))  # a partition: every block exactly once
+        loads = [sum(work[i] for i in s) for s in shards]
+        if ws == 2:
+            assert max(loads) - min(loads) <= max(work)
+    assert shard_lpt([], 4) == [[], [], [], []]
+    assert len(set(rank_seeds(1, 0, 100)) & set(rank_seeds(1, 1, 100))) == 0
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from hiphase_amd.shard import gather_hets, max_over_ranks
+    from oracle_ffi import oracle_solve, oracle_synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = [120, 15, 60, 33, 7, 90, 45, 21]
+    blocks = [oracle_synth(n, 12, 8, 0.02, 0.02, 500 + i)[0] for i, n in enumerate(sizes)]
+    mine = shard_lpt([b.n_cells for b in blocks], world)[rank]
+    res = {i: oracle_solve(blocks[i])[2] for i in mine}
+    total = gather_hets(dist, sum(sizes[i] for i in mine))
+    tmax = max_over_ranks(dist, 0.5 + rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)   # results only, for the test's check
+    if rank == 0:
+        merged = {}
+        for g in gathered:
+            merged.update(g)
+        out.put((total, tmax, merged))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    from oracle_ffi import oracle_solve, oracle_synth
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    total, tmax, merged = q.get(timeout=150)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = [120, 15, 60, 33, 7, 90, 45, 21]
+    assert total == sum(sizes) and tmax == 1.5
+    assert sorted(merged) == list(range(len(sizes)))
+    for i, n in enumerate(sizes):   # sharded results == single-process results
+        assert merged[i] == oracle_solve(oracle_synth(n, 12, 8, 0.02, 0.02, 500 + i)[0])[2]
