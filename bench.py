@@ -119,6 +119,19 @@ def main():
     res, ctrs, _ = rb.results()
     cells_per_step = sum(c.cells for c in ctrs)
     evals_per_step = sum(c.evals for c in ctrs)
+    cyc_heur = sum(c.reserved[0] for c in ctrs) / max(1, len(ctrs))
+    cyc_main = sum(c.reserved[1] for c in ctrs) / max(1, len(ctrs))
+    # HBM traffic (PMC) cannot be collected from inside this process; the value measured with
+    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on the same workload is kept under profiles/ and scaled
+    # to this launch's hets (see profiles/round1/README.md). null when no measurement matches the workload.
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "round1", "traffic.json")))
+        if tj["workload"] == args.workload and args.hets == 5000 and args.coverage == 30 and args.span == 20:
+            traffic = tj["bytes_per_het"] * hets_per_step
+            traffic_src = tj["source"]
+    except Exception:
+        pass
     out = None
     if rank == 0:
         kavg_ms = sum(kernel_ms) / len(kernel_ms)
@@ -144,10 +157,11 @@ def main():
                        "min_queue_size": 1000, "queue_increment": 3, "hets_per_step_per_gpu": hets_per_step,
                        "pack_upload_s": round(t_pack, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "hp::hp_astar_kernel", "kernel_ms": kavg_ms,
                          "algorithmic_bytes_per_launch": b_alg, "cells_per_het": cells_per_step / hets_per_step,
-                         "evals_per_het": evals_per_step / hets_per_step},
+                         "evals_per_het": evals_per_step / hets_per_step,
+                         "mean_wave_cycles_heuristic": cyc_heur, "mean_wave_cycles_main": cyc_main},
         }
         if not args.no_cpu:
             cb, octr, ores = cpu_baseline(args, blocks)

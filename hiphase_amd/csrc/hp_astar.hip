@@ -189,6 +189,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     prm.max_n_vars = max_n;
     const char* dbg = std::getenv("HP_DEBUG_STAGE");
     prm.pad0 = dbg ? (uint32_t)std::atoi(dbg) : 0;
+    prm.pad1 = std::getenv("HP_SEG_PROFILE") ? 1u : 0u;   // per-segment s_memtime profile of the sub-solver loop
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const size_t lds_bytes = LDS_HEAP_OFF + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup

@@ -190,6 +190,31 @@ template <bool LDS> struct SubHeap {
         }
         if (k < top) { top = k; top_lane = tgt; }
     }
+    // up to four uniform keys (~0 = absent) with distinct target lanes (consecutive node indices): the target
+    // lanes sift up concurrently inside one divergent region
+    DEVINL void push4(uint64_t ka, uint64_t kb, uint64_t kc, uint64_t kd2) {
+        const uint32_t lane = lane_id();
+        uint64_t mine = ~0ull;
+        if (ka != ~0ull && (subkey_idx(ka) & 63u) == lane) mine = ka;
+        if (kb != ~0ull && (subkey_idx(kb) & 63u) == lane) mine = kb;
+        if (kc != ~0ull && (subkey_idx(kc) & 63u) == lane) mine = kc;
+        if (kd2 != ~0ull && (subkey_idx(kd2) & 63u) == lane) mine = kd2;
+        if (mine != ~0ull) {
+            if (cnt >= jcap) ovf = 1;
+            else {
+                uint32_t j = cnt;
+                while (j > 0) {
+                    const uint32_t pj = (j - 1) >> 1;
+                    const uint64_t pk = ld(pj);
+                    if (mine < pk) { st(j, pk); j = pj; } else break;
+                }
+                st(j, mine);
+                cnt += 1;
+            }
+        }
+        const uint64_t m = umin64(umin64(ka, kb), umin64(kc, kd2));
+        if (m < top) { top = m; top_lane = subkey_idx(m) & 63u; }
+    }
     DEVINL void pop() {  // removes the global minimum (caller copied `top` first)
         if (lane_id() == top_lane) {
             cnt -= 1;
@@ -292,6 +317,21 @@ DEVINL Cur cur_from_rec(const NodeRec& r, uint64_t total, uint64_t idx) {
     return n;
 }
 
+struct WaveCounters {
+    uint64_t sub_pops, main_pops, nodes;
+    uint64_t seg[6];   // HP_SEG_PROFILE: shader-clock cycles per sub-solver segment (prm.pad1 != 0)
+    uint64_t tlast;
+};
+// segment profiling (bring-up/tuning aid, off in production): drain outstanding memory ops, read s_memtime
+DEVINL void seg_stamp(WaveCounters& wc, bool on, int which) {
+    if (on) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const uint64_t t = __builtin_amdgcn_s_memtime();
+        if (which >= 0) wc.seg[which] += t - wc.tlast;
+        wc.tlast = t;
+    }
+}
+
 struct Ctx {
     const uint32_t *rstart, *rend, *rword;
     const uint32_t* words;
@@ -336,6 +376,29 @@ template <int S> DEVINL void kid_store(NodeRec* pool, const Kids& k, uint64_t ne
     store_rec(pool + (next_idx + kid_rank<S>(k)), kid_frozen<S>(k), k.depth, kid_hets<S>(k), k.anc1, k.anc2, kid_win<S>(k), k.w1);
 }
 
+// All sibling records of one expansion in ONE store instruction: the children have consecutive node indices, so
+// their 48-byte records are contiguous; lane l (< 3*n) writes 16-byte part l%3 of the child of rank l/3.
+// (Only the sub-solver uses this: its heap-pop path re-reads records through lane 0 behind a workgroup fence.)
+DEVINL void kids_store_all(NodeRec* pool, const Kids& k, uint32_t next_idx) {
+    const uint32_t lane = lane_id();
+    const uint32_t rank = lane / 3u, part = lane - rank * 3u;
+    // rank -> slot of hap_order: with the (1,0) child present ranks map 1:1, without it ranks 1,2 are slots 2,3
+    const uint32_t slot = k.bad ? 0u : (k.has1 ? rank : (rank == 0 ? 0u : rank + 1u));
+    const uint64_t frozen = slot == 0 ? k.frozen0 : slot == 1 ? k.frozen1 : slot == 2 ? k.frozen2 : k.frozen3;
+    const uint32_t hets = (slot <= 1 && !k.bad) ? k.hets_het : k.hets_hom;
+    Win w = k.base;
+    if (!k.bad) {
+        w.nv &= ~k.bit;
+        if (slot == 1 || slot == 3) w.h1 |= k.bit;
+        if (slot == 0 || slot == 3) w.h2 |= k.bit;
+    }
+    uint4 x;
+    if (part == 0) x = make_uint4((uint32_t)frozen, (uint32_t)(frozen >> 32), k.depth, hets);
+    else if (part == 1) x = make_uint4(k.anc1, k.anc2, w.h1, w.h2);
+    else x = make_uint4(w.nv, k.w1.h1, k.w1.h2, k.w1.nv);
+    if (lane < 3u * k.n) reinterpret_cast<uint4*>(pool + next_idx)[lane] = x;
+}
+
 // weighted popcount: sum_b popc(M & Q_b) << b   (Horner over the 8 quality bit-planes)
 DEVINL uint32_t wpop(uint32_t M, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t q4, uint32_t q5,
                      uint32_t q6, uint32_t q7) {
@@ -356,7 +419,7 @@ DEVINL uint32_t wpop(uint32_t M, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t
 // so the O(overlap) part is shared by the children; it is evaluated bit-parallel per 32-variant word.
 // [lo, hi) = candidate rows of variant p (start-sorted), bad = variant ignored.
 DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t lo, uint32_t hi, bool bad,
-                   uint64_t h_next, NodeRec* pool, Kids& kd) {
+                   uint64_t h_next, NodeRec* pool, Kids& kd, WaveCounters& wc, bool prof) {
     const uint32_t lane = lane_id();
     const uint32_t kp = p >> 5, bp = p & 31u;
     const uint32_t ck = cur.depth ? ((off + cur.depth - 1) >> 5) : (off >> 5);
@@ -379,46 +442,65 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
             rw = cx.rword[r];
         }
         valid = valid && re > p;  // start <= p by construction of vhi
+        seg_stamp(wc, prof, 1);   // [1] row metadata loads
         const uint32_t kr = rs >> 5;
         const uint32_t myj = kp - kr;  // words before the one holding p (garbage when !valid)
         uint32_t s1 = 0, s2 = 0, ap = 3, qp = 0;
-        // haplotype-chain walker state (uniform)
-        uint32_t chain_slot = cur.anc2, chain_phase = 0, chain_next = NONE32, guard = 0;
-        Win cw1 = fresh_win();
-        for (uint32_t j = 0;; ++j) {
-            const bool need = valid && (j <= myj);
-            if (!__any(need)) break;
-            Win w;
-            if (j == 0) w = W0;
-            else if (j == 1) w = W1;
-            else if (trans && j == 2) w = W2;
-            else {
-                if (chain_phase == 0) {
-                    if (chain_slot == NONE32 || ++guard > (cx.N >> 6) + 4) break;  // nothing older: zero cost
-                    const NodeRec a = load_rec(pool + chain_slot);
-                    w = a.w0;
-                    cw1 = a.w1;
-                    chain_next = a.anc2;
-                    chain_phase = 1;
-                } else {
-                    w = cw1;
-                    chain_slot = chain_next;
-                    chain_phase = 0;
+        const uint32_t* wbase = cx.words + (size_t)(rw + (kp - kr)) * WORD_DWORDS;  // plane word holding p
+        // ---- j = 0: the word that holds p (every valid lane) ------------------------------------------------
+        if (valid) {
+            const uint4* pw = reinterpret_cast<const uint4*>(wbase);
+            const uint4 x0 = pw[0], x1 = pw[1], x2 = pw[2];
+            const uint32_t aLo = x0.x, aHi = x0.y;
+            const uint32_t M1 = ~W0.nv & ((aLo ^ W0.h1) | aHi);
+            const uint32_t M2 = ~W0.nv & ((aLo ^ W0.h2) | aHi);
+            s1 = wpop(M1, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
+            s2 = wpop(M2, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
+            ap = ((aLo >> bp) & 1u) | (((aHi >> bp) & 1u) << 1);
+            qp = ((x0.z >> bp) & 1u) | (((x0.w >> bp) & 1u) << 1) | (((x1.x >> bp) & 1u) << 2) |
+                 (((x1.y >> bp) & 1u) << 3) | (((x1.z >> bp) & 1u) << 4) | (((x1.w >> bp) & 1u) << 5) |
+                 (((x2.x >> bp) & 1u) << 6) | (((x2.y >> bp) & 1u) << 7);
+        }
+        // ---- j = 1: the previous chunk (rows that started before this chunk) -------------------------------
+        const bool need1 = valid && myj >= 1;
+        if (need1) {
+            const uint4* pw = reinterpret_cast<const uint4*>(wbase - WORD_DWORDS);
+            const uint4 x0 = pw[0], x1 = pw[1], x2 = pw[2];
+            const uint32_t M1 = ~W1.nv & ((x0.x ^ W1.h1) | x0.y);
+            const uint32_t M2 = ~W1.nv & ((x0.x ^ W1.h2) | x0.y);
+            s1 += wpop(M1, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
+            s2 += wpop(M2, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
+        }
+        // ---- j >= 2: rows spanning more than two chunks walk the haplotype-window chain (rare) --------------
+        if (__any(valid && myj >= 2)) {
+            uint32_t chain_slot = cur.anc2, chain_phase = 0, chain_next = NONE32, guard = 0;
+            Win cw1 = fresh_win();
+            for (uint32_t j = 2;; ++j) {
+                const bool need = valid && (j <= myj);
+                if (!__any(need)) break;
+                Win w;
+                if (trans && j == 2) w = W2;
+                else {
+                    if (chain_phase == 0) {
+                        if (chain_slot == NONE32 || ++guard > (cx.N >> 6) + 4) break;  // nothing older: zero cost
+                        const NodeRec a = load_rec(pool + chain_slot);
+                        w = a.w0;
+                        cw1 = a.w1;
+                        chain_next = a.anc2;
+                        chain_phase = 1;
+                    } else {
+                        w = cw1;
+                        chain_slot = chain_next;
+                        chain_phase = 0;
+                    }
                 }
-            }
-            if (need) {
-                const uint4* pw = reinterpret_cast<const uint4*>(cx.words + (size_t)(rw + (kp - j - kr)) * WORD_DWORDS);
-                const uint4 x0 = pw[0], x1 = pw[1], x2 = pw[2];
-                const uint32_t aLo = x0.x, aHi = x0.y;
-                const uint32_t M1 = ~w.nv & ((aLo ^ w.h1) | aHi);
-                const uint32_t M2 = ~w.nv & ((aLo ^ w.h2) | aHi);
-                s1 += wpop(M1, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
-                s2 += wpop(M2, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
-                if (j == 0) {
-                    ap = ((aLo >> bp) & 1u) | (((aHi >> bp) & 1u) << 1);
-                    qp = ((x0.z >> bp) & 1u) | (((x0.w >> bp) & 1u) << 1) | (((x1.x >> bp) & 1u) << 2) |
-                         (((x1.y >> bp) & 1u) << 3) | (((x1.z >> bp) & 1u) << 4) | (((x1.w >> bp) & 1u) << 5) |
-                         (((x2.x >> bp) & 1u) << 6) | (((x2.y >> bp) & 1u) << 7);
+                if (need) {
+                    const uint4* pw = reinterpret_cast<const uint4*>(wbase - (size_t)j * WORD_DWORDS);
+                    const uint4 x0 = pw[0], x1 = pw[1], x2 = pw[2];
+                    const uint32_t M1 = ~w.nv & ((x0.x ^ w.h1) | x0.y);
+                    const uint32_t M2 = ~w.nv & ((x0.x ^ w.h2) | x0.y);
+                    s1 += wpop(M1, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
+                    s2 += wpop(M2, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
                 }
             }
         }
@@ -438,8 +520,10 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
             cx.cells += (uint64_t)nkids * (uint64_t)(p + 1 - max(rs, off));
         }
     }
+    seg_stamp(wc, prof, 2);       // [2] plane-word loads + bit-sliced scoring
     uint32_t sum[8];
     wave_sum8(acc, sum);
+    seg_stamp(wc, prof, 3);       // [3] wave reduction
 
     kd.bad = bad;
     kd.has1 = !bad && cur.hets != 0;
@@ -458,16 +542,10 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
     kd.frozen3 = cur.frozen + sum[3]; kd.total3 = kd.frozen3 + sum[7] + h_next;
 }
 
-struct WaveCounters {
-    uint64_t sub_pops, main_pops, nodes;
-};
-
-// LDS rings, indexed by (variant & 63): H[x] and the per-variant (lo, hi, flags) triple. Written and read by
-// lane 0 only, then broadcast.
-DEVINL uint64_t ringH_get(uint32_t x) {
-    uint64_t v = 0;
-    if (lane_id() == 0) v = reinterpret_cast<const uint64_t*>(hp_smem + LDS_HRING_OFF)[x & 63u];
-    return bcast64(v);
+// LDS rings, indexed by (variant & 63): H[x] and the per-variant (lo, hi, flags) triple. Written by lane 0, read by
+// all lanes at one address (LDS operations of a wave execute in order), then made scalar with v_readfirstlane.
+DEVINL uint64_t ringH_get(uint32_t x) {  // every lane reads the same address: one broadcast LDS access, no exec masking
+    return bcast64(reinterpret_cast<const uint64_t*>(hp_smem + LDS_HRING_OFF)[x & 63u]);
 }
 DEVINL void ringH_set(uint32_t x, uint64_t v) {
     if (lane_id() == 0) reinterpret_cast<uint64_t*>(hp_smem + LDS_HRING_OFF)[x & 63u] = v;
@@ -476,8 +554,7 @@ DEVINL void ringV_set(uint32_t x, uint32_t lo, uint32_t hi, uint32_t flags) {
     if (lane_id() == 0) reinterpret_cast<uint4*>(hp_smem + LDS_VRING_OFF)[x & 63u] = make_uint4(lo, hi, flags, 0);
 }
 DEVINL void ringV_get(uint32_t x, uint32_t& lo, uint32_t& hi, uint32_t& flags) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (lane_id() == 0) v = reinterpret_cast<const uint4*>(hp_smem + LDS_VRING_OFF)[x & 63u];
+    const uint4 v = reinterpret_cast<const uint4*>(hp_smem + LDS_VRING_OFF)[x & 63u];
     lo = bcast32(v.x);
     hi = bcast32(v.y);
     flags = bcast32(v.z);
@@ -488,6 +565,8 @@ template <bool SUB_LDS>
 DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t ps, SubHeap<SUB_LDS>& heap,
                         NodeRec* pool, WaveCounters& wc, uint64_t& est, uint32_t& solved) {
     heap.reset();
+    const bool prof = prm.pad1 != 0;
+    seg_stamp(wc, prof, -1);
     uint32_t next_idx = 1;
     Cur cur = root_node(ringH_get(off + 1));  // initial_estimate = H[off+1] (astar_phaser.rs:322)
     uint32_t next_expected = 0, visited = 0;
@@ -502,10 +581,13 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
             next_expected += 1;
         }
         const uint32_t p = off + cur.depth;
-        uint32_t lo, hi, flags;
-        ringV_get(p, lo, hi, flags);
+        // both ring reads are issued before either result is consumed
+        const uint4 rv = reinterpret_cast<const uint4*>(hp_smem + LDS_VRING_OFF)[p & 63u];
+        const uint64_t rh = reinterpret_cast<const uint64_t*>(hp_smem + LDS_HRING_OFF)[(p + 1) & 63u];
+        const uint32_t lo = bcast32(rv.x), hi = bcast32(rv.y), flags = bcast32(rv.z);
         Kids kd;
-        expand(cx, cur, off, p, lo, hi, (flags & HP_VAR_IGNORED) != 0, ringH_get(p + 1), pool, kd);
+        seg_stamp(wc, prof, 0);       // [0] loop head + LDS ring reads
+        expand(cx, cur, off, p, lo, hi, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pool, kd, wc, prof);
         wc.nodes += kd.n;
         if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
         if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
@@ -518,10 +600,10 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         // If the best child beats everything queued it is the next pop: keep it in registers (push + pop elided;
         // the priority is a total order, so this is exactly what the reference's queue would return).
         const bool take_child = kbest < heap.top;
-        if (!(take_child && k0 == kbest)) { kid_store<0>(pool, kd, next_idx); heap.push(k0); }
-        if (k1 != ~0ull && !(take_child && k1 == kbest)) { kid_store<1>(pool, kd, next_idx); heap.push(k1); }
-        if (k2 != ~0ull && !(take_child && k2 == kbest)) { kid_store<2>(pool, kd, next_idx); heap.push(k2); }
-        if (k3 != ~0ull && !(take_child && k3 == kbest)) { kid_store<3>(pool, kd, next_idx); heap.push(k3); }
+        seg_stamp(wc, prof, 4);   // [4] child totals + keys
+        kids_store_all(pool, kd, next_idx);  // every sibling (the kept one too: harmless) in one 16 B/lane store
+        heap.push4((take_child && k0 == kbest) ? ~0ull : k0, (take_child && k1 == kbest) ? ~0ull : k1,
+                   (take_child && k2 == kbest) ? ~0ull : k2, (take_child && k3 == kbest) ? ~0ull : k3);
         if (take_child) {
             if (k0 == kbest) cur = kid_as_cur<0>(kd, next_idx);
             else if (k1 == kbest) cur = kid_as_cur<1>(kd, next_idx);
@@ -530,9 +612,12 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         } else {
             const uint64_t t = heap.top;
             heap.pop();
+            // records were written by lanes 0..11 (kids_store_all) and are re-read by lane 0: order the accesses
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             cur = cur_from_rec(load_rec(pool + subkey_idx(t)), subkey_total(t), subkey_idx(t));
         }
         next_idx += kd.n;
+        seg_stamp(wc, prof, 5);   // [5] record store + heap pushes (+ pop on the slow path)
         if (__any(heap.ovf)) { st = ST_OVERFLOW; break; }
     }
     if (cur.depth == ps) {  // astar_phaser.rs:395-399 (peek, not pop)
@@ -561,8 +646,9 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
     NodeRec* sub_pool = B.sub_pool + (size_t)slot * prm.cap_sub;
     NodeRec* main_pool = B.main_pool + (size_t)slot * prm.cap_main;
     uint32_t* tracker = B.tracker + (size_t)slot * ((size_t)prm.max_n_vars + 1);
-    WaveCounters wc{0, 0, 0};
+    WaveCounters wc{0, 0, 0, {0, 0, 0, 0, 0, 0}, 0};
     int32_t st = ST_OK;
+    const uint64_t t_start = __builtin_readcyclecounter();
     const bool resume = bcast32(lane == 0 ? (uint32_t)B.status[blk] : 0u) == (uint32_t)ST_OVERFLOW_MAIN;
 
     if (!resume) {
@@ -608,6 +694,7 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
         wc.sub_pops = bcast64(a);
         wc.nodes = bcast64(b2);
     }
+    const uint64_t t_heur = __builtin_readcyclecounter();
     // counters of the heuristic phase, kept in case the main search has to be re-run with more scratch
     const uint64_t h_evals = wave_sum_u64(cx.evals), h_cells = wave_sum_u64(cx.cells);
     const uint64_t h_nodes = wc.nodes;
@@ -665,7 +752,7 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
             if (lane == 0) { fl = vflags[p]; l = vlo[p]; h = vhi[p]; hn = H[p + 1]; }
             fl = bcast32(fl); l = bcast32(l); h = bcast32(h); hn = bcast64(hn);
             Kids kd;
-            expand(cx, cur, 0, p, l, h, (fl & HP_VAR_IGNORED) != 0, hn, main_pool, kd);
+            expand(cx, cur, 0, p, l, h, (fl & HP_VAR_IGNORED) != 0, hn, main_pool, kd, wc, false);
             wc.nodes += kd.n;
             if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; break; }
             if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:529
@@ -787,6 +874,13 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
             c.evals = h_evals; c.cells = h_cells; c.nodes_created = h_nodes;
         } else {
             c.main_pops = wc.main_pops; c.evals = h_evals + m_evals; c.cells = h_cells + m_cells; c.nodes_created = wc.nodes;
+        }
+        c.reserved[0] = t_heur - t_start;                      // shader-clock cycles spent in the heuristic chain
+        c.reserved[1] = __builtin_readcyclecounter() - t_heur;  // ... in the main search + emit
+        if (prm.pad1 != 0) {  // segment profile: pack 6 x 32-bit kilo-cycle counters
+            c.reserved[0] = (wc.seg[0] >> 10) | ((wc.seg[1] >> 10) << 32);
+            c.reserved[1] = (wc.seg[2] >> 10) | ((wc.seg[3] >> 10) << 32);
+            c.reserved[2] = (wc.seg[4] >> 10) | ((wc.seg[5] >> 10) << 32);
         }
         B.counters[blk] = c;
         B.status[blk] = st;
