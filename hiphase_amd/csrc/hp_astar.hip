@@ -124,7 +124,8 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     if (max_row_qual * (uint64_t)std::max(max_cov, 1u) >= (1ull << 32)) {
         set_error("row quality mass x coverage overflows the u32 score accumulators"); return HP_ERR_UNSUPPORTED;
     }
-    if (total_qual >= (1ull << 37)) { set_error("total quality mass of the block exceeds the packed key range"); return HP_ERR_UNSUPPORTED; }
+    if (total_qual >= (1ull << 35)) { set_error("total quality mass of the block exceeds the packed key range (2^35)"); return HP_ERR_UNSUPPORTED; }
+    if (idx.size() >= (1u << 28)) { set_error("more than 2^28 rows in one block"); return HP_ERR_UNSUPPORTED; }
     d.max_cov = max_cov;
     d.n_words = (uint32_t)n_words;
     hpk.desc.push_back(d);
@@ -193,10 +194,12 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const size_t lds_bytes = LDS_HEAP_OFF + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup
-    uint32_t per_cu = (uint32_t)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
+    uint32_t per_cu = (uint32_t)std::min<size_t>(20, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
     if (per_cu == 0) per_cu = 1;
-    const size_t per_slot = (size_t)cap_main * sizeof(NodeRec) + (size_t)prm.jcap_main * 64 * sizeof(Key) +
-                            (size_t)prm.cap_sub * sizeof(NodeRec) + ((size_t)max_n + 1) * 4 +
+    prm.cap_chunk_main = cap_main / 4 + 64;
+    const size_t main_pool_bytes = (size_t)cap_main * sizeof(FamRec) + (size_t)prm.cap_chunk_main * sizeof(ChunkRec);
+    const size_t sub_pool_bytes = (size_t)prm.cap_sub * sizeof(FamRec) + (size_t)prm.cap_chunk_sub * sizeof(ChunkRec);
+    const size_t per_slot = main_pool_bytes + (size_t)prm.jcap_main * 64 * sizeof(Key) + sub_pool_bytes + ((size_t)max_n + 1) * 4 +
                             (prm.sub_heap_in_lds ? 0 : (size_t)prm.jcap_sub * 64 * sizeof(uint64_t));
     size_t free_b = 0, total_b = 0;
     HP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
@@ -206,9 +209,9 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     if (per_slot > budget) { set_error("a single block needs %zu bytes of solver scratch; only %zu available", per_slot, budget); return HP_ERR_OOM; }
     if (have_slots < slots || have_cap != cap_main || tracker.bytes < (size_t)slots * ((size_t)max_n + 1) * 4) {
         int rc;
-        if ((rc = main_pool.alloc((size_t)slots * cap_main * sizeof(NodeRec))) != HP_OK) return rc;
+        if ((rc = main_pool.alloc((size_t)slots * main_pool_bytes)) != HP_OK) return rc;
         if ((rc = main_heap.alloc((size_t)slots * prm.jcap_main * 64 * sizeof(Key))) != HP_OK) return rc;
-        if ((rc = sub_pool.alloc((size_t)slots * prm.cap_sub * sizeof(NodeRec))) != HP_OK) return rc;
+        if ((rc = sub_pool.alloc((size_t)slots * sub_pool_bytes)) != HP_OK) return rc;
         if ((rc = tracker.alloc((size_t)slots * ((size_t)max_n + 1) * 4)) != HP_OK) return rc;
         if (!prm.sub_heap_in_lds && (rc = sub_heap.alloc((size_t)slots * prm.jcap_sub * 64 * sizeof(uint64_t))) != HP_OK) return rc;
         have_slots = slots;
@@ -230,7 +233,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     B.H = b->d_H.as<uint64_t>(); B.h1 = b->d_h1.as<uint8_t>(); B.h2 = b->d_h2.as<uint8_t>();
     B.stats = b->d_stats.as<hp_phase_stats>(); B.counters = b->d_counters.as<hp_work_counters>();
     B.status = b->d_status.as<int32_t>();
-    B.sub_pool = sub_pool.as<NodeRec>(); B.main_pool = main_pool.as<NodeRec>();
+    B.sub_pool = sub_pool.as<unsigned char>(); B.main_pool = main_pool.as<unsigned char>();
     B.sub_heap_g = sub_heap.as<uint64_t>(); B.main_heap = main_heap.as<Key>(); B.tracker = tracker.as<uint32_t>();
     B.prm = prm;
     if (verbose) { fprintf(stderr, "[hp] launch items=%zu slots=%u cap_main=%u cap_sub=%u jcap_sub=%u lds=%zu stage=%u\n", items.size(), slots, cap_main, prm.cap_sub, prm.jcap_sub, lds_bytes, prm.pad0); fflush(stderr); }
@@ -280,8 +283,9 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     prm.qinc = (uint32_t)p->queue_increment;
     prm.max_seg = (uint32_t)max_seg;
     const uint64_t max_visits = (uint64_t)prm.minq_sub + (uint64_t)prm.qinc * max_seg;
-    prm.cap_sub = (uint32_t)(4 * max_visits + 8);
-    prm.jcap_sub = (prm.cap_sub + 63) / 64 + 1;
+    prm.cap_sub = (uint32_t)(4 * max_visits + 1);   // root + at most 4 children per visit
+    prm.jcap_sub = (prm.cap_sub + 63) / 64;   // node_index % 64 deals at most ceil(cap/64) keys to a lane
+    prm.cap_chunk_sub = (uint32_t)max_visits + 8;   // at most one ChunkRec per expansion
     prm.sub_heap_in_lds = ((size_t)prm.jcap_sub * 64 * sizeof(uint64_t) <= LDS_SUB_HEAP_MAX_BYTES) ? 1 : 0;
     if (prm.cap_sub >= (1u << 14)) { set_error("min_queue_size/10 + queue_increment*max_segment_size = %llu visits exceeds the packed sub-key limit (4093)", (unsigned long long)max_visits); return fail(HP_ERR_UNSUPPORTED); }
 
@@ -318,7 +322,7 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     // pass 0: every block, scratch sized generously above the clean-data bound (<= 4N+1 nodes); blocks whose
     // frontier outgrows it (noisy data) keep their finished heuristic and only their main search is re-run
     // with 4x the capacity until it fits (or memory runs out).
-    uint32_t cap_main = 6 * b->max_n + 2048;
+    uint32_t cap_main = 6 * b->max_n + 2048;   // node_index < 2^38 is guaranteed by cap64 <= 0xF0000000 below
     int rc = launch_pass(b, st, b->order, cap_main, b->s_main_pool, b->s_main_heap, b->s_sub_pool, b->s_sub_heap,
                          b->s_tracker, b->scratch_slots, b->scratch_cap_main, b->d_order);
     if (rc != HP_OK) return rc;

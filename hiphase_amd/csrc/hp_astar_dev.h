@@ -36,7 +36,8 @@ struct BlockDesc {
 
 // Priority key (astar_phaser.rs:131-133): min total cost, then MORE hets, then OLDER node.
 //   hi = cost << 24 | (0xFFFFFF - num_hets)      cost < 2^40 (sum of all quals of a block < 2^40)
-//   lo = node_index << 24 | depth                node_index < 2^40, depth <= N < 2^24
+//   lo = node_index << 26 | rank << 24 | depth   node_index < 2^38, creation rank among siblings (0..3),
+//                                                depth <= N < 2^24  (rank never decides: node_index is unique)
 // Lexicographic (hi, lo) order == the reference's pop order; node_index is unique so it is total.
 // depth rides in the low bits so the full prune (astar_phaser.rs:576-581) needs no node lookup.
 struct Key {
@@ -48,18 +49,28 @@ struct Win {  // haplotype window over one 32-variant chunk
     uint32_t nv;      // 1 = not assigned yet, before the sub-problem offset, or (2,2)
 };
 
-// Search-tree node as stored in the pool: O(1) state instead of the reference's O(len) Vec copies
-// (astar_phaser.rs:79-82). The haplotype is a chain of 32-variant chunks: w0 = chunk of the last
-// assigned position, w1 = the chunk before it; anc1/anc2 = pool slots of the ancestors that hold the
-// complete chunks ck-1 / ck-2 (their w0), so any look-back costs one hop per two chunks.
-struct NodeRec {  // 48 B
-    uint64_t frozen;
-    uint32_t depth;
-    uint32_t hets;
-    uint32_t anc1, anc2;
-    Win w0, w1;
+// Search-tree state in HBM. O(1) per node instead of the reference's O(len) Vec copies (astar_phaser.rs:79-82):
+//  * one FamRec per EXPANSION (not per child): everything the siblings share + the four per-slot frozen
+//    increments; a child is rebuilt from (family, creation rank) only if it is ever popped from the queue —
+//    on HiFi-like data 97 % of the children never are. Stored at fam[node_index of the first child].
+//  * one ChunkRec per completed 32-variant haplotype chunk on a path: w0 = that chunk, w1 = the chunk before,
+//    anc2 = the ChunkRec two chunks back. A node carries (w0, w1, anc1, anc2), so any look-back costs one hop
+//    per two chunks and rows shorter than 64 variants never touch memory.
+struct FamRec {  // 64 B
+    uint64_t frozen;       // parent's frozen cost
+    uint32_t depth_flags;  // parent depth | bad << 30 | has_10_child << 31
+    uint32_t hets;         // parent's num_hets
+    uint32_t anc1, anc2;   // the children's chunk links
+    Win base;              // parent's window in the children's chunk (fresh when they open a new chunk)
+    Win w1;                // the chunk before it
+    uint32_t sumF[4];      // frozen increment of slot 0..3 = (0,1) (1,0) (0,0) (1,1)
 };
-static_assert(sizeof(NodeRec) == 48, "NodeRec must be 48 bytes");
+static_assert(sizeof(FamRec) == 64, "FamRec must be 64 bytes");
+struct ChunkRec {  // 32 B
+    Win w0, w1;
+    uint32_t anc2, pad;
+};
+static_assert(sizeof(ChunkRec) == 32, "ChunkRec must be 32 bytes");
 
 struct SolveParams {
     uint32_t minq_main;   // min_queue_size
@@ -72,7 +83,9 @@ struct SolveParams {
     uint32_t jcap_main;   // per-lane heap capacity (main)
     uint32_t sub_heap_in_lds;
     uint32_t max_n_vars;  // largest N among the blocks of this launch (tracker stride)
-    uint32_t pad0, pad1;
+    uint32_t pad0, pad1;  // bring-up / segment-profile switches
+    uint32_t cap_chunk_sub, cap_chunk_main;  // ChunkRec capacities
+    uint32_t pad2, pad3;
 };
 
 // block status written by the kernel
@@ -97,8 +110,8 @@ struct BatchDev {
     hp_work_counters* counters;
     int32_t* status;
     // per-workgroup-slot scratch
-    NodeRec* sub_pool;    // [slots][cap_sub]
-    NodeRec* main_pool;   // [slots][cap_main]
+    unsigned char* sub_pool;   // [slots][cap_sub x FamRec | cap_chunk_sub x ChunkRec]
+    unsigned char* main_pool;  // [slots][cap_main x FamRec | cap_chunk_main x ChunkRec]
     uint64_t* sub_heap_g; // [slots][jcap_sub*64] packed sub keys (only when the sub heap does not fit LDS)
     Key* main_heap;       // [slots][jcap_main*64]
     uint32_t* tracker;    // [slots][max_n_vars+1]

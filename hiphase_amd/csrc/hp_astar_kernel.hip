@@ -27,10 +27,11 @@ namespace hp {
 
 #define DEVINL __device__ __forceinline__
 
-// LDS layout (bytes): [0,512) H ring (64 x u64) | [512,1536) variant ring (64 x uint4) | [1536,...) sub heap
+// LDS layout (bytes): [0,512) H ring (64 x u64) | [512,1024) variant ring (64 x {lo, hi | flags << 28}) | [1024,...) sub heap
+// 1024 + 14 x 512 B of heap = 8 KiB at default parameters -> 20 single-wave workgroups per CU
 constexpr uint32_t LDS_HRING_OFF = 0;
 constexpr uint32_t LDS_VRING_OFF = 512;
-constexpr uint32_t LDS_HEAP_OFF = 1536;
+constexpr uint32_t LDS_HEAP_OFF = 1024;
 extern __shared__ __attribute__((aligned(16))) unsigned char hp_smem[];
 
 DEVINL uint32_t lane_id() { return __lane_id(); }
@@ -101,9 +102,11 @@ DEVINL uint64_t wave_min_u64(uint64_t v) {
 // ---- keys ------------------------------------------------------------------------------------------------
 DEVINL bool key_less(const Key& a, const Key& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
 DEVINL Key key_inf() { return Key{~0ull, ~0ull}; }
-DEVINL Key make_key(uint64_t total, uint32_t hets, uint64_t idx, uint32_t depth) {
-    return Key{(total << 24) | (uint64_t)(0xFFFFFFu - hets), (idx << 24) | (uint64_t)depth};
+DEVINL Key make_key(uint64_t total, uint32_t hets, uint64_t idx, uint32_t rank, uint32_t depth) {
+    return Key{(total << 24) | (uint64_t)(0xFFFFFFu - hets), (idx << 26) | ((uint64_t)rank << 24) | (uint64_t)depth};
 }
+DEVINL uint64_t key_idx(const Key& k) { return k.lo >> 26; }
+DEVINL uint32_t key_rank(const Key& k) { return (uint32_t)(k.lo >> 24) & 3u; }
 DEVINL Key wave_min_key(Key k) {  // 128-bit lexicographic minimum (main heap; slow path only)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -115,44 +118,49 @@ DEVINL Key wave_min_key(Key k) {  // 128-bit lexicographic minimum (main heap; s
     return Key{bcast64(k.hi), bcast64(k.lo)};
 }
 // Sub-solver key, one u64 (astar_phaser.rs:131-133 restricted to a <= 62-variant sub-problem):
-//   cost:38 | (63 - hets):6 | node_index:14 | depth:6      (host checks cost < 2^38, nodes < 2^14)
-DEVINL uint64_t make_subkey(uint64_t total, uint32_t hets, uint32_t idx, uint32_t depth) {
-    return (total << 26) | ((uint64_t)(63u - hets) << 20) | ((uint64_t)idx << 6) | (uint64_t)depth;
+//   cost:36 | (63 - hets):6 | node_index:14 | depth:6 | rank:2   (host checks cost < 2^36, nodes < 2^14);
+//   rank = creation rank among the siblings; it sits below node_index, which is unique, so it never decides.
+DEVINL uint64_t make_subkey(uint64_t total, uint32_t hets, uint32_t idx, uint32_t rank, uint32_t depth) {
+    return (total << 28) | ((uint64_t)(63u - hets) << 22) | ((uint64_t)idx << 8) | ((uint64_t)depth << 2) | (uint64_t)rank;
 }
-DEVINL uint64_t subkey_total(uint64_t k) { return k >> 26; }
-DEVINL uint32_t subkey_idx(uint64_t k) { return (uint32_t)(k >> 6) & 0x3FFFu; }
+DEVINL uint64_t subkey_total(uint64_t k) { return k >> 28; }
+DEVINL uint32_t subkey_idx(uint64_t k) { return (uint32_t)(k >> 8) & 0x3FFFu; }
+DEVINL uint32_t subkey_rank(uint64_t k) { return (uint32_t)k & 3u; }
 
-// ---- node record I/O: lane 0 writes, lane 0 reads, broadcast -----------------------------------------------
-DEVINL void store_rec(NodeRec* dst, uint64_t frozen, uint32_t depth, uint32_t hets, uint32_t anc1, uint32_t anc2,
-                      const Win& w0, const Win& w1) {
+// ---- record I/O: lane 0 writes, lane 0 reads, broadcast (same-lane rule) ---------------------------------------
+DEVINL void store_chunk(ChunkRec* dst, const Win& w0, const Win& w1, uint32_t anc2) {
     if (lane_id() == 0) {
         uint4* d = reinterpret_cast<uint4*>(dst);
-        d[0] = make_uint4((uint32_t)frozen, (uint32_t)(frozen >> 32), depth, hets);
-        d[1] = make_uint4(anc1, anc2, w0.h1, w0.h2);
-        d[2] = make_uint4(w0.nv, w1.h1, w1.h2, w1.nv);
+        d[0] = make_uint4(w0.h1, w0.h2, w0.nv, w1.h1);
+        d[1] = make_uint4(w1.h2, w1.nv, anc2, 0u);
     }
 }
-DEVINL NodeRec load_rec(const NodeRec* src) {
-    uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a;
+DEVINL ChunkRec load_chunk(const ChunkRec* src) {
+    uint4 a = make_uint4(0, 0, 0, 0), b = a;
     if (lane_id() == 0) {
         const uint4* s = reinterpret_cast<const uint4*>(src);
         a = s[0];
         b = s[1];
-        c = s[2];
     }
-    NodeRec r;
-    r.frozen = ((uint64_t)bcast32(a.y) << 32) | bcast32(a.x);
-    r.depth = bcast32(a.z);
-    r.hets = bcast32(a.w);
-    r.anc1 = bcast32(b.x);
-    r.anc2 = bcast32(b.y);
-    r.w0.h1 = bcast32(b.z);
-    r.w0.h2 = bcast32(b.w);
-    r.w0.nv = bcast32(c.x);
-    r.w1.h1 = bcast32(c.y);
-    r.w1.h2 = bcast32(c.z);
-    r.w1.nv = bcast32(c.w);
+    ChunkRec r;
+    r.w0.h1 = bcast32(a.x); r.w0.h2 = bcast32(a.y); r.w0.nv = bcast32(a.z);
+    r.w1.h1 = bcast32(a.w); r.w1.h2 = bcast32(b.x); r.w1.nv = bcast32(b.y);
+    r.anc2 = bcast32(b.z); r.pad = 0;
     return r;
+}
+DEVINL FamRec load_fam(const FamRec* src) {
+    uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, d = a;
+    if (lane_id() == 0) {
+        const uint4* s = reinterpret_cast<const uint4*>(src);
+        a = s[0]; b = s[1]; c = s[2]; d = s[3];
+    }
+    FamRec f;
+    f.frozen = ((uint64_t)bcast32(a.y) << 32) | bcast32(a.x);
+    f.depth_flags = bcast32(a.z); f.hets = bcast32(a.w);
+    f.anc1 = bcast32(b.x); f.anc2 = bcast32(b.y); f.base.h1 = bcast32(b.z); f.base.h2 = bcast32(b.w);
+    f.base.nv = bcast32(c.x); f.w1.h1 = bcast32(c.y); f.w1.h2 = bcast32(c.z); f.w1.nv = bcast32(c.w);
+    f.sumF[0] = bcast32(d.x); f.sumF[1] = bcast32(d.y); f.sumF[2] = bcast32(d.z); f.sumF[3] = bcast32(d.w);
+    return f;
 }
 
 // ---- 64-way sharded heaps: lane l owns elements [j*64 + l] -------------------------------------------------
@@ -265,7 +273,7 @@ struct MainHeap {
         st(i, k);
     }
     DEVINL void push(const Key& k) {
-        const uint32_t tgt = (uint32_t)(k.lo >> 24) & 63u;
+        const uint32_t tgt = (uint32_t)key_idx(k) & 63u;
         if (lane_id() == tgt) {
             if (cnt >= jcap) ovf = 1;
             else {
@@ -310,10 +318,24 @@ DEVINL Cur root_node(uint64_t heur) {
     n.w0 = fresh_win(); n.w1 = fresh_win();
     return n;
 }
-DEVINL Cur cur_from_rec(const NodeRec& r, uint64_t total, uint64_t idx) {
+// rebuilds a queued child from its family record and creation rank (slow path: the node was popped from the heap)
+DEVINL Cur cur_from_fam(const FamRec& f, uint32_t rank, uint64_t total, uint64_t idx, uint32_t off) {
+    const bool bad = (f.depth_flags >> 30) & 1u, has1 = (f.depth_flags >> 31) & 1u;
+    const uint32_t pdepth = f.depth_flags & 0xFFFFFFu;
+    const uint32_t slot = bad ? 0u : (has1 ? rank : (rank == 0 ? 0u : rank + 1u));
+    const uint32_t bit = 1u << ((off + pdepth) & 31u);
     Cur n;
-    n.frozen = r.frozen; n.total = total; n.idx = idx; n.depth = r.depth; n.hets = r.hets;
-    n.anc1 = r.anc1; n.anc2 = r.anc2; n.w0 = r.w0; n.w1 = r.w1;
+    n.frozen = f.frozen + (slot == 0 ? f.sumF[0] : slot == 1 ? f.sumF[1] : slot == 2 ? f.sumF[2] : f.sumF[3]);
+    n.total = total; n.idx = idx; n.depth = pdepth + 1;
+    n.hets = f.hets + ((slot <= 1 && !bad) ? 1u : 0u);
+    n.anc1 = f.anc1; n.anc2 = f.anc2;
+    n.w0 = f.base;
+    if (!bad) {
+        n.w0.nv &= ~bit;
+        if (slot == 1 || slot == 3) n.w0.h1 |= bit;
+        if (slot == 0 || slot == 3) n.w0.h2 |= bit;
+    }
+    n.w1 = f.w1;
     return n;
 }
 
@@ -332,6 +354,14 @@ DEVINL void seg_stamp(WaveCounters& wc, bool on, int which) {
     }
 }
 
+struct Pools {   // per-wave scratch of one search (sub-solver or main)
+    FamRec* fam;        // [cap] indexed by the node_index of an expansion's first child
+    ChunkRec* chunk;    // [cap_chunk] appended at chunk transitions
+    uint32_t cap_chunk;
+    uint32_t n_chunk;   // uniform append cursor
+    uint32_t ovf;       // uniform: chunk pool exhausted
+};
+
 struct Ctx {
     const uint32_t *rstart, *rend, *rword;
     const uint32_t* words;
@@ -347,6 +377,7 @@ struct Kids {
     uint64_t frozen0, frozen1, frozen2, frozen3;
     uint64_t total0, total1, total2, total3;
     uint32_t depth, anc1, anc2, hets_het, hets_hom;
+    uint32_t sumF0, sumF1, sumF2, sumF3;   // frozen increments (what the family record keeps)
     Win base, w1;          // base = parent's window in the child's chunk (fresh when a new chunk opens)
     uint32_t bit;          // 1 << (p & 31)
 };
@@ -372,31 +403,16 @@ template <int S> DEVINL Cur kid_as_cur(const Kids& k, uint64_t next_idx) {
     n.w0 = kid_win<S>(k); n.w1 = k.w1;
     return n;
 }
-template <int S> DEVINL void kid_store(NodeRec* pool, const Kids& k, uint64_t next_idx) {
-    store_rec(pool + (next_idx + kid_rank<S>(k)), kid_frozen<S>(k), k.depth, kid_hets<S>(k), k.anc1, k.anc2, kid_win<S>(k), k.w1);
-}
-
-// All sibling records of one expansion in ONE store instruction: the children have consecutive node indices, so
-// their 48-byte records are contiguous; lane l (< 3*n) writes 16-byte part l%3 of the child of rank l/3.
-// (Only the sub-solver uses this: its heap-pop path re-reads records through lane 0 behind a workgroup fence.)
-DEVINL void kids_store_all(NodeRec* pool, const Kids& k, uint32_t next_idx) {
-    const uint32_t lane = lane_id();
-    const uint32_t rank = lane / 3u, part = lane - rank * 3u;
-    // rank -> slot of hap_order: with the (1,0) child present ranks map 1:1, without it ranks 1,2 are slots 2,3
-    const uint32_t slot = k.bad ? 0u : (k.has1 ? rank : (rank == 0 ? 0u : rank + 1u));
-    const uint64_t frozen = slot == 0 ? k.frozen0 : slot == 1 ? k.frozen1 : slot == 2 ? k.frozen2 : k.frozen3;
-    const uint32_t hets = (slot <= 1 && !k.bad) ? k.hets_het : k.hets_hom;
-    Win w = k.base;
-    if (!k.bad) {
-        w.nv &= ~k.bit;
-        if (slot == 1 || slot == 3) w.h1 |= k.bit;
-        if (slot == 0 || slot == 3) w.h2 |= k.bit;
+// one 64-byte family record per expansion, written by lane 0 at fam[node_index of the first child]
+DEVINL void fam_store(FamRec* fam, const Kids& k, const Cur& parent, uint32_t next_idx) {
+    if (lane_id() == 0) {
+        uint4* d = reinterpret_cast<uint4*>(fam + next_idx);
+        d[0] = make_uint4((uint32_t)parent.frozen, (uint32_t)(parent.frozen >> 32),
+                          parent.depth | (k.bad ? (1u << 30) : 0u) | (k.has1 ? (1u << 31) : 0u), parent.hets);
+        d[1] = make_uint4(k.anc1, k.anc2, k.base.h1, k.base.h2);
+        d[2] = make_uint4(k.base.nv, k.w1.h1, k.w1.h2, k.w1.nv);
+        d[3] = make_uint4(k.sumF0, k.sumF1, k.sumF2, k.sumF3);
     }
-    uint4 x;
-    if (part == 0) x = make_uint4((uint32_t)frozen, (uint32_t)(frozen >> 32), k.depth, hets);
-    else if (part == 1) x = make_uint4(k.anc1, k.anc2, w.h1, w.h2);
-    else x = make_uint4(w.nv, k.w1.h1, k.w1.h2, k.w1.nv);
-    if (lane < 3u * k.n) reinterpret_cast<uint4*>(pool + next_idx)[lane] = x;
 }
 
 // weighted popcount: sum_b popc(M & Q_b) << b   (Horner over the 8 quality bit-planes)
@@ -419,13 +435,19 @@ DEVINL uint32_t wpop(uint32_t M, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t
 // so the O(overlap) part is shared by the children; it is evaluated bit-parallel per 32-variant word.
 // [lo, hi) = candidate rows of variant p (start-sorted), bad = variant ignored.
 DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t lo, uint32_t hi, bool bad,
-                   uint64_t h_next, NodeRec* pool, Kids& kd, WaveCounters& wc, bool prof) {
+                   uint64_t h_next, Pools& pl, Kids& kd, WaveCounters& wc, bool prof) {
     const uint32_t lane = lane_id();
     const uint32_t kp = p >> 5, bp = p & 31u;
     const uint32_t ck = cur.depth ? ((off + cur.depth - 1) >> 5) : (off >> 5);
     const bool trans = (ck != kp);  // the child opens a new 32-variant chunk
-    if (trans)  // cur becomes the holder of a complete chunk that its descendants link to: persist it
-        store_rec(pool + cur.idx, cur.frozen, cur.depth, cur.hets, cur.anc1, cur.anc2, cur.w0, cur.w1);
+    uint32_t new_chunk = NONE32;
+    if (trans) {  // cur's window is a complete chunk that its descendants link to: persist it as a ChunkRec
+        if (pl.n_chunk >= pl.cap_chunk) pl.ovf = 1;
+        else {
+            new_chunk = pl.n_chunk++;
+            store_chunk(pl.chunk + new_chunk, cur.w0, cur.w1, cur.anc2);
+        }
+    }
     const Win W0 = trans ? fresh_win() : cur.w0;
     const Win W1 = trans ? cur.w0 : cur.w1;
     const Win W2 = cur.w1;  // only meaningful when trans
@@ -483,7 +505,7 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
                 else {
                     if (chain_phase == 0) {
                         if (chain_slot == NONE32 || ++guard > (cx.N >> 6) + 4) break;  // nothing older: zero cost
-                        const NodeRec a = load_rec(pool + chain_slot);
+                        const ChunkRec a = load_chunk(pl.chunk + chain_slot);
                         w = a.w0;
                         cw1 = a.w1;
                         chain_next = a.anc2;
@@ -529,13 +551,14 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
     kd.has1 = !bad && cur.hets != 0;
     kd.n = nkids;
     kd.depth = cur.depth + 1;
-    kd.anc1 = trans ? (uint32_t)cur.idx : cur.anc1;
+    kd.anc1 = trans ? new_chunk : cur.anc1;
     kd.anc2 = trans ? cur.anc1 : cur.anc2;
     kd.w1 = W1;
     kd.base = W0;
     kd.bit = 1u << bp;
     kd.hets_het = cur.hets + 1;
     kd.hets_hom = cur.hets;
+    kd.sumF0 = sum[0]; kd.sumF1 = sum[1]; kd.sumF2 = sum[2]; kd.sumF3 = sum[3];
     kd.frozen0 = cur.frozen + sum[0]; kd.total0 = kd.frozen0 + sum[4] + h_next;
     kd.frozen1 = cur.frozen + sum[1]; kd.total1 = kd.frozen1 + sum[5] + h_next;
     kd.frozen2 = cur.frozen + sum[2]; kd.total2 = kd.frozen2 + sum[6] + h_next;
@@ -550,21 +573,15 @@ DEVINL uint64_t ringH_get(uint32_t x) {  // every lane reads the same address: o
 DEVINL void ringH_set(uint32_t x, uint64_t v) {
     if (lane_id() == 0) reinterpret_cast<uint64_t*>(hp_smem + LDS_HRING_OFF)[x & 63u] = v;
 }
-DEVINL void ringV_set(uint32_t x, uint32_t lo, uint32_t hi, uint32_t flags) {
-    if (lane_id() == 0) reinterpret_cast<uint4*>(hp_smem + LDS_VRING_OFF)[x & 63u] = make_uint4(lo, hi, flags, 0);
+DEVINL void ringV_set(uint32_t x, uint32_t lo, uint32_t hi, uint32_t flags) {  // rows per block < 2^28 (host check)
+    if (lane_id() == 0) reinterpret_cast<uint2*>(hp_smem + LDS_VRING_OFF)[x & 63u] = make_uint2(lo, hi | (flags << 28));
 }
-DEVINL void ringV_get(uint32_t x, uint32_t& lo, uint32_t& hi, uint32_t& flags) {
-    const uint4 v = reinterpret_cast<const uint4*>(hp_smem + LDS_VRING_OFF)[x & 63u];
-    lo = bcast32(v.x);
-    hi = bcast32(v.y);
-    flags = bcast32(v.z);
-}
-
 // astar_subsolver (astar_phaser.rs:311-405). Returns status; outputs (max_cost_so_far, farthest).
 template <bool SUB_LDS>
 DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t ps, SubHeap<SUB_LDS>& heap,
-                        NodeRec* pool, WaveCounters& wc, uint64_t& est, uint32_t& solved) {
+                        Pools& pl, WaveCounters& wc, uint64_t& est, uint32_t& solved) {
     heap.reset();
+    pl.n_chunk = 0;
     const bool prof = prm.pad1 != 0;
     seg_stamp(wc, prof, -1);
     uint32_t next_idx = 1;
@@ -582,26 +599,26 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         }
         const uint32_t p = off + cur.depth;
         // both ring reads are issued before either result is consumed
-        const uint4 rv = reinterpret_cast<const uint4*>(hp_smem + LDS_VRING_OFF)[p & 63u];
+        const uint2 rv = reinterpret_cast<const uint2*>(hp_smem + LDS_VRING_OFF)[p & 63u];
         const uint64_t rh = reinterpret_cast<const uint64_t*>(hp_smem + LDS_HRING_OFF)[(p + 1) & 63u];
-        const uint32_t lo = bcast32(rv.x), hi = bcast32(rv.y), flags = bcast32(rv.z);
+        const uint32_t lo = bcast32(rv.x), hiw = bcast32(rv.y), hi = hiw & 0x0FFFFFFFu, flags = hiw >> 28;
         Kids kd;
         seg_stamp(wc, prof, 0);       // [0] loop head + LDS ring reads
-        expand(cx, cur, off, p, lo, hi, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pool, kd, wc, prof);
+        expand(cx, cur, off, p, lo, hi, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, prof);
         wc.nodes += kd.n;
         if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
         if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
         // keys of the (up to 4) children; invalid slots get the infinite key
-        const uint64_t k0 = make_subkey(kd.total0, kid_hets<0>(kd), next_idx + kid_rank<0>(kd), kd.depth);
-        const uint64_t k1 = kid_valid<1>(kd) ? make_subkey(kd.total1, kid_hets<1>(kd), next_idx + kid_rank<1>(kd), kd.depth) : ~0ull;
-        const uint64_t k2 = kid_valid<2>(kd) ? make_subkey(kd.total2, kid_hets<2>(kd), next_idx + kid_rank<2>(kd), kd.depth) : ~0ull;
-        const uint64_t k3 = kid_valid<3>(kd) ? make_subkey(kd.total3, kid_hets<3>(kd), next_idx + kid_rank<3>(kd), kd.depth) : ~0ull;
+        const uint64_t k0 = make_subkey(kd.total0, kid_hets<0>(kd), next_idx + kid_rank<0>(kd), kid_rank<0>(kd), kd.depth);
+        const uint64_t k1 = kid_valid<1>(kd) ? make_subkey(kd.total1, kid_hets<1>(kd), next_idx + kid_rank<1>(kd), kid_rank<1>(kd), kd.depth) : ~0ull;
+        const uint64_t k2 = kid_valid<2>(kd) ? make_subkey(kd.total2, kid_hets<2>(kd), next_idx + kid_rank<2>(kd), kid_rank<2>(kd), kd.depth) : ~0ull;
+        const uint64_t k3 = kid_valid<3>(kd) ? make_subkey(kd.total3, kid_hets<3>(kd), next_idx + kid_rank<3>(kd), kid_rank<3>(kd), kd.depth) : ~0ull;
         const uint64_t kbest = umin64(umin64(k0, k1), umin64(k2, k3));
         // If the best child beats everything queued it is the next pop: keep it in registers (push + pop elided;
         // the priority is a total order, so this is exactly what the reference's queue would return).
         const bool take_child = kbest < heap.top;
         seg_stamp(wc, prof, 4);   // [4] child totals + keys
-        kids_store_all(pool, kd, next_idx);  // every sibling (the kept one too: harmless) in one 16 B/lane store
+        fam_store(pl.fam, kd, cur, next_idx);  // one 64-byte record for all siblings
         heap.push4((take_child && k0 == kbest) ? ~0ull : k0, (take_child && k1 == kbest) ? ~0ull : k1,
                    (take_child && k2 == kbest) ? ~0ull : k2, (take_child && k3 == kbest) ? ~0ull : k3);
         if (take_child) {
@@ -612,13 +629,11 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         } else {
             const uint64_t t = heap.top;
             heap.pop();
-            // records were written by lanes 0..11 (kids_store_all) and are re-read by lane 0: order the accesses
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            cur = cur_from_rec(load_rec(pool + subkey_idx(t)), subkey_total(t), subkey_idx(t));
+            cur = cur_from_fam(load_fam(pl.fam + (subkey_idx(t) - subkey_rank(t))), subkey_rank(t), subkey_total(t), subkey_idx(t), off);
         }
         next_idx += kd.n;
         seg_stamp(wc, prof, 5);   // [5] record store + heap pushes (+ pop on the slow path)
-        if (__any(heap.ovf)) { st = ST_OVERFLOW; break; }
+        if (__any(heap.ovf) || pl.ovf) { st = ST_OVERFLOW; break; }
     }
     if (cur.depth == ps) {  // astar_phaser.rs:395-399 (peek, not pop)
         max_cost = max(max_cost, cur.total);
@@ -643,8 +658,17 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
     cx.words = B.words + d.word_off * WORD_DWORDS;
     cx.N = N; cx.evals = 0; cx.cells = 0;
     uint64_t* H = B.H + d.h_off;
-    NodeRec* sub_pool = B.sub_pool + (size_t)slot * prm.cap_sub;
-    NodeRec* main_pool = B.main_pool + (size_t)slot * prm.cap_main;
+    Pools subp, mainp;
+    {
+        unsigned char* sb = B.sub_pool + (size_t)slot * ((size_t)prm.cap_sub * sizeof(FamRec) + (size_t)prm.cap_chunk_sub * sizeof(ChunkRec));
+        subp.fam = reinterpret_cast<FamRec*>(sb);
+        subp.chunk = reinterpret_cast<ChunkRec*>(sb + (size_t)prm.cap_sub * sizeof(FamRec));
+        subp.cap_chunk = prm.cap_chunk_sub; subp.n_chunk = 0; subp.ovf = 0;
+        unsigned char* mb = B.main_pool + (size_t)slot * ((size_t)prm.cap_main * sizeof(FamRec) + (size_t)prm.cap_chunk_main * sizeof(ChunkRec));
+        mainp.fam = reinterpret_cast<FamRec*>(mb);
+        mainp.chunk = reinterpret_cast<ChunkRec*>(mb + (size_t)prm.cap_main * sizeof(FamRec));
+        mainp.cap_chunk = prm.cap_chunk_main; mainp.n_chunk = 0; mainp.ovf = 0;
+    }
     uint32_t* tracker = B.tracker + (size_t)slot * ((size_t)prm.max_n_vars + 1);
     WaveCounters wc{0, 0, 0, {0, 0, 0, 0, 0, 0}, 0};
     int32_t st = ST_OK;
@@ -668,7 +692,7 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
             ringV_set(v, l, h, fl);
             uint64_t est = 0;
             uint32_t solved = 0;
-            st = subsolve<SUB_LDS>(cx, prm, v, clip, sub, sub_pool, wc, est, solved);
+            st = subsolve<SUB_LDS>(cx, prm, v, clip, sub, subp, wc, est, solved);
             if (st != ST_OK) break;
             if (solved < min(clip, 2u)) { st = ST_INVARIANT; break; }  // astar_phaser.rs:268
             const bool bad = (fl & HP_VAR_IGNORED) != 0;
@@ -743,7 +767,7 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
                 if (hq.empty()) { st = ST_INVARIANT; break; }
                 const Key t = hq.top;
                 hq.pop();
-                cur = cur_from_rec(load_rec(main_pool + (t.lo >> 24)), t.hi >> 24, t.lo >> 24);
+                cur = cur_from_fam(load_fam(mainp.fam + (key_idx(t) - key_rank(t))), key_rank(t), t.hi >> 24, key_idx(t), 0);
                 continue;
             }
             const uint32_t p = cur.depth;
@@ -752,14 +776,14 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
             if (lane == 0) { fl = vflags[p]; l = vlo[p]; h = vhi[p]; hn = H[p + 1]; }
             fl = bcast32(fl); l = bcast32(l); h = bcast32(h); hn = bcast64(hn);
             Kids kd;
-            expand(cx, cur, 0, p, l, h, (fl & HP_VAR_IGNORED) != 0, hn, main_pool, kd, wc, false);
+            expand(cx, cur, 0, p, l, h, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, false);
             wc.nodes += kd.n;
             if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; break; }
             if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:529
-            const Key k0 = make_key(kd.total0, kid_hets<0>(kd), next_idx + kid_rank<0>(kd), kd.depth);
-            const Key k1 = kid_valid<1>(kd) ? make_key(kd.total1, kid_hets<1>(kd), next_idx + kid_rank<1>(kd), kd.depth) : key_inf();
-            const Key k2 = kid_valid<2>(kd) ? make_key(kd.total2, kid_hets<2>(kd), next_idx + kid_rank<2>(kd), kd.depth) : key_inf();
-            const Key k3 = kid_valid<3>(kd) ? make_key(kd.total3, kid_hets<3>(kd), next_idx + kid_rank<3>(kd), kd.depth) : key_inf();
+            const Key k0 = make_key(kd.total0, kid_hets<0>(kd), next_idx + kid_rank<0>(kd), kid_rank<0>(kd), kd.depth);
+            const Key k1 = kid_valid<1>(kd) ? make_key(kd.total1, kid_hets<1>(kd), next_idx + kid_rank<1>(kd), kid_rank<1>(kd), kd.depth) : key_inf();
+            const Key k2 = kid_valid<2>(kd) ? make_key(kd.total2, kid_hets<2>(kd), next_idx + kid_rank<2>(kd), kid_rank<2>(kd), kd.depth) : key_inf();
+            const Key k3 = kid_valid<3>(kd) ? make_key(kd.total3, kid_hets<3>(kd), next_idx + kid_rank<3>(kd), kid_rank<3>(kd), kd.depth) : key_inf();
             int best = 0;
             Key kbest = k0;
             if (key_less(k1, kbest)) { kbest = k1; best = 1; }
@@ -767,10 +791,11 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
             if (key_less(k3, kbest)) { kbest = k3; best = 3; }
             // push every child except the best one, which is held in registers (it is logically queued)
             trk_add(kd.depth, kd.n);
-            if (best != 0) { kid_store<0>(main_pool, kd, next_idx); hq.push(k0); }
-            if (kid_valid<1>(kd) && best != 1) { kid_store<1>(main_pool, kd, next_idx); hq.push(k1); }
-            if (kid_valid<2>(kd) && best != 2) { kid_store<2>(main_pool, kd, next_idx); hq.push(k2); }
-            if (kid_valid<3>(kd) && best != 3) { kid_store<3>(main_pool, kd, next_idx); hq.push(k3); }
+            fam_store(mainp.fam, kd, cur, (uint32_t)next_idx);
+            if (best != 0) hq.push(k0);
+            if (kid_valid<1>(kd) && best != 1) hq.push(k1);
+            if (kid_valid<2>(kd) && best != 2) hq.push(k2);
+            if (kid_valid<3>(kd) && best != 3) hq.push(k3);
             qlen += kd.n;
             // astar_phaser.rs:564-585
             while (trk_total > thr && min_progress < next_expected) {
@@ -803,17 +828,13 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
                 else cur = kid_as_cur<3>(kd, next_idx);
                 cur.total = kbest.hi >> 24;
             } else {
-                if (best == 0) kid_store<0>(main_pool, kd, next_idx);
-                else if (best == 1) kid_store<1>(main_pool, kd, next_idx);
-                else if (best == 2) kid_store<2>(main_pool, kd, next_idx);
-                else kid_store<3>(main_pool, kd, next_idx);
                 hq.push(kbest);
                 const Key t = hq.top;
                 hq.pop();
-                cur = cur_from_rec(load_rec(main_pool + (t.lo >> 24)), t.hi >> 24, t.lo >> 24);
+                cur = cur_from_fam(load_fam(mainp.fam + (key_idx(t) - key_rank(t))), key_rank(t), t.hi >> 24, key_idx(t), 0);
             }
             next_idx += kd.n;
-            if (__any(hq.ovf)) { st = ST_OVERFLOW_MAIN; break; }
+            if (__any(hq.ovf) || mainp.ovf) { st = ST_OVERFLOW_MAIN; break; }
         }
 
         if (st == ST_OK) {
@@ -847,7 +868,7 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
                     have_wn = false;
                 } else {
                     if (slot_next == NONE32) { st = ST_INVARIANT; break; }
-                    const NodeRec a = load_rec(main_pool + slot_next);
+                    const ChunkRec a = load_chunk(mainp.chunk + slot_next);
                     w = a.w0;
                     wn = a.w1;
                     slot_next = a.anc2;
@@ -888,7 +909,7 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
 }
 
 template <bool SUB_LDS>
-__global__ void __launch_bounds__(64) hp_astar_kernel(BatchDev B) {
+__global__ void __launch_bounds__(64, 5) hp_astar_kernel(BatchDev B) {
     const uint32_t slot = blockIdx.x;
     const uint32_t G = gridDim.x;
     // Static "snake" assignment over the LPT-sorted work list: workgroup w takes ranks w, 2G-1-w, 2G+w, ...
