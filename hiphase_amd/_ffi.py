@@ -127,6 +127,7 @@ EXPORTS = [
     "hp_batch_create",
     "hp_batch_solve",
     "hp_batch_results",
+    "hp_batch_postprocess",
     "hp_batch_destroy",
     "hp_wfa_assign_batch",
     "hp_edit_distance_batch",
@@ -174,6 +175,8 @@ def lib():
     dll.hp_batch_solve.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     dll.hp_batch_results.restype = C.c_int
     dll.hp_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    dll.hp_batch_postprocess.restype = C.c_int
+    dll.hp_batch_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     dll.hp_batch_destroy.restype = None
     dll.hp_batch_destroy.argtypes = [C.c_void_p]
     dll.hp_wfa_assign_batch.restype = C.c_int

@@ -57,6 +57,7 @@ class ResidentBatch:
         dll = _ffi.lib()
         self._dll = dll
         self.n_vars = [b.n_variants for b in blocks]
+        self.n_reads = [b.n_reads for b in blocks]
         n = len(blocks)
         views = (_ffi.BlockView * n)(*[b.view() for b in blocks])
         p = _params(min_queue_size, queue_increment, max_segment_size)
@@ -88,6 +89,21 @@ class ResidentBatch:
             ho = np.concatenate([[0], np.cumsum([n + 1 for n in self.n_vars])])
             hs = [heur[ho[i]:ho[i + 1]] for i in range(self.n_blocks)]
         return res, list(ctr), hs
+
+    def postprocess(self):
+        """hp_batch_postprocess -> per block (span_counts[N-1], haplotag[R], first_het[R]) in caller row order."""
+        nj = sum(max(n - 1, 0) for n in self.n_vars)
+        nr = sum(self.n_reads)
+        spans = np.zeros(max(nj, 1), np.uint64)
+        ht = np.zeros(max(nr, 1), np.uint8)
+        fh = np.zeros(max(nr, 1), np.uint32)
+        _ffi.check(self._dll.hp_batch_postprocess(self._h, spans.ctypes.data, ht.ctypes.data, fh.ctypes.data))
+        out, jo, ro = [], 0, 0
+        for n, r in zip(self.n_vars, self.n_reads):
+            out.append((spans[jo:jo + max(n - 1, 0)], ht[ro:ro + r], fh[ro:ro + r]))
+            jo += max(n - 1, 0)
+            ro += r
+        return out
 
     def close(self):
         if self._h:

@@ -25,6 +25,11 @@ struct HostPack {
     std::vector<uint32_t> rstart, rend, rword;
     std::vector<uint32_t> words;
     std::vector<uint64_t> work;  // LPT estimate per block
+    std::vector<uint32_t> row_block;   // packed row -> block
+    std::vector<uint32_t> row_orig;    // packed row -> caller's row index inside its block
+    std::vector<uint64_t> caller_row_off;  // per block: offset of its rows in the caller's concatenated order
+    uint64_t caller_rows = 0;
+    uint64_t chunk_total = 0;
     uint64_t h_total = 0;
     uint32_t max_n = 0;
 };
@@ -65,6 +70,11 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     d.word_off = hpk.words.size() / WORD_DWORDS;
     d.h_off = hpk.h_total;
     hpk.h_total += (uint64_t)N + 1;
+    d.chunk_off = hpk.chunk_total;
+    hpk.chunk_total += ((uint64_t)N + 31) / 32;
+    hpk.caller_row_off.push_back(hpk.caller_rows);
+    hpk.caller_rows += R;
+    const uint32_t blk_index = (uint32_t)hpk.desc.size();
 
     const size_t v0 = hpk.vlo.size();
     hpk.vlo.resize(v0 + N, 0xFFFFFFFFu);
@@ -80,6 +90,8 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
         if (n_words > 0xFFFFFFF0ull) { set_error("block too large (plane words)"); return HP_ERR_UNSUPPORTED; }
         hpk.rstart.push_back(s);
         hpk.rend.push_back(e);
+        hpk.row_block.push_back(blk_index);
+        hpk.row_orig.push_back(r);
         hpk.rword.push_back((uint32_t)n_words);
         const size_t w0 = hpk.words.size();
         hpk.words.resize(w0 + (size_t)(k1 - k0 + 1) * WORD_DWORDS, 0);
@@ -161,7 +173,13 @@ struct hp_batch {
     // device inputs
     DevBuf d_desc, d_order, d_vlo, d_vhi, d_vflags, d_rstart, d_rend, d_rword, d_words, d_head;
     // device outputs
-    DevBuf d_H, d_h1, d_h2, d_stats, d_counters, d_status;
+    DevBuf d_H, d_h1, d_h2, d_stats, d_counters, d_status, d_hapw;
+    // post-processing (phaser.rs:350-388, :714-750)
+    DevBuf d_row_block, d_haplotag, d_first_het, d_js, d_je, d_junc_block, d_junc_off, d_span;
+    std::vector<uint32_t> row_orig, row_block_h;
+    std::vector<uint64_t> caller_row_off;
+    uint64_t caller_rows = 0, n_rows_packed = 0, n_junctures = 0;
+    bool solved = false;
     // scratch (sized on first solve, kept)
     DevBuf s_sub_pool, s_main_pool, s_sub_heap, s_main_heap, s_tracker;
     uint32_t scratch_slots = 0, scratch_cap_main = 0;
@@ -230,7 +248,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     B.vlo = b->d_vlo.as<uint32_t>(); B.vhi = b->d_vhi.as<uint32_t>(); B.vflags = b->d_vflags.as<uint8_t>();
     B.rstart = b->d_rstart.as<uint32_t>(); B.rend = b->d_rend.as<uint32_t>(); B.rword = b->d_rword.as<uint32_t>();
     B.words = b->d_words.as<uint32_t>();
-    B.H = b->d_H.as<uint64_t>(); B.h1 = b->d_h1.as<uint8_t>(); B.h2 = b->d_h2.as<uint8_t>();
+    B.H = b->d_H.as<uint64_t>(); B.h1 = b->d_h1.as<uint8_t>(); B.h2 = b->d_h2.as<uint8_t>(); B.hapw = b->d_hapw.as<Win>();
     B.stats = b->d_stats.as<hp_phase_stats>(); B.counters = b->d_counters.as<hp_work_counters>();
     B.status = b->d_status.as<int32_t>();
     B.sub_pool = sub_pool.as<unsigned char>(); B.main_pool = main_pool.as<unsigned char>();
@@ -272,6 +290,11 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     b->max_n = hpk.max_n;
     b->sum_h = hpk.h_total;
     b->sum_n = hpk.vlo.size();
+    b->row_orig = hpk.row_orig;
+    b->row_block_h = hpk.row_block;
+    b->caller_row_off = hpk.caller_row_off;
+    b->caller_rows = hpk.caller_rows;
+    b->n_rows_packed = hpk.row_block.size();
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) b->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(HP_ERR_HIP); }
@@ -299,6 +322,8 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     UP(d_desc, desc); UP(d_vlo, vlo); UP(d_vhi, vhi); UP(d_vflags, vflags);
     UP(d_rstart, rstart); UP(d_rend, rend); UP(d_rword, rword); UP(d_words, words);
 #undef UP
+    if ((rc = upload(b->d_row_block, hpk.row_block, s)) != HP_OK) return fail(rc);
+    if ((rc = b->d_hapw.alloc(hpk.chunk_total * sizeof(Win) + 16)) != HP_OK) return fail(rc);
     if ((rc = b->d_head.alloc(16)) != HP_OK) return fail(rc);
     if ((rc = b->d_H.alloc(b->sum_h * 8)) != HP_OK) return fail(rc);
     if ((rc = b->d_h1.alloc(b->sum_n)) != HP_OK) return fail(rc);
@@ -360,7 +385,9 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     }
     if (kernel_ms) *kernel_ms = ms_total;
     g_last_kernel_ms = ms_total;
+    b->solved = true;
     for (size_t i = 0; i < status.size(); ++i) {
+        if (status[i] != ST_OK) b->solved = false;
         if (status[i] == ST_INVARIANT) {
             set_error("block %zu: solver invariant violated (the reference would panic/assert, astar_phaser.rs:268,284,360,529,631)", i);
             return HP_ERR_INVARIANT;
@@ -378,6 +405,69 @@ int hp_batch_results(hp_batch* b, uint8_t* h1, uint8_t* h2, hp_phase_stats* stat
     if (stats) HP_HIP_CHECK(hipMemcpy(stats, b->d_stats.p, b->n_blocks * sizeof(hp_phase_stats), hipMemcpyDeviceToHost));
     if (counters) HP_HIP_CHECK(hipMemcpy(counters, b->d_counters.p, b->n_blocks * sizeof(hp_work_counters), hipMemcpyDeviceToHost));
     if (heuristics) HP_HIP_CHECK(hipMemcpy(heuristics, b->d_H.p, b->sum_h * 8, hipMemcpyDeviceToHost));
+    return HP_OK;
+}
+
+int hp_batch_postprocess(hp_batch* b, uint64_t* span_counts, uint8_t* haplotag, uint32_t* first_het) {
+    if (!b) { set_error("null batch"); return HP_ERR_ARG; }
+    if (!b->solved) { set_error("hp_batch_postprocess needs a successful hp_batch_solve first"); return HP_ERR_ARG; }
+    HP_HIP_CHECK(hipSetDevice(b->device));
+    hipStream_t st = b->stream;
+    int rc;
+    if (!b->d_js.p) {
+        std::vector<uint32_t> junc_block;
+        std::vector<uint64_t> junc_off(b->n_blocks);
+        uint64_t nj = 0;
+        for (size_t i = 0; i < b->n_blocks; ++i) {
+            junc_off[i] = nj;
+            const uint32_t n = b->desc[i].n_vars;
+            for (uint32_t j = 0; j + 1 < n; ++j) junc_block.push_back((uint32_t)i);
+            nj += n > 0 ? n - 1 : 0;
+        }
+        b->n_junctures = nj;
+        if ((rc = upload(b->d_junc_block, junc_block, st)) != HP_OK) return rc;
+        if ((rc = upload(b->d_junc_off, junc_off, st)) != HP_OK) return rc;
+        if ((rc = b->d_haplotag.alloc(b->n_rows_packed + 16)) || (rc = b->d_first_het.alloc(b->n_rows_packed * 4 + 16)) ||
+            (rc = b->d_js.alloc(b->n_rows_packed * 4 + 16)) || (rc = b->d_je.alloc(b->n_rows_packed * 4 + 16)) ||
+            (rc = b->d_span.alloc(nj * 8 + 16)))
+            return rc;
+    }
+    PostDev P{};
+    P.desc = b->d_desc.as<BlockDesc>(); P.row_block = b->d_row_block.as<uint32_t>();
+    P.rstart = b->d_rstart.as<uint32_t>(); P.rend = b->d_rend.as<uint32_t>(); P.rword = b->d_rword.as<uint32_t>();
+    P.words = b->d_words.as<uint32_t>(); P.vlo = b->d_vlo.as<uint32_t>(); P.vhi = b->d_vhi.as<uint32_t>();
+    P.hapw = b->d_hapw.as<Win>(); P.n_rows_total = (uint32_t)b->n_rows_packed; P.n_junctures_total = b->n_junctures;
+    P.haplotag = b->d_haplotag.as<uint8_t>(); P.first_het = b->d_first_het.as<uint32_t>();
+    P.js = b->d_js.as<uint32_t>(); P.je = b->d_je.as<uint32_t>();
+    P.junc_block = b->d_junc_block.as<uint32_t>(); P.junc_off = b->d_junc_off.as<uint64_t>(); P.span_counts = b->d_span.as<uint64_t>();
+    HP_HIP_CHECK(hipEventRecord(b->ev0, st));
+    if (b->n_rows_packed)
+        hipLaunchKernelGGL(hp_post_rows_kernel, dim3((unsigned)((b->n_rows_packed + 255) / 256)), dim3(256), 0, st, P);
+    if (b->n_junctures)
+        hipLaunchKernelGGL(hp_post_spans_kernel, dim3((unsigned)((b->n_junctures + 255) / 256)), dim3(256), 0, st, P);
+    HP_HIP_CHECK(hipGetLastError());
+    HP_HIP_CHECK(hipEventRecord(b->ev1, st));
+    HP_HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HP_HIP_CHECK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    g_last_kernel_ms = ms;
+    if (span_counts && b->n_junctures) HP_HIP_CHECK(hipMemcpy(span_counts, b->d_span.p, b->n_junctures * 8, hipMemcpyDeviceToHost));
+    if (haplotag || first_het) {
+        std::vector<uint8_t> ht(b->n_rows_packed + 1);
+        std::vector<uint32_t> fh(b->n_rows_packed + 1);
+        if (b->n_rows_packed) {
+            HP_HIP_CHECK(hipMemcpy(ht.data(), b->d_haplotag.p, b->n_rows_packed, hipMemcpyDeviceToHost));
+            HP_HIP_CHECK(hipMemcpy(fh.data(), b->d_first_het.p, b->n_rows_packed * 4, hipMemcpyDeviceToHost));
+        }
+        // back to the caller's row order; inert rows (start == end) are untagged
+        if (haplotag) std::memset(haplotag, 2, b->caller_rows);
+        if (first_het) for (uint64_t i = 0; i < b->caller_rows; ++i) first_het[i] = 0xFFFFFFFFu;
+        for (uint64_t r = 0; r < b->n_rows_packed; ++r) {
+            const uint64_t dst = b->caller_row_off[b->row_block_h[r]] + b->row_orig[r];
+            if (haplotag) haplotag[dst] = ht[r];
+            if (first_het) first_het[dst] = fh[r];
+        }
+    }
     return HP_OK;
 }
 

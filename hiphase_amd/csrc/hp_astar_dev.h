@@ -32,6 +32,7 @@ struct BlockDesc {
     uint64_t h_off;     // into H
     uint32_t max_cov;   // max over p of vhi-vlo
     uint32_t n_words;
+    uint64_t chunk_off; // into hapw (one Win per 32-variant chunk of the solution)
 };
 
 // Priority key (astar_phaser.rs:131-133): min total cost, then MORE hets, then OLDER node.
@@ -106,6 +107,7 @@ struct BatchDev {
     const uint32_t* words;
     uint64_t* H;
     uint8_t *h1, *h2;
+    Win* hapw;            // packed solution windows, written at emission (input of the post-processing kernels)
     hp_phase_stats* stats;
     hp_work_counters* counters;
     int32_t* status;

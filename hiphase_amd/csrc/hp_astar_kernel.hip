@@ -851,6 +851,7 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
                 const bool inb = lane < 32 && pos < N;
                 const uint32_t bit = lane & 31u;
                 const uint32_t nvb = (w.nv >> bit) & 1u, b1 = (w.h1 >> bit) & 1u, b2 = (w.h2 >> bit) & 1u;
+                if (lane == 0) B.hapw[d.chunk_off + chunk] = w;
                 if (inb) {
                     o1[pos] = nvb ? 2 : (uint8_t)b1;
                     o2[pos] = nvb ? 2 : (uint8_t)b2;
@@ -906,6 +907,80 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
         B.counters[blk] = c;
         B.status[blk] = st;
     }
+}
+
+// ---- post-processing on the resident matrix (reference src/phaser.rs:350-388 and :714-750) ---------------------
+// Kernel A, one thread per packed row: scores the row against both solved haplotypes (haplotag_reads), finds the
+// first het it resolves, and the juncture range [js, je) it supports after trimming solution-homozygous ends.
+struct PostDev {
+    const BlockDesc* desc;
+    const uint32_t* row_block;   // packed row -> block
+    const uint32_t *rstart, *rend, *rword;
+    const uint32_t* words;
+    const uint32_t *vlo, *vhi;
+    const Win* hapw;
+    uint32_t n_rows_total;
+    uint64_t n_junctures_total;
+    uint8_t* haplotag;     // per packed row: 0 / 1 / 2 (untagged)
+    uint32_t* first_het;   // per packed row: block-local index of the first resolved het (NONE32 when untagged)
+    uint32_t *js, *je;     // per packed row
+    const uint32_t* junc_block;  // juncture -> block
+    const uint64_t* junc_off;    // per block: first juncture index
+    uint64_t* span_counts;       // per juncture
+};
+
+__global__ void __launch_bounds__(256) hp_post_rows_kernel(PostDev P) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.n_rows_total) return;
+    const BlockDesc d = P.desc[P.row_block[r]];
+    const uint32_t rs = P.rstart[r], re = P.rend[r];
+    const uint32_t* wbase = P.words + (d.word_off + P.rword[r]) * (size_t)WORD_DWORDS;
+    const Win* hw = P.hapw + d.chunk_off;
+    uint32_t s1 = 0, s2 = 0, fh = NONE32, firstD = NONE32, lastD = NONE32;
+    const uint32_t k0 = rs >> 5, k1 = (re - 1) >> 5;
+    for (uint32_t k = k0; k <= k1; ++k) {
+        const uint4* pw = reinterpret_cast<const uint4*>(wbase + (size_t)(k - k0) * WORD_DWORDS);
+        const uint4 x0 = pw[0], x1 = pw[1], x2 = pw[2];
+        const Win w = hw[k];
+        uint32_t rmask = 0xFFFFFFFFu;
+        if (k == k0) rmask &= 0xFFFFFFFFu << (rs & 31u);
+        if (k == k1 && (re & 31u)) rmask &= 0xFFFFFFFFu >> (32u - (re & 31u));
+        const uint32_t M1 = ~w.nv & ((x0.x ^ w.h1) | x0.y) & rmask;
+        const uint32_t M2 = ~w.nv & ((x0.x ^ w.h2) | x0.y) & rmask;
+        s1 += wpop(M1, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
+        s2 += wpop(M2, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y);
+        const uint32_t D = ~w.nv & (w.h1 ^ w.h2) & rmask;   // solution is heterozygous here
+        if (D) {
+            if (firstD == NONE32) firstD = k * 32 + (uint32_t)__builtin_ctz(D);
+            lastD = k * 32 + 31u - (uint32_t)__builtin_clz(D);
+            const uint32_t R = D & ~x0.y;                    // ... and the row's allele is set (0/1)
+            if (R && fh == NONE32) fh = k * 32 + (uint32_t)__builtin_ctz(R);
+        }
+    }
+    const uint8_t tag = s1 < s2 ? 0 : (s1 > s2 ? 1 : 2);
+    P.haplotag[r] = tag;
+    P.first_het[r] = tag == 2 ? NONE32 : fh;
+    // get_solution_span_counts: junctures [rs, re-1); skip homozygous positions at both ends
+    uint32_t js = (firstD != NONE32 && firstD < re - 1) ? firstD : re - 1;
+    uint32_t je = (lastD != NONE32 && lastD > js) ? lastD : js;
+    P.js[r] = js;
+    P.je[r] = je;
+}
+
+// Kernel B, one thread per juncture: number of rows whose trimmed range covers it (no atomics).
+__global__ void __launch_bounds__(256) hp_post_spans_kernel(PostDev P) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P.n_junctures_total) return;
+    const uint32_t blk = P.junc_block[g];
+    const BlockDesc d = P.desc[blk];
+    const uint32_t j = (uint32_t)(g - P.junc_off[blk]);
+    const uint32_t lo = P.vlo[d.var_off + j], hi = P.vhi[d.var_off + j];
+    uint64_t c = 0;
+    for (uint32_t r = lo; r < hi; ++r) {
+        const uint64_t gr = d.read_off + r;
+        c += (P.js[gr] <= j && j < P.je[gr]) ? 1u : 0u;
+    }
+    P.span_counts[g] = c;
 }
 
 template <bool SUB_LDS>

@@ -7,6 +7,7 @@
  *   - src/read_parsing.rs:769-780      WFAGraph::from_reference_variants_with_hom + edit_distance_with_pruning
  *                                                                                  -> hp_wfa_assign_batch
  *   - src/data_types/variants.rs:627   sequence_alignment::edit_distance           -> hp_edit_distance_batch
+ *   - src/phaser.rs:546,614-623        get_solution_span_counts / haplotag_reads   -> hp_batch_postprocess
  * INTEGRATION.md shows the `extern "C"` block + call-site patch a HiPhase maintainer would add.
  *
  * Conventions: plain pointers and sizes, caller owns every buffer, no pointer outlives a call
@@ -119,6 +120,13 @@ int  hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms);
  * (sum N_i bytes); stats/counters: [n_blocks]. */
 int  hp_batch_results(hp_batch* b, uint8_t* h1, uint8_t* h2, hp_phase_stats* stats,
                       hp_work_counters* counters, uint64_t* heuristics /* sum (N_i+1) or NULL */);
+/* Post-processing on the resident matrix after a successful hp_batch_solve (reference src/phaser.rs:350-388
+ * get_solution_span_counts and :714-750 haplotag_reads). Any pointer may be NULL.
+ *   span_counts: concatenated over blocks, N_i - 1 junctures each;
+ *   haplotag / first_het: concatenated over blocks in the CALLER's row order (R_i each): haplotag 0 / 1, or 2 =
+ *   untagged (tie); first_het = block-local index of the first het the row resolves (UINT32_MAX when untagged).
+ *   The caller looks block_tags[first_het] up itself (phaser.rs:740) — tags need variant positions. */
+int  hp_batch_postprocess(hp_batch* b, uint64_t* span_counts, uint8_t* haplotag, uint32_t* first_het);
 void hp_batch_destroy(hp_batch* b);
 
 /* ---- graph-WFA allele assignment ---------------------------------------------------------- */

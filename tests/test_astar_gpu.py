@@ -182,3 +182,101 @@ def test_many_c2_blocks_properties():
             tot += min(s)
         assert tot == r.statistics.actual_cost
         assert r.statistics.actual_cost >= r.statistics.estimated_cost
+
+
+def test_random_stress_vs_oracle():
+    """Many small random blocks x several queue parameter sets (rare paths: full prune, chunk transitions,
+    main-search scratch retry, ignored variants, rows longer than 3 chunks, coverage > 64)."""
+    from hiphase_amd._ffi import HpError
+    rng = np.random.default_rng(2025)
+    param_sets = [(1000, 3), (200, 2), (60, 1), (25, 1)]
+    for pi, (minq, qinc) in enumerate(param_sets):
+        blocks, expect = [], []
+        for i in range(40):
+            n = int(rng.integers(1, 260))
+            c = int(rng.integers(2, 90))
+            s = int(rng.integers(2, 110))
+            e = float(rng.choice([0.0, 0.01, 0.05, 0.15, 0.3]))
+            a = float(rng.choice([0.0, 0.02, 0.1]))
+            ign = int(rng.choice([0, 0, 60]))
+            blk, _ = synth_block(n, c, s, e, a, 9000 + 100 * pi + i, ignored_permille=ign)
+            try:
+                exp = oracle_solve(blk, min_queue_size=minq, queue_increment=qinc, want_heuristics=True)
+            except HpError as err:
+                assert err.code == -3
+                with pytest.raises(HpError):
+                    astar_solver(0, blk, min_queue_size=minq, queue_increment=qinc)
+                continue
+            blocks.append(blk)
+            expect.append(exp)
+        rb = ResidentBatch(blocks, min_queue_size=minq, queue_increment=qinc)
+        rb.solve()
+        res, ctrs, heur = rb.results(want_heuristics=True)
+        rb.close()
+        for k, (r, c, h, exp) in enumerate(zip(res, ctrs, heur, expect)):
+            h1, h2, st, octr, oh = exp
+            assert np.array_equal(r.haplotype_1, h1) and np.array_equal(r.haplotype_2, h2), (pi, k)
+            assert r.statistics.as_tuple() == st, (pi, k)
+            assert np.array_equal(h, oh), (pi, k)
+            assert c.as_tuple() == octr, (pi, k, c.as_tuple(), octr)
+
+
+def test_threads_are_reentrant():
+    """The ABI is called from HiPhase's --threads pool (main.rs:332,385): concurrent callers, each with its own
+    blocks, must all get the oracle's answers."""
+    import threading
+    blocks = [synth_block(120 + 7 * i, 20, 15, 0.03, 0.02, 4000 + i)[0] for i in range(12)]
+    expect = [oracle_solve(b)[:3] for b in blocks]
+    errors = []
+
+    def work(tid):
+        try:
+            for rep in range(3):
+                for i in range(tid, len(blocks), 4):
+                    r = astar_solver(i, blocks[i])
+                    h1, h2, st = expect[i]
+                    assert np.array_equal(r.haplotype_1, h1) and np.array_equal(r.haplotype_2, h2)
+                    assert r.statistics.as_tuple() == st
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
+def test_postprocess_span_counts_and_haplotags():
+    """hp_batch_postprocess == get_solution_span_counts (phaser.rs:350-388) + haplotag_reads (phaser.rs:714-750)
+    of the oracle, on the golden fixtures' shapes and on noisy synthetic blocks (homozygous calls, ignored
+    variants, inert rows, ties)."""
+    g = load_golden("phaser.json")
+    blocks = [synth_block(n, c, s, e, 0.05, 600 + i, ignored_permille=ign)[0]
+              for i, (n, c, s, e, ign) in enumerate([(200, 30, 20, 0.15, 0), (90, 12, 40, 0.3, 50), (33, 4, 3, 0.05, 0),
+                                                     (1, 3, 2, 0.0, 0), (2, 6, 2, 0.2, 0), (400, 60, 20, 0.25, 30)])]
+    blocks.append(BlockMatrix.from_rows([(r["alleles"], r["quals"]) for r in g["haplotag"]["reads"]]))
+    blocks.append(BlockMatrix.from_rows([(r["alleles"], r["quals"]) for r in g["span_counts"]["reads"]] +
+                                        [([3] * 6, [0] * 6)]))   # + an inert row
+    rb = ResidentBatch(blocks)
+    rb.solve()
+    res, _, _ = rb.results()
+    post = rb.postprocess()
+    rb.close()
+    d = oracle()
+    for blk, r, (spans, ht, fh) in zip(blocks, res, post):
+        v = blk.view()
+        n = blk.n_variants
+        exp_sp = np.zeros(max(n - 1, 1), np.uint64)
+        assert d.hpo_solution_span_counts(C.byref(v), r.haplotype_1.ctypes.data, r.haplotype_2.ctypes.data, exp_sp.ctypes.data) == 0
+        assert np.array_equal(spans, exp_sp[:max(n - 1, 0)])
+        tags = np.arange(n, dtype=np.uint64)
+        eht = np.zeros(blk.n_reads, np.uint8)
+        epb = np.zeros(blk.n_reads, np.uint64)
+        assert d.hpo_haplotag_reads(C.byref(v), r.haplotype_1.ctypes.data, r.haplotype_2.ctypes.data, tags.ctypes.data,
+                                    eht.ctypes.data, epb.ctypes.data) == 0
+        assert np.array_equal(ht, eht)
+        tagged = eht != 2
+        assert np.array_equal(fh[tagged].astype(np.uint64), epb[tagged])
+        assert (fh[~tagged] == 0xFFFFFFFF).all()
