@@ -25,6 +25,15 @@ def make_blocks(args, rank):
     from hiphase_amd import synth_block
     from hiphase_amd.shard import rank_seeds
     blocks = []
+    if args.replay:   # captured real blocks (.hpbk, hiphase_amd/block_io.py): every rank replays its LPT shard
+        from hiphase_amd.block_io import read_blocks
+        from hiphase_amd.shard import shard_lpt
+        with open(args.replay, "rb") as f:
+            allb = list(read_blocks(f))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        mine = shard_lpt([b.n_cells for b, _, _ in allb], world)[rank]
+        args.replay_expected = [allb[i][2] for i in mine]
+        return [allb[i][0] for i in mine]
     if args.workload == "c2":
         for seed in rank_seeds(20250509, rank, args.blocks):   # disjoint seed ranges per rank (weak scaling)
             blocks.append(synth_block(args.hets, args.coverage, args.span, args.error, 0.02, seed)[0])
@@ -74,6 +83,7 @@ def main():
     ap.add_argument("--error", type=float, default=0.01)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--replay", default=None, help=".hpbk capture of real phase blocks (strong scaling over ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -163,6 +173,14 @@ def main():
                          "evals_per_het": evals_per_step / hets_per_step,
                          "mean_wave_cycles_heuristic": cyc_heur, "mean_wave_cycles_main": cyc_main},
         }
+        if args.replay:
+            out["scaling"] = "strong"
+            out["config"]["workload"] = f"replay of {os.path.basename(args.replay)}: {len(blocks)} captured blocks on rank 0"
+            exp = [e for e in getattr(args, "replay_expected", []) if e is not None]
+            if exp:
+                ok = all((r.haplotype_1 == e[0]).all() and (r.haplotype_2 == e[1]).all() and r.statistics.as_tuple() == tuple(e[2])
+                         for r, e in zip(res, getattr(args, "replay_expected")) if e is not None)
+                out["parity_vs_capture"] = {"blocks_compared": len(exp), "bit_identical": bool(ok)}
         if not args.no_cpu:
             cb, octr, ores = cpu_baseline(args, blocks)
             out["cpu_baseline"] = cb
