@@ -180,6 +180,14 @@ struct hp_batch {
     std::vector<uint64_t> caller_row_off;
     uint64_t caller_rows = 0, n_rows_packed = 0, n_junctures = 0;
     bool solved = false;
+    // segment-parallel heuristic (large blocks on an otherwise idle GPU)
+    DevBuf d_segs, d_seg_order, d_seg_out, d_seg_off, d_sb_first, d_sb_n, d_sb_id, s_seg_pool;
+    uint32_t last_n_segs = 0;
+    // second stream + scratch: segmented blocks run beside the sequential pass of all the others
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DevBuf g_main_pool, g_main_heap, g_sub_pool, g_sub_heap, g_tracker, d_order2, d_order1;
+    uint32_t g_slots = 0, g_cap = 0;
     // scratch (sized on first solve, kept)
     DevBuf s_sub_pool, s_main_pool, s_sub_heap, s_main_heap, s_tracker;
     uint32_t scratch_slots = 0, scratch_cap_main = 0;
@@ -189,6 +197,9 @@ struct hp_batch {
         (void)hipSetDevice(device);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -196,6 +207,84 @@ struct hp_batch {
 namespace {
 
 constexpr uint32_t LDS_SUB_HEAP_MAX_BYTES = 24 * 1024;  // keep >= 6 waves per CU resident (160 KiB LDS)
+
+// Plans and launches the segment-parallel heuristic for blocks that would otherwise be the critical path
+// (heavy-tailed block sizes, or few blocks): see hp_astar_dev.h. Blocks whose seams verify get status ST_H_READY
+// and their final H[]; everything else is left for the sequential path of hp_astar_kernel.
+int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_blocks) {
+    b->last_n_segs = 0;
+    seg_blocks.clear();
+    if (std::getenv("HP_NO_SEGMENTS") || !b->prm.sub_heap_in_lds || b->prm.max_seg > SEG_STATE) return HP_OK;
+    const size_t lds_bytes = LDS_HEAP_OFF + (size_t)b->prm.jcap_sub * 64 * sizeof(uint64_t);
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(20, (160 * 1024) / lds_bytes);
+    const uint64_t max_slots = (uint64_t)b->n_cu * std::max(per_cu, 1u);
+    uint64_t total = 0;
+    for (auto& d : b->desc) total += d.n_vars;
+    const char* tenv = std::getenv("HP_SEG_TARGET");
+    uint64_t target = tenv ? (uint64_t)std::atoll(tenv) : std::max<uint64_t>(256, total / max_slots);
+    target = std::max<uint64_t>(64, (target + 63) / 64 * 64);
+    const char* wenv = std::getenv("HP_SEG_WARM");
+    const uint32_t warm = wenv ? (uint32_t)std::atoi(wenv) : 160;
+    std::vector<SegDesc> segs;
+    std::vector<uint32_t> sb_first, sb_n, sb_id;
+    for (uint32_t i = 0; i < b->desc.size(); ++i) {
+        const uint32_t N = b->desc[i].n_vars;
+        if ((uint64_t)N < 2 * target) continue;
+        const uint32_t ns = (uint32_t)(N / target);   // last (top) segment takes the remainder: length in [target, 2*target)
+        sb_first.push_back((uint32_t)segs.size());
+        sb_n.push_back(ns);
+        sb_id.push_back(i);
+        for (uint32_t k = 0; k < ns; ++k) {
+            SegDesc sd;
+            sd.blk = i;
+            sd.a = (uint32_t)(k * target);
+            sd.b = (k + 1 == ns) ? N : (uint32_t)((k + 1) * target);
+            sd.v0 = (k + 1 == ns) ? N : std::min<uint32_t>(N, sd.b + warm);
+            segs.push_back(sd);
+        }
+    }
+    if (segs.empty()) return HP_OK;
+    std::vector<uint32_t> order(segs.size());
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return segs[x].v0 - segs[x].a > segs[y].v0 - segs[y].a; });
+    const uint32_t slots = (uint32_t)std::min<uint64_t>(segs.size(), max_slots);
+    SolveParams prm = b->prm;
+    prm.pad0 = 0; prm.pad1 = 0;
+    const size_t sub_pool_bytes = (size_t)prm.cap_sub * sizeof(FamRec) + (size_t)prm.cap_chunk_sub * sizeof(ChunkRec);
+    int rc;
+    if (b->s_seg_pool.bytes < (size_t)slots * sub_pool_bytes && (rc = b->s_seg_pool.alloc((size_t)slots * sub_pool_bytes)) != HP_OK) return rc;
+    if ((rc = upload(b->d_segs, segs, st)) || (rc = upload(b->d_seg_order, order, st)) || (rc = upload(b->d_sb_first, sb_first, st)) ||
+        (rc = upload(b->d_sb_n, sb_n, st)) || (rc = upload(b->d_sb_id, sb_id, st)))
+        return rc;
+    if ((rc = b->d_seg_out.alloc(segs.size() * sizeof(SegOut))) || (rc = b->d_seg_off.alloc(segs.size() * 8))) return rc;
+    HP_HIP_CHECK(hipMemsetAsync(b->d_seg_off.p, 0, segs.size() * 8, st));
+    SegBatchDev S{};
+    BatchDev& B = S.B;
+    B.desc = b->d_desc.as<BlockDesc>();
+    B.vlo = b->d_vlo.as<uint32_t>(); B.vhi = b->d_vhi.as<uint32_t>(); B.vflags = b->d_vflags.as<uint8_t>();
+    B.rstart = b->d_rstart.as<uint32_t>(); B.rend = b->d_rend.as<uint32_t>(); B.rword = b->d_rword.as<uint32_t>();
+    B.words = b->d_words.as<uint32_t>();
+    B.H = b->d_H.as<uint64_t>();
+    B.sub_pool = b->s_seg_pool.as<unsigned char>();
+    B.prm = prm;
+    S.segs = b->d_segs.as<SegDesc>(); S.seg_order = b->d_seg_order.as<uint32_t>(); S.n_segs = (uint32_t)segs.size();
+    S.out = b->d_seg_out.as<SegOut>();
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] segment-parallel heuristic: %zu segments of ~%llu hets (+%u warm-up) over %zu blocks, slots=%u\n", segs.size(), (unsigned long long)target, warm, sb_id.size(), slots); fflush(stderr); }
+    hipLaunchKernelGGL(hp_heur_seg_kernel<true>, dim3(slots), dim3(64), lds_bytes, st, S);
+    StitchDev T{};
+    T.desc = B.desc; T.segs = S.segs; T.out = S.out;
+    T.blk_first_seg = b->d_sb_first.as<uint32_t>(); T.blk_n_seg = b->d_sb_n.as<uint32_t>(); T.blk_id = b->d_sb_id.as<uint32_t>();
+    T.n_seg_blocks = (uint32_t)sb_id.size(); T.H = B.H; T.seg_offset = b->d_seg_off.as<uint64_t>();
+    T.status = b->d_status.as<int32_t>(); T.counters = b->d_counters.as<hp_work_counters>();
+    hipLaunchKernelGGL(hp_heur_stitch_kernel, dim3((T.n_seg_blocks + 63) / 64), dim3(64), 0, st, T);
+    ApplyDev A{};
+    A.segs = S.segs; A.seg_offset = T.seg_offset; A.desc = B.desc; A.n_segs = S.n_segs; A.H = B.H;
+    hipLaunchKernelGGL(hp_heur_apply_kernel, dim3(S.n_segs), dim3(256), 0, st, A);
+    HP_HIP_CHECK(hipGetLastError());
+    b->last_n_segs = S.n_segs;
+    seg_blocks = sb_id;
+    return HP_OK;
+}
 
 int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items, uint32_t cap_main,
                 DevBuf& main_pool, DevBuf& main_heap, DevBuf& sub_pool, DevBuf& sub_heap, DevBuf& tracker,
@@ -299,6 +388,8 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) b->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(HP_ERR_HIP); }
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { set_error("hipEventCreate failed"); return fail(HP_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&b->ev_fork) != hipSuccess ||
+        hipEventCreate(&b->ev_join) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(HP_ERR_HIP); }
 
     SolveParams& prm = b->prm;
     prm.minq_main = (uint32_t)p->min_queue_size;
@@ -348,9 +439,35 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     // frontier outgrows it (noisy data) keep their finished heuristic and only their main search is re-run
     // with 4x the capacity until it fits (or memory runs out).
     uint32_t cap_main = 6 * b->max_n + 2048;   // node_index < 2^38 is guaranteed by cap64 <= 0xF0000000 below
-    int rc = launch_pass(b, st, b->order, cap_main, b->s_main_pool, b->s_main_heap, b->s_sub_pool, b->s_sub_heap,
-                         b->s_tracker, b->scratch_slots, b->scratch_cap_main, b->d_order);
+    // Large blocks that would be the critical path get a segment-parallel heuristic on a second stream, beside the
+    // ordinary pass over all other blocks; their (short) main search follows on that stream.
+    HP_HIP_CHECK(hipEventRecord(b->ev_fork, st));
+    HP_HIP_CHECK(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+    std::vector<uint32_t> seg_blocks;
+    int rc = launch_segments(b, b->stream2, seg_blocks);
     if (rc != HP_OK) return rc;
+    std::vector<uint32_t> items_seq = b->order, items_seg;
+    if (!seg_blocks.empty()) {
+        std::vector<uint8_t> is_seg(b->n_blocks, 0);
+        for (uint32_t i : seg_blocks) is_seg[i] = 1;
+        items_seq.clear();
+        for (uint32_t i : b->order) (is_seg[i] ? items_seg : items_seq).push_back(i);
+        uint32_t seg_max_n = 0;
+        for (uint32_t i : items_seg) seg_max_n = std::max(seg_max_n, b->desc[i].n_vars);
+        rc = launch_pass(b, b->stream2, items_seg, 6 * seg_max_n + 2048, b->g_main_pool, b->g_main_heap, b->g_sub_pool, b->g_sub_heap,
+                         b->g_tracker, b->g_slots, b->g_cap, b->d_order2);
+        if (rc != HP_OK) return rc;
+        HP_HIP_CHECK(hipEventRecord(b->ev_join, b->stream2));
+        uint32_t seq_max_n = 0;
+        for (uint32_t i : items_seq) seq_max_n = std::max(seq_max_n, b->desc[i].n_vars);
+        cap_main = 6 * seq_max_n + 2048;
+    }
+    if (!items_seq.empty()) {
+        rc = launch_pass(b, st, items_seq, cap_main, b->s_main_pool, b->s_main_heap, b->s_sub_pool, b->s_sub_heap,
+                         b->s_tracker, b->scratch_slots, b->scratch_cap_main, b->d_order1);
+        if (rc != HP_OK) return rc;
+    }
+    if (!seg_blocks.empty()) HP_HIP_CHECK(hipStreamWaitEvent(st, b->ev_join, 0));
     HP_HIP_CHECK(hipEventRecord(b->ev1, st));
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] waiting for kernel\n"); fflush(stderr); }
     HP_HIP_CHECK(hipStreamSynchronize(st));
@@ -363,7 +480,7 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     for (uint32_t i : b->order) if (status[i] == ST_OVERFLOW_MAIN) retry.push_back(i);
     DevBuf r_main_pool, r_main_heap, r_sub_pool, r_sub_heap, r_tracker, r_items;
     uint32_t r_slots = 0, r_cap = 0;
-    uint64_t cap64 = cap_main;
+    uint64_t cap64 = 6ull * b->max_n + 2048;
     while (!retry.empty()) {
         cap64 *= 4;
         if (cap64 > 0xF0000000ull) { set_error("search frontier exceeds 2^32 nodes"); return HP_ERR_OOM; }

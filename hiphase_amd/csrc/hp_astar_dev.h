@@ -89,12 +89,35 @@ struct SolveParams {
     uint32_t pad2, pad3;
 };
 
+// ---- segment-parallel heuristic (DESIGN.md §3.1 "speculative segments") --------------------------------------
+// The heuristic chain H[v] = f(H[v+1..v+40], clip) is sequential, but it forgets its start: a chain started cold
+// (H = 0, clip = 1) ~100 variants above a seam reproduces the exact differences H[v] - H[v+1] below it. A large
+// block is therefore cut into segments that run concurrently, each warming up over `warm` extra variants; a seam
+// is accepted only if the 40-value state (relative H + clip) entering the owned range is IDENTICAL to what the
+// segment above produced — then everything below is the same function of the same inputs, i.e. exact. A failed
+// seam sends the block down the sequential path.
+constexpr uint32_t SEG_STATE = 40;   // >= max_segment_size look-ahead (host enforces max_seg <= 40 when segmenting)
+struct SegDesc {
+    uint32_t blk;
+    uint32_t a, b;      // owned variants [a, b)
+    uint32_t v0;        // cold start: chain runs v0-1 .. a   (v0 == N for the top segment: the true block end)
+};
+struct SegOut {
+    uint64_t seam[SEG_STATE];  // warm-up values H_w[b + j], j = 0..39 (relative to this segment's cold start)
+    uint32_t clip_at_b;        // clip entering v = b-1 as the warm-up computed it
+    uint32_t clip_out;         // clip entering v = a-1 (what the segment below must have warmed up to)
+    int32_t status;
+    uint32_t pad;
+    hp_work_counters ctr;      // owned steps only
+};
+
 // block status written by the kernel
 constexpr int32_t ST_OK = 0;
 constexpr int32_t ST_OVERFLOW = 1;        // sub-solver pool/heap capacity exceeded (cannot happen with the host's sizing)
 constexpr int32_t ST_OVERFLOW_MAIN = 2;   // main-search scratch exceeded: H[] is complete, host re-launches with 4x scratch
 constexpr int32_t ST_INVARIANT = -3;      // a reference assert!/panic! would have fired
 constexpr int32_t ST_PENDING = 7;
+constexpr int32_t ST_H_READY = ST_OVERFLOW_MAIN;  // same meaning for the solver: heuristic complete, run the main search
 
 struct BatchDev {
     const BlockDesc* desc;

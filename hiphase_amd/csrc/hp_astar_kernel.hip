@@ -909,6 +909,164 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
     }
 }
 
+
+// ---- segment-parallel heuristic: one wavefront per segment ------------------------------------------------------
+struct SegBatchDev {
+    BatchDev B;
+    const SegDesc* segs;
+    const uint32_t* seg_order;
+    uint32_t n_segs;
+    SegOut* out;
+};
+
+template <bool SUB_LDS>
+DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
+    const BatchDev& B = S.B;
+    const SolveParams& prm = B.prm;
+    const SegDesc sd = S.segs[seg];
+    const BlockDesc d = B.desc[sd.blk];
+    const uint32_t N = d.n_vars;
+    const uint32_t lane = lane_id();
+    Ctx cx;
+    const uint32_t* vlo = B.vlo + d.var_off;
+    const uint32_t* vhi = B.vhi + d.var_off;
+    const uint8_t* vflags = B.vflags + d.var_off;
+    cx.rstart = B.rstart + d.read_off; cx.rend = B.rend + d.read_off; cx.rword = B.rword + d.read_off;
+    cx.words = B.words + d.word_off * WORD_DWORDS;
+    cx.N = N; cx.evals = 0; cx.cells = 0;
+    uint64_t* H = B.H + d.h_off;
+    Pools subp;
+    {
+        unsigned char* sb = B.sub_pool + (size_t)slot * ((size_t)prm.cap_sub * sizeof(FamRec) + (size_t)prm.cap_chunk_sub * sizeof(ChunkRec));
+        subp.fam = reinterpret_cast<FamRec*>(sb);
+        subp.chunk = reinterpret_cast<ChunkRec*>(sb + (size_t)prm.cap_sub * sizeof(FamRec));
+        subp.cap_chunk = prm.cap_chunk_sub; subp.n_chunk = 0; subp.ovf = 0;
+    }
+    WaveCounters wc{0, 0, 0, {0, 0, 0, 0, 0, 0}, 0};
+    SubHeap<SUB_LDS> sub;
+    sub.gbase = SUB_LDS ? nullptr : reinterpret_cast<uint64_t*>(B.sub_heap_g) + (size_t)slot * prm.jcap_sub * 64;
+    sub.jcap = prm.jcap_sub;
+    sub.ovf = 0;
+    SegOut* out = S.out + seg;
+    int32_t st = ST_OK;
+    if (sd.v0 == N && lane == 0) H[N] = 0;
+    ringH_set(sd.v0, 0);   // cold start (for the top segment this IS heuristic_costs[N] = 0)
+    uint32_t clip = 1, clip_at_b = 1;
+    for (uint32_t v = sd.v0; v-- > sd.a;) {
+        if (v + 1 == sd.b) {   // entering the owned range: only owned work is counted (== the sequential chain's work)
+            wc.sub_pops = 0; wc.nodes = 0; cx.evals = 0; cx.cells = 0;
+            clip_at_b = clip;
+        }
+        ringH_set(v, 0);
+        uint32_t fl = 0, l = 0, h = 0;
+        if (lane == 0) { fl = vflags[v]; l = vlo[v]; h = vhi[v]; }
+        fl = bcast32(fl);
+        ringV_set(v, l, h, fl);
+        uint64_t est = 0;
+        uint32_t solved = 0;
+        st = subsolve<SUB_LDS>(cx, prm, v, clip, sub, subp, wc, est, solved);
+        if (st != ST_OK) break;
+        if (solved < min(clip, 2u)) { st = ST_INVARIANT; break; }
+        const bool bad = (fl & HP_VAR_IGNORED) != 0;
+        const uint64_t hnext = ringH_get(v + 1);
+        uint64_t hv;
+        if (bad) hv = hnext;
+        else {
+            if (est < hnext) { st = ST_INVARIANT; break; }
+            hv = est;
+        }
+        ringH_set(v, hv);
+        if (lane == 0) {
+            if (v < sd.b) H[v] = hv;                                    // owned: relative to this segment's cold start
+            else if (v - sd.b < SEG_STATE) out->seam[v - sd.b] = hv;    // warm-up values the seam check compares
+        }
+        clip = min(solved + 1, prm.max_seg);
+    }
+    // a warm-up failure (e.g. an invariant that only holds with true look-ahead) is not an error of the block:
+    // the seam check fails and the block takes the sequential path, which reports real invariant violations.
+    const uint64_t evals = wave_sum_u64(cx.evals), cells = wave_sum_u64(cx.cells);
+    if (lane == 0) {
+        out->clip_at_b = clip_at_b;
+        out->clip_out = clip;
+        out->status = st;
+        hp_work_counters c{};
+        c.sub_pops = wc.sub_pops; c.evals = evals; c.cells = cells; c.nodes_created = wc.nodes;
+        out->ctr = c;
+    }
+}
+
+template <bool SUB_LDS>
+__global__ void __launch_bounds__(64, 5) hp_heur_seg_kernel(SegBatchDev S) {
+    const uint32_t slot = blockIdx.x, G = gridDim.x;
+    for (uint32_t round = 0;; ++round) {
+        const uint32_t base = round * G;
+        if (base >= S.n_segs) break;
+        const uint32_t i = base + ((round & 1u) ? (G - 1u - slot) : slot);
+        if (i < S.n_segs) solve_segment<SUB_LDS>(S, S.seg_order[i], slot);
+    }
+}
+template __global__ void hp_heur_seg_kernel<true>(SegBatchDev);
+template __global__ void hp_heur_seg_kernel<false>(SegBatchDev);
+
+// Seam verification + offsets, one thread per segmented block (segments of a block are consecutive, bottom first).
+struct StitchDev {
+    const BlockDesc* desc;
+    const SegDesc* segs;
+    SegOut* out;
+    const uint32_t* blk_first_seg;   // per segmented block
+    const uint32_t* blk_n_seg;
+    const uint32_t* blk_id;
+    uint32_t n_seg_blocks;
+    uint64_t* H;
+    uint64_t* seg_offset;            // per segment: what to add to its owned H values
+    int32_t* status;
+    hp_work_counters* counters;
+};
+__global__ void __launch_bounds__(64) hp_heur_stitch_kernel(StitchDev T) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T.n_seg_blocks) return;
+    const uint32_t blk = T.blk_id[t], s0 = T.blk_first_seg[t], ns = T.blk_n_seg[t];
+    const BlockDesc d = T.desc[blk];
+    const uint64_t* H = T.H + d.h_off;
+    bool ok = T.out[s0 + ns - 1].status == ST_OK;
+    hp_work_counters tot = T.out[s0 + ns - 1].ctr;
+    T.seg_offset[s0 + ns - 1] = 0;
+    for (uint32_t k = ns - 1; ok && k-- > 0;) {
+        const uint32_t seg = s0 + k, above = seg + 1;
+        const SegOut& o = T.out[seg];
+        const uint32_t b = T.segs[seg].b;
+        ok = ok && o.status == ST_OK && o.clip_at_b == T.out[above].clip_out;
+        for (uint32_t j = 1; ok && j < SEG_STATE && b + j <= d.n_vars; ++j)
+            ok = (o.seam[j] - o.seam[0]) == (H[b + j] - H[b]);   // identical look-ahead state (differences)
+        if (ok) {
+            T.seg_offset[seg] = T.seg_offset[above] + H[b] - o.seam[0];
+            tot.sub_pops += o.ctr.sub_pops; tot.evals += o.ctr.evals; tot.cells += o.ctr.cells; tot.nodes_created += o.ctr.nodes_created;
+        }
+    }
+    if (ok) {
+        T.counters[blk] = tot;
+        T.status[blk] = ST_H_READY;
+    } else {
+        for (uint32_t k = 0; k < ns; ++k) T.seg_offset[s0 + k] = 0;   // block falls back to the sequential chain
+    }
+}
+struct ApplyDev {
+    const SegDesc* segs;
+    const uint64_t* seg_offset;
+    const BlockDesc* desc;
+    uint32_t n_segs;
+    uint64_t* H;
+};
+__global__ void __launch_bounds__(256) hp_heur_apply_kernel(ApplyDev A) {
+    const uint32_t seg = blockIdx.x;
+    if (seg >= A.n_segs) return;
+    const uint64_t off = A.seg_offset[seg];
+    if (off == 0) return;
+    const SegDesc sd = A.segs[seg];
+    uint64_t* H = A.H + A.desc[sd.blk].h_off;
+    for (uint32_t v = sd.a + threadIdx.x; v < sd.b; v += blockDim.x) H[v] += off;
+}
+
 // ---- post-processing on the resident matrix (reference src/phaser.rs:350-388 and :714-750) ---------------------
 // Kernel A, one thread per packed row: scores the row against both solved haplotypes (haplotag_reads), finds the
 // first het it resolves, and the juncture range [js, je) it supports after trimming solution-homozygous ends.

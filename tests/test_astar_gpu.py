@@ -280,3 +280,28 @@ def test_postprocess_span_counts_and_haplotags():
         tagged = eht != 2
         assert np.array_equal(fh[tagged].astype(np.uint64), epb[tagged])
         assert (fh[~tagged] == 0xFFFFFFFF).all()
+
+
+@pytest.mark.parametrize("target,warm", [(64, 160), (128, 200), (64, 8)])
+def test_segment_parallel_heuristic_is_exact(monkeypatch, target, warm):
+    """Large blocks are cut into concurrently solved segments with a cold warm-up; seams are accepted only when the
+    40-value look-ahead state matches exactly, otherwise the block falls back to the sequential chain (warm=8
+    forces that). Either way H[], haplotypes, stats and work counters equal the oracle's."""
+    monkeypatch.setenv("HP_SEG_TARGET", str(target))
+    monkeypatch.setenv("HP_SEG_WARM", str(warm))
+    blocks = [synth_block(n, c, s, e, 0.02, 8100 + i, ignored_permille=ign)[0]
+              for i, (n, c, s, e, ign) in enumerate([(700, 30, 20, 0.01, 0), (513, 30, 20, 0.15, 0), (900, 60, 40, 0.05, 20),
+                                                     (130, 30, 20, 0.01, 0), (40, 30, 20, 0.01, 0), (1300, 12, 150, 0.03, 0)])]
+    check_batch(blocks)
+
+
+def test_single_block_latency_uses_segments(monkeypatch):
+    """One 5000-het block alone (BASELINE.json configs[1] as written): the planner segments it by itself."""
+    monkeypatch.delenv("HP_SEG_TARGET", raising=False)
+    blk, _ = synth_block(5000, 30, 20, 0.01, 0.02, 20250509)
+    ms_seg = check_batch([blk])
+    monkeypatch.setenv("HP_NO_SEGMENTS", "1")
+    rb = ResidentBatch([blk])
+    ms_seq = rb.solve()
+    rb.close()
+    assert ms_seg < ms_seq   # and typically > 10x faster
