@@ -35,9 +35,11 @@ struct DevBuf {
         p = nullptr;
         bytes = 0;
     }
+    // grows only: hipFree/hipMalloc synchronise the whole device, which would serialise the two solver streams
     int alloc(size_t n) {
-        release();
         if (n == 0) n = 16;
+        if (p && bytes >= n) return HP_OK;
+        release();
         HP_HIP_CHECK(hipMalloc(&p, n));
         bytes = n;
         return HP_OK;
