@@ -13,43 +13,78 @@
 #include <ctime>
 #include <memory>
 #include <numeric>
+#include <atomic>
 #include <set>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace hp {
 namespace {
 
-struct HostNode {
+struct HostNode {          // POD: parent / child lists live in the job's flat arrays (few allocations per read)
     uint32_t seq_off, seq_len;
-    std::vector<uint32_t> parents;   // sorted (wfa_graph.rs:36)
-    std::vector<uint32_t> children;  // creation order (wfa_graph.rs:321-323)
-    int64_t emin = 0, emax = 0;      // shortest / longest path length from the root to this node's first base
+    uint32_t par_off, n_par;      // into HostJob::par (sorted, wfa_graph.rs:36)
+    uint32_t child_off, n_child;  // into HostJob::child (creation order, wfa_graph.rs:321-323); filled by finish_graph
+    int64_t emin, emax;           // shortest / longest path length from the root to this node's first base
 };
 
 struct HostJob {
     std::vector<HostNode> nodes;
-    std::vector<uint8_t> seq;                 // [ref slice][alt alleles...][read][pad]
-    uint32_t read_off = 0, read_len = 0;
+    std::vector<uint32_t> par, child;
+    // device sequence buffer layout: [ref slice][alt allele bytes][read][pad]; only the (small) allele bytes are
+    // copied here, the reference slice and the read are copied once, straight into the upload staging buffer
+    const uint8_t* ref_ptr = nullptr;
+    uint32_t ref_len = 0;
+    std::vector<uint8_t> alt;
+    const uint8_t* read_ptr = nullptr;
+    uint32_t read_off = 0, read_len = 0, seq_bytes = 0;
     // node_to_alleles (wfa_graph.rs:19): (node, het index, allele)
     std::vector<std::array<uint32_t, 3>> tags;
 };
 
 // WFAGraph::add_node (wfa_graph.rs:298-331)
-int add_node(HostJob& g, uint32_t seq_off, uint32_t seq_len, std::vector<uint32_t> parents) {
+int add_node(HostJob& g, uint32_t seq_off, uint32_t seq_len, const std::vector<uint32_t>& parents) {
     const uint32_t idx = (uint32_t)g.nodes.size();
     if (idx == 0) { if (!parents.empty()) return -1; }
     else {
         if (parents.empty()) return -1;
         for (uint32_t p : parents) if (idx <= p) return -1;
     }
-    for (uint32_t p : parents) g.nodes[p].children.push_back(idx);
-    std::sort(parents.begin(), parents.end());
-    HostNode n;
+    HostNode n{};
     n.seq_off = seq_off;
     n.seq_len = seq_len;
-    n.parents = std::move(parents);
-    g.nodes.push_back(std::move(n));
+    n.par_off = (uint32_t)g.par.size();
+    n.n_par = (uint32_t)parents.size();
+    g.par.insert(g.par.end(), parents.begin(), parents.end());
+    std::sort(g.par.begin() + n.par_off, g.par.end());
+    g.nodes.push_back(n);
     return (int)idx;
+}
+
+// children lists (edges[p].push(child) in creation order) + path-length ranges, once all nodes exist
+void finish_graph(HostJob& g) {
+    const size_t nn = g.nodes.size();
+    std::vector<uint32_t> cnt(nn + 1, 0);
+    for (size_t n = 0; n < nn; ++n)
+        for (uint32_t k = 0; k < g.nodes[n].n_par; ++k) cnt[g.par[g.nodes[n].par_off + k] + 1]++;
+    for (size_t n = 0; n < nn; ++n) { cnt[n + 1] += cnt[n]; g.nodes[n].child_off = cnt[n]; g.nodes[n].n_child = 0; }
+    g.child.assign(g.par.size(), 0);
+    for (size_t n = 0; n < nn; ++n)   // ascending child index == creation order
+        for (uint32_t k = 0; k < g.nodes[n].n_par; ++k) {
+            HostNode& p = g.nodes[g.par[g.nodes[n].par_off + k]];
+            g.child[p.child_off + p.n_child++] = (uint32_t)n;
+        }
+    for (size_t n = 1; n < nn; ++n) {
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (uint32_t k = 0; k < g.nodes[n].n_par; ++k) {
+            const HostNode& q = g.nodes[g.par[g.nodes[n].par_off + k]];
+            lo = std::min(lo, q.emin + (int64_t)q.seq_len);
+            hi = std::max(hi, q.emax + (int64_t)q.seq_len);
+        }
+        g.nodes[n].emin = lo;
+        g.nodes[n].emax = hi;
+    }
 }
 
 // from_reference_variants_with_hom (wfa_graph.rs:119-284). Reference nodes are spans of the copied
@@ -57,7 +92,8 @@ int add_node(HostJob& g, uint32_t seq_off, uint32_t seq_len, std::vector<uint32_
 int build_graph(const hp_wfa_job* job, HostJob& g) {
     if (job->ref_end < job->ref_start || job->ref_start < job->ref_base) { set_error("bad reference window"); return HP_ERR_ARG; }
     const size_t ref_len = (size_t)(job->ref_end - job->ref_start);
-    g.seq.assign(job->reference + (job->ref_start - job->ref_base), job->reference + (job->ref_start - job->ref_base) + ref_len);
+    g.ref_ptr = job->reference + (job->ref_start - job->ref_base);
+    g.ref_len = (uint32_t)ref_len;
     auto ref_span = [&](uint64_t a) { return (uint32_t)(a - job->ref_start); };
     const uint64_t ref_start = job->ref_start, ref_end = job->ref_end;
     uint64_t previous_end = ref_start;
@@ -94,8 +130,8 @@ int build_graph(const hp_wfa_job* job, HostJob& g) {
         return true;
     };
     auto add_allele = [&](const uint8_t* bytes, uint32_t len) -> int {
-        const uint32_t off = (uint32_t)g.seq.size();
-        g.seq.insert(g.seq.end(), bytes, bytes + len);
+        const uint32_t off = g.ref_len + (uint32_t)g.alt.size();
+        g.alt.insert(g.alt.end(), bytes, bytes + len);
         return add_node(g, off, len, reference_reconnect);
     };
 
@@ -138,21 +174,11 @@ int build_graph(const hp_wfa_job* job, HostJob& g) {
     }
     if (!reference_alleles.empty()) { set_error("graph construction assert (dangling reference alleles)"); return HP_ERR_INVARIANT; }
 
-    g.read_off = (uint32_t)g.seq.size();
+    g.read_off = g.ref_len + (uint32_t)g.alt.size();
     g.read_len = job->read_len;
-    g.seq.insert(g.seq.end(), job->read, job->read + job->read_len);
-    g.seq.resize(g.seq.size() + 16, 0);  // 8-byte compares may read past the last base
-    while (g.seq.size() & 15) g.seq.push_back(0);
-    // path-length range to every node (band placement)
-    for (size_t n = 1; n < g.nodes.size(); ++n) {
-        int64_t lo = INT64_MAX, hi = INT64_MIN;
-        for (uint32_t q : g.nodes[n].parents) {
-            lo = std::min(lo, g.nodes[q].emin + (int64_t)g.nodes[q].seq_len);
-            hi = std::max(hi, g.nodes[q].emax + (int64_t)g.nodes[q].seq_len);
-        }
-        g.nodes[n].emin = lo;
-        g.nodes[n].emax = hi;
-    }
+    g.read_ptr = job->read;
+    g.seq_bytes = (g.read_off + g.read_len + 16 + 15) & ~15u;  // 8-byte compares may read past the last base
+    finish_graph(g);
     return HP_OK;
 }
 
@@ -172,11 +198,13 @@ double now_ms() {
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+thread_local std::vector<uint8_t> g_seq_stage;   // reused upload staging for the sequence bytes
+
 struct WfaPack {
     std::vector<WfaJobDesc> jobs;
     std::vector<WfaNode> nodes;
     std::vector<WfaEdge> edges;
-    std::vector<uint8_t> seq;
+    std::vector<uint8_t>& seq = g_seq_stage;
     uint64_t out_set_words = 0;
     uint64_t max_scratch = 0;
     uint32_t max_nodes = 0;
@@ -205,9 +233,9 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
             dn.seq_off = hn.seq_off;
             dn.seq_len = hn.seq_len;
             dn.child_off = (uint32_t)(pk.edges.size() - jd.edge_off);
-            dn.n_children = (uint16_t)hn.children.size();
-            const uint32_t np = n == 0 ? 1u : (uint32_t)hn.parents.size();
-            if (np > 32 || hn.children.size() > 65535) { set_error("graph node with %u parents (> 32 supported)", np); return HP_ERR_UNSUPPORTED; }
+            dn.n_children = (uint16_t)hn.n_child;
+            const uint32_t np = n == 0 ? 1u : hn.n_par;
+            if (np > 32 || hn.n_child > 65535) { set_error("graph node with %u parents (> 32 supported)", np); return HP_ERR_UNSUPPORTED; }
             dn.n_parents = (uint16_t)np;
             const int64_t width = (hn.emax - hn.emin) + 2 * (int64_t)band + 3;
             if (width > 65535) { set_error("diagonal band of %lld exceeds 65535", (long long)width); return HP_ERR_UNSUPPORTED; }
@@ -217,9 +245,10 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
             dn.entry_off = (uint32_t)entry_off;
             entry_off += (uint64_t)dn.width * dn.entry_stride;
             if (entry_off > 0xFFFFFFF0ull) { set_error("WFA scratch of one read exceeds 16 GiB"); return HP_ERR_UNSUPPORTED; }
-            for (uint32_t c : hn.children) {
-                const auto& cp = g.nodes[c].parents;
-                const uint32_t ord = (uint32_t)(std::lower_bound(cp.begin(), cp.end(), n) - cp.begin());
+            for (uint32_t ci = 0; ci < hn.n_child; ++ci) {
+                const uint32_t c = g.child[hn.child_off + ci];
+                const uint32_t* cp = g.par.data() + g.nodes[c].par_off;
+                const uint32_t ord = (uint32_t)(std::lower_bound(cp, cp + g.nodes[c].n_par, n) - cp);
                 pk.edges.push_back(WfaEdge{c, ord});
             }
             pk.nodes.push_back(dn);
@@ -227,7 +256,15 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
         jd.scratch_dwords = (uint32_t)entry_off;
         pk.max_scratch = std::max<uint64_t>(pk.max_scratch, entry_off);
         pk.max_nodes = std::max(pk.max_nodes, jd.n_nodes);
-        pk.seq.insert(pk.seq.end(), g.seq.begin(), g.seq.end());
+        {
+            const size_t o = pk.seq.size();
+            pk.seq.resize(o + g.seq_bytes);   // staging buffer is thread-local and reused: no page faults after warm-up
+            uint8_t* dst = pk.seq.data() + o;
+            std::memcpy(dst, g.ref_ptr, g.ref_len);
+            if (!g.alt.empty()) std::memcpy(dst + g.ref_len, g.alt.data(), g.alt.size());
+            if (g.read_len) std::memcpy(dst + g.read_off, g.read_ptr, g.read_len);
+            std::memset(dst + g.read_off + g.read_len, 0, g.seq_bytes - g.read_off - g.read_len);
+        }
         pk.jobs.push_back(jd);
     }
     return HP_OK;
@@ -244,7 +281,18 @@ template <class T> int up(DevBuf& buf, const std::vector<T>& v) {
 int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, uint32_t band, uint64_t prune, uint64_t max_ed,
              int n_cu, std::vector<int32_t>& status, std::vector<uint64_t>& score, std::vector<std::vector<uint32_t>>& sets) {
     WfaPack pk;
+    pk.seq.clear();
+    {
+        size_t tot = 0, nn = 0;
+        for (uint32_t id : ids) { tot += hj[id].seq_bytes; nn += hj[id].nodes.size(); }
+        pk.seq.reserve(tot);
+        pk.nodes.reserve(nn);
+        pk.edges.reserve(nn * 2);
+        pk.jobs.reserve(ids.size());
+    }
+    const double t_pk0 = now_ms();
     int rc = pack_jobs(hj, ids, band, pk);
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa pack_jobs %.2f ms\n", now_ms() - t_pk0); fflush(stderr); }
     if (rc != HP_OK) return rc;
     const size_t n = ids.size();
     std::vector<uint32_t> order(n);
@@ -300,6 +348,7 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     (void)hipEventDestroy(e1);
     g_last_kernel_ms += kms;
     if (verbose) { fprintf(stderr, "[hp] wfa pack+upload %.2f ms, alloc/memset %.2f ms, kernel %.3f ms\n", t_up - t_pack, now_ms() - t_up - kms, kms); fflush(stderr); }
+    const double t_dl = now_ms();
     std::vector<int32_t> st(n);
     std::vector<uint64_t> sc(n);
     std::vector<uint32_t> all_sets(pk.out_set_words + 4);
@@ -311,6 +360,7 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
         score[ids[i]] = sc[i];
         sets[ids[i]].assign(all_sets.begin() + pk.jobs[i].out_set_off, all_sets.begin() + pk.jobs[i].out_set_off + pk.jobs[i].set_words);
     }
+    if (verbose) { fprintf(stderr, "[hp] wfa download+scatter %.2f ms\n", now_ms() - t_dl); fflush(stderr); }
     return HP_OK;
 }
 
@@ -328,10 +378,36 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
     std::vector<HostJob> hj(n);
     g_last_kernel_ms = 0.0;
     const double t_build = now_ms();
-    for (size_t i = 0; i < n; ++i) {
-        if (!jobs[i].reference || (!jobs[i].read && jobs[i].read_len)) { set_error("job %zu: null sequence", i); return HP_ERR_ARG; }
-        int rc = build_graph(&jobs[i], hj[i]);
-        if (rc != HP_OK) return rc;
+    {
+        // graph construction is independent per read: spread it over host threads (HP_WFA_HOST_THREADS, default
+        // min(8, cores)); the caller's own thread pool (main.rs:332) composes with this
+        const char* tenv = std::getenv("HP_WFA_HOST_THREADS");
+        unsigned nt = tenv ? (unsigned)std::atoi(tenv) : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        nt = (unsigned)std::min<size_t>(std::max(1u, nt), std::max<size_t>(1, n / 64));
+        std::atomic<int> first_rc{HP_OK};
+        std::vector<std::string> errs(nt);
+        auto work = [&](unsigned t) {
+            for (size_t i = t; i < n && first_rc.load(std::memory_order_relaxed) == HP_OK; i += nt) {
+                int rc = HP_OK;
+                if (!jobs[i].reference || (!jobs[i].read && jobs[i].read_len)) { set_error("job %zu: null sequence", i); rc = HP_ERR_ARG; }
+                else rc = build_graph(&jobs[i], hj[i]);
+                if (rc != HP_OK) {
+                    int exp = HP_OK;
+                    if (first_rc.compare_exchange_strong(exp, rc)) errs[t] = hp_last_error();
+                    return;
+                }
+            }
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+            for (auto& x : th) x.join();
+        }
+        if (first_rc.load() != HP_OK) {
+            for (auto& e : errs) if (!e.empty()) { set_error("%s", e.c_str()); break; }
+            return first_rc.load();
+        }
     }
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa graph build %.2f ms for %zu jobs\n", now_ms() - t_build, n); fflush(stderr); }
     // host-side work is done; from here on a GPU is mandatory (no CPU fallback)
@@ -359,6 +435,7 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
         band = (uint32_t)std::min<uint64_t>(max_ed, (uint64_t)band * 6);
         ids.swap(again);
     }
+    const double t_map = now_ms();
     for (size_t i = 0; i < n; ++i) {
         if (status[i] != WFA_ST_OK && status[i] != WFA_ST_MAX_ED) { set_error("job %zu: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
         out[i].status = status[i] == WFA_ST_OK ? HP_OK : HP_WFA_MAX_ED;
@@ -379,5 +456,6 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
             }
         }
     }
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa allele mapping %.2f ms\n", now_ms() - t_map); fflush(stderr); }
     return HP_OK;
 }
