@@ -617,8 +617,12 @@ int hp_astar_solve_batch(size_t n_blocks, const hp_block_view* blks, const hp_as
 
     // device_id == -1: host-side work queue over every visible GPU: blocks sorted by
     // estimated work (LPT), cut into chunks, one worker thread per device pulls chunks. No collective.
-    const int ndev = hp_device_count();
-    if (ndev <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return HP_ERR_HIP; }
+    const int real_dev = hp_device_count();
+    if (real_dev <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return HP_ERR_HIP; }
+    // HP_QUEUE_WORKERS=n (test hook): run the multi-device queue with n workers even on a 1-GPU box; worker w
+    // uses device w % real_dev
+    const char* wenv = std::getenv("HP_QUEUE_WORKERS");
+    const int ndev = wenv ? std::max(1, std::atoi(wenv)) : real_dev;
     if (ndev == 1) return solve_on_device(n_blocks, blks, p, h1, h2, out, 0);
     std::vector<uint32_t> order(n_blocks);
     std::iota(order.begin(), order.end(), 0u);
@@ -644,7 +648,7 @@ int hp_astar_solve_batch(size_t n_blocks, const hp_block_view* blks, const hp_as
                 std::vector<uint8_t*> p1(ids.size()), p2(ids.size());
                 std::vector<hp_phase_stats> st(ids.size());
                 for (size_t k = 0; k < ids.size(); ++k) { v[k] = blks[ids[k]]; p1[k] = h1 ? h1[ids[k]] : nullptr; p2[k] = h2 ? h2[ids[k]] : nullptr; }
-                int rc = solve_on_device(ids.size(), v.data(), p, p1.data(), p2.data(), st.data(), dev);
+                int rc = solve_on_device(ids.size(), v.data(), p, p1.data(), p2.data(), st.data(), dev % real_dev);
                 if (rc != HP_OK) { int exp = HP_OK; if (first_err.compare_exchange_strong(exp, rc)) errs[dev] = hp_last_error(); break; }
                 if (out) for (size_t k = 0; k < ids.size(); ++k) out[ids[k]] = st[k];
             }

@@ -305,3 +305,14 @@ def test_single_block_latency_uses_segments(monkeypatch):
     ms_seq = rb.solve()
     rb.close()
     assert ms_seg < ms_seq   # and typically > 10x faster
+
+
+def test_multi_device_queue_path(monkeypatch):
+    """hp_astar_solve_batch(device_id=-1): LPT-sorted, interleaved chunks pulled by one worker thread per device.
+    With one GPU on the box the queue is exercised with 3 workers sharing it (HP_QUEUE_WORKERS)."""
+    monkeypatch.setenv("HP_QUEUE_WORKERS", "3")
+    blocks = [synth_block(30 + 17 * i, 20, 12, 0.03, 0.02, 5200 + i)[0] for i in range(29)]
+    res = astar_solve_batch(blocks, device_id=-1)
+    for blk, r in zip(blocks, res):
+        h1, h2, st, _ = oracle_solve(blk)
+        assert np.array_equal(r.haplotype_1, h1) and np.array_equal(r.haplotype_2, h2) and r.statistics.as_tuple() == st
