@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["c2", "wgs"], default="c2")
-    ap.add_argument("--blocks", type=int, default=5120, help="blocks per GPU (20 resident single-wave workgroups per CU x 256 CUs)")
+    ap.add_argument("--blocks", type=int, default=6144, help="blocks per GPU (24 resident single-wave workgroups per CU x 256 CUs)")
     ap.add_argument("--hets", type=int, default=5000)
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--span", type=int, default=20)

@@ -216,7 +216,7 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     seg_blocks.clear();
     if (std::getenv("HP_NO_SEGMENTS") || !b->prm.sub_heap_in_lds || b->prm.max_seg > SEG_STATE) return HP_OK;
     const size_t lds_bytes = LDS_HEAP_OFF + (size_t)b->prm.jcap_sub * 64 * sizeof(uint64_t);
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(20, (160 * 1024) / lds_bytes);
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(24, (160 * 1024) / lds_bytes);
     const uint64_t max_slots = (uint64_t)b->n_cu * std::max(per_cu, 1u);
     uint64_t total = 0;
     for (auto& d : b->desc) total += d.n_vars;
@@ -301,7 +301,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const size_t lds_bytes = LDS_HEAP_OFF + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup
-    uint32_t per_cu = (uint32_t)std::min<size_t>(20, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
+    uint32_t per_cu = (uint32_t)std::min<size_t>(24, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
     if (per_cu == 0) per_cu = 1;
     prm.cap_chunk_main = cap_main / 4 + 64;
     const size_t main_pool_bytes = (size_t)cap_main * sizeof(FamRec) + (size_t)prm.cap_chunk_main * sizeof(ChunkRec);
@@ -398,7 +398,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     prm.max_seg = (uint32_t)max_seg;
     const uint64_t max_visits = (uint64_t)prm.minq_sub + (uint64_t)prm.qinc * max_seg;
     prm.cap_sub = (uint32_t)(4 * max_visits + 1);   // root + at most 4 children per visit
-    prm.jcap_sub = (prm.cap_sub + 63) / 64;   // node_index % 64 deals at most ceil(cap/64) keys to a lane
+    prm.jcap_sub = (uint32_t)((3 * max_visits + 63) / 64);   // <= 3 keys per visit are dealt round-robin to the lanes (SubHeap::replace_push)
     prm.cap_chunk_sub = (uint32_t)max_visits + 8;   // at most one ChunkRec per expansion
     prm.sub_heap_in_lds = ((size_t)prm.jcap_sub * 64 * sizeof(uint64_t) <= LDS_SUB_HEAP_MAX_BYTES) ? 1 : 0;
     if (prm.cap_sub >= (1u << 14)) { set_error("min_queue_size/10 + queue_increment*max_segment_size = %llu visits exceeds the packed sub-key limit (4093)", (unsigned long long)max_visits); return fail(HP_ERR_UNSUPPORTED); }

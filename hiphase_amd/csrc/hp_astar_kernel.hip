@@ -28,7 +28,7 @@ namespace hp {
 #define DEVINL __device__ __forceinline__
 
 // LDS layout (bytes): [0,512) H ring (64 x u64) | [512,1024) variant ring (64 x {lo, hi | flags << 28}) | [1024,...) sub heap
-// 1024 + 14 x 512 B of heap = 8 KiB at default parameters -> 20 single-wave workgroups per CU
+// 1024 + 11 x 512 B of heap = 6.5 KiB at default parameters -> up to 24 single-wave workgroups per CU
 constexpr uint32_t LDS_HRING_OFF = 0;
 constexpr uint32_t LDS_VRING_OFF = 512;
 constexpr uint32_t LDS_HEAP_OFF = 1024;
@@ -74,10 +74,17 @@ DEVINL void wave_sum8(const uint32_t (&a)[8], uint32_t (&out)[8]) {
     const uint32_t keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
     const uint32_t d = keep + dpp<0x128>(send);
     const uint32_t e = d + dpp_xor4(d);
+    // the four 16-lane rows are folded with the gfx950 row/half swaps (v_permlane16_swap: odd rows of the first
+    // operand <-> even rows of the second; v_permlane32_swap: upper half <-> lower half), leaving the total in
+    // every lane
+    const auto r16 = __builtin_amdgcn_permlane16_swap(e, e, false, false);
+    const uint32_t f = r16[0] + r16[1];
+    const auto r32 = __builtin_amdgcn_permlane32_swap(f, f, false, false);
+    const uint32_t g = r32[0] + r32[1];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int L = (j >> 2) | (((j >> 1) & 1) << 1) | ((j & 1) << 3);
-        out[j] = rdlane(e, L) + rdlane(e, L + 16) + rdlane(e, L + 32) + rdlane(e, L + 48);
+        out[j] = rdlane(g, L);
     }
 }
 DEVINL uint64_t wave_sum_u64(uint64_t v) {
@@ -172,6 +179,7 @@ template <bool LDS> struct SubHeap {
     uint64_t top;       // uniform cache of the global minimum (~0 when empty)
     uint32_t top_lane;  // uniform
     uint32_t ovf;       // per lane
+    uint32_t dealt;     // uniform: keys pushed so far (round-robin target lane)
     DEVINL uint64_t ld(uint32_t j) const {
         if (LDS) return reinterpret_cast<const uint64_t*>(hp_smem + LDS_HEAP_OFF)[j * 64 + lane_id()];
         return gbase[(size_t)j * 64 + lane_id()];
@@ -180,7 +188,7 @@ template <bool LDS> struct SubHeap {
         if (LDS) reinterpret_cast<uint64_t*>(hp_smem + LDS_HEAP_OFF)[j * 64 + lane_id()] = k;
         else gbase[(size_t)j * 64 + lane_id()] = k;
     }
-    DEVINL void reset() { cnt = 0; top = ~0ull; top_lane = 0; }
+    DEVINL void reset() { cnt = 0; top = ~0ull; top_lane = 0; dealt = 0; }
     DEVINL void push(uint64_t k) {  // uniform key; lane (node_index % 64) inserts it
         const uint32_t tgt = subkey_idx(k) & 63u;
         if (lane_id() == tgt) {
@@ -201,12 +209,16 @@ template <bool LDS> struct SubHeap {
     // up to four uniform keys (~0 = absent) with distinct target lanes (consecutive node indices): the target
     // lanes sift up concurrently inside one divergent region
     DEVINL void push4(uint64_t ka, uint64_t kb, uint64_t kc, uint64_t kd2) {
+        // keys are dealt to lanes round-robin by push order (uniform counter `dealt`): at most
+        // ceil(pushes/64) keys per lane, and only the non-kept children are ever pushed (<= 3 per visit)
         const uint32_t lane = lane_id();
         uint64_t mine = ~0ull;
-        if (ka != ~0ull && (subkey_idx(ka) & 63u) == lane) mine = ka;
-        if (kb != ~0ull && (subkey_idx(kb) & 63u) == lane) mine = kb;
-        if (kc != ~0ull && (subkey_idx(kc) & 63u) == lane) mine = kc;
-        if (kd2 != ~0ull && (subkey_idx(kd2) & 63u) == lane) mine = kd2;
+        uint32_t c = dealt;
+        const uint32_t ta = c & 63u; if (ka != ~0ull) { if (lane == ta) mine = ka; c += 1; }
+        const uint32_t tb = c & 63u; if (kb != ~0ull) { if (lane == tb) mine = kb; c += 1; }
+        const uint32_t tc = c & 63u; if (kc != ~0ull) { if (lane == tc) mine = kc; c += 1; }
+        const uint32_t td = c & 63u; if (kd2 != ~0ull) { if (lane == td) mine = kd2; c += 1; }
+        dealt = c;
         if (mine != ~0ull) {
             if (cnt >= jcap) ovf = 1;
             else {
@@ -220,8 +232,54 @@ template <bool LDS> struct SubHeap {
                 cnt += 1;
             }
         }
-        const uint64_t m = umin64(umin64(ka, kb), umin64(kc, kd2));
-        if (m < top) { top = m; top_lane = subkey_idx(m) & 63u; }
+        uint64_t m = ka; uint32_t tm = ta;
+        if (kb < m) { m = kb; tm = tb; }
+        if (kc < m) { m = kc; tm = tc; }
+        if (kd2 < m) { m = kd2; tm = td; }
+        if (m < top) { top = m; top_lane = tm; }
+    }
+    // pops the minimum and pushes k0 (present) + up to three more keys: the owner of the minimum re-uses the
+    // freed slot for k0 (one sift-down), so only k1..k3 are dealt out -> at most three dealt keys per visit and
+    // a per-lane bound of ceil(3 * max_visits / 64) entries (caller copied `top` first; heap is non-empty)
+    DEVINL void replace_push(uint64_t k0, uint64_t kb, uint64_t kc, uint64_t kd2) {
+        const uint32_t lane = lane_id();
+        uint64_t mine = ~0ull;
+        uint32_t c = dealt;
+        if (kb != ~0ull) { if (lane == (c & 63u)) mine = kb; c += 1; }
+        if (kc != ~0ull) { if (lane == (c & 63u)) mine = kc; c += 1; }
+        if (kd2 != ~0ull) { if (lane == (c & 63u)) mine = kd2; c += 1; }
+        dealt = c;
+        if (lane == top_lane) {
+            uint32_t i = 0;
+            for (;;) {
+                uint32_t ch = 2 * i + 1;
+                if (ch >= cnt) break;
+                uint64_t ck = ld(ch);
+                if (ch + 1 < cnt) {
+                    const uint64_t c2 = ld(ch + 1);
+                    if (c2 < ck) { ck = c2; ch += 1; }
+                }
+                if (ck < k0) { st(i, ck); i = ch; } else break;
+            }
+            st(i, k0);
+        }
+        if (mine != ~0ull) {
+            if (cnt >= jcap) ovf = 1;
+            else {
+                uint32_t j = cnt;
+                while (j > 0) {
+                    const uint32_t pj = (j - 1) >> 1;
+                    const uint64_t pk = ld(pj);
+                    if (mine < pk) { st(j, pk); j = pj; } else break;
+                }
+                st(j, mine);
+                cnt += 1;
+            }
+        }
+        const uint64_t root = cnt > 0 ? ld(0) : ~0ull;
+        top = wave_min_u64(root);
+        const uint64_t who = __ballot(cnt > 0 && root == top);
+        top_lane = who ? (uint32_t)__builtin_ctzll(who) : 0u;
     }
     DEVINL void pop() {  // removes the global minimum (caller copied `top` first)
         if (lane_id() == top_lane) {
@@ -619,17 +677,17 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         const bool take_child = kbest < heap.top;
         seg_stamp(wc, prof, 4);   // [4] child totals + keys
         fam_store(pl.fam, kd, cur, next_idx);  // one 64-byte record for all siblings
-        heap.push4((take_child && k0 == kbest) ? ~0ull : k0, (take_child && k1 == kbest) ? ~0ull : k1,
-                   (take_child && k2 == kbest) ? ~0ull : k2, (take_child && k3 == kbest) ? ~0ull : k3);
         if (take_child) {
+            heap.push4(k0 == kbest ? ~0ull : k0, k1 == kbest ? ~0ull : k1, k2 == kbest ? ~0ull : k2, k3 == kbest ? ~0ull : k3);
             if (k0 == kbest) cur = kid_as_cur<0>(kd, next_idx);
             else if (k1 == kbest) cur = kid_as_cur<1>(kd, next_idx);
             else if (k2 == kbest) cur = kid_as_cur<2>(kd, next_idx);
             else cur = kid_as_cur<3>(kd, next_idx);
         } else {
             const uint64_t t = heap.top;
-            heap.pop();
-            cur = cur_from_fam(load_fam(pl.fam + (subkey_idx(t) - subkey_rank(t))), subkey_rank(t), subkey_total(t), subkey_idx(t), off);
+            const FamRec fr = load_fam(pl.fam + (subkey_idx(t) - subkey_rank(t)));  // in flight during the heap update
+            heap.replace_push(k0, k1, k2, k3);
+            cur = cur_from_fam(fr, subkey_rank(t), subkey_total(t), subkey_idx(t), off);
         }
         next_idx += kd.n;
         seg_stamp(wc, prof, 5);   // [5] record store + heap pushes (+ pop on the slow path)
@@ -996,7 +1054,7 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
 }
 
 template <bool SUB_LDS>
-__global__ void __launch_bounds__(64, 5) hp_heur_seg_kernel(SegBatchDev S) {
+__global__ void __launch_bounds__(64, 6) hp_heur_seg_kernel(SegBatchDev S) {
     const uint32_t slot = blockIdx.x, G = gridDim.x;
     for (uint32_t round = 0;; ++round) {
         const uint32_t base = round * G;
@@ -1142,7 +1200,7 @@ __global__ void __launch_bounds__(256) hp_post_spans_kernel(PostDev P) {
 }
 
 template <bool SUB_LDS>
-__global__ void __launch_bounds__(64, 5) hp_astar_kernel(BatchDev B) {
+__global__ void __launch_bounds__(64, 6) hp_astar_kernel(BatchDev B) {
     const uint32_t slot = blockIdx.x;
     const uint32_t G = gridDim.x;
     // Static "snake" assignment over the LPT-sorted work list: workgroup w takes ranks w, 2G-1-w, 2G+w, ...
