@@ -216,7 +216,8 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     seg_blocks.clear();
     if (std::getenv("HP_NO_SEGMENTS") || !b->prm.sub_heap_in_lds || b->prm.max_seg > SEG_STATE) return HP_OK;
     const size_t lds_bytes = LDS_HEAP_OFF + (size_t)b->prm.jcap_sub * 64 * sizeof(uint64_t);
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(24, (160 * 1024) / lds_bytes);
+    const int occ = 6;
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(4 * occ, (160 * 1024) / lds_bytes);
     const uint64_t max_slots = (uint64_t)b->n_cu * std::max(per_cu, 1u);
     uint64_t total = 0;
     for (auto& d : b->desc) total += d.n_vars;
@@ -270,7 +271,7 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     S.segs = b->d_segs.as<SegDesc>(); S.seg_order = b->d_seg_order.as<uint32_t>(); S.n_segs = (uint32_t)segs.size();
     S.out = b->d_seg_out.as<SegOut>();
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] segment-parallel heuristic: %zu segments of ~%llu hets (+%u warm-up) over %zu blocks, slots=%u\n", segs.size(), (unsigned long long)target, warm, sb_id.size(), slots); fflush(stderr); }
-    hipLaunchKernelGGL(hp_heur_seg_kernel<true>, dim3(slots), dim3(64), lds_bytes, st, S);
+    hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6>), dim3(slots), dim3(64), lds_bytes, st, S);
     StitchDev T{};
     T.desc = B.desc; T.segs = S.segs; T.out = S.out;
     T.blk_first_seg = b->d_sb_first.as<uint32_t>(); T.blk_n_seg = b->d_sb_n.as<uint32_t>(); T.blk_id = b->d_sb_id.as<uint32_t>();
@@ -301,7 +302,8 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const size_t lds_bytes = LDS_HEAP_OFF + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup
-    uint32_t per_cu = (uint32_t)std::min<size_t>(24, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
+    const int occ = prm.sub_heap_in_lds ? 6 : 4;
+    uint32_t per_cu = (uint32_t)std::min<size_t>(4 * occ, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
     if (per_cu == 0) per_cu = 1;
     prm.cap_chunk_main = cap_main / 4 + 64;
     const size_t main_pool_bytes = (size_t)cap_main * sizeof(FamRec) + (size_t)prm.cap_chunk_main * sizeof(ChunkRec);
@@ -344,10 +346,8 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     B.sub_heap_g = sub_heap.as<uint64_t>(); B.main_heap = main_heap.as<Key>(); B.tracker = tracker.as<uint32_t>();
     B.prm = prm;
     if (verbose) { fprintf(stderr, "[hp] launch items=%zu slots=%u cap_main=%u cap_sub=%u jcap_sub=%u lds=%zu stage=%u\n", items.size(), slots, cap_main, prm.cap_sub, prm.jcap_sub, lds_bytes, prm.pad0); fflush(stderr); }
-    if (prm.sub_heap_in_lds)
-        hipLaunchKernelGGL(hp_astar_kernel<true>, dim3(slots), dim3(64), lds_bytes, st, B);
-    else
-        hipLaunchKernelGGL(hp_astar_kernel<false>, dim3(slots), dim3(64), lds_bytes, st, B);
+    if (!prm.sub_heap_in_lds) hipLaunchKernelGGL((hp_astar_kernel<false, 4>), dim3(slots), dim3(64), lds_bytes, st, B);
+    else hipLaunchKernelGGL((hp_astar_kernel<true, 6>), dim3(slots), dim3(64), lds_bytes, st, B);
     HP_HIP_CHECK(hipGetLastError());
     return HP_OK;
 }
@@ -388,7 +388,11 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) b->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(HP_ERR_HIP); }
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { set_error("hipEventCreate failed"); return fail(HP_ERR_HIP); }
-    if (hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&b->ev_fork) != hipSuccess ||
+    // the segment stream carries the critical path: a high-priority stream also gets a hardware queue of its own
+    // (streams of equal priority may share one when the host process has created many, e.g. under PyTorch)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess || hipEventCreate(&b->ev_fork) != hipSuccess ||
         hipEventCreate(&b->ev_join) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(HP_ERR_HIP); }
 
     SolveParams& prm = b->prm;
