@@ -120,6 +120,53 @@ class EdPair(C.Structure):
     ]
 
 
+class LocalVariant(C.Structure):
+    _fields_ = [
+        ("position", C.c_int64),
+        ("ref_len", C.c_uint32),
+        ("variant_type", C.c_uint32),
+        ("prefix_len", C.c_uint32),
+        ("postfix_len", C.c_uint32),
+        ("allele0", C.POINTER(C.c_uint8)),
+        ("allele1", C.POINTER(C.c_uint8)),
+        ("allele0_len", C.c_uint32),
+        ("allele1_len", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class LocalRead(C.Structure):
+    _fields_ = [
+        ("pos", C.c_int64),
+        ("cigar", C.POINTER(C.c_uint32)),
+        ("n_cigar", C.c_uint32),
+        ("seq_len", C.c_uint32),
+        ("seq", C.POINTER(C.c_uint8)),
+        ("qual", C.POINTER(C.c_uint8)),
+    ]
+
+
+N_VARIANT_TYPES = 11
+
+
+class ReadStats(C.Structure):
+    _fields_ = [
+        ("skipped_reads", C.c_uint64),
+        ("num_alleles", C.c_uint64),
+        ("exact_matches", C.c_uint64 * N_VARIANT_TYPES),
+        ("inexact_matches", C.c_uint64 * N_VARIANT_TYPES),
+        ("failed_matches", C.c_uint64 * N_VARIANT_TYPES),
+        ("allele0_matches", C.c_uint64 * N_VARIANT_TYPES),
+        ("allele1_matches", C.c_uint64 * N_VARIANT_TYPES),
+        ("local_aligned", C.c_uint64),
+    ]
+
+    def as_tuple(self):
+        return (self.skipped_reads, self.num_alleles, tuple(self.exact_matches), tuple(self.inexact_matches),
+                tuple(self.failed_matches), tuple(self.allele0_matches), tuple(self.allele1_matches), self.local_aligned)
+
+
 # Every symbol include/hiphase_gpu.h declares; tests check the library exports all of them.
 EXPORTS = [
     "hp_astar_solve",
@@ -131,6 +178,7 @@ EXPORTS = [
     "hp_batch_destroy",
     "hp_wfa_assign_batch",
     "hp_edit_distance_batch",
+    "hp_local_realign_batch",
     "hp_device_count",
     "hp_default_device",
     "hp_last_error",
@@ -184,6 +232,9 @@ def lib():
                                         C.POINTER(WfaResult), C.POINTER(C.c_void_p), C.c_int]
     dll.hp_edit_distance_batch.restype = C.c_int
     dll.hp_edit_distance_batch.argtypes = [C.POINTER(EdPair), C.c_size_t, C.POINTER(C.c_uint64), C.c_int]
+    dll.hp_local_realign_batch.restype = C.c_int
+    dll.hp_local_realign_batch.argtypes = [C.POINTER(LocalRead), C.c_size_t, C.POINTER(LocalVariant), C.c_size_t,
+                                           C.c_void_p, C.c_void_p, C.POINTER(ReadStats), C.c_int]
     dll.hp_device_count.restype = C.c_int
     dll.hp_default_device.restype = C.c_int
     dll.hp_last_error.restype = C.c_char_p

@@ -6,7 +6,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from .astar_phaser import astar_solver
-from .read_parsing import load_full_read_segments
+from .read_parsing import load_full_read_segments, load_read_segments
 from .read_segments import AlleleType, BlockMatrix
 from .wfa_graph import VariantType
 
@@ -44,6 +44,41 @@ def haplotag_reads(read_segments, h1, h2, block_tags):
     return out
 
 
+def add_reference_buffer(variant_calls, reference, reference_buffer=15, ref_base=0):
+    """The +-reference_buffer allele padding of `load_variant_calls` (phaser.rs:236-294) for the het calls of a
+    block, in VCF order: prefix = up to `reference_buffer` reference bases before the variant (not reaching into the
+    previous het, whose postfix is truncated instead), postfix = `reference_buffer` bases after it. Only local
+    re-alignment reads the padded alleles; the WFA path uses the truncated ones."""
+    if reference_buffer <= 0:
+        return
+    previous_het_end = 0
+    prev = None
+    for v in variant_calls:
+        position, ref_len = v.position, v.ref_len
+        ref_prefix_start = position - reference_buffer if position > reference_buffer else 0
+        ref_postfix_start = position + ref_len
+        if ref_prefix_start < previous_het_end:
+            assert prev is not None
+            current_end = prev.position + prev.ref_len + prev.postfix_len
+            prev.truncate_reference_postfix(min(current_end - position, prev.postfix_len))
+            ref_prefix_start = min(previous_het_end, position)
+        v.add_reference_prefix(reference[ref_prefix_start - ref_base:position - ref_base])
+        v.add_reference_postfix(reference[ref_postfix_start - ref_base:ref_postfix_start + reference_buffer - ref_base])
+        previous_het_end = position + ref_len
+        prev = v
+
+
+def ignore_tandem_repeat_contained(variant_calls, hom_calls):
+    """phaser.rs:448-513: every non-TR variant fully contained in a loaded TandemRepeat call is set ignored."""
+    trs = [(v.position, v.position + v.ref_len) for v in list(variant_calls) + list(hom_calls)
+           if v.variant_type == VariantType.TandemRepeat]
+    for v in list(variant_calls) + list(hom_calls):
+        if v.variant_type != VariantType.TandemRepeat:
+            start, end = v.position, v.position + v.ref_len
+            if any(s <= start and e >= end and s < end and start < e for s, e in trs):
+                v.is_ignored = True
+
+
 @dataclass
 class PhaseResult:
     """phaser.rs:326-343 (the solver-facing fields)"""
@@ -56,10 +91,15 @@ class PhaseResult:
 
 
 def solve_block(block_index, records, variant_calls, hom_calls, reference, ref_base=0, min_matched_alleles=2,
-                min_queue_size=1000, queue_increment=3, global_config=None, local_realignment=None, device_id=0):
-    """phaser.rs:406-649 from `load_full_read_segments` on."""
-    segs, phasable, _stats = load_full_read_segments(records, variant_calls, hom_calls, reference, ref_base,
-                                                      min_matched_alleles, global_config, local_realignment, device_id)
+                min_queue_size=1000, queue_increment=3, global_config=None, device_id=0, global_realignment=True):
+    """phaser.rs:406-649 from the read loading on: global re-alignment (`load_full_read_segments`, records are
+    AlignedRecord) or, with global_realignment=False (--disable-global-realignment, phaser.rs:521-537), local
+    re-alignment (`load_read_segments`, records are LocalRecord)."""
+    if global_realignment:
+        segs, phasable, _stats = load_full_read_segments(records, variant_calls, hom_calls, reference, ref_base,
+                                                          min_matched_alleles, global_config, device_id)
+    else:
+        segs, phasable, _stats, _ = load_read_segments(records, variant_calls, min_matched_alleles, device_id)
     flags = np.asarray([(1 if v.is_ignored else 0) | (2 if v.variant_type == VariantType.Snv else 0)
                         for v in variant_calls], np.uint8)
     matrix = BlockMatrix.from_segments(segs, len(variant_calls), flags)

@@ -47,6 +47,39 @@ class Variant:
     index_allele1: int = 1
     is_ignored: bool = False
     vcf_index: int = 0
+    prefix: bytes = b""     # reference bases added by add_reference_prefix (local re-alignment only)
+    postfix: bytes = b""    # ... add_reference_postfix
+
+    # +-reference_buffer padding (variants.rs:497-539; applied by phaser.rs:236-294), used by local re-alignment
+    def add_reference_prefix(self, prefix):
+        assert len(prefix) <= self.position - len(self.prefix)
+        self.prefix = bytes(prefix) + self.prefix
+
+    def add_reference_postfix(self, postfix):
+        self.postfix = self.postfix + bytes(postfix)
+
+    def truncate_reference_postfix(self, amount):
+        assert amount <= len(self.postfix)
+        self.postfix = self.postfix[:len(self.postfix) - amount]
+
+    @property
+    def prefix_len(self):
+        return len(self.prefix)
+
+    @property
+    def postfix_len(self):
+        return len(self.postfix)
+
+    def get_allele0(self):
+        return self.prefix + self.allele0 + self.postfix
+
+    def get_allele1(self):
+        return self.prefix + self.allele1 + self.postfix
+
+    def match_allele(self, allele):
+        """variants.rs:598-606"""
+        allele = bytes(allele)
+        return 0 if allele == self.get_allele0() else (1 if allele == self.get_allele1() else 2)
 
     # constructors with the reference's validation essentials (variants.rs:109-492)
     @staticmethod

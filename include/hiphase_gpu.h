@@ -7,6 +7,7 @@
  *   - src/read_parsing.rs:769-780      WFAGraph::from_reference_variants_with_hom + edit_distance_with_pruning
  *                                                                                  -> hp_wfa_assign_batch
  *   - src/data_types/variants.rs:627   sequence_alignment::edit_distance           -> hp_edit_distance_batch
+ *   - src/read_parsing.rs:75,570       local_realignment(&read, variant_calls)     -> hp_local_realign_batch
  *   - src/phaser.rs:546,614-623        get_solution_span_counts / haplotag_reads   -> hp_batch_postprocess
  * INTEGRATION.md shows the `extern "C"` block + call-site patch a HiPhase maintainer would add.
  *
@@ -176,6 +177,54 @@ int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
 /* ---- Levenshtein (sequence_alignment.rs:7-38) --------------------------------------------- */
 typedef struct hp_ed_pair { const uint8_t* a; const uint8_t* b; uint32_t a_len; uint32_t b_len; } hp_ed_pair;
 int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_t* out, int device_id);
+
+/* ---- local re-alignment (read_parsing.rs:121-503) ------------------------------------------ */
+/* Replaces `local_realignment(read, variant_calls)` for a batch of BAM records of one block: the per-variant
+ * coordinate logic, exact matching and quality scaling run on the host exactly as the reference runs them; every
+ * inexact allele (Variant::closest_allele_clip, variants.rs:624-641) of the whole batch goes to the device in ONE
+ * Levenshtein launch. Used by `load_read_segments` (read_parsing.rs:47-113, --disable-global-realignment) and
+ * by the fallback branch of `load_full_read_segments` (read_parsing.rs:564-575). */
+typedef struct hp_local_variant {        /* what local_realignment reads from a `Variant` (variants.rs:67-94) */
+    int64_t        position;             /* Variant::position() */
+    uint32_t       ref_len;              /* get_ref_len() */
+    uint32_t       variant_type;         /* VariantType repr, variants.rs:10-33 (Snv 0 ... Unknown 10) */
+    uint32_t       prefix_len;           /* get_prefix_len() */
+    uint32_t       postfix_len;          /* get_postfix_len() */
+    const uint8_t* allele0;              /* get_allele0(): prefix + allele + postfix */
+    const uint8_t* allele1;              /* get_allele1() */
+    uint32_t       allele0_len;
+    uint32_t       allele1_len;
+    uint32_t       flags;                /* HP_VAR_IGNORED */
+    uint32_t       reserved;
+} hp_local_variant;
+
+typedef struct hp_local_read {           /* what local_realignment reads from a bam::Record */
+    int64_t         pos;                 /* read.pos() */
+    const uint32_t* cigar;               /* BAM encoding: op_len << 4 | op (MIDNSHP=X = 0..8) */
+    uint32_t        n_cigar;
+    uint32_t        seq_len;
+    const uint8_t*  seq;                 /* read.seq().as_bytes() (ASCII) */
+    const uint8_t*  qual;                /* read.qual() */
+} hp_local_read;
+
+#define HP_N_VARIANT_TYPES 11            /* VariantType::Unknown as usize + 1 */
+typedef struct hp_read_stats {           /* ReadStats of one record (writers/phase_stats.rs:12-33) */
+    uint64_t skipped_reads;              /* 1 when no allele was determined */
+    uint64_t num_alleles;
+    uint64_t exact_matches[HP_N_VARIANT_TYPES];
+    uint64_t inexact_matches[HP_N_VARIANT_TYPES];
+    uint64_t failed_matches[HP_N_VARIANT_TYPES];
+    uint64_t allele0_matches[HP_N_VARIANT_TYPES];
+    uint64_t allele1_matches[HP_N_VARIANT_TYPES];
+    uint64_t local_aligned;
+} hp_read_stats;
+
+/* alleles / quals: n_reads x n_variants bytes, row-major (row r = the Vec<AlleleType> / Vec<u8> the reference
+ * returns for reads[r]). stats: n_reads entries or NULL. A CIGAR with a Pad op returns HP_ERR_UNSUPPORTED (the
+ * reference's rust-htslib 0.39.5 `aligned_pairs` panics on it); a variant type the reference has no
+ * implementation for (read_parsing.rs:317,455 panic) returns HP_ERR_INVARIANT. */
+int hp_local_realign_batch(const hp_local_read* reads, size_t n_reads, const hp_local_variant* variants,
+                           size_t n_variants, uint8_t* alleles, uint8_t* quals, hp_read_stats* stats, int device_id);
 
 /* ---- misc --------------------------------------------------------------------------------- */
 int         hp_device_count(void);

@@ -64,6 +64,16 @@ int hpo_haplotag_reads(const hp_block_view* blk, const uint8_t* h1, const uint8_
 /* ---- sequence_alignment.rs -------------------------------------------------------------------- */
 uint64_t hpo_edit_distance(const uint8_t* v1, size_t l1, const uint8_t* v2, size_t l2);
 
+/* ---- read_parsing.rs: local re-alignment (hp_oracle_local.cpp; PARITY UNPINNED upstream) -------- */
+/* Variant::match_allele (variants.rs:598-606) -> 0 / 1 / 2 */
+int hpo_match_allele(const hp_local_variant* variant, const uint8_t* allele, size_t len);
+/* Variant::closest_allele_clip (variants.rs:624-641) -> AlleleType 0/1/2 (+ min / other distance), -1 on a failed assert */
+int hpo_closest_allele_clip(const hp_local_variant* variant, const uint8_t* allele, size_t len, size_t head_clip,
+                            size_t tail_clip, uint64_t* dmin, uint64_t* dother);
+/* local_realignment (read_parsing.rs:121-503) for ONE record: alleles/quals hold num_variants bytes; -3 = panic */
+int hpo_local_realignment(const hp_local_read* read, const hp_local_variant* variant_calls, size_t num_variants,
+                          uint8_t* alleles, uint8_t* quals, hp_read_stats* stats);
+
 /* ---- wfa_graph.rs ------------------------------------------------------------------------------ */
 typedef struct hpo_graph hpo_graph;
 hpo_graph* hpo_graph_new(uint64_t max_edit_distance);

@@ -156,7 +156,21 @@ seq_align = {
             ["A", 0, 5, 7], ["AGT", 0, 4, 5], ["AG", 0, 4, 6],
             ["ACAGGC", 0, 0, 2], ["ACAGTGGC", 1, 0, 2], ["ACAGGGC", 2, 1, 1],
         ],
+        # same test, :832-835: the un-padded alleles no longer match exactly once prefix/postfix are attached
+        "match_after_padding": [["A", 2], ["AGT", 2], ["AG", 2]],
     },
+    # Variant::match_allele on the constructor tests, variants.rs:668-797: (kind, position, ref_len, allele0,
+    # allele1, index_allele0, index_allele1, [(observed, expected 0/1/2)])
+    "match_allele": [
+        ["snv", 1, 1, "A", "C", 0, 1, [["A", 0], ["C", 1], ["G", 2], ["T", 2]]],                  # :668-687
+        ["deletion", 10, 3, "AGT", "A", 0, 1, [["AGT", 0], ["A", 1], ["AG", 2]]],                # :689-700
+        ["deletion", 10, 4, "C", "A", 1, 2, [["ACCC", 2], ["C", 0], ["A", 1]]],                  # :702-714
+        ["insertion", 20, 1, "A", "AGT", 0, 1, [["A", 0], ["AGT", 1], ["AG", 2]]],               # :718-731
+        ["indel", 20, 2, "A", "AGT", 1, 2, [["A", 0], ["AGT", 1], ["AG", 2]]],                   # :733-747
+        ["sv_insertion", 20, 1, "A", "AGT", 0, 1, [["A", 0], ["AGT", 1], ["AG", 2]]],            # :749-763
+        ["sv_deletion", 10, 3, "AGT", "A", 0, 1, [["AGT", 0], ["A", 1], ["AG", 2]]],             # :765-780
+        ["tandem_repeat", 10, 4, "AAAC", "AAACAAAC", 0, 1, [["AAAC", 0], ["AAACAAAC", 1], ["AAACAA", 2]]],  # :782-797
+    ],
 }
 dump("sequence_alignment.json", seq_align)
 

@@ -55,6 +55,14 @@ def oracle():
                                      C.c_void_p]
     d.hpo_edit_distance.restype = C.c_uint64
     d.hpo_edit_distance.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    d.hpo_match_allele.restype = C.c_int
+    d.hpo_match_allele.argtypes = [C.POINTER(_ffi.LocalVariant), C.c_void_p, C.c_size_t]
+    d.hpo_closest_allele_clip.restype = C.c_int
+    d.hpo_closest_allele_clip.argtypes = [C.POINTER(_ffi.LocalVariant), C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                          u64p, u64p]
+    d.hpo_local_realignment.restype = C.c_int
+    d.hpo_local_realignment.argtypes = [C.POINTER(_ffi.LocalRead), C.POINTER(_ffi.LocalVariant), C.c_size_t, C.c_void_p,
+                                        C.c_void_p, C.POINTER(_ffi.ReadStats)]
     d.hpo_graph_new.restype = C.c_void_p
     d.hpo_graph_new.argtypes = [C.c_uint64]
     d.hpo_graph_free.restype = None

@@ -81,19 +81,3 @@ def test_block_end_to_end(seed):
     ph = h1 != h2
     agree = (h1[ph] == np.asarray(truth)[ph]).mean()
     assert min(agree, 1 - agree) < 0.05
-
-
-def test_fallback_replay_rule():
-    """global_disabled (read_parsing.rs:597-600): with global_failure_minimum=1 and max_edit_distance so small that
-    the first overlapping read fails, every later read goes to the local callback without consulting its WFA result."""
-    ref, hets, homs, records, _ = make_block(4, n_reads=30)
-    calls = []
-
-    def local(rec):
-        calls.append(rec.qname)
-        return np.full(len(hets), 3, np.uint8), np.zeros(len(hets), np.uint8)
-
-    cfg = GlobalRealignmentConfig(max_edit_distance=0, global_failure_minimum=1, global_failure_ratio=0.5)
-    segs, phasable, stats = load_full_read_segments(records, hets, homs, ref, config=cfg, local_realignment=local)
-    assert stats.global_aligned + stats.local_aligned == len(calls) + stats.global_aligned
-    assert stats.local_aligned >= 1 and stats.global_aligned <= 1 and not segs

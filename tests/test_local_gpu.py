@@ -1,0 +1,210 @@
+"""hp_local_realign_batch (HIP edit-distance batch + host coordinate logic) against the CPU oracle's per-record
+`local_realignment` (oracle/hp_oracle_local.cpp), plus the two callers: `load_read_segments` (local mode) and the
+order-dependent fallback replay of `load_full_read_segments` (read_parsing.rs:556-605)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from hiphase_amd import _ffi
+from hiphase_amd._ffi import HpError
+from hiphase_amd.phaser import solve_block
+from hiphase_amd.read_parsing import (AlignedRecord, GlobalRealignmentConfig, LocalRecord, load_full_read_segments,
+                                      load_read_segments, local_realignment_batch)
+from hiphase_amd.read_segments import BlockMatrix, ReadSegment
+from hiphase_amd.wfa_graph import BASE_QUAL, Variant, VariantType, WfaJobSpec, make_jobs
+from local_util import make_local_block, oracle_local
+from oracle_ffi import oracle, oracle_solve
+
+pytestmark = pytest.mark.gpu
+
+
+def seg_tuple(s):
+    return (s.read_name, s.start, s.end, list(s.alleles), list(s.quals))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_local_batch_vs_oracle(hp_lib, oracle_lib, seed):
+    ref, variants, truth, records = make_local_block(seed, noise=0.004 * seed)
+    al, ql, st = local_realignment_batch(records, variants)
+    oal, oql, ost, rcs = oracle_local(oracle_lib, records, variants)
+    assert all(rc == 0 for rc in rcs)
+    assert np.array_equal(al, oal)
+    assert np.array_equal(ql, oql)
+    assert [s.as_tuple() for s in st] == ost
+    # the test data exercises the device path: some alleles were decided by edit distances
+    assert sum(sum(s[3]) for s in ost) > 0
+
+
+def test_local_batch_large_and_thread_invariant(hp_lib, oracle_lib):
+    ref, variants, truth, records = make_local_block(77, ref_len=60000, n_vars=500, n_reads=600, read_len=(2000, 15000), noise=0.01)
+    al, ql, st = local_realignment_batch(records, variants)
+    os.environ["HP_LOCAL_HOST_THREADS"] = "1"
+    try:
+        al1, ql1, st1 = local_realignment_batch(records, variants)
+    finally:
+        del os.environ["HP_LOCAL_HOST_THREADS"]
+    assert np.array_equal(al, al1) and np.array_equal(ql, ql1)
+    assert [s.as_tuple() for s in st] == [s.as_tuple() for s in st1]
+    oal, oql, ost, rcs = oracle_local(oracle_lib, records, variants)
+    assert all(rc == 0 for rc in rcs)
+    assert np.array_equal(al, oal) and np.array_equal(ql, oql) and [s.as_tuple() for s in st] == ost
+
+
+def test_local_batch_edge_cases(hp_lib, oracle_lib):
+    ref, variants, truth, records = make_local_block(9, n_reads=4)
+    # empty inputs
+    al, ql, st = local_realignment_batch([], variants)
+    assert al.shape[0] == 0 and st == []
+    al, ql, st = local_realignment_batch(records, [])
+    assert al.shape == (len(records), 0) and all(s.skipped_reads == 1 for s in st)
+    # a record without any aligned base, and one with an empty CIGAR
+    odd = [LocalRecord("clip", 100, [("S", 20)], ref[:20], bytes([30]) * 20), LocalRecord("none", 100, [], b"", b"")]
+    al, ql, st = local_realignment_batch(odd, variants)
+    oal, oql, ost, rcs = oracle_local(oracle_lib, odd, variants)
+    assert rcs == [0, 0] and np.array_equal(al, oal) and np.array_equal(ql, oql) and [s.as_tuple() for s in st] == ost
+    # errors mirror the reference's panics
+    with pytest.raises(HpError) as e:
+        local_realignment_batch([LocalRecord("pad", 10, [("M", 5), ("P", 1), ("M", 5)], ref[10:20], bytes([30]) * 10)], variants)
+    assert e.value.code == -5
+    bad = Variant(VariantType.SvInversion, 500, 1, b"A", b"C")
+    with pytest.raises(HpError) as e:
+        local_realignment_batch(records, [bad])
+    assert e.value.code == -3
+    with pytest.raises(HpError) as e:   # CIGAR longer than the sequence (slice panic upstream)
+        local_realignment_batch([LocalRecord("short", 10, [("M", 50)], ref[10:30], bytes([30]) * 20)], variants)
+    assert e.value.code == -4
+
+
+def oracle_segments(oracle_lib, records, variants, min_matched=2):
+    oal, oql, ost, rcs = oracle_local(oracle_lib, records, variants)
+    groups = {}
+    for i, rec in enumerate(records):
+        if ost[i][0] == 0:
+            groups.setdefault(rec.qname, []).append(ReadSegment(rec.qname, oal[i].tolist(), oql[i].tolist()))
+    segs, phasable = [], []
+    for q, grp in groups.items():
+        col = ReadSegment.collapse(grp)
+        if col.get_num_set() >= min_matched:
+            segs.append(col)
+        elif col.get_num_set() > 0:
+            phasable.append(col)
+    return segs, phasable
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_local_mode_block_end_to_end(hp_lib, oracle_lib, seed):
+    """--disable-global-realignment: load_read_segments -> matrix -> HIP A* against the oracle-assembled pipeline."""
+    ref, variants, truth, records = make_local_block(seed, ref_len=20000, n_vars=120, n_reads=200, read_len=(1500, 6000))
+    # supplementary-style second record under an existing qname -> collapse
+    records.append(LocalRecord(records[0].qname, records[5].pos, records[5].cigar, records[5].seq, records[5].qual))
+    segs, phasable, stats, _ = load_read_segments(records, variants)
+    osegs, ophas = oracle_segments(oracle_lib, records, variants)
+    assert [seg_tuple(s) for s in segs] == [seg_tuple(s) for s in osegs]
+    assert [seg_tuple(s) for s in phasable] == [seg_tuple(s) for s in ophas]
+    res, matrix, _ = solve_block(3, records, variants, [], ref, global_realignment=False)
+    flags = np.asarray([(1 if v.is_ignored else 0) | (2 if v.variant_type == VariantType.Snv else 0) for v in variants], np.uint8)
+    om = BlockMatrix.from_segments(osegs, len(variants), flags)
+    h1, h2, st, _ = oracle_solve(om)
+    assert np.array_equal(res.haplotype_1, h1) and np.array_equal(res.haplotype_2, h2) and res.statistics == st
+
+
+def to_aligned(rec):
+    """AlignedRecord view of a LocalRecord (read_parsing.rs:672-742): first/last aligned reference base and the read
+    bases between them."""
+    q, r, first, last = 0, rec.pos, None, None
+    for op, n in rec.cigar:
+        if op in "M=X":
+            if first is None:
+                first = (r, q)
+            last = (r + n - 1, q + n - 1)
+            q += n; r += n
+        elif op in "IS":
+            q += n
+        elif op in "DN":
+            r += n
+    return AlignedRecord(rec.qname, first[0], last[0], rec.seq[first[1]:last[1] + 1], rec)
+
+
+def reference_order_replay(oracle_lib, ref, hets, records, cfg):
+    """load_full_read_segments exactly as the reference runs it, one record at a time (read_parsing.rs:545-605), on
+    the oracle's WFA and local re-alignment."""
+    d = oracle_lib
+    groups, n = {}, len(hets)
+    global_disabled, fails, total = False, 0.0, 0.0
+    n_local = n_global = n_skipped = 0
+    for rec in records:
+        def local():
+            al, ql, st, rc = oracle_local(d, [rec.local], hets)
+            assert rc == [0]
+            return al[0].tolist(), ql[0].tolist(), st[0][0] == 1
+        if global_disabled:
+            alleles, quals, skipped = local()
+            was_local = True
+        else:
+            idx = [i for i, v in enumerate(hets) if rec.min_position <= v.position <= rec.max_position]
+            if not idx:
+                n_skipped += 1
+                continue
+            first, last = idx[0], idx[-1] + 1
+            spec = WfaJobSpec(ref, rec.min_position, rec.max_position + 1, hets[first:last], [], rec.read_align)
+            jobs, keep = make_jobs([spec])
+            out = _ffi.WfaResult()
+            al = np.full(max(1, last - first), 3, np.uint8)
+            assert d.hpo_wfa_assign(C.byref(jobs[0]), cfg.wfa_prune_distance, cfg.max_edit_distance, C.byref(out), al.ctypes.data) == 0
+            if out.status != 0:
+                alleles, quals, skipped = local()
+                was_local = True
+            else:
+                alleles, quals = [3] * n, [0] * n
+                for k, i in enumerate(range(first, last)):
+                    alleles[i] = int(al[k])
+                    if alleles[i] < 2:
+                        quals[i] = 2 * BASE_QUAL[VariantType(hets[i].variant_type)]
+                skipped, was_local = False, False
+        if skipped:
+            n_skipped += 1
+            continue
+        groups.setdefault(rec.qname, []).append(ReadSegment(rec.qname, alleles, quals))
+        n_local += was_local
+        n_global += not was_local
+        fails += 1.0 if was_local else 0.0
+        total += 1.0
+        if not global_disabled and fails >= cfg.global_failure_minimum and fails / total >= cfg.global_failure_ratio:
+            global_disabled = True
+    segs = []
+    for q, grp in groups.items():
+        col = ReadSegment.collapse(grp)
+        if col.get_num_set() >= 2:
+            segs.append(col)
+    return segs, n_local, n_global, global_disabled
+
+
+@pytest.mark.parametrize("max_ed,minimum,ratio,expect_flip", [(4, 5, 0.3, True), (8, 10, 0.9, False), (3000, 1, 0.5, False)])
+def test_fallback_replay_vs_reference_order(hp_lib, oracle_lib, max_ed, minimum, ratio, expect_flip):
+    ref, variants, truth, lrecs = make_local_block(21, ref_len=20000, n_vars=100, n_reads=120, read_len=(800, 3000), noise=0.004)
+    hets = [v for v in variants if int(v.variant_type) in (0, 1, 2, 3)]   # small variants: quick WFA jobs
+    records = [to_aligned(r) for r in lrecs if any(op in "M=X" for op, _ in r.cigar)]
+    cfg = GlobalRealignmentConfig(max_edit_distance=max_ed, wfa_prune_distance=max_ed, global_failure_minimum=minimum,
+                                  global_failure_ratio=ratio)
+    segs, phasable, stats = load_full_read_segments(records, hets, [], ref, config=cfg)
+    osegs, n_local, n_global, flipped = reference_order_replay(oracle_lib, ref, hets, records, cfg)
+    assert flipped == expect_flip
+    assert (stats.local_aligned, stats.global_aligned) == (n_local, n_global)
+    assert [seg_tuple(s) for s in segs] == [seg_tuple(s) for s in osegs]
+    if max_ed == 3000:
+        assert stats.local_aligned == 0
+    else:
+        assert stats.local_aligned > 0
+
+
+def test_fallback_without_cigar_is_loud(hp_lib):
+    ref, variants, truth, lrecs = make_local_block(22, n_reads=10)
+    hets = [v for v in variants if int(v.variant_type) in (0, 1, 2, 3)]
+    records = [to_aligned(r) for r in lrecs if any(op in "M=X" for op, _ in r.cigar)]
+    for r in records:
+        r.local = None
+    cfg = GlobalRealignmentConfig(max_edit_distance=0, wfa_prune_distance=0)
+    with pytest.raises(NotImplementedError):
+        load_full_read_segments(records, hets, [], ref, config=cfg)
