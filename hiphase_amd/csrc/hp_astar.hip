@@ -346,8 +346,9 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     B.sub_heap_g = sub_heap.as<uint64_t>(); B.main_heap = main_heap.as<Key>(); B.tracker = tracker.as<uint32_t>();
     B.prm = prm;
     if (verbose) { fprintf(stderr, "[hp] launch items=%zu slots=%u cap_main=%u cap_sub=%u jcap_sub=%u lds=%zu stage=%u\n", items.size(), slots, cap_main, prm.cap_sub, prm.jcap_sub, lds_bytes, prm.pad0); fflush(stderr); }
-    if (!prm.sub_heap_in_lds) hipLaunchKernelGGL((hp_astar_kernel<false, 4>), dim3(slots), dim3(64), lds_bytes, st, B);
-    else hipLaunchKernelGGL((hp_astar_kernel<true, 6>), dim3(slots), dim3(64), lds_bytes, st, B);
+    if (!prm.sub_heap_in_lds) hipLaunchKernelGGL((hp_astar_kernel<false, 4, false>), dim3(slots), dim3(64), lds_bytes, st, B);
+    else if (prm.pad1) hipLaunchKernelGGL((hp_astar_kernel<true, 6, true>), dim3(slots), dim3(64), lds_bytes, st, B);
+    else hipLaunchKernelGGL((hp_astar_kernel<true, 6, false>), dim3(slots), dim3(64), lds_bytes, st, B);
     HP_HIP_CHECK(hipGetLastError());
     return HP_OK;
 }

@@ -402,9 +402,11 @@ struct WaveCounters {
     uint64_t seg[6];   // HP_SEG_PROFILE: shader-clock cycles per sub-solver segment (prm.pad1 != 0)
     uint64_t tlast;
 };
-// segment profiling (bring-up/tuning aid, off in production): drain outstanding memory ops, read s_memtime
-DEVINL void seg_stamp(WaveCounters& wc, bool on, int which) {
-    if (on) {
+// segment profiling (tuning aid; PROF is a compile-time switch so the production kernel carries none of its state):
+// drain outstanding memory ops, read s_memtime
+template <bool PROF>
+DEVINL void seg_stamp(WaveCounters& wc, int which) {
+    if (PROF) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const uint64_t t = __builtin_amdgcn_s_memtime();
         if (which >= 0) wc.seg[which] += t - wc.tlast;
@@ -425,6 +427,8 @@ struct Ctx {
     const uint32_t* words;
     uint32_t N;
     uint64_t evals, cells;  // per-lane work counters
+    uint32_t ev32, cl32;    // ... their 32-bit front end (one sub-solve / one main pop), folded in by flush()
+    DEVINL void flush() { evals += ev32; cells += cl32; ev32 = 0; cl32 = 0; }
 };
 
 // The children of one expansion, fixed slots in the reference's hap_order (astar_phaser.rs:367-372):
@@ -492,8 +496,9 @@ DEVINL uint32_t wpop(uint32_t M, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t
 //   score(h') = S(parent prefix over [max(start_r, off), p)) + (allele_r[p] != a ? qual_r[p] : 0)
 // so the O(overlap) part is shared by the children; it is evaluated bit-parallel per 32-variant word.
 // [lo, hi) = candidate rows of variant p (start-sorted), bad = variant ignored.
+template <bool PROF>
 DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t lo, uint32_t hi, bool bad,
-                   uint64_t h_next, Pools& pl, Kids& kd, WaveCounters& wc, bool prof) {
+                   uint64_t h_next, Pools& pl, Kids& kd, WaveCounters& wc) {
     const uint32_t lane = lane_id();
     const uint32_t kp = p >> 5, bp = p & 31u;
     const uint32_t ck = cur.depth ? ((off + cur.depth - 1) >> 5) : (off >> 5);
@@ -522,7 +527,7 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
             rw = cx.rword[r];
         }
         valid = valid && re > p;  // start <= p by construction of vhi
-        seg_stamp(wc, prof, 1);   // [1] row metadata loads
+        seg_stamp<PROF>(wc, 1);   // [1] row metadata loads
         const uint32_t kr = rs >> 5;
         const uint32_t myj = kp - kr;  // words before the one holding p (garbage when !valid)
         uint32_t s1 = 0, s2 = 0, ap = 3, qp = 0;
@@ -596,14 +601,15 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
             acc[1] += frozen ? c1 : 0u; acc[5] += frozen ? 0u : c1;
             acc[2] += frozen ? c2 : 0u; acc[6] += frozen ? 0u : c2;
             acc[3] += frozen ? c3 : 0u; acc[7] += frozen ? 0u : c3;
-            cx.evals += (uint64_t)nkids;
-            cx.cells += (uint64_t)nkids * (uint64_t)(p + 1 - max(rs, off));
+            cx.ev32 += nkids;
+            cx.cl32 += nkids * (p + 1 - max(rs, off));
         }
+        if (base != lo) cx.flush();   // > 64 candidate rows (rare): keep the 32-bit counters far from wrapping
     }
-    seg_stamp(wc, prof, 2);       // [2] plane-word loads + bit-sliced scoring
+    seg_stamp<PROF>(wc, 2);       // [2] plane-word loads + bit-sliced scoring
     uint32_t sum[8];
     wave_sum8(acc, sum);
-    seg_stamp(wc, prof, 3);       // [3] wave reduction
+    seg_stamp<PROF>(wc, 3);       // [3] wave reduction
 
     kd.bad = bad;
     kd.has1 = !bad && cur.hets != 0;
@@ -635,13 +641,12 @@ DEVINL void ringV_set(uint32_t x, uint32_t lo, uint32_t hi, uint32_t flags) {  /
     if (lane_id() == 0) reinterpret_cast<uint2*>(hp_smem + LDS_VRING_OFF)[x & 63u] = make_uint2(lo, hi | (flags << 28));
 }
 // astar_subsolver (astar_phaser.rs:311-405). Returns status; outputs (max_cost_so_far, farthest).
-template <bool SUB_LDS>
+template <bool SUB_LDS, bool PROF>
 DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t ps, SubHeap<SUB_LDS>& heap,
                         Pools& pl, WaveCounters& wc, uint64_t& est, uint32_t& solved) {
     heap.reset();
     pl.n_chunk = 0;
-    const bool prof = prm.pad1 != 0;
-    seg_stamp(wc, prof, -1);
+    seg_stamp<PROF>(wc, -1);
     uint32_t next_idx = 1;
     Cur cur = root_node(ringH_get(off + 1));  // initial_estimate = H[off+1] (astar_phaser.rs:322)
     uint32_t next_expected = 0, visited = 0;
@@ -661,8 +666,8 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         const uint64_t rh = reinterpret_cast<const uint64_t*>(hp_smem + LDS_HRING_OFF)[(p + 1) & 63u];
         const uint32_t lo = bcast32(rv.x), hiw = bcast32(rv.y), hi = hiw & 0x0FFFFFFFu, flags = hiw >> 28;
         Kids kd;
-        seg_stamp(wc, prof, 0);       // [0] loop head + LDS ring reads
-        expand(cx, cur, off, p, lo, hi, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, prof);
+        seg_stamp<PROF>(wc, 0);       // [0] loop head + LDS ring reads
+        expand<PROF>(cx, cur, off, p, lo, hi, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc);
         wc.nodes += kd.n;
         if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
         if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
@@ -675,7 +680,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         // If the best child beats everything queued it is the next pop: keep it in registers (push + pop elided;
         // the priority is a total order, so this is exactly what the reference's queue would return).
         const bool take_child = kbest < heap.top;
-        seg_stamp(wc, prof, 4);   // [4] child totals + keys
+        seg_stamp<PROF>(wc, 4);   // [4] child totals + keys
         fam_store(pl.fam, kd, cur, next_idx);  // one 64-byte record for all siblings
         if (take_child) {
             heap.push4(k0 == kbest ? ~0ull : k0, k1 == kbest ? ~0ull : k1, k2 == kbest ? ~0ull : k2, k3 == kbest ? ~0ull : k3);
@@ -690,7 +695,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
             cur = cur_from_fam(fr, subkey_rank(t), subkey_total(t), subkey_idx(t), off);
         }
         next_idx += kd.n;
-        seg_stamp(wc, prof, 5);   // [5] record store + heap pushes (+ pop on the slow path)
+        seg_stamp<PROF>(wc, 5);   // [5] record store + heap pushes (+ pop on the slow path)
         if (__any(heap.ovf) || pl.ovf) { st = ST_OVERFLOW; break; }
     }
     if (cur.depth == ps) {  // astar_phaser.rs:395-399 (peek, not pop)
@@ -699,11 +704,20 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
     }
     est = max_cost;
     solved = next_expected - 1;
+    cx.flush();
     return st;
 }
 
-template <bool SUB_LDS>
-DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
+// What the main search needs from the heuristic phase of the same block (all wave-uniform).
+struct HeurResult {
+    int32_t st;
+    uint64_t sub_pops, nodes, evals, cells;   // work of the heuristic chain
+    uint64_t t_start, t_heur;
+};
+
+// calculate_astar_heuristic (astar_phaser.rs:246-292): the chain of N sub-solves, i.e. ~97 % of a block's work.
+template <bool SUB_LDS, bool PROF>
+DEVINL HeurResult heuristic_phase(const BatchDev& B, uint32_t blk, uint32_t slot, WaveCounters& wc) {
     const SolveParams& prm = B.prm;
     const BlockDesc d = B.desc[blk];
     const uint32_t N = d.n_vars;
@@ -714,21 +728,15 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
     const uint8_t* vflags = B.vflags + d.var_off;
     cx.rstart = B.rstart + d.read_off; cx.rend = B.rend + d.read_off; cx.rword = B.rword + d.read_off;
     cx.words = B.words + d.word_off * WORD_DWORDS;
-    cx.N = N; cx.evals = 0; cx.cells = 0;
+    cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
     uint64_t* H = B.H + d.h_off;
-    Pools subp, mainp;
+    Pools subp;
     {
         unsigned char* sb = B.sub_pool + (size_t)slot * ((size_t)prm.cap_sub * sizeof(FamRec) + (size_t)prm.cap_chunk_sub * sizeof(ChunkRec));
         subp.fam = reinterpret_cast<FamRec*>(sb);
         subp.chunk = reinterpret_cast<ChunkRec*>(sb + (size_t)prm.cap_sub * sizeof(FamRec));
         subp.cap_chunk = prm.cap_chunk_sub; subp.n_chunk = 0; subp.ovf = 0;
-        unsigned char* mb = B.main_pool + (size_t)slot * ((size_t)prm.cap_main * sizeof(FamRec) + (size_t)prm.cap_chunk_main * sizeof(ChunkRec));
-        mainp.fam = reinterpret_cast<FamRec*>(mb);
-        mainp.chunk = reinterpret_cast<ChunkRec*>(mb + (size_t)prm.cap_main * sizeof(FamRec));
-        mainp.cap_chunk = prm.cap_chunk_main; mainp.n_chunk = 0; mainp.ovf = 0;
     }
-    uint32_t* tracker = B.tracker + (size_t)slot * ((size_t)prm.max_n_vars + 1);
-    WaveCounters wc{0, 0, 0, {0, 0, 0, 0, 0, 0}, 0};
     int32_t st = ST_OK;
     const uint64_t t_start = __builtin_readcyclecounter();
     const bool resume = bcast32(lane == 0 ? (uint32_t)B.status[blk] : 0u) == (uint32_t)ST_OVERFLOW_MAIN;
@@ -750,7 +758,7 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
             ringV_set(v, l, h, fl);
             uint64_t est = 0;
             uint32_t solved = 0;
-            st = subsolve<SUB_LDS>(cx, prm, v, clip, sub, subp, wc, est, solved);
+            st = subsolve<SUB_LDS, PROF>(cx, prm, v, clip, sub, subp, wc, est, solved);
             if (st != ST_OK) break;
             if (solved < min(clip, 2u)) { st = ST_INVARIANT; break; }  // astar_phaser.rs:268
             const bool bad = (fl & HP_VAR_IGNORED) != 0;
@@ -779,8 +787,40 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
     const uint64_t t_heur = __builtin_readcyclecounter();
     // counters of the heuristic phase, kept in case the main search has to be re-run with more scratch
     const uint64_t h_evals = wave_sum_u64(cx.evals), h_cells = wave_sum_u64(cx.cells);
-    const uint64_t h_nodes = wc.nodes;
-    cx.evals = 0; cx.cells = 0;
+    HeurResult hr;
+    hr.st = st; hr.sub_pops = wc.sub_pops; hr.nodes = wc.nodes; hr.evals = h_evals; hr.cells = h_cells;
+    hr.t_start = t_start; hr.t_heur = t_heur;
+    return hr;
+}
+
+
+// astar_solver's main pruned search + emission (astar_phaser.rs:451-633) for a block whose H[] is complete.
+// (Tried as a real, non-inlined call to keep its state out of the sub-solver loop's register allocation: the
+// heuristic chain got 3 % faster, the main search 2.5x slower through its stack frame - a net loss.)
+DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResult hr) {
+    const SolveParams& prm = B.prm;
+    const BlockDesc d = B.desc[blk];
+    const uint32_t N = d.n_vars;
+    const uint32_t lane = lane_id();
+    Ctx cx;
+    const uint32_t* vlo = B.vlo + d.var_off;
+    const uint32_t* vhi = B.vhi + d.var_off;
+    const uint8_t* vflags = B.vflags + d.var_off;
+    cx.rstart = B.rstart + d.read_off; cx.rend = B.rend + d.read_off; cx.rword = B.rword + d.read_off;
+    cx.words = B.words + d.word_off * WORD_DWORDS;
+    cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
+    uint64_t* H = B.H + d.h_off;
+    Pools mainp;
+    {
+        unsigned char* mb = B.main_pool + (size_t)slot * ((size_t)prm.cap_main * sizeof(FamRec) + (size_t)prm.cap_chunk_main * sizeof(ChunkRec));
+        mainp.fam = reinterpret_cast<FamRec*>(mb);
+        mainp.chunk = reinterpret_cast<ChunkRec*>(mb + (size_t)prm.cap_main * sizeof(FamRec));
+        mainp.cap_chunk = prm.cap_chunk_main; mainp.n_chunk = 0; mainp.ovf = 0;
+    }
+    uint32_t* tracker = B.tracker + (size_t)slot * ((size_t)prm.max_n_vars + 1);
+    WaveCounters wc{hr.sub_pops, 0, hr.nodes, {0, 0, 0, 0, 0, 0}, 0};
+    int32_t st = hr.st;
+    const uint64_t h_evals = hr.evals, h_cells = hr.cells, h_nodes = hr.nodes, t_start = hr.t_start, t_heur = hr.t_heur;
 
     // ---- main pruned search (astar_phaser.rs:451-633) ---------------------------------------------------
     hp_phase_stats stats{};
@@ -834,7 +874,8 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
             if (lane == 0) { fl = vflags[p]; l = vlo[p]; h = vhi[p]; hn = H[p + 1]; }
             fl = bcast32(fl); l = bcast32(l); h = bcast32(h); hn = bcast64(hn);
             Kids kd;
-            expand(cx, cur, 0, p, l, h, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, false);
+            expand<false>(cx, cur, 0, p, l, h, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc);
+            cx.flush();
             wc.nodes += kd.n;
             if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; break; }
             if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:529
@@ -957,13 +998,21 @@ DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
         }
         c.reserved[0] = t_heur - t_start;                      // shader-clock cycles spent in the heuristic chain
         c.reserved[1] = __builtin_readcyclecounter() - t_heur;  // ... in the main search + emit
-        if (prm.pad1 != 0) {  // segment profile: pack 6 x 32-bit kilo-cycle counters
-            c.reserved[0] = (wc.seg[0] >> 10) | ((wc.seg[1] >> 10) << 32);
-            c.reserved[1] = (wc.seg[2] >> 10) | ((wc.seg[3] >> 10) << 32);
-            c.reserved[2] = (wc.seg[4] >> 10) | ((wc.seg[5] >> 10) << 32);
-        }
         B.counters[blk] = c;
         B.status[blk] = st;
+    }
+}
+
+template <bool SUB_LDS, bool PROF>
+DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
+    WaveCounters wc{0, 0, 0, {0, 0, 0, 0, 0, 0}, 0};
+    const HeurResult hr = heuristic_phase<SUB_LDS, PROF>(B, blk, slot, wc);
+    main_phase(B, blk, slot, hr);
+    if (PROF && lane_id() == 0) {  // segment profile: pack 6 x 32-bit kilo-cycle counters over the cycle fields
+        hp_work_counters* c = B.counters + blk;
+        c->reserved[0] = (wc.seg[0] >> 10) | ((wc.seg[1] >> 10) << 32);
+        c->reserved[1] = (wc.seg[2] >> 10) | ((wc.seg[3] >> 10) << 32);
+        c->reserved[2] = (wc.seg[4] >> 10) | ((wc.seg[5] >> 10) << 32);
     }
 }
 
@@ -991,7 +1040,7 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
     const uint8_t* vflags = B.vflags + d.var_off;
     cx.rstart = B.rstart + d.read_off; cx.rend = B.rend + d.read_off; cx.rword = B.rword + d.read_off;
     cx.words = B.words + d.word_off * WORD_DWORDS;
-    cx.N = N; cx.evals = 0; cx.cells = 0;
+    cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
     uint64_t* H = B.H + d.h_off;
     Pools subp;
     {
@@ -1022,7 +1071,7 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
         ringV_set(v, l, h, fl);
         uint64_t est = 0;
         uint32_t solved = 0;
-        st = subsolve<SUB_LDS>(cx, prm, v, clip, sub, subp, wc, est, solved);
+        st = subsolve<SUB_LDS, false>(cx, prm, v, clip, sub, subp, wc, est, solved);
         if (st != ST_OK) break;
         if (solved < min(clip, 2u)) { st = ST_INVARIANT; break; }
         const bool bad = (fl & HP_VAR_IGNORED) != 0;
@@ -1200,7 +1249,7 @@ __global__ void __launch_bounds__(256) hp_post_spans_kernel(PostDev P) {
     P.span_counts[g] = c;
 }
 
-template <bool SUB_LDS, int OCC>
+template <bool SUB_LDS, int OCC, bool PROF>
 __global__ void __launch_bounds__(64, OCC) hp_astar_kernel(BatchDev B) {
     const uint32_t slot = blockIdx.x;
     const uint32_t G = gridDim.x;
@@ -1210,11 +1259,12 @@ __global__ void __launch_bounds__(64, OCC) hp_astar_kernel(BatchDev B) {
         const uint32_t base = round * G;
         if (base >= B.n_items) break;
         const uint32_t i = base + ((round & 1u) ? (G - 1u - slot) : slot);
-        if (i < B.n_items) solve_block<SUB_LDS>(B, B.order[i], slot);
+        if (i < B.n_items) solve_block<SUB_LDS, PROF>(B, B.order[i], slot);
     }
 }
 
-template __global__ void hp_astar_kernel<true, 6>(BatchDev);
-template __global__ void hp_astar_kernel<false, 4>(BatchDev);
+template __global__ void hp_astar_kernel<true, 6, false>(BatchDev);
+template __global__ void hp_astar_kernel<true, 6, true>(BatchDev);    // HP_SEG_PROFILE=1
+template __global__ void hp_astar_kernel<false, 4, false>(BatchDev);
 
 }  // namespace hp
