@@ -31,6 +31,7 @@ struct HostPack {
     uint64_t caller_rows = 0;
     uint64_t chunk_total = 0;
     uint64_t h_total = 0;
+    uint64_t cell_total = 0;   // entries of the per-position cell tables (device-built)
     uint32_t max_n = 0;
 };
 
@@ -80,6 +81,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     hpk.vlo.resize(v0 + N, 0xFFFFFFFFu);
     hpk.vhi.resize(v0 + N, 0);
     hpk.vflags.insert(hpk.vflags.end(), v->var_flags, v->var_flags + N);
+    for (uint32_t p = 0; p < N; ++p) hpk.vflags[v0 + p] &= (uint8_t)(HP_VAR_IGNORED | HP_VAR_SNV);   // bit 2 is VAR_NOFAST (device-only)
 
     uint64_t n_words = 0, cells = 0, max_row_qual = 0, total_qual = 0;
     for (uint32_t i = 0; i < idx.size(); ++i) {
@@ -140,6 +142,28 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     if (idx.size() >= (1u << 28)) { set_error("more than 2^28 rows in one block"); return HP_ERR_UNSUPPORTED; }
     d.max_cov = max_cov;
     d.n_words = (uint32_t)n_words;
+    // per-position cell table (incremental scoring in the sub-solver); variants where two covering rows collide on
+    // (row index mod 64) are flagged for the plane-word path. HP_NO_CTAB=1 switches the table off (A/B testing).
+    static const bool no_ctab = std::getenv("HP_NO_CTAB") != nullptr;
+    if (!no_ctab) {
+        d.cell_off = hpk.cell_total;
+        hpk.cell_total += (uint64_t)N * 64;
+        if (max_cov > 64) {
+            for (uint32_t p = 0; p < N; ++p) {
+                const uint32_t lo = hpk.vlo[v0 + p], hi = hpk.vhi[v0 + p];
+                if (hi - lo <= 64) continue;
+                uint64_t seen = 0;
+                for (uint32_t i = lo; i < hi; ++i) {
+                    if (v->read_end[idx[i]] <= p) continue;
+                    const uint64_t bit = 1ull << (i & 63u);
+                    if (seen & bit) { hpk.vflags[v0 + p] |= VAR_NOFAST; break; }
+                    seen |= bit;
+                }
+            }
+        }
+    } else {
+        d.cell_off = ~0ull;
+    }
     hpk.desc.push_back(d);
     hpk.work.push_back(cells * 8 + N);
     hpk.max_n = std::max(hpk.max_n, N);
@@ -171,7 +195,7 @@ struct hp_batch {
     uint32_t max_n = 0;
     int n_cu = 256;
     // device inputs
-    DevBuf d_desc, d_order, d_vlo, d_vhi, d_vflags, d_rstart, d_rend, d_rword, d_words, d_head;
+    DevBuf d_desc, d_order, d_vlo, d_vhi, d_vflags, d_rstart, d_rend, d_rword, d_words, d_head, d_ctab;
     // device outputs
     DevBuf d_H, d_h1, d_h2, d_stats, d_counters, d_status, d_hapw;
     // post-processing (phaser.rs:350-388, :714-750)
@@ -265,6 +289,7 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     B.vlo = b->d_vlo.as<uint32_t>(); B.vhi = b->d_vhi.as<uint32_t>(); B.vflags = b->d_vflags.as<uint8_t>();
     B.rstart = b->d_rstart.as<uint32_t>(); B.rend = b->d_rend.as<uint32_t>(); B.rword = b->d_rword.as<uint32_t>();
     B.words = b->d_words.as<uint32_t>();
+    B.ctab = b->d_ctab.as<uint32_t>();
     B.H = b->d_H.as<uint64_t>();
     B.sub_pool = b->s_seg_pool.as<unsigned char>();
     B.prm = prm;
@@ -339,6 +364,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     B.vlo = b->d_vlo.as<uint32_t>(); B.vhi = b->d_vhi.as<uint32_t>(); B.vflags = b->d_vflags.as<uint8_t>();
     B.rstart = b->d_rstart.as<uint32_t>(); B.rend = b->d_rend.as<uint32_t>(); B.rword = b->d_rword.as<uint32_t>();
     B.words = b->d_words.as<uint32_t>();
+    B.ctab = b->d_ctab.as<uint32_t>();
     B.H = b->d_H.as<uint64_t>(); B.h1 = b->d_h1.as<uint8_t>(); B.h2 = b->d_h2.as<uint8_t>(); B.hapw = b->d_hapw.as<Win>();
     B.stats = b->d_stats.as<hp_phase_stats>(); B.counters = b->d_counters.as<hp_work_counters>();
     B.status = b->d_status.as<int32_t>();
@@ -419,6 +445,17 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     UP(d_rstart, rstart); UP(d_rend, rend); UP(d_rword, rword); UP(d_words, words);
 #undef UP
     if ((rc = upload(b->d_row_block, hpk.row_block, s)) != HP_OK) return fail(rc);
+    // per-position cell tables are derived on the device from the rows just uploaded
+    if ((rc = b->d_ctab.alloc(hpk.cell_total * sizeof(uint32_t) + 16)) != HP_OK) return fail(rc);
+    if (hpk.cell_total && !hpk.row_block.empty()) {
+        if (hipMemsetAsync(b->d_ctab.p, 0, hpk.cell_total * sizeof(uint32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return fail(HP_ERR_HIP); }
+        CtabDev T{};
+        T.desc = b->d_desc.as<BlockDesc>(); T.row_block = b->d_row_block.as<uint32_t>();
+        T.rstart = b->d_rstart.as<uint32_t>(); T.rend = b->d_rend.as<uint32_t>(); T.rword = b->d_rword.as<uint32_t>();
+        T.words = b->d_words.as<uint32_t>(); T.ctab = b->d_ctab.as<uint32_t>(); T.n_rows = hpk.row_block.size();
+        hipLaunchKernelGGL(hp_build_ctab_kernel, dim3((unsigned)((T.n_rows + 3) / 4)), dim3(256), 0, s, T);
+        if (hipGetLastError() != hipSuccess) { set_error("hp_build_ctab_kernel launch failed"); return fail(HP_ERR_HIP); }
+    }
     if ((rc = b->d_hapw.alloc(hpk.chunk_total * sizeof(Win) + 16)) != HP_OK) return fail(rc);
     if ((rc = b->d_head.alloc(16)) != HP_OK) return fail(rc);
     if ((rc = b->d_H.alloc(b->sum_h * 8)) != HP_OK) return fail(rc);

@@ -10,6 +10,7 @@
 //                                       (aligned to absolute variant index / 32) of one row:
 //                                       [0] allele bit0, [1] allele bit1, [2..9] qual bit-planes 0..7, [10..11] pad.
 //                                       Cells outside the row's region are allele 3 (NoOverlap), qual 0.
+//   ctab[sum N'][64]  u32               per-position cell table (blocks with max_cov <= 64 only), see CELL_* below
 //   H[sum (N+1)]      u64               heuristic array (output, astar_phaser.rs:252)
 //   h1/h2[sum N]      u8                haplotypes (output)
 //   stats/counters/status per block
@@ -33,7 +34,18 @@ struct BlockDesc {
     uint32_t max_cov;   // max over p of vhi-vlo
     uint32_t n_words;
     uint64_t chunk_off; // into hapw (one Win per 32-variant chunk of the solution)
+    uint64_t cell_off;  // into ctab (entries); ~0 when the block has no cell table (HP_NO_CTAB)
 };
+// device-only bit of vflags[p] (the caller's bits are HP_VAR_IGNORED / HP_VAR_SNV): two rows covering p share a cell
+// table entry (same row index mod 64), so the incremental path must not be used at p
+constexpr uint8_t VAR_NOFAST = 0x4;
+
+// Per-position cell table (built on the device by hp_build_ctab_kernel): 64 u32 entries per variant p, entry
+// (row index mod 64) describes that row's cell at p. Variants where two covering rows would share an entry carry
+// VAR_NOFAST and are handled by the plane-word path.
+//   bits 0-7 qual | 8-9 allele (NoOverlap stored as Ambiguous: both mismatch 0 and 1, and NoOverlap has qual 0) |
+//   10 row ends here (end == p+1) | 11 valid (row covers p) | 12-31 min(p - row start, 2^20-1)
+constexpr uint32_t CELL_ENDS = 1u << 10, CELL_VALID = 1u << 11, CELL_T_SHIFT = 12, CELL_T_MAX = (1u << 20) - 1;
 
 // Priority key (astar_phaser.rs:131-133): min total cost, then MORE hets, then OLDER node.
 //   hi = cost << 24 | (0xFFFFFF - num_hets)      cost < 2^40 (sum of all quals of a block < 2^40)
@@ -128,6 +140,7 @@ struct BatchDev {
     const uint8_t* vflags;
     const uint32_t *rstart, *rend, *rword;
     const uint32_t* words;
+    const uint32_t* ctab;    // per-position cell tables (see CELL_*)
     uint64_t* H;
     uint8_t *h1, *h2;
     Win* hapw;            // packed solution windows, written at emission (input of the post-processing kernels)

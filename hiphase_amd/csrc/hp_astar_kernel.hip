@@ -425,6 +425,7 @@ struct Pools {   // per-wave scratch of one search (sub-solver or main)
 struct Ctx {
     const uint32_t *rstart, *rend, *rword;
     const uint32_t* words;
+    const uint32_t* ctab;   // per-position cell table of the block (hp_astar_dev.h CELL_*), nullptr with HP_NO_CTAB
     uint32_t N;
     uint64_t evals, cells;  // per-lane work counters
     uint32_t ev32, cl32;    // ... their 32-bit front end (one sub-solve / one main pop), folded in by flush()
@@ -494,31 +495,84 @@ DEVINL uint32_t wpop(uint32_t M, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t
 // new_extended_node (astar_phaser.rs:69-119) for all children of `cur` at once.
 // Row r covering p contributes min(score(h1'), score(h2')) where h' = parent prefix + child allele:
 //   score(h') = S(parent prefix over [max(start_r, off), p)) + (allele_r[p] != a ? qual_r[p] : 0)
-// so the O(overlap) part is shared by the children; it is evaluated bit-parallel per 32-variant word.
-// [lo, hi) = candidate rows of variant p (start-sorted), bad = variant ignored.
-template <bool PROF>
-DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t lo, uint32_t hi, bool bad,
-                   uint64_t h_next, Pools& pl, Kids& kd, WaveCounters& wc) {
-    const uint32_t lane = lane_id();
-    const uint32_t kp = p >> 5, bp = p & 31u;
+// so the O(overlap) part S is shared by the children. Two ways to get it:
+//   * expand():      from scratch, bit-parallel per 32-variant plane word (any node, any coverage);
+//   * expand_fast(): carried in two registers per lane from the parent's expansion when the node being expanded
+//                    is the child the previous expansion kept (86 % of the sub-solver's pops on HiFi-like data):
+//                    S(child) = S(parent) + the child's own cell, read from the per-position cell table.
+// Rows are dealt to lanes by (row index mod 64) in both, so a row keeps its lane from one position to the next.
+struct ExpPre {
+    bool trans;
+    uint32_t new_chunk, nkids, bp;
+    Win W0, W1, W2;
+};
+DEVINL ExpPre expand_begin(const Cur& cur, uint32_t off, uint32_t p, bool bad, Pools& pl) {
+    ExpPre e;
+    const uint32_t kp = p >> 5;
+    e.bp = p & 31u;
     const uint32_t ck = cur.depth ? ((off + cur.depth - 1) >> 5) : (off >> 5);
-    const bool trans = (ck != kp);  // the child opens a new 32-variant chunk
-    uint32_t new_chunk = NONE32;
-    if (trans) {  // cur's window is a complete chunk that its descendants link to: persist it as a ChunkRec
+    e.trans = (ck != kp);  // the child opens a new 32-variant chunk
+    e.new_chunk = NONE32;
+    if (e.trans) {  // cur's window is a complete chunk that its descendants link to: persist it as a ChunkRec
         if (pl.n_chunk >= pl.cap_chunk) pl.ovf = 1;
         else {
-            new_chunk = pl.n_chunk++;
-            store_chunk(pl.chunk + new_chunk, cur.w0, cur.w1, cur.anc2);
+            e.new_chunk = pl.n_chunk++;
+            store_chunk(pl.chunk + e.new_chunk, cur.w0, cur.w1, cur.anc2);
         }
     }
-    const Win W0 = trans ? fresh_win() : cur.w0;
-    const Win W1 = trans ? cur.w0 : cur.w1;
-    const Win W2 = cur.w1;  // only meaningful when trans
-    const uint32_t nkids = bad ? 1u : (cur.hets != 0 ? 4u : 3u);
+    e.W0 = e.trans ? fresh_win() : cur.w0;
+    e.W1 = e.trans ? cur.w0 : cur.w1;
+    e.W2 = cur.w1;  // only meaningful when trans
+    e.nkids = bad ? 1u : (cur.hets != 0 ? 4u : 3u);
+    return e;
+}
+DEVINL void expand_finish(const ExpPre& e, const Cur& cur, bool bad, uint64_t h_next, const uint32_t (&sum)[8], Kids& kd) {
+    kd.bad = bad;
+    kd.has1 = !bad && cur.hets != 0;
+    kd.n = e.nkids;
+    kd.depth = cur.depth + 1;
+    kd.anc1 = e.trans ? e.new_chunk : cur.anc1;
+    kd.anc2 = e.trans ? cur.anc1 : cur.anc2;
+    kd.w1 = e.W1;
+    kd.base = e.W0;
+    kd.bit = 1u << e.bp;
+    kd.hets_het = cur.hets + 1;
+    kd.hets_hom = cur.hets;
+    kd.sumF0 = sum[0]; kd.sumF1 = sum[1]; kd.sumF2 = sum[2]; kd.sumF3 = sum[3];
+    kd.frozen0 = cur.frozen + sum[0]; kd.total0 = kd.frozen0 + sum[4] + h_next;
+    kd.frozen1 = cur.frozen + sum[1]; kd.total1 = kd.frozen1 + sum[5] + h_next;
+    kd.frozen2 = cur.frozen + sum[2]; kd.total2 = kd.frozen2 + sum[6] + h_next;
+    kd.frozen3 = cur.frozen + sum[3]; kd.total3 = kd.frozen3 + sum[7] + h_next;
+}
+// the per-row part shared by both paths: child costs from (S1, S2) and the cell at p, split into frozen / fluid
+DEVINL void row_costs(uint32_t s1, uint32_t s2, uint32_t x0, uint32_t x1, bool frozen, uint32_t (&acc)[8]) {
+    const uint32_t c0 = min(s1 + x0, s2 + x1);  // (0,1)  [== min(s1, s2) for the (2,2) child]
+    const uint32_t c1 = min(s1 + x1, s2 + x0);  // (1,0)
+    const uint32_t c2 = min(s1 + x0, s2 + x0);  // (0,0)
+    const uint32_t c3 = min(s1 + x1, s2 + x1);  // (1,1)
+    acc[0] += frozen ? c0 : 0u; acc[4] += frozen ? 0u : c0;
+    acc[1] += frozen ? c1 : 0u; acc[5] += frozen ? 0u : c1;
+    acc[2] += frozen ? c2 : 0u; acc[6] += frozen ? 0u : c2;
+    acc[3] += frozen ? c3 : 0u; acc[7] += frozen ? 0u : c3;
+}
+
+// [lo, hi) = candidate rows of variant p (start-sorted), bad = variant ignored. Leaves, per lane, the scores of the
+// parent prefix (ps1, ps2) and the cell costs (px0, px1) of its row (zeros if it has none).
+template <bool PROF>
+DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t lo, uint32_t hi, bool bad,
+                   uint64_t h_next, Pools& pl, Kids& kd, WaveCounters& wc, uint32_t& ps1, uint32_t& ps2,
+                   uint32_t& px0, uint32_t& px1) {
+    const uint32_t lane = lane_id();
+    const ExpPre e = expand_begin(cur, off, p, bad, pl);
+    const uint32_t kp = p >> 5, bp = e.bp;
+    const bool trans = e.trans;
+    const Win W0 = e.W0, W1 = e.W1, W2 = e.W2;
+    const uint32_t nkids = e.nkids;
     uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0..3] frozen per slot, [4..7] fluid per slot
+    ps1 = 0; ps2 = 0; px0 = 0; px1 = 0;
 
     for (uint32_t base = lo; base < hi; base += 64) {
-        const uint32_t r = base + lane;
+        const uint32_t r = base + ((lane - base) & 63u);   // lane == r mod 64
         bool valid = r < hi;
         uint32_t rs = 0, re = 0, rw = 0;
         if (valid) {
@@ -592,17 +646,10 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
         if (valid) {
             const uint32_t x0 = (!bad && ap != 0u) ? qp : 0u;  // cost of giving a haplotype allele 0 here
             const uint32_t x1 = (!bad && ap != 1u) ? qp : 0u;  // ... allele 1
-            const uint32_t c0 = min(s1 + x0, s2 + x1);  // (0,1)  [== min(s1, s2) for the (2,2) child]
-            const uint32_t c1 = min(s1 + x1, s2 + x0);  // (1,0)
-            const uint32_t c2 = min(s1 + x0, s2 + x0);  // (0,0)
-            const uint32_t c3 = min(s1 + x1, s2 + x1);  // (1,1)
-            const bool frozen = (re == p + 1);           // rs.region().end <= hap_len (astar_phaser.rs:101)
-            acc[0] += frozen ? c0 : 0u; acc[4] += frozen ? 0u : c0;
-            acc[1] += frozen ? c1 : 0u; acc[5] += frozen ? 0u : c1;
-            acc[2] += frozen ? c2 : 0u; acc[6] += frozen ? 0u : c2;
-            acc[3] += frozen ? c3 : 0u; acc[7] += frozen ? 0u : c3;
+            row_costs(s1, s2, x0, x1, re == p + 1 /* rs.region().end <= hap_len (astar_phaser.rs:101) */, acc);
             cx.ev32 += nkids;
             cx.cl32 += nkids * (p + 1 - max(rs, off));
+            ps1 = s1; ps2 = s2; px0 = x0; px1 = x1;   // a lane has one live row unless the variant is VAR_NOFAST
         }
         if (base != lo) cx.flush();   // > 64 candidate rows (rare): keep the 32-bit counters far from wrapping
     }
@@ -610,23 +657,36 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
     uint32_t sum[8];
     wave_sum8(acc, sum);
     seg_stamp<PROF>(wc, 3);       // [3] wave reduction
+    expand_finish(e, cur, bad, h_next, sum, kd);
+}
 
-    kd.bad = bad;
-    kd.has1 = !bad && cur.hets != 0;
-    kd.n = nkids;
-    kd.depth = cur.depth + 1;
-    kd.anc1 = trans ? new_chunk : cur.anc1;
-    kd.anc2 = trans ? cur.anc1 : cur.anc2;
-    kd.w1 = W1;
-    kd.base = W0;
-    kd.bit = 1u << bp;
-    kd.hets_het = cur.hets + 1;
-    kd.hets_hom = cur.hets;
-    kd.sumF0 = sum[0]; kd.sumF1 = sum[1]; kd.sumF2 = sum[2]; kd.sumF3 = sum[3];
-    kd.frozen0 = cur.frozen + sum[0]; kd.total0 = kd.frozen0 + sum[4] + h_next;
-    kd.frozen1 = cur.frozen + sum[1]; kd.total1 = kd.frozen1 + sum[5] + h_next;
-    kd.frozen2 = cur.frozen + sum[2]; kd.total2 = kd.frozen2 + sum[6] + h_next;
-    kd.frozen3 = cur.frozen + sum[3]; kd.total3 = kd.frozen3 + sum[7] + h_next;
+// The same expansion when (fs1, fs2) already hold, per lane, the scores of cur's haplotype prefix against the lane's
+// row (see above): one coalesced 256-byte read of the cell table row of p replaces the row metadata and plane words.
+template <bool PROF>
+DEVINL void expand_fast(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, bool bad, uint64_t h_next, Pools& pl,
+                        Kids& kd, WaveCounters& wc, uint32_t& fs1, uint32_t& fs2, uint32_t& px0, uint32_t& px1) {
+    const uint32_t cell = cx.ctab[((size_t)p << 6) + lane_id()];
+    const ExpPre e = expand_begin(cur, off, p, bad, pl);
+    seg_stamp<PROF>(wc, 1);
+    const bool valid = (cell & CELL_VALID) != 0;
+    const uint32_t t = cell >> CELL_T_SHIFT;          // p - row start (saturated): 0 = the row starts here
+    if (t == 0) { fs1 = 0; fs2 = 0; }
+    const uint32_t ap = (cell >> 8) & 3u, qp = cell & 0xFFu;
+    const uint32_t x0 = (valid && !bad && ap != 0u) ? qp : 0u;
+    const uint32_t x1 = (valid && !bad && ap != 1u) ? qp : 0u;
+    const uint32_t s1 = valid ? fs1 : 0u, s2 = valid ? fs2 : 0u;
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    row_costs(s1, s2, x0, x1, (cell & CELL_ENDS) != 0, acc);
+    if (valid) {
+        cx.ev32 += e.nkids;
+        cx.cl32 += e.nkids * (min(t, p - off) + 1u);    // == p + 1 - max(row start, off)
+    }
+    px0 = x0; px1 = x1;
+    seg_stamp<PROF>(wc, 2);
+    uint32_t sum[8];
+    wave_sum8(acc, sum);
+    seg_stamp<PROF>(wc, 3);
+    expand_finish(e, cur, bad, h_next, sum, kd);
 }
 
 // LDS rings, indexed by (variant & 63): H[x] and the per-variant (lo, hi, flags) triple. Written by lane 0, read by
@@ -653,6 +713,11 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
     uint64_t max_cost = 0;
     const uint32_t max_visits = prm.minq_sub + prm.qinc * ps;
     int32_t st = ST_OK;
+    // (fs1, fs2): per-lane scores of cur's prefix against the lane's row, valid while cur is the child the previous
+    // expansion kept in registers; the root has scored nothing yet, so it starts valid (all zero)
+    const bool fast_ok = cx.ctab != nullptr;
+    bool fast_valid = fast_ok;
+    uint32_t fs1 = 0, fs2 = 0;
     while (cur.depth < ps && visited < max_visits) {
         visited += 1;
         wc.sub_pops += 1;
@@ -667,7 +732,10 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         const uint32_t lo = bcast32(rv.x), hiw = bcast32(rv.y), hi = hiw & 0x0FFFFFFFu, flags = hiw >> 28;
         Kids kd;
         seg_stamp<PROF>(wc, 0);       // [0] loop head + LDS ring reads
-        expand<PROF>(cx, cur, off, p, lo, hi, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc);
+        uint32_t x0, x1;
+        const bool collide = (flags & VAR_NOFAST) != 0;   // two rows of this variant on one lane: plane-word path only
+        if (fast_valid && !collide) expand_fast<PROF>(cx, cur, off, p, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs1, fs2, x0, x1);
+        else expand<PROF>(cx, cur, off, p, lo, hi, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs1, fs2, x0, x1);
         wc.nodes += kd.n;
         if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
         if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
@@ -684,15 +752,18 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         fam_store(pl.fam, kd, cur, next_idx);  // one 64-byte record for all siblings
         if (take_child) {
             heap.push4(k0 == kbest ? ~0ull : k0, k1 == kbest ? ~0ull : k1, k2 == kbest ? ~0ull : k2, k3 == kbest ? ~0ull : k3);
-            if (k0 == kbest) cur = kid_as_cur<0>(kd, next_idx);
-            else if (k1 == kbest) cur = kid_as_cur<1>(kd, next_idx);
-            else if (k2 == kbest) cur = kid_as_cur<2>(kd, next_idx);
-            else cur = kid_as_cur<3>(kd, next_idx);
+            // slots (a1,a2): 0 = (0,1), 1 = (1,0), 2 = (0,0), 3 = (1,1); the kept child's own cell joins the prefix scores
+            if (k0 == kbest) { cur = kid_as_cur<0>(kd, next_idx); fs1 += x0; fs2 += x1; }
+            else if (k1 == kbest) { cur = kid_as_cur<1>(kd, next_idx); fs1 += x1; fs2 += x0; }
+            else if (k2 == kbest) { cur = kid_as_cur<2>(kd, next_idx); fs1 += x0; fs2 += x0; }
+            else { cur = kid_as_cur<3>(kd, next_idx); fs1 += x1; fs2 += x1; }
+            fast_valid = fast_ok && !collide;
         } else {
             const uint64_t t = heap.top;
             const FamRec fr = load_fam(pl.fam + (subkey_idx(t) - subkey_rank(t)));  // in flight during the heap update
             heap.replace_push(k0, k1, k2, k3);
             cur = cur_from_fam(fr, subkey_rank(t), subkey_total(t), subkey_idx(t), off);
+            fast_valid = false;   // a queued node: its prefix scores are rebuilt from the plane words
         }
         next_idx += kd.n;
         seg_stamp<PROF>(wc, 5);   // [5] record store + heap pushes (+ pop on the slow path)
@@ -728,6 +799,7 @@ DEVINL HeurResult heuristic_phase(const BatchDev& B, uint32_t blk, uint32_t slot
     const uint8_t* vflags = B.vflags + d.var_off;
     cx.rstart = B.rstart + d.read_off; cx.rend = B.rend + d.read_off; cx.rword = B.rword + d.read_off;
     cx.words = B.words + d.word_off * WORD_DWORDS;
+    cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
     cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
     uint64_t* H = B.H + d.h_off;
     Pools subp;
@@ -808,6 +880,7 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
     const uint8_t* vflags = B.vflags + d.var_off;
     cx.rstart = B.rstart + d.read_off; cx.rend = B.rend + d.read_off; cx.rword = B.rword + d.read_off;
     cx.words = B.words + d.word_off * WORD_DWORDS;
+    cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
     cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
     uint64_t* H = B.H + d.h_off;
     Pools mainp;
@@ -874,7 +947,8 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
             if (lane == 0) { fl = vflags[p]; l = vlo[p]; h = vhi[p]; hn = H[p + 1]; }
             fl = bcast32(fl); l = bcast32(l); h = bcast32(h); hn = bcast64(hn);
             Kids kd;
-            expand<false>(cx, cur, 0, p, l, h, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc);
+            uint32_t u1, u2, u3, u4;
+            expand<false>(cx, cur, 0, p, l, h, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, u1, u2, u3, u4);
             cx.flush();
             wc.nodes += kd.n;
             if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; break; }
@@ -1040,6 +1114,7 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
     const uint8_t* vflags = B.vflags + d.var_off;
     cx.rstart = B.rstart + d.read_off; cx.rend = B.rend + d.read_off; cx.rword = B.rword + d.read_off;
     cx.words = B.words + d.word_off * WORD_DWORDS;
+    cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
     cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
     uint64_t* H = B.H + d.h_off;
     Pools subp;
@@ -1247,6 +1322,38 @@ __global__ void __launch_bounds__(256) hp_post_spans_kernel(PostDev P) {
         c += (P.js[gr] <= j && j < P.je[gr]) ? 1u : 0u;
     }
     P.span_counts[g] = c;
+}
+
+// Fills the per-position cell tables (hp_astar_dev.h CELL_*) from the packed rows: one wavefront per row, lanes over
+// the row's cells; the table was zeroed (= no valid entry) beforehand.
+struct CtabDev {
+    const BlockDesc* desc;
+    const uint32_t* row_block;            // packed row -> block
+    const uint32_t *rstart, *rend, *rword;
+    const uint32_t* words;
+    uint32_t* ctab;
+    uint64_t n_rows;
+};
+__global__ void __launch_bounds__(256) hp_build_ctab_kernel(CtabDev T) {
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T.n_rows) return;
+    const BlockDesc d = T.desc[T.row_block[row]];
+    if (d.cell_off == ~0ull) return;
+    const uint32_t rs = T.rstart[row], re = T.rend[row];
+    const uint32_t entry = (uint32_t)(row - d.read_off) & 63u;
+    const uint32_t* w0 = T.words + ((size_t)d.word_off + T.rword[row]) * WORD_DWORDS;
+    uint32_t* tab = T.ctab + d.cell_off;
+    for (uint32_t p = rs + (threadIdx.x & 63u); p < re; p += 64) {
+        const uint32_t* w = w0 + (size_t)((p >> 5) - (rs >> 5)) * WORD_DWORDS;
+        const uint32_t b = p & 31u;
+        uint32_t a = ((w[0] >> b) & 1u) | (((w[1] >> b) & 1u) << 1);
+        if (a == 3u) a = 2u;
+        uint32_t q = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q |= ((w[2 + k] >> b) & 1u) << k;
+        tab[((size_t)p << 6) + entry] = q | (a << 8) | (p + 1 == re ? CELL_ENDS : 0u) | CELL_VALID |
+                                        (min(p - rs, CELL_T_MAX) << CELL_T_SHIFT);
+    }
 }
 
 template <bool SUB_LDS, int OCC, bool PROF>
