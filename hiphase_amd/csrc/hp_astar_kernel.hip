@@ -347,6 +347,31 @@ struct MainHeap {
         }
         if (key_less(k, top)) { top = k; top_lane = tgt; }
     }
+    // astar_phaser.rs:576-581: every queued node with depth < min_progress gets cost 0. Clearing is a decrease-key,
+    // so each lane scans its heap front to back (independent, coalesced loads) and sifts UP only the entries that
+    // are newly cleared — the pop order is a total order on the keys, so the heap's internal layout is free.
+    DEVINL void clear_below(uint32_t min_progress) {
+        for (uint32_t j0 = 0; j0 < cnt; j0 += 4) {
+            Key k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = (j0 + u < cnt) ? ld(j0 + u) : key_inf();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if ((uint32_t)(k[u].lo & 0xFFFFFFu) < min_progress && (k[u].hi >> 24) != 0) {
+                    Key c = k[u];
+                    c.hi &= 0xFFFFFFull;
+                    uint32_t j = j0 + u;
+                    while (j > 0) {
+                        const uint32_t pj = (j - 1) >> 1;
+                        const Key pk = ld(pj);
+                        if (key_less(c, pk)) { st(j, pk); j = pj; } else break;
+                    }
+                    st(j, c);
+                }
+            }
+        }
+        recompute_top();
+    }
     DEVINL void recompute_top() {
         Key mine = key_inf();
         if (cnt > 0) mine = ld(0);
@@ -981,16 +1006,8 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
                 }
                 if (qlen > max_q) {
                     // full prune: every queued node shorter than min_progress gets the cleared priority
-                    // (cost 0, same hets, same index); each lane rewrites and re-heapifies its private heap
-                    for (uint32_t j = 0; j < hq.cnt; ++j) {
-                        Key k = hq.ld(j);
-                        if ((uint32_t)(k.lo & 0xFFFFFFu) < min_progress) {
-                            k.hi &= 0xFFFFFFull;
-                            hq.st(j, k);
-                        }
-                    }
-                    for (uint32_t i = hq.cnt / 2; i-- > 0;) hq.sift_down(i, hq.ld(i));
-                    hq.recompute_top();
+                    // (cost 0, same hets, same index)
+                    hq.clear_below(min_progress);
                     if (kd.depth < min_progress) kbest.hi &= 0xFFFFFFull;
                 }
             }
