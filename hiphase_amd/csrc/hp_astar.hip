@@ -371,6 +371,11 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     B.sub_pool = sub_pool.as<unsigned char>(); B.main_pool = main_pool.as<unsigned char>();
     B.sub_heap_g = sub_heap.as<uint64_t>(); B.main_heap = main_heap.as<Key>(); B.tracker = tracker.as<uint32_t>();
     B.prm = prm;
+    if (verbose) {
+        int occ_blocks = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_blocks, hp_astar_kernel<true, 6, false>, 64, lds_bytes);
+        fprintf(stderr, "[hp] hipOccupancyMaxActiveBlocksPerMultiprocessor(hp_astar_kernel, 64, %zu) = %d\n", lds_bytes, occ_blocks);
+    }
     if (verbose) { fprintf(stderr, "[hp] launch items=%zu slots=%u cap_main=%u cap_sub=%u jcap_sub=%u lds=%zu stage=%u\n", items.size(), slots, cap_main, prm.cap_sub, prm.jcap_sub, lds_bytes, prm.pad0); fflush(stderr); }
     if (!prm.sub_heap_in_lds) hipLaunchKernelGGL((hp_astar_kernel<false, 4, false>), dim3(slots), dim3(64), lds_bytes, st, B);
     else if (prm.pad1) hipLaunchKernelGGL((hp_astar_kernel<true, 6, true>), dim3(slots), dim3(64), lds_bytes, st, B);

@@ -27,11 +27,12 @@ namespace hp {
 
 #define DEVINL __device__ __forceinline__
 
-// LDS layout (bytes): [0,512) H ring (64 x u64) | [512,1024) variant ring (64 x {lo, hi | flags << 28}) | [1024,...) sub heap
-// 1024 + 11 x 512 B of heap = 6.5 KiB at default parameters -> up to 24 single-wave workgroups per CU
+// LDS layout (bytes): [0,512) H ring (64 x u64) | [512,768) variant ring (64 x (lo | flags << 28)) | [768,...) sub heap
+// 768 + 11 x 512 B of heap = 6400 B at default parameters = exactly five 1280-byte LDS allocation granules of gfx950
+// (measured, scripts/lds_probe.hip) -> 25 workgroups per CU by LDS, 24 by registers
 constexpr uint32_t LDS_HRING_OFF = 0;
 constexpr uint32_t LDS_VRING_OFF = 512;
-constexpr uint32_t LDS_HEAP_OFF = 1024;
+constexpr uint32_t LDS_HEAP_OFF = 768;
 extern __shared__ __attribute__((aligned(16))) unsigned char hp_smem[];
 
 DEVINL uint32_t lane_id() { return __lane_id(); }
@@ -450,6 +451,7 @@ struct Pools {   // per-wave scratch of one search (sub-solver or main)
 struct Ctx {
     const uint32_t *rstart, *rend, *rword;
     const uint32_t* words;
+    uint32_t n_rows;
     const uint32_t* ctab;   // per-position cell table of the block (hp_astar_dev.h CELL_*), nullptr with HP_NO_CTAB
     uint32_t N;
     uint64_t evals, cells;  // per-lane work counters
@@ -581,10 +583,11 @@ DEVINL void row_costs(uint32_t s1, uint32_t s2, uint32_t x0, uint32_t x1, bool f
     acc[3] += frozen ? c3 : 0u; acc[7] += frozen ? 0u : c3;
 }
 
-// [lo, hi) = candidate rows of variant p (start-sorted), bad = variant ignored. Leaves, per lane, the scores of the
+// lo = first candidate row of variant p (rows are start-sorted; the candidates end with the last row whose start
+// is <= p), bad = variant ignored. Leaves, per lane, the scores of the
 // parent prefix (ps1, ps2) and the cell costs (px0, px1) of its row (zeros if it has none).
 template <bool PROF>
-DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t lo, uint32_t hi, bool bad,
+DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t lo, bool bad,
                    uint64_t h_next, Pools& pl, Kids& kd, WaveCounters& wc, uint32_t& ps1, uint32_t& ps2,
                    uint32_t& px0, uint32_t& px1) {
     const uint32_t lane = lane_id();
@@ -596,16 +599,17 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
     uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0..3] frozen per slot, [4..7] fluid per slot
     ps1 = 0; ps2 = 0; px0 = 0; px1 = 0;
 
-    for (uint32_t base = lo; base < hi; base += 64) {
+    for (uint32_t base = lo;; base += 64) {
         const uint32_t r = base + ((lane - base) & 63u);   // lane == r mod 64
-        bool valid = r < hi;
-        uint32_t rs = 0, re = 0, rw = 0;
-        if (valid) {
+        const bool inb = r < cx.n_rows;
+        uint32_t rs = 0xFFFFFFFFu, re = 0, rw = 0;
+        if (inb) {
             rs = cx.rstart[r];
             re = cx.rend[r];
             rw = cx.rword[r];
         }
-        valid = valid && re > p;  // start <= p by construction of vhi
+        const bool started = inb && rs <= p;   // rows are sorted by start: the candidates are a prefix of the tile
+        const bool valid = started && re > p;
         seg_stamp<PROF>(wc, 1);   // [1] row metadata loads
         const uint32_t kr = rs >> 5;
         const uint32_t myj = kp - kr;  // words before the one holding p (garbage when !valid)
@@ -677,6 +681,7 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
             ps1 = s1; ps2 = s2; px0 = x0; px1 = x1;   // a lane has one live row unless the variant is VAR_NOFAST
         }
         if (base != lo) cx.flush();   // > 64 candidate rows (rare): keep the 32-bit counters far from wrapping
+        if (!__all(started)) break;   // a lane ran past the last candidate: no further tile
     }
     seg_stamp<PROF>(wc, 2);       // [2] plane-word loads + bit-sliced scoring
     uint32_t sum[8];
@@ -722,8 +727,8 @@ DEVINL uint64_t ringH_get(uint32_t x) {  // every lane reads the same address: o
 DEVINL void ringH_set(uint32_t x, uint64_t v) {
     if (lane_id() == 0) reinterpret_cast<uint64_t*>(hp_smem + LDS_HRING_OFF)[x & 63u] = v;
 }
-DEVINL void ringV_set(uint32_t x, uint32_t lo, uint32_t hi, uint32_t flags) {  // rows per block < 2^28 (host check)
-    if (lane_id() == 0) reinterpret_cast<uint2*>(hp_smem + LDS_VRING_OFF)[x & 63u] = make_uint2(lo, hi | (flags << 28));
+DEVINL void ringV_set(uint32_t x, uint32_t lo, uint32_t flags) {  // rows per block < 2^28 (host check)
+    if (lane_id() == 0) reinterpret_cast<uint32_t*>(hp_smem + LDS_VRING_OFF)[x & 63u] = lo | (flags << 28);
 }
 // astar_subsolver (astar_phaser.rs:311-405). Returns status; outputs (max_cost_so_far, farthest).
 template <bool SUB_LDS, bool PROF>
@@ -752,15 +757,15 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         }
         const uint32_t p = off + cur.depth;
         // both ring reads are issued before either result is consumed
-        const uint2 rv = reinterpret_cast<const uint2*>(hp_smem + LDS_VRING_OFF)[p & 63u];
+        const uint32_t rv = reinterpret_cast<const uint32_t*>(hp_smem + LDS_VRING_OFF)[p & 63u];
         const uint64_t rh = reinterpret_cast<const uint64_t*>(hp_smem + LDS_HRING_OFF)[(p + 1) & 63u];
-        const uint32_t lo = bcast32(rv.x), hiw = bcast32(rv.y), hi = hiw & 0x0FFFFFFFu, flags = hiw >> 28;
+        const uint32_t low = bcast32(rv), lo = low & 0x0FFFFFFFu, flags = low >> 28;
         Kids kd;
         seg_stamp<PROF>(wc, 0);       // [0] loop head + LDS ring reads
         uint32_t x0, x1;
         const bool collide = (flags & VAR_NOFAST) != 0;   // two rows of this variant on one lane: plane-word path only
         if (fast_valid && !collide) expand_fast<PROF>(cx, cur, off, p, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs1, fs2, x0, x1);
-        else expand<PROF>(cx, cur, off, p, lo, hi, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs1, fs2, x0, x1);
+        else expand<PROF>(cx, cur, off, p, lo, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs1, fs2, x0, x1);
         wc.nodes += kd.n;
         if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
         if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
@@ -825,6 +830,7 @@ DEVINL HeurResult heuristic_phase(const BatchDev& B, uint32_t blk, uint32_t slot
     cx.rstart = B.rstart + d.read_off; cx.rend = B.rend + d.read_off; cx.rword = B.rword + d.read_off;
     cx.words = B.words + d.word_off * WORD_DWORDS;
     cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
+    cx.n_rows = d.n_reads;
     cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
     uint64_t* H = B.H + d.h_off;
     Pools subp;
@@ -850,9 +856,9 @@ DEVINL HeurResult heuristic_phase(const BatchDev& B, uint32_t blk, uint32_t slot
         for (uint32_t v = N; v-- > 0;) {
             ringH_set(v, 0);  // heuristic_costs[problem_offset] is still 0 (astar_phaser.rs:320)
             uint32_t fl = 0, l = 0, h = 0;
-            if (lane == 0) { fl = vflags[v]; l = vlo[v]; h = vhi[v]; }
+            if (lane == 0) { fl = vflags[v]; l = vlo[v]; }
             fl = bcast32(fl);
-            ringV_set(v, l, h, fl);
+            ringV_set(v, l, fl);
             uint64_t est = 0;
             uint32_t solved = 0;
             st = subsolve<SUB_LDS, PROF>(cx, prm, v, clip, sub, subp, wc, est, solved);
@@ -906,6 +912,7 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
     cx.rstart = B.rstart + d.read_off; cx.rend = B.rend + d.read_off; cx.rword = B.rword + d.read_off;
     cx.words = B.words + d.word_off * WORD_DWORDS;
     cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
+    cx.n_rows = d.n_reads;
     cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
     uint64_t* H = B.H + d.h_off;
     Pools mainp;
@@ -969,11 +976,11 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
             const uint32_t p = cur.depth;
             uint32_t fl = 0, l = 0, h = 0;
             uint64_t hn = 0;
-            if (lane == 0) { fl = vflags[p]; l = vlo[p]; h = vhi[p]; hn = H[p + 1]; }
+            if (lane == 0) { fl = vflags[p]; l = vlo[p]; hn = H[p + 1]; }
             fl = bcast32(fl); l = bcast32(l); h = bcast32(h); hn = bcast64(hn);
             Kids kd;
             uint32_t u1, u2, u3, u4;
-            expand<false>(cx, cur, 0, p, l, h, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, u1, u2, u3, u4);
+            expand<false>(cx, cur, 0, p, l, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, u1, u2, u3, u4);
             cx.flush();
             wc.nodes += kd.n;
             if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; break; }
@@ -1132,6 +1139,7 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
     cx.rstart = B.rstart + d.read_off; cx.rend = B.rend + d.read_off; cx.rword = B.rword + d.read_off;
     cx.words = B.words + d.word_off * WORD_DWORDS;
     cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
+    cx.n_rows = d.n_reads;
     cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
     uint64_t* H = B.H + d.h_off;
     Pools subp;
@@ -1158,9 +1166,9 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
         }
         ringH_set(v, 0);
         uint32_t fl = 0, l = 0, h = 0;
-        if (lane == 0) { fl = vflags[v]; l = vlo[v]; h = vhi[v]; }
+        if (lane == 0) { fl = vflags[v]; l = vlo[v]; }
         fl = bcast32(fl);
-        ringV_set(v, l, h, fl);
+        ringV_set(v, l, fl);
         uint64_t est = 0;
         uint32_t solved = 0;
         st = subsolve<SUB_LDS, false>(cx, prm, v, clip, sub, subp, wc, est, solved);

@@ -11,3 +11,5 @@ print(f"blocks={nb} kernel_ms={ms:.1f}; heuristic ms mean {hc.mean()/2.4e6:.1f} 
 for i in np.argsort(-mc)[:8]:
     c, st = ctrs[i], res[i].statistics
     print(f"  block {i}: main {mc[i]/2.4e6:8.1f} ms  heur {hc[i]/2.4e6:7.1f} ms  main_pops {c.main_pops:8d}  pruned {st.pruned_solutions:7d}  est {st.estimated_cost} actual {st.actual_cost}  cycles/main_pop {mc[i]/max(c.main_pops,1):.0f}")
+tot = (mc + hc) / 2.4e6
+print("per-block total ms percentiles (50/90/99/max):", np.percentile(tot, [50, 90, 99, 100]).round(1), " sum/slots:", round(tot.sum() / min(nb, 6144), 1))
