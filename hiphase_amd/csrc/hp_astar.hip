@@ -434,7 +434,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     prm.max_seg = (uint32_t)max_seg;
     const uint64_t max_visits = (uint64_t)prm.minq_sub + (uint64_t)prm.qinc * max_seg;
     prm.cap_sub = (uint32_t)(4 * max_visits + 1);   // root + at most 4 children per visit
-    prm.jcap_sub = (uint32_t)((3 * max_visits + 63) / 64);   // <= 3 keys per visit are dealt round-robin to the lanes (SubHeap::replace_push)
+    prm.jcap_sub = (uint32_t)((max_visits + 63) / 64);   // one key per family; <= 1 key per visit is dealt round-robin to the lanes (SubHeap::deal)
     prm.cap_chunk_sub = (uint32_t)max_visits + 8;   // at most one ChunkRec per expansion
     prm.sub_heap_in_lds = ((size_t)prm.jcap_sub * 64 * sizeof(uint64_t) <= LDS_SUB_HEAP_MAX_BYTES) ? 1 : 0;
     if (prm.cap_sub >= (1u << 14)) { set_error("min_queue_size/10 + queue_increment*max_segment_size = %llu visits exceeds the packed sub-key limit (4093)", (unsigned long long)max_visits); return fail(HP_ERR_UNSUPPORTED); }

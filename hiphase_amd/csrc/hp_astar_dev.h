@@ -64,12 +64,14 @@ struct Win {  // haplotype window over one 32-variant chunk
 
 // Search-tree state in HBM. O(1) per node instead of the reference's O(len) Vec copies (astar_phaser.rs:79-82):
 //  * one FamRec per EXPANSION (not per child): everything the siblings share + the four per-slot frozen
-//    increments; a child is rebuilt from (family, creation rank) only if it is ever popped from the queue —
-//    on HiFi-like data 97 % of the children never are. Stored at fam[node_index of the first child].
+//    increments and cost sums; a child is rebuilt from (family, creation rank) only if it is ever popped from the
+//    queue — on HiFi-like data 97 % of the children never are. Stored at fam[node_index of the first child].
+//    The sub-solver queues ONE key per family (its best not-yet-popped child) and derives the next one from the
+//    record when that child is popped: the pop sequence is the reference's, the heap is a third of the size.
 //  * one ChunkRec per completed 32-variant haplotype chunk on a path: w0 = that chunk, w1 = the chunk before,
 //    anc2 = the ChunkRec two chunks back. A node carries (w0, w1, anc1, anc2), so any look-back costs one hop
 //    per two chunks and rows shorter than 64 variants never touch memory.
-struct FamRec {  // 64 B
+struct FamRec {  // 80 B
     uint64_t frozen;       // parent's frozen cost
     uint32_t depth_flags;  // parent depth | bad << 30 | has_10_child << 31
     uint32_t hets;         // parent's num_hets
@@ -77,8 +79,9 @@ struct FamRec {  // 64 B
     Win base;              // parent's window in the children's chunk (fresh when they open a new chunk)
     Win w1;                // the chunk before it
     uint32_t sumF[4];      // frozen increment of slot 0..3 = (0,1) (1,0) (0,0) (1,1)
+    uint32_t tot[4];       // frozen + fluid increment of the slot: total = frozen + tot[slot] + H[child depth]
 };
-static_assert(sizeof(FamRec) == 64, "FamRec must be 64 bytes");
+static_assert(sizeof(FamRec) == 80, "FamRec must be 80 bytes");
 struct ChunkRec {  // 32 B
     Win w0, w1;
     uint32_t anc2, pad;

@@ -134,6 +134,7 @@ DEVINL uint64_t make_subkey(uint64_t total, uint32_t hets, uint32_t idx, uint32_
 DEVINL uint64_t subkey_total(uint64_t k) { return k >> 28; }
 DEVINL uint32_t subkey_idx(uint64_t k) { return (uint32_t)(k >> 8) & 0x3FFFu; }
 DEVINL uint32_t subkey_rank(uint64_t k) { return (uint32_t)k & 3u; }
+DEVINL uint32_t subkey_depth(uint64_t k) { return (uint32_t)(k >> 2) & 63u; }
 
 // ---- record I/O: lane 0 writes, lane 0 reads, broadcast (same-lane rule) ---------------------------------------
 DEVINL void store_chunk(ChunkRec* dst, const Win& w0, const Win& w1, uint32_t anc2) {
@@ -157,10 +158,10 @@ DEVINL ChunkRec load_chunk(const ChunkRec* src) {
     return r;
 }
 DEVINL FamRec load_fam(const FamRec* src) {
-    uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, d = a;
+    uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, d = a, e = a;
     if (lane_id() == 0) {
         const uint4* s = reinterpret_cast<const uint4*>(src);
-        a = s[0]; b = s[1]; c = s[2]; d = s[3];
+        a = s[0]; b = s[1]; c = s[2]; d = s[3]; e = s[4];
     }
     FamRec f;
     f.frozen = ((uint64_t)bcast32(a.y) << 32) | bcast32(a.x);
@@ -168,6 +169,7 @@ DEVINL FamRec load_fam(const FamRec* src) {
     f.anc1 = bcast32(b.x); f.anc2 = bcast32(b.y); f.base.h1 = bcast32(b.z); f.base.h2 = bcast32(b.w);
     f.base.nv = bcast32(c.x); f.w1.h1 = bcast32(c.y); f.w1.h2 = bcast32(c.z); f.w1.nv = bcast32(c.w);
     f.sumF[0] = bcast32(d.x); f.sumF[1] = bcast32(d.y); f.sumF[2] = bcast32(d.z); f.sumF[3] = bcast32(d.w);
+    f.tot[0] = bcast32(e.x); f.tot[1] = bcast32(e.y); f.tot[2] = bcast32(e.z); f.tot[3] = bcast32(e.w);
     return f;
 }
 
@@ -190,8 +192,12 @@ template <bool LDS> struct SubHeap {
         else gbase[(size_t)j * 64 + lane_id()] = k;
     }
     DEVINL void reset() { cnt = 0; top = ~0ull; top_lane = 0; dealt = 0; }
-    DEVINL void push(uint64_t k) {  // uniform key; lane (node_index % 64) inserts it
-        const uint32_t tgt = subkey_idx(k) & 63u;
+    // The queue holds one key per family (expansion) that still has an unpopped child. Keys are dealt to the lanes
+    // round-robin by push order (uniform counter `dealt`); every visit deals at most one key, so a lane never
+    // holds more than ceil(max_visits / 64) entries.
+    DEVINL void deal(uint64_t k) {   // k != ~0
+        const uint32_t tgt = dealt & 63u;
+        dealt += 1;
         if (lane_id() == tgt) {
             if (cnt >= jcap) ovf = 1;
             else {
@@ -207,50 +213,9 @@ template <bool LDS> struct SubHeap {
         }
         if (k < top) { top = k; top_lane = tgt; }
     }
-    // up to four uniform keys (~0 = absent) with distinct target lanes (consecutive node indices): the target
-    // lanes sift up concurrently inside one divergent region
-    DEVINL void push4(uint64_t ka, uint64_t kb, uint64_t kc, uint64_t kd2) {
-        // keys are dealt to lanes round-robin by push order (uniform counter `dealt`): at most
-        // ceil(pushes/64) keys per lane, and only the non-kept children are ever pushed (<= 3 per visit)
-        const uint32_t lane = lane_id();
-        uint64_t mine = ~0ull;
-        uint32_t c = dealt;
-        const uint32_t ta = c & 63u; if (ka != ~0ull) { if (lane == ta) mine = ka; c += 1; }
-        const uint32_t tb = c & 63u; if (kb != ~0ull) { if (lane == tb) mine = kb; c += 1; }
-        const uint32_t tc = c & 63u; if (kc != ~0ull) { if (lane == tc) mine = kc; c += 1; }
-        const uint32_t td = c & 63u; if (kd2 != ~0ull) { if (lane == td) mine = kd2; c += 1; }
-        dealt = c;
-        if (mine != ~0ull) {
-            if (cnt >= jcap) ovf = 1;
-            else {
-                uint32_t j = cnt;
-                while (j > 0) {
-                    const uint32_t pj = (j - 1) >> 1;
-                    const uint64_t pk = ld(pj);
-                    if (mine < pk) { st(j, pk); j = pj; } else break;
-                }
-                st(j, mine);
-                cnt += 1;
-            }
-        }
-        uint64_t m = ka; uint32_t tm = ta;
-        if (kb < m) { m = kb; tm = tb; }
-        if (kc < m) { m = kc; tm = tc; }
-        if (kd2 < m) { m = kd2; tm = td; }
-        if (m < top) { top = m; top_lane = tm; }
-    }
-    // pops the minimum and pushes k0 (present) + up to three more keys: the owner of the minimum re-uses the
-    // freed slot for k0 (one sift-down), so only k1..k3 are dealt out -> at most three dealt keys per visit and
-    // a per-lane bound of ceil(3 * max_visits / 64) entries (caller copied `top` first; heap is non-empty)
-    DEVINL void replace_push(uint64_t k0, uint64_t kb, uint64_t kc, uint64_t kd2) {
-        const uint32_t lane = lane_id();
-        uint64_t mine = ~0ull;
-        uint32_t c = dealt;
-        if (kb != ~0ull) { if (lane == (c & 63u)) mine = kb; c += 1; }
-        if (kc != ~0ull) { if (lane == (c & 63u)) mine = kc; c += 1; }
-        if (kd2 != ~0ull) { if (lane == (c & 63u)) mine = kd2; c += 1; }
-        dealt = c;
-        if (lane == top_lane) {
+    // pops the minimum and queues ka (present: it re-uses the freed slot, one sift-down) and kb (~0 = absent, dealt)
+    DEVINL void replace_push(uint64_t ka, uint64_t kb) {
+        if (lane_id() == top_lane) {
             uint32_t i = 0;
             for (;;) {
                 uint32_t ch = 2 * i + 1;
@@ -260,27 +225,15 @@ template <bool LDS> struct SubHeap {
                     const uint64_t c2 = ld(ch + 1);
                     if (c2 < ck) { ck = c2; ch += 1; }
                 }
-                if (ck < k0) { st(i, ck); i = ch; } else break;
+                if (ck < ka) { st(i, ck); i = ch; } else break;
             }
-            st(i, k0);
-        }
-        if (mine != ~0ull) {
-            if (cnt >= jcap) ovf = 1;
-            else {
-                uint32_t j = cnt;
-                while (j > 0) {
-                    const uint32_t pj = (j - 1) >> 1;
-                    const uint64_t pk = ld(pj);
-                    if (mine < pk) { st(j, pk); j = pj; } else break;
-                }
-                st(j, mine);
-                cnt += 1;
-            }
+            st(i, ka);
         }
         const uint64_t root = cnt > 0 ? ld(0) : ~0ull;
         top = wave_min_u64(root);
         const uint64_t who = __ballot(cnt > 0 && root == top);
         top_lane = who ? (uint32_t)__builtin_ctzll(who) : 0u;
+        if (kb != ~0ull) deal(kb);
     }
     DEVINL void pop() {  // removes the global minimum (caller copied `top` first)
         if (lane_id() == top_lane) {
@@ -468,6 +421,7 @@ struct Kids {
     uint64_t total0, total1, total2, total3;
     uint32_t depth, anc1, anc2, hets_het, hets_hom;
     uint32_t sumF0, sumF1, sumF2, sumF3;   // frozen increments (what the family record keeps)
+    uint32_t sumT0, sumT1, sumT2, sumT3;   // frozen + fluid increments
     Win base, w1;          // base = parent's window in the child's chunk (fresh when a new chunk opens)
     uint32_t bit;          // 1 << (p & 31)
 };
@@ -493,7 +447,7 @@ template <int S> DEVINL Cur kid_as_cur(const Kids& k, uint64_t next_idx) {
     n.w0 = kid_win<S>(k); n.w1 = k.w1;
     return n;
 }
-// one 64-byte family record per expansion, written by lane 0 at fam[node_index of the first child]
+// one 80-byte family record per expansion, written by lane 0 at fam[node_index of the first child]
 DEVINL void fam_store(FamRec* fam, const Kids& k, const Cur& parent, uint32_t next_idx) {
     if (lane_id() == 0) {
         uint4* d = reinterpret_cast<uint4*>(fam + next_idx);
@@ -502,6 +456,7 @@ DEVINL void fam_store(FamRec* fam, const Kids& k, const Cur& parent, uint32_t ne
         d[1] = make_uint4(k.anc1, k.anc2, k.base.h1, k.base.h2);
         d[2] = make_uint4(k.base.nv, k.w1.h1, k.w1.h2, k.w1.nv);
         d[3] = make_uint4(k.sumF0, k.sumF1, k.sumF2, k.sumF3);
+        d[4] = make_uint4(k.sumT0, k.sumT1, k.sumT2, k.sumT3);
     }
 }
 
@@ -566,6 +521,7 @@ DEVINL void expand_finish(const ExpPre& e, const Cur& cur, bool bad, uint64_t h_
     kd.hets_het = cur.hets + 1;
     kd.hets_hom = cur.hets;
     kd.sumF0 = sum[0]; kd.sumF1 = sum[1]; kd.sumF2 = sum[2]; kd.sumF3 = sum[3];
+    kd.sumT0 = sum[0] + sum[4]; kd.sumT1 = sum[1] + sum[5]; kd.sumT2 = sum[2] + sum[6]; kd.sumT3 = sum[3] + sum[7];
     kd.frozen0 = cur.frozen + sum[0]; kd.total0 = kd.frozen0 + sum[4] + h_next;
     kd.frozen1 = cur.frozen + sum[1]; kd.total1 = kd.frozen1 + sum[5] + h_next;
     kd.frozen2 = cur.frozen + sum[2]; kd.total2 = kd.frozen2 + sum[6] + h_next;
@@ -775,13 +731,16 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         const uint64_t k2 = kid_valid<2>(kd) ? make_subkey(kd.total2, kid_hets<2>(kd), next_idx + kid_rank<2>(kd), kid_rank<2>(kd), kd.depth) : ~0ull;
         const uint64_t k3 = kid_valid<3>(kd) ? make_subkey(kd.total3, kid_hets<3>(kd), next_idx + kid_rank<3>(kd), kid_rank<3>(kd), kd.depth) : ~0ull;
         const uint64_t kbest = umin64(umin64(k0, k1), umin64(k2, k3));
+        // the family's next key should kbest leave it: its smallest other child (~0: none)
+        const uint64_t ksecond = umin64(umin64(k0 == kbest ? ~0ull : k0, k1 == kbest ? ~0ull : k1),
+                                        umin64(k2 == kbest ? ~0ull : k2, k3 == kbest ? ~0ull : k3));
         // If the best child beats everything queued it is the next pop: keep it in registers (push + pop elided;
         // the priority is a total order, so this is exactly what the reference's queue would return).
         const bool take_child = kbest < heap.top;
         seg_stamp<PROF>(wc, 4);   // [4] child totals + keys
-        fam_store(pl.fam, kd, cur, next_idx);  // one 64-byte record for all siblings
+        fam_store(pl.fam, kd, cur, next_idx);  // one record for all siblings
         if (take_child) {
-            heap.push4(k0 == kbest ? ~0ull : k0, k1 == kbest ? ~0ull : k1, k2 == kbest ? ~0ull : k2, k3 == kbest ? ~0ull : k3);
+            if (ksecond != ~0ull) heap.deal(ksecond);
             // slots (a1,a2): 0 = (0,1), 1 = (1,0), 2 = (0,0), 3 = (1,1); the kept child's own cell joins the prefix scores
             if (k0 == kbest) { cur = kid_as_cur<0>(kd, next_idx); fs1 += x0; fs2 += x1; }
             else if (k1 == kbest) { cur = kid_as_cur<1>(kd, next_idx); fs1 += x1; fs2 += x0; }
@@ -789,9 +748,23 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
             else { cur = kid_as_cur<3>(kd, next_idx); fs1 += x1; fs2 += x1; }
             fast_valid = fast_ok && !collide;
         } else {
+            // the queue's minimum t is a child of an earlier expansion: rebuild it from its family record, and put
+            // that family's next child (the smallest sibling key above t) back in the queue together with kbest
             const uint64_t t = heap.top;
-            const FamRec fr = load_fam(pl.fam + (subkey_idx(t) - subkey_rank(t)));  // in flight during the heap update
-            heap.replace_push(k0, k1, k2, k3);
+            const uint32_t fbase = subkey_idx(t) - subkey_rank(t);
+            const FamRec fr = load_fam(pl.fam + fbase);
+            const uint64_t hn_t = ringH_get(off + subkey_depth(t));
+            const bool fbad = (fr.depth_flags >> 30) & 1u, fhas1 = (fr.depth_flags >> 31) & 1u;
+            const uint32_t fdepth = (fr.depth_flags & 0xFFFFFFu) + 1u;
+            const uint32_t r2 = fhas1 ? 2u : 1u, r3 = fhas1 ? 3u : 2u;
+            const uint64_t fb = fr.frozen + hn_t;
+            const uint64_t s0 = make_subkey(fb + fr.tot[0], fbad ? fr.hets : fr.hets + 1u, fbase, 0u, fdepth);
+            const uint64_t s1 = (!fbad && fhas1) ? make_subkey(fb + fr.tot[1], fr.hets + 1u, fbase + 1u, 1u, fdepth) : ~0ull;
+            const uint64_t s2 = !fbad ? make_subkey(fb + fr.tot[2], fr.hets, fbase + r2, r2, fdepth) : ~0ull;
+            const uint64_t s3 = !fbad ? make_subkey(fb + fr.tot[3], fr.hets, fbase + r3, r3, fdepth) : ~0ull;
+            const uint64_t knext = umin64(umin64(s0 > t ? s0 : ~0ull, s1 > t ? s1 : ~0ull),
+                                          umin64(s2 > t ? s2 : ~0ull, s3 > t ? s3 : ~0ull));
+            heap.replace_push(kbest, knext);
             cur = cur_from_fam(fr, subkey_rank(t), subkey_total(t), subkey_idx(t), off);
             fast_valid = false;   // a queued node: its prefix scores are rebuilt from the plane words
         }
