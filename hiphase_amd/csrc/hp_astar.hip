@@ -327,7 +327,8 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const size_t lds_bytes = LDS_HEAP_OFF + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup
-    const int occ = prm.sub_heap_in_lds ? 6 : 4;
+    int occ = prm.sub_heap_in_lds ? 6 : 4;
+    if (const char* e = std::getenv("HP_OCC")) { const int o = std::atoi(e); if (prm.sub_heap_in_lds && o >= 6 && o <= 8) occ = o; }
     uint32_t per_cu = (uint32_t)std::min<size_t>(4 * occ, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
     if (per_cu == 0) per_cu = 1;
     prm.cap_chunk_main = cap_main / 4 + 64;
@@ -379,6 +380,8 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     if (verbose) { fprintf(stderr, "[hp] launch items=%zu slots=%u cap_main=%u cap_sub=%u jcap_sub=%u lds=%zu stage=%u\n", items.size(), slots, cap_main, prm.cap_sub, prm.jcap_sub, lds_bytes, prm.pad0); fflush(stderr); }
     if (!prm.sub_heap_in_lds) hipLaunchKernelGGL((hp_astar_kernel<false, 4, false>), dim3(slots), dim3(64), lds_bytes, st, B);
     else if (prm.pad1) hipLaunchKernelGGL((hp_astar_kernel<true, 6, true>), dim3(slots), dim3(64), lds_bytes, st, B);
+    else if (occ == 8) hipLaunchKernelGGL((hp_astar_kernel<true, 8, false>), dim3(slots), dim3(64), lds_bytes, st, B);
+    else if (occ == 7) hipLaunchKernelGGL((hp_astar_kernel<true, 7, false>), dim3(slots), dim3(64), lds_bytes, st, B);
     else hipLaunchKernelGGL((hp_astar_kernel<true, 6, false>), dim3(slots), dim3(64), lds_bytes, st, B);
     HP_HIP_CHECK(hipGetLastError());
     return HP_OK;

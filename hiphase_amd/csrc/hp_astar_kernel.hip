@@ -417,16 +417,18 @@ struct Ctx {
 struct Kids {
     bool bad, has1;        // has1: the (1,0) child exists (parent haplotypes differ <=> hets != 0)
     uint32_t n;            // number of children created
-    uint64_t frozen0, frozen1, frozen2, frozen3;
-    uint64_t total0, total1, total2, total3;
+    uint64_t pfrozen;      // parent's frozen cost:  child frozen = pfrozen + sumF<slot>
+    uint64_t tbase;        // pfrozen + H[child depth]: child total = tbase + sumT<slot>
     uint32_t depth, anc1, anc2, hets_het, hets_hom;
     uint32_t sumF0, sumF1, sumF2, sumF3;   // frozen increments (what the family record keeps)
     uint32_t sumT0, sumT1, sumT2, sumT3;   // frozen + fluid increments
     Win base, w1;          // base = parent's window in the child's chunk (fresh when a new chunk opens)
     uint32_t bit;          // 1 << (p & 31)
 };
-template <int S> DEVINL uint64_t kid_total(const Kids& k) { return S == 0 ? k.total0 : S == 1 ? k.total1 : S == 2 ? k.total2 : k.total3; }
-template <int S> DEVINL uint64_t kid_frozen(const Kids& k) { return S == 0 ? k.frozen0 : S == 1 ? k.frozen1 : S == 2 ? k.frozen2 : k.frozen3; }
+template <int S> DEVINL uint32_t kid_sumT(const Kids& k) { return S == 0 ? k.sumT0 : S == 1 ? k.sumT1 : S == 2 ? k.sumT2 : k.sumT3; }
+template <int S> DEVINL uint32_t kid_sumF(const Kids& k) { return S == 0 ? k.sumF0 : S == 1 ? k.sumF1 : S == 2 ? k.sumF2 : k.sumF3; }
+template <int S> DEVINL uint64_t kid_total(const Kids& k) { return k.tbase + kid_sumT<S>(k); }
+template <int S> DEVINL uint64_t kid_frozen(const Kids& k) { return k.pfrozen + kid_sumF<S>(k); }
 template <int S> DEVINL bool kid_valid(const Kids& k) { return S == 0 ? true : k.bad ? false : (S == 1 ? k.has1 : true); }
 template <int S> DEVINL uint32_t kid_hets(const Kids& k) { return (S <= 1 && !k.bad) ? k.hets_het : k.hets_hom; }
 // creation rank of slot S among the children of this expansion (node_index = next_idx + rank)
@@ -522,10 +524,8 @@ DEVINL void expand_finish(const ExpPre& e, const Cur& cur, bool bad, uint64_t h_
     kd.hets_hom = cur.hets;
     kd.sumF0 = sum[0]; kd.sumF1 = sum[1]; kd.sumF2 = sum[2]; kd.sumF3 = sum[3];
     kd.sumT0 = sum[0] + sum[4]; kd.sumT1 = sum[1] + sum[5]; kd.sumT2 = sum[2] + sum[6]; kd.sumT3 = sum[3] + sum[7];
-    kd.frozen0 = cur.frozen + sum[0]; kd.total0 = kd.frozen0 + sum[4] + h_next;
-    kd.frozen1 = cur.frozen + sum[1]; kd.total1 = kd.frozen1 + sum[5] + h_next;
-    kd.frozen2 = cur.frozen + sum[2]; kd.total2 = kd.frozen2 + sum[6] + h_next;
-    kd.frozen3 = cur.frozen + sum[3]; kd.total3 = kd.frozen3 + sum[7] + h_next;
+    kd.pfrozen = cur.frozen;
+    kd.tbase = cur.frozen + h_next;
 }
 // the per-row part shared by both paths: child costs from (S1, S2) and the cell at p, split into frozen / fluid
 DEVINL void row_costs(uint32_t s1, uint32_t s2, uint32_t x0, uint32_t x1, bool frozen, uint32_t (&acc)[8]) {
@@ -724,12 +724,17 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         else expand<PROF>(cx, cur, off, p, lo, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs1, fs2, x0, x1);
         wc.nodes += kd.n;
         if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
-        if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
-        // keys of the (up to 4) children; invalid slots get the infinite key
-        const uint64_t k0 = make_subkey(kd.total0, kid_hets<0>(kd), next_idx + kid_rank<0>(kd), kid_rank<0>(kd), kd.depth);
-        const uint64_t k1 = kid_valid<1>(kd) ? make_subkey(kd.total1, kid_hets<1>(kd), next_idx + kid_rank<1>(kd), kid_rank<1>(kd), kd.depth) : ~0ull;
-        const uint64_t k2 = kid_valid<2>(kd) ? make_subkey(kd.total2, kid_hets<2>(kd), next_idx + kid_rank<2>(kd), kid_rank<2>(kd), kd.depth) : ~0ull;
-        const uint64_t k3 = kid_valid<3>(kd) ? make_subkey(kd.total3, kid_hets<3>(kd), next_idx + kid_rank<3>(kd), kid_rank<3>(kd), kd.depth) : ~0ull;
+        if (kd.bad && kid_total<0>(kd) != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
+        // keys of the (up to 4) children; invalid slots get the infinite key. make_subkey(total, hets, idx, rank, depth)
+        // with total = tbase + sumT<slot> is linear in its fields (they do not overlap), so the shared part is
+        // built once:  key = kc + (sumT << 28) + rank * 257 - (het slot ? 1 << 22 : 0)
+        const uint64_t kc = make_subkey(kd.tbase, kd.hets_hom, next_idx, 0u, kd.depth);
+        const uint64_t khet = kd.bad ? 0ull : (1ull << 22);   // slots 0/1 of a real expansion carry one more het
+        const uint32_t rk2 = kd.has1 ? 2u : 1u;
+        const uint64_t k0 = kc + ((uint64_t)kd.sumT0 << 28) - khet;
+        const uint64_t k1 = kid_valid<1>(kd) ? kc + ((uint64_t)kd.sumT1 << 28) + 257ull - khet : ~0ull;
+        const uint64_t k2 = kid_valid<2>(kd) ? kc + ((uint64_t)kd.sumT2 << 28) + 257ull * rk2 : ~0ull;
+        const uint64_t k3 = kid_valid<3>(kd) ? kc + ((uint64_t)kd.sumT3 << 28) + 257ull * (rk2 + 1u) : ~0ull;
         const uint64_t kbest = umin64(umin64(k0, k1), umin64(k2, k3));
         // the family's next key should kbest leave it: its smallest other child (~0: none)
         const uint64_t ksecond = umin64(umin64(k0 == kbest ? ~0ull : k0, k1 == kbest ? ~0ull : k1),
@@ -957,11 +962,11 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
             cx.flush();
             wc.nodes += kd.n;
             if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; break; }
-            if (kd.bad && kd.total0 != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:529
-            const Key k0 = make_key(kd.total0, kid_hets<0>(kd), next_idx + kid_rank<0>(kd), kid_rank<0>(kd), kd.depth);
-            const Key k1 = kid_valid<1>(kd) ? make_key(kd.total1, kid_hets<1>(kd), next_idx + kid_rank<1>(kd), kid_rank<1>(kd), kd.depth) : key_inf();
-            const Key k2 = kid_valid<2>(kd) ? make_key(kd.total2, kid_hets<2>(kd), next_idx + kid_rank<2>(kd), kid_rank<2>(kd), kd.depth) : key_inf();
-            const Key k3 = kid_valid<3>(kd) ? make_key(kd.total3, kid_hets<3>(kd), next_idx + kid_rank<3>(kd), kid_rank<3>(kd), kd.depth) : key_inf();
+            if (kd.bad && kid_total<0>(kd) != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:529
+            const Key k0 = make_key(kid_total<0>(kd), kid_hets<0>(kd), next_idx + kid_rank<0>(kd), kid_rank<0>(kd), kd.depth);
+            const Key k1 = kid_valid<1>(kd) ? make_key(kid_total<1>(kd), kid_hets<1>(kd), next_idx + kid_rank<1>(kd), kid_rank<1>(kd), kd.depth) : key_inf();
+            const Key k2 = kid_valid<2>(kd) ? make_key(kid_total<2>(kd), kid_hets<2>(kd), next_idx + kid_rank<2>(kd), kid_rank<2>(kd), kd.depth) : key_inf();
+            const Key k3 = kid_valid<3>(kd) ? make_key(kid_total<3>(kd), kid_hets<3>(kd), next_idx + kid_rank<3>(kd), kid_rank<3>(kd), kd.depth) : key_inf();
             int best = 0;
             Key kbest = k0;
             if (key_less(k1, kbest)) { kbest = k1; best = 1; }
