@@ -46,13 +46,16 @@ DEVINL uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_re
 // ---- DPP helpers -----------------------------------------------------------------------------------------
 // quad_perm [1,0,3,2] = 0xB1 (lane^1), [2,3,0,1] = 0x4E (lane^2), row_ror:8 = 0x128 (lane^8 inside a 16-lane
 // row), row_shr:4 = 0x114, row_shl:4 = 0x104, row_half_mirror = 0x141, row_mirror = 0x140.
+// old = 0 with bound_ctrl lets the backend fold the lane permutation into the consuming add (v_add_u32_dpp): every
+// lane of these patterns has a valid source, so the zero is never observed.
 template <int CTRL> DEVINL uint32_t dpp(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
-DEVINL uint32_t dpp_xor4(uint32_t v) {  // lanes with bit2 set take lane-4 (banks 1,3), the others lane+4 (banks 0,2)
-    int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xF, 0xA, false);
-    t = __builtin_amdgcn_update_dpp(t, (int)v, 0x104, 0xF, 0x5, false);
-    return (uint32_t)t;
+// v + v[lane ^ 4]: lanes with bit2 set take lane-4 (banks 1,3), the others lane+4 (banks 0,2); a disabled bank reads 0
+DEVINL uint32_t add_xor4(uint32_t v) {
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xA, true);
+    const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, true);
+    return v + up + dn;
 }
 
 // Sum of 8 per-lane values over the 64 lanes -> 8 uniform results. Transpose-butterfly: three halving
@@ -74,7 +77,7 @@ DEVINL void wave_sum8(const uint32_t (&a)[8], uint32_t (&out)[8]) {
     }
     const uint32_t keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
     const uint32_t d = keep + dpp<0x128>(send);
-    const uint32_t e = d + dpp_xor4(d);
+    const uint32_t e = add_xor4(d);
     // the four 16-lane rows are folded with the gfx950 row/half swaps (v_permlane16_swap: odd rows of the first
     // operand <-> even rows of the second; v_permlane32_swap: upper half <-> lower half), leaving the total in
     // every lane
