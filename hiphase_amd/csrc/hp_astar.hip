@@ -84,6 +84,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     for (uint32_t p = 0; p < N; ++p) hpk.vflags[v0 + p] &= (uint8_t)(HP_VAR_IGNORED | HP_VAR_SNV);   // bit 2 is VAR_NOFAST (device-only)
 
     uint64_t n_words = 0, cells = 0, max_row_qual = 0, total_qual = 0;
+    uint32_t max_row_len = 0;
     for (uint32_t i = 0; i < idx.size(); ++i) {
         const uint32_t r = idx[i];
         const uint32_t s = v->read_start[r], e = v->read_end[r];
@@ -120,6 +121,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
             if (lo == 0xFFFFFFFFu) lo = i;  // rows are visited in sorted order: the first one covering p is the min
         }
         max_row_qual = std::max(max_row_qual, row_qual);
+        max_row_len = std::max(max_row_len, e - s);
         total_qual += row_qual;
         n_words += k1 - k0 + 1;
         cells += e - s;
@@ -145,7 +147,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     // per-position cell table (incremental scoring in the sub-solver); variants where two covering rows collide on
     // (row index mod 64) are flagged for the plane-word path. HP_NO_CTAB=1 switches the table off (A/B testing).
     static const bool no_ctab = std::getenv("HP_NO_CTAB") != nullptr;
-    if (!no_ctab) {
+    if (!no_ctab && max_row_len <= CELL_T_MAX) {   // the cell table stores (p - row start) in 20 bits
         d.cell_off = hpk.cell_total;
         hpk.cell_total += (uint64_t)N * 64;
         if (max_cov > 64) {
@@ -246,7 +248,7 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     uint64_t total = 0;
     for (auto& d : b->desc) total += d.n_vars;
     const char* tenv = std::getenv("HP_SEG_TARGET");
-    uint64_t target = tenv ? (uint64_t)std::atoll(tenv) : std::max<uint64_t>(256, total / max_slots);
+    uint64_t target = tenv ? (uint64_t)std::atoll(tenv) : std::max<uint64_t>(64, total / max_slots);
     target = std::max<uint64_t>(64, (target + 63) / 64 * 64);
     const char* wenv = std::getenv("HP_SEG_WARM");
     const uint32_t warm = wenv ? (uint32_t)std::atoi(wenv) : 160;

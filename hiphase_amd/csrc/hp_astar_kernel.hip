@@ -304,6 +304,32 @@ struct MainHeap {
         }
         if (key_less(k, top)) { top = k; top_lane = tgt; }
     }
+    // up to three keys of consecutive node indices (key_inf() = absent): their owner lanes differ, so the sift-ups
+    // (dependent loads from HBM) run side by side in one divergent region instead of one after the other
+    DEVINL void push3(const Key& ka, const Key& kb, const Key& kc) {
+        const uint32_t lane = lane_id();
+        Key mine = key_inf();
+        const bool pa = (ka.hi & ka.lo) != ~0ull, pb = (kb.hi & kb.lo) != ~0ull, pc = (kc.hi & kc.lo) != ~0ull;
+        if (pa && lane == ((uint32_t)key_idx(ka) & 63u)) mine = ka;
+        if (pb && lane == ((uint32_t)key_idx(kb) & 63u)) mine = kb;
+        if (pc && lane == ((uint32_t)key_idx(kc) & 63u)) mine = kc;
+        if ((mine.hi & mine.lo) != ~0ull) {
+            if (cnt >= jcap) ovf = 1;
+            else {
+                uint32_t j = cnt;
+                while (j > 0) {
+                    const uint32_t pj = (j - 1) >> 1;
+                    const Key pk = ld(pj);
+                    if (key_less(mine, pk)) { st(j, pk); j = pj; } else break;
+                }
+                st(j, mine);
+                cnt += 1;
+            }
+        }
+        if (pa && key_less(ka, top)) { top = ka; top_lane = (uint32_t)key_idx(ka) & 63u; }
+        if (pb && key_less(kb, top)) { top = kb; top_lane = (uint32_t)key_idx(kb) & 63u; }
+        if (pc && key_less(kc, top)) { top = kc; top_lane = (uint32_t)key_idx(kc) & 63u; }
+    }
     // astar_phaser.rs:576-581: every queued node with depth < min_progress gets cost 0. Clearing is a decrease-key,
     // so each lane scans its heap front to back (independent, coalesced loads) and sifts UP only the entries that
     // are newly cleared — the pop order is a total order on the keys, so the heap's internal layout is free.
@@ -936,6 +962,10 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
         const uint64_t h0 = bcast64(lane == 0 ? H[0] : 0);
         Cur cur = root_node(h0);
         trk_add(0, 1);
+        // incremental scoring as in the sub-solver (see expand_fast): the root has scored nothing yet
+        const bool fast_ok = cx.ctab != nullptr;
+        bool fast_valid = fast_ok;
+        uint32_t fs1 = 0, fs2 = 0;
 
         while (cur.depth < N) {
             wc.main_pops += 1;
@@ -952,6 +982,7 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
                 const Key t = hq.top;
                 hq.pop();
                 cur = cur_from_fam(load_fam(mainp.fam + (key_idx(t) - key_rank(t))), key_rank(t), t.hi >> 24, key_idx(t), 0);
+                fast_valid = false;
                 continue;
             }
             const uint32_t p = cur.depth;
@@ -960,8 +991,10 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
             if (lane == 0) { fl = vflags[p]; l = vlo[p]; hn = H[p + 1]; }
             fl = bcast32(fl); l = bcast32(l); h = bcast32(h); hn = bcast64(hn);
             Kids kd;
-            uint32_t u1, u2, u3, u4;
-            expand<false>(cx, cur, 0, p, l, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, u1, u2, u3, u4);
+            uint32_t x0, x1;
+            const bool collide = (fl & VAR_NOFAST) != 0;
+            if (fast_valid && !collide) expand_fast<false>(cx, cur, 0, p, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, fs1, fs2, x0, x1);
+            else expand<false>(cx, cur, 0, p, l, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, fs1, fs2, x0, x1);
             cx.flush();
             wc.nodes += kd.n;
             if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; break; }
@@ -978,10 +1011,12 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
             // push every child except the best one, which is held in registers (it is logically queued)
             trk_add(kd.depth, kd.n);
             fam_store(mainp.fam, kd, cur, (uint32_t)next_idx);
-            if (best != 0) hq.push(k0);
-            if (kid_valid<1>(kd) && best != 1) hq.push(k1);
-            if (kid_valid<2>(kd) && best != 2) hq.push(k2);
-            if (kid_valid<3>(kd) && best != 3) hq.push(k3);
+            {   // the (at most three) children other than `best`
+                const Key q0 = best == 0 ? k1 : k0;
+                const Key q1 = best <= 1 ? k2 : k1;
+                const Key q2 = best <= 2 ? k3 : k2;
+                hq.push3(q0 /* never the infinite key unless a lone child */, q1, q2);
+            }
             qlen += kd.n;
             // astar_phaser.rs:564-585
             while (trk_total > thr && min_progress < next_expected) {
@@ -1000,12 +1035,14 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
                 }
             }
             if (key_less(kbest, hq.top)) {
-                if (best == 0) cur = kid_as_cur<0>(kd, next_idx);
-                else if (best == 1) cur = kid_as_cur<1>(kd, next_idx);
-                else if (best == 2) cur = kid_as_cur<2>(kd, next_idx);
-                else cur = kid_as_cur<3>(kd, next_idx);
+                if (best == 0) { cur = kid_as_cur<0>(kd, next_idx); fs1 += x0; fs2 += x1; }
+                else if (best == 1) { cur = kid_as_cur<1>(kd, next_idx); fs1 += x1; fs2 += x0; }
+                else if (best == 2) { cur = kid_as_cur<2>(kd, next_idx); fs1 += x0; fs2 += x0; }
+                else { cur = kid_as_cur<3>(kd, next_idx); fs1 += x1; fs2 += x1; }
                 cur.total = kbest.hi >> 24;
+                fast_valid = fast_ok && !collide;
             } else {
+                fast_valid = false;
                 hq.push(kbest);
                 const Key t = hq.top;
                 hq.pop();
