@@ -264,7 +264,8 @@ template <bool LDS> struct SubHeap {
     }
 };
 
-// (b) main heap: 128-bit keys in HBM scratch
+// (b) main heap: 128-bit keys in HBM scratch. Every level of a sift is a dependent HBM/L2 round trip, so the
+// per-lane heaps are 4-ary: half the levels of a binary heap, the four children of a node are fetched together.
 struct MainHeap {
     Key* base;
     uint32_t jcap, cnt;
@@ -276,13 +277,15 @@ struct MainHeap {
     DEVINL bool empty() const { return (top.hi & top.lo) == ~0ull; }
     DEVINL void sift_down(uint32_t i, Key k) {
         for (;;) {
-            uint32_t c = 2 * i + 1;
-            if (c >= cnt) break;
-            Key ck = ld(c);
-            if (c + 1 < cnt) {
-                const Key c2 = ld(c + 1);
-                if (key_less(c2, ck)) { ck = c2; c += 1; }
-            }
+            const uint32_t c0 = 4 * i + 1;
+            if (c0 >= cnt) break;
+            Key kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kk[u] = (c0 + u < cnt) ? ld(c0 + u) : key_inf();
+            Key ck = kk[0];
+            uint32_t c = c0;
+#pragma unroll
+            for (int u = 1; u < 4; ++u) if (key_less(kk[u], ck)) { ck = kk[u]; c = c0 + u; }
             if (key_less(ck, k)) { st(i, ck); i = c; } else break;
         }
         st(i, k);
@@ -294,7 +297,7 @@ struct MainHeap {
             else {
                 uint32_t j = cnt;
                 while (j > 0) {
-                    const uint32_t pj = (j - 1) >> 1;
+                    const uint32_t pj = (j - 1) >> 2;
                     const Key pk = ld(pj);
                     if (key_less(k, pk)) { st(j, pk); j = pj; } else break;
                 }
@@ -318,7 +321,7 @@ struct MainHeap {
             else {
                 uint32_t j = cnt;
                 while (j > 0) {
-                    const uint32_t pj = (j - 1) >> 1;
+                    const uint32_t pj = (j - 1) >> 2;
                     const Key pk = ld(pj);
                     if (key_less(mine, pk)) { st(j, pk); j = pj; } else break;
                 }
@@ -345,7 +348,7 @@ struct MainHeap {
                     c.hi &= 0xFFFFFFull;
                     uint32_t j = j0 + u;
                     while (j > 0) {
-                        const uint32_t pj = (j - 1) >> 1;
+                        const uint32_t pj = (j - 1) >> 2;
                         const Key pk = ld(pj);
                         if (key_less(c, pk)) { st(j, pk); j = pj; } else break;
                     }
