@@ -146,7 +146,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     d.n_words = (uint32_t)n_words;
     // per-position cell table (incremental scoring in the sub-solver); variants where two covering rows collide on
     // (row index mod 64) are flagged for the plane-word path. HP_NO_CTAB=1 switches the table off (A/B testing).
-    static const bool no_ctab = std::getenv("HP_NO_CTAB") != nullptr;
+    const bool no_ctab = std::getenv("HP_NO_CTAB") != nullptr;
     if (!no_ctab && max_row_len <= CELL_T_MAX) {   // the cell table stores (p - row start) in 20 bits
         d.cell_off = hpk.cell_total;
         hpk.cell_total += (uint64_t)N * 64;

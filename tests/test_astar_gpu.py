@@ -316,3 +316,30 @@ def test_multi_device_queue_path(monkeypatch):
     for blk, r in zip(blocks, res):
         h1, h2, st, _ = oracle_solve(blk)
         assert np.array_equal(r.haplotype_1, h1) and np.array_equal(r.haplotype_2, h2) and r.statistics.as_tuple() == st
+
+
+def test_c2_noisy_frontier_stress():
+    """SURVEY.md §8(d) "C2-noisy" (C=60, e=0.15; proxy for the 60x config): > 64 candidate rows per variant, so
+    the cell-table path is interleaved with VAR_NOFAST variants and multi-tile plane-word expansions."""
+    blk, _ = synth_block(1500, 60, 20, 0.15, 0.02, 20250509)
+    check_block(blk)
+
+
+def test_cell_table_on_off(monkeypatch):
+    """The incremental scoring path (per-position cell table) and the plane-word path give the same bits."""
+    blocks = [synth_block(n, c, s, e, 0.03, 8800 + i, ignored_permille=ign)[0]
+              for i, (n, c, s, e, ign) in enumerate([(600, 30, 20, 0.01, 0), (400, 45, 25, 0.05, 20), (300, 70, 18, 0.1, 0),
+                                                     (200, 10, 40, 0.02, 50), (90, 25, 70, 0.03, 0)])]
+    exp = [oracle_solve(b, want_heuristics=True) for b in blocks]
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("HP_NO_CTAB", "1")
+        rb = ResidentBatch(blocks)
+        rb.solve()
+        res, ctrs, hs = rb.results(want_heuristics=True)
+        rb.close()
+        for r, c, h, (h1, h2, st, octr, oh) in zip(res, ctrs, hs, exp):
+            assert np.array_equal(r.haplotype_1, h1) and np.array_equal(r.haplotype_2, h2)
+            assert r.statistics.as_tuple() == st
+            assert np.array_equal(h, oh)
+            assert c.as_tuple() == octr
