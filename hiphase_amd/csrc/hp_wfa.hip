@@ -198,26 +198,61 @@ double now_ms() {
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-thread_local std::vector<uint8_t> g_seq_stage;   // reused upload staging for the sequence bytes
+// Reused upload staging for the sequence bytes: pinned host memory (DMA straight from it), grow-only, never
+// value-initialised (a std::vector would memset ~35 KB per read on every call).
+struct StageBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0, len = 0;
+    ~StageBuf() { if (p) (void)hipHostFree(p); }
+    int resize(size_t n) {
+        if (n > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = n + n / 4 + 4096;
+            if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
+                p = nullptr;
+                set_error("hipHostMalloc(%zu) failed", want);
+                return HP_ERR_OOM;
+            }
+            cap = want;
+        }
+        len = n;
+        return HP_OK;
+    }
+    uint8_t* data() { return p; }
+    size_t size() const { return len; }
+};
+thread_local StageBuf g_seq_stage;
 
 struct WfaPack {
     std::vector<WfaJobDesc> jobs;
     std::vector<WfaNode> nodes;
     std::vector<WfaEdge> edges;
-    std::vector<uint8_t>& seq = g_seq_stage;
+    StageBuf& seq = g_seq_stage;
     uint64_t out_set_words = 0;
     uint64_t max_scratch = 0;
     uint32_t max_nodes = 0;
 };
 
-// lays the jobs `ids` out for edit-distance capacity `band`
+unsigned wfa_host_threads(size_t n) {
+    const char* tenv = std::getenv("HP_WFA_HOST_THREADS");
+    unsigned nt = tenv ? (unsigned)std::atoi(tenv) : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    return (unsigned)std::min<size_t>(std::max(1u, nt), std::max<size_t>(1, n / 64));
+}
+
+// lays the jobs `ids` out for edit-distance capacity `band`: offsets first (serial prefix sums over sizes that the
+// graphs already know), then the node/edge tables and the sequence bytes are filled by host threads
 int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, uint32_t band, WfaPack& pk) {
-    for (uint32_t id : ids) {
-        const HostJob& g = hj[id];
-        WfaJobDesc jd{};
-        jd.node_off = pk.nodes.size();
-        jd.edge_off = pk.edges.size();
-        jd.seq_off = pk.seq.size();
+    const size_t n = ids.size();
+    pk.jobs.resize(n);
+    uint64_t node_off = 0, edge_off = 0, seq_off = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const HostJob& g = hj[ids[i]];
+        WfaJobDesc& jd = pk.jobs[i];
+        jd = WfaJobDesc{};
+        jd.node_off = node_off;
+        jd.edge_off = edge_off;
+        jd.seq_off = seq_off;
         jd.n_nodes = (uint32_t)g.nodes.size();
         jd.set_words = (jd.n_nodes + 31) / 32;
         jd.read_off = g.read_off;
@@ -226,46 +261,71 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
         jd.out_set_off = pk.out_set_words;
         pk.out_set_words += jd.set_words;
         if (jd.n_nodes > WFA_MAX_NODES) { set_error("read overlaps a graph of %u nodes (> %u supported)", jd.n_nodes, WFA_MAX_NODES); return HP_ERR_UNSUPPORTED; }
-        uint64_t entry_off = 0;
-        for (uint32_t n = 0; n < jd.n_nodes; ++n) {
-            const HostNode& hn = g.nodes[n];
-            WfaNode dn{};
-            dn.seq_off = hn.seq_off;
-            dn.seq_len = hn.seq_len;
-            dn.child_off = (uint32_t)(pk.edges.size() - jd.edge_off);
-            dn.n_children = (uint16_t)hn.n_child;
-            const uint32_t np = n == 0 ? 1u : hn.n_par;
-            if (np > 32 || hn.n_child > 65535) { set_error("graph node with %u parents (> 32 supported)", np); return HP_ERR_UNSUPPORTED; }
-            dn.n_parents = (uint16_t)np;
-            const int64_t width = (hn.emax - hn.emin) + 2 * (int64_t)band + 3;
-            if (width > 65535) { set_error("diagonal band of %lld exceeds 65535", (long long)width); return HP_ERR_UNSUPPORTED; }
-            dn.dbase = (int32_t)(hn.emin - (int64_t)band - 1);
-            dn.width = (uint32_t)width;
-            dn.entry_stride = 5 + 2 * jd.set_words + np * jd.set_words;
-            dn.entry_off = (uint32_t)entry_off;
-            entry_off += (uint64_t)dn.width * dn.entry_stride;
-            if (entry_off > 0xFFFFFFF0ull) { set_error("WFA scratch of one read exceeds 16 GiB"); return HP_ERR_UNSUPPORTED; }
-            for (uint32_t ci = 0; ci < hn.n_child; ++ci) {
-                const uint32_t c = g.child[hn.child_off + ci];
-                const uint32_t* cp = g.par.data() + g.nodes[c].par_off;
-                const uint32_t ord = (uint32_t)(std::lower_bound(cp, cp + g.nodes[c].n_par, n) - cp);
-                pk.edges.push_back(WfaEdge{c, ord});
-            }
-            pk.nodes.push_back(dn);
-        }
-        jd.scratch_dwords = (uint32_t)entry_off;
-        pk.max_scratch = std::max<uint64_t>(pk.max_scratch, entry_off);
+        node_off += g.nodes.size();
+        edge_off += g.child.size();
+        seq_off += g.seq_bytes;
         pk.max_nodes = std::max(pk.max_nodes, jd.n_nodes);
-        {
-            const size_t o = pk.seq.size();
-            pk.seq.resize(o + g.seq_bytes);   // staging buffer is thread-local and reused: no page faults after warm-up
-            uint8_t* dst = pk.seq.data() + o;
+    }
+    pk.nodes.resize(node_off);
+    pk.edges.resize(edge_off);
+    if (int rc = pk.seq.resize(seq_off)) return rc;
+    const unsigned nt = wfa_host_threads(n);
+    std::vector<int> rcs(nt, HP_OK);
+    std::vector<std::string> errs(nt);
+    std::vector<uint64_t> max_scratch(nt, 0);
+    auto work = [&](unsigned t) {
+        char msg[160];
+        for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
+            const HostJob& g = hj[ids[i]];
+            WfaJobDesc& jd = pk.jobs[i];
+            WfaNode* nodes = pk.nodes.data() + jd.node_off;
+            WfaEdge* edges = pk.edges.data() + jd.edge_off;
+            uint64_t entry_off = 0;
+            uint32_t e_cur = 0;
+            for (uint32_t k = 0; k < jd.n_nodes; ++k) {
+                const HostNode& hn = g.nodes[k];
+                WfaNode dn{};
+                dn.seq_off = hn.seq_off;
+                dn.seq_len = hn.seq_len;
+                dn.child_off = e_cur;
+                dn.n_children = (uint16_t)hn.n_child;
+                const uint32_t np = k == 0 ? 1u : hn.n_par;
+                if (np > 32 || hn.n_child > 65535) { snprintf(msg, sizeof msg, "graph node with %u parents (> 32 supported)", np); errs[t] = msg; rcs[t] = HP_ERR_UNSUPPORTED; return; }
+                dn.n_parents = (uint16_t)np;
+                const int64_t width = (hn.emax - hn.emin) + 2 * (int64_t)band + 3;
+                if (width > 65535) { snprintf(msg, sizeof msg, "diagonal band of %lld exceeds 65535", (long long)width); errs[t] = msg; rcs[t] = HP_ERR_UNSUPPORTED; return; }
+                dn.dbase = (int32_t)(hn.emin - (int64_t)band - 1);
+                dn.width = (uint32_t)width;
+                dn.entry_stride = 5 + 2 * jd.set_words + np * jd.set_words;
+                dn.entry_off = (uint32_t)entry_off;
+                entry_off += (uint64_t)dn.width * dn.entry_stride;
+                if (entry_off > 0xFFFFFFF0ull) { errs[t] = "WFA scratch of one read exceeds 16 GiB"; rcs[t] = HP_ERR_UNSUPPORTED; return; }
+                for (uint32_t ci = 0; ci < hn.n_child; ++ci) {
+                    const uint32_t c = g.child[hn.child_off + ci];
+                    const uint32_t* cp = g.par.data() + g.nodes[c].par_off;
+                    const uint32_t ord = (uint32_t)(std::lower_bound(cp, cp + g.nodes[c].n_par, k) - cp);
+                    edges[e_cur++] = WfaEdge{c, ord};
+                }
+                nodes[k] = dn;
+            }
+            jd.scratch_dwords = (uint32_t)entry_off;
+            max_scratch[t] = std::max<uint64_t>(max_scratch[t], entry_off);
+            uint8_t* dst = pk.seq.data() + jd.seq_off;
             std::memcpy(dst, g.ref_ptr, g.ref_len);
             if (!g.alt.empty()) std::memcpy(dst + g.ref_len, g.alt.data(), g.alt.size());
             if (g.read_len) std::memcpy(dst + g.read_off, g.read_ptr, g.read_len);
             std::memset(dst + g.read_off + g.read_len, 0, g.seq_bytes - g.read_off - g.read_len);
         }
-        pk.jobs.push_back(jd);
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    for (unsigned t = 0; t < nt; ++t) {
+        if (rcs[t] != HP_OK) { set_error("%s", errs[t].c_str()); return rcs[t]; }
+        pk.max_scratch = std::max(pk.max_scratch, max_scratch[t]);
     }
     return HP_OK;
 }
@@ -281,11 +341,9 @@ template <class T> int up(DevBuf& buf, const std::vector<T>& v) {
 int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, uint32_t band, uint64_t prune, uint64_t max_ed,
              int n_cu, std::vector<int32_t>& status, std::vector<uint64_t>& score, std::vector<std::vector<uint32_t>>& sets) {
     WfaPack pk;
-    pk.seq.clear();
     {
         size_t tot = 0, nn = 0;
         for (uint32_t id : ids) { tot += hj[id].seq_bytes; nn += hj[id].nodes.size(); }
-        pk.seq.reserve(tot);
         pk.nodes.reserve(nn);
         pk.edges.reserve(nn * 2);
         pk.jobs.reserve(ids.size());
@@ -302,8 +360,9 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     const double t_pack = now_ms();
     DevBuf d_jobs, d_order, d_nodes, d_edges, d_seq, d_sets, d_score, d_status;
     if ((rc = up(d_jobs, pk.jobs)) || (rc = up(d_order, order)) || (rc = up(d_nodes, pk.nodes)) || (rc = up(d_edges, pk.edges)) ||
-        (rc = up(d_seq, pk.seq)))
+        (rc = d_seq.alloc(pk.seq.size())))
         return rc;
+    if (pk.seq.size()) HP_HIP_CHECK(hipMemcpy(d_seq.p, pk.seq.data(), pk.seq.size(), hipMemcpyHostToDevice));
     if ((rc = d_sets.alloc(pk.out_set_words * 4 + 16)) || (rc = d_score.alloc(n * 8)) || (rc = d_status.alloc(n * 4))) return rc;
     std::vector<int32_t> st0(n, WFA_ST_PENDING);
     HP_HIP_CHECK(hipMemcpy(d_status.p, st0.data(), n * 4, hipMemcpyHostToDevice));
@@ -381,9 +440,7 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
     {
         // graph construction is independent per read: spread it over host threads (HP_WFA_HOST_THREADS, default
         // min(8, cores)); the caller's own thread pool (main.rs:332) composes with this
-        const char* tenv = std::getenv("HP_WFA_HOST_THREADS");
-        unsigned nt = tenv ? (unsigned)std::atoi(tenv) : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-        nt = (unsigned)std::min<size_t>(std::max(1u, nt), std::max<size_t>(1, n / 64));
+        const unsigned nt = wfa_host_threads(n);
         std::atomic<int> first_rc{HP_OK};
         std::vector<std::string> errs(nt);
         auto work = [&](unsigned t) {

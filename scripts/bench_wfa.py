@@ -19,6 +19,7 @@ base = [synth_wfa_job(1000 + s, ref_len=args.ref_len, n_vars=24, n_homs=8, noise
 specs = [base[i % args.distinct] for i in range(args.jobs)]
 wfa_assign_batch(specs[:64])  # warm-up (module load)
 pb = PreparedWfaBatch(specs)
+pb.run()  # steady state: a worker thread's staging buffers and band scratch are sized by its first block
 t0 = time.perf_counter(); res = pb.run(); dt = time.perf_counter() - t0
 kms = _ffi.lib().hp_last_kernel_ms()
 bases = sum(len(s.read) for s in specs)
