@@ -329,8 +329,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const size_t lds_bytes = LDS_HEAP_OFF + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup
-    int occ = prm.sub_heap_in_lds ? 6 : 4;
-    if (const char* e = std::getenv("HP_OCC")) { const int o = std::atoi(e); if (prm.sub_heap_in_lds && o >= 6 && o <= 8) occ = o; }
+    const int occ = prm.sub_heap_in_lds ? 6 : 4;
     uint32_t per_cu = (uint32_t)std::min<size_t>(4 * occ, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
     if (per_cu == 0) per_cu = 1;
     prm.cap_chunk_main = cap_main / 4 + 64;
@@ -382,8 +381,6 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     if (verbose) { fprintf(stderr, "[hp] launch items=%zu slots=%u cap_main=%u cap_sub=%u jcap_sub=%u lds=%zu stage=%u\n", items.size(), slots, cap_main, prm.cap_sub, prm.jcap_sub, lds_bytes, prm.pad0); fflush(stderr); }
     if (!prm.sub_heap_in_lds) hipLaunchKernelGGL((hp_astar_kernel<false, 4, false>), dim3(slots), dim3(64), lds_bytes, st, B);
     else if (prm.pad1) hipLaunchKernelGGL((hp_astar_kernel<true, 6, true>), dim3(slots), dim3(64), lds_bytes, st, B);
-    else if (occ == 8) hipLaunchKernelGGL((hp_astar_kernel<true, 8, false>), dim3(slots), dim3(64), lds_bytes, st, B);
-    else if (occ == 7) hipLaunchKernelGGL((hp_astar_kernel<true, 7, false>), dim3(slots), dim3(64), lds_bytes, st, B);
     else hipLaunchKernelGGL((hp_astar_kernel<true, 6, false>), dim3(slots), dim3(64), lds_bytes, st, B);
     HP_HIP_CHECK(hipGetLastError());
     return HP_OK;
@@ -400,11 +397,61 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     if (max_seg < 2 || max_seg > 62) { set_error("max_segment_size %llu outside [2,62]", (unsigned long long)max_seg); return fail(HP_ERR_UNSUPPORTED); }
     if (p->min_queue_size > (1u << 26) || p->queue_increment > (1u << 20)) { set_error("queue parameters too large"); return fail(HP_ERR_UNSUPPORTED); }
 
-    HostPack hpk;
-    for (size_t i = 0; i < n_blocks; ++i) {
-        int rc = pack_block(&blks[i], hpk);
-        if (rc != HP_OK) return fail(rc);
+    // Validation + packing is independent per block: host threads (HP_PACK_THREADS, default min(16, cores)) each
+    // pack a contiguous range of blocks into their own arrays; the parts are uploaded side by side and only the
+    // small per-block tables are merged.
+    unsigned nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = std::getenv("HP_PACK_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
+    nt = (unsigned)std::min<size_t>(nt, n_blocks / 8 + 1);
+    std::vector<HostPack> parts(nt);
+    {
+        std::vector<int> rcs(nt, HP_OK);
+        std::vector<std::string> errs(nt);
+        auto work = [&](unsigned t) {
+            for (size_t i = n_blocks * t / nt; i < n_blocks * (t + 1) / nt; ++i) {
+                const int rc = pack_block(&blks[i], parts[t]);
+                if (rc != HP_OK) {
+                    rcs[t] = rc;
+                    errs[t] = "block " + std::to_string(i) + ": " + hp_last_error();
+                    return;
+                }
+            }
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+            for (auto& x : th) x.join();
+        }
+        for (unsigned t = 0; t < nt; ++t) if (rcs[t] != HP_OK) { set_error("%s", errs[t].c_str()); return fail(rcs[t]); }
     }
+    HostPack hpk;   // merged view: per-block tables and totals only (the large arrays stay in `parts`)
+    struct PartBase { uint64_t var, read, word, h, chunk, cell, rows; uint32_t blk; };
+    std::vector<PartBase> base(nt);
+    {
+        PartBase acc{0, 0, 0, 0, 0, 0, 0, 0};
+        for (unsigned t = 0; t < nt; ++t) {
+            HostPack& q = parts[t];
+            base[t] = acc;
+            for (BlockDesc d : q.desc) {
+                d.var_off += acc.var; d.read_off += acc.read; d.word_off += acc.word; d.h_off += acc.h; d.chunk_off += acc.chunk;
+                if (d.cell_off != ~0ull) d.cell_off += acc.cell;
+                hpk.desc.push_back(d);
+            }
+            for (uint32_t rb : q.row_block) hpk.row_block.push_back(rb + acc.blk);
+            hpk.row_orig.insert(hpk.row_orig.end(), q.row_orig.begin(), q.row_orig.end());
+            for (uint64_t o : q.caller_row_off) hpk.caller_row_off.push_back(o + acc.rows);
+            hpk.work.insert(hpk.work.end(), q.work.begin(), q.work.end());
+            hpk.max_n = std::max(hpk.max_n, q.max_n);
+            acc.var += q.vlo.size(); acc.read += q.rstart.size(); acc.word += q.words.size() / WORD_DWORDS;
+            acc.h += q.h_total; acc.chunk += q.chunk_total; acc.cell += q.cell_total; acc.rows += q.caller_rows;
+            acc.blk += (uint32_t)q.desc.size();
+        }
+        hpk.h_total = acc.h; hpk.chunk_total = acc.chunk; hpk.cell_total = acc.cell; hpk.caller_rows = acc.rows;
+    }
+    const uint64_t tot_vars = base[nt - 1].var + parts[nt - 1].vlo.size(), tot_rows = base[nt - 1].read + parts[nt - 1].rstart.size();
+    const uint64_t tot_words = base[nt - 1].word + parts[nt - 1].words.size() / WORD_DWORDS;
+    if (tot_words > 0xFFFFFFFFFFull) { set_error("batch too large"); return fail(HP_ERR_UNSUPPORTED); }
     // host-side validation/packing is done; from here on a GPU is mandatory
     if (device_id < 0) device_id = hp_default_device();
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return fail(HP_ERR_HIP); }
@@ -415,7 +462,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     b->desc = hpk.desc;
     b->max_n = hpk.max_n;
     b->sum_h = hpk.h_total;
-    b->sum_n = hpk.vlo.size();
+    b->sum_n = tot_vars;
     b->row_orig = hpk.row_orig;
     b->row_block_h = hpk.row_block;
     b->caller_row_off = hpk.caller_row_off;
@@ -450,10 +497,25 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
 
     hipStream_t s = b->stream;
     int rc;
-#define UP(buf, vec) if ((rc = upload(b->buf, hpk.vec, s)) != HP_OK) return fail(rc)
-    UP(d_desc, desc); UP(d_vlo, vlo); UP(d_vhi, vhi); UP(d_vflags, vflags);
-    UP(d_rstart, rstart); UP(d_rend, rend); UP(d_rword, rword); UP(d_words, words);
-#undef UP
+    if ((rc = upload(b->d_desc, hpk.desc, s)) != HP_OK) return fail(rc);
+    if ((rc = b->d_vlo.alloc(tot_vars * 4)) || (rc = b->d_vhi.alloc(tot_vars * 4)) || (rc = b->d_vflags.alloc(tot_vars)) ||
+        (rc = b->d_rstart.alloc(tot_rows * 4)) || (rc = b->d_rend.alloc(tot_rows * 4)) || (rc = b->d_rword.alloc(tot_rows * 4)) ||
+        (rc = b->d_words.alloc(tot_words * WORD_DWORDS * 4)))
+        return fail(rc);
+    for (unsigned t = 0; t < nt; ++t) {
+        const HostPack& q = parts[t];
+        const PartBase& o = base[t];
+        auto put = [&](DevBuf& dst, uint64_t off_bytes, const void* src, size_t bytes) {
+            return bytes == 0 || hipMemcpyAsync(dst.as<unsigned char>() + off_bytes, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+        };
+        if (!put(b->d_vlo, o.var * 4, q.vlo.data(), q.vlo.size() * 4) || !put(b->d_vhi, o.var * 4, q.vhi.data(), q.vhi.size() * 4) ||
+            !put(b->d_vflags, o.var, q.vflags.data(), q.vflags.size()) || !put(b->d_rstart, o.read * 4, q.rstart.data(), q.rstart.size() * 4) ||
+            !put(b->d_rend, o.read * 4, q.rend.data(), q.rend.size() * 4) || !put(b->d_rword, o.read * 4, q.rword.data(), q.rword.size() * 4) ||
+            !put(b->d_words, o.word * WORD_DWORDS * 4, q.words.data(), q.words.size() * 4)) {
+            set_error("upload failed: %s", hipGetErrorString(hipGetLastError()));
+            return fail(HP_ERR_HIP);
+        }
+    }
     if ((rc = upload(b->d_row_block, hpk.row_block, s)) != HP_OK) return fail(rc);
     // per-position cell tables are derived on the device from the rows just uploaded
     if ((rc = b->d_ctab.alloc(hpk.cell_total * sizeof(uint32_t) + 16)) != HP_OK) return fail(rc);

@@ -10,7 +10,7 @@ def run(tag, a):
     rb.solve()
     ms = min(rb.solve() for _ in range(3))
     rb.close()
-    print(f"{tag} HP_OCC={os.environ.get('HP_OCC')} blocks={len(blocks)} ms={ms:.1f}", flush=True)
+    print(f"{tag} blocks={len(blocks)} ms={ms:.1f}", flush=True)
 
 base = dict(replay=None, hets=5000, coverage=30, span=20, error=0.01)
 run("wgs12000", argparse.Namespace(workload="wgs", blocks=12000, **base))
