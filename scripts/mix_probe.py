@@ -1,4 +1,5 @@
-"""Times the WGS-like mix and a small C2 batch under the current HP_OCC / HP_NO_SEGMENTS environment."""
+"""Times the heavy-tailed WGS-like block mix and a single C2 block (latency-bound cases); honours HP_NO_SEGMENTS /
+HP_SEG_TARGET / HP_NO_CTAB from the environment."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
