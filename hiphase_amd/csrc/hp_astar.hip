@@ -148,23 +148,33 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     // (row index mod 64) are flagged for the plane-word path. HP_NO_CTAB=1 switches the table off (A/B testing).
     const bool no_ctab = std::getenv("HP_NO_CTAB") != nullptr;
     if (!no_ctab && max_row_len <= CELL_T_MAX) {   // the cell table stores (p - row start) in 20 bits
-        d.cell_off = hpk.cell_total;
-        hpk.cell_total += (uint64_t)N * 64;
-        if (max_cov > 64) {
+        // entries per variant (hp_astar_dev.h CELL_*): 64, unless that leaves more than 2 % of the variants with two
+        // covering rows on one entry (high coverage), then 128
+        auto collisions = [&](uint32_t ents, bool mark) {
+            uint32_t n_bad = 0;
             for (uint32_t p = 0; p < N; ++p) {
                 const uint32_t lo = hpk.vlo[v0 + p], hi = hpk.vhi[v0 + p];
-                if (hi - lo <= 64) continue;
-                uint64_t seen = 0;
+                if (hi - lo <= ents) continue;
+                uint64_t seen[2] = {0, 0};
                 for (uint32_t i = lo; i < hi; ++i) {
                     if (v->read_end[idx[i]] <= p) continue;
-                    const uint64_t bit = 1ull << (i & 63u);
-                    if (seen & bit) { hpk.vflags[v0 + p] |= VAR_NOFAST; break; }
-                    seen |= bit;
+                    const uint32_t e = i & (ents - 1u);
+                    const uint64_t bit = 1ull << (e & 63u);
+                    if (seen[e >> 6] & bit) { n_bad += 1; if (mark) hpk.vflags[v0 + p] |= VAR_NOFAST; break; }
+                    seen[e >> 6] |= bit;
                 }
             }
-        }
+            return n_bad;
+        };
+        uint32_t ents = 64;
+        if (max_cov > 64 && (uint64_t)collisions(64, false) * 50 > N) ents = 128;
+        if (max_cov > ents) collisions(ents, true);
+        d.ctab_shift = ents == 128 ? 7u : 6u;
+        d.cell_off = hpk.cell_total;
+        hpk.cell_total += (uint64_t)N * ents;
     } else {
         d.cell_off = ~0ull;
+        d.ctab_shift = 6;
     }
     hpk.desc.push_back(d);
     hpk.work.push_back(cells * 8 + N);
@@ -195,6 +205,7 @@ struct hp_batch {
     std::vector<uint32_t> order;  // LPT
     uint64_t sum_n = 0, sum_h = 0;
     uint32_t max_n = 0;
+    uint32_t tiles = 1;     // 2 when some block's cell table has 128 entries per variant (selects the TILES kernel variant)
     int n_cu = 256;
     // device inputs
     DevBuf d_desc, d_order, d_vlo, d_vhi, d_vflags, d_rstart, d_rend, d_rword, d_words, d_head, d_ctab;
@@ -298,7 +309,8 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     S.segs = b->d_segs.as<SegDesc>(); S.seg_order = b->d_seg_order.as<uint32_t>(); S.n_segs = (uint32_t)segs.size();
     S.out = b->d_seg_out.as<SegOut>();
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] segment-parallel heuristic: %zu segments of ~%llu hets (+%u warm-up) over %zu blocks, slots=%u\n", segs.size(), (unsigned long long)target, warm, sb_id.size(), slots); fflush(stderr); }
-    hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6>), dim3(slots), dim3(64), lds_bytes, st, S);
+    if (b->tiles == 2) hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 2>), dim3(slots), dim3(64), lds_bytes, st, S);
+    else hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 1>), dim3(slots), dim3(64), lds_bytes, st, S);
     StitchDev T{};
     T.desc = B.desc; T.segs = S.segs; T.out = S.out;
     T.blk_first_seg = b->d_sb_first.as<uint32_t>(); T.blk_n_seg = b->d_sb_n.as<uint32_t>(); T.blk_id = b->d_sb_id.as<uint32_t>();
@@ -375,13 +387,14 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     B.prm = prm;
     if (verbose) {
         int occ_blocks = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_blocks, hp_astar_kernel<true, 6, false>, 64, lds_bytes);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_blocks, hp_astar_kernel<true, 6, false, 1>, 64, lds_bytes);
         fprintf(stderr, "[hp] hipOccupancyMaxActiveBlocksPerMultiprocessor(hp_astar_kernel, 64, %zu) = %d\n", lds_bytes, occ_blocks);
     }
     if (verbose) { fprintf(stderr, "[hp] launch items=%zu slots=%u cap_main=%u cap_sub=%u jcap_sub=%u lds=%zu stage=%u\n", items.size(), slots, cap_main, prm.cap_sub, prm.jcap_sub, lds_bytes, prm.pad0); fflush(stderr); }
-    if (!prm.sub_heap_in_lds) hipLaunchKernelGGL((hp_astar_kernel<false, 4, false>), dim3(slots), dim3(64), lds_bytes, st, B);
-    else if (prm.pad1) hipLaunchKernelGGL((hp_astar_kernel<true, 6, true>), dim3(slots), dim3(64), lds_bytes, st, B);
-    else hipLaunchKernelGGL((hp_astar_kernel<true, 6, false>), dim3(slots), dim3(64), lds_bytes, st, B);
+    if (!prm.sub_heap_in_lds) hipLaunchKernelGGL((hp_astar_kernel<false, 4, false, 2>), dim3(slots), dim3(64), lds_bytes, st, B);
+    else if (b->tiles == 2) hipLaunchKernelGGL((hp_astar_kernel<true, 6, false, 2>), dim3(slots), dim3(64), lds_bytes, st, B);
+    else if (prm.pad1) hipLaunchKernelGGL((hp_astar_kernel<true, 6, true, 1>), dim3(slots), dim3(64), lds_bytes, st, B);
+    else hipLaunchKernelGGL((hp_astar_kernel<true, 6, false, 1>), dim3(slots), dim3(64), lds_bytes, st, B);
     HP_HIP_CHECK(hipGetLastError());
     return HP_OK;
 }
@@ -461,6 +474,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     b->params = *p;
     b->desc = hpk.desc;
     b->max_n = hpk.max_n;
+    for (const BlockDesc& d : hpk.desc) if (d.ctab_shift == 7) b->tiles = 2;
     b->sum_h = hpk.h_total;
     b->sum_n = tot_vars;
     b->row_orig = hpk.row_orig;

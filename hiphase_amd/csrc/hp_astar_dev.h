@@ -35,14 +35,17 @@ struct BlockDesc {
     uint32_t n_words;
     uint64_t chunk_off; // into hapw (one Win per 32-variant chunk of the solution)
     uint64_t cell_off;  // into ctab (entries); ~0 when the block has no cell table (HP_NO_CTAB)
+    uint32_t ctab_shift; // log2(entries per variant) of the block's cell table: 6 or 7
+    uint32_t pad;
 };
 // device-only bit of vflags[p] (the caller's bits are HP_VAR_IGNORED / HP_VAR_SNV): two rows covering p share a cell
 // table entry (same row index mod 64), so the incremental path must not be used at p
 constexpr uint8_t VAR_NOFAST = 0x4;
 
-// Per-position cell table (built on the device by hp_build_ctab_kernel): 64 u32 entries per variant p, entry
-// (row index mod 64) describes that row's cell at p. Variants where two covering rows would share an entry carry
-// VAR_NOFAST and are handled by the plane-word path.
+// Per-position cell table (built on the device by hp_build_ctab_kernel): E u32 entries per variant p, E = 64 for
+// blocks with at most 64 candidate rows per variant (max_cov), else 128; entry (row index mod E) describes that
+// row's cell at p (lane = entry & 63, tile = entry >> 6). Variants where two covering rows would share an entry
+// carry VAR_NOFAST and are handled by the plane-word path.
 //   bits 0-7 qual | 8-9 allele (NoOverlap stored as Ambiguous: both mismatch 0 and 1, and NoOverlap has qual 0) |
 //   10 row ends here (end == p+1) | 11 valid (row covers p) | 12-31 min(p - row start, 2^20-1)
 constexpr uint32_t CELL_ENDS = 1u << 10, CELL_VALID = 1u << 11, CELL_T_SHIFT = 12, CELL_T_MAX = (1u << 20) - 1;

@@ -437,6 +437,7 @@ struct Ctx {
     const uint32_t *rstart, *rend, *rword;
     const uint32_t* words;
     uint32_t n_rows;
+    uint32_t tiles;         // 64-entry tiles per variant in the cell table (1 or 2)
     const uint32_t* ctab;   // per-position cell table of the block (hp_astar_dev.h CELL_*), nullptr with HP_NO_CTAB
     uint32_t N;
     uint64_t evals, cells;  // per-lane work counters
@@ -517,6 +518,16 @@ DEVINL uint32_t wpop(uint32_t M, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t
 //                    is the child the previous expansion kept (86 % of the sub-solver's pops on HiFi-like data):
 //                    S(child) = S(parent) + the child's own cell, read from the per-position cell table.
 // Rows are dealt to lanes by (row index mod 64) in both, so a row keeps its lane from one position to the next.
+// Per-lane incremental state: prefix scores of the lane's row in each of the (up to two) 64-row tiles of the cell
+// table, and the cost of the row's cell at the variant being expanded for haplotype allele 0 / 1.
+struct FastState { uint32_t s1a, s2a, s1b, s2b; };
+struct CellCost { uint32_t x0a, x1a, x0b, x1b; };
+template <int TILES>
+DEVINL void fast_apply(FastState& f, const CellCost& c, bool a1, bool a2) {   // the kept child carries alleles (a1, a2)
+    f.s1a += a1 ? c.x1a : c.x0a; f.s2a += a2 ? c.x1a : c.x0a;
+    if (TILES == 2) { f.s1b += a1 ? c.x1b : c.x0b; f.s2b += a2 ? c.x1b : c.x0b; }   // second tile: dead state otherwise
+}
+
 struct ExpPre {
     bool trans;
     uint32_t new_chunk, nkids, bp;
@@ -573,11 +584,10 @@ DEVINL void row_costs(uint32_t s1, uint32_t s2, uint32_t x0, uint32_t x1, bool f
 
 // lo = first candidate row of variant p (rows are start-sorted; the candidates end with the last row whose start
 // is <= p), bad = variant ignored. Leaves, per lane, the scores of the
-// parent prefix (ps1, ps2) and the cell costs (px0, px1) of its row (zeros if it has none).
-template <bool PROF>
+// parent prefix and the cell costs of its row(s) (zeros where it has none).
+template <bool PROF, int TILES>
 DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t lo, bool bad,
-                   uint64_t h_next, Pools& pl, Kids& kd, WaveCounters& wc, uint32_t& ps1, uint32_t& ps2,
-                   uint32_t& px0, uint32_t& px1) {
+                   uint64_t h_next, Pools& pl, Kids& kd, WaveCounters& wc, FastState& fs, CellCost& cc) {
     const uint32_t lane = lane_id();
     const ExpPre e = expand_begin(cur, off, p, bad, pl);
     const uint32_t kp = p >> 5, bp = e.bp;
@@ -585,7 +595,8 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
     const Win W0 = e.W0, W1 = e.W1, W2 = e.W2;
     const uint32_t nkids = e.nkids;
     uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0..3] frozen per slot, [4..7] fluid per slot
-    ps1 = 0; ps2 = 0; px0 = 0; px1 = 0;
+    fs = FastState{0, 0, 0, 0};
+    cc = CellCost{0, 0, 0, 0};
 
     for (uint32_t base = lo;; base += 64) {
         const uint32_t r = base + ((lane - base) & 63u);   // lane == r mod 64
@@ -666,7 +677,9 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
             row_costs(s1, s2, x0, x1, re == p + 1 /* rs.region().end <= hap_len (astar_phaser.rs:101) */, acc);
             cx.ev32 += nkids;
             cx.cl32 += nkids * (p + 1 - max(rs, off));
-            ps1 = s1; ps2 = s2; px0 = x0; px1 = x1;   // a lane has one live row unless the variant is VAR_NOFAST
+            // seed the incremental state (a lane has one live row per tile unless the variant is VAR_NOFAST)
+            if (TILES == 2 && cx.tiles == 2u && (r & 64u)) { fs.s1b = s1; fs.s2b = s2; cc.x0b = x0; cc.x1b = x1; }
+            else { fs.s1a = s1; fs.s2a = s2; cc.x0a = x0; cc.x1a = x1; }
         }
         if (base != lo) cx.flush();   // > 64 candidate rows (rare): keep the 32-bit counters far from wrapping
         if (!__all(started)) break;   // a lane ran past the last candidate: no further tile
@@ -678,14 +691,11 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
     expand_finish(e, cur, bad, h_next, sum, kd);
 }
 
-// The same expansion when (fs1, fs2) already hold, per lane, the scores of cur's haplotype prefix against the lane's
-// row (see above): one coalesced 256-byte read of the cell table row of p replaces the row metadata and plane words.
-template <bool PROF>
-DEVINL void expand_fast(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, bool bad, uint64_t h_next, Pools& pl,
-                        Kids& kd, WaveCounters& wc, uint32_t& fs1, uint32_t& fs2, uint32_t& px0, uint32_t& px1) {
-    const uint32_t cell = cx.ctab[((size_t)p << 6) + lane_id()];
-    const ExpPre e = expand_begin(cur, off, p, bad, pl);
-    seg_stamp<PROF>(wc, 1);
+// The same expansion when `fs` already holds, per lane, the scores of cur's haplotype prefix against the lane's row(s)
+// (see above): one coalesced 256-byte read per tile of the cell table row of p replaces the row metadata and plane
+// words. Blocks with up to 64 candidate rows per variant use one tile, others two (row index mod 128).
+DEVINL void fast_tile(Ctx& cx, uint32_t cell, uint32_t p, uint32_t off, bool bad, uint32_t nkids, uint32_t& fs1, uint32_t& fs2,
+                      uint32_t& px0, uint32_t& px1, uint32_t (&acc)[8]) {
     const bool valid = (cell & CELL_VALID) != 0;
     const uint32_t t = cell >> CELL_T_SHIFT;          // p - row start (saturated): 0 = the row starts here
     if (t == 0) { fs1 = 0; fs2 = 0; }
@@ -693,13 +703,26 @@ DEVINL void expand_fast(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, bool 
     const uint32_t x0 = (valid && !bad && ap != 0u) ? qp : 0u;
     const uint32_t x1 = (valid && !bad && ap != 1u) ? qp : 0u;
     const uint32_t s1 = valid ? fs1 : 0u, s2 = valid ? fs2 : 0u;
-    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     row_costs(s1, s2, x0, x1, (cell & CELL_ENDS) != 0, acc);
     if (valid) {
-        cx.ev32 += e.nkids;
-        cx.cl32 += e.nkids * (min(t, p - off) + 1u);    // == p + 1 - max(row start, off)
+        cx.ev32 += nkids;
+        cx.cl32 += nkids * (min(t, p - off) + 1u);    // == p + 1 - max(row start, off)
     }
     px0 = x0; px1 = x1;
+}
+template <bool PROF, int TILES>
+DEVINL void expand_fast(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, bool bad, uint64_t h_next, Pools& pl,
+                        Kids& kd, WaveCounters& wc, FastState& fs, CellCost& cc) {
+    const bool two = TILES == 2 && cx.tiles == 2u;   // TILES: what the launch supports, cx.tiles: this block's table
+    const uint32_t* row = cx.ctab + ((size_t)p << (two ? 7 : 6)) + lane_id();
+    const uint32_t cell_a = row[0];
+    const uint32_t cell_b = two ? row[64] : 0u;
+    const ExpPre e = expand_begin(cur, off, p, bad, pl);
+    seg_stamp<PROF>(wc, 1);
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    fast_tile(cx, cell_a, p, off, bad, e.nkids, fs.s1a, fs.s2a, cc.x0a, cc.x1a, acc);
+    if (two) fast_tile(cx, cell_b, p, off, bad, e.nkids, fs.s1b, fs.s2b, cc.x0b, cc.x1b, acc);
+    else if (TILES == 2) { cc.x0b = 0; cc.x1b = 0; }
     seg_stamp<PROF>(wc, 2);
     uint32_t sum[8];
     wave_sum8(acc, sum);
@@ -719,7 +742,7 @@ DEVINL void ringV_set(uint32_t x, uint32_t lo, uint32_t flags) {  // rows per bl
     if (lane_id() == 0) reinterpret_cast<uint32_t*>(hp_smem + LDS_VRING_OFF)[x & 63u] = lo | (flags << 28);
 }
 // astar_subsolver (astar_phaser.rs:311-405). Returns status; outputs (max_cost_so_far, farthest).
-template <bool SUB_LDS, bool PROF>
+template <bool SUB_LDS, bool PROF, int TILES>
 DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t ps, SubHeap<SUB_LDS>& heap,
                         Pools& pl, WaveCounters& wc, uint64_t& est, uint32_t& solved) {
     heap.reset();
@@ -735,7 +758,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
     // expansion kept in registers; the root has scored nothing yet, so it starts valid (all zero)
     const bool fast_ok = cx.ctab != nullptr;
     bool fast_valid = fast_ok;
-    uint32_t fs1 = 0, fs2 = 0;
+    FastState fs{0, 0, 0, 0};
     while (cur.depth < ps && visited < max_visits) {
         visited += 1;
         wc.sub_pops += 1;
@@ -750,10 +773,10 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         const uint32_t low = bcast32(rv), lo = low & 0x0FFFFFFFu, flags = low >> 28;
         Kids kd;
         seg_stamp<PROF>(wc, 0);       // [0] loop head + LDS ring reads
-        uint32_t x0, x1;
+        CellCost cc;
         const bool collide = (flags & VAR_NOFAST) != 0;   // two rows of this variant on one lane: plane-word path only
-        if (fast_valid && !collide) expand_fast<PROF>(cx, cur, off, p, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs1, fs2, x0, x1);
-        else expand<PROF>(cx, cur, off, p, lo, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs1, fs2, x0, x1);
+        if (fast_valid && !collide) expand_fast<PROF, TILES>(cx, cur, off, p, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs, cc);
+        else expand<PROF, TILES>(cx, cur, off, p, lo, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs, cc);
         wc.nodes += kd.n;
         if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
         if (kd.bad && kid_total<0>(kd) != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
@@ -779,10 +802,10 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         if (take_child) {
             if (ksecond != ~0ull) heap.deal(ksecond);
             // slots (a1,a2): 0 = (0,1), 1 = (1,0), 2 = (0,0), 3 = (1,1); the kept child's own cell joins the prefix scores
-            if (k0 == kbest) { cur = kid_as_cur<0>(kd, next_idx); fs1 += x0; fs2 += x1; }
-            else if (k1 == kbest) { cur = kid_as_cur<1>(kd, next_idx); fs1 += x1; fs2 += x0; }
-            else if (k2 == kbest) { cur = kid_as_cur<2>(kd, next_idx); fs1 += x0; fs2 += x0; }
-            else { cur = kid_as_cur<3>(kd, next_idx); fs1 += x1; fs2 += x1; }
+            if (k0 == kbest) { cur = kid_as_cur<0>(kd, next_idx); fast_apply<TILES>(fs, cc, false, true); }
+            else if (k1 == kbest) { cur = kid_as_cur<1>(kd, next_idx); fast_apply<TILES>(fs, cc, true, false); }
+            else if (k2 == kbest) { cur = kid_as_cur<2>(kd, next_idx); fast_apply<TILES>(fs, cc, false, false); }
+            else { cur = kid_as_cur<3>(kd, next_idx); fast_apply<TILES>(fs, cc, true, true); }
             fast_valid = fast_ok && !collide;
         } else {
             // the queue's minimum t is a child of an earlier expansion: rebuild it from its family record, and put
@@ -827,7 +850,7 @@ struct HeurResult {
 };
 
 // calculate_astar_heuristic (astar_phaser.rs:246-292): the chain of N sub-solves, i.e. ~97 % of a block's work.
-template <bool SUB_LDS, bool PROF>
+template <bool SUB_LDS, bool PROF, int TILES>
 DEVINL HeurResult heuristic_phase(const BatchDev& B, uint32_t blk, uint32_t slot, WaveCounters& wc) {
     const SolveParams& prm = B.prm;
     const BlockDesc d = B.desc[blk];
@@ -841,6 +864,7 @@ DEVINL HeurResult heuristic_phase(const BatchDev& B, uint32_t blk, uint32_t slot
     cx.words = B.words + d.word_off * WORD_DWORDS;
     cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
     cx.n_rows = d.n_reads;
+    cx.tiles = d.ctab_shift == 7u ? 2u : 1u;
     cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
     uint64_t* H = B.H + d.h_off;
     Pools subp;
@@ -871,7 +895,7 @@ DEVINL HeurResult heuristic_phase(const BatchDev& B, uint32_t blk, uint32_t slot
             ringV_set(v, l, fl);
             uint64_t est = 0;
             uint32_t solved = 0;
-            st = subsolve<SUB_LDS, PROF>(cx, prm, v, clip, sub, subp, wc, est, solved);
+            st = subsolve<SUB_LDS, PROF, TILES>(cx, prm, v, clip, sub, subp, wc, est, solved);
             if (st != ST_OK) break;
             if (solved < min(clip, 2u)) { st = ST_INVARIANT; break; }  // astar_phaser.rs:268
             const bool bad = (fl & HP_VAR_IGNORED) != 0;
@@ -910,6 +934,7 @@ DEVINL HeurResult heuristic_phase(const BatchDev& B, uint32_t blk, uint32_t slot
 // astar_solver's main pruned search + emission (astar_phaser.rs:451-633) for a block whose H[] is complete.
 // (Tried as a real, non-inlined call to keep its state out of the sub-solver loop's register allocation: the
 // heuristic chain got 3 % faster, the main search 2.5x slower through its stack frame - a net loss.)
+template <int TILES>
 DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResult hr) {
     const SolveParams& prm = B.prm;
     const BlockDesc d = B.desc[blk];
@@ -923,6 +948,7 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
     cx.words = B.words + d.word_off * WORD_DWORDS;
     cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
     cx.n_rows = d.n_reads;
+    cx.tiles = d.ctab_shift == 7u ? 2u : 1u;
     cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
     uint64_t* H = B.H + d.h_off;
     Pools mainp;
@@ -968,7 +994,7 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
         // incremental scoring as in the sub-solver (see expand_fast): the root has scored nothing yet
         const bool fast_ok = cx.ctab != nullptr;
         bool fast_valid = fast_ok;
-        uint32_t fs1 = 0, fs2 = 0;
+        FastState fs{0, 0, 0, 0};
 
         while (cur.depth < N) {
             wc.main_pops += 1;
@@ -994,10 +1020,10 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
             if (lane == 0) { fl = vflags[p]; l = vlo[p]; hn = H[p + 1]; }
             fl = bcast32(fl); l = bcast32(l); h = bcast32(h); hn = bcast64(hn);
             Kids kd;
-            uint32_t x0, x1;
+            CellCost cc;
             const bool collide = (fl & VAR_NOFAST) != 0;
-            if (fast_valid && !collide) expand_fast<false>(cx, cur, 0, p, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, fs1, fs2, x0, x1);
-            else expand<false>(cx, cur, 0, p, l, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, fs1, fs2, x0, x1);
+            if (fast_valid && !collide) expand_fast<false, TILES>(cx, cur, 0, p, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, fs, cc);
+            else expand<false, TILES>(cx, cur, 0, p, l, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, fs, cc);
             cx.flush();
             wc.nodes += kd.n;
             if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; break; }
@@ -1038,10 +1064,10 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
                 }
             }
             if (key_less(kbest, hq.top)) {
-                if (best == 0) { cur = kid_as_cur<0>(kd, next_idx); fs1 += x0; fs2 += x1; }
-                else if (best == 1) { cur = kid_as_cur<1>(kd, next_idx); fs1 += x1; fs2 += x0; }
-                else if (best == 2) { cur = kid_as_cur<2>(kd, next_idx); fs1 += x0; fs2 += x0; }
-                else { cur = kid_as_cur<3>(kd, next_idx); fs1 += x1; fs2 += x1; }
+                if (best == 0) { cur = kid_as_cur<0>(kd, next_idx); fast_apply<TILES>(fs, cc, false, true); }
+                else if (best == 1) { cur = kid_as_cur<1>(kd, next_idx); fast_apply<TILES>(fs, cc, true, false); }
+                else if (best == 2) { cur = kid_as_cur<2>(kd, next_idx); fast_apply<TILES>(fs, cc, false, false); }
+                else { cur = kid_as_cur<3>(kd, next_idx); fast_apply<TILES>(fs, cc, true, true); }
                 cur.total = kbest.hi >> 24;
                 fast_valid = fast_ok && !collide;
             } else {
@@ -1122,11 +1148,11 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
     }
 }
 
-template <bool SUB_LDS, bool PROF>
+template <bool SUB_LDS, bool PROF, int TILES>
 DEVINL void solve_block(const BatchDev& B, uint32_t blk, uint32_t slot) {
     WaveCounters wc{0, 0, 0, {0, 0, 0, 0, 0, 0}, 0};
-    const HeurResult hr = heuristic_phase<SUB_LDS, PROF>(B, blk, slot, wc);
-    main_phase(B, blk, slot, hr);
+    const HeurResult hr = heuristic_phase<SUB_LDS, PROF, TILES>(B, blk, slot, wc);
+    main_phase<TILES>(B, blk, slot, hr);
     if (PROF && lane_id() == 0) {  // segment profile: pack 6 x 32-bit kilo-cycle counters over the cycle fields
         hp_work_counters* c = B.counters + blk;
         c->reserved[0] = (wc.seg[0] >> 10) | ((wc.seg[1] >> 10) << 32);
@@ -1145,7 +1171,7 @@ struct SegBatchDev {
     SegOut* out;
 };
 
-template <bool SUB_LDS>
+template <bool SUB_LDS, int TILES>
 DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
     const BatchDev& B = S.B;
     const SolveParams& prm = B.prm;
@@ -1161,6 +1187,7 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
     cx.words = B.words + d.word_off * WORD_DWORDS;
     cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
     cx.n_rows = d.n_reads;
+    cx.tiles = d.ctab_shift == 7u ? 2u : 1u;
     cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
     uint64_t* H = B.H + d.h_off;
     Pools subp;
@@ -1192,7 +1219,7 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
         ringV_set(v, l, fl);
         uint64_t est = 0;
         uint32_t solved = 0;
-        st = subsolve<SUB_LDS, false>(cx, prm, v, clip, sub, subp, wc, est, solved);
+        st = subsolve<SUB_LDS, false, TILES>(cx, prm, v, clip, sub, subp, wc, est, solved);
         if (st != ST_OK) break;
         if (solved < min(clip, 2u)) { st = ST_INVARIANT; break; }
         const bool bad = (fl & HP_VAR_IGNORED) != 0;
@@ -1225,17 +1252,18 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
 
 // OCC = waves per SIMD the register allocation targets. 6 (80 VGPRs, a few spills) measured equal or faster than
 // the spill-free 4 on every workload tried (throughput batches, a single block, the heavy-tailed mix).
-template <bool SUB_LDS, int OCC>
+template <bool SUB_LDS, int OCC, int TILES>
 __global__ void __launch_bounds__(64, OCC) hp_heur_seg_kernel(SegBatchDev S) {
     const uint32_t slot = blockIdx.x, G = gridDim.x;
     for (uint32_t round = 0;; ++round) {
         const uint32_t base = round * G;
         if (base >= S.n_segs) break;
         const uint32_t i = base + ((round & 1u) ? (G - 1u - slot) : slot);
-        if (i < S.n_segs) solve_segment<SUB_LDS>(S, S.seg_order[i], slot);
+        if (i < S.n_segs) solve_segment<SUB_LDS, TILES>(S, S.seg_order[i], slot);
     }
 }
-template __global__ void hp_heur_seg_kernel<true, 6>(SegBatchDev);
+template __global__ void hp_heur_seg_kernel<true, 6, 1>(SegBatchDev);
+template __global__ void hp_heur_seg_kernel<true, 6, 2>(SegBatchDev);
 
 // Seam verification + offsets, one thread per segmented block (segments of a block are consecutive, bottom first).
 struct StitchDev {
@@ -1386,7 +1414,8 @@ __global__ void __launch_bounds__(256) hp_build_ctab_kernel(CtabDev T) {
     const BlockDesc d = T.desc[T.row_block[row]];
     if (d.cell_off == ~0ull) return;
     const uint32_t rs = T.rstart[row], re = T.rend[row];
-    const uint32_t entry = (uint32_t)(row - d.read_off) & 63u;
+    const uint32_t sh = d.ctab_shift;   // entries per variant: 64 or 128
+    const uint32_t entry = (uint32_t)(row - d.read_off) & ((1u << sh) - 1u);
     const uint32_t* w0 = T.words + ((size_t)d.word_off + T.rword[row]) * WORD_DWORDS;
     uint32_t* tab = T.ctab + d.cell_off;
     for (uint32_t p = rs + (threadIdx.x & 63u); p < re; p += 64) {
@@ -1397,12 +1426,14 @@ __global__ void __launch_bounds__(256) hp_build_ctab_kernel(CtabDev T) {
         uint32_t q = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) q |= ((w[2 + k] >> b) & 1u) << k;
-        tab[((size_t)p << 6) + entry] = q | (a << 8) | (p + 1 == re ? CELL_ENDS : 0u) | CELL_VALID |
+        tab[((size_t)p << sh) + entry] = q | (a << 8) | (p + 1 == re ? CELL_ENDS : 0u) | CELL_VALID |
                                         (min(p - rs, CELL_T_MAX) << CELL_T_SHIFT);
     }
 }
 
-template <bool SUB_LDS, int OCC, bool PROF>
+// TILES = 64-row tiles of the per-position cell table the launch supports (2 costs two more VGPRs per lane and is
+// only used when some block of the launch has more than 64 candidate rows per variant)
+template <bool SUB_LDS, int OCC, bool PROF, int TILES>
 __global__ void __launch_bounds__(64, OCC) hp_astar_kernel(BatchDev B) {
     const uint32_t slot = blockIdx.x;
     const uint32_t G = gridDim.x;
@@ -1412,12 +1443,13 @@ __global__ void __launch_bounds__(64, OCC) hp_astar_kernel(BatchDev B) {
         const uint32_t base = round * G;
         if (base >= B.n_items) break;
         const uint32_t i = base + ((round & 1u) ? (G - 1u - slot) : slot);
-        if (i < B.n_items) solve_block<SUB_LDS, PROF>(B, B.order[i], slot);
+        if (i < B.n_items) solve_block<SUB_LDS, PROF, TILES>(B, B.order[i], slot);
     }
 }
 
-template __global__ void hp_astar_kernel<true, 6, false>(BatchDev);
-template __global__ void hp_astar_kernel<true, 6, true>(BatchDev);    // HP_SEG_PROFILE=1
-template __global__ void hp_astar_kernel<false, 4, false>(BatchDev);
+template __global__ void hp_astar_kernel<true, 6, false, 1>(BatchDev);
+template __global__ void hp_astar_kernel<true, 6, false, 2>(BatchDev);
+template __global__ void hp_astar_kernel<true, 6, true, 1>(BatchDev);    // HP_SEG_PROFILE=1
+template __global__ void hp_astar_kernel<false, 4, false, 2>(BatchDev);
 
 }  // namespace hp
