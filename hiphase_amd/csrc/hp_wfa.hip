@@ -366,8 +366,9 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     if ((rc = d_sets.alloc(pk.out_set_words * 4 + 16)) || (rc = d_score.alloc(n * 8)) || (rc = d_status.alloc(n * 4))) return rc;
     std::vector<int32_t> st0(n, WFA_ST_PENDING);
     HP_HIP_CHECK(hipMemcpy(d_status.p, st0.data(), n * 4, hipMemcpyHostToDevice));
-    const size_t lds = (size_t)pk.max_nodes * WFA_NODE_STATE_BYTES;
-    uint32_t per_cu = (uint32_t)std::min<size_t>(12, (160 * 1024) / std::max<size_t>(lds, 1024));
+    const uint32_t lds_nodes_off = (uint32_t)(((size_t)pk.max_nodes * WFA_NODE_STATE_BYTES + 15) & ~(size_t)15);
+    const size_t lds = (size_t)lds_nodes_off + (size_t)pk.max_nodes * 32;
+    uint32_t per_cu = (uint32_t)std::min<size_t>(12, (160 * 1024) / std::max<size_t>((lds + 1279) / 1280 * 1280, 1280));
     if (per_cu == 0) per_cu = 1;
     size_t free_b = 0, total_b = 0;
     HP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
@@ -392,6 +393,7 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     B.nodes = d_nodes.as<WfaNode>(); B.edges = d_edges.as<WfaEdge>(); B.seq = d_seq.as<uint8_t>();
     B.out_sets = d_sets.as<uint32_t>(); B.out_score = d_score.as<uint64_t>(); B.status = d_status.as<int32_t>();
     B.scratch = g_ctx.scratch.as<uint32_t>(); B.scratch_stride = stride; B.prune_distance = prune; B.max_ed = max_ed;
+    B.lds_nodes_off = lds_nodes_off;
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa launch jobs=%zu band=%u slots=%u lds=%zu scratch/slot=%zu B\n", n, band, slots, lds, per_slot); fflush(stderr); }
     hipEvent_t e0, e1;
     HP_HIP_CHECK(hipEventCreate(&e0));

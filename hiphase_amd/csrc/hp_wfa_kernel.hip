@@ -64,22 +64,20 @@ WDEV uint64_t ld8(const uint8_t* p) {
 }
 
 // Length of the common prefix of a[0..maxlen) and b[0..maxlen) for every lane (maxlen == 0 for idle lanes).
-// Phase 1: each lane compares up to 64 bytes, 8 at a time. Phase 2: lanes that are still matching are served
-// one after the other by the whole wave, 512 bytes per step (coalesced 8-byte loads + ballot).
-// Buffers are padded so that reading 8 bytes at any in-range position is legal.
+// Phase 1: every lane compares its first 16 bytes in ONE memory round trip (four independent 8-byte loads) - a
+// diagonal that is not the alignment's own mismatches within a base or two, so this settles almost every lane.
+// Phase 2: lanes that are still matching are served one after the other by the whole wave, 512 bytes per step
+// (coalesced 8-byte loads + ballot). Buffers are padded so that reading 16 bytes at any in-range position is legal.
 WDEV uint32_t match_run(const uint8_t* a, const uint8_t* b, uint32_t maxlen) {
     uint32_t n = 0;
     bool done = (maxlen == 0);
-#pragma unroll 1
-    for (int it = 0; it < 8; ++it) {
-        if (!__any(!done)) break;
+    if (__any(!done)) {
         if (!done) {
-            const uint64_t x = ld8(a + n) ^ ld8(b + n);
-            const uint32_t rem = maxlen - n;
-            uint32_t m = x ? ((uint32_t)__builtin_ctzll(x) >> 3) : 8u;
-            if (m > rem) m = rem;
-            n += m;
-            if (m < 8 || n >= maxlen) done = true;
+            const uint64_t x0 = ld8(a) ^ ld8(b), x1 = ld8(a + 8) ^ ld8(b + 8);
+            uint32_t m = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : (x1 ? 8u + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16u);
+            if (m > maxlen) m = maxlen;
+            n = m;
+            if (m < 16 || n >= maxlen) done = true;
         }
     }
     uint64_t pending = __ballot(!done);
@@ -123,13 +121,11 @@ struct WfaNodeU {  // uniform copy of a WfaNode
     uint32_t seq_off, seq_len, child_off, n_children, n_parents, width, entry_off, entry_stride;
     int32_t dbase;
 };
+// The job's node table is copied into LDS once (solve_job): a node lookup is then a broadcast LDS read instead of a
+// dependent HBM round trip at the head of every (round, node) step.
 WDEV WfaNodeU load_node(const WfaNode* p) {
-    uint4 a = make_uint4(0, 0, 0, 0), b = a;
-    if (wlane() == 0) {
-        const uint4* s = reinterpret_cast<const uint4*>(p);
-        a = s[0];
-        b = s[1];
-    }
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+    const uint4 a = s[0], b = s[1];   // every lane reads the same address
     WfaNodeU u;
     u.seq_off = wb32(a.x);
     u.seq_len = wb32(a.y);
@@ -148,16 +144,20 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
     const uint32_t lane = wlane();
     const WfaJobDesc jd = B.jobs[job];
     const uint32_t n_nodes = jd.n_nodes, W = jd.set_words;
-    const WfaNode* nodes = B.nodes + jd.node_off;
+    const WfaNode* gnodes = B.nodes + jd.node_off;
     const WfaEdge* edges = B.edges + jd.edge_off;
     const uint8_t* seq = B.seq + jd.seq_off;
     const uint8_t* read = seq + jd.read_off;
     const uint32_t other_len = jd.read_len;
     uint32_t* scr = B.scratch + (size_t)slot * B.scratch_stride;
     NodeState* ns = reinterpret_cast<NodeState*>(wfa_smem);
+    WfaNode* nodes = reinterpret_cast<WfaNode*>(wfa_smem + (size_t)B.lds_nodes_off);
     uint32_t* out_set = B.out_sets + jd.out_set_off;
 
     for (uint32_t i = lane; i < n_nodes; i += 64) ns[i] = NodeState{{HULL_EMPTY, HULL_EMPTY}, {0xFFFFFFFFu, 0xFFFFFFFFu}, HULL_EMPTY, HULL_EMPTY};
+    for (uint32_t i = lane; i < n_nodes * 2; i += 64)   // 32-byte node entries as 16-byte halves
+        reinterpret_cast<uint4*>(nodes)[i] = reinterpret_cast<const uint4*>(gnodes)[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (lane == 0) for (uint32_t w = 0; w < W; ++w) out_set[w] = 0;
 
     int32_t status = WFA_ST_PENDING;
