@@ -2,8 +2,64 @@
 #include "hp_common.h"
 
 #include <cstdlib>
+#include <map>
 
 namespace hp {
+namespace {
+// see hp_common.h: size classes = next power of two up to 1 MiB, then multiples of 1 MiB (so a re-run of a similar
+// batch finds its blocks again); at most 8 GiB per thread stay cached, single blocks above 2 GiB never do.
+struct DevCache {
+    std::multimap<std::pair<int, size_t>, void*> free_;   // (device, bytes) -> block
+    size_t cached = 0;
+    static constexpr size_t kMaxCached = 8ull << 30, kMaxBlock = 2ull << 30;
+    static size_t round_up(size_t n) {
+        if (n <= (1u << 20)) { size_t r = 256; while (r < n) r <<= 1; return r; }
+        return (n + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    }
+    ~DevCache() { for (auto& kv : free_) (void)hipFree(kv.second); }
+};
+thread_local DevCache g_dev_cache;
+}  // namespace
+
+void* dev_cache_get(size_t bytes, size_t* got) {
+    const size_t want = DevCache::round_up(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    DevCache& c = g_dev_cache;
+    auto it = c.free_.lower_bound({dev, want});
+    if (it != c.free_.end() && it->first.first == dev && it->first.second <= want + want / 4) {
+        void* p = it->second;
+        *got = it->first.second;
+        c.cached -= it->first.second;
+        c.free_.erase(it);
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess && !c.free_.empty()) {   // give the cache back and try once more
+        for (auto& kv : c.free_) (void)hipFree(kv.second);
+        c.free_.clear();
+        c.cached = 0;
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return nullptr; }
+    *got = want;
+    return p;
+}
+
+void dev_cache_put(void* p, size_t bytes) {
+    DevCache& c = g_dev_cache;
+    int dev = 0;
+    if (bytes > DevCache::kMaxBlock || c.cached + bytes > DevCache::kMaxCached || hipGetDevice(&dev) != hipSuccess) {
+        (void)hipFree(p);
+        return;
+    }
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
+    c.free_.insert({{dev, bytes}, p});
+    c.cached += bytes;
+}
+
 static thread_local std::string g_err;
 thread_local double g_last_kernel_ms = 0.0;
 void set_error(const char* fmt, ...) {

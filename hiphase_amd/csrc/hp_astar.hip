@@ -232,6 +232,9 @@ struct hp_batch {
 
     ~hp_batch() {
         (void)hipSetDevice(device);
+        // the device buffers go back to the per-thread cache (hp_common.h), not to hipFree: nothing may still use them
+        if (stream2) (void)hipStreamSynchronize(stream2);
+        if (stream) (void)hipStreamSynchronize(stream);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev_fork) (void)hipEventDestroy(ev_fork);

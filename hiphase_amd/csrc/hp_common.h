@@ -22,6 +22,13 @@ extern thread_local double g_last_kernel_ms;  // see hp_last_kernel_ms()  // thr
         }                                                                                          \
     } while (0)
 
+// Per-thread cache of device allocations: every entry point allocates a couple of dozen buffers per call, and
+// hipMalloc / hipFree cost ~100 us each and synchronise the device. Blocks are handed back to the cache instead of
+// being freed and re-used by later calls of the same thread on the same device (sizes are rounded up so that they
+// match); the cache is bounded and released at thread exit. hp_common.h declares, hp_api.hip defines.
+void* dev_cache_get(size_t bytes, size_t* got);       // nullptr on failure (error set)
+void dev_cache_put(void* p, size_t bytes);
+
 // RAII device buffer
 struct DevBuf {
     void* p = nullptr;
@@ -31,7 +38,7 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) dev_cache_put(p, bytes);
         p = nullptr;
         bytes = 0;
     }
@@ -40,8 +47,8 @@ struct DevBuf {
         if (n == 0) n = 16;
         if (p && bytes >= n) return HP_OK;
         release();
-        HP_HIP_CHECK(hipMalloc(&p, n));
-        bytes = n;
+        p = dev_cache_get(n, &bytes);
+        if (!p) { bytes = 0; return HP_ERR_OOM; }
         return HP_OK;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
