@@ -1,6 +1,7 @@
 // hp_api.hip — misc entry points of the C ABI (errors, device discovery, version).
 #include "hp_common.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <map>
 
@@ -45,6 +46,17 @@ void* dev_cache_get(size_t bytes, size_t* got) {
     if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return nullptr; }
     *got = want;
     return p;
+}
+
+int device_cu_count(int device_id) {
+    static std::atomic<int> cached[64];
+    if (device_id < 0 || device_id >= 64) return 256;
+    int v = cached[device_id].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cached[device_id].store(v, std::memory_order_relaxed);
+    return v;
 }
 
 void dev_cache_put(void* p, size_t bytes) {

@@ -195,6 +195,48 @@ template <class T> int upload(DevBuf& buf, const std::vector<T>& v, hipStream_t 
 
 using namespace hp;
 
+// Streams and events of a batch come from a per-thread pool (creating two streams and four events costs milliseconds,
+// which matters when a caller solves one small block per call).
+struct StreamSet {
+    int device = -1;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    bool create(int dev) {
+        device = dev;
+        // the segment stream carries the critical path: a high-priority stream also gets a hardware queue of its own
+        // (streams of equal priority may share one when the host process has created many, e.g. under PyTorch)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        return hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+               hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+               hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess &&
+               hipEventCreate(&ev_fork) == hipSuccess && hipEventCreate(&ev_join) == hipSuccess;
+    }
+    void destroy() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (stream2) (void)hipStreamDestroy(stream2);
+        if (stream) (void)hipStreamDestroy(stream);
+        *this = StreamSet{};
+    }
+};
+struct StreamPool {
+    std::vector<StreamSet> free_;
+    ~StreamPool() { for (auto& s : free_) s.destroy(); }
+    bool get(int dev, StreamSet& out) {
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].device == dev) { out = free_[i]; free_.erase(free_.begin() + i); return true; }
+        return out.create(dev);
+    }
+    void put(StreamSet& s) {
+        if (free_.size() < 8) free_.push_back(s); else s.destroy();
+        s = StreamSet{};
+    }
+};
+thread_local StreamPool g_stream_pool;
+
 struct hp_batch {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -235,12 +277,9 @@ struct hp_batch {
         // the device buffers go back to the per-thread cache (hp_common.h), not to hipFree: nothing may still use them
         if (stream2) (void)hipStreamSynchronize(stream2);
         if (stream) (void)hipStreamSynchronize(stream);
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (stream2) (void)hipStreamDestroy(stream2);
-        if (stream) (void)hipStreamDestroy(stream);
+        StreamSet ss;
+        ss.device = device; ss.stream = stream; ss.stream2 = stream2; ss.ev0 = ev0; ss.ev1 = ev1; ss.ev_fork = ev_fork; ss.ev_join = ev_join;
+        if (stream && stream2 && ev0 && ev1 && ev_fork && ev_join) g_stream_pool.put(ss); else ss.destroy();
     }
 };
 
@@ -485,16 +524,13 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     b->caller_row_off = hpk.caller_row_off;
     b->caller_rows = hpk.caller_rows;
     b->n_rows_packed = hpk.row_block.size();
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) b->n_cu = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(HP_ERR_HIP); }
-    if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { set_error("hipEventCreate failed"); return fail(HP_ERR_HIP); }
-    // the segment stream carries the critical path: a high-priority stream also gets a hardware queue of its own
-    // (streams of equal priority may share one when the host process has created many, e.g. under PyTorch)
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (hipStreamCreateWithPriority(&b->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess || hipEventCreate(&b->ev_fork) != hipSuccess ||
-        hipEventCreate(&b->ev_join) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(HP_ERR_HIP); }
+    b->n_cu = device_cu_count(device_id);
+    {
+        StreamSet ss;
+        const bool ok = g_stream_pool.get(device_id, ss);
+        b->stream = ss.stream; b->stream2 = ss.stream2; b->ev0 = ss.ev0; b->ev1 = ss.ev1; b->ev_fork = ss.ev_fork; b->ev_join = ss.ev_join;
+        if (!ok) { set_error("creating the streams/events of a batch failed"); return fail(HP_ERR_HIP); }
+    }
 
     SolveParams& prm = b->prm;
     prm.minq_main = (uint32_t)p->min_queue_size;
@@ -724,14 +760,20 @@ void hp_batch_destroy(hp_batch* b) { delete b; }
 static int solve_on_device(size_t n, const hp_block_view* blks, const hp_astar_params* p, uint8_t* const* h1,
                            uint8_t* const* h2, hp_phase_stats* out, int device_id) {
     int status = HP_OK;
+    const bool verbose = std::getenv("HP_DEBUG") != nullptr;
+    auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t0 = now();
     hp_batch* b = hp_batch_create(n, blks, p, device_id, &status);
     if (!b) return status;
     std::unique_ptr<hp_batch> guard(b);
+    const double t1 = now();
     int rc = hp_batch_solve(b, nullptr, nullptr);
     if (rc != HP_OK) return rc;
+    const double t2 = now();
     std::vector<uint8_t> a1(b->sum_n), a2(b->sum_n);
     rc = hp_batch_results(b, a1.data(), a2.data(), out, nullptr, nullptr);
     if (rc != HP_OK) return rc;
+    if (verbose) { fprintf(stderr, "[hp] solve_on_device: create %.2f ms, solve %.2f ms (kernel %.2f), results %.2f ms\n", t1 - t0, t2 - t1, g_last_kernel_ms, now() - t2); fflush(stderr); }
     for (size_t i = 0; i < n; ++i) {
         const BlockDesc& d = b->desc[i];
         if (h1 && h1[i]) std::memcpy(h1[i], a1.data() + d.var_off, d.n_vars);

@@ -29,6 +29,9 @@ extern thread_local double g_last_kernel_ms;  // see hp_last_kernel_ms()  // thr
 void* dev_cache_get(size_t bytes, size_t* got);       // nullptr on failure (error set)
 void dev_cache_put(void* p, size_t bytes);
 
+// number of compute units of a device, queried once (hipGetDeviceProperties costs milliseconds per call)
+int device_cu_count(int device_id);
+
 // RAII device buffer
 struct DevBuf {
     void* p = nullptr;

@@ -123,9 +123,7 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
     bytes.resize(bytes.size() + 16, 0);
     if (device_id < 0) device_id = hp_default_device();
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
-    int n_cu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) n_cu = prop.multiProcessorCount;
+    const int n_cu = device_cu_count(device_id);
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {

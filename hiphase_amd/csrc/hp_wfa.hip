@@ -472,9 +472,7 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
     // host-side work is done; from here on a GPU is mandatory (no CPU fallback)
     if (device_id < 0) device_id = hp_default_device();
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
-    int n_cu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) n_cu = prop.multiProcessorCount;
+    const int n_cu = device_cu_count(device_id);
 
     std::vector<int32_t> status(n, WFA_ST_PENDING);
     std::vector<uint64_t> score(n, 0);
