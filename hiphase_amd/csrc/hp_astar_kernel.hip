@@ -58,10 +58,13 @@ DEVINL uint32_t add_xor4(uint32_t v) {
     return v + up + dn;
 }
 
-// Sum of 8 per-lane values over the 64 lanes -> 8 uniform results. Transpose-butterfly: three halving
-// exchanges (lane^1, lane^2, lane^8) leave one value per lane (index = b0*4 + b1*2 + b3), one more exchange
-// (lane^4) completes the 16-lane row, and the four rows are combined through v_readlane into SGPRs.
-DEVINL void wave_sum8(const uint32_t (&a)[8], uint32_t (&out)[8]) {
+// Sum of 8 per-lane values over the 64 lanes. Transpose-butterfly: three halving exchanges (lane^1, lane^2, lane^8)
+// leave one value per lane (index = b0*4 + b1*2 + b3 of the lane number), one more exchange (lane^4) completes the
+// 16-lane row, and the four rows are folded with the gfx950 row/half swaps (v_permlane16_swap: odd rows of the first
+// operand <-> even rows of the second; v_permlane32_swap: upper half <-> lower half). Result: EVERY lane l holds the
+// total of value j(l) = (l & 1) * 4 + ((l >> 1) & 1) * 2 + ((l >> 3) & 1); SUM8_LANE(j) is the lowest such lane.
+#define SUM8_LANE(j) ((((j) >> 2) & 1) | ((((j) >> 1) & 1) << 1) | (((j) & 1) << 3))
+DEVINL uint32_t wave_sum8(const uint32_t (&a)[8]) {
     const uint32_t lane = lane_id();
     const bool b0 = (lane & 1u) != 0, b1 = (lane & 2u) != 0, b3 = (lane & 8u) != 0;
     uint32_t b[4], c[2];
@@ -78,18 +81,10 @@ DEVINL void wave_sum8(const uint32_t (&a)[8], uint32_t (&out)[8]) {
     const uint32_t keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
     const uint32_t d = keep + dpp<0x128>(send);
     const uint32_t e = add_xor4(d);
-    // the four 16-lane rows are folded with the gfx950 row/half swaps (v_permlane16_swap: odd rows of the first
-    // operand <-> even rows of the second; v_permlane32_swap: upper half <-> lower half), leaving the total in
-    // every lane
     const auto r16 = __builtin_amdgcn_permlane16_swap(e, e, false, false);
     const uint32_t f = r16[0] + r16[1];
     const auto r32 = __builtin_amdgcn_permlane32_swap(f, f, false, false);
-    const uint32_t g = r32[0] + r32[1];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int L = (j >> 2) | (((j >> 1) & 1) << 1) | ((j & 1) << 3);
-        out[j] = rdlane(g, L);
-    }
+    return r32[0] + r32[1];
 }
 DEVINL uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
@@ -108,6 +103,14 @@ DEVINL uint64_t wave_min_u64(uint64_t v) {
     v = umin64(v, dpp64<0x141>(v));
     v = umin64(v, dpp64<0x140>(v));
     return umin64(umin64(rdlane64(v, 0), rdlane64(v, 16)), umin64(rdlane64(v, 32), rdlane64(v, 48)));
+}
+
+// minimum over the four slot groups of the wave_sum8 lane layout (lane ^ 2 and lane ^ 8 exchanges): every lane ends
+// up with the minimum of the four distinct per-slot values
+DEVINL uint64_t lane_min4(uint64_t v) {
+    v = umin64(v, dpp64<0x4E>(v));
+    v = umin64(v, dpp64<0x128>(v));
+    return v;
 }
 
 // ---- keys ------------------------------------------------------------------------------------------------
@@ -455,6 +458,7 @@ struct Kids {
     uint32_t depth, anc1, anc2, hets_het, hets_hom;
     uint32_t sumF0, sumF1, sumF2, sumF3;   // frozen increments (what the family record keeps)
     uint32_t sumT0, sumT1, sumT2, sumT3;   // frozen + fluid increments
+    uint32_t tvec;         // PER LANE: lane l holds the frozen + fluid increment of slot ((l >> 1) & 1) * 2 + ((l >> 3) & 1)
     Win base, w1;          // base = parent's window in the child's chunk (fresh when a new chunk opens)
     uint32_t bit;          // 1 << (p & 31)
 };
@@ -553,7 +557,7 @@ DEVINL ExpPre expand_begin(const Cur& cur, uint32_t off, uint32_t p, bool bad, P
     e.nkids = bad ? 1u : (cur.hets != 0 ? 4u : 3u);
     return e;
 }
-DEVINL void expand_finish(const ExpPre& e, const Cur& cur, bool bad, uint64_t h_next, const uint32_t (&sum)[8], Kids& kd) {
+DEVINL void expand_finish(const ExpPre& e, const Cur& cur, bool bad, uint64_t h_next, uint32_t g, Kids& kd) {
     kd.bad = bad;
     kd.has1 = !bad && cur.hets != 0;
     kd.n = e.nkids;
@@ -565,8 +569,10 @@ DEVINL void expand_finish(const ExpPre& e, const Cur& cur, bool bad, uint64_t h_
     kd.bit = 1u << e.bp;
     kd.hets_het = cur.hets + 1;
     kd.hets_hom = cur.hets;
-    kd.sumF0 = sum[0]; kd.sumF1 = sum[1]; kd.sumF2 = sum[2]; kd.sumF3 = sum[3];
-    kd.sumT0 = sum[0] + sum[4]; kd.sumT1 = sum[1] + sum[5]; kd.sumT2 = sum[2] + sum[6]; kd.sumT3 = sum[3] + sum[7];
+    // g (wave_sum8): even lanes hold the frozen sum of their slot, the odd neighbour its fluid sum
+    kd.tvec = g + dpp<0xB1>(g);
+    kd.sumF0 = rdlane(g, SUM8_LANE(0)); kd.sumF1 = rdlane(g, SUM8_LANE(1)); kd.sumF2 = rdlane(g, SUM8_LANE(2)); kd.sumF3 = rdlane(g, SUM8_LANE(3));
+    kd.sumT0 = rdlane(kd.tvec, SUM8_LANE(0)); kd.sumT1 = rdlane(kd.tvec, SUM8_LANE(1)); kd.sumT2 = rdlane(kd.tvec, SUM8_LANE(2)); kd.sumT3 = rdlane(kd.tvec, SUM8_LANE(3));
     kd.pfrozen = cur.frozen;
     kd.tbase = cur.frozen + h_next;
 }
@@ -685,10 +691,9 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
         if (!__all(started)) break;   // a lane ran past the last candidate: no further tile
     }
     seg_stamp<PROF>(wc, 2);       // [2] plane-word loads + bit-sliced scoring
-    uint32_t sum[8];
-    wave_sum8(acc, sum);
+    const uint32_t g = wave_sum8(acc);
     seg_stamp<PROF>(wc, 3);       // [3] wave reduction
-    expand_finish(e, cur, bad, h_next, sum, kd);
+    expand_finish(e, cur, bad, h_next, g, kd);
 }
 
 // The same expansion when `fs` already holds, per lane, the scores of cur's haplotype prefix against the lane's row(s)
@@ -724,10 +729,9 @@ DEVINL void expand_fast(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, bool 
     if (two) fast_tile(cx, cell_b, p, off, bad, e.nkids, fs.s1b, fs.s2b, cc.x0b, cc.x1b, acc);
     else if (TILES == 2) { cc.x0b = 0; cc.x1b = 0; }
     seg_stamp<PROF>(wc, 2);
-    uint32_t sum[8];
-    wave_sum8(acc, sum);
+    const uint32_t g = wave_sum8(acc);
     seg_stamp<PROF>(wc, 3);
-    expand_finish(e, cur, bad, h_next, sum, kd);
+    expand_finish(e, cur, bad, h_next, g, kd);
 }
 
 // LDS rings, indexed by (variant & 63): H[x] and the per-variant (lo, hi, flags) triple. Written by lane 0, read by
@@ -780,20 +784,23 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         wc.nodes += kd.n;
         if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
         if (kd.bad && kid_total<0>(kd) != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
-        // keys of the (up to 4) children; invalid slots get the infinite key. make_subkey(total, hets, idx, rank, depth)
-        // with total = tbase + sumT<slot> is linear in its fields (they do not overlap), so the shared part is
-        // built once:  key = kc + (sumT << 28) + rank * 257 - (het slot ? 1 << 22 : 0)
+        // Keys of the (up to 4) children, one slot per lane group, on the vector ALU: the scalar unit is the busier of
+        // the two pipes in this loop (measured: an extra scalar instruction per pop costs four times an extra vector
+        // one), and lane l already holds the cost sum of slot s(l) = ((l >> 1) & 1) * 2 + ((l >> 3) & 1).
+        // make_subkey(total, hets, idx, rank, depth) with total = tbase + sumT<slot> is linear in its fields (they do
+        // not overlap):  key = kc + (sumT << 28) + rank * 257 - (het slot ? 1 << 22 : 0); invalid slots: ~0.
         const uint64_t kc = make_subkey(kd.tbase, kd.hets_hom, next_idx, 0u, kd.depth);
-        const uint64_t khet = kd.bad ? 0ull : (1ull << 22);   // slots 0/1 of a real expansion carry one more het
-        const uint32_t rk2 = kd.has1 ? 2u : 1u;
-        const uint64_t k0 = kc + ((uint64_t)kd.sumT0 << 28) - khet;
-        const uint64_t k1 = kid_valid<1>(kd) ? kc + ((uint64_t)kd.sumT1 << 28) + 257ull - khet : ~0ull;
-        const uint64_t k2 = kid_valid<2>(kd) ? kc + ((uint64_t)kd.sumT2 << 28) + 257ull * rk2 : ~0ull;
-        const uint64_t k3 = kid_valid<3>(kd) ? kc + ((uint64_t)kd.sumT3 << 28) + 257ull * (rk2 + 1u) : ~0ull;
-        const uint64_t kbest = umin64(umin64(k0, k1), umin64(k2, k3));
+        const uint32_t lslot = ((lane_id() >> 1) & 1u) * 2u + ((lane_id() >> 3) & 1u);
+        const uint32_t lrank = lslot - ((lslot >= 2u && !kd.has1) ? 1u : 0u);
+        const bool lvalid = lslot == 0u || (!kd.bad && (lslot != 1u || kd.has1));
+        uint64_t kl = kc + ((uint64_t)kd.tvec << 28) + (uint64_t)(lrank * 257u);
+        if (lslot < 2u && !kd.bad) kl -= (1ull << 22);   // slots 0/1 of a real expansion carry one more het
+        kl = lvalid ? kl : ~0ull;
+        const uint64_t kbest = bcast64(lane_min4(kl));
         // the family's next key should kbest leave it: its smallest other child (~0: none)
-        const uint64_t ksecond = umin64(umin64(k0 == kbest ? ~0ull : k0, k1 == kbest ? ~0ull : k1),
-                                        umin64(k2 == kbest ? ~0ull : k2, k3 == kbest ? ~0ull : k3));
+        const uint64_t ksecond = bcast64(lane_min4(kl == kbest ? ~0ull : kl));
+        const uint32_t best_lane = (uint32_t)__builtin_ctzll(__ballot(kl == kbest));   // lowest lane of the best slot
+        const uint32_t best = ((best_lane >> 1) & 1u) * 2u + ((best_lane >> 3) & 1u);
         // If the best child beats everything queued it is the next pop: keep it in registers (push + pop elided;
         // the priority is a total order, so this is exactly what the reference's queue would return).
         const bool take_child = kbest < heap.top;
@@ -802,9 +809,9 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         if (take_child) {
             if (ksecond != ~0ull) heap.deal(ksecond);
             // slots (a1,a2): 0 = (0,1), 1 = (1,0), 2 = (0,0), 3 = (1,1); the kept child's own cell joins the prefix scores
-            if (k0 == kbest) { cur = kid_as_cur<0>(kd, next_idx); fast_apply<TILES>(fs, cc, false, true); }
-            else if (k1 == kbest) { cur = kid_as_cur<1>(kd, next_idx); fast_apply<TILES>(fs, cc, true, false); }
-            else if (k2 == kbest) { cur = kid_as_cur<2>(kd, next_idx); fast_apply<TILES>(fs, cc, false, false); }
+            if (best == 0u) { cur = kid_as_cur<0>(kd, next_idx); fast_apply<TILES>(fs, cc, false, true); }
+            else if (best == 1u) { cur = kid_as_cur<1>(kd, next_idx); fast_apply<TILES>(fs, cc, true, false); }
+            else if (best == 2u) { cur = kid_as_cur<2>(kd, next_idx); fast_apply<TILES>(fs, cc, false, false); }
             else { cur = kid_as_cur<3>(kd, next_idx); fast_apply<TILES>(fs, cc, true, true); }
             fast_valid = fast_ok && !collide;
         } else {
