@@ -141,6 +141,19 @@ DEVINL uint64_t subkey_total(uint64_t k) { return k >> 28; }
 DEVINL uint32_t subkey_idx(uint64_t k) { return (uint32_t)(k >> 8) & 0x3FFFu; }
 DEVINL uint32_t subkey_rank(uint64_t k) { return (uint32_t)k & 3u; }
 DEVINL uint32_t subkey_depth(uint64_t k) { return (uint32_t)(k >> 2) & 63u; }
+// The key of the child in slot `lslot` (a per-lane value) of an expansion, computed entirely on the vector ALU:
+// sumT = the lane's frozen + fluid increment of that slot; slots that do not exist get ~0.
+//   slot 0 = (0,1)  1 = (1,0) [only if the parent's haplotypes differ]  2 = (0,0)  3 = (1,1);  ignored variant: slot 0 only
+DEVINL uint64_t lane_subkey(uint32_t lslot, bool bad, bool has1, uint64_t tbase, uint32_t sumT, uint32_t hets_hom,
+                            uint32_t first_idx, uint32_t depth) {
+    const uint32_t lrank = lslot - ((lslot >= 2u && !has1) ? 1u : 0u);          // creation rank among the siblings
+    const bool lvalid = lslot == 0u || (!bad && (lslot != 1u || has1));
+    const uint32_t lhets = hets_hom + ((lslot < 2u && !bad) ? 1u : 0u);
+    const uint64_t total = tbase + sumT;
+    const uint32_t low = ((63u - lhets) << 22) | ((first_idx + lrank) << 8) | (depth << 2) | lrank;   // < 2^28
+    const uint64_t k = (total << 28) | low;
+    return lvalid ? k : ~0ull;
+}
 
 // ---- record I/O: lane 0 writes, lane 0 reads, broadcast (same-lane rule) ---------------------------------------
 DEVINL void store_chunk(ChunkRec* dst, const Win& w0, const Win& w1, uint32_t anc2) {
@@ -765,7 +778,6 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
     FastState fs{0, 0, 0, 0};
     while (cur.depth < ps && visited < max_visits) {
         visited += 1;
-        wc.sub_pops += 1;
         if (cur.depth == next_expected) {
             max_cost = max(max_cost, cur.total);
             next_expected += 1;
@@ -781,21 +793,13 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         const bool collide = (flags & VAR_NOFAST) != 0;   // two rows of this variant on one lane: plane-word path only
         if (fast_valid && !collide) expand_fast<PROF, TILES>(cx, cur, off, p, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs, cc);
         else expand<PROF, TILES>(cx, cur, off, p, lo, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs, cc);
-        wc.nodes += kd.n;
         if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
         if (kd.bad && kid_total<0>(kd) != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
         // Keys of the (up to 4) children, one slot per lane group, on the vector ALU: the scalar unit is the busier of
         // the two pipes in this loop (measured: an extra scalar instruction per pop costs four times an extra vector
         // one), and lane l already holds the cost sum of slot s(l) = ((l >> 1) & 1) * 2 + ((l >> 3) & 1).
-        // make_subkey(total, hets, idx, rank, depth) with total = tbase + sumT<slot> is linear in its fields (they do
-        // not overlap):  key = kc + (sumT << 28) + rank * 257 - (het slot ? 1 << 22 : 0); invalid slots: ~0.
-        const uint64_t kc = make_subkey(kd.tbase, kd.hets_hom, next_idx, 0u, kd.depth);
         const uint32_t lslot = ((lane_id() >> 1) & 1u) * 2u + ((lane_id() >> 3) & 1u);
-        const uint32_t lrank = lslot - ((lslot >= 2u && !kd.has1) ? 1u : 0u);
-        const bool lvalid = lslot == 0u || (!kd.bad && (lslot != 1u || kd.has1));
-        uint64_t kl = kc + ((uint64_t)kd.tvec << 28) + (uint64_t)(lrank * 257u);
-        if (lslot < 2u && !kd.bad) kl -= (1ull << 22);   // slots 0/1 of a real expansion carry one more het
-        kl = lvalid ? kl : ~0ull;
+        const uint64_t kl = lane_subkey(lslot, kd.bad, kd.has1, kd.tbase, kd.tvec, kd.hets_hom, next_idx, kd.depth);
         const uint64_t kbest = bcast64(lane_min4(kl));
         // the family's next key should kbest leave it: its smallest other child (~0: none)
         const uint64_t ksecond = bcast64(lane_min4(kl == kbest ? ~0ull : kl));
@@ -823,14 +827,10 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
             const uint64_t hn_t = ringH_get(off + subkey_depth(t));
             const bool fbad = (fr.depth_flags >> 30) & 1u, fhas1 = (fr.depth_flags >> 31) & 1u;
             const uint32_t fdepth = (fr.depth_flags & 0xFFFFFFu) + 1u;
-            const uint32_t r2 = fhas1 ? 2u : 1u, r3 = fhas1 ? 3u : 2u;
-            const uint64_t fb = fr.frozen + hn_t;
-            const uint64_t s0 = make_subkey(fb + fr.tot[0], fbad ? fr.hets : fr.hets + 1u, fbase, 0u, fdepth);
-            const uint64_t s1 = (!fbad && fhas1) ? make_subkey(fb + fr.tot[1], fr.hets + 1u, fbase + 1u, 1u, fdepth) : ~0ull;
-            const uint64_t s2 = !fbad ? make_subkey(fb + fr.tot[2], fr.hets, fbase + r2, r2, fdepth) : ~0ull;
-            const uint64_t s3 = !fbad ? make_subkey(fb + fr.tot[3], fr.hets, fbase + r3, r3, fdepth) : ~0ull;
-            const uint64_t knext = umin64(umin64(s0 > t ? s0 : ~0ull, s1 > t ? s1 : ~0ull),
-                                          umin64(s2 > t ? s2 : ~0ull, s3 > t ? s3 : ~0ull));
+            // the siblings' keys, again one slot per lane group: each lane fetches its slot's cost sum from the record
+            const uint32_t ftot = reinterpret_cast<const uint32_t*>(pl.fam + fbase)[16 + lslot];   // FamRec::tot[lslot]
+            const uint64_t sk = lane_subkey(lslot, fbad, fhas1, fr.frozen + hn_t, ftot, fr.hets, fbase, fdepth);
+            const uint64_t knext = bcast64(lane_min4(sk > t ? sk : ~0ull));
             heap.replace_push(kbest, knext);
             cur = cur_from_fam(fr, subkey_rank(t), subkey_total(t), subkey_idx(t), off);
             fast_valid = false;   // a queued node: its prefix scores are rebuilt from the plane words
@@ -845,6 +845,8 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
     }
     est = max_cost;
     solved = next_expected - 1;
+    wc.sub_pops += visited;        // the work counters advance once per sub-solve, not once per pop
+    wc.nodes += next_idx - 1;      // children created (node_index 0 is the root)
     cx.flush();
     return st;
 }
