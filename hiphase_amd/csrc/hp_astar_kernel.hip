@@ -113,6 +113,32 @@ DEVINL uint64_t lane_min4(uint64_t v) {
     return v;
 }
 
+// minimum of a u64 over the wave, left in EVERY lane (no scalar instructions): rows by DPP, then the gfx950 row / half
+// swaps. `opaque()` hides from the compiler that a value is wave-uniform, so that what is computed from it stays on
+// the vector ALU (the scalar unit is the bottleneck of the sub-solver loop).
+DEVINL uint64_t wave_min_u64_v(uint64_t v) {
+    v = umin64(v, dpp64<0xB1>(v));
+    v = umin64(v, dpp64<0x4E>(v));
+    v = umin64(v, dpp64<0x141>(v));
+    v = umin64(v, dpp64<0x140>(v));
+    {
+        const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)v, (uint32_t)v, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(v >> 32), (uint32_t)(v >> 32), false, false);
+        v = umin64(((uint64_t)hi[0] << 32) | lo[0], ((uint64_t)hi[1] << 32) | lo[1]);
+    }
+    {
+        const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)v, (uint32_t)v, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(v >> 32), (uint32_t)(v >> 32), false, false);
+        v = umin64(((uint64_t)hi[0] << 32) | lo[0], ((uint64_t)hi[1] << 32) | lo[1]);
+    }
+    return v;
+}
+DEVINL uint64_t opaque(uint64_t x) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // ---- keys ------------------------------------------------------------------------------------------------
 DEVINL bool key_less(const Key& a, const Key& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
 DEVINL Key key_inf() { return Key{~0ull, ~0ull}; }
@@ -198,8 +224,8 @@ template <bool LDS> struct SubHeap {
     uint64_t* gbase;    // used when !LDS
     uint32_t jcap;      // per-lane capacity
     uint32_t cnt;       // per lane
-    uint64_t top;       // uniform cache of the global minimum (~0 when empty)
-    uint32_t top_lane;  // uniform
+    uint64_t top;       // cache of the global minimum (~0 when empty): wave-uniform, but kept in vector registers
+    uint32_t top_lane;  // its owner lane, likewise
     uint32_t ovf;       // per lane
     uint32_t dealt;     // uniform: keys pushed so far (round-robin target lane)
     DEVINL uint64_t ld(uint32_t j) const {
@@ -210,7 +236,7 @@ template <bool LDS> struct SubHeap {
         if (LDS) reinterpret_cast<uint64_t*>(hp_smem + LDS_HEAP_OFF)[j * 64 + lane_id()] = k;
         else gbase[(size_t)j * 64 + lane_id()] = k;
     }
-    DEVINL void reset() { cnt = 0; top = ~0ull; top_lane = 0; dealt = 0; }
+    DEVINL void reset() { cnt = 0; top = opaque(~0ull); top_lane = 0; dealt = 0; }
     // The queue holds one key per family (expansion) that still has an unpopped child. Keys are dealt to the lanes
     // round-robin by push order (uniform counter `dealt`); every visit deals at most one key, so a lane never
     // holds more than ceil(max_visits / 64) entries.
@@ -249,7 +275,7 @@ template <bool LDS> struct SubHeap {
             st(i, ka);
         }
         const uint64_t root = cnt > 0 ? ld(0) : ~0ull;
-        top = wave_min_u64(root);
+        top = wave_min_u64_v(root);
         const uint64_t who = __ballot(cnt > 0 && root == top);
         top_lane = who ? (uint32_t)__builtin_ctzll(who) : 0u;
         if (kb != ~0ull) deal(kb);
@@ -768,7 +794,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
     uint32_t next_idx = 1;
     Cur cur = root_node(ringH_get(off + 1));  // initial_estimate = H[off+1] (astar_phaser.rs:322)
     uint32_t next_expected = 0, visited = 0;
-    uint64_t max_cost = 0;
+    uint64_t max_cost = opaque(0);   // wave-uniform, updated on the vector ALU
     const uint32_t max_visits = prm.minq_sub + prm.qinc * ps;
     int32_t st = ST_OK;
     // (fs1, fs2): per-lane scores of cur's prefix against the lane's row, valid while cur is the child the previous
@@ -807,7 +833,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         const uint32_t best = ((best_lane >> 1) & 1u) * 2u + ((best_lane >> 3) & 1u);
         // If the best child beats everything queued it is the next pop: keep it in registers (push + pop elided;
         // the priority is a total order, so this is exactly what the reference's queue would return).
-        const bool take_child = kbest < heap.top;
+        const bool take_child = __any(kbest < heap.top);   // heap.top lives in vector registers (uniform value)
         seg_stamp<PROF>(wc, 4);   // [4] child totals + keys
         fam_store(pl.fam, kd, cur, next_idx);  // one record for all siblings
         if (take_child) {
@@ -821,7 +847,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         } else {
             // the queue's minimum t is a child of an earlier expansion: rebuild it from its family record, and put
             // that family's next child (the smallest sibling key above t) back in the queue together with kbest
-            const uint64_t t = heap.top;
+            const uint64_t t = bcast64(heap.top);
             const uint32_t fbase = subkey_idx(t) - subkey_rank(t);
             const FamRec fr = load_fam(pl.fam + fbase);
             const uint64_t hn_t = ringH_get(off + subkey_depth(t));
@@ -837,13 +863,15 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         }
         next_idx += kd.n;
         seg_stamp<PROF>(wc, 5);   // [5] record store + heap pushes (+ pop on the slow path)
-        if (__any(heap.ovf) || pl.ovf) { st = ST_OVERFLOW; break; }
     }
+    // the heap and the chunk pool never write past their capacity (they drop the item and raise a sticky flag), so
+    // the flags are looked at once per sub-solve; the host's sizing makes them unreachable anyway
+    if (st == ST_OK && (__any(heap.ovf) || pl.ovf)) st = ST_OVERFLOW;
     if (cur.depth == ps) {  // astar_phaser.rs:395-399 (peek, not pop)
         max_cost = max(max_cost, cur.total);
         next_expected += 1;
     }
-    est = max_cost;
+    est = bcast64(max_cost);
     solved = next_expected - 1;
     wc.sub_pops += visited;        // the work counters advance once per sub-solve, not once per pop
     wc.nodes += next_idx - 1;      // children created (node_index 0 is the root)
