@@ -498,6 +498,7 @@ struct Kids {
     uint32_t sumF0, sumF1, sumF2, sumF3;   // frozen increments (what the family record keeps)
     uint32_t sumT0, sumT1, sumT2, sumT3;   // frozen + fluid increments
     uint32_t tvec;         // PER LANE: lane l holds the frozen + fluid increment of slot ((l >> 1) & 1) * 2 + ((l >> 3) & 1)
+    uint32_t gvec;         // PER LANE: wave_sum8's result (even lanes: the frozen increment of the lane's slot)
     Win base, w1;          // base = parent's window in the child's chunk (fresh when a new chunk opens)
     uint32_t bit;          // 1 << (p & 31)
 };
@@ -524,6 +525,31 @@ template <int S> DEVINL Cur kid_as_cur(const Kids& k, uint64_t next_idx) {
     n.depth = k.depth; n.hets = kid_hets<S>(k); n.anc1 = k.anc1; n.anc2 = k.anc2;
     n.w0 = kid_win<S>(k); n.w1 = k.w1;
     return n;
+}
+// ... the same minus the two cost fields (the sub-solver takes those from the key / the lane vector)
+template <int S> DEVINL void kid_into_cur(const Kids& k, uint64_t next_idx, Cur& n) {
+    n.idx = next_idx + kid_rank<S>(k);
+    n.depth = k.depth; n.hets = kid_hets<S>(k); n.anc1 = k.anc1; n.anc2 = k.anc2;
+    n.w0 = kid_win<S>(k); n.w1 = k.w1;
+}
+// Sub-solver form of fam_store: lane 0 writes the 48 bytes the siblings share, the four even lanes that hold the
+// slots' sums (wave_sum8 layout) write sumF[slot] / tot[slot] themselves - no trip through scalar registers.
+DEVINL void fam_store_lanes(FamRec* fam, const Kids& k, const Cur& parent, uint32_t next_idx) {
+    const uint32_t lane = lane_id();
+    FamRec* rec = fam + next_idx;
+    if (lane == 0) {
+        uint4* d = reinterpret_cast<uint4*>(rec);
+        d[0] = make_uint4((uint32_t)parent.frozen, (uint32_t)(parent.frozen >> 32),
+                          parent.depth | (k.bad ? (1u << 30) : 0u) | (k.has1 ? (1u << 31) : 0u), parent.hets);
+        d[1] = make_uint4(k.anc1, k.anc2, k.base.h1, k.base.h2);
+        d[2] = make_uint4(k.base.nv, k.w1.h1, k.w1.h2, k.w1.nv);
+    }
+    if ((lane & ~10u) == 0u) {   // lanes 0, 2, 8, 10
+        const uint32_t slot = ((lane >> 1) & 1u) * 2u + ((lane >> 3) & 1u);
+        uint32_t* w = reinterpret_cast<uint32_t*>(rec);
+        w[12 + slot] = k.gvec;   // FamRec::sumF[slot]
+        w[16 + slot] = k.tvec;   // FamRec::tot[slot]
+    }
 }
 // one 80-byte family record per expansion, written by lane 0 at fam[node_index of the first child]
 DEVINL void fam_store(FamRec* fam, const Kids& k, const Cur& parent, uint32_t next_idx) {
@@ -610,6 +636,7 @@ DEVINL void expand_finish(const ExpPre& e, const Cur& cur, bool bad, uint64_t h_
     kd.hets_hom = cur.hets;
     // g (wave_sum8): even lanes hold the frozen sum of their slot, the odd neighbour its fluid sum
     kd.tvec = g + dpp<0xB1>(g);
+    kd.gvec = g;
     kd.sumF0 = rdlane(g, SUM8_LANE(0)); kd.sumF1 = rdlane(g, SUM8_LANE(1)); kd.sumF2 = rdlane(g, SUM8_LANE(2)); kd.sumF3 = rdlane(g, SUM8_LANE(3));
     kd.sumT0 = rdlane(kd.tvec, SUM8_LANE(0)); kd.sumT1 = rdlane(kd.tvec, SUM8_LANE(1)); kd.sumT2 = rdlane(kd.tvec, SUM8_LANE(2)); kd.sumT3 = rdlane(kd.tvec, SUM8_LANE(3));
     kd.pfrozen = cur.frozen;
@@ -820,7 +847,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         if (fast_valid && !collide) expand_fast<PROF, TILES>(cx, cur, off, p, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs, cc);
         else expand<PROF, TILES>(cx, cur, off, p, lo, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs, cc);
         if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
-        if (kd.bad && kid_total<0>(kd) != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
+        if (kd.bad && kd.tbase + rdlane(kd.tvec, 0) != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
         // Keys of the (up to 4) children, one slot per lane group, on the vector ALU: the scalar unit is the busier of
         // the two pipes in this loop (measured: an extra scalar instruction per pop costs four times an extra vector
         // one), and lane l already holds the cost sum of slot s(l) = ((l >> 1) & 1) * 2 + ((l >> 3) & 1).
@@ -835,14 +862,16 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         // the priority is a total order, so this is exactly what the reference's queue would return).
         const bool take_child = __any(kbest < heap.top);   // heap.top lives in vector registers (uniform value)
         seg_stamp<PROF>(wc, 4);   // [4] child totals + keys
-        fam_store(pl.fam, kd, cur, next_idx);  // one record for all siblings
+        fam_store_lanes(pl.fam, kd, cur, next_idx);  // one record for all siblings
         if (take_child) {
             if (ksecond != ~0ull) heap.deal(ksecond);
             // slots (a1,a2): 0 = (0,1), 1 = (1,0), 2 = (0,0), 3 = (1,1); the kept child's own cell joins the prefix scores
-            if (best == 0u) { cur = kid_as_cur<0>(kd, next_idx); fast_apply<TILES>(fs, cc, false, true); }
-            else if (best == 1u) { cur = kid_as_cur<1>(kd, next_idx); fast_apply<TILES>(fs, cc, true, false); }
-            else if (best == 2u) { cur = kid_as_cur<2>(kd, next_idx); fast_apply<TILES>(fs, cc, false, false); }
-            else { cur = kid_as_cur<3>(kd, next_idx); fast_apply<TILES>(fs, cc, true, true); }
+            cur.frozen = kd.pfrozen + (uint32_t)__builtin_amdgcn_readlane((int)kd.gvec, (int)best_lane);   // best_lane is even
+            cur.total = subkey_total(kbest);
+            if (best == 0u) { kid_into_cur<0>(kd, next_idx, cur); fast_apply<TILES>(fs, cc, false, true); }
+            else if (best == 1u) { kid_into_cur<1>(kd, next_idx, cur); fast_apply<TILES>(fs, cc, true, false); }
+            else if (best == 2u) { kid_into_cur<2>(kd, next_idx, cur); fast_apply<TILES>(fs, cc, false, false); }
+            else { kid_into_cur<3>(kd, next_idx, cur); fast_apply<TILES>(fs, cc, true, true); }
             fast_valid = fast_ok && !collide;
         } else {
             // the queue's minimum t is a child of an earlier expansion: rebuild it from its family record, and put
