@@ -634,11 +634,14 @@ DEVINL void expand_finish(const ExpPre& e, const Cur& cur, bool bad, uint64_t h_
     kd.bit = 1u << e.bp;
     kd.hets_het = cur.hets + 1;
     kd.hets_hom = cur.hets;
-    // g (wave_sum8): even lanes hold the frozen sum of their slot, the odd neighbour its fluid sum
-    kd.tvec = g + dpp<0xB1>(g);
+    // g (wave_sum8): even lanes hold the frozen sum of their slot, the odd neighbour its frozen + fluid sum
+    uint32_t o = dpp<0xB1>(g);
+    asm volatile("" : "+v"(o));   // keep the lane exchange out of the select below: a DPP read under a partial EXEC
+                                  // mask sees the masked-off neighbours as zero
+    kd.tvec = (lane_id() & 1u) ? g : o;
     kd.gvec = g;
     kd.sumF0 = rdlane(g, SUM8_LANE(0)); kd.sumF1 = rdlane(g, SUM8_LANE(1)); kd.sumF2 = rdlane(g, SUM8_LANE(2)); kd.sumF3 = rdlane(g, SUM8_LANE(3));
-    kd.sumT0 = rdlane(kd.tvec, SUM8_LANE(0)); kd.sumT1 = rdlane(kd.tvec, SUM8_LANE(1)); kd.sumT2 = rdlane(kd.tvec, SUM8_LANE(2)); kd.sumT3 = rdlane(kd.tvec, SUM8_LANE(3));
+    kd.sumT0 = rdlane(g, SUM8_LANE(4)); kd.sumT1 = rdlane(g, SUM8_LANE(5)); kd.sumT2 = rdlane(g, SUM8_LANE(6)); kd.sumT3 = rdlane(g, SUM8_LANE(7));
     kd.pfrozen = cur.frozen;
     kd.tbase = cur.frozen + h_next;
 }
@@ -648,10 +651,11 @@ DEVINL void row_costs(uint32_t s1, uint32_t s2, uint32_t x0, uint32_t x1, bool f
     const uint32_t c1 = min(s1 + x1, s2 + x0);  // (1,0)
     const uint32_t c2 = min(s1 + x0, s2 + x0);  // (0,0)
     const uint32_t c3 = min(s1 + x1, s2 + x1);  // (1,1)
-    acc[0] += frozen ? c0 : 0u; acc[4] += frozen ? 0u : c0;
-    acc[1] += frozen ? c1 : 0u; acc[5] += frozen ? 0u : c1;
-    acc[2] += frozen ? c2 : 0u; acc[6] += frozen ? 0u : c2;
-    acc[3] += frozen ? c3 : 0u; acc[7] += frozen ? 0u : c3;
+    // [0..3] frozen part per slot (rows whose last cell is this one), [4..7] frozen + fluid per slot
+    acc[0] += frozen ? c0 : 0u; acc[4] += c0;
+    acc[1] += frozen ? c1 : 0u; acc[5] += c1;
+    acc[2] += frozen ? c2 : 0u; acc[6] += c2;
+    acc[3] += frozen ? c3 : 0u; acc[7] += c3;
 }
 
 // lo = first candidate row of variant p (rows are start-sorted; the candidates end with the last row whose start
@@ -666,7 +670,7 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
     const bool trans = e.trans;
     const Win W0 = e.W0, W1 = e.W1, W2 = e.W2;
     const uint32_t nkids = e.nkids;
-    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0..3] frozen per slot, [4..7] fluid per slot
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0..3] frozen per slot, [4..7] frozen + fluid per slot
     fs = FastState{0, 0, 0, 0};
     cc = CellCost{0, 0, 0, 0};
 
