@@ -147,7 +147,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     // per-position cell table (incremental scoring in the sub-solver); variants where two covering rows collide on
     // (row index mod 64) are flagged for the plane-word path. HP_NO_CTAB=1 switches the table off (A/B testing).
     const bool no_ctab = std::getenv("HP_NO_CTAB") != nullptr;
-    if (!no_ctab && max_row_len <= CELL_T_MAX) {   // the cell table stores (p - row start) in 20 bits
+    if (!no_ctab && max_row_len <= CELL_T_MAX) {   // the cell table stores (p - row start) in 14 bits
         // entries per variant (hp_astar_dev.h CELL_*): 64, unless that leaves more than 2 % of the variants with two
         // covering rows on one entry (high coverage), then 128
         auto collisions = [&](uint32_t ents, bool mark) {
@@ -578,6 +578,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
         T.desc = b->d_desc.as<BlockDesc>(); T.row_block = b->d_row_block.as<uint32_t>();
         T.rstart = b->d_rstart.as<uint32_t>(); T.rend = b->d_rend.as<uint32_t>(); T.rword = b->d_rword.as<uint32_t>();
         T.words = b->d_words.as<uint32_t>(); T.ctab = b->d_ctab.as<uint32_t>(); T.n_rows = hpk.row_block.size();
+        T.vflags = b->d_vflags.as<uint8_t>();
         hipLaunchKernelGGL(hp_build_ctab_kernel, dim3((unsigned)((T.n_rows + 3) / 4)), dim3(256), 0, s, T);
         if (hipGetLastError() != hipSuccess) { set_error("hp_build_ctab_kernel launch failed"); return fail(HP_ERR_HIP); }
     }

@@ -46,9 +46,10 @@ constexpr uint8_t VAR_NOFAST = 0x4;
 // blocks with at most 64 candidate rows per variant (max_cov), else 128; entry (row index mod E) describes that
 // row's cell at p (lane = entry & 63, tile = entry >> 6). Variants where two covering rows would share an entry
 // carry VAR_NOFAST and are handled by the plane-word path.
-//   bits 0-7 qual | 8-9 allele (NoOverlap stored as Ambiguous: both mismatch 0 and 1, and NoOverlap has qual 0) |
-//   10 row ends here (end == p+1) | 11 valid (row covers p) | 12-31 min(p - row start, 2^20-1)
-constexpr uint32_t CELL_ENDS = 1u << 10, CELL_VALID = 1u << 11, CELL_T_SHIFT = 12, CELL_T_MAX = (1u << 20) - 1;
+//   bits 0-7 x0 = cost of giving a haplotype allele 0 at p against this row ((allele != 0) ? qual : 0) | 8-15 x1 =
+//   the same for allele 1 (both 0 for an ignored variant: astar_phaser.rs:348-364 scores nothing there) |
+//   16 row ends here (end == p+1) | 17 valid (row covers p) | 18-31 min(p - row start, 2^14-1)
+constexpr uint32_t CELL_ENDS = 1u << 16, CELL_VALID = 1u << 17, CELL_T_SHIFT = 18, CELL_T_MAX = (1u << 14) - 1;
 
 // Priority key (astar_phaser.rs:131-133): min total cost, then MORE hets, then OLDER node.
 //   hi = cost << 24 | (0xFFFFFF - num_hets)      cost < 2^40 (sum of all quals of a block < 2^40)

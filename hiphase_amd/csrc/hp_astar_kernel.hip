@@ -769,14 +769,12 @@ DEVINL void expand(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, uint32_t l
 // The same expansion when `fs` already holds, per lane, the scores of cur's haplotype prefix against the lane's row(s)
 // (see above): one coalesced 256-byte read per tile of the cell table row of p replaces the row metadata and plane
 // words. Blocks with up to 64 candidate rows per variant use one tile, others two (row index mod 128).
-DEVINL void fast_tile(Ctx& cx, uint32_t cell, uint32_t p, uint32_t off, bool bad, uint32_t nkids, uint32_t& fs1, uint32_t& fs2,
+DEVINL void fast_tile(Ctx& cx, uint32_t cell, uint32_t p, uint32_t off, uint32_t nkids, uint32_t& fs1, uint32_t& fs2,
                       uint32_t& px0, uint32_t& px1, uint32_t (&acc)[8]) {
     const bool valid = (cell & CELL_VALID) != 0;
     const uint32_t t = cell >> CELL_T_SHIFT;          // p - row start (saturated): 0 = the row starts here
     if (t == 0) { fs1 = 0; fs2 = 0; }
-    const uint32_t ap = (cell >> 8) & 3u, qp = cell & 0xFFu;
-    const uint32_t x0 = (valid && !bad && ap != 0u) ? qp : 0u;
-    const uint32_t x1 = (valid && !bad && ap != 1u) ? qp : 0u;
+    const uint32_t x0 = cell & 0xFFu, x1 = (cell >> 8) & 0xFFu;   // both 0 for an empty entry or an ignored variant
     const uint32_t s1 = valid ? fs1 : 0u, s2 = valid ? fs2 : 0u;
     row_costs(s1, s2, x0, x1, (cell & CELL_ENDS) != 0, acc);
     if (valid) {
@@ -795,8 +793,8 @@ DEVINL void expand_fast(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, bool 
     const ExpPre e = expand_begin(cur, off, p, bad, pl);
     seg_stamp<PROF>(wc, 1);
     uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    fast_tile(cx, cell_a, p, off, bad, e.nkids, fs.s1a, fs.s2a, cc.x0a, cc.x1a, acc);
-    if (two) fast_tile(cx, cell_b, p, off, bad, e.nkids, fs.s1b, fs.s2b, cc.x0b, cc.x1b, acc);
+    fast_tile(cx, cell_a, p, off, e.nkids, fs.s1a, fs.s2a, cc.x0a, cc.x1a, acc);
+    if (two) fast_tile(cx, cell_b, p, off, e.nkids, fs.s1b, fs.s2b, cc.x0b, cc.x1b, acc);
     else if (TILES == 2) { cc.x0b = 0; cc.x1b = 0; }
     seg_stamp<PROF>(wc, 2);
     const uint32_t g = wave_sum8(acc);
@@ -1475,6 +1473,7 @@ struct CtabDev {
     const uint32_t* row_block;            // packed row -> block
     const uint32_t *rstart, *rend, *rword;
     const uint32_t* words;
+    const uint8_t* vflags;
     uint32_t* ctab;
     uint64_t n_rows;
 };
@@ -1491,13 +1490,14 @@ __global__ void __launch_bounds__(256) hp_build_ctab_kernel(CtabDev T) {
     for (uint32_t p = rs + (threadIdx.x & 63u); p < re; p += 64) {
         const uint32_t* w = w0 + (size_t)((p >> 5) - (rs >> 5)) * WORD_DWORDS;
         const uint32_t b = p & 31u;
-        uint32_t a = ((w[0] >> b) & 1u) | (((w[1] >> b) & 1u) << 1);
-        if (a == 3u) a = 2u;
+        const uint32_t a = ((w[0] >> b) & 1u) | (((w[1] >> b) & 1u) << 1);
         uint32_t q = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) q |= ((w[2 + k] >> b) & 1u) << k;
-        tab[((size_t)p << sh) + entry] = q | (a << 8) | (p + 1 == re ? CELL_ENDS : 0u) | CELL_VALID |
-                                        (min(p - rs, CELL_T_MAX) << CELL_T_SHIFT);
+        if (T.vflags[d.var_off + p] & HP_VAR_IGNORED) q = 0;
+        const uint32_t x0 = a != 0u ? q : 0u, x1 = a != 1u ? q : 0u;
+        tab[((size_t)p << sh) + entry] = x0 | (x1 << 8) | (p + 1 == re ? CELL_ENDS : 0u) | CELL_VALID |
+                                         (min(p - rs, CELL_T_MAX) << CELL_T_SHIFT);
     }
 }
 
