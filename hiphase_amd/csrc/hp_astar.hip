@@ -330,7 +330,7 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     const uint32_t slots = (uint32_t)std::min<uint64_t>(segs.size(), max_slots);
     SolveParams prm = b->prm;
     prm.pad0 = 0; prm.pad1 = 0;
-    const size_t sub_pool_bytes = (size_t)prm.cap_sub * sizeof(FamRec) + (size_t)prm.cap_chunk_sub * sizeof(ChunkRec);
+    const size_t sub_pool_bytes = sub_pool_bytes_per_slot(prm);
     int rc;
     if (b->s_seg_pool.bytes < (size_t)slots * sub_pool_bytes && (rc = b->s_seg_pool.alloc((size_t)slots * sub_pool_bytes)) != HP_OK) return rc;
     if ((rc = upload(b->d_segs, segs, st)) || (rc = upload(b->d_seg_order, order, st)) || (rc = upload(b->d_sb_first, sb_first, st)) ||
@@ -388,7 +388,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     if (per_cu == 0) per_cu = 1;
     prm.cap_chunk_main = cap_main / 4 + 64;
     const size_t main_pool_bytes = (size_t)cap_main * sizeof(FamRec) + (size_t)prm.cap_chunk_main * sizeof(ChunkRec);
-    const size_t sub_pool_bytes = (size_t)prm.cap_sub * sizeof(FamRec) + (size_t)prm.cap_chunk_sub * sizeof(ChunkRec);
+    const size_t sub_pool_bytes = sub_pool_bytes_per_slot(prm);
     const size_t per_slot = main_pool_bytes + (size_t)prm.jcap_main * 64 * sizeof(Key) + sub_pool_bytes + ((size_t)max_n + 1) * 4 +
                             (prm.sub_heap_in_lds ? 0 : (size_t)prm.jcap_sub * 64 * sizeof(uint64_t));
     size_t free_b = 0, total_b = 0;
@@ -542,6 +542,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     prm.jcap_sub = (uint32_t)((max_visits + 63) / 64);   // one key per family; <= 1 key per visit is dealt round-robin to the lanes (SubHeap::deal)
     prm.cap_chunk_sub = (uint32_t)max_visits + 8;   // at most one ChunkRec per expansion
     prm.sub_heap_in_lds = ((size_t)prm.jcap_sub * 64 * sizeof(uint64_t) <= LDS_SUB_HEAP_MAX_BYTES) ? 1 : 0;
+    prm.save_state = (b->tiles == 2) ? 1u : 0u;   // must match the TILES template argument of the launches (see subsolve)
     if (prm.cap_sub >= (1u << 14)) { set_error("min_queue_size/10 + queue_increment*max_segment_size = %llu visits exceeds the packed sub-key limit (4093)", (unsigned long long)max_visits); return fail(HP_ERR_UNSUPPORTED); }
 
     b->order.resize(n_blocks);

@@ -15,6 +15,7 @@
 //   h1/h2[sum N]      u8                haplotypes (output)
 //   stats/counters/status per block
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/hiphase_gpu.h"
@@ -105,8 +106,19 @@ struct SolveParams {
     uint32_t max_n_vars;  // largest N among the blocks of this launch (tracker stride)
     uint32_t pad0, pad1;  // bring-up / segment-profile switches
     uint32_t cap_chunk_sub, cap_chunk_main;  // ChunkRec capacities
-    uint32_t pad2, pad3;
+    uint32_t save_state;  // 1: the sub-solver pool has room for the per-expansion prefix scores (TILES == 2 launches)
+    uint32_t pad3;
 };
+
+// Per-slot scratch of the sub-solver: [cap_sub x FamRec | cap_chunk_sub x ChunkRec | cap_sub x 64 lanes x 16 B of
+// saved prefix scores (the incremental-scoring state of every expansion, so that a node popped from the queue
+// resumes on the cell-table path)]
+inline __host__ __device__ size_t sub_pool_vec_off(const SolveParams& prm) {
+    return ((size_t)prm.cap_sub * sizeof(FamRec) + (size_t)prm.cap_chunk_sub * sizeof(ChunkRec) + 15) & ~(size_t)15;
+}
+inline __host__ __device__ size_t sub_pool_bytes_per_slot(const SolveParams& prm) {
+    return sub_pool_vec_off(prm) + (prm.save_state ? (size_t)prm.cap_sub * 64 * 16 : 0);
+}
 
 // ---- segment-parallel heuristic (DESIGN.md §3.1 "speculative segments") --------------------------------------
 // The heuristic chain H[v] = f(H[v+1..v+40], clip) is sequential, but it forgets its start: a chain started cold
