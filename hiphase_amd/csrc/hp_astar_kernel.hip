@@ -855,7 +855,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         // starting here already reset) with the family: a sibling popped from the queue later resumes from it instead
         // of re-scoring two tiles of plane words. Measured: at coverage 60 that is +20 %, at coverage 30 the extra
         // 512 B written per pop cost more than the rebuilds they save (58 -> 51 M hets/s), hence the compile-time gate.
-        constexpr bool SAVE_STATE = TILES == 2;
+        const bool SAVE_STATE = TILES == 2 && prm.save_state != 0;   // the host sized the pool for it
         if (SAVE_STATE && fast_ok && !collide)
             pl.vec[(size_t)next_idx * 64 + lane_id()] = make_uint4(fs.s1a, fs.s2a, fs.s1b, fs.s2b);
         // Keys of the (up to 4) children, one slot per lane group, on the vector ALU: the scalar unit is the busier of
