@@ -849,7 +849,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         const bool collide = (flags & VAR_NOFAST) != 0;   // two rows of this variant on one lane: plane-word path only
         if (fast_valid && !collide) expand_fast<PROF, TILES>(cx, cur, off, p, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs, cc);
         else expand<PROF, TILES>(cx, cur, off, p, lo, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs, cc);
-        if (next_idx + kd.n > prm.cap_sub) { st = ST_OVERFLOW; break; }
+        // (no capacity check: next_idx <= 4 * visited + 1 <= 4 * max_visits + 1 == cap_sub, see hp_batch_create)
         if (kd.bad && kd.tbase + rdlane(kd.tvec, 0) != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
         // High-coverage launches (TILES == 2) keep the incremental state of every expansion (prefix scores of cur, rows
         // starting here already reset) with the family: a sibling popped from the queue later resumes from it instead
