@@ -278,7 +278,7 @@ template <bool LDS> struct SubHeap {
         top = wave_min_u64_v(root);
         const uint64_t who = __ballot(cnt > 0 && root == top);
         top_lane = who ? (uint32_t)__builtin_ctzll(who) : 0u;
-        if (kb != ~0ull) deal(kb);
+        if (__any(kb != ~0ull)) deal(kb);
     }
     DEVINL void pop() {  // removes the global minimum (caller copied `top` first)
         if (lane_id() == top_lane) {
@@ -865,7 +865,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         const uint64_t kl = lane_subkey(lslot, kd.bad, kd.has1, kd.tbase, kd.tvec, kd.hets_hom, next_idx, kd.depth);
         const uint64_t kbest = bcast64(lane_min4(kl));
         // the family's next key should kbest leave it: its smallest other child (~0: none)
-        const uint64_t ksecond = bcast64(lane_min4(kl == kbest ? ~0ull : kl));
+        const uint64_t ksecond = lane_min4(kl == kbest ? ~0ull : kl);   // stays in vector registers (uniform value)
         const uint32_t best_lane = (uint32_t)__builtin_ctzll(__ballot(kl == kbest));   // lowest lane of the best slot
         const uint32_t best = ((best_lane >> 1) & 1u) * 2u + ((best_lane >> 3) & 1u);
         // If the best child beats everything queued it is the next pop: keep it in registers (push + pop elided;
@@ -874,7 +874,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         seg_stamp<PROF>(wc, 4);   // [4] child totals + keys
         fam_store_lanes(pl.fam, kd, cur, next_idx);  // one record for all siblings
         if (take_child) {
-            if (ksecond != ~0ull) heap.deal(ksecond);
+            if (__any(ksecond != ~0ull)) heap.deal(ksecond);
             // slots (a1,a2): 0 = (0,1), 1 = (1,0), 2 = (0,0), 3 = (1,1); the kept child's own cell joins the prefix scores
             cur.frozen = kd.pfrozen + (uint32_t)__builtin_amdgcn_readlane((int)kd.gvec, (int)best_lane);   // best_lane is even
             cur.total = subkey_total(kbest);
@@ -895,7 +895,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
             // the siblings' keys, again one slot per lane group: each lane fetches its slot's cost sum from the record
             const uint32_t ftot = reinterpret_cast<const uint32_t*>(pl.fam + fbase)[16 + lslot];   // FamRec::tot[lslot]
             const uint64_t sk = lane_subkey(lslot, fbad, fhas1, fr.frozen + hn_t, ftot, fr.hets, fbase, fdepth);
-            const uint64_t knext = bcast64(lane_min4(sk > t ? sk : ~0ull));
+            const uint64_t knext = lane_min4(sk > t ? sk : ~0ull);
             heap.replace_push(kbest, knext);
             cur = cur_from_fam(fr, subkey_rank(t), subkey_total(t), subkey_idx(t), off);
             // resume the incremental state: the family's saved prefix scores + the popped child's own cell at the
