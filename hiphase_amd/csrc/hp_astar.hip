@@ -250,7 +250,7 @@ struct hp_batch {
     uint32_t tiles = 1;     // 2 when some block's cell table has 128 entries per variant (selects the TILES kernel variant)
     int n_cu = 256;
     // device inputs
-    DevBuf d_desc, d_order, d_vlo, d_vhi, d_vflags, d_rstart, d_rend, d_rword, d_words, d_head, d_ctab;
+    DevBuf d_desc, d_order, d_vlo, d_vhi, d_vflags, d_rstart, d_rend, d_rword, d_words, d_ctab;
     // device outputs
     DevBuf d_H, d_h1, d_h2, d_stats, d_counters, d_status, d_hapw;
     // post-processing (phaser.rs:350-388, :714-750)
@@ -329,7 +329,7 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return segs[x].v0 - segs[x].a > segs[y].v0 - segs[y].a; });
     const uint32_t slots = (uint32_t)std::min<uint64_t>(segs.size(), max_slots);
     SolveParams prm = b->prm;
-    prm.pad0 = 0; prm.pad1 = 0;
+    prm.seg_profile = 0;
     const size_t sub_pool_bytes = sub_pool_bytes_per_slot(prm);
     int rc;
     if (b->s_seg_pool.bytes < (size_t)slots * sub_pool_bytes && (rc = b->s_seg_pool.alloc((size_t)slots * sub_pool_bytes)) != HP_OK) return rc;
@@ -377,9 +377,7 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     uint32_t max_n = 0;
     for (uint32_t i : items) max_n = std::max(max_n, b->desc[i].n_vars);
     prm.max_n_vars = max_n;
-    const char* dbg = std::getenv("HP_DEBUG_STAGE");
-    prm.pad0 = dbg ? (uint32_t)std::atoi(dbg) : 0;
-    prm.pad1 = std::getenv("HP_SEG_PROFILE") ? 1u : 0u;   // per-segment s_memtime profile of the sub-solver loop
+    prm.seg_profile = std::getenv("HP_SEG_PROFILE") ? 1u : 0u;   // per-segment s_memtime profile of the sub-solver loop
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const size_t lds_bytes = LDS_HEAP_OFF + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup
@@ -410,13 +408,11 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     slots = std::min(slots, have_slots);
     int rc = upload(d_items, items, st);
     if (rc != HP_OK) return rc;
-    HP_HIP_CHECK(hipMemsetAsync(b->d_head.p, 0, sizeof(uint32_t), st));
 
     BatchDev B{};
     B.desc = b->d_desc.as<BlockDesc>();
     B.order = d_items.as<uint32_t>();
     B.n_items = (uint32_t)items.size();
-    B.queue_head = b->d_head.as<uint32_t>();
     B.vlo = b->d_vlo.as<uint32_t>(); B.vhi = b->d_vhi.as<uint32_t>(); B.vflags = b->d_vflags.as<uint8_t>();
     B.rstart = b->d_rstart.as<uint32_t>(); B.rend = b->d_rend.as<uint32_t>(); B.rword = b->d_rword.as<uint32_t>();
     B.words = b->d_words.as<uint32_t>();
@@ -432,10 +428,10 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_blocks, hp_astar_kernel<true, 6, false, 1>, 64, lds_bytes);
         fprintf(stderr, "[hp] hipOccupancyMaxActiveBlocksPerMultiprocessor(hp_astar_kernel, 64, %zu) = %d\n", lds_bytes, occ_blocks);
     }
-    if (verbose) { fprintf(stderr, "[hp] launch items=%zu slots=%u cap_main=%u cap_sub=%u jcap_sub=%u lds=%zu stage=%u\n", items.size(), slots, cap_main, prm.cap_sub, prm.jcap_sub, lds_bytes, prm.pad0); fflush(stderr); }
+    if (verbose) { fprintf(stderr, "[hp] launch items=%zu slots=%u cap_main=%u cap_sub=%u jcap_sub=%u lds=%zu\n", items.size(), slots, cap_main, prm.cap_sub, prm.jcap_sub, lds_bytes); fflush(stderr); }
     if (!prm.sub_heap_in_lds) hipLaunchKernelGGL((hp_astar_kernel<false, 4, false, 2>), dim3(slots), dim3(64), lds_bytes, st, B);
     else if (b->tiles == 2) hipLaunchKernelGGL((hp_astar_kernel<true, 6, false, 2>), dim3(slots), dim3(64), lds_bytes, st, B);
-    else if (prm.pad1) hipLaunchKernelGGL((hp_astar_kernel<true, 6, true, 1>), dim3(slots), dim3(64), lds_bytes, st, B);
+    else if (prm.seg_profile) hipLaunchKernelGGL((hp_astar_kernel<true, 6, true, 1>), dim3(slots), dim3(64), lds_bytes, st, B);
     else hipLaunchKernelGGL((hp_astar_kernel<true, 6, false, 1>), dim3(slots), dim3(64), lds_bytes, st, B);
     HP_HIP_CHECK(hipGetLastError());
     return HP_OK;
@@ -584,7 +580,6 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
         if (hipGetLastError() != hipSuccess) { set_error("hp_build_ctab_kernel launch failed"); return fail(HP_ERR_HIP); }
     }
     if ((rc = b->d_hapw.alloc(hpk.chunk_total * sizeof(Win) + 16)) != HP_OK) return fail(rc);
-    if ((rc = b->d_head.alloc(16)) != HP_OK) return fail(rc);
     if ((rc = b->d_H.alloc(b->sum_h * 8)) != HP_OK) return fail(rc);
     if ((rc = b->d_h1.alloc(b->sum_n)) != HP_OK) return fail(rc);
     if ((rc = b->d_h2.alloc(b->sum_n)) != HP_OK) return fail(rc);
@@ -638,9 +633,7 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     }
     if (!seg_blocks.empty()) HP_HIP_CHECK(hipStreamWaitEvent(st, b->ev_join, 0));
     HP_HIP_CHECK(hipEventRecord(b->ev1, st));
-    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] waiting for kernel\n"); fflush(stderr); }
     HP_HIP_CHECK(hipStreamSynchronize(st));
-    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] kernel done\n"); fflush(stderr); }
     float ms_total = 0.f;
     HP_HIP_CHECK(hipEventElapsedTime(&ms_total, b->ev0, b->ev1));
     HP_HIP_CHECK(hipMemcpy(status.data(), b->d_status.p, status.size() * 4, hipMemcpyDeviceToHost));

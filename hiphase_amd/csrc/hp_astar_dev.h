@@ -104,7 +104,8 @@ struct SolveParams {
     uint32_t jcap_main;   // per-lane heap capacity (main)
     uint32_t sub_heap_in_lds;
     uint32_t max_n_vars;  // largest N among the blocks of this launch (tracker stride)
-    uint32_t pad0, pad1;  // bring-up / segment-profile switches
+    uint32_t seg_profile; // 1: launch the s_memtime-instrumented kernel variant (HP_SEG_PROFILE, tuning aid)
+    uint32_t pad1;
     uint32_t cap_chunk_sub, cap_chunk_main;  // ChunkRec capacities
     uint32_t save_state;  // 1: the sub-solver pool has room for the per-expansion prefix scores (TILES == 2 launches)
     uint32_t pad3;
@@ -154,7 +155,6 @@ struct BatchDev {
     const BlockDesc* desc;
     const uint32_t* order;   // LPT work list: indices of the blocks this launch solves
     uint32_t n_items;
-    uint32_t* queue_head;
     const uint32_t *vlo, *vhi;
     const uint8_t* vflags;
     const uint32_t *rstart, *rend, *rword;

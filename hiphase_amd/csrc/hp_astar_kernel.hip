@@ -94,16 +94,7 @@ DEVINL uint64_t wave_sum_u64(uint64_t v) {
 template <int CTRL> DEVINL uint64_t dpp64(uint64_t v) {
     return ((uint64_t)dpp<CTRL>((uint32_t)(v >> 32)) << 32) | dpp<CTRL>((uint32_t)v);
 }
-DEVINL uint64_t rdlane64(uint64_t v, int l) { return ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l); }
 DEVINL uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
-// minimum of a u64 over the wave, uniform result
-DEVINL uint64_t wave_min_u64(uint64_t v) {
-    v = umin64(v, dpp64<0xB1>(v));
-    v = umin64(v, dpp64<0x4E>(v));
-    v = umin64(v, dpp64<0x141>(v));
-    v = umin64(v, dpp64<0x140>(v));
-    return umin64(umin64(rdlane64(v, 0), rdlane64(v, 16)), umin64(rdlane64(v, 32), rdlane64(v, 48)));
-}
 
 // minimum over the four slot groups of the wave_sum8 lane layout (lane ^ 2 and lane ^ 8 exchanges): every lane ends
 // up with the minimum of the four distinct per-slot values
@@ -160,9 +151,7 @@ DEVINL Key wave_min_key(Key k) {  // 128-bit lexicographic minimum (main heap; s
 // Sub-solver key, one u64 (astar_phaser.rs:131-133 restricted to a <= 62-variant sub-problem):
 //   cost:36 | (63 - hets):6 | node_index:14 | depth:6 | rank:2   (host checks cost < 2^36, nodes < 2^14);
 //   rank = creation rank among the siblings; it sits below node_index, which is unique, so it never decides.
-DEVINL uint64_t make_subkey(uint64_t total, uint32_t hets, uint32_t idx, uint32_t rank, uint32_t depth) {
-    return (total << 28) | ((uint64_t)(63u - hets) << 22) | ((uint64_t)idx << 8) | ((uint64_t)depth << 2) | (uint64_t)rank;
-}
+//   key = total << 28 | (63 - hets) << 22 | node_index << 8 | depth << 2 | rank   (built per lane by lane_subkey)
 DEVINL uint64_t subkey_total(uint64_t k) { return k >> 28; }
 DEVINL uint32_t subkey_idx(uint64_t k) { return (uint32_t)(k >> 8) & 0x3FFFu; }
 DEVINL uint32_t subkey_rank(uint64_t k) { return (uint32_t)k & 3u; }
@@ -279,30 +268,6 @@ template <bool LDS> struct SubHeap {
         const uint64_t who = __ballot(cnt > 0 && root == top);
         top_lane = who ? (uint32_t)__builtin_ctzll(who) : 0u;
         if (__any(kb != ~0ull)) deal(kb);
-    }
-    DEVINL void pop() {  // removes the global minimum (caller copied `top` first)
-        if (lane_id() == top_lane) {
-            cnt -= 1;
-            if (cnt > 0) {
-                const uint64_t k = ld(cnt);
-                uint32_t i = 0;
-                for (;;) {
-                    uint32_t c = 2 * i + 1;
-                    if (c >= cnt) break;
-                    uint64_t ck = ld(c);
-                    if (c + 1 < cnt) {
-                        const uint64_t c2 = ld(c + 1);
-                        if (c2 < ck) { ck = c2; c += 1; }
-                    }
-                    if (ck < k) { st(i, ck); i = c; } else break;
-                }
-                st(i, k);
-            }
-        }
-        const uint64_t mine = cnt > 0 ? ld(0) : ~0ull;
-        top = wave_min_u64(mine);
-        const uint64_t who = __ballot(cnt > 0 && mine == top);
-        top_lane = who ? (uint32_t)__builtin_ctzll(who) : 0u;
     }
 };
 
@@ -452,7 +417,7 @@ DEVINL Cur cur_from_fam(const FamRec& f, uint32_t rank, uint64_t total, uint64_t
 
 struct WaveCounters {
     uint64_t sub_pops, main_pops, nodes;
-    uint64_t seg[6];   // HP_SEG_PROFILE: shader-clock cycles per sub-solver segment (prm.pad1 != 0)
+    uint64_t seg[6];   // HP_SEG_PROFILE: shader-clock cycles per sub-solver segment (prm.seg_profile != 0)
     uint64_t tlast;
 };
 // segment profiling (tuning aid; PROF is a compile-time switch so the production kernel carries none of its state):

@@ -1,6 +1,7 @@
 """Per-segment shader-clock profile of the sub-solver loop (HP_SEG_PROFILE=1)."""
 import os, sys
 os.environ["HP_SEG_PROFILE"] = "1"
+os.environ["HP_NO_SEGMENTS"] = "1"   # the segment kernel carries no instrumentation
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from hiphase_amd import ResidentBatch, synth_block
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
