@@ -161,13 +161,16 @@ DEVINL uint32_t subkey_depth(uint64_t k) { return (uint32_t)(k >> 2) & 63u; }
 //   slot 0 = (0,1)  1 = (1,0) [only if the parent's haplotypes differ]  2 = (0,0)  3 = (1,1);  ignored variant: slot 0 only
 DEVINL uint64_t lane_subkey(uint32_t lslot, bool bad, bool has1, uint64_t tbase, uint32_t sumT, uint32_t hets_hom,
                             uint32_t first_idx, uint32_t depth) {
-    const uint32_t lrank = lslot - ((lslot >= 2u && !has1) ? 1u : 0u);          // creation rank among the siblings
-    const bool lvalid = lslot == 0u || (!bad && (lslot != 1u || has1));
-    const uint32_t lhets = hets_hom + ((lslot < 2u && !bad) ? 1u : 0u);
+    // per-slot predicates as arithmetic on the lane's slot number and three uniform words (no per-lane-set masks,
+    // which the compiler would hoist out of the loop and then spill)
+    const uint32_t valid_set = bad ? 0x1u : (has1 ? 0xFu : 0xDu);      // bit s: slot s exists
+    const uint32_t no10 = has1 ? 0u : 1u, real = bad ? 0u : 1u;
+    const uint32_t lrank = lslot - ((lslot >> 1) & no10);              // creation rank among the siblings
+    const uint32_t lhets = hets_hom + ((~lslot >> 1) & real);          // slots 0/1 of a real expansion: one more het
     const uint64_t total = tbase + sumT;
     const uint32_t low = ((63u - lhets) << 22) | ((first_idx + lrank) << 8) | (depth << 2) | lrank;   // < 2^28
     const uint64_t k = (total << 28) | low;
-    return lvalid ? k : ~0ull;
+    return ((valid_set >> lslot) & 1u) ? k : ~0ull;
 }
 
 // ---- record I/O: lane 0 writes, lane 0 reads, broadcast (same-lane rule) ---------------------------------------
