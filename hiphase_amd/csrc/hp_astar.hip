@@ -23,7 +23,11 @@ struct HostPack {
     std::vector<uint32_t> vlo, vhi;
     std::vector<uint8_t> vflags;
     std::vector<uint32_t> rstart, rend, rword;
-    std::vector<uint32_t> words;
+    uint64_t n_words = 0;              // plane words of all rows (built on the device, hp_pack_words_kernel)
+    std::vector<uint64_t> rcell;       // packed row -> offset of its first cell in the block's caller arrays
+    std::vector<uint8_t> raw_alleles;  // the caller's alleles_2bit / quals of every block, concatenated (byte-aligned)
+    std::vector<uint8_t> raw_quals;
+    std::vector<PackRaw> raw;          // per block: where its bytes start
     std::vector<uint64_t> work;  // LPT estimate per block
     std::vector<uint32_t> row_block;   // packed row -> block
     std::vector<uint32_t> row_orig;    // packed row -> caller's row index inside its block
@@ -68,7 +72,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     d.n_reads = (uint32_t)idx.size();
     d.var_off = hpk.vlo.size();
     d.read_off = hpk.rstart.size();
-    d.word_off = hpk.words.size() / WORD_DWORDS;
+    d.word_off = hpk.n_words;
     d.h_off = hpk.h_total;
     hpk.h_total += (uint64_t)N + 1;
     d.chunk_off = hpk.chunk_total;
@@ -83,56 +87,56 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     hpk.vflags.insert(hpk.vflags.end(), v->var_flags, v->var_flags + N);
     for (uint32_t p = 0; p < N; ++p) hpk.vflags[v0 + p] &= (uint8_t)(HP_VAR_IGNORED | HP_VAR_SNV);   // bit 2 is VAR_NOFAST (device-only)
 
+    // The rows' cells stay in the caller's layout: they are uploaded as they are and the bit-sliced plane words are
+    // built on the device (hp_pack_words_kernel). The host keeps the cheap parts: the quality sums behind the packed
+    // limits and the ignored-variant invariant (only rows crossing an ignored variant are looked at).
     uint64_t n_words = 0, cells = 0, max_row_qual = 0, total_qual = 0;
     uint32_t max_row_len = 0;
+    const uint64_t n_cells_blk = R ? v->row_off[R] : 0;
+    hpk.raw.push_back(PackRaw{hpk.raw_alleles.size(), hpk.raw_quals.size()});
+    if (n_cells_blk) {
+        hpk.raw_alleles.insert(hpk.raw_alleles.end(), v->alleles_2bit, v->alleles_2bit + (n_cells_blk + 3) / 4);
+        hpk.raw_quals.insert(hpk.raw_quals.end(), v->quals, v->quals + n_cells_blk);
+    }
+    std::vector<uint32_t> ignored;
+    for (uint32_t p = 0; p < N; ++p) if (v->var_flags[p] & HP_VAR_IGNORED) ignored.push_back(p);
     for (uint32_t i = 0; i < idx.size(); ++i) {
         const uint32_t r = idx[i];
         const uint32_t s = v->read_start[r], e = v->read_end[r];
-        const uint64_t ro = v->row_off[r];
         const uint32_t k0 = s >> 5, k1 = (e - 1) >> 5;
         if (n_words > 0xFFFFFFF0ull) { set_error("block too large (plane words)"); return HP_ERR_UNSUPPORTED; }
+        if (v->row_off[r] + (e - s) > n_cells_blk) { set_error("row %u: row_off outside the cell arrays", r); return HP_ERR_ARG; }
         hpk.rstart.push_back(s);
         hpk.rend.push_back(e);
         hpk.row_block.push_back(blk_index);
         hpk.row_orig.push_back(r);
         hpk.rword.push_back((uint32_t)n_words);
-        const size_t w0 = hpk.words.size();
-        hpk.words.resize(w0 + (size_t)(k1 - k0 + 1) * WORD_DWORDS, 0);
-        uint32_t* W = hpk.words.data() + w0;
-        for (uint32_t k = k0; k <= k1; ++k) {  // default: NoOverlap (3), qual 0
-            W[(size_t)(k - k0) * WORD_DWORDS + 0] = 0xFFFFFFFFu;
-            W[(size_t)(k - k0) * WORD_DWORDS + 1] = 0xFFFFFFFFu;
-        }
+        hpk.rcell.push_back(v->row_off[r]);
+        const uint64_t ro = v->row_off[r];
         uint64_t row_qual = 0;
-        for (uint32_t p = s; p < e; ++p) {
-            const uint64_t cell = ro + (p - s);
-            const uint8_t a = cell_allele(v, cell), q = v->quals[cell];
-            if ((v->var_flags[p] & HP_VAR_IGNORED) && a != HP_ALLELE_NOOVERLAP) {
-                set_error("row %u has allele %u at ignored variant %u (astar_phaser.rs:435-442 assert)", r, a, p);
+        for (uint64_t c = ro; c < ro + (e - s); ++c) row_qual += v->quals[c];
+        for (auto it = std::lower_bound(ignored.begin(), ignored.end(), s); it != ignored.end() && *it < e; ++it) {
+            const uint8_t a = cell_allele(v, ro + (*it - s));
+            if (a != HP_ALLELE_NOOVERLAP) {
+                set_error("row %u has allele %u at ignored variant %u (astar_phaser.rs:435-442 assert)", r, a, *it);
                 return HP_ERR_INVARIANT;
             }
-            uint32_t* w = W + (size_t)((p >> 5) - k0) * WORD_DWORDS;
-            const uint32_t bit = 1u << (p & 31);
-            if (!(a & 1)) w[0] &= ~bit;
-            if (!(a & 2)) w[1] &= ~bit;
-            for (int b = 0; b < 8; ++b) if ((q >> b) & 1) w[2 + b] |= bit;
-            row_qual += q;
-            uint32_t& lo = hpk.vlo[v0 + p];
-            if (lo == 0xFFFFFFFFu) lo = i;  // rows are visited in sorted order: the first one covering p is the min
         }
         max_row_qual = std::max(max_row_qual, row_qual);
-        max_row_len = std::max(max_row_len, e - s);
         total_qual += row_qual;
+        max_row_len = std::max(max_row_len, e - s);
         n_words += k1 - k0 + 1;
         cells += e - s;
     }
-    // vhi[p] = number of rows with start <= p
+    // candidate rows of variant p: [vlo[p], vhi[p]) with vhi[p] = number of rows with start <= p and vlo[p] = the
+    // first row that covers p (vhi[p] if none). Rows are sorted by start, so both only move forward.
     {
-        uint32_t j = 0;
+        uint32_t j = 0, lo = 0;
         for (uint32_t p = 0; p < N; ++p) {
             while (j < idx.size() && v->read_start[idx[j]] <= p) ++j;
+            while (lo < j && v->read_end[idx[lo]] <= p) ++lo;
             hpk.vhi[v0 + p] = j;
-            if (hpk.vlo[v0 + p] == 0xFFFFFFFFu) hpk.vlo[v0 + p] = j;  // no row covers p: empty range
+            hpk.vlo[v0 + p] = lo;
         }
     }
     uint32_t max_cov = 0;
@@ -144,6 +148,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     if (idx.size() >= (1u << 28)) { set_error("more than 2^28 rows in one block"); return HP_ERR_UNSUPPORTED; }
     d.max_cov = max_cov;
     d.n_words = (uint32_t)n_words;
+    hpk.n_words += n_words;
     // per-position cell table (incremental scoring in the sub-solver); variants where two covering rows collide on
     // (row index mod 64) are flagged for the plane-word path. HP_NO_CTAB=1 switches the table off (A/B testing).
     const bool no_ctab = std::getenv("HP_NO_CTAB") != nullptr;
@@ -181,6 +186,8 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     hpk.max_n = std::max(hpk.max_n, N);
     return HP_OK;
 }
+
+inline double wall_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 template <class T> int upload(DevBuf& buf, const std::vector<T>& v, hipStream_t s) {
     int rc = buf.alloc(v.size() * sizeof(T));
@@ -442,7 +449,9 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
 extern "C" {
 
 hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_astar_params* p, int device_id, int* status) {
-    auto fail = [&](int code) { if (status) *status = code; return (hp_batch*)nullptr; };
+    bool device_touched = false;
+    // on a failure after work was queued, wait for it: the buffers go back to the per-thread cache on return
+    auto fail = [&](int code) { if (device_touched) (void)hipDeviceSynchronize(); if (status) *status = code; return (hp_batch*)nullptr; };
     if (!blks || !p || n_blocks == 0 || n_blocks > 0x7FFFFFFFull) { set_error("bad arguments to hp_batch_create"); return fail(HP_ERR_ARG); }
     const uint64_t max_seg = p->max_segment_size ? p->max_segment_size : 40;
     if (max_seg < 2 || max_seg > 62) { set_error("max_segment_size %llu outside [2,62]", (unsigned long long)max_seg); return fail(HP_ERR_UNSUPPORTED); }
@@ -451,6 +460,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     // Validation + packing is independent per block: host threads (HP_PACK_THREADS, default min(16, cores)) each
     // pack a contiguous range of blocks into their own arrays; the parts are uploaded side by side and only the
     // small per-block tables are merged.
+    const double t_pack0 = wall_ms();
     unsigned nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* e = std::getenv("HP_PACK_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
     nt = (unsigned)std::min<size_t>(nt, n_blocks / 8 + 1);
@@ -476,11 +486,12 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
         }
         for (unsigned t = 0; t < nt; ++t) if (rcs[t] != HP_OK) { set_error("%s", errs[t].c_str()); return fail(rcs[t]); }
     }
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] host pack of %zu blocks on %u threads: %.1f ms\n", n_blocks, nt, wall_ms() - t_pack0); fflush(stderr); }
     HostPack hpk;   // merged view: per-block tables and totals only (the large arrays stay in `parts`)
-    struct PartBase { uint64_t var, read, word, h, chunk, cell, rows; uint32_t blk; };
+    struct PartBase { uint64_t var, read, word, h, chunk, cell, rows, ral, rq; uint32_t blk; };
     std::vector<PartBase> base(nt);
     {
-        PartBase acc{0, 0, 0, 0, 0, 0, 0, 0};
+        PartBase acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (unsigned t = 0; t < nt; ++t) {
             HostPack& q = parts[t];
             base[t] = acc;
@@ -490,22 +501,26 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
                 hpk.desc.push_back(d);
             }
             for (uint32_t rb : q.row_block) hpk.row_block.push_back(rb + acc.blk);
+            for (const PackRaw& pr : q.raw) hpk.raw.push_back(PackRaw{pr.allele_off + acc.ral, pr.qual_off + acc.rq});
             hpk.row_orig.insert(hpk.row_orig.end(), q.row_orig.begin(), q.row_orig.end());
             for (uint64_t o : q.caller_row_off) hpk.caller_row_off.push_back(o + acc.rows);
             hpk.work.insert(hpk.work.end(), q.work.begin(), q.work.end());
             hpk.max_n = std::max(hpk.max_n, q.max_n);
-            acc.var += q.vlo.size(); acc.read += q.rstart.size(); acc.word += q.words.size() / WORD_DWORDS;
+            acc.var += q.vlo.size(); acc.read += q.rstart.size(); acc.word += q.n_words;
+            acc.ral += q.raw_alleles.size(); acc.rq += q.raw_quals.size();
             acc.h += q.h_total; acc.chunk += q.chunk_total; acc.cell += q.cell_total; acc.rows += q.caller_rows;
             acc.blk += (uint32_t)q.desc.size();
         }
         hpk.h_total = acc.h; hpk.chunk_total = acc.chunk; hpk.cell_total = acc.cell; hpk.caller_rows = acc.rows;
     }
     const uint64_t tot_vars = base[nt - 1].var + parts[nt - 1].vlo.size(), tot_rows = base[nt - 1].read + parts[nt - 1].rstart.size();
-    const uint64_t tot_words = base[nt - 1].word + parts[nt - 1].words.size() / WORD_DWORDS;
+    const uint64_t tot_words = base[nt - 1].word + parts[nt - 1].n_words;
+    const uint64_t tot_ral = base[nt - 1].ral + parts[nt - 1].raw_alleles.size(), tot_rq = base[nt - 1].rq + parts[nt - 1].raw_quals.size();
     if (tot_words > 0xFFFFFFFFFFull) { set_error("batch too large"); return fail(HP_ERR_UNSUPPORTED); }
     // host-side validation/packing is done; from here on a GPU is mandatory
     if (device_id < 0) device_id = hp_default_device();
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return fail(HP_ERR_HIP); }
+    device_touched = true;
     std::unique_ptr<hp_batch> b(new hp_batch());
     b->device = device_id;
     b->n_blocks = n_blocks;
@@ -552,6 +567,10 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
         (rc = b->d_rstart.alloc(tot_rows * 4)) || (rc = b->d_rend.alloc(tot_rows * 4)) || (rc = b->d_rword.alloc(tot_rows * 4)) ||
         (rc = b->d_words.alloc(tot_words * WORD_DWORDS * 4)))
         return fail(rc);
+    DevBuf d_rcell, d_ral, d_rq, d_raw;   // inputs of the device-side packing only: released when this function returns
+    if ((rc = d_rcell.alloc(tot_rows * 8)) || (rc = d_ral.alloc(tot_ral + 16)) || (rc = d_rq.alloc(tot_rq + 16)) ||
+        (rc = upload(d_raw, hpk.raw, s)))
+        return fail(rc);
     for (unsigned t = 0; t < nt; ++t) {
         const HostPack& q = parts[t];
         const PartBase& o = base[t];
@@ -561,12 +580,23 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
         if (!put(b->d_vlo, o.var * 4, q.vlo.data(), q.vlo.size() * 4) || !put(b->d_vhi, o.var * 4, q.vhi.data(), q.vhi.size() * 4) ||
             !put(b->d_vflags, o.var, q.vflags.data(), q.vflags.size()) || !put(b->d_rstart, o.read * 4, q.rstart.data(), q.rstart.size() * 4) ||
             !put(b->d_rend, o.read * 4, q.rend.data(), q.rend.size() * 4) || !put(b->d_rword, o.read * 4, q.rword.data(), q.rword.size() * 4) ||
-            !put(b->d_words, o.word * WORD_DWORDS * 4, q.words.data(), q.words.size() * 4)) {
+            !put(d_rcell, o.read * 8, q.rcell.data(), q.rcell.size() * 8) || !put(d_ral, o.ral, q.raw_alleles.data(), q.raw_alleles.size()) ||
+            !put(d_rq, o.rq, q.raw_quals.data(), q.raw_quals.size())) {
             set_error("upload failed: %s", hipGetErrorString(hipGetLastError()));
             return fail(HP_ERR_HIP);
         }
     }
     if ((rc = upload(b->d_row_block, hpk.row_block, s)) != HP_OK) return fail(rc);
+    // the bit-sliced plane words are built on the device from the caller's cells
+    if (!hpk.row_block.empty()) {
+        PackDev P{};
+        P.desc = b->d_desc.as<BlockDesc>(); P.raw = d_raw.as<PackRaw>(); P.row_block = b->d_row_block.as<uint32_t>();
+        P.rstart = b->d_rstart.as<uint32_t>(); P.rend = b->d_rend.as<uint32_t>(); P.rword = b->d_rword.as<uint32_t>();
+        P.rcell = d_rcell.as<uint64_t>(); P.alleles = d_ral.as<uint8_t>(); P.quals = d_rq.as<uint8_t>();
+        P.words = b->d_words.as<uint32_t>(); P.n_rows = hpk.row_block.size();
+        hipLaunchKernelGGL(hp_pack_words_kernel, dim3((unsigned)((P.n_rows + 255) / 256)), dim3(256), 0, s, P);
+        if (hipGetLastError() != hipSuccess) { set_error("hp_pack_words_kernel launch failed"); return fail(HP_ERR_HIP); }
+    }
     // per-position cell tables are derived on the device from the rows just uploaded
     if ((rc = b->d_ctab.alloc(hpk.cell_total * sizeof(uint32_t) + 16)) != HP_OK) return fail(rc);
     if (hpk.cell_total && !hpk.row_block.empty()) {
@@ -587,6 +617,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     if ((rc = b->d_counters.alloc(n_blocks * sizeof(hp_work_counters))) != HP_OK) return fail(rc);
     if ((rc = b->d_status.alloc(n_blocks * sizeof(int32_t))) != HP_OK) return fail(rc);
     if (hipStreamSynchronize(s) != hipSuccess) { set_error("upload failed"); return fail(HP_ERR_HIP); }
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] hp_batch_create total %.1f ms\n", wall_ms() - t_pack0); fflush(stderr); }
     if (status) *status = HP_OK;
     return b.release();
 }

@@ -52,6 +52,9 @@ constexpr uint8_t VAR_NOFAST = 0x4;
 //   16 row ends here (end == p+1) | 17 valid (row covers p) | 18-31 min(p - row start, 2^14-1)
 constexpr uint32_t CELL_ENDS = 1u << 16, CELL_VALID = 1u << 17, CELL_T_SHIFT = 18, CELL_T_MAX = (1u << 14) - 1;
 
+// where a block's cells start in the concatenated caller arrays uploaded for the device-side packing
+struct PackRaw { uint64_t allele_off, qual_off; };   // bytes into the 2-bit allele / u8 quality uploads
+
 // Priority key (astar_phaser.rs:131-133): min total cost, then MORE hets, then OLDER node.
 //   hi = cost << 24 | (0xFFFFFF - num_hets)      cost < 2^40 (sum of all quals of a block < 2^40)
 //   lo = node_index << 26 | rank << 24 | depth   node_index < 2^38, creation rank among siblings (0..3),

@@ -1462,6 +1462,48 @@ __global__ void __launch_bounds__(256) hp_post_spans_kernel(PostDev P) {
     P.span_counts[g] = c;
 }
 
+// Builds the bit-sliced plane words (hp_astar_dev.h) of every row from the caller's cells (2-bit alleles, u8
+// qualities, row-major): one thread per row, one 48-byte word per 32 variants. Cells outside the row's region are
+// NoOverlap (allele 3), quality 0.
+struct PackDev {
+    const BlockDesc* desc;
+    const PackRaw* raw;
+    const uint32_t* row_block;
+    const uint32_t *rstart, *rend, *rword;
+    const uint64_t* rcell;
+    const uint8_t *alleles, *quals;
+    uint32_t* words;
+    uint64_t n_rows;
+};
+__global__ void __launch_bounds__(256) hp_pack_words_kernel(PackDev P) {
+    const uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= P.n_rows) return;
+    const uint32_t blk = P.row_block[row];
+    const BlockDesc d = P.desc[blk];
+    const PackRaw raw = P.raw[blk];
+    const uint32_t rs = P.rstart[row], re = P.rend[row];
+    const uint64_t cell0 = P.rcell[row];
+    const uint8_t* al = P.alleles + raw.allele_off;
+    const uint8_t* ql = P.quals + raw.qual_off;
+    uint32_t* w = P.words + ((size_t)d.word_off + P.rword[row]) * WORD_DWORDS;
+    for (uint32_t k = rs >> 5; k <= (re - 1) >> 5; ++k, w += WORD_DWORDS) {
+        uint32_t a0 = 0xFFFFFFFFu, a1 = 0xFFFFFFFFu, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint32_t p0 = max(rs, k << 5), p1 = min(re, (k + 1) << 5);
+        for (uint32_t p = p0; p < p1; ++p) {
+            const uint64_t cell = cell0 + (p - rs);
+            const uint32_t a = (al[cell >> 2] >> (2u * ((uint32_t)cell & 3u))) & 3u, qv = ql[cell];
+            const uint32_t b = p & 31u;
+            a0 &= ~((~a & 1u) << b);
+            a1 &= ~(((~a >> 1) & 1u) << b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] |= ((qv >> j) & 1u) << b;
+        }
+        reinterpret_cast<uint4*>(w)[0] = make_uint4(a0, a1, q[0], q[1]);
+        reinterpret_cast<uint4*>(w)[1] = make_uint4(q[2], q[3], q[4], q[5]);
+        reinterpret_cast<uint4*>(w)[2] = make_uint4(q[6], q[7], 0u, 0u);
+    }
+}
+
 // Fills the per-position cell tables (hp_astar_dev.h CELL_*) from the packed rows: one wavefront per row, lanes over
 // the row's cells; the table was zeroed (= no valid entry) beforehand.
 struct CtabDev {
