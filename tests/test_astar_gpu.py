@@ -343,3 +343,10 @@ def test_cell_table_on_off(monkeypatch):
             assert r.statistics.as_tuple() == st
             assert np.array_equal(h, oh)
             assert c.as_tuple() == octr
+
+
+def test_large_queue_parameters_use_the_hbm_sub_heap():
+    """min_queue_size large enough that the sub-solver's queue no longer fits the LDS budget: the kernel variant with
+    the queue in HBM scratch (and TILES = 2) must give the same bits."""
+    blocks = [synth_block(n, c, 12, e, 0.02, 8600 + i)[0] for i, (n, c, e) in enumerate([(60, 20, 0.05), (90, 70, 0.1), (40, 10, 0.3)])]
+    check_batch(blocks, min_queue_size=35000, queue_increment=3)
