@@ -172,7 +172,10 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
             return n_bad;
         };
         uint32_t ents = 64;
-        if (max_cov > 64 && (uint64_t)collisions(64, false) * 50 > N) ents = 128;
+        if (max_cov > 64) {   // (a handful of colliding variants in a small block is not worth the wider kernel variant)
+            const uint32_t n_bad = collisions(64, false);
+            if ((uint64_t)n_bad * 50 > N && n_bad >= 32) ents = 128;
+        }
         if (max_cov > ents) collisions(ents, true);
         d.ctab_shift = ents == 128 ? 7u : 6u;
         d.cell_off = hpk.cell_total;
