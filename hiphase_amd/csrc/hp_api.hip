@@ -17,15 +17,31 @@ struct DevCache {
         if (n <= (1u << 20)) { size_t r = 256; while (r < n) r <<= 1; return r; }
         return (n + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
     }
-    ~DevCache() { for (auto& kv : free_) (void)hipFree(kv.second); }
+    ~DevCache();
 };
+// Thread-local objects of other translation units (the WFA context's scratch DevBuf) may be destroyed AFTER this
+// cache at thread / process exit and hand their block back then: once the cache is gone, get/put talk to
+// hipMalloc/hipFree directly. A plain bool has no destructor, so it stays readable for the rest of the thread's life.
+thread_local bool g_dev_cache_dead = false;
 thread_local DevCache g_dev_cache;
+DevCache::~DevCache() {
+    for (auto& kv : free_) (void)hipFree(kv.second);
+    free_.clear();
+    g_dev_cache_dead = true;
+}
 }  // namespace
 
 void* dev_cache_get(size_t bytes, size_t* got) {
     const size_t want = DevCache::round_up(bytes);
     int dev = 0;
     (void)hipGetDevice(&dev);
+    if (g_dev_cache_dead) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, want);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return nullptr; }
+        *got = want;
+        return q;
+    }
     DevCache& c = g_dev_cache;
     auto it = c.free_.lower_bound({dev, want});
     if (it != c.free_.end() && it->first.first == dev && it->first.second <= want + want / 4) {
@@ -60,6 +76,7 @@ int device_cu_count(int device_id) {
 }
 
 void dev_cache_put(void* p, size_t bytes) {
+    if (g_dev_cache_dead) { (void)hipFree(p); return; }
     DevCache& c = g_dev_cache;
     int dev = 0;
     if (bytes > DevCache::kMaxBlock || c.cached + bytes > DevCache::kMaxCached || hipGetDevice(&dev) != hipSuccess) {

@@ -232,16 +232,17 @@ struct StreamSet {
         *this = StreamSet{};
     }
 };
+thread_local bool g_stream_pool_dead = false;   // a batch destroyed after the pool (thread exit) destroys its streams itself
 struct StreamPool {
     std::vector<StreamSet> free_;
-    ~StreamPool() { for (auto& s : free_) s.destroy(); }
+    ~StreamPool() { for (auto& s : free_) s.destroy(); free_.clear(); g_stream_pool_dead = true; }
     bool get(int dev, StreamSet& out) {
         for (size_t i = 0; i < free_.size(); ++i)
             if (free_[i].device == dev) { out = free_[i]; free_.erase(free_.begin() + i); return true; }
         return out.create(dev);
     }
     void put(StreamSet& s) {
-        if (free_.size() < 8) free_.push_back(s); else s.destroy();
+        if (!g_stream_pool_dead && free_.size() < 8) free_.push_back(s); else s.destroy();
         s = StreamSet{};
     }
 };
