@@ -70,6 +70,53 @@ def cpu_baseline(args, blocks):
             "sample": f"first {used} block(s) of the same batch ({hets} hets), single thread, {dt:.1f}s"}, counters, results
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask, clipped by the cgroup CPU quota, at most 32 threads (each
+    thread finishes the block it started, so more threads than cores would overrun the time budget)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:   # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline_all_cores(args, blocks, skip):
+    """The same restatement on every host core: independent blocks on independent threads, as the reference's own
+    worker pool does (main.rs:385). ctypes releases the GIL for the duration of each oracle call."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import threading
+    import oracle_ffi
+    n_thr = max(1, min(usable_cores(), len(blocks) - skip))
+    budget_s = args.cpu_seconds * 0.6
+    done = [0] * n_thr
+    t0 = time.perf_counter()
+
+    def work(t):
+        for blk in blocks[skip + t::n_thr]:
+            oracle_ffi.oracle_solve(blk)
+            done[t] += blk.n_variants
+            if time.perf_counter() - t0 > budget_s:
+                break
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(n_thr)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    return {"value": sum(done) / dt, "unit": "hets/s", "cores": n_thr, "kind": "port",
+            "sample": f"{sum(done)} hets of the same batch, one block per thread at a time on {n_thr} threads, {dt:.1f}s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,9 +229,11 @@ def main():
                 ok = all((r.haplotype_1 == e[0]).all() and (r.haplotype_2 == e[1]).all() and r.statistics.as_tuple() == tuple(e[2])
                          for r, e in zip(res, getattr(args, "replay_expected")) if e is not None)
                 out["parity_vs_capture"] = {"blocks_compared": len(exp), "bit_identical": bool(ok)}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # the CPU leg is timed at N=1 only
             cb, octr, ores = cpu_baseline(args, blocks)
             out["cpu_baseline"] = cb
+            if usable_cores() > 1 and len(blocks) > len(ores) + 1:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args, blocks, len(ores))
             # the oracle doubles as a live parity check on the sampled blocks
             ok = all((r.haplotype_1 == o[0]).all() and (r.haplotype_2 == o[1]).all() and r.statistics.as_tuple() == o[2]
                      for r, o in zip(res, ores))

@@ -148,3 +148,32 @@ def test_edit_distance_random_vs_oracle():
         A = np.frombuffer(a, np.uint8) if a else np.zeros(1, np.uint8)
         Bv = np.frombuffer(b, np.uint8) if b else np.zeros(1, np.uint8)
         assert g == d.hpo_edit_distance(A.ctypes.data, len(a), Bv.ctypes.data, len(b)), (len(a), len(b))
+
+
+def test_concurrent_callers_and_thread_exit():
+    """hp_wfa_assign_batch is called from HiPhase's worker threads (main.rs:332,385; read_parsing.rs:769-780), each
+    with its own records: concurrent calls must not share state, and a worker that exits hands its per-thread
+    device buffers back (thread-local teardown order once corrupted the heap at exit)."""
+    import threading
+    specs = [synth_wfa_job(7100 + s, ref_len=1500 + 40 * s, n_vars=10, n_homs=3, noise=0.01)[0] for s in range(24)]
+    expect = wfa_assign_batch(specs, prune_distance=500, max_edit_distance=500)
+    errors = []
+
+    def work(tid):
+        try:
+            for rep in range(3):
+                mine = specs[tid::4]
+                got = wfa_assign_batch(mine, prune_distance=500, max_edit_distance=500)
+                for g, e in zip(got, expect[tid::4]):
+                    assert g[:3] == e[:3] and np.array_equal(g[3], e[3])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    for wave in range(2):   # the second wave runs after the first wave's threads (and their caches) are gone
+        ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert not errors, errors
+    check_specs(specs[:4])
