@@ -245,7 +245,23 @@ unsigned wfa_host_threads(size_t n) {
 int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, uint32_t band, WfaPack& pk) {
     const size_t n = ids.size();
     pk.jobs.resize(n);
+    // Reference slices: the reads of a block look at overlapping windows of ONE caller buffer (the chromosome), so
+    // the union of the host address ranges is uploaded once and every job points into it (16 readable bytes follow
+    // each range: the kernel's 16-byte compares may run past a node's last base).
+    struct Range { const uint8_t* lo; const uint8_t* hi; uint64_t dev_off; };
+    std::vector<Range> ranges;
+    {
+        std::vector<std::pair<const uint8_t*, uint32_t>> iv;
+        iv.reserve(n);
+        for (size_t i = 0; i < n; ++i) if (hj[ids[i]].ref_len) iv.push_back({hj[ids[i]].ref_ptr, hj[ids[i]].ref_len});
+        std::sort(iv.begin(), iv.end());
+        for (auto& v : iv) {
+            if (!ranges.empty() && v.first <= ranges.back().hi) ranges.back().hi = std::max(ranges.back().hi, v.first + v.second);
+            else ranges.push_back({v.first, v.first + v.second, 0});
+        }
+    }
     uint64_t node_off = 0, edge_off = 0, seq_off = 0;
+    for (auto& r : ranges) { r.dev_off = seq_off; seq_off += ((uint64_t)(r.hi - r.lo) + 16 + 15) & ~15ull; }
     for (size_t i = 0; i < n; ++i) {
         const HostJob& g = hj[ids[i]];
         WfaJobDesc& jd = pk.jobs[i];
@@ -253,9 +269,14 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
         jd.node_off = node_off;
         jd.edge_off = edge_off;
         jd.seq_off = seq_off;
+        if (g.ref_len) {
+            auto it = std::upper_bound(ranges.begin(), ranges.end(), g.ref_ptr, [](const uint8_t* p, const Range& r) { return p < r.lo; });
+            --it;
+            jd.ref_off = it->dev_off + (uint64_t)(g.ref_ptr - it->lo);
+        }
         jd.n_nodes = (uint32_t)g.nodes.size();
         jd.set_words = (jd.n_nodes + 31) / 32;
-        jd.read_off = g.read_off;
+        jd.read_off = g.read_off - g.ref_len;
         jd.read_len = g.read_len;
         jd.band = band;
         jd.out_set_off = pk.out_set_words;
@@ -263,7 +284,7 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
         if (jd.n_nodes > WFA_MAX_NODES) { set_error("read overlaps a graph of %u nodes (> %u supported)", jd.n_nodes, WFA_MAX_NODES); return HP_ERR_UNSUPPORTED; }
         node_off += g.nodes.size();
         edge_off += g.child.size();
-        seq_off += g.seq_bytes;
+        seq_off += g.seq_bytes - g.ref_len;
         pk.max_nodes = std::max(pk.max_nodes, jd.n_nodes);
     }
     pk.nodes.resize(node_off);
@@ -285,13 +306,14 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
             for (uint32_t k = 0; k < jd.n_nodes; ++k) {
                 const HostNode& hn = g.nodes[k];
                 WfaNode dn{};
-                dn.seq_off = hn.seq_off;
+                const bool is_ref = hn.seq_off < g.ref_len;
+                dn.seq_off = is_ref ? hn.seq_off : hn.seq_off - g.ref_len;   // reference span | job-private bytes
                 dn.seq_len = hn.seq_len;
                 dn.child_off = e_cur;
                 dn.n_children = (uint16_t)hn.n_child;
                 const uint32_t np = k == 0 ? 1u : hn.n_par;
                 if (np > 32 || hn.n_child > 65535) { snprintf(msg, sizeof msg, "graph node with %u parents (> 32 supported)", np); errs[t] = msg; rcs[t] = HP_ERR_UNSUPPORTED; return; }
-                dn.n_parents = (uint16_t)np;
+                dn.n_parents = (uint16_t)(np | (is_ref ? WFA_NODE_IS_REF : 0u));
                 const int64_t width = (hn.emax - hn.emin) + 2 * (int64_t)band + 3;
                 if (width > 65535) { snprintf(msg, sizeof msg, "diagonal band of %lld exceeds 65535", (long long)width); errs[t] = msg; rcs[t] = HP_ERR_UNSUPPORTED; return; }
                 dn.dbase = (int32_t)(hn.emin - (int64_t)band - 1);
@@ -310,11 +332,19 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
             }
             jd.scratch_dwords = (uint32_t)entry_off;
             max_scratch[t] = std::max<uint64_t>(max_scratch[t], entry_off);
-            uint8_t* dst = pk.seq.data() + jd.seq_off;
-            std::memcpy(dst, g.ref_ptr, g.ref_len);
-            if (!g.alt.empty()) std::memcpy(dst + g.ref_len, g.alt.data(), g.alt.size());
-            if (g.read_len) std::memcpy(dst + g.read_off, g.read_ptr, g.read_len);
-            std::memset(dst + g.read_off + g.read_len, 0, g.seq_bytes - g.read_off - g.read_len);
+            uint8_t* dst = pk.seq.data() + jd.seq_off;   // [alt allele bytes][read][pad]
+            if (!g.alt.empty()) std::memcpy(dst, g.alt.data(), g.alt.size());
+            if (g.read_len) std::memcpy(dst + jd.read_off, g.read_ptr, g.read_len);
+            std::memset(dst + jd.read_off + g.read_len, 0, g.seq_bytes - g.read_off - g.read_len);
+        }
+        // this thread's share of the merged reference ranges, in 256 KiB pieces
+        constexpr uint64_t PIECE = 256u << 10;
+        uint64_t piece = 0;
+        for (const Range& r : ranges) {
+            const uint64_t len = (uint64_t)(r.hi - r.lo);
+            for (uint64_t o = 0; o < len; o += PIECE, ++piece)
+                if (piece % nt == t) std::memcpy(pk.seq.data() + r.dev_off + o, r.lo + o, (size_t)std::min(PIECE, len - o));
+            if (piece % nt == t) std::memset(pk.seq.data() + r.dev_off + len, 0, (size_t)((((len + 16 + 15) & ~15ull)) - len));
         }
     };
     if (nt == 1) work(0);

@@ -21,12 +21,13 @@
 
 namespace hp {
 
+constexpr uint32_t WFA_NODE_IS_REF = 0x8000u;   // bit of WfaNode::n_parents: the node is a span of the reference slice
 struct WfaNode {          // 32 B
-    uint32_t seq_off;     // into the job's sequence buffer
+    uint32_t seq_off;     // into the job's reference slice (WFA_NODE_IS_REF) or into its private bytes
     uint32_t seq_len;
     uint32_t child_off;   // into the job's edge list
     uint16_t n_children;
-    uint16_t n_parents;   // number of injection slots (node 0 has one virtual parent: the start wave)
+    uint16_t n_parents;   // number of injection slots (node 0 has one virtual parent: the start wave) | WFA_NODE_IS_REF
     int32_t  dbase;       // diagonal of di == 0
     uint32_t width;       // number of diagonals in the band
     uint32_t entry_off;   // dword offset of this node's band inside the job scratch
@@ -41,15 +42,15 @@ struct WfaEdge {
 struct WfaJobDesc {       // 64 B
     uint64_t node_off;    // into nodes[]
     uint64_t edge_off;    // into edges[]
-    uint64_t seq_off;     // into seq[] (bytes)
+    uint64_t seq_off;     // into seq[] (bytes): the job's private bytes = [alt allele bytes][read][pad]
     uint32_t n_nodes;
     uint32_t set_words;   // W
-    uint32_t read_off;    // read position inside the job's sequence buffer
+    uint32_t read_off;    // read position inside the job's private bytes
     uint32_t read_len;
     uint32_t band;        // edit-distance capacity of this layout
     uint32_t scratch_dwords;
     uint64_t out_set_off; // into out_sets[] (dwords)
-    uint32_t pad[2];
+    uint64_t ref_off;     // into seq[] (bytes): first base of the job's reference window inside the shared upload
 };
 
 constexpr int32_t WFA_ST_OK = 0;

@@ -120,6 +120,7 @@ WDEV uint32_t match_run(const uint8_t* a, const uint8_t* b, uint32_t maxlen) {
 struct WfaNodeU {  // uniform copy of a WfaNode
     uint32_t seq_off, seq_len, child_off, n_children, n_parents, width, entry_off, entry_stride;
     int32_t dbase;
+    bool is_ref;
 };
 // The job's node table is copied into LDS once (solve_job): a node lookup is then a broadcast LDS read instead of a
 // dependent HBM round trip at the head of every (round, node) step.
@@ -132,7 +133,8 @@ WDEV WfaNodeU load_node(const WfaNode* p) {
     u.child_off = wb32(a.z);
     const uint32_t cp = wb32(a.w);
     u.n_children = cp & 0xFFFFu;
-    u.n_parents = cp >> 16;
+    u.n_parents = (cp >> 16) & (WFA_NODE_IS_REF - 1);
+    u.is_ref = (cp >> 16) & WFA_NODE_IS_REF;
     u.dbase = (int32_t)wb32(b.x);
     u.width = wb32(b.y);
     u.entry_off = wb32(b.z);
@@ -147,6 +149,7 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
     const WfaNode* gnodes = B.nodes + jd.node_off;
     const WfaEdge* edges = B.edges + jd.edge_off;
     const uint8_t* seq = B.seq + jd.seq_off;
+    const uint8_t* refseq = B.seq + jd.ref_off;
     const uint8_t* read = seq + jd.read_off;
     const uint32_t other_len = jd.read_len;
     uint32_t* scr = B.scratch + (size_t)slot * B.scratch_stride;
@@ -204,7 +207,7 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                 lo = hull_lo(g);
                 hi = hull_hi(g);
             }
-            const uint8_t* nseq = seq + nd.seq_off;
+            const uint8_t* nseq = (nd.is_ref ? refseq : seq) + nd.seq_off;
             const uint32_t len = nd.seq_len;
             const uint32_t ES = nd.entry_stride;
             uint32_t* ebase = scr + nd.entry_off;
