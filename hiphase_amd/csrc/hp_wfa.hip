@@ -222,16 +222,24 @@ struct StageBuf {
     uint8_t* data() { return p; }
     size_t size() const { return len; }
 };
+template <class T> struct StageVec {   // typed view of a StageBuf (node / edge tables: tens of MB per call)
+    StageBuf b;
+    int resize(size_t n) { return b.resize(n * sizeof(T)); }
+    T* data() { return reinterpret_cast<T*>(b.p); }
+    size_t size() const { return b.len / sizeof(T); }
+};
 thread_local StageBuf g_seq_stage;
+thread_local StageVec<WfaNode> g_node_stage;
+thread_local StageVec<WfaEdge> g_edge_stage;
 
 struct WfaPack {
     std::vector<WfaJobDesc> jobs;
-    std::vector<WfaNode> nodes;
-    std::vector<WfaEdge> edges;
+    StageVec<WfaNode>& nodes = g_node_stage;
+    StageVec<WfaEdge>& edges = g_edge_stage;
     StageBuf& seq = g_seq_stage;
     uint64_t out_set_words = 0;
     uint64_t max_scratch = 0;
-    uint32_t max_nodes = 0;
+    uint32_t max_nodes = 0, max_edges = 0;
 };
 
 unsigned wfa_host_threads(size_t n) {
@@ -275,6 +283,8 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
             jd.ref_off = it->dev_off + (uint64_t)(g.ref_ptr - it->lo);
         }
         jd.n_nodes = (uint32_t)g.nodes.size();
+        jd.n_edges = (uint32_t)g.child.size();
+        pk.max_edges = std::max(pk.max_edges, jd.n_edges);
         jd.set_words = (jd.n_nodes + 31) / 32;
         jd.read_off = g.read_off - g.ref_len;
         jd.read_len = g.read_len;
@@ -287,8 +297,8 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
         seq_off += g.seq_bytes - g.ref_len;
         pk.max_nodes = std::max(pk.max_nodes, jd.n_nodes);
     }
-    pk.nodes.resize(node_off);
-    pk.edges.resize(edge_off);
+    if (int rc = pk.nodes.resize(node_off)) return rc;
+    if (int rc = pk.edges.resize(edge_off)) return rc;
     if (int rc = pk.seq.resize(seq_off)) return rc;
     const unsigned nt = wfa_host_threads(n);
     std::vector<int> rcs(nt, HP_OK);
@@ -360,6 +370,12 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
     return HP_OK;
 }
 
+template <class T> int up(DevBuf& buf, StageVec<T>& v) {
+    int rc = buf.alloc(v.size() * sizeof(T));
+    if (rc != HP_OK) return rc;
+    if (v.size()) HP_HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return HP_OK;
+}
 template <class T> int up(DevBuf& buf, const std::vector<T>& v) {
     int rc = buf.alloc(v.size() * sizeof(T));
     if (rc != HP_OK) return rc;
@@ -374,8 +390,6 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     {
         size_t tot = 0, nn = 0;
         for (uint32_t id : ids) { tot += hj[id].seq_bytes; nn += hj[id].nodes.size(); }
-        pk.nodes.reserve(nn);
-        pk.edges.reserve(nn * 2);
         pk.jobs.reserve(ids.size());
     }
     const double t_pk0 = now_ms();
@@ -397,8 +411,13 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     std::vector<int32_t> st0(n, WFA_ST_PENDING);
     HP_HIP_CHECK(hipMemcpy(d_status.p, st0.data(), n * 4, hipMemcpyHostToDevice));
     const uint32_t lds_nodes_off = (uint32_t)(((size_t)pk.max_nodes * WFA_NODE_STATE_BYTES + 15) & ~(size_t)15);
-    const size_t lds = (size_t)lds_nodes_off + (size_t)pk.max_nodes * 32;
-    uint32_t per_cu = (uint32_t)std::min<size_t>(12, (160 * 1024) / std::max<size_t>((lds + 1279) / 1280 * 1280, 1280));
+    const uint32_t lds_edges_off = lds_nodes_off + pk.max_nodes * 32;
+    const size_t lds = (size_t)lds_edges_off + (size_t)pk.max_edges * sizeof(WfaEdge);
+    // resident single-wave workgroups per CU: the kernel is a chain of dependent memory round trips per read, so
+    // throughput comes from resident reads; 113 VGPRs allow 4 per SIMD = 16 per CU (measured, 4096 x 17 kb reads:
+    // 8 -> 4.6 ms, 12 -> 4.3 ms, 16 -> 2.8 ms)
+    const char* pcenv = std::getenv("HP_WFA_PER_CU");
+    uint32_t per_cu = (uint32_t)std::min<size_t>(pcenv ? std::atoi(pcenv) : 16, (160 * 1024) / std::max<size_t>((lds + 1279) / 1280 * 1280, 1280));
     if (per_cu == 0) per_cu = 1;
     size_t free_b = 0, total_b = 0;
     HP_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
@@ -424,6 +443,7 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     B.out_sets = d_sets.as<uint32_t>(); B.out_score = d_score.as<uint64_t>(); B.status = d_status.as<int32_t>();
     B.scratch = g_ctx.scratch.as<uint32_t>(); B.scratch_stride = stride; B.prune_distance = prune; B.max_ed = max_ed;
     B.lds_nodes_off = lds_nodes_off;
+    B.lds_edges_off = lds_edges_off;
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa launch jobs=%zu band=%u slots=%u lds=%zu scratch/slot=%zu B\n", n, band, slots, lds, per_slot); fflush(stderr); }
     hipEvent_t e0, e1;
     HP_HIP_CHECK(hipEventCreate(&e0));

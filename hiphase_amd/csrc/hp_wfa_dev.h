@@ -39,7 +39,7 @@ struct WfaEdge {
     uint32_t ordinal;     // which injection slot of the child this parent owns
 };
 
-struct WfaJobDesc {       // 64 B
+struct WfaJobDesc {       // 72 B
     uint64_t node_off;    // into nodes[]
     uint64_t edge_off;    // into edges[]
     uint64_t seq_off;     // into seq[] (bytes): the job's private bytes = [alt allele bytes][read][pad]
@@ -49,6 +49,8 @@ struct WfaJobDesc {       // 64 B
     uint32_t read_len;
     uint32_t band;        // edit-distance capacity of this layout
     uint32_t scratch_dwords;
+    uint32_t n_edges;
+    uint32_t pad;
     uint64_t out_set_off; // into out_sets[] (dwords)
     uint64_t ref_off;     // into seq[] (bytes): first base of the job's reference window inside the shared upload
 };
@@ -83,7 +85,7 @@ struct WfaBatchDev {
     uint64_t prune_distance; // UINT64_MAX disables pruning
     uint64_t max_ed;
     uint32_t lds_nodes_off;  // byte offset of the node-table copy in LDS (after the NodeState array, 16-byte aligned)
-    uint32_t pad;
+    uint32_t lds_edges_off;  // byte offset of the edge-list copy (after the node table)
 };
 
 }  // namespace hp

@@ -18,6 +18,15 @@
 namespace hp {
 
 #define WDEV __device__ __forceinline__
+#define WFA_PROF 0
+#if WFA_PROF
+#define PT(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); pc[i] += t_ - tl; tl = t_; } while (0)
+#define PC(i, v) do { pn[i] += (v); } while (0)
+#else
+#define PT(i)
+#define PC(i, v)
+#endif
+__device__ uint32_t g_p2_iters, g_p2_lanes;
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wfa_smem[];
 // LDS node state: 4 hulls of u16 pairs (lo, hi), empty = (0xFFFF, 0)
@@ -68,18 +77,34 @@ WDEV uint64_t ld8(const uint8_t* p) {
 // diagonal that is not the alignment's own mismatches within a base or two, so this settles almost every lane.
 // Phase 2: lanes that are still matching are served one after the other by the whole wave, 512 bytes per step
 // (coalesced 8-byte loads + ballot). Buffers are padded so that reading 16 bytes at any in-range position is legal.
+struct Pre16 { uint64_t a0, a1, b0, b1; };
+// issues the four 8-byte loads of a phase-1 compare without using them: several of these are put in flight
+// together (the extension and its tie checks), so a (round, node) step pays ONE sequence round trip
+WDEV Pre16 pre16(const uint8_t* a, const uint8_t* b, bool on) {
+    Pre16 p{0, 0, 0, 0};
+    if (on) { p.a0 = ld8(a); p.a1 = ld8(a + 8); p.b0 = ld8(b); p.b1 = ld8(b + 8); }
+    return p;
+}
+WDEV uint32_t pre16_len(const Pre16& p) {   // common prefix of the two 16-byte windows
+    const uint64_t x0 = p.a0 ^ p.b0, x1 = p.a1 ^ p.b1;
+    return x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : (x1 ? 8u + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16u);
+}
+WDEV uint32_t match_rest(const uint8_t* a, const uint8_t* b, uint32_t maxlen, uint32_t n, bool done);
 WDEV uint32_t match_run(const uint8_t* a, const uint8_t* b, uint32_t maxlen) {
     uint32_t n = 0;
     bool done = (maxlen == 0);
     if (__any(!done)) {
         if (!done) {
-            const uint64_t x0 = ld8(a) ^ ld8(b), x1 = ld8(a + 8) ^ ld8(b + 8);
-            uint32_t m = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : (x1 ? 8u + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16u);
+            uint32_t m = pre16_len(pre16(a, b, true));
             if (m > maxlen) m = maxlen;
             n = m;
             if (m < 16 || n >= maxlen) done = true;
         }
     }
+    return match_rest(a, b, maxlen, n, done);
+}
+// phase 2: lanes with `done == false` have matched their first n (= 16) bytes and have more to compare
+WDEV uint32_t match_rest(const uint8_t* a, const uint8_t* b, uint32_t maxlen, uint32_t n, bool done) {
     uint64_t pending = __ballot(!done);
     while (pending) {
         const int L = __builtin_ctzll(pending);
@@ -144,10 +169,14 @@ WDEV WfaNodeU load_node(const WfaNode* p) {
 
 WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
     const uint32_t lane = wlane();
+    uint64_t pc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; uint32_t pn[8] = {0,0,0,0,0,0,0,0};
+    uint64_t tl = __builtin_amdgcn_s_memtime();
+    const uint64_t tstart = tl;
     const WfaJobDesc jd = B.jobs[job];
     const uint32_t n_nodes = jd.n_nodes, W = jd.set_words;
     const WfaNode* gnodes = B.nodes + jd.node_off;
-    const WfaEdge* edges = B.edges + jd.edge_off;
+    const WfaEdge* gedges = B.edges + jd.edge_off;
+    WfaEdge* edges = reinterpret_cast<WfaEdge*>(wfa_smem + (size_t)B.lds_edges_off);
     const uint8_t* seq = B.seq + jd.seq_off;
     const uint8_t* refseq = B.seq + jd.ref_off;
     const uint8_t* read = seq + jd.read_off;
@@ -160,6 +189,7 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
     for (uint32_t i = lane; i < n_nodes; i += 64) ns[i] = NodeState{{HULL_EMPTY, HULL_EMPTY}, {0xFFFFFFFFu, 0xFFFFFFFFu}, HULL_EMPTY, HULL_EMPTY};
     for (uint32_t i = lane; i < n_nodes * 2; i += 64)   // 32-byte node entries as 16-byte halves
         reinterpret_cast<uint4*>(nodes)[i] = reinterpret_cast<const uint4*>(gnodes)[i];
+    for (uint32_t i = lane; i < jd.n_edges; i += 64) edges[i] = gedges[i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (lane == 0) for (uint32_t w = 0; w < W; ++w) out_set[w] = 0;
 
@@ -181,17 +211,21 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
     uint64_t farthest = 0, min_prog = 0;
     const uint32_t last = n_nodes - 1;
 
+    PT(0);
     for (uint32_t ed = 0; status == WFA_ST_PENDING; ++ed) {
+        PC(0, 1);
         const uint32_t c = ed & 1u, p = c ^ 1u;
         uint32_t lane_far = 0;
         bool final_found = false;
         uint32_t new_amin = 0xFFFFFFFFu, new_amax = 0;
         bool band_overflow = false;
         for (uint32_t n = amin; n <= amax && n < n_nodes; ++n) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // results/injections written by other lanes
+            // results / injections written by other lanes of THIS wavefront (the only one of the workgroup): the
+            // memory pipeline executes a wave's accesses in order, so only the compiler must not move them
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const uint32_t ph = (ed > 0 && ns[n].stamp[p] == ed - 1) ? ns[n].hull[p] : HULL_EMPTY;
             const uint32_t ih = ns[n].inj;
-            if (hull_empty(ph) && hull_empty(ih)) continue;
+            if (hull_empty(ph) && hull_empty(ih)) { PC(1, 1); PT(1); continue; }
             const WfaNodeU nd = load_node(nodes + n);
             // this round's hull: previous results grown by one diagonal each side, plus the injection targets
             uint32_t lo, hi;
@@ -214,7 +248,9 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
             bool any_valid = false;
             bool any_final_here = false;
 
+            PT(2);
             for (uint32_t base = lo; base <= hi; base += 64) {
+                PC(2, 1);
                 const int32_t di = (int32_t)(base + lane);
                 const bool act = (uint32_t)di <= hi;
                 const int32_t d = nd.dbase + di;  // other_start
@@ -222,18 +258,32 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                 // ---- gather candidates -------------------------------------------------------------------
                 // A: from d+1 (offset+1)  B: from d (offset+1)  C: from d-1 (offset)  D_k: injections (offset 0)
                 int32_t oA = -1, oB = -1, oC = -1;
+                uint32_t mf = 0;   // max_wavefronts of this diagonal, fetched with the candidates (same round trip)
+                // the first four set words of each candidate travel with its (offset, kind): graphs of up to 128 nodes
+                // (W <= 4) never need a second round trip for the union of the tied sets
+                uint32_t qA[4] = {0u, 0u, 0u, 0u}, qB[4] = {0u, 0u, 0u, 0u}, qC[4] = {0u, 0u, 0u, 0u};
                 if (act) {
+                    mf = e[0];
                     if (hull_has(ph, di + 1)) {
                         const uint32_t* r = e + ES + 1 + p * (2 + W);
-                        if (r[1] & 1u) oA = (int32_t)r[0] + 1;
+                        const uint32_t r0 = r[0], r1 = r[1];
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) if (j < W) qA[j] = r[2 + j];
+                        if (r1 & 1u) oA = (int32_t)r0 + 1;
                     }
                     if (hull_has(ph, di)) {
                         const uint32_t* r = e + 1 + p * (2 + W);
-                        if (r[1] == WFA_KIND_INTERIOR_READ) oB = (int32_t)r[0] + 1;
+                        const uint32_t r0 = r[0], r1 = r[1];
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) if (j < W) qB[j] = r[2 + j];
+                        if (r1 == WFA_KIND_INTERIOR_READ) oB = (int32_t)r0 + 1;
                     }
                     if (hull_has(ph, di - 1)) {
                         const uint32_t* r = e - ES + 1 + p * (2 + W);
-                        if (r[1] == WFA_KIND_INTERIOR_READ || r[1] == WFA_KIND_END_LAST) oC = (int32_t)r[0];
+                        const uint32_t r0 = r[0], r1 = r[1];
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) if (j < W) qC[j] = r[2 + j];
+                        if (r1 == WFA_KIND_INTERIOR_READ || r1 == WFA_KIND_END_LAST) oC = (int32_t)r0;
                     }
                 }
                 uint32_t inj_mask = 0;  // which parents injected on this diagonal (n_parents <= 32 checked by host)
@@ -256,25 +306,65 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                     const uint32_t rr = (pos0 >= 0 && (uint64_t)pos0 < other_len) ? (uint32_t)(other_len - (uint64_t)pos0) : 0u;
                     room = min(rn, rr);
                 }
-                const uint32_t E = (uint32_t)omax + match_run(nseq + omax, read + (has ? pos0 : 0), room);
+                PT(3);
                 bool tA = has && oA == omax, tB = has && oB == omax, tC = has && oC == omax;
                 bool tD = has && inj_mask != 0 && omax == 0;
+                // candidates behind the furthest one tie with it iff they match the read up to its start
+                const bool nA = has && oA >= 0 && oA < omax, nB = has && oB >= 0 && oB < omax, nC = has && oC >= 0 && oC < omax;
+                const bool nD = has && inj_mask != 0 && omax > 0;
+                // all sequence loads of this step go out together: the extension's first 16 bytes and the first 16
+                // bytes of every tie check (their gaps are almost always a base or two, so this settles them)
+                const uint8_t* ra = read + (has ? pos0 : 0);
+                const Pre16 pm = pre16(nseq + omax, ra, room > 0);
+                const Pre16 pA = pre16(nseq + (nA ? oA : 0), read + (nA ? (int64_t)d + oA : 0), nA);
+                const Pre16 pB = pre16(nseq + (nB ? oB : 0), read + (nB ? (int64_t)d + oB : 0), nB);
+                const Pre16 pC = pre16(nseq + (nC ? oC : 0), read + (nC ? (int64_t)d + oC : 0), nC);
+                const Pre16 pD = pre16(nseq, read + (nD ? (int64_t)d : 0), nD);
+                uint32_t E;
                 {
-                    const bool nA = has && oA >= 0 && oA < omax, nB = has && oB >= 0 && oB < omax, nC = has && oC >= 0 && oC < omax;
-                    const bool nD = has && inj_mask != 0 && omax > 0;
-                    // match_run is a wave-collective: every lane must call it (no short-circuit around the call)
-                    if (__any(nA)) { const uint32_t g = (uint32_t)(omax - oA); const uint32_t mr = match_run(nseq + (nA ? oA : 0), read + (nA ? (int64_t)d + oA : 0), nA ? g : 0u); tA = tA || (nA && mr == g); }
-                    if (__any(nB)) { const uint32_t g = (uint32_t)(omax - oB); const uint32_t mr = match_run(nseq + (nB ? oB : 0), read + (nB ? (int64_t)d + oB : 0), nB ? g : 0u); tB = tB || (nB && mr == g); }
-                    if (__any(nC)) { const uint32_t g = (uint32_t)(omax - oC); const uint32_t mr = match_run(nseq + (nC ? oC : 0), read + (nC ? (int64_t)d + oC : 0), nC ? g : 0u); tC = tC || (nC && mr == g); }
-                    if (__any(nD)) { const uint32_t g = (uint32_t)omax; const uint32_t mr = match_run(nseq, read + (nD ? (int64_t)d : 0), nD ? g : 0u); tD = tD || (nD && mr == g); }
+                    uint32_t n0 = 0;
+                    bool done = (room == 0);
+                    if (!done) {
+                        uint32_t m = pre16_len(pm);
+                        if (m > room) m = room;
+                        n0 = m;
+                        if (m < 16 || n0 >= room) done = true;
+                    }
+                    E = (uint32_t)omax + match_rest(nseq + omax, ra, room, n0, done);   // wave-collective
                 }
+                PT(4);
+                PC(3, __popcll(__ballot(has)));
+                PC(4, __popcll(__ballot(nA)) + __popcll(__ballot(nB)) + __popcll(__ballot(nC)) + __popcll(__ballot(nD)));
+                {
+                    // a tie check whose gap exceeds 16 bytes and whose first 16 match falls back to the full compare
+                    // (match_run is a wave-collective: every lane must call it, no short-circuit around the call)
+                    auto tie = [&](const Pre16& pp, bool nX, int32_t oX) -> bool {
+                        const uint32_t g = nX ? (uint32_t)(omax - oX) : 0u;
+                        bool res = false, pend = false;
+                        if (nX) {
+                            const uint32_t m = pre16_len(pp);
+                            if (g <= 16) res = (m >= g);
+                            else pend = (m == 16);
+                        }
+                        if (__any(pend)) {
+                            const uint32_t mr = match_run(nseq + (pend ? oX : 0), read + (pend ? (int64_t)d + oX : 0), pend ? g : 0u);
+                            res = res || (pend && mr == g);
+                        }
+                        return res;
+                    };
+                    const bool xA = tie(pA, nA, oA), xB = tie(pB, nB, oB), xC = tie(pC, nC, oC), xD = tie(pD, nD, 0);   // no `||`: every lane must take part
+                    tA = tA || xA;
+                    tB = tB || xB;
+                    tC = tC || xC;
+                    tD = tD || xD;
+                }
+                PT(5);
                 // ---- decide (wfa_graph.rs:463-474) -----------------------------------------------------------
                 const uint64_t pos_end = has ? (uint64_t)((int64_t)d + (int64_t)E) : 0;
                 const bool is_final = has && n == last && E == len && pos_end == other_len;
                 uint32_t kind = WFA_KIND_NONE;
                 bool inject = false;
                 if (has) {
-                    const uint32_t mf = e[0];
                     const bool skip = (E < mf) || (pos_end < min_prog);
                     if (!skip) {
                         e[0] = E;
@@ -288,22 +378,39 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                     }
                 }
                 // ---- write this round's result and the union of the tied sets ---------------------------------
+                uint32_t keep[4] = {0u, 0u, 0u, 0u};   // first four words of this diagonal's new set (reused by the hand-off below)
                 if (act) {
                     uint32_t* r = e + 1 + c * (2 + W);
                     r[0] = E;
                     r[1] = kind;
-                    for (uint32_t w = 0; w < W; ++w) {
-                        uint32_t bs = 0;
-                        if (tA) bs |= (e + ES + 1 + p * (2 + W))[2 + w];
-                        if (tB) bs |= (e + 1 + p * (2 + W))[2 + w];
-                        if (tC) bs |= (e - ES + 1 + p * (2 + W))[2 + w];
-                        if (inj_mask) {
-                            for (uint32_t k = 0; k < nd.n_parents; ++k) {
-                                uint32_t* s = e + 5 + 2 * W + k * W;
-                                if (tD) bs |= s[w];
+                    // four set words at a time: all loads first, then the stores (a store between two loads would
+                    // serialise them - the compiler cannot tell that the parities do not alias)
+                    const uint32_t* sA = e + ES + 1 + p * (2 + W) + 2;
+                    const uint32_t* sB = e + 1 + p * (2 + W) + 2;
+                    const uint32_t* sC = e - ES + 1 + p * (2 + W) + 2;
+                    for (uint32_t w0 = 0; w0 < W; w0 += 4) {
+                        uint32_t bs[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) {
+                            const uint32_t w = w0 + j;
+                            if (w < W) {
+                                if (w0 == 0) {   // fetched with the candidates
+                                    if (tA) bs[j] |= qA[j];
+                                    if (tB) bs[j] |= qB[j];
+                                    if (tC) bs[j] |= qC[j];
+                                } else {
+                                    if (tA) bs[j] |= sA[w];
+                                    if (tB) bs[j] |= sB[w];
+                                    if (tC) bs[j] |= sC[w];
+                                }
+                                if (tD) for (uint32_t k = 0; k < nd.n_parents; ++k) bs[j] |= (e + 5 + 2 * W + k * W)[w];
                             }
                         }
-                        r[2 + w] = bs;
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) {
+                            if (w0 + j < W) r[2 + w0 + j] = bs[j];
+                            if (w0 == 0) keep[j] = bs[j];
+                        }
                     }
                     if (inj_mask) {  // consume the injections (leave the slots zeroed)
                         for (uint32_t k = 0; k < nd.n_parents; ++k) {
@@ -312,12 +419,13 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                         }
                     }
                 }
+                PT(6);
                 if (__any(kind != WFA_KIND_NONE)) any_valid = true;
                 // ---- hand waves that finished this node to its successors, same round (wfa_graph.rs:527-553) ----
                 if (__any(inject)) {
                     for (uint32_t j = 0; j < nd.n_children; ++j) {
                         uint32_t cid = 0, ord = 0;
-                        if (lane == 0) { const WfaEdge ed2 = edges[nd.child_off + j]; cid = ed2.child; ord = ed2.ordinal; }
+                        { const WfaEdge ed2 = edges[nd.child_off + j]; cid = ed2.child; ord = ed2.ordinal; }   // LDS broadcast
                         cid = wb32(cid);
                         ord = wb32(ord);
                         const WfaNodeU ch = load_node(nodes + cid);
@@ -327,7 +435,10 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                         if (ok) {
                             uint32_t* s = scr + ch.entry_off + (size_t)tdi * ch.entry_stride + 5 + 2 * W + ord * W;
                             const uint32_t* r = e + 1 + c * (2 + W);
-                            for (uint32_t w = 0; w < W; ++w) {
+#pragma unroll
+                            for (uint32_t w = 0; w < 4; ++w)   // still in registers from the union above
+                                if (w < W) s[w] = keep[w] | (((cid >> 5) == w) ? 1u << (cid & 31u) : 0u);
+                            for (uint32_t w = 4; w < W; ++w) {
                                 uint32_t v = r[2 + w];
                                 if ((cid >> 5) == w) v |= 1u << (cid & 31u);
                                 s[w] = v;
@@ -346,6 +457,7 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                         }
                     }
                 }
+                PT(7);
                 // ---- finals (wfa_graph.rs:576-629): every wave of the last node that consumed node and read ----
                 if (__any(is_final)) {
                     any_final_here = true;
@@ -381,6 +493,7 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
         amax = new_amax;
     }
 
+    PT(8);
     // ---- leave the scratch zeroed for the next job of this slot -----------------------------------------
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     for (uint32_t n = 0; n < n_nodes; ++n) {
@@ -392,10 +505,17 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
         for (uint32_t i = lane; i < cnt; i += 64) b0[i] = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    PT(9);
     if (lane == 0) {
         B.status[job] = status;
         B.out_score[job] = score;
     }
+#if WFA_PROF
+    if (lane == 0 && (job % 1024) == 5)
+        printf("job %u nodes %u score %llu total %llu | init %llu skip %llu nodehead %llu gather %llu match %llu tie %llu decide+write %llu inject %llu tail %llu cleanup %llu | rounds %u skipped %u steps %u has-lanes %u tie-lanes %u\n",
+               job, n_nodes, (unsigned long long)score, (unsigned long long)(tl - tstart), (unsigned long long)pc[0], (unsigned long long)pc[1], (unsigned long long)pc[2], (unsigned long long)pc[3], (unsigned long long)pc[4], (unsigned long long)pc[5],
+               (unsigned long long)pc[6], (unsigned long long)pc[7], (unsigned long long)pc[8], (unsigned long long)pc[9], pn[0], pn[1], pn[2], pn[3], pn[4]);
+#endif
 }
 
 __global__ void __launch_bounds__(64) hp_wfa_kernel(WfaBatchDev B) {
