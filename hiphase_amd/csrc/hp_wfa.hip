@@ -179,6 +179,8 @@ int build_graph(const hp_wfa_job* job, HostJob& g) {
     g.read_ptr = job->read;
     g.seq_bytes = (g.read_off + g.read_len + 16 + 15) & ~15u;  // 8-byte compares may read past the last base
     finish_graph(g);
+    // the allele mapping walks the traversed nodes in ascending order (read_parsing.rs:790-800)
+    std::stable_sort(g.tags.begin(), g.tags.end(), [](const std::array<uint32_t, 3>& x, const std::array<uint32_t, 3>& y) { return x[0] < y[0]; });
     return HP_OK;
 }
 
@@ -553,9 +555,7 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
             for (uint32_t k = 0; k < jobs[i].n_hets; ++k) a[k] = HP_ALLELE_NOOVERLAP;
             if (status[i] == WFA_ST_OK) {
                 // read_parsing.rs:790-800: traversed nodes ascending; first assignment wins, a different one -> Ambiguous
-                std::vector<std::array<uint32_t, 3>> tags = hj[i].tags;
-                std::stable_sort(tags.begin(), tags.end(), [](const std::array<uint32_t, 3>& x, const std::array<uint32_t, 3>& y) { return x[0] < y[0]; });
-                for (auto& t : tags) {
+                for (auto& t : hj[i].tags) {   // sorted by node in build_graph
                     if (!((sets[i][t[0] >> 5] >> (t[0] & 31)) & 1u)) continue;
                     if (a[t[1]] == HP_ALLELE_NOOVERLAP) a[t[1]] = (uint8_t)t[2];
                     else if (a[t[1]] != (uint8_t)t[2]) a[t[1]] = HP_ALLELE_AMBIGUOUS;
