@@ -1,0 +1,639 @@
+// hiphase_gpu.hpp — C++17 host side ABOVE the C ABI (include/hiphase_gpu.h): the reference's own interfaces for
+// the accelerated path, with the reference's names, argument meaning and error behaviour, so that C++ callers (and
+// the parity tests in tests/cpp/) read like the Rust they stand in for. Header-only; link with -lhiphase_gpu.
+//
+// The reference is Rust and this image has no Rust toolchain, so the caller-side logic that INTEGRATION.md patches
+// into phaser.rs / read_parsing.rs is written here in C++ (hiphase_amd/*.py is the same mirror for the Python
+// tests). Every function cites the reference lines it follows. Nothing in this header computes on the CPU what the
+// library computes on the GPU: scoring, A*, graph-WFA, Levenshtein and local re-alignment all go through the C ABI
+// and fail with hiphase::Error when there is no device (the library has no CPU fallback).
+//
+//   read_segments.rs   AlleleType, ReadSegment (new / collapse / allele / qual / get_num_set)
+//   astar_phaser.rs    astar_solver -> AstarResult{haplotype_1, haplotype_2, PhaseStats}
+//   variants.rs        VariantType, Variant (constructors, truncated / padded alleles, match_allele)
+//   wfa_graph.rs +     global_realignment_batch: WFAGraph::from_reference_variants_with_hom +
+//   read_parsing.rs      edit_distance_with_pruning + the node->allele mapping, for all records of a block at once;
+//                      local_realignment_batch; load_read_segments; load_full_read_segments (incl. the
+//                      order-dependent fallback replay); sequence_alignment::edit_distance
+//   phaser.rs          get_solution_span_counts, haplotag_reads, solve_block (from decoded records on)
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "hiphase_gpu.h"
+
+namespace hiphase {
+
+// The solver never returns an error in the reference: an inconsistency is a panic! that ends the process
+// (astar_phaser.rs:631; main.rs:401-405). Here a negative C-ABI status becomes this exception.
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+inline void check(int rc, const char* where) {
+    if (rc < 0) throw Error(rc, std::string(where) + ": " + hp_last_error());
+}
+// the reference's assert!s on caller input
+inline void require(bool ok, const char* what) {
+    if (!ok) throw std::invalid_argument(what);
+}
+
+using Bytes = std::vector<uint8_t>;
+inline Bytes bytes(const std::string& s) { return Bytes(s.begin(), s.end()); }
+
+// ---- read_segments.rs ----------------------------------------------------------------------------------------
+enum class AlleleType : uint8_t { Reference = 0, Alternate = 1, Ambiguous = 2, NoOverlap = 3 };  // read_segments.rs:5-16
+
+class ReadSegment {  // read_segments.rs:19-62 — one clipped matrix row
+public:
+    // ReadSegment::new: clips to [first set allele, last set allele + 1); no set allele -> len..len
+    ReadSegment(std::string read_name, const Bytes& alleles, const Bytes& quals) : read_name_(std::move(read_name)) {
+        require(alleles.size() == quals.size(), "alleles and quals differ in length");
+        const size_t n = alleles.size();
+        size_t first = n, last = n;
+        for (size_t i = 0; i < n; ++i) if (alleles[i] < (uint8_t)AlleleType::Ambiguous) { first = i; break; }
+        for (size_t i = n; i-- > 0;) if (alleles[i] < (uint8_t)AlleleType::Ambiguous) { last = i + 1; break; }
+        start_ = first;
+        end_ = last;
+        alleles_.assign(alleles.begin() + first, alleles.begin() + last);
+        quals_.assign(quals.begin() + first, quals.begin() + last);
+    }
+    const std::string& read_name() const { return read_name_; }
+    std::pair<size_t, size_t> region() const { return {start_, end_}; }
+    size_t start() const { return start_; }
+    size_t end() const { return end_; }
+    const Bytes& alleles() const { return alleles_; }
+    const Bytes& quals() const { return quals_; }
+    uint8_t allele(size_t i) const {  // read_segments.rs:128-134
+        return (i >= start_ && i < end_) ? alleles_[i - start_] : (uint8_t)AlleleType::NoOverlap;
+    }
+    uint8_t qual(size_t i) const {  // read_segments.rs:137-143
+        return (i >= start_ && i < end_) ? quals_[i - start_] : 0;
+    }
+    size_t get_num_set() const {  // read_segments.rs:151-155
+        size_t n = 0;
+        for (uint8_t a : alleles_) n += a < (uint8_t)AlleleType::Ambiguous;
+        return n;
+    }
+    // read_segments.rs:71-121: merge the mappings of one read; first non-NoOverlap wins, equal alleles keep the
+    // larger quality (which must be > 0), different alleles -> Ambiguous with quality 0; then re-clip
+    static ReadSegment collapse(const std::vector<ReadSegment>& rs) {
+        require(!rs.empty(), "collapse of nothing");
+        if (rs.size() == 1) return rs[0];
+        size_t min_start = rs[0].start_, max_end = rs[0].end_;
+        for (const auto& r : rs) { min_start = std::min(min_start, r.start_); max_end = std::max(max_end, r.end_); }
+        Bytes alleles(max_end, (uint8_t)AlleleType::NoOverlap), quals(max_end, 0);
+        for (const auto& r : rs) {
+            require(r.read_name_ == rs[0].read_name_, "collapse of different reads");
+            for (size_t i = min_start; i < max_end; ++i) {
+                const uint8_t a = r.allele(i), q = r.qual(i);
+                if (a == (uint8_t)AlleleType::NoOverlap) continue;
+                if (alleles[i] == (uint8_t)AlleleType::NoOverlap) { alleles[i] = a; quals[i] = q; }
+                else if (alleles[i] == (uint8_t)AlleleType::Ambiguous) {}
+                else if (alleles[i] == a) {
+                    quals[i] = std::max(quals[i], q);
+                    require(quals[i] > 0, "assert!(quals[i] > 0) (read_segments.rs:105)");
+                } else { alleles[i] = (uint8_t)AlleleType::Ambiguous; quals[i] = 0; }
+            }
+        }
+        return ReadSegment(rs[0].read_name_, alleles, quals);
+    }
+    bool operator==(const ReadSegment& o) const {
+        return read_name_ == o.read_name_ && start_ == o.start_ && end_ == o.end_ && alleles_ == o.alleles_ && quals_ == o.quals_;
+    }
+
+private:
+    std::string read_name_;
+    size_t start_ = 0, end_ = 0;
+    Bytes alleles_, quals_;
+};
+
+// The solver's IntervalTree<usize, ReadSegment> (phaser.rs:514-533) as the CSR view the C ABI takes.
+struct BlockMatrix {
+    std::vector<uint32_t> read_start, read_end;
+    std::vector<uint64_t> row_off;
+    Bytes alleles_2bit, quals, var_flags;
+    BlockMatrix(const std::vector<ReadSegment>& segs, const Bytes& flags) : var_flags(flags) {
+        row_off.push_back(0);
+        Bytes cells;
+        for (const auto& s : segs) {
+            read_start.push_back((uint32_t)s.start());
+            read_end.push_back((uint32_t)s.end());
+            row_off.push_back(row_off.back() + (s.end() - s.start()));
+            cells.insert(cells.end(), s.alleles().begin(), s.alleles().end());
+            quals.insert(quals.end(), s.quals().begin(), s.quals().end());
+        }
+        alleles_2bit.assign((cells.size() + 3) / 4 + 1, 0);
+        for (size_t i = 0; i < cells.size(); ++i) alleles_2bit[i >> 2] |= (uint8_t)(cells[i] << (2 * (i & 3)));
+        if (quals.empty()) quals.push_back(0);
+    }
+    hp_block_view view() const {
+        hp_block_view v{};
+        v.n_variants = (uint32_t)var_flags.size();
+        v.n_reads = (uint32_t)read_start.size();
+        v.read_start = read_start.data();
+        v.read_end = read_end.data();
+        v.row_off = row_off.data();
+        v.alleles_2bit = alleles_2bit.data();
+        v.quals = quals.data();
+        v.var_flags = var_flags.data();
+        return v;
+    }
+};
+
+// ---- variants.rs ---------------------------------------------------------------------------------------------
+enum class VariantType : uint32_t {  // variants.rs:10-33
+    Snv = 0, Insertion, Deletion, Indel, SvInsertion, SvDeletion, SvDuplication, SvInversion, SvBreakend, TandemRepeat, Unknown
+};
+// read_parsing.rs:18-22: base qualities per type; global re-alignment doubles them (read_parsing.rs:815)
+inline uint8_t base_quality(VariantType t) {
+    switch (t) {
+        case VariantType::Snv: return 80;
+        case VariantType::Insertion: case VariantType::Deletion: case VariantType::Indel: return 10;
+        case VariantType::SvInsertion: case VariantType::SvDeletion: return 20;
+        case VariantType::TandemRepeat: return 40;
+        default: throw std::invalid_argument("variant type without a base quality (read_parsing.rs:18-22)");
+    }
+}
+
+struct Variant {  // what the path reads from a `Variant` (variants.rs:67-94)
+    uint32_t vcf_index = 0;
+    VariantType variant_type = VariantType::Unknown;
+    int64_t position = 0;
+    uint32_t ref_len = 0;
+    Bytes allele0, allele1;            // truncated alleles (variants.rs:581-591): what the WFA graph uses
+    uint32_t index_allele0 = 0, index_allele1 = 1;
+    bool is_ignored = false;
+    Bytes prefix, postfix;             // +-reference_buffer padding (variants.rs:497-539), local re-alignment only
+
+    Bytes get_allele0() const { Bytes a = prefix; a.insert(a.end(), allele0.begin(), allele0.end()); a.insert(a.end(), postfix.begin(), postfix.end()); return a; }
+    Bytes get_allele1() const { Bytes a = prefix; a.insert(a.end(), allele1.begin(), allele1.end()); a.insert(a.end(), postfix.begin(), postfix.end()); return a; }
+    uint8_t match_allele(const Bytes& a) const {  // variants.rs:598-606
+        return a == get_allele0() ? 0 : (a == get_allele1() ? 1 : 2);
+    }
+    // constructors with the reference's validation essentials (variants.rs:109-492)
+    static Variant make(uint32_t vi, VariantType t, int64_t pos, uint32_t rl, Bytes a0, Bytes a1, uint32_t i0, uint32_t i1) {
+        Variant v;
+        v.vcf_index = vi; v.variant_type = t; v.position = pos; v.ref_len = rl;
+        v.allele0 = std::move(a0); v.allele1 = std::move(a1); v.index_allele0 = i0; v.index_allele1 = i1;
+        return v;
+    }
+    static Variant new_snv(uint32_t vi, int64_t pos, Bytes a0, Bytes a1, uint32_t i0, uint32_t i1) {
+        require(i0 < i1 && a0.size() == 1 && a1.size() == 1, "new_snv");
+        return make(vi, VariantType::Snv, pos, 1, std::move(a0), std::move(a1), i0, i1);
+    }
+    static Variant new_deletion(uint32_t vi, int64_t pos, uint32_t rl, Bytes a0, Bytes a1, uint32_t i0, uint32_t i1) {
+        require(i0 < i1 && rl > 1 && a1.size() == 1 && a0.size() == (i0 == 0 ? rl : 1u), "new_deletion");
+        return make(vi, VariantType::Deletion, pos, rl, std::move(a0), std::move(a1), i0, i1);
+    }
+    static Variant new_insertion(uint32_t vi, int64_t pos, Bytes a0, Bytes a1, uint32_t i0, uint32_t i1) {
+        require(i0 < i1 && !a1.empty() && (i0 == 0 ? a0.size() == 1 : !a0.empty()), "new_insertion");
+        return make(vi, VariantType::Insertion, pos, 1, std::move(a0), std::move(a1), i0, i1);
+    }
+    static Variant new_indel(uint32_t vi, int64_t pos, uint32_t rl, Bytes a0, Bytes a1, uint32_t i0, uint32_t i1) {
+        require(i0 < i1 && rl > 1 && !a1.empty() && (i0 == 0 ? a0.size() == rl : !a0.empty()), "new_indel");
+        return make(vi, VariantType::Indel, pos, rl, std::move(a0), std::move(a1), i0, i1);
+    }
+    static Variant new_sv_deletion(uint32_t vi, int64_t pos, uint32_t rl, Bytes a0, Bytes a1) {
+        require(a0.size() == rl && !a1.empty() && a1.size() <= a0.size(), "new_sv_deletion");
+        return make(vi, VariantType::SvDeletion, pos, rl, std::move(a0), std::move(a1), 0, 1);
+    }
+    static Variant new_sv_insertion(uint32_t vi, int64_t pos, uint32_t rl, Bytes a0, Bytes a1) {
+        require(a0.size() == rl && !a0.empty() && a1.size() >= a0.size(), "new_sv_insertion");
+        return make(vi, VariantType::SvInsertion, pos, rl, std::move(a0), std::move(a1), 0, 1);
+    }
+    static Variant new_tandem_repeat(uint32_t vi, int64_t pos, uint32_t rl, Bytes a0, Bytes a1, uint32_t i0, uint32_t i1) {
+        require(i0 < i1 && !a0.empty() && !a1.empty() && (i0 != 0 || a0.size() == rl), "new_tandem_repeat");
+        return make(vi, VariantType::TandemRepeat, pos, rl, std::move(a0), std::move(a1), i0, i1);
+    }
+};
+
+// ---- astar_phaser.rs -----------------------------------------------------------------------------------------
+struct PhaseStats {  // writers/phase_stats.rs:131-173 (the solver's fields)
+    uint64_t pruned_solutions = 0, estimated_cost = 0, actual_cost = 0, phased_variants = 0, phased_snvs = 0,
+             homozygous_variants = 0, skipped_variants = 0;
+    bool operator==(const PhaseStats& o) const {
+        return pruned_solutions == o.pruned_solutions && estimated_cost == o.estimated_cost && actual_cost == o.actual_cost &&
+               phased_variants == o.phased_variants && phased_snvs == o.phased_snvs &&
+               homozygous_variants == o.homozygous_variants && skipped_variants == o.skipped_variants;
+    }
+};
+struct AstarResult {  // astar_phaser.rs:408-415
+    Bytes haplotype_1, haplotype_2;
+    PhaseStats statistics;
+};
+inline Bytes variant_flags(const std::vector<Variant>& variants) {  // what astar_solver reads from &[Variant]
+    Bytes f(variants.size());
+    for (size_t i = 0; i < variants.size(); ++i)
+        f[i] = (uint8_t)((variants[i].is_ignored ? HP_VAR_IGNORED : 0) | (variants[i].variant_type == VariantType::Snv ? HP_VAR_SNV : 0));
+    return f;
+}
+// astar_solver(phase_block, variants, read_segments, min_queue_size, queue_increment) (astar_phaser.rs:426-429):
+// from the PhaseBlock only the index is read (diagnostics), from each Variant is_ignored() and get_type() == Snv
+inline AstarResult astar_solver(uint64_t block_index, const Bytes& var_flags, const std::vector<ReadSegment>& read_segments,
+                                uint64_t min_queue_size = 1000, uint64_t queue_increment = 3) {
+    const BlockMatrix m(read_segments, var_flags);
+    const hp_block_view v = m.view();
+    hp_astar_params p{min_queue_size, queue_increment, 0, block_index};
+    AstarResult r;
+    r.haplotype_1.assign(var_flags.size(), 0);
+    r.haplotype_2.assign(var_flags.size(), 0);
+    hp_phase_stats st{};
+    check(hp_astar_solve(&v, &p, r.haplotype_1.data(), r.haplotype_2.data(), &st), "hp_astar_solve");
+    r.statistics = PhaseStats{st.pruned_solutions, st.estimated_cost, st.actual_cost, st.phased_variants, st.phased_snvs,
+                              st.homozygous_variants, st.skipped_variants};
+    return r;
+}
+inline AstarResult astar_solver(uint64_t block_index, const std::vector<Variant>& variants, const std::vector<ReadSegment>& read_segments,
+                                uint64_t min_queue_size = 1000, uint64_t queue_increment = 3) {
+    return astar_solver(block_index, variant_flags(variants), read_segments, min_queue_size, queue_increment);
+}
+
+// ---- sequence_alignment.rs -----------------------------------------------------------------------------------
+inline uint64_t edit_distance(const Bytes& v1, const Bytes& v2) {  // sequence_alignment.rs:7-38
+    static const uint8_t none = 0;
+    hp_ed_pair pr{v1.empty() ? &none : v1.data(), v2.empty() ? &none : v2.data(), (uint32_t)v1.size(), (uint32_t)v2.size()};
+    uint64_t out = 0;
+    check(hp_edit_distance_batch(&pr, 1, &out, -1), "hp_edit_distance_batch");
+    return out;
+}
+
+// ---- read_parsing.rs -----------------------------------------------------------------------------------------
+struct GlobalRealignmentConfig {  // read_parsing.rs:25-34 (defaults: cli.rs:189-210)
+    uint64_t max_edit_distance = 500, wfa_prune_distance = 500;
+    double global_failure_ratio = 0.5;
+    uint64_t global_failure_minimum = 50;
+};
+struct LocalRecord {  // what local_realignment reads from a bam::Record (read_parsing.rs:121-160)
+    std::string qname;
+    int64_t pos = 0;
+    std::vector<uint32_t> cigar;   // BAM encoding: len << 4 | op (MIDNSHP=X = 0..8)
+    Bytes seq, qual;
+};
+struct AlignedRecord {  // what global_realignment needs from one record (read_parsing.rs:672-742)
+    std::string qname;
+    int64_t min_position = 0, max_position = 0;   // first / last reference base of the alignment (inclusive)
+    Bytes read_align;                             // seq[read_start..=read_end]
+    bool has_local = false;
+    LocalRecord local;                            // CIGAR view of the same record (needed when it falls back)
+};
+struct LoadStats {
+    uint64_t num_reads = 0, skipped_reads = 0, global_aligned = 0, local_aligned = 0;
+    std::vector<uint64_t> edit_distances;
+};
+struct WfaOutcome {  // Ok(WFAResult) mapped to per-het alleles (read_parsing.rs:790-800) | Err(MaxEditDistance)
+    bool max_edit_distance = false;
+    uint64_t score = 0;
+    uint32_t num_nodes = 0;
+    Bytes alleles;   // one AlleleType per het variant handed to the job
+};
+struct WfaJob {  // one record's WFAGraph::from_reference_variants_with_hom + edit_distance_with_pruning
+    const Bytes* reference = nullptr;   // chromosome (or slice) with (*reference)[0] at coordinate ref_base
+    uint64_t ref_base = 0, ref_start = 0, ref_end = 0;
+    const Variant* hets = nullptr; size_t n_hets = 0;
+    const Variant* homs = nullptr; size_t n_homs = 0;
+    const Bytes* read = nullptr;
+};
+namespace detail {
+inline void pack_variants(const Variant* v, size_t n, std::vector<hp_wfa_variant>& out) {
+    static const uint8_t none = 0;
+    for (size_t i = 0; i < n; ++i) {
+        hp_wfa_variant w{};
+        w.position = v[i].position;
+        w.ref_len = v[i].ref_len;
+        w.flags = (v[i].is_ignored ? 1u : 0u) | (v[i].index_allele0 != 0 ? 2u : 0u);
+        w.allele0 = v[i].allele0.empty() ? &none : v[i].allele0.data();
+        w.allele1 = v[i].allele1.empty() ? &none : v[i].allele1.data();
+        w.allele0_len = (uint32_t)v[i].allele0.size();
+        w.allele1_len = (uint32_t)v[i].allele1.size();
+        out.push_back(w);
+    }
+}
+// indices [first, last) of the variants with lo <= position <= hi (read_parsing.rs:688-700, 721-730)
+inline bool overlap_range(const std::vector<Variant>& v, int64_t lo, int64_t hi, size_t& first, size_t& last) {
+    bool any = false;
+    for (size_t i = 0; i < v.size(); ++i)
+        if (lo <= v[i].position && v[i].position <= hi) { if (!any) { first = i; any = true; } last = i + 1; }
+    return any;
+}
+}  // namespace detail
+
+// read_parsing.rs:769-800 for a batch of records: one hp_wfa_assign_batch call
+inline std::vector<WfaOutcome> global_realignment_batch(const std::vector<WfaJob>& jobs, uint64_t prune_distance, uint64_t max_edit_distance) {
+    const size_t n = jobs.size();
+    std::vector<WfaOutcome> out(n);
+    if (n == 0) return out;
+    std::vector<std::vector<hp_wfa_variant>> hv(n), mv(n);
+    std::vector<hp_wfa_job> cj(n);
+    std::vector<uint8_t*> ptrs(n);
+    static const uint8_t none = 0;
+    for (size_t i = 0; i < n; ++i) {
+        detail::pack_variants(jobs[i].hets, jobs[i].n_hets, hv[i]);
+        detail::pack_variants(jobs[i].homs, jobs[i].n_homs, mv[i]);
+        hp_wfa_job j{};
+        j.reference = jobs[i].reference->data();
+        j.ref_base = jobs[i].ref_base; j.ref_start = jobs[i].ref_start; j.ref_end = jobs[i].ref_end;
+        j.hets = hv[i].data(); j.n_hets = (uint32_t)hv[i].size();
+        j.homs = mv[i].data(); j.n_homs = (uint32_t)mv[i].size();
+        j.read = jobs[i].read->empty() ? &none : jobs[i].read->data();
+        j.read_len = (uint32_t)jobs[i].read->size();
+        cj[i] = j;
+        out[i].alleles.assign(std::max<size_t>(jobs[i].n_hets, 1), (uint8_t)AlleleType::NoOverlap);
+        ptrs[i] = out[i].alleles.data();
+    }
+    std::vector<hp_wfa_result> res(n);
+    check(hp_wfa_assign_batch(cj.data(), n, prune_distance == 0 ? UINT64_MAX : prune_distance, max_edit_distance, res.data(), ptrs.data(), -1),
+          "hp_wfa_assign_batch");
+    for (size_t i = 0; i < n; ++i) {
+        out[i].alleles.resize(jobs[i].n_hets);
+        out[i].max_edit_distance = res[i].status == HP_WFA_MAX_ED;
+        out[i].score = res[i].score;
+        out[i].num_nodes = res[i].n_nodes;
+    }
+    return out;
+}
+
+struct LocalResult { Bytes alleles, quals; hp_read_stats stats; };
+// `local_realignment(read, variant_calls)` (read_parsing.rs:121-503) for a list of records: hp_local_realign_batch
+inline std::vector<LocalResult> local_realignment_batch(const std::vector<const LocalRecord*>& records, const std::vector<Variant>& variant_calls) {
+    const size_t nr = records.size(), nv = variant_calls.size();
+    std::vector<LocalResult> out(nr);
+    if (nr == 0) return out;
+    static const uint8_t none = 0;
+    static const uint32_t none32 = 0;
+    std::vector<Bytes> a0(nv), a1(nv);
+    std::vector<hp_local_variant> vs(std::max<size_t>(nv, 1));
+    for (size_t i = 0; i < nv; ++i) {
+        const Variant& v = variant_calls[i];
+        a0[i] = v.get_allele0();
+        a1[i] = v.get_allele1();
+        hp_local_variant w{};
+        w.position = v.position; w.ref_len = v.ref_len; w.variant_type = (uint32_t)v.variant_type;
+        w.prefix_len = (uint32_t)v.prefix.size(); w.postfix_len = (uint32_t)v.postfix.size();
+        w.allele0 = a0[i].empty() ? &none : a0[i].data(); w.allele1 = a1[i].empty() ? &none : a1[i].data();
+        w.allele0_len = (uint32_t)a0[i].size(); w.allele1_len = (uint32_t)a1[i].size();
+        w.flags = v.is_ignored ? HP_VAR_IGNORED : 0;
+        vs[i] = w;
+    }
+    std::vector<hp_local_read> rs(nr);
+    for (size_t i = 0; i < nr; ++i) {
+        const LocalRecord& r = *records[i];
+        require(r.seq.size() == r.qual.size(), "assert_eq!(sequence length, quality length) (read_parsing.rs:155)");
+        hp_local_read lr{};
+        lr.pos = r.pos;
+        lr.cigar = r.cigar.empty() ? &none32 : r.cigar.data();
+        lr.n_cigar = (uint32_t)r.cigar.size();
+        lr.seq_len = (uint32_t)r.seq.size();
+        lr.seq = r.seq.empty() ? &none : r.seq.data();
+        lr.qual = r.qual.empty() ? &none : r.qual.data();
+        rs[i] = lr;
+    }
+    const size_t stride = std::max<size_t>(nv, 1);
+    Bytes alleles(nr * stride, 0), quals(nr * stride, 0);
+    std::vector<hp_read_stats> stats(nr);
+    check(hp_local_realign_batch(rs.data(), nr, vs.data(), nv, alleles.data(), quals.data(), stats.data(), -1), "hp_local_realign_batch");
+    for (size_t i = 0; i < nr; ++i) {
+        out[i].alleles.assign(alleles.begin() + i * stride, alleles.begin() + i * stride + nv);
+        out[i].quals.assign(quals.begin() + i * stride, quals.begin() + i * stride + nv);
+        out[i].stats = stats[i];
+    }
+    return out;
+}
+
+struct LoadedSegments {
+    std::vector<ReadSegment> read_segments, phasable_segments;   // first-seen qname order
+    LoadStats stats;
+};
+namespace detail {
+// collapse per qname + the min_matched_alleles split (read_parsing.rs:611-629 / :95-113)
+inline void finish_groups(const std::vector<std::string>& order, std::map<std::string, std::vector<ReadSegment>>& groups,
+                          size_t min_matched_alleles, LoadedSegments& out) {
+    for (const auto& q : order) {
+        auto& grp = groups[q];
+        ReadSegment col = ReadSegment::collapse(grp);
+        const size_t num_set = col.get_num_set();
+        if (num_set >= min_matched_alleles) { out.read_segments.push_back(col); out.stats.num_reads += grp.size(); }
+        else { out.stats.skipped_reads += grp.size(); if (num_set > 0) out.phasable_segments.push_back(col); }
+    }
+}
+inline void add_to_group(const std::string& q, ReadSegment seg, std::vector<std::string>& order, std::map<std::string, std::vector<ReadSegment>>& groups) {
+    auto it = groups.find(q);
+    if (it == groups.end()) { order.push_back(q); groups[q].push_back(std::move(seg)); }
+    else it->second.push_back(std::move(seg));
+}
+}  // namespace detail
+
+// load_read_segments (read_parsing.rs:47-113, --disable-global-realignment) over decoded records
+inline LoadedSegments load_read_segments(const std::vector<LocalRecord>& records, const std::vector<Variant>& variant_calls, size_t min_matched_alleles = 2) {
+    std::vector<const LocalRecord*> ptrs;
+    for (const auto& r : records) ptrs.push_back(&r);
+    const auto res = local_realignment_batch(ptrs, variant_calls);
+    LoadedSegments out;
+    std::vector<std::string> order;
+    std::map<std::string, std::vector<ReadSegment>> groups;
+    for (size_t i = 0; i < records.size(); ++i) {
+        if (res[i].stats.skipped_reads == 0) {
+            detail::add_to_group(records[i].qname, ReadSegment(records[i].qname, res[i].alleles, res[i].quals), order, groups);
+            out.stats.local_aligned += 1;
+        } else out.stats.skipped_reads += 1;
+    }
+    detail::finish_groups(order, groups, min_matched_alleles, out);
+    return out;
+}
+
+// load_full_read_segments (read_parsing.rs:520-637): one WFA batch for the block, then the order-dependent tail
+// replayed exactly as the reference runs it — Err(MaxEditDistance) -> local re-alignment of that record (:564-575);
+// the `global_disabled` switch (:597-600), whose counters advance only for records that were not skipped; qualities
+// 2 x base(type) for 0/1 alleles (:803-835); ReadSegment::new; collapse per qname; min_matched_alleles split.
+inline LoadedSegments load_full_read_segments(const std::vector<AlignedRecord>& records, const std::vector<Variant>& variant_calls,
+                                              const std::vector<Variant>& hom_calls, const Bytes& reference, uint64_t ref_base = 0,
+                                              size_t min_matched_alleles = 2, const GlobalRealignmentConfig& config = GlobalRealignmentConfig()) {
+    const size_t n_var = variant_calls.size(), n_rec = records.size();
+    struct Meta { bool any = false; size_t job = 0, first = 0, last = 0; };
+    std::vector<Meta> meta(n_rec);
+    std::vector<WfaJob> jobs;
+    for (size_t i = 0; i < n_rec; ++i) {
+        const AlignedRecord& rec = records[i];
+        size_t first = 0, last = 0;
+        if (!detail::overlap_range(variant_calls, rec.min_position, rec.max_position, first, last)) continue;   // :703-712
+        size_t hf = 0, hl = 0;
+        const bool homs = detail::overlap_range(hom_calls, rec.min_position, rec.max_position, hf, hl);
+        WfaJob j;
+        j.reference = &reference; j.ref_base = ref_base;
+        j.ref_start = (uint64_t)rec.min_position; j.ref_end = (uint64_t)rec.max_position + 1;
+        j.hets = variant_calls.data() + first; j.n_hets = last - first;
+        j.homs = homs ? hom_calls.data() + hf : nullptr; j.n_homs = homs ? hl - hf : 0;
+        j.read = &rec.read_align;
+        meta[i] = Meta{true, jobs.size(), first, last};
+        jobs.push_back(j);
+    }
+    const auto results = global_realignment_batch(jobs, config.wfa_prune_distance, config.max_edit_distance);
+
+    // A record's local result does not depend on any other record: the WFA failures are solved up front in one
+    // batch, everything after the `global_disabled` flip the first time the replay needs it.
+    std::map<size_t, LocalResult> local_rows;
+    auto solve_local = [&](std::vector<size_t> idx) {
+        std::vector<size_t> need;
+        std::vector<const LocalRecord*> ptrs;
+        for (size_t i : idx) {
+            if (local_rows.count(i)) continue;
+            if (!records[i].has_local) throw std::logic_error("record needs local re-alignment (read_parsing.rs:121-503), which needs its CIGAR: set AlignedRecord::local");
+            need.push_back(i);
+            ptrs.push_back(&records[i].local);
+        }
+        auto res = local_realignment_batch(ptrs, variant_calls);
+        for (size_t k = 0; k < need.size(); ++k) local_rows[need[k]] = std::move(res[k]);
+    };
+    {
+        std::vector<size_t> failed;
+        for (size_t i = 0; i < n_rec; ++i) if (meta[i].any && results[meta[i].job].max_edit_distance) failed.push_back(i);
+        solve_local(failed);
+    }
+    LoadedSegments out;
+    std::vector<std::string> order;
+    std::map<std::string, std::vector<ReadSegment>> groups;
+    bool global_disabled = false;
+    double num_global_failures = 0.0, total_parsed = 0.0;
+    for (size_t idx = 0; idx < n_rec; ++idx) {
+        const Meta& m = meta[idx];
+        if (!m.any) { out.stats.skipped_reads += 1; continue; }
+        const WfaOutcome& w = results[m.job];
+        Bytes alleles, quals;
+        uint64_t wfa_score;
+        bool skipped;
+        double local_aligned;
+        if (global_disabled || w.max_edit_distance) {
+            if (!local_rows.count(idx)) {
+                std::vector<size_t> rest;
+                for (size_t i = idx; i < n_rec; ++i) if (meta[i].any) rest.push_back(i);
+                solve_local(rest);
+            }
+            const LocalResult& l = local_rows[idx];
+            alleles = l.alleles; quals = l.quals;
+            wfa_score = config.max_edit_distance;
+            skipped = l.stats.skipped_reads == 1;
+            local_aligned = 1.0;
+        } else {
+            alleles.assign(n_var, (uint8_t)AlleleType::NoOverlap);
+            quals.assign(n_var, 0);
+            for (size_t i = m.first; i < m.last; ++i) {
+                alleles[i] = w.alleles[i - m.first];
+                if (alleles[i] < 2) quals[i] = (uint8_t)(2 * base_quality(variant_calls[i].variant_type));
+            }
+            wfa_score = w.score;
+            skipped = false;
+            local_aligned = 0.0;
+        }
+        if (skipped) { out.stats.skipped_reads += 1; continue; }
+        out.stats.local_aligned += (uint64_t)local_aligned;
+        out.stats.global_aligned += 1 - (uint64_t)local_aligned;
+        detail::add_to_group(records[idx].qname, ReadSegment(records[idx].qname, alleles, quals), order, groups);
+        out.stats.edit_distances.push_back(wfa_score);
+        num_global_failures += local_aligned;
+        total_parsed += 1.0;
+        if (!global_disabled && num_global_failures >= (double)config.global_failure_minimum &&
+            num_global_failures / total_parsed >= config.global_failure_ratio)
+            global_disabled = true;   // read_parsing.rs:597-600
+    }
+    detail::finish_groups(order, groups, min_matched_alleles, out);
+    return out;
+}
+
+// ---- phaser.rs -----------------------------------------------------------------------------------------------
+// get_solution_span_counts (phaser.rs:350-388): per juncture, the reads spanning it after trimming the ends of the
+// read that the solution leaves homozygous
+inline std::vector<uint64_t> get_solution_span_counts(const std::vector<ReadSegment>& read_segments, const Bytes& h1, const Bytes& h2) {
+    std::vector<uint64_t> counts(h1.empty() ? 0 : h1.size() - 1, 0);
+    for (const auto& rs : read_segments) {
+        if (rs.end() == rs.start()) continue;
+        size_t js = rs.start(), je = rs.end() - 1;
+        while (js < je && h1[js] == h2[js]) ++js;
+        while (js < je && h1[je] == h2[je]) --je;
+        for (size_t j = js; j < je; ++j) counts[j] += 1;
+    }
+    return counts;
+}
+struct Haplotag { std::string read_name; int64_t phase_block = 0; uint8_t haplotag = 0; };
+// haplotag_reads (phaser.rs:714-750): argmin of the two haplotype scores, ties untagged; PS = the tag of the first
+// het the read resolves. Rows in read_segments order (the reference's hash map is keyed by read name).
+inline std::vector<Haplotag> haplotag_reads(const std::vector<ReadSegment>& read_segments, const Bytes& h1, const Bytes& h2,
+                                            const std::vector<int64_t>& block_tags) {
+    std::vector<Haplotag> out;
+    for (const auto& rs : read_segments) {
+        uint64_t s1 = 0, s2 = 0;
+        for (size_t i = rs.start(); i < rs.end(); ++i) {   // score_haplotype (read_segments.rs:161-206)
+            const uint8_t a = rs.allele(i), q = rs.qual(i);
+            if (h1[i] < 2 && a != h1[i]) s1 += q;
+            if (h2[i] < 2 && a != h2[i]) s2 += q;
+        }
+        if (s1 == s2) continue;
+        size_t first = rs.start();
+        while (h1[first] == h2[first] || rs.allele(first) >= (uint8_t)AlleleType::Ambiguous) ++first;
+        out.push_back(Haplotag{rs.read_name(), block_tags[first], (uint8_t)(s1 < s2 ? 0 : 1)});
+    }
+    return out;
+}
+
+struct PhaseResult {  // phaser.rs:326-343 (the solver-facing fields)
+    Bytes haplotype_1, haplotype_2;
+    std::vector<int64_t> block_ids;                    // PS tag per variant
+    std::vector<std::vector<size_t>> sub_phase_blocks; // phased hets per sub-block
+    PhaseStats statistics;
+    std::vector<Haplotag> haplotags;
+    LoadStats load_stats;
+    std::vector<ReadSegment> read_segments;
+};
+// solve_block (phaser.rs:406-649) from the decoded records on: allele assignment (global: WFA batch + fallback
+// replay; else local re-alignment) -> matrix -> A* -> span counts -> sub-block split (:546-611) -> haplotags
+inline PhaseResult solve_block(uint64_t block_index, const std::vector<AlignedRecord>& records, const std::vector<Variant>& variant_calls,
+                               const std::vector<Variant>& hom_calls, const Bytes& reference, uint64_t ref_base = 0,
+                               size_t min_matched_alleles = 2, uint64_t min_queue_size = 1000, uint64_t queue_increment = 3,
+                               const GlobalRealignmentConfig* global_config = nullptr, bool global_realignment = true) {
+    require(!variant_calls.empty(), "solve_block needs at least one variant");
+    LoadedSegments ls;
+    if (global_realignment) {
+        ls = load_full_read_segments(records, variant_calls, hom_calls, reference, ref_base, min_matched_alleles,
+                                     global_config ? *global_config : GlobalRealignmentConfig());
+    } else {
+        std::vector<LocalRecord> loc;
+        for (const auto& r : records) { require(r.has_local, "local mode needs the CIGAR view of every record"); loc.push_back(r.local); }
+        ls = load_read_segments(loc, variant_calls, min_matched_alleles);
+    }
+    PhaseResult pr;
+    const AstarResult res = astar_solver(block_index, variant_calls, ls.read_segments, min_queue_size, queue_increment);
+    pr.haplotype_1 = res.haplotype_1;
+    pr.haplotype_2 = res.haplotype_2;
+    pr.statistics = res.statistics;
+    const auto spans = get_solution_span_counts(ls.read_segments, pr.haplotype_1, pr.haplotype_2);
+    int64_t cur = variant_calls[0].position;
+    for (size_t i = 0; i < variant_calls.size(); ++i) {   // phaser.rs:557-565
+        if (i > 0 && spans[i - 1] == 0) cur = variant_calls[i].position;
+        pr.block_ids.push_back(cur);
+    }
+    std::vector<size_t> block;                            // phaser.rs:569-611
+    int64_t cur_tag = pr.block_ids[0];
+    for (size_t i = 0; i < variant_calls.size(); ++i) {
+        const uint8_t a = pr.haplotype_1[i], b = pr.haplotype_2[i];
+        if (a < 2 && b < 2 && a != b) {
+            if (cur_tag != pr.block_ids[i]) {
+                if (!block.empty()) { pr.sub_phase_blocks.push_back(block); block.clear(); }
+                cur_tag = pr.block_ids[i];
+            }
+            block.push_back(i);
+        }
+    }
+    if (!block.empty()) pr.sub_phase_blocks.push_back(block);
+    pr.haplotags = haplotag_reads(ls.read_segments, pr.haplotype_1, pr.haplotype_2, pr.block_ids);
+    // reads with too few alleles to enter the solver are still tagged against the solution (phaser.rs:620-630)
+    for (auto& t : haplotag_reads(ls.phasable_segments, pr.haplotype_1, pr.haplotype_2, pr.block_ids)) pr.haplotags.push_back(t);
+    pr.load_stats = ls.stats;
+    pr.read_segments = std::move(ls.read_segments);
+    return pr;
+}
+
+}  // namespace hiphase
