@@ -473,6 +473,24 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
         std::vector<int> rcs(nt, HP_OK);
         std::vector<std::string> errs(nt);
         auto work = [&](unsigned t) {
+            {   // exact capacities up front: no reallocation copies while packing (rows with an empty region are dropped,
+                // so the row tables may end up a little shorter; malformed views are rejected by pack_block)
+                uint64_t rows = 0, cells = 0, vars = 0, abytes = 0;
+                for (size_t i = n_blocks * t / nt; i < n_blocks * (t + 1) / nt; ++i) {
+                    const hp_block_view& v = blks[i];
+                    if (!v.row_off || v.n_reads > (1u << 28) || v.n_variants > (1u << 24)) { rows = 0; cells = 0; vars = 0; abytes = 0; break; }
+                    const uint64_t c = v.n_reads ? v.row_off[v.n_reads] : 0;
+                    if (c > (1ull << 40)) { rows = 0; cells = 0; vars = 0; abytes = 0; break; }
+                    rows += v.n_reads; cells += c; vars += v.n_variants; abytes += (c + 3) / 4;
+                }
+                HostPack& q = parts[t];
+                try {
+                    q.vlo.reserve(vars); q.vhi.reserve(vars); q.vflags.reserve(vars);
+                    q.rstart.reserve(rows); q.rend.reserve(rows); q.rword.reserve(rows); q.rcell.reserve(rows);
+                    q.row_block.reserve(rows); q.row_orig.reserve(rows);
+                    q.raw_alleles.reserve(abytes); q.raw_quals.reserve(cells);
+                } catch (...) {}   // a hint only: a view with absurd sizes is reported by pack_block, not here
+            }
             for (size_t i = n_blocks * t / nt; i < n_blocks * (t + 1) / nt; ++i) {
                 const int rc = pack_block(&blks[i], parts[t]);
                 if (rc != HP_OK) {
@@ -504,9 +522,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
                 if (d.cell_off != ~0ull) d.cell_off += acc.cell;
                 hpk.desc.push_back(d);
             }
-            for (uint32_t rb : q.row_block) hpk.row_block.push_back(rb + acc.blk);
             for (const PackRaw& pr : q.raw) hpk.raw.push_back(PackRaw{pr.allele_off + acc.ral, pr.qual_off + acc.rq});
-            hpk.row_orig.insert(hpk.row_orig.end(), q.row_orig.begin(), q.row_orig.end());
             for (uint64_t o : q.caller_row_off) hpk.caller_row_off.push_back(o + acc.rows);
             hpk.work.insert(hpk.work.end(), q.work.begin(), q.work.end());
             hpk.max_n = std::max(hpk.max_n, q.max_n);
@@ -516,7 +532,23 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
             acc.blk += (uint32_t)q.desc.size();
         }
         hpk.h_total = acc.h; hpk.chunk_total = acc.chunk; hpk.cell_total = acc.cell; hpk.caller_rows = acc.rows;
+        // the two per-row tables the batch keeps on the host (tens of millions of rows): merged by the same threads
+        hpk.row_block.resize(acc.read);
+        hpk.row_orig.resize(acc.read);
+        auto merge_rows = [&](unsigned t) {
+            const HostPack& q = parts[t];
+            uint32_t* rb = hpk.row_block.data() + base[t].read;
+            for (size_t i = 0; i < q.row_block.size(); ++i) rb[i] = q.row_block[i] + base[t].blk;
+            if (!q.row_orig.empty()) std::memcpy(hpk.row_orig.data() + base[t].read, q.row_orig.data(), q.row_orig.size() * sizeof(q.row_orig[0]));
+        };
+        if (nt == 1) merge_rows(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(merge_rows, t);
+            for (auto& x : th) x.join();
+        }
     }
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp]   merged the per-thread parts at %.1f ms\n", wall_ms() - t_pack0); fflush(stderr); }
     const uint64_t tot_vars = base[nt - 1].var + parts[nt - 1].vlo.size(), tot_rows = base[nt - 1].read + parts[nt - 1].rstart.size();
     const uint64_t tot_words = base[nt - 1].word + parts[nt - 1].n_words;
     const uint64_t tot_ral = base[nt - 1].ral + parts[nt - 1].raw_alleles.size(), tot_rq = base[nt - 1].rq + parts[nt - 1].raw_quals.size();
@@ -534,11 +566,11 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     for (const BlockDesc& d : hpk.desc) if (d.ctab_shift == 7) b->tiles = 2;
     b->sum_h = hpk.h_total;
     b->sum_n = tot_vars;
-    b->row_orig = hpk.row_orig;
-    b->row_block_h = hpk.row_block;
-    b->caller_row_off = hpk.caller_row_off;
+    b->row_orig = std::move(hpk.row_orig);
+    b->row_block_h = std::move(hpk.row_block);
+    b->caller_row_off = std::move(hpk.caller_row_off);
     b->caller_rows = hpk.caller_rows;
-    b->n_rows_packed = hpk.row_block.size();
+    b->n_rows_packed = b->row_block_h.size();
     b->n_cu = device_cu_count(device_id);
     {
         StreamSet ss;
@@ -547,6 +579,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
         if (!ok) { set_error("creating the streams/events of a batch failed"); return fail(HP_ERR_HIP); }
     }
 
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp]   batch object filled at %.1f ms\n", wall_ms() - t_pack0); fflush(stderr); }
     SolveParams& prm = b->prm;
     prm.minq_main = (uint32_t)p->min_queue_size;
     prm.minq_sub = (uint32_t)(p->min_queue_size / 10);
@@ -590,25 +623,26 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
             return fail(HP_ERR_HIP);
         }
     }
-    if ((rc = upload(b->d_row_block, hpk.row_block, s)) != HP_OK) return fail(rc);
+    if ((rc = upload(b->d_row_block, b->row_block_h, s)) != HP_OK) return fail(rc);
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp]   uploads queued at %.1f ms\n", wall_ms() - t_pack0); fflush(stderr); }
     // the bit-sliced plane words are built on the device from the caller's cells
-    if (!hpk.row_block.empty()) {
+    if (!b->row_block_h.empty()) {
         PackDev P{};
         P.desc = b->d_desc.as<BlockDesc>(); P.raw = d_raw.as<PackRaw>(); P.row_block = b->d_row_block.as<uint32_t>();
         P.rstart = b->d_rstart.as<uint32_t>(); P.rend = b->d_rend.as<uint32_t>(); P.rword = b->d_rword.as<uint32_t>();
         P.rcell = d_rcell.as<uint64_t>(); P.alleles = d_ral.as<uint8_t>(); P.quals = d_rq.as<uint8_t>();
-        P.words = b->d_words.as<uint32_t>(); P.n_rows = hpk.row_block.size();
+        P.words = b->d_words.as<uint32_t>(); P.n_rows = b->row_block_h.size();
         hipLaunchKernelGGL(hp_pack_words_kernel, dim3((unsigned)((P.n_rows + 255) / 256)), dim3(256), 0, s, P);
         if (hipGetLastError() != hipSuccess) { set_error("hp_pack_words_kernel launch failed"); return fail(HP_ERR_HIP); }
     }
     // per-position cell tables are derived on the device from the rows just uploaded
     if ((rc = b->d_ctab.alloc(hpk.cell_total * sizeof(uint32_t) + 16)) != HP_OK) return fail(rc);
-    if (hpk.cell_total && !hpk.row_block.empty()) {
+    if (hpk.cell_total && !b->row_block_h.empty()) {
         if (hipMemsetAsync(b->d_ctab.p, 0, hpk.cell_total * sizeof(uint32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return fail(HP_ERR_HIP); }
         CtabDev T{};
         T.desc = b->d_desc.as<BlockDesc>(); T.row_block = b->d_row_block.as<uint32_t>();
         T.rstart = b->d_rstart.as<uint32_t>(); T.rend = b->d_rend.as<uint32_t>(); T.rword = b->d_rword.as<uint32_t>();
-        T.words = b->d_words.as<uint32_t>(); T.ctab = b->d_ctab.as<uint32_t>(); T.n_rows = hpk.row_block.size();
+        T.words = b->d_words.as<uint32_t>(); T.ctab = b->d_ctab.as<uint32_t>(); T.n_rows = b->row_block_h.size();
         T.vflags = b->d_vflags.as<uint8_t>();
         hipLaunchKernelGGL(hp_build_ctab_kernel, dim3((unsigned)((T.n_rows + 3) / 4)), dim3(256), 0, s, T);
         if (hipGetLastError() != hipSuccess) { set_error("hp_build_ctab_kernel launch failed"); return fail(HP_ERR_HIP); }
