@@ -138,11 +138,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("HP_BENCH_BACKEND", "nccl")   # "gloo": control-flow test of the N>1 path on a box with fewer GPUs
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank %= max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
 
     from hiphase_amd import ResidentBatch, _ffi
     lib = _ffi.lib()
@@ -172,7 +178,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         from hiphase_amd.shard import max_over_ranks
-        elapsed = max_over_ranks(dist, elapsed, device="cuda")   # timing only; no block data crosses ranks
+        elapsed = max_over_ranks(dist, elapsed, device="cuda" if backend == "nccl" else "cpu")   # timing only; no block data crosses ranks
 
     res, ctrs, _ = rb.results()
     cells_per_step = sum(c.cells for c in ctrs)
