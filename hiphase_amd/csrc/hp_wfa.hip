@@ -14,7 +14,6 @@
 #include <memory>
 #include <numeric>
 #include <atomic>
-#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -99,14 +98,41 @@ int build_graph(const hp_wfa_job* job, HostJob& g) {
     uint64_t previous_end = ref_start;
     std::vector<uint32_t> reference_reconnect;
     std::vector<std::pair<uint32_t, uint32_t>> reference_alleles;  // (het index, 0)
-    std::set<std::pair<uint64_t, uint32_t>> reconnect_queue;       // (reconnect position, alt node); ties in any order
+    // (reconnect position, alt node), smallest first; a handful of entries at most, so a sorted vector (no node
+    // allocations) stands in for the reference's priority queue; ties in any order
+    struct ReconnectQueue {
+        std::vector<std::pair<uint64_t, uint32_t>> v;
+        bool empty() const { return v.empty(); }
+        const std::pair<uint64_t, uint32_t>* begin() const { return v.data(); }
+        void insert(std::pair<uint64_t, uint32_t> x) { v.insert(std::upper_bound(v.begin(), v.end(), x), x); }
+        void erase(const std::pair<uint64_t, uint32_t>*) { v.erase(v.begin()); }
+    } reconnect_queue;
 
     struct VarRef { const hp_wfa_variant* v; int64_t index; };
     std::vector<VarRef> all;
     all.reserve((size_t)job->n_hets + job->n_homs);
     for (uint32_t i = 0; i < job->n_hets; ++i) all.push_back({&job->hets[i], (int64_t)i});
     for (uint32_t i = 0; i < job->n_homs; ++i) all.push_back({&job->homs[i], -1});
-    std::stable_sort(all.begin(), all.end(), [](const VarRef& a, const VarRef& b) { return a.v->position < b.v->position; });
+    {   // stable by position, hets before homs on ties (wfa_graph.rs:137-144); both lists normally arrive sorted, then a
+        // merge does it without stable_sort's temporary buffer
+        auto by_pos = [](const VarRef& a, const VarRef& b) { return a.v->position < b.v->position; };
+        const auto mid = all.begin() + job->n_hets;
+        if (std::is_sorted(all.begin(), mid, by_pos) && std::is_sorted(mid, all.end(), by_pos)) {
+            std::vector<VarRef> merged(all.size());
+            std::merge(all.begin(), mid, mid, all.end(), merged.begin(), by_pos);
+            all.swap(merged);
+        } else std::stable_sort(all.begin(), all.end(), by_pos);
+    }
+    {   // capacities up front: at most 3 nodes per variant + 2, one or two parents each
+        size_t alt_bytes = 0;
+        for (auto& vr : all) alt_bytes += (size_t)vr.v->allele1_len + ((vr.v->flags & 2u) ? vr.v->allele0_len : 0u);
+        g.nodes.reserve(3 * all.size() + 2);
+        g.par.reserve(6 * all.size() + 4);
+        g.tags.reserve(2 * (size_t)job->n_hets + 2);
+        g.alt.reserve(alt_bytes);
+        reference_reconnect.reserve(8);
+        reconnect_queue.v.reserve(8);
+    }
 
     auto flush_ref_alleles = [&](int node) {
         for (auto& ra : reference_alleles) g.tags.push_back({(uint32_t)node, ra.first, ra.second});
@@ -180,7 +206,9 @@ int build_graph(const hp_wfa_job* job, HostJob& g) {
     g.seq_bytes = (g.read_off + g.read_len + 16 + 15) & ~15u;  // 8-byte compares may read past the last base
     finish_graph(g);
     // the allele mapping walks the traversed nodes in ascending order (read_parsing.rs:790-800)
-    std::stable_sort(g.tags.begin(), g.tags.end(), [](const std::array<uint32_t, 3>& x, const std::array<uint32_t, 3>& y) { return x[0] < y[0]; });
+    // (tags are pushed when the node they name is created, so they normally are in node order already)
+    auto by_node = [](const std::array<uint32_t, 3>& x, const std::array<uint32_t, 3>& y) { return x[0] < y[0]; };
+    if (!std::is_sorted(g.tags.begin(), g.tags.end(), by_node)) std::stable_sort(g.tags.begin(), g.tags.end(), by_node);
     return HP_OK;
 }
 
