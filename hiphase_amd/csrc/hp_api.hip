@@ -31,10 +31,11 @@ DevCache::~DevCache() {
 }
 }  // namespace
 
-void* dev_cache_get(size_t bytes, size_t* got) {
+void* dev_cache_get(size_t bytes, size_t* got, int* dev_out) {
     const size_t want = DevCache::round_up(bytes);
     int dev = 0;
     (void)hipGetDevice(&dev);
+    *dev_out = dev;
     if (g_dev_cache_dead) {
         void* q = nullptr;
         hipError_t e = hipMalloc(&q, want);
@@ -75,16 +76,13 @@ int device_cu_count(int device_id) {
     return v;
 }
 
-void dev_cache_put(void* p, size_t bytes) {
+void dev_cache_put(void* p, size_t bytes, int dev) {   // dev: what dev_cache_get reported for this block
     if (g_dev_cache_dead) { (void)hipFree(p); return; }
     DevCache& c = g_dev_cache;
-    int dev = 0;
-    if (bytes > DevCache::kMaxBlock || c.cached + bytes > DevCache::kMaxCached || hipGetDevice(&dev) != hipSuccess) {
+    if (bytes > DevCache::kMaxBlock || c.cached + bytes > DevCache::kMaxCached) {
         (void)hipFree(p);
         return;
     }
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
     c.free_.insert({{dev, bytes}, p});
     c.cached += bytes;
 }

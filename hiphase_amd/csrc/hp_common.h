@@ -26,8 +26,8 @@ extern thread_local double g_last_kernel_ms;  // see hp_last_kernel_ms()  // thr
 // hipMalloc / hipFree cost ~100 us each and synchronise the device. Blocks are handed back to the cache instead of
 // being freed and re-used by later calls of the same thread on the same device (sizes are rounded up so that they
 // match); the cache is bounded and released at thread exit. hp_common.h declares, hp_api.hip defines.
-void* dev_cache_get(size_t bytes, size_t* got);       // nullptr on failure (error set)
-void dev_cache_put(void* p, size_t bytes);
+void* dev_cache_get(size_t bytes, size_t* got, int* dev);   // nullptr on failure (error set); *dev = the device it lives on
+void dev_cache_put(void* p, size_t bytes, int dev);
 
 // number of compute units of a device, queried once (hipGetDeviceProperties costs milliseconds per call)
 int device_cu_count(int device_id);
@@ -36,12 +36,13 @@ int device_cu_count(int device_id);
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    int dev = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) dev_cache_put(p, bytes);
+        if (p) dev_cache_put(p, bytes, dev);
         p = nullptr;
         bytes = 0;
     }
@@ -50,7 +51,7 @@ struct DevBuf {
         if (n == 0) n = 16;
         if (p && bytes >= n) return HP_OK;
         release();
-        p = dev_cache_get(n, &bytes);
+        p = dev_cache_get(n, &bytes, &dev);
         if (!p) { bytes = 0; return HP_ERR_OOM; }
         return HP_OK;
     }

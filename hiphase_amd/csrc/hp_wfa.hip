@@ -28,7 +28,8 @@ struct HostNode {          // POD: parent / child lists live in the job's flat a
     int64_t emin, emax;           // shortest / longest path length from the root to this node's first base
 };
 
-struct HostJob {
+// graph under construction: a per-thread scratch whose vectors keep their capacity from one read to the next
+struct GraphBuild {
     std::vector<HostNode> nodes;
     std::vector<uint32_t> par, child;
     // device sequence buffer layout: [ref slice][alt allele bytes][read][pad]; only the (small) allele bytes are
@@ -40,10 +41,53 @@ struct HostJob {
     uint32_t read_off = 0, read_len = 0, seq_bytes = 0;
     // node_to_alleles (wfa_graph.rs:19): (node, het index, allele)
     std::vector<std::array<uint32_t, 3>> tags;
+    void clear() { nodes.clear(); par.clear(); child.clear(); alt.clear(); tags.clear(); ref_ptr = read_ptr = nullptr; ref_len = read_off = read_len = seq_bytes = 0; }
+};
+// The finished graphs of all reads a worker thread built live back to back in that thread's arena (five
+// allocations per thread instead of five per read; freed in one go), a HostJob is a set of views into it.
+template <class T> struct View {
+    const T* p = nullptr;
+    size_t n = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    const T* data() const { return p; }
+    const T* begin() const { return p; }
+    const T* end() const { return p + n; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+struct GraphArena {
+    std::vector<HostNode> nodes;
+    std::vector<uint32_t> par, child;
+    std::vector<uint8_t> alt;
+    std::vector<std::array<uint32_t, 3>> tags;
+};
+struct HostJob {
+    View<HostNode> nodes;
+    View<uint32_t> par, child;
+    View<uint8_t> alt;
+    View<std::array<uint32_t, 3>> tags;
+    const uint8_t* ref_ptr = nullptr;
+    const uint8_t* read_ptr = nullptr;
+    uint32_t ref_len = 0, read_off = 0, read_len = 0, seq_bytes = 0;
+    size_t off[5] = {0, 0, 0, 0, 0};   // arena offsets until the views are bound (the arena may still grow)
+    void stash(const GraphBuild& g, GraphArena& a) {
+        off[0] = a.nodes.size(); off[1] = a.par.size(); off[2] = a.child.size(); off[3] = a.alt.size(); off[4] = a.tags.size();
+        a.nodes.insert(a.nodes.end(), g.nodes.begin(), g.nodes.end());
+        a.par.insert(a.par.end(), g.par.begin(), g.par.end());
+        a.child.insert(a.child.end(), g.child.begin(), g.child.end());
+        a.alt.insert(a.alt.end(), g.alt.begin(), g.alt.end());
+        a.tags.insert(a.tags.end(), g.tags.begin(), g.tags.end());
+        nodes.n = g.nodes.size(); par.n = g.par.size(); child.n = g.child.size(); alt.n = g.alt.size(); tags.n = g.tags.size();
+        ref_ptr = g.ref_ptr; read_ptr = g.read_ptr; ref_len = g.ref_len; read_off = g.read_off; read_len = g.read_len; seq_bytes = g.seq_bytes;
+    }
+    void bind(const GraphArena& a) {
+        nodes.p = a.nodes.data() + off[0]; par.p = a.par.data() + off[1]; child.p = a.child.data() + off[2];
+        alt.p = a.alt.data() + off[3]; tags.p = a.tags.data() + off[4];
+    }
 };
 
 // WFAGraph::add_node (wfa_graph.rs:298-331)
-int add_node(HostJob& g, uint32_t seq_off, uint32_t seq_len, const std::vector<uint32_t>& parents) {
+int add_node(GraphBuild& g, uint32_t seq_off, uint32_t seq_len, const std::vector<uint32_t>& parents) {
     const uint32_t idx = (uint32_t)g.nodes.size();
     if (idx == 0) { if (!parents.empty()) return -1; }
     else {
@@ -62,7 +106,7 @@ int add_node(HostJob& g, uint32_t seq_off, uint32_t seq_len, const std::vector<u
 }
 
 // children lists (edges[p].push(child) in creation order) + path-length ranges, once all nodes exist
-void finish_graph(HostJob& g) {
+void finish_graph(GraphBuild& g) {
     const size_t nn = g.nodes.size();
     std::vector<uint32_t> cnt(nn + 1, 0);
     for (size_t n = 0; n < nn; ++n)
@@ -88,7 +132,7 @@ void finish_graph(HostJob& g) {
 
 // from_reference_variants_with_hom (wfa_graph.rs:119-284). Reference nodes are spans of the copied
 // reference slice; allele nodes are spans of the appended allele bytes.
-int build_graph(const hp_wfa_job* job, HostJob& g) {
+int build_graph(const hp_wfa_job* job, GraphBuild& g) {
     if (job->ref_end < job->ref_start || job->ref_start < job->ref_base) { set_error("bad reference window"); return HP_ERR_ARG; }
     const size_t ref_len = (size_t)(job->ref_end - job->ref_start);
     g.ref_ptr = job->reference + (job->ref_start - job->ref_base);
@@ -415,7 +459,7 @@ template <class T> int up(DevBuf& buf, const std::vector<T>& v) {
 
 // one launch over `ids` with capacity `band`; fills status/score/sets for those jobs
 int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, uint32_t band, uint64_t prune, uint64_t max_ed,
-             int n_cu, std::vector<int32_t>& status, std::vector<uint64_t>& score, std::vector<std::vector<uint32_t>>& sets) {
+             int n_cu, std::vector<int32_t>& status, std::vector<uint64_t>& score, std::vector<uint32_t>& sets, const std::vector<uint64_t>& set_off) {
     WfaPack pk;
     {
         size_t tot = 0, nn = 0;
@@ -499,9 +543,9 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     for (size_t i = 0; i < n; ++i) {
         status[ids[i]] = st[i];
         score[ids[i]] = sc[i];
-        sets[ids[i]].assign(all_sets.begin() + pk.jobs[i].out_set_off, all_sets.begin() + pk.jobs[i].out_set_off + pk.jobs[i].set_words);
+        std::memcpy(sets.data() + set_off[ids[i]], all_sets.data() + pk.jobs[i].out_set_off, (size_t)pk.jobs[i].set_words * 4);
     }
-    if (verbose) { fprintf(stderr, "[hp] wfa download+scatter %.2f ms\n", now_ms() - t_dl); fflush(stderr); }
+    if (verbose) { fprintf(stderr, "[hp] wfa download+scatter %.2f ms (pass so far %.2f ms)\n", now_ms() - t_dl, now_ms() - t_pk0); fflush(stderr); }
     return HP_OK;
 }
 
@@ -510,12 +554,22 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
 
 using namespace hp;
 
+static int wfa_assign_batch_impl(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
+                                 hp_wfa_result* out, uint8_t* const* alleles, int device_id);
 extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
                                    hp_wfa_result* out, uint8_t* const* alleles, int device_id) {
+    const double t0 = now_ms();
+    const int rc = wfa_assign_batch_impl(jobs, n, prune_distance, max_ed, out, alleles, device_id);
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] hp_wfa_assign_batch total %.2f ms\n", now_ms() - t0); fflush(stderr); }
+    return rc;
+}
+static int wfa_assign_batch_impl(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
+                                 hp_wfa_result* out, uint8_t* const* alleles, int device_id) {
     if (n == 0) return HP_OK;
     if (!jobs || !out) { set_error("null argument"); return HP_ERR_ARG; }
     if (n > 0x7FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
     if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
+    std::vector<GraphArena> arenas;
     std::vector<HostJob> hj(n);
     g_last_kernel_ms = 0.0;
     const double t_build = now_ms();
@@ -525,17 +579,23 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
         const unsigned nt = wfa_host_threads(n);
         std::atomic<int> first_rc{HP_OK};
         std::vector<std::string> errs(nt);
+        arenas.resize(nt);
         auto work = [&](unsigned t) {
+            GraphBuild g;
+            GraphArena& arena = arenas[t];
             for (size_t i = t; i < n && first_rc.load(std::memory_order_relaxed) == HP_OK; i += nt) {
                 int rc = HP_OK;
+                g.clear();
                 if (!jobs[i].reference || (!jobs[i].read && jobs[i].read_len)) { set_error("job %zu: null sequence", i); rc = HP_ERR_ARG; }
-                else rc = build_graph(&jobs[i], hj[i]);
+                else rc = build_graph(&jobs[i], g);
                 if (rc != HP_OK) {
                     int exp = HP_OK;
                     if (first_rc.compare_exchange_strong(exp, rc)) errs[t] = hp_last_error();
                     return;
                 }
+                hj[i].stash(g, arena);
             }
+            for (size_t i = t; i < n; i += nt) hj[i].bind(arena);
         };
         if (nt == 1) work(0);
         else {
@@ -556,14 +616,17 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
 
     std::vector<int32_t> status(n, WFA_ST_PENDING);
     std::vector<uint64_t> score(n, 0);
-    std::vector<std::vector<uint32_t>> sets(n);
+    // traversed-node bitsets of all jobs in one flat array ((n_nodes + 31) / 32 words per job)
+    std::vector<uint64_t> set_off(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) set_off[i + 1] = set_off[i] + (hj[i].nodes.size() + 31) / 32;
+    std::vector<uint32_t> sets(set_off[n], 0);
     std::vector<uint32_t> ids(n);
     std::iota(ids.begin(), ids.end(), 0u);
     // pass 1 with a narrow band (most reads finish within a few dozen edits); the rest re-run at full width
     const char* benv = std::getenv("HP_WFA_BAND");
     uint32_t band = (uint32_t)std::min<uint64_t>(max_ed, benv ? (uint64_t)std::atoi(benv) : 96);
     for (;;) {
-        int rc = run_pass(hj, ids, band, prune_distance, max_ed, n_cu, status, score, sets);
+        int rc = run_pass(hj, ids, band, prune_distance, max_ed, n_cu, status, score, sets, set_off);
         if (rc != HP_OK) return rc;
         std::vector<uint32_t> again;
         for (uint32_t id : ids) if (status[id] == WFA_ST_NEED_BAND) again.push_back(id);
@@ -573,24 +636,37 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
         ids.swap(again);
     }
     const double t_map = now_ms();
-    for (size_t i = 0; i < n; ++i) {
+    for (size_t i = 0; i < n; ++i)
         if (status[i] != WFA_ST_OK && status[i] != WFA_ST_MAX_ED) { set_error("job %zu: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
-        out[i].status = status[i] == WFA_ST_OK ? HP_OK : HP_WFA_MAX_ED;
-        out[i].n_nodes = (uint32_t)hj[i].nodes.size();
-        out[i].score = score[i];
-        if (alleles && alleles[i]) {
-            uint8_t* a = alleles[i];
-            for (uint32_t k = 0; k < jobs[i].n_hets; ++k) a[k] = HP_ALLELE_NOOVERLAP;
-            if (status[i] == WFA_ST_OK) {
-                // read_parsing.rs:790-800: traversed nodes ascending; first assignment wins, a different one -> Ambiguous
-                for (auto& t : hj[i].tags) {   // sorted by node in build_graph
-                    if (!((sets[i][t[0] >> 5] >> (t[0] & 31)) & 1u)) continue;
-                    if (a[t[1]] == HP_ALLELE_NOOVERLAP) a[t[1]] = (uint8_t)t[2];
-                    else if (a[t[1]] != (uint8_t)t[2]) a[t[1]] = HP_ALLELE_AMBIGUOUS;
+    auto map_jobs = [&](unsigned t, unsigned nt) {
+        for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
+            out[i].status = status[i] == WFA_ST_OK ? HP_OK : HP_WFA_MAX_ED;
+            out[i].n_nodes = (uint32_t)hj[i].nodes.size();
+            out[i].score = score[i];
+            if (alleles && alleles[i]) {
+                uint8_t* a = alleles[i];
+                for (uint32_t k = 0; k < jobs[i].n_hets; ++k) a[k] = HP_ALLELE_NOOVERLAP;
+                if (status[i] == WFA_ST_OK) {
+                    // read_parsing.rs:790-800: traversed nodes ascending; first assignment wins, a different one -> Ambiguous
+                    const uint32_t* set = sets.data() + set_off[i];
+                    for (auto& t3 : hj[i].tags) {   // sorted by node in build_graph
+                        if (!((set[t3[0] >> 5] >> (t3[0] & 31)) & 1u)) continue;
+                        if (a[t3[1]] == HP_ALLELE_NOOVERLAP) a[t3[1]] = (uint8_t)t3[2];
+                        else if (a[t3[1]] != (uint8_t)t3[2]) a[t3[1]] = HP_ALLELE_AMBIGUOUS;
+                    }
                 }
             }
         }
+    };
+    {
+        const unsigned nt = wfa_host_threads(n);
+        if (nt == 1) map_jobs(0, 1);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(map_jobs, t, nt);
+            for (auto& x : th) x.join();
+        }
     }
-    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa allele mapping %.2f ms\n", now_ms() - t_map); fflush(stderr); }
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa allele mapping %.2f ms (function body so far %.2f ms)\n", now_ms() - t_map, now_ms() - t_build); fflush(stderr); }
     return HP_OK;
 }

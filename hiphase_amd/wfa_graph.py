@@ -189,7 +189,11 @@ class PreparedWfaBatch:
     def run(self, prune_distance=500, max_edit_distance=500, device_id=0):
         dll = _ffi.lib()
         prune = (2 ** 64 - 1) if prune_distance in (0, None) else prune_distance
-        _ffi.check(dll.hp_wfa_assign_batch(self.jobs, self.n, prune, max_edit_distance, self.out, self.ptrs, device_id))
+        import time
+        t0 = time.perf_counter()
+        rc = dll.hp_wfa_assign_batch(self.jobs, self.n, prune, max_edit_distance, self.out, self.ptrs, device_id)
+        self.last_call_s = time.perf_counter() - t0   # the C call alone (the result list below is Python overhead)
+        _ffi.check(rc)
         return [(self.out[i].status, self.out[i].score, self.out[i].n_nodes, self.alleles[i][:len(self.specs[i].hets)])
                 for i in range(self.n)]
 

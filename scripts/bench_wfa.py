@@ -23,7 +23,7 @@ pb.run()  # steady state: a worker thread's staging buffers and band scratch are
 t0 = time.perf_counter(); res = pb.run(); dt = time.perf_counter() - t0
 kms = _ffi.lib().hp_last_kernel_ms()
 bases = sum(len(s.read) for s in specs)
-out = {"jobs": args.jobs, "c_call_s": dt, "kernel_ms": kms, "kernel_reads_per_s": args.jobs / (kms * 1e-3), "reads_per_s": args.jobs / dt, "read_bases_per_s": bases / dt,
+out = {"jobs": args.jobs, "c_call_s": pb.last_call_s, "python_call_s": dt, "kernel_ms": kms, "kernel_reads_per_s": args.jobs / (kms * 1e-3), "reads_per_s": args.jobs / pb.last_call_s, "read_bases_per_s": bases / pb.last_call_s,
        "mean_score": float(np.mean([r[1] for r in res])), "max_score": int(max(r[1] for r in res))}
 import oracle_ffi
 d = oracle_ffi.oracle()
