@@ -117,6 +117,37 @@ def cpu_baseline_all_cores(args, blocks, skip):
             "sample": f"{sum(done)} hets of the same batch, one block per thread at a time on {n_thr} threads, {dt:.1f}s"}
 
 
+def wfa_secondary(device_id):
+    """Second line item (not `value`): the graph-WFA allele assignment that builds the matrix rows (SURVEY.md §8d 'WFA
+    synthetic': 17-kb reads over 24 het + 8 hom variants, 0.4 % noise), one hp_wfa_assign_batch call of 4096 reads in
+    steady state, with a live parity check of a sample against the oracle."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi
+    from hiphase_amd import _ffi
+    from hiphase_amd.wfa_graph import PreparedWfaBatch, make_jobs
+    from wfa_util import synth_wfa_job
+    base = [synth_wfa_job(1000 + s, ref_len=17000, n_vars=24, n_homs=8, noise=0.004)[0] for s in range(32)]
+    specs = [base[i % len(base)] for i in range(4096)]
+    pb = PreparedWfaBatch(specs)
+    pb.run(device_id=device_id)
+    res = pb.run(device_id=device_id)
+    call_s, kms = pb.last_call_s, _ffi.lib().hp_last_kernel_ms()
+    d = oracle_ffi.oracle()
+    ok, t0 = True, time.perf_counter()
+    for i in range(4):
+        jobs, keep = make_jobs([specs[i]])
+        o = _ffi.WfaResult()
+        al = np.full(max(1, len(specs[i].hets)), 3, np.uint8)
+        d.hpo_wfa_assign(C.byref(jobs[0]), 500, 500, C.byref(o), al.ctypes.data)
+        ok = ok and (res[i][0], res[i][1], res[i][2]) == (o.status, o.score, o.n_nodes) and np.array_equal(res[i][3], al[:len(specs[i].hets)])
+    cpu = (time.perf_counter() - t0) / 4
+    return {"reads": len(specs), "read_len": 17000, "kernel_ms": kms, "kernel_reads_per_s": len(specs) / (kms * 1e-3),
+            "c_call_ms": call_s * 1e3, "reads_per_s": len(specs) / call_s, "cpu_oracle_reads_per_s": 1.0 / cpu,
+            "parity": {"reads_compared": 4, "bit_identical": bool(ok)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,6 +290,7 @@ def main():
             h2 = sum(b.n_variants for b in b2)
             out["secondary_wgs_like"] = {"blocks": len(b2), "hets": h2, "kernel_ms": ms2, "hets_per_s": h2 / (ms2 * 1e-3),
                                          "note": "lognormal block sizes (median 15, max 4000); segment-parallel heuristic on"}
+            out["secondary_graph_wfa"] = wfa_secondary(local_rank)
         print(json.dumps(out), flush=True)
     rb.close()
     if dist is not None:
