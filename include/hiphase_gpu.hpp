@@ -8,9 +8,9 @@
 // library computes on the GPU: scoring, A*, graph-WFA, Levenshtein and local re-alignment all go through the C ABI
 // and fail with hiphase::Error when there is no device (the library has no CPU fallback).
 //
-//   read_segments.rs   AlleleType, ReadSegment (new / collapse / allele / qual / get_num_set)
+//   read_segments.rs   AlleleType, ReadSegment (new / collapse / allele / qual / get_num_set / score_*_haplotype)
 //   astar_phaser.rs    astar_solver -> AstarResult{haplotype_1, haplotype_2, PhaseStats}
-//   variants.rs        VariantType, Variant (constructors, truncated / padded alleles, match_allele)
+//   variants.rs        VariantType, Variant (constructors, truncated / padded alleles, match_allele), closest_allele_clip
 //   wfa_graph.rs +     global_realignment_batch: WFAGraph::from_reference_variants_with_hom +
 //   read_parsing.rs      edit_distance_with_pruning + the node->allele mapping, for all records of a block at once;
 //                      local_realignment_batch; load_read_segments; load_full_read_segments (incl. the
@@ -74,6 +74,23 @@ public:
     }
     uint8_t qual(size_t i) const {  // read_segments.rs:137-143
         return (i >= start_ && i < end_) ? quals_[i - start_] : 0;
+    }
+    // score_partial_haplotype (read_segments.rs:177-206): qualities of the cells where the haplotype (starting at
+    // variant `offset`) is set and differs from the read; 0 when they do not overlap. On the solver path this is what
+    // the kernels compute on the device; the host form is for callers and tests, as in the reference.
+    uint64_t score_partial_haplotype(const Bytes& haplotype, size_t offset) const {
+        if (haplotype.size() + offset <= start_ || offset >= end_) return 0;
+        const size_t lo = std::max(start_, offset), hi = std::min(end_, offset + haplotype.size());
+        uint64_t sum = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            const uint8_t h = haplotype[i - offset];
+            if (h < (uint8_t)AlleleType::Ambiguous && allele(i) != h) sum += qual(i);
+        }
+        return sum;
+    }
+    uint64_t score_haplotype(const Bytes& haplotype) const {  // read_segments.rs:161-168
+        require(end_ <= haplotype.size(), "assert!(region.end <= haplotype.len()) (read_segments.rs:163)");
+        return score_partial_haplotype(haplotype, 0);
     }
     size_t get_num_set() const {  // read_segments.rs:151-155
         size_t n = 0;
@@ -261,6 +278,24 @@ inline uint64_t edit_distance(const Bytes& v1, const Bytes& v2) {  // sequence_a
     uint64_t out = 0;
     check(hp_edit_distance_batch(&pr, 1, &out, -1), "hp_edit_distance_batch");
     return out;
+}
+
+// Variant::closest_allele_clip (variants.rs:624-641): the allele (0 / 1 / 2 = Ambiguous on a tie) nearer to `allele`
+// in edit distance once `head_clip` / `tail_clip` bases are removed from both padded alleles; both distances ride along
+struct ClosestAllele { uint8_t allele; uint64_t min_ed, other_ed; };
+inline ClosestAllele closest_allele_clip(const Variant& v, const Bytes& allele, size_t head_clip = 0, size_t tail_clip = 0) {
+    const Bytes f0 = v.get_allele0(), f1 = v.get_allele1();
+    require(head_clip + tail_clip <= f0.size() && head_clip + tail_clip <= f1.size(), "clip longer than an allele");
+    const Bytes a0(f0.begin() + head_clip, f0.end() - tail_clip), a1(f1.begin() + head_clip, f1.end() - tail_clip);
+    static const uint8_t none = 0;
+    auto ptr = [](const Bytes& b) { return b.empty() ? &none : b.data(); };
+    hp_ed_pair pr[2] = {{ptr(allele), ptr(a0), (uint32_t)allele.size(), (uint32_t)a0.size()},
+                        {ptr(allele), ptr(a1), (uint32_t)allele.size(), (uint32_t)a1.size()}};
+    uint64_t d[2] = {0, 0};
+    check(hp_edit_distance_batch(pr, 2, d, -1), "hp_edit_distance_batch");
+    if (d[0] < d[1]) return {0, d[0], d[1]};
+    if (d[0] > d[1]) return {1, d[1], d[0]};
+    return {2, d[0], d[1]};
 }
 
 // ---- read_parsing.rs -----------------------------------------------------------------------------------------

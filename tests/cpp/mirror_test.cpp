@@ -48,6 +48,38 @@ static void test_read_segment_empty_and_num_set() {
     CHECK(rs.allele(0) == 3 && rs.allele(7) == 1 && rs.allele(8) == 3 && rs.qual(8) == 0);
 }
 
+static void test_score_haplotype() {   // fn test_score_haplotype / fn test_score_partial_haplotype
+    const ReadSegment rs("read_name", {3, 0, 1, 0, 0, 1, 2, 1, 3, 3}, {0, 1, 2, 3, 4, 5, 6, 7, 0, 0});
+    CHECK(rs.region() == std::pair<size_t, size_t>(1, 8));
+    CHECK(rs.score_haplotype({0, 0, 1, 0, 0, 1, 1, 1, 0, 0}) == 6);
+    CHECK(rs.score_haplotype({2, 2, 2, 2, 2, 2, 2, 2, 2, 2}) == 0);
+    CHECK(rs.score_haplotype({1, 1, 0, 1, 1, 0, 0, 0, 1, 1}) == 28);
+    const ReadSegment rp("read_name", {2, 0, 1, 0, 0, 1, 2, 1, 2, 2}, {0, 1, 2, 3, 4, 5, 6, 7, 0, 0});
+    CHECK(rp.score_partial_haplotype({0, 1, 0, 0, 1, 1, 1}, 1) == 6);
+    CHECK(rp.score_partial_haplotype({2, 2, 2, 2, 2, 2, 2}, 2) == 0);
+    CHECK(rp.score_partial_haplotype({1, 0, 1, 1, 0, 0, 0}, 1) == 28);
+    CHECK(rp.score_partial_haplotype({0, 1, 1, 0, 0, 0}, 2) == 27);
+    CHECK(rp.score_partial_haplotype({1, 1, 0, 0, 0}, 3) == 25);
+    CHECK(rp.score_partial_haplotype({1, 0, 0, 0}, 4) == 22);
+    CHECK(rp.score_partial_haplotype({0, 0, 0}, 5) == 18);
+    CHECK(rp.score_partial_haplotype({0, 0}, 6) == 13);
+    CHECK(rp.score_partial_haplotype({0}, 7) == 7);
+}
+
+// ---- variants.rs:800-846 fn test_closest_allele ---------------------------------------------------------------------
+static void test_closest_allele() {
+    Variant v = Variant::new_insertion(0, 10, bytes("A"), bytes("AGT"), 0, 1);
+    v.prefix = bytes("AC");     // add_reference_prefix / add_reference_postfix (variants.rs:497-539)
+    v.postfix = bytes("GGC");
+    CHECK(v.get_allele0() == bytes("ACAGGC") && v.get_allele1() == bytes("ACAGTGGC"));
+    struct K { const char* a; uint8_t allele; uint64_t lo, hi; };
+    for (const K& k : {K{"A", 0, 5, 7}, K{"AGT", 0, 4, 5}, K{"AG", 0, 4, 6}, K{"ACAGGC", 0, 0, 2}, K{"ACAGTGGC", 1, 0, 2}, K{"ACAGGGC", 2, 1, 1}}) {
+        const ClosestAllele c = closest_allele_clip(v, bytes(k.a));
+        CHECK(c.allele == k.allele && c.min_ed == k.lo && c.other_ed == k.hi);
+    }
+    CHECK(v.match_allele(bytes("ACAGGC")) == 0 && v.match_allele(bytes("ACAGTGGC")) == 1 && v.match_allele(bytes("A")) == 2);
+}
+
 // ---- sequence_alignment.rs:45-76 ---------------------------------------------------------------------------------
 static void test_edit_distance() {   // fn test_edit_distance (the HIP Levenshtein kernel behind the same signature)
     const Bytes v1{0, 1, 2, 4, 5}, v2{0, 1, 3, 4, 5}, v3{1, 2, 3, 5}, v4{};
@@ -231,6 +263,8 @@ int main(int argc, char** argv) {
         test_read_segment_constructor();
         test_read_segment_collapse();
         test_read_segment_empty_and_num_set();
+        test_score_haplotype();
+        test_closest_allele();
         test_edit_distance();
         test_simple_snv();
         test_span_counts_and_haplotags();
