@@ -32,8 +32,9 @@ struct HostNode {          // POD: parent / child lists live in the job's flat a
 struct GraphBuild {
     std::vector<HostNode> nodes;
     std::vector<uint32_t> par, child;
-    // device sequence buffer layout: [ref slice][alt allele bytes][read][pad]; only the (small) allele bytes are
-    // copied here, the reference slice and the read are copied once, straight into the upload staging buffer
+    // sequence offsets are "virtual": [ref slice][alt allele bytes][read][pad]. On the device the reference slice lives
+    // in the shared merged ranges and [alt][read][pad] are the job's private bytes (pack_jobs); only the (small)
+    // allele bytes are copied here, reference and read go straight from the caller into the upload staging buffer
     const uint8_t* ref_ptr = nullptr;
     uint32_t ref_len = 0;
     std::vector<uint8_t> alt;
