@@ -109,6 +109,11 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
     std::vector<EdPairDev> dp(n);
     std::vector<uint8_t> bytes;
     uint32_t max_short = 0;
+    {
+        size_t total = 16;
+        for (size_t i = 0; i < n; ++i) total += (size_t)pairs[i].a_len + pairs[i].b_len;
+        bytes.reserve(total);
+    }
     for (size_t i = 0; i < n; ++i) {
         const hp_ed_pair& p = pairs[i];
         if ((p.a_len && !p.a) || (p.b_len && !p.b)) { set_error("pair %zu: null sequence", i); return HP_ERR_ARG; }
@@ -124,11 +129,19 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
     if (device_id < 0) device_id = hp_default_device();
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
     const int n_cu = device_cu_count(device_id);
+    // largest tables first (LPT). The order only balances the work list, so a counting sort over 65536 size classes
+    // (O(n)) does as well as an exact sort
     std::vector<uint32_t> order(n);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        return (uint64_t)dp[x].a_len * dp[x].b_len > (uint64_t)dp[y].a_len * dp[y].b_len;
-    });
+    {
+        uint64_t max_cells = 1;
+        for (size_t i = 0; i < n; ++i) max_cells = std::max(max_cells, (uint64_t)dp[i].a_len * dp[i].b_len);
+        constexpr uint32_t NB = 65536;
+        auto bucket = [&](size_t i) { return NB - 1 - (uint32_t)((unsigned __int128)((uint64_t)dp[i].a_len * dp[i].b_len) * (NB - 1) / max_cells); };
+        std::vector<uint32_t> start(NB + 1, 0);
+        for (size_t i = 0; i < n; ++i) start[bucket(i) + 1]++;
+        for (uint32_t b = 0; b < NB; ++b) start[b + 1] += start[b];
+        for (size_t i = 0; i < n; ++i) order[start[bucket(i)]++] = (uint32_t)i;
+    }
     const uint32_t lds_row_cap = 2048;  // 2 rows x 2048 cells x 4 B = 16 KiB of LDS per wave
     const uint64_t row_stride = ((uint64_t)max_short + 1 + 63) & ~63ull;
     const uint32_t slots = (uint32_t)std::min<size_t>(n, (size_t)n_cu * 8);

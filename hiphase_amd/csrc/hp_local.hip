@@ -13,6 +13,8 @@
 
 #include "hp_common.h"
 
+#include <ctime>
+
 namespace hp {
 namespace {
 
@@ -222,6 +224,9 @@ extern "C" int hp_local_realign_batch(const hp_local_read* reads, size_t n_reads
             return HP_ERR_ARG;
         }
     }
+    const bool verbose = std::getenv("HP_DEBUG") != nullptr;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t0 = now_ms();
     std::vector<uint8_t> flags(n_reads * n_variants);
     unsigned nt = std::thread::hardware_concurrency();
     if (const char* e = std::getenv("HP_LOCAL_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
@@ -240,6 +245,7 @@ extern "C" int hp_local_realign_batch(const hp_local_read* reads, size_t n_reads
         for (unsigned t = 0; t < nt; ++t) th.emplace_back(body, t);
         for (auto& x : th) x.join();
     }
+    const double t1 = now_ms();
     size_t n_pending = 0;
     for (auto& w : workers) {
         if (w.rc != HP_OK) { set_error("%s", w.err.c_str()); return w.rc; }
@@ -267,8 +273,10 @@ extern "C" int hp_local_realign_batch(const hp_local_read* reads, size_t n_reads
                 alleles[(size_t)p.read * n_variants + p.var] = d0 < d1 ? A_REF : (d0 > d1 ? A_ALT : A_AMBIGUOUS);  // variants.rs:633-640
             }
     }
+    const double t2 = now_ms();
     if (stats) {   // read_parsing.rs:460-499
-        for (size_t r = 0; r < n_reads; ++r) {
+        auto stat_rows = [&](unsigned t) {
+        for (size_t r = n_reads * t / nt; r < n_reads * (t + 1) / nt; ++r) {
             hp_read_stats s{};
             uint64_t overlaps = 0;
             for (size_t vi = 0; vi < n_variants; ++vi) {
@@ -285,6 +293,14 @@ extern "C" int hp_local_realign_batch(const hp_local_read* reads, size_t n_reads
             s.local_aligned = 1 - s.skipped_reads;
             stats[r] = s;
         }
+        };
+        if (nt == 1) stat_rows(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(stat_rows, t);
+            for (auto& x : th) x.join();
+        }
     }
+    if (verbose) { fprintf(stderr, "[hp] local re-alignment of %zu records x %zu variants on %u threads: coordinates %.2f ms, %zu inexact alleles on the device %.2f ms, statistics %.2f ms\n", n_reads, n_variants, nt, t1 - t0, n_pending, t2 - t1, now_ms() - t2); fflush(stderr); }
     return HP_OK;
 }
