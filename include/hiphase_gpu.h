@@ -170,7 +170,10 @@ typedef struct hp_wfa_result {
  * read_parsing.rs:790-800 for n jobs. alleles[i] must hold jobs[i].n_hets bytes and receives one
  * AlleleType per het of the job (NoOverlap / Reference / Alternate / Ambiguous).
  * prune_distance: GlobalRealignmentConfig::wfa_prune_distance (UINT64_MAX disables pruning).
- * max_ed: GlobalRealignmentConfig::max_edit_distance. */
+ * max_ed: GlobalRealignmentConfig::max_edit_distance.
+ * The jobs of a block normally point at ONE reference buffer (the chromosome) with their own windows: the
+ * library uploads the union of the windows' address ranges once. Every pointer stays owned by the caller and
+ * must remain valid (and unmodified) until the call returns; nothing is retained afterwards. */
 int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
                         hp_wfa_result* out, uint8_t* const* alleles, int device_id);
 
