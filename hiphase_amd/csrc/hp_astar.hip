@@ -62,11 +62,31 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
         }
         if (e > s) idx.push_back(r);
     }
-    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
-        if (v->read_start[a] != v->read_start[b]) return v->read_start[a] < v->read_start[b];
-        if (v->read_end[a] != v->read_end[b]) return v->read_end[a] < v->read_end[b];
-        return a < b;
-    });
+    // rows ordered by (start, end, caller index): a counting sort over the N possible starts, then the (short) runs
+    // of equal start are ordered by end; rows of equal (start, end) keep the caller's order
+    {
+        std::vector<uint32_t> first(N + 2, 0);
+        for (uint32_t r : idx) first[v->read_start[r] + 1]++;
+        for (uint32_t p = 0; p <= N; ++p) first[p + 1] += first[p];
+        std::vector<uint32_t> sorted(idx.size());
+        {
+            std::vector<uint32_t> cur(first.begin(), first.end() - 1);
+            for (uint32_t r : idx) sorted[cur[v->read_start[r]]++] = r;   // idx is ascending in r: stable
+        }
+        for (uint32_t p = 0; p <= N; ++p) {
+            const uint32_t a = first[p], b = first[p + 1];
+            if (b - a > 16)
+                std::stable_sort(sorted.begin() + a, sorted.begin() + b, [&](uint32_t x, uint32_t y) { return v->read_end[x] < v->read_end[y]; });
+            else
+                for (uint32_t i = a + 1; i < b; ++i) {   // stable insertion sort of a short run
+                    const uint32_t x = sorted[i], ex = v->read_end[x];
+                    uint32_t j = i;
+                    while (j > a && v->read_end[sorted[j - 1]] > ex) { sorted[j] = sorted[j - 1]; --j; }
+                    sorted[j] = x;
+                }
+        }
+        idx.swap(sorted);
+    }
     BlockDesc d{};
     d.n_vars = N;
     d.n_reads = (uint32_t)idx.size();
@@ -100,21 +120,26 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     }
     std::vector<uint32_t> ignored;
     for (uint32_t p = 0; p < N; ++p) if (v->var_flags[p] & HP_VAR_IGNORED) ignored.push_back(p);
+    const size_t row0 = hpk.rstart.size();
+    hpk.rstart.resize(row0 + idx.size()); hpk.rend.resize(row0 + idx.size()); hpk.row_block.resize(row0 + idx.size());
+    hpk.row_orig.resize(row0 + idx.size()); hpk.rword.resize(row0 + idx.size()); hpk.rcell.resize(row0 + idx.size());
+    uint32_t *p_rstart = hpk.rstart.data() + row0, *p_rend = hpk.rend.data() + row0, *p_row_block = hpk.row_block.data() + row0,
+             *p_row_orig = hpk.row_orig.data() + row0, *p_rword = hpk.rword.data() + row0;
+    uint64_t* p_rcell = hpk.rcell.data() + row0;
     for (uint32_t i = 0; i < idx.size(); ++i) {
         const uint32_t r = idx[i];
         const uint32_t s = v->read_start[r], e = v->read_end[r];
         const uint32_t k0 = s >> 5, k1 = (e - 1) >> 5;
         if (n_words > 0xFFFFFFF0ull) { set_error("block too large (plane words)"); return HP_ERR_UNSUPPORTED; }
         if (v->row_off[r] + (e - s) > n_cells_blk) { set_error("row %u: row_off outside the cell arrays", r); return HP_ERR_ARG; }
-        hpk.rstart.push_back(s);
-        hpk.rend.push_back(e);
-        hpk.row_block.push_back(blk_index);
-        hpk.row_orig.push_back(r);
-        hpk.rword.push_back((uint32_t)n_words);
-        hpk.rcell.push_back(v->row_off[r]);
+        p_rstart[i] = s;
+        p_rend[i] = e;
+        p_row_block[i] = blk_index;
+        p_row_orig[i] = r;
+        p_rword[i] = (uint32_t)n_words;
+        p_rcell[i] = v->row_off[r];
         const uint64_t ro = v->row_off[r];
-        uint64_t row_qual = 0;
-        for (uint64_t c = ro; c < ro + (e - s); ++c) row_qual += v->quals[c];
+        if (!ignored.empty())
         for (auto it = std::lower_bound(ignored.begin(), ignored.end(), s); it != ignored.end() && *it < e; ++it) {
             const uint8_t a = cell_allele(v, ro + (*it - s));
             if (a != HP_ALLELE_NOOVERLAP) {
@@ -122,8 +147,6 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
                 return HP_ERR_INVARIANT;
             }
         }
-        max_row_qual = std::max(max_row_qual, row_qual);
-        total_qual += row_qual;
         max_row_len = std::max(max_row_len, e - s);
         n_words += k1 - k0 + 1;
         cells += e - s;
@@ -141,6 +164,20 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     }
     uint32_t max_cov = 0;
     for (uint32_t p = 0; p < N; ++p) max_cov = std::max(max_cov, hpk.vhi[v0 + p] - hpk.vlo[v0 + p]);
+    // quality mass behind the packed limits: qualities are bytes, so 255 x length bounds a row and 255 x cells the block;
+    // the exact sums are only needed when those coarse bounds do not already clear the limits
+    max_row_qual = 255ull * max_row_len;
+    total_qual = 255ull * cells;
+    if (max_row_qual * (uint64_t)std::max(max_cov, 1u) >= (1ull << 32) || total_qual >= (1ull << 35)) {
+        max_row_qual = 0; total_qual = 0;
+        for (uint32_t r : idx) {
+            const uint8_t* q = v->quals + v->row_off[r];
+            uint64_t acc = 0;
+            for (uint32_t c = 0; c < v->read_end[r] - v->read_start[r]; ++c) acc += q[c];
+            max_row_qual = std::max(max_row_qual, acc);
+            total_qual += acc;
+        }
+    }
     if (max_row_qual * (uint64_t)std::max(max_cov, 1u) >= (1ull << 32)) {
         set_error("row quality mass x coverage overflows the u32 score accumulators"); return HP_ERR_UNSUPPORTED;
     }
