@@ -177,3 +177,29 @@ def test_concurrent_callers_and_thread_exit():
             t.join()
     assert not errors, errors
     check_specs(specs[:4])
+
+
+def test_jobs_sharing_one_reference_buffer():
+    """The reads of a block pass windows of ONE chromosome buffer (read_parsing.rs:738-768): the library uploads the
+    union of the windows' address ranges once. Overlapping, nested, adjacent and disjoint windows, plus a job with its
+    own buffer, must all score as if each had its own copy."""
+    from hiphase_amd.wfa_graph import WfaJobSpec
+    r = _Rng(4242)
+    base, _ = synth_wfa_job(5150, ref_len=9000, n_vars=26, n_homs=5, noise=0.0, multiallelic=0.2)
+    L = len(base.reference)
+    windows = [(0, 900), (100, 700), (700, 1500), (1500, 2300), (2299, 4000), (5000, L), (5200, 5900), (0, L)]
+    windows += [(a, min(L, a + r.randint(300, 2500))) for a in (r.randint(0, L - 400) for _ in range(24))]
+    specs = []
+    for a, b in windows:
+        read = bytearray(base.reference[a:b])
+        for k in range(len(read)):
+            if r.u01() < 0.01:
+                read[k] = b"ACGT"[r.next() & 3]
+        for v in base.hets + base.homs:   # carry some same-length alternate alleles
+            if a <= v.position and v.position + v.ref_len <= b and len(v.allele1) == v.ref_len and r.u01() < 0.5:
+                read[v.position - a:v.position - a + v.ref_len] = v.allele1
+        specs.append(WfaJobSpec(reference=base.reference, ref_start=a, ref_end=b, hets=base.hets, homs=base.homs,
+                                read=bytes(read), ref_base=0))
+    specs.append(synth_wfa_job(5151, ref_len=1200, n_vars=6)[0])   # a buffer of its own in the same batch
+    check_specs(specs)
+    check_specs(specs[::-1], prune=50, max_ed=40)
