@@ -246,6 +246,7 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
             const uint32_t ES = nd.entry_stride;
             uint32_t* ebase = scr + nd.entry_off;
             bool any_valid = false;
+            uint32_t vlo = 0xFFFFu, vhi = 0;   // diagonals that produced a wave the next round can pull from
             bool any_final_here = false;
 
             PT(2);
@@ -420,7 +421,14 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                     }
                 }
                 PT(6);
-                if (__any(kind != WFA_KIND_NONE)) any_valid = true;
+                {
+                    const uint64_t vm = __ballot(kind != WFA_KIND_NONE);
+                    if (vm) {
+                        any_valid = true;
+                        vlo = min(vlo, base + (uint32_t)__builtin_ctzll(vm));
+                        vhi = max(vhi, base + 63u - (uint32_t)__builtin_clzll(vm));
+                    }
+                }
                 // ---- hand waves that finished this node to its successors, same round (wfa_graph.rs:527-553) ----
                 if (__any(inject)) {
                     for (uint32_t j = 0; j < nd.n_children; ++j) {
@@ -469,7 +477,9 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                 }
             }
             if (lane == 0) {
-                ns[n].hull[c] = hull_make(lo, hi);
+                // the next round pulls only from diagonals that hold a live wave: pruned and stale waves (most of a
+                // hull that has grown by one diagonal a round) drop out here instead of costing steps
+                ns[n].hull[c] = any_valid ? hull_make(vlo, vhi) : HULL_EMPTY;
                 ns[n].stamp[c] = ed;
                 ns[n].inj = HULL_EMPTY;
                 ns[n].ever = hull_union(ns[n].ever, hull_make(lo, hi));
