@@ -72,3 +72,56 @@ def test_fails_loudly_without_gpu(hp_lib):
     blk, _ = synth_block(20, 8, 6, 0.0, 0.0, 1, dll=hp_lib)
     assert _solve_rc(hp_lib, blk) == -1  # HP_ERR_HIP
     assert b"no CPU fallback" in hp_lib.hp_last_error()
+
+
+# ---- the other entry points: host-side validation runs before the device is touched, and without a GPU every one of
+# ---- them fails loudly (there is no CPU fallback anywhere on the product path) ----------------------------------------
+def _wfa_rc(hp_lib, specs, prune=500, max_ed=500):
+    from hiphase_amd.wfa_graph import make_jobs
+    jobs, keep = make_jobs(specs)
+    out = (_ffi.WfaResult * len(specs))()
+    als = [np.full(max(1, len(s.hets)), 3, np.uint8) for s in specs]
+    ptrs = (C.c_void_p * len(specs))(*[a.ctypes.data for a in als])
+    return hp_lib.hp_wfa_assign_batch(jobs, len(specs), prune, max_ed, out, ptrs, 0), jobs
+
+
+def test_wfa_host_validation_and_no_fallback(hp_lib):
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from wfa_util import synth_wfa_job
+    spec = synth_wfa_job(5, ref_len=900, n_vars=6)[0]
+    rc, _ = _wfa_rc(hp_lib, [spec], max_ed=70000)
+    assert rc == -5 and b"max_edit_distance" in hp_lib.hp_last_error()          # HP_ERR_UNSUPPORTED
+    bad = synth_wfa_job(6, ref_len=900, n_vars=6)[0]
+    bad.ref_start, bad.ref_end = 500, 100                                          # window turned inside out
+    rc, _ = _wfa_rc(hp_lib, [bad])
+    assert rc == -4 and b"reference window" in hp_lib.hp_last_error()            # HP_ERR_ARG
+    if hp_lib.hp_device_count() == 0:
+        rc, _ = _wfa_rc(hp_lib, [spec])                                            # valid job: the graph is built, then ...
+        assert rc == -1 and b"no CPU fallback" in hp_lib.hp_last_error()         # HP_ERR_HIP
+
+
+def test_edit_distance_and_local_batches_fail_loudly(hp_lib):
+    a = np.frombuffer(b"ACGT", np.uint8)
+    pr = (_ffi.EdPair * 1)()
+    pr[0].a = a.ctypes.data_as(C.POINTER(C.c_uint8)); pr[0].b = pr[0].a; pr[0].a_len = pr[0].b_len = 4
+    out = np.zeros(1, np.uint64)
+    assert hp_lib.hp_edit_distance_batch(pr, 1, None, 0) == -4                      # null output
+    if hp_lib.hp_device_count() == 0:
+        assert hp_lib.hp_edit_distance_batch(pr, 1, out.ctypes.data_as(C.POINTER(C.c_uint64)), 0) == -1
+        assert b"no CPU fallback" in hp_lib.hp_last_error()
+    # a CIGAR with a Pad op is rejected on the host (rust-htslib's aligned_pairs panics on it, read_parsing.rs:165)
+    rd = (_ffi.LocalRead * 1)()
+    cg = np.array([(4 << 4) | 6], np.uint32)                                        # 4P
+    sq = np.frombuffer(b"ACGT", np.uint8); ql = np.full(4, 30, np.uint8)
+    rd[0].pos, rd[0].cigar, rd[0].n_cigar = 10, cg.ctypes.data_as(C.POINTER(C.c_uint32)), 1
+    rd[0].seq_len, rd[0].seq, rd[0].qual = 4, sq.ctypes.data_as(C.POINTER(C.c_uint8)), ql.ctypes.data_as(C.POINTER(C.c_uint8))
+    vs = (_ffi.LocalVariant * 1)()
+    al0 = np.frombuffer(b"A", np.uint8); al1 = np.frombuffer(b"C", np.uint8)
+    vs[0].position, vs[0].ref_len, vs[0].variant_type = 11, 1, 0
+    vs[0].allele0, vs[0].allele1 = al0.ctypes.data_as(C.POINTER(C.c_uint8)), al1.ctypes.data_as(C.POINTER(C.c_uint8))
+    vs[0].allele0_len = vs[0].allele1_len = 1
+    alleles = np.zeros(1, np.uint8); quals = np.zeros(1, np.uint8)
+    st = (_ffi.ReadStats * 1)()
+    rc = hp_lib.hp_local_realign_batch(rd, 1, vs, 1, alleles.ctypes.data, quals.ctypes.data, st, 0)
+    assert rc == -5, hp_lib.hp_last_error()                                         # HP_ERR_UNSUPPORTED
