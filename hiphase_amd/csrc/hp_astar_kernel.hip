@@ -1058,6 +1058,7 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
         const bool fast_ok = cx.ctab != nullptr;
         bool fast_valid = fast_ok;
         FastState fs{0, 0, 0, 0};
+        uint32_t ring_chunk = NONE32;   // which 64-variant chunk the LDS rings hold
 
         while (cur.depth < N) {
             wc.main_pops += 1;
@@ -1078,10 +1079,19 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
                 continue;
             }
             const uint32_t p = cur.depth;
-            uint32_t fl = 0, l = 0, h = 0;
-            uint64_t hn = 0;
-            if (lane == 0) { fl = vflags[p]; l = vlo[p]; hn = H[p + 1]; }
-            fl = bcast32(fl); l = bcast32(l); h = bcast32(h); hn = bcast64(hn);
+            // per-variant inputs (flags, first candidate row, H[p + 1]) come from the LDS rings of the heuristic phase,
+            // refilled 64 variants at a time with coalesced loads: one HBM round trip per 64 pops of a dive instead of
+            // one per pop at the head of the loop
+            if ((p >> 6) != ring_chunk) {
+                const uint32_t cb = p & ~63u;
+                const uint32_t x = cb + lane, y = cb + 1u + lane;
+                if (x < N) reinterpret_cast<uint32_t*>(hp_smem + LDS_VRING_OFF)[x & 63u] = vlo[x] | ((uint32_t)vflags[x] << 28);
+                if (y <= N) reinterpret_cast<uint64_t*>(hp_smem + LDS_HRING_OFF)[y & 63u] = H[y];
+                ring_chunk = p >> 6;
+            }
+            const uint32_t rv = bcast32(reinterpret_cast<const uint32_t*>(hp_smem + LDS_VRING_OFF)[p & 63u]);
+            const uint64_t hn = bcast64(reinterpret_cast<const uint64_t*>(hp_smem + LDS_HRING_OFF)[(p + 1u) & 63u]);
+            const uint32_t fl = rv >> 28, l = rv & 0x0FFFFFFFu;
             Kids kd;
             CellCost cc;
             const bool collide = (fl & VAR_NOFAST) != 0;
