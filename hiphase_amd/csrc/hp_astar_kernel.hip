@@ -276,15 +276,34 @@ template <bool LDS> struct SubHeap {
 
 // (b) main heap: 128-bit keys in HBM scratch. Every level of a sift is a dependent HBM/L2 round trip, so the
 // per-lane heaps are 4-ary: half the levels of a binary heap, the four children of a node are fetched together.
+// Insertion is LAZY: a pushed key is appended behind the lane's heap-ordered prefix (one store, no load) and only the
+// running minimum `top` is updated; the appended keys are sifted into place when the heap order is actually needed - at
+// the next pop or full prune. A dive that never pops from the queue (the common case: the heuristic is exact on clean
+// data) never pays the dependent parent loads of a sift-up; a search that does pop pays exactly what it paid before.
 struct MainHeap {
     Key* base;
     uint32_t jcap, cnt;
+    uint32_t hcnt;   // per lane: entries [0, hcnt) are heap-ordered, [hcnt, cnt) are appended and pending
     Key top;
     uint32_t top_lane, ovf;
     DEVINL Key ld(uint32_t j) const { return base[(size_t)j * 64 + lane_id()]; }
     DEVINL void st(uint32_t j, const Key& k) { base[(size_t)j * 64 + lane_id()] = k; }
-    DEVINL void reset() { cnt = 0; top = key_inf(); top_lane = 0; }
+    DEVINL void reset() { cnt = 0; hcnt = 0; top = key_inf(); top_lane = 0; }
     DEVINL bool empty() const { return (top.hi & top.lo) == ~0ull; }
+    // sift the pending entries of this lane into its heap (every lane runs its own loop)
+    DEVINL void integrate() {
+        while (hcnt < cnt) {
+            const Key k = ld(hcnt);
+            uint32_t j = hcnt;
+            while (j > 0) {
+                const uint32_t pj = (j - 1) >> 2;
+                const Key pk = ld(pj);
+                if (key_less(k, pk)) { st(j, pk); j = pj; } else break;
+            }
+            if (j != hcnt) st(j, k);
+            hcnt += 1;
+        }
+    }
     DEVINL void sift_down(uint32_t i, Key k) {
         for (;;) {
             const uint32_t c0 = 4 * i + 1;
@@ -304,21 +323,11 @@ struct MainHeap {
         const uint32_t tgt = (uint32_t)key_idx(k) & 63u;
         if (lane_id() == tgt) {
             if (cnt >= jcap) ovf = 1;
-            else {
-                uint32_t j = cnt;
-                while (j > 0) {
-                    const uint32_t pj = (j - 1) >> 2;
-                    const Key pk = ld(pj);
-                    if (key_less(k, pk)) { st(j, pk); j = pj; } else break;
-                }
-                st(j, k);
-                cnt += 1;
-            }
+            else { st(cnt, k); cnt += 1; }
         }
         if (key_less(k, top)) { top = k; top_lane = tgt; }
     }
-    // up to three keys of consecutive node indices (key_inf() = absent): their owner lanes differ, so the sift-ups
-    // (dependent loads from HBM) run side by side in one divergent region instead of one after the other
+    // up to three keys of consecutive node indices (key_inf() = absent): their owner lanes differ
     DEVINL void push3(const Key& ka, const Key& kb, const Key& kc) {
         const uint32_t lane = lane_id();
         Key mine = key_inf();
@@ -328,16 +337,7 @@ struct MainHeap {
         if (pc && lane == ((uint32_t)key_idx(kc) & 63u)) mine = kc;
         if ((mine.hi & mine.lo) != ~0ull) {
             if (cnt >= jcap) ovf = 1;
-            else {
-                uint32_t j = cnt;
-                while (j > 0) {
-                    const uint32_t pj = (j - 1) >> 2;
-                    const Key pk = ld(pj);
-                    if (key_less(mine, pk)) { st(j, pk); j = pj; } else break;
-                }
-                st(j, mine);
-                cnt += 1;
-            }
+            else { st(cnt, mine); cnt += 1; }
         }
         if (pa && key_less(ka, top)) { top = ka; top_lane = (uint32_t)key_idx(ka) & 63u; }
         if (pb && key_less(kb, top)) { top = kb; top_lane = (uint32_t)key_idx(kb) & 63u; }
@@ -347,6 +347,7 @@ struct MainHeap {
     // so each lane scans its heap front to back (independent, coalesced loads) and sifts UP only the entries that
     // are newly cleared — the pop order is a total order on the keys, so the heap's internal layout is free.
     DEVINL void clear_below(uint32_t min_progress) {
+        integrate();
         for (uint32_t j0 = 0; j0 < cnt; j0 += 4) {
             Key k[4];
 #pragma unroll
@@ -376,8 +377,10 @@ struct MainHeap {
         top_lane = who ? (uint32_t)__builtin_ctzll(who) : 0;
     }
     DEVINL void pop() {
+        integrate();   // the lane minima below are the heap roots
         if (lane_id() == top_lane) {
             cnt -= 1;
+            hcnt = cnt;
             if (cnt > 0) sift_down(0, ld(cnt));
         }
         recompute_top();
