@@ -1039,14 +1039,34 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
         hq.reset();
         // PQueueHapTracker (astar_phaser.rs:171-231): per-length counts live in global scratch and are only
         // ever touched by lane 0 (plain same-thread read-modify-write); the running total is a register.
-        if (lane == 0) for (uint32_t i = 0; i <= N; ++i) tracker[i] = 0;
+        for (uint32_t i = lane; i <= N; i += 64) tracker[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         uint32_t trk_total = 0, trk_thr = 0;
+        // The histogram lives in HBM (N + 1 counters), but a dive touches it in a fixed pattern: add at a NEW largest
+        // length, then remove from that same length at the next pop. One entry is therefore kept in (uniform)
+        // registers and written back when another length is touched; a length above everything touched so far is known
+        // to be zero and is not loaded. Only a jump back in the search loads a counter (one round trip) - the two
+        // read-modify-writes per pop used to stall the wave twice per pop.
+        uint32_t tc_len = NONE32, tc_val = 0, tc_top = 0;   // cached length, its count, largest length touched + 1
+        auto trk_at = [&](uint32_t len) {
+            if (len == tc_len) return;
+            if (tc_len != NONE32 && lane == 0) tracker[tc_len] = tc_val;
+            if (len >= tc_top) { tc_val = 0; tc_top = len + 1; }
+            else {
+                uint32_t v = 0;
+                if (lane == 0) v = tracker[len];
+                tc_val = bcast32(v);
+            }
+            tc_len = len;
+        };
         auto trk_add = [&](uint32_t len, uint32_t n) {
-            if (lane == 0) tracker[len] = tracker[len] + n;
+            trk_at(len);
+            tc_val += n;
             if (len >= trk_thr) trk_total += n;
         };
         auto trk_remove = [&](uint32_t len) {
-            if (lane == 0) tracker[len] = tracker[len] - 1u;
+            trk_at(len);
+            tc_val -= 1u;
             if (len >= trk_thr) trk_total -= 1;
         };
 
@@ -1128,8 +1148,9 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
                 min_progress += 1;
                 {   // increase_threshold(min_progress)
                     uint32_t c = 0;
-                    if (lane == 0) c = tracker[min_progress - 1];
-                    trk_total -= bcast32(c);
+                    if (min_progress - 1 == tc_len) c = tc_val;
+                    else { if (lane == 0) c = tracker[min_progress - 1]; c = bcast32(c); }
+                    trk_total -= c;
                     trk_thr = min_progress;
                 }
                 if (qlen > max_q) {
