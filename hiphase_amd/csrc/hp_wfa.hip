@@ -553,26 +553,34 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
 }  // namespace
 }  // namespace hp
 
+namespace hp {
+int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
+                        uint8_t* const* alleles, int device_id);   // hp_wfa2.hip
+int wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
+                        uint8_t* const* alleles, int device_id);
+}
 using namespace hp;
 
-static int wfa_assign_batch_impl(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
-                                 hp_wfa_result* out, uint8_t* const* alleles, int device_id);
+// The compact several-reads-per-wavefront kernel (hp_wfa2.hip) takes every job it can hold; HP_WFA_V1=1 forces the
+// dense-band path below for all of them (the path the leftovers take anyway).
 extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
                                    hp_wfa_result* out, uint8_t* const* alleles, int device_id) {
     const double t0 = now_ms();
-    const int rc = wfa_assign_batch_impl(jobs, n, prune_distance, max_ed, out, alleles, device_id);
+    const char* v1 = std::getenv("HP_WFA_V1");
+    const int rc = (v1 && v1[0] == '1') ? wfa_assign_batch_v1(jobs, n, prune_distance, max_ed, out, alleles, device_id)
+                                        : wfa_assign_batch_v2(jobs, n, prune_distance, max_ed, out, alleles, device_id);
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] hp_wfa_assign_batch total %.2f ms\n", now_ms() - t0); fflush(stderr); }
     return rc;
 }
-static int wfa_assign_batch_impl(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
-                                 hp_wfa_result* out, uint8_t* const* alleles, int device_id) {
+int hp::wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
+                            hp_wfa_result* out, uint8_t* const* alleles, int device_id) {
     if (n == 0) return HP_OK;
     if (!jobs || !out) { set_error("null argument"); return HP_ERR_ARG; }
     if (n > 0x7FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
     if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
     std::vector<GraphArena> arenas;
     std::vector<HostJob> hj(n);
-    g_last_kernel_ms = 0.0;
+    g_last_kernel_ms = 0.0;   // (the caller adds the compact path's time back when this runs its leftovers)
     const double t_build = now_ms();
     {
         // graph construction is independent per read: spread it over host threads (HP_WFA_HOST_THREADS, default

@@ -1,0 +1,407 @@
+// hp_wfa2.hip — host side of the second-generation graph-WFA stage (hp_wfa2_kernel.hip).
+//
+// hp_wfa_assign_batch (the seam at reference src/read_parsing.rs:769-800) now does nothing per read on the host:
+//   1. the batch is laid out for the device - the union of the jobs' reference windows once, every distinct
+//      hp_wfa_variant once (jobs pass slices of their block's variant vectors: the address ranges are merged exactly
+//      like the reference windows), the read bases - and uploaded from pinned staging;
+//   2. hp_wfa2_build_kernel builds every read's graph on the device (wfa_graph.rs:119-284);
+//   3. hp_wfa2_kernel<G, W> aligns the reads, several per wavefront, one launch per graph-size class;
+//   4. hp_wfa2_map_kernel turns traversed nodes into the per-het allele row (read_parsing.rs:790-800);
+//   5. reads that outgrow the compact state or the device builder's fixed queues (W2_ST_NEED_BIG / W2B_NEED_HOST)
+//      are re-run by the dense-band path of hp_wfa.hip (host graph build + hp_wfa_kernel). Same results either way.
+#include "hp_wfa2_kernel.hip"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace hp {
+
+// hp_wfa.hip: the dense-band implementation (host graph build + hp_wfa_kernel), used for the leftovers
+int wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
+                        uint8_t* const* alleles, int device_id);
+
+namespace {
+
+double w2_now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+// grow-only pinned staging (DMA straight from it; never value-initialised)
+struct PinBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    int reserve(size_t n) {
+        if (n <= cap) return HP_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 4 + 4096;
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
+            p = nullptr;
+            set_error("hipHostMalloc(%zu) failed", want);
+            return HP_ERR_OOM;
+        }
+        cap = want;
+        return HP_OK;
+    }
+};
+
+constexpr uint32_t W2_HCAP_LOG2 = 11;   // 2048 keys (16 KiB) per group
+
+// per-(thread, device) state that survives across calls
+struct W2Context {
+    int device = -1;
+    DevBuf htab;             // capped-diagonal hash sets, [groups][1 << W2_HCAP_LOG2]; zeroed once, then tagged
+    uint32_t htab_groups = 0;
+    uint32_t tag_next = 0;   // tags handed out so far (tag 0 = empty)
+    PinBuf stage;            // upload staging: seq bytes, then the tables
+    PinBuf down;             // download staging
+    hipStream_t stream = nullptr;
+    ~W2Context() { if (stream) (void)hipStreamDestroy(stream); }
+};
+thread_local W2Context g_w2;
+
+unsigned w2_host_threads(size_t n, size_t per_thread) {
+    const char* tenv = std::getenv("HP_WFA_HOST_THREADS");
+    unsigned nt = tenv ? (unsigned)std::atoi(tenv) : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    return (unsigned)std::min<size_t>(std::max(1u, nt), std::max<size_t>(1, n / per_thread));
+}
+template <class F> void w2_parallel(unsigned nt, F&& f) {
+    if (nt <= 1) { f(0u, 1u); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back([&f, t, nt]() { f(t, nt); });
+    for (auto& x : th) x.join();
+}
+
+// union of address ranges [p, p + len): sorted, merged where they overlap or touch
+struct Range { const uint8_t* lo; const uint8_t* hi; uint64_t dev; };
+void merge_ranges(std::vector<std::pair<const uint8_t*, uint64_t>>& iv, std::vector<Range>& out, uint64_t elem) {
+    std::sort(iv.begin(), iv.end());
+    for (auto& v : iv) {
+        // variants: only merge on element boundaries (a slice of the same array), bytes: always
+        if (!out.empty() && v.first <= out.back().hi && (uint64_t)(v.first - out.back().lo) % elem == 0)
+            out.back().hi = std::max(out.back().hi, v.first + v.second);
+        else out.push_back({v.first, v.first + v.second, 0});
+    }
+}
+template <int G, int W> int w2_launch(const W2Batch& B, uint32_t n_items, int n_cu, uint32_t max_groups, hipStream_t st, uint32_t* groups_used) {
+    using C = W2Cfg<W>;
+    constexpr uint32_t NG = 64 / G;
+    const size_t lds = (size_t)C::BYTES * NG;
+    const size_t lds_alloc = (lds + 1279) / 1280 * 1280;   // gfx950 allocates LDS in 1280-byte granules
+    uint32_t per_cu = (uint32_t)std::min<size_t>(32, (160 * 1024) / lds_alloc);
+    if (const char* e = std::getenv("HP_WFA2_PER_CU")) per_cu = std::max(1, std::min((int)per_cu, std::atoi(e)));
+    uint32_t grid = std::min<uint32_t>((n_items + NG - 1) / NG, (uint32_t)n_cu * per_cu);
+    grid = std::min<uint32_t>(grid, max_groups / NG);
+    if (grid == 0) grid = 1;
+    static std::atomic<bool> attr_set{false};
+    if (lds > 64 * 1024 || !attr_set.load()) {
+        HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_kernel<G, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    *groups_used = grid * NG;
+    hipLaunchKernelGGL((hp_wfa2_kernel<G, W>), dim3(grid), dim3(64), lds, st, B);
+    HP_HIP_CHECK(hipGetLastError());
+    return HP_OK;
+}
+
+}  // namespace
+
+int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
+                        uint8_t* const* alleles, int device_id) {
+    if (n == 0) return HP_OK;
+    if (!jobs || !out) { set_error("null argument"); return HP_ERR_ARG; }
+    if (n > 0x3FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
+    if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
+    const bool verbose = std::getenv("HP_DEBUG") != nullptr;
+    const double t0 = w2_now_ms();
+    g_last_kernel_ms = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        const hp_wfa_job& j = jobs[i];
+        if (!j.reference || (!j.read && j.read_len)) { set_error("job %zu: null sequence", i); return HP_ERR_ARG; }
+        if (j.ref_end < j.ref_start || j.ref_start < j.ref_base) { set_error("bad reference window"); return HP_ERR_ARG; }
+        if ((j.n_hets && !j.hets) || (j.n_homs && !j.homs)) { set_error("job %zu: null variant list", i); return HP_ERR_ARG; }
+        if (j.ref_end - j.ref_start >= 0x7FFFFFFFull) { set_error("job %zu: reference window too long", i); return HP_ERR_UNSUPPORTED; }
+    }
+
+    // ---- 1. layout: merged reference windows, distinct variants, read bases ------------------------------------------
+    std::vector<Range> ref_ranges, var_ranges;
+    {
+        std::vector<std::pair<const uint8_t*, uint64_t>> iv;
+        iv.reserve(n);
+        for (size_t i = 0; i < n; ++i)
+            if (jobs[i].ref_end > jobs[i].ref_start) iv.push_back({jobs[i].reference + (jobs[i].ref_start - jobs[i].ref_base), jobs[i].ref_end - jobs[i].ref_start});
+        merge_ranges(iv, ref_ranges, 1);
+        iv.clear();
+        for (size_t i = 0; i < n; ++i) {
+            if (jobs[i].n_hets) iv.push_back({reinterpret_cast<const uint8_t*>(jobs[i].hets), (uint64_t)jobs[i].n_hets * sizeof(hp_wfa_variant)});
+            if (jobs[i].n_homs) iv.push_back({reinterpret_cast<const uint8_t*>(jobs[i].homs), (uint64_t)jobs[i].n_homs * sizeof(hp_wfa_variant)});
+        }
+        merge_ranges(iv, var_ranges, sizeof(hp_wfa_variant));
+    }
+    uint64_t seq_bytes = 0, n_vars = 0;
+    for (auto& r : ref_ranges) { r.dev = seq_bytes; seq_bytes += ((uint64_t)(r.hi - r.lo) + 15) & ~15ull; }
+    for (auto& r : var_ranges) { r.dev = n_vars; n_vars += (uint64_t)(r.hi - r.lo) / sizeof(hp_wfa_variant); }
+    if (n_vars >= 0xFFFFFFF0ull) { set_error("too many variants"); return HP_ERR_UNSUPPORTED; }
+    // allele pool: every distinct variant's truncated alleles once
+    std::vector<W2Variant> vars((size_t)n_vars);
+    uint64_t pool_bytes = 0;
+    for (auto& r : var_ranges) {
+        const hp_wfa_variant* hv = reinterpret_cast<const hp_wfa_variant*>(r.lo);
+        const size_t cnt = (size_t)(r.hi - r.lo) / sizeof(hp_wfa_variant);
+        for (size_t k = 0; k < cnt; ++k) {
+            W2Variant& w = vars[(size_t)r.dev + k];
+            w.position = hv[k].position; w.ref_len = hv[k].ref_len; w.flags = hv[k].flags;
+            w.a0_off = w.a0_len = 0;
+            if (hv[k].flags & 2u) {
+                if (!hv[k].allele0 && hv[k].allele0_len) { set_error("variant with null allele0"); return HP_ERR_ARG; }
+                w.a0_off = (uint32_t)pool_bytes; w.a0_len = hv[k].allele0_len; pool_bytes += hv[k].allele0_len;
+            }
+            if (!hv[k].allele1 && hv[k].allele1_len) { set_error("variant with null allele1"); return HP_ERR_ARG; }
+            w.a1_off = (uint32_t)pool_bytes; w.a1_len = hv[k].allele1_len; pool_bytes += hv[k].allele1_len;
+            if (pool_bytes >= 0xFFFFFF00ull) { set_error("allele pool exceeds 4 GiB"); return HP_ERR_UNSUPPORTED; }
+        }
+    }
+    const uint64_t alt_off = seq_bytes;
+    seq_bytes += (pool_bytes + 15) & ~15ull;
+    std::vector<W2Job> dj(n);
+    uint64_t node_tot = 0, edge_tot = 0, tag_tot = 0, allele_tot = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const hp_wfa_job& j = jobs[i];
+        W2Job& d = dj[i];
+        d = W2Job{};
+        d.ref_start = (int64_t)j.ref_start;
+        d.ref_len = (uint32_t)(j.ref_end - j.ref_start);
+        if (d.ref_len) {
+            const uint8_t* p = j.reference + (j.ref_start - j.ref_base);
+            auto it = std::upper_bound(ref_ranges.begin(), ref_ranges.end(), p, [](const uint8_t* q, const Range& r) { return q < r.lo; });
+            --it;
+            d.ref_off = it->dev + (uint64_t)(p - it->lo);
+        }
+        auto var_index = [&](const hp_wfa_variant* p, uint32_t cnt, uint32_t& first) -> bool {
+            first = 0;
+            if (cnt == 0) return true;
+            const uint8_t* q = reinterpret_cast<const uint8_t*>(p);
+            auto it = std::upper_bound(var_ranges.begin(), var_ranges.end(), q, [](const uint8_t* a, const Range& r) { return a < r.lo; });
+            while (it != var_ranges.begin()) {   // ranges that could not be merged may nest: find the one holding the slice
+                --it;
+                if (q >= it->lo && q + (uint64_t)cnt * sizeof(hp_wfa_variant) <= it->hi && (uint64_t)(q - it->lo) % sizeof(hp_wfa_variant) == 0) {
+                    first = (uint32_t)(it->dev + (uint64_t)(q - it->lo) / sizeof(hp_wfa_variant));
+                    return true;
+                }
+            }
+            return false;
+        };
+        if (!var_index(j.hets, j.n_hets, d.het_first) || !var_index(j.homs, j.n_homs, d.hom_first)) { set_error("internal: variant slice not found"); return HP_ERR_INVARIANT; }
+        d.n_hets = j.n_hets; d.n_homs = j.n_homs;
+        d.read_off = seq_bytes; d.read_len = j.read_len;
+        seq_bytes += ((uint64_t)j.read_len + 15) & ~15ull;
+        const uint64_t V = (uint64_t)j.n_hets + j.n_homs;
+        const uint64_t ncap = 5 * V + 2, ecap = 4 * ncap, tcap = 2 * (uint64_t)j.n_hets + 2;
+        if (node_tot + ncap >= 0xFFFFFFF0ull || edge_tot + ecap >= 0xFFFFFFF0ull || allele_tot + j.n_hets >= 0xFFFFFFF0ull) { set_error("batch too large"); return HP_ERR_UNSUPPORTED; }
+        d.node_off = (uint32_t)node_tot; d.node_cap = (uint32_t)ncap; node_tot += ncap;
+        d.edge_off = (uint32_t)edge_tot; d.edge_cap = (uint32_t)ecap; edge_tot += ecap;
+        d.tag_off = (uint32_t)tag_tot; d.tag_cap = (uint32_t)tcap; tag_tot += tcap;
+        d.allele_off = (uint32_t)allele_tot; allele_tot += j.n_hets;
+    }
+    seq_bytes += 256;   // the 32-byte compares may run past the last base of the last read
+
+    // ---- from here on a GPU is mandatory (no CPU fallback) -------------------------------------------------------------
+    if (device_id < 0) device_id = hp_default_device();
+    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
+    const int n_cu = device_cu_count(device_id);
+    W2Context& cx = g_w2;
+    if (cx.device != device_id) {
+        cx.htab.release(); cx.htab_groups = 0; cx.tag_next = 0;
+        if (cx.stream) { (void)hipStreamDestroy(cx.stream); cx.stream = nullptr; }
+        cx.device = device_id;
+    }
+    if (!cx.stream) HP_HIP_CHECK(hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking));
+    hipStream_t st = cx.stream;
+    // host tables that stream operations read or write; the guard below (destroyed first) drains the stream on every
+    // exit path, so none of them goes out of scope with a copy in flight
+    std::vector<W2Info> info(n);
+    std::vector<uint32_t> order;
+    std::vector<int32_t> status(n), st0(n, W2_ST_NEED_BIG);
+    std::vector<uint64_t> score(n);
+    std::vector<uint8_t> al((size_t)std::max<uint64_t>(allele_tot, 1));
+    struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{st};
+
+    // ---- 2. stage + upload -----------------------------------------------------------------------------------------------
+    int rc;
+    if ((rc = cx.stage.reserve(seq_bytes)) != HP_OK) return rc;
+    {
+        uint8_t* sb = cx.stage.p;
+        uint64_t ref_total = 0;
+        for (auto& r : ref_ranges) ref_total += (uint64_t)(r.hi - r.lo);
+        uint64_t read_total = 0;
+        for (size_t i = 0; i < n; ++i) read_total += jobs[i].read_len;
+        const unsigned nt = w2_host_threads((size_t)((ref_total + read_total) >> 16) + 1, 16);
+        w2_parallel(nt, [&](unsigned t, unsigned T) {
+            constexpr uint64_t PIECE = 256u << 10;
+            uint64_t piece = 0;
+            for (const Range& r : ref_ranges) {
+                const uint64_t len = (uint64_t)(r.hi - r.lo);
+                for (uint64_t o = 0; o < len; o += PIECE, ++piece)
+                    if (piece % T == t) std::memcpy(sb + r.dev + o, r.lo + o, (size_t)std::min(PIECE, len - o));
+            }
+            for (size_t i = n * t / T; i < n * (t + 1) / T; ++i)
+                if (jobs[i].read_len) std::memcpy(sb + dj[i].read_off, jobs[i].read, jobs[i].read_len);
+            if (t == 0) {
+                for (auto& r : var_ranges) {
+                    const hp_wfa_variant* hv = reinterpret_cast<const hp_wfa_variant*>(r.lo);
+                    const size_t cnt = (size_t)(r.hi - r.lo) / sizeof(hp_wfa_variant);
+                    for (size_t k = 0; k < cnt; ++k) {
+                        const W2Variant& w = vars[(size_t)r.dev + k];
+                        if (w.a0_len) std::memcpy(sb + alt_off + w.a0_off, hv[k].allele0, w.a0_len);
+                        if (w.a1_len) std::memcpy(sb + alt_off + w.a1_off, hv[k].allele1, w.a1_len);
+                    }
+                }
+                std::memset(sb + seq_bytes - 256, 0, 256);
+            }
+        });
+    }
+    const double t_stage = w2_now_ms();
+    DevBuf d_seq, d_vars, d_jobs, d_nodes, d_edges, d_tags, d_par, d_poff, d_cnt, d_info, d_order, d_sets, d_score, d_status, d_alleles;
+    if ((rc = d_seq.alloc(seq_bytes)) || (rc = d_vars.alloc(std::max<size_t>(1, vars.size()) * sizeof(W2Variant))) || (rc = d_jobs.alloc(n * sizeof(W2Job))) ||
+        (rc = d_nodes.alloc((size_t)node_tot * sizeof(W2Node))) || (rc = d_edges.alloc((size_t)edge_tot * 2)) || (rc = d_tags.alloc((size_t)tag_tot * 4)) ||
+        (rc = d_par.alloc((size_t)edge_tot * 2)) || (rc = d_poff.alloc(((size_t)node_tot + n) * 4)) || (rc = d_cnt.alloc((size_t)node_tot * 4)) ||
+        (rc = d_info.alloc(n * sizeof(W2Info))) || (rc = d_order.alloc(n * 4)) || (rc = d_sets.alloc(n * W2_SET_STRIDE * 4)) ||
+        (rc = d_score.alloc(n * 8)) || (rc = d_status.alloc(n * 4)) || (rc = d_alleles.alloc(std::max<uint64_t>(allele_tot, 16))))
+        return rc;
+    HP_HIP_CHECK(hipMemcpyAsync(d_seq.p, cx.stage.p, seq_bytes, hipMemcpyHostToDevice, st));
+    // the small tables are pageable std::vectors that live until the end of this function; every stream operation that
+    // reads them is waited for below (hipStreamSynchronize) before they go out of scope
+    if (!vars.empty()) HP_HIP_CHECK(hipMemcpyAsync(d_vars.p, vars.data(), vars.size() * sizeof(W2Variant), hipMemcpyHostToDevice, st));
+    HP_HIP_CHECK(hipMemcpyAsync(d_jobs.p, dj.data(), n * sizeof(W2Job), hipMemcpyHostToDevice, st));
+
+    // ---- 3. graphs on the device ----------------------------------------------------------------------------------------
+    hipEvent_t e0, e1, e2, e3;
+    HP_HIP_CHECK(hipEventCreate(&e0)); HP_HIP_CHECK(hipEventCreate(&e1)); HP_HIP_CHECK(hipEventCreate(&e2)); HP_HIP_CHECK(hipEventCreate(&e3));
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e[i]); } };
+    hipEvent_t evs[4] = {e0, e1, e2, e3};
+    EvGuard evg{evs};
+    {
+        W2BuildArgs A{};
+        A.jobs = d_jobs.as<W2Job>(); A.n_jobs = (uint32_t)n; A.vars = d_vars.as<W2Variant>();
+        A.nodes = d_nodes.as<W2Node>(); A.edges = d_edges.as<uint16_t>(); A.tags = d_tags.as<uint32_t>();
+        A.par = d_par.as<uint16_t>(); A.poff = d_poff.as<uint32_t>(); A.cnt = d_cnt.as<uint32_t>(); A.info = d_info.as<W2Info>();
+        HP_HIP_CHECK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(hp_wfa2_build_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, A);
+        HP_HIP_CHECK(hipGetLastError());
+        HP_HIP_CHECK(hipEventRecord(e1, st));
+    }
+    HP_HIP_CHECK(hipMemcpyAsync(info.data(), d_info.p, n * sizeof(W2Info), hipMemcpyDeviceToHost, st));
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA graph-build kernel failed"); return HP_ERR_HIP; }
+    const double t_built = w2_now_ms();
+
+    // ---- 4. classes by graph size, longest read first ----------------------------------------------------------------------
+    std::vector<uint32_t> cls[3], big;
+    for (size_t i = 0; i < n; ++i) {
+        if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %zu", i); return HP_ERR_INVARIANT; }
+        if (info[i].status != W2B_OK || jobs[i].read_len >= (uint32_t)W2_DIAG_LIM) { big.push_back((uint32_t)i); continue; }
+        const uint32_t nn = info[i].n_nodes, ne = info[i].n_edges;
+        if (nn <= (uint32_t)W2Cfg<2>::MAXN && ne <= (uint32_t)W2Cfg<2>::MAXE) cls[0].push_back((uint32_t)i);
+        else if (nn <= (uint32_t)W2Cfg<4>::MAXN && ne <= (uint32_t)W2Cfg<4>::MAXE) cls[1].push_back((uint32_t)i);
+        else if (nn <= (uint32_t)W2Cfg<8>::MAXN && ne <= (uint32_t)W2Cfg<8>::MAXE) cls[2].push_back((uint32_t)i);
+        else big.push_back((uint32_t)i);
+    }
+    order.reserve(n);
+    size_t cls_off[3];
+    for (int k = 0; k < 3; ++k) {
+        std::stable_sort(cls[k].begin(), cls[k].end(), [&](uint32_t a, uint32_t b) { return jobs[a].read_len > jobs[b].read_len; });
+        cls_off[k] = order.size();
+        order.insert(order.end(), cls[k].begin(), cls[k].end());
+    }
+    // capped-diagonal hash sets: one per resident group, kept (and never cleared) across calls
+    const uint32_t max_groups = (uint32_t)n_cu * 32u;
+    if (cx.htab_groups < max_groups) {
+        if ((rc = cx.htab.alloc(((size_t)max_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
+        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)max_groups << W2_HCAP_LOG2) * 8, st));
+        cx.htab_groups = max_groups; cx.tag_next = 0;
+    }
+    if ((uint64_t)cx.tag_next + n + 2 >= 0xFFFFFFF0ull) {
+        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)cx.htab_groups << W2_HCAP_LOG2) * 8, st));
+        cx.tag_next = 0;
+    }
+    const uint32_t tag_base = cx.tag_next;
+    cx.tag_next += (uint32_t)n + 1;
+    if (!order.empty()) HP_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
+    {   // status of the jobs no class takes: NEED_BIG (the map kernel leaves their rows NoOverlap; the host path fills them)
+        for (int k = 0; k < 3; ++k) for (uint32_t id : cls[k]) st0[id] = W2_ST_PENDING;
+        HP_HIP_CHECK(hipMemcpyAsync(d_status.p, st0.data(), n * 4, hipMemcpyHostToDevice, st));
+        HP_HIP_CHECK(hipMemsetAsync(d_sets.p, 0, n * W2_SET_STRIDE * 4, st));
+    }
+    W2Batch B{};
+    B.jobs = d_jobs.as<W2Job>(); B.info = d_info.as<W2Info>(); B.tag_base = tag_base;
+    B.nodes = d_nodes.as<W2Node>(); B.edges = d_edges.as<uint16_t>(); B.seq = d_seq.as<uint8_t>(); B.alt_off = alt_off;
+    B.out_sets = d_sets.as<uint32_t>(); B.out_score = d_score.as<uint64_t>(); B.status = d_status.as<int32_t>();
+    B.htab = cx.htab.as<uint64_t>(); B.hcap_log2 = W2_HCAP_LOG2; B.prune_distance = prune_distance; B.max_ed = max_ed;
+    HP_HIP_CHECK(hipEventRecord(e2, st));
+    uint32_t groups_used[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+        if (cls[k].empty()) continue;
+        B.order = d_order.as<uint32_t>() + cls_off[k];
+        B.n_items = (uint32_t)cls[k].size();
+        if (k == 0) rc = w2_launch<8, 2>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k]);
+        else if (k == 1) rc = w2_launch<8, 4>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k]);
+        else rc = w2_launch<16, 8>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k]);
+        if (rc != HP_OK) return rc;
+    }
+    {
+        W2MapArgs M{};
+        M.jobs = d_jobs.as<W2Job>(); M.info = d_info.as<W2Info>(); M.n_jobs = (uint32_t)n; M.tags = d_tags.as<uint32_t>();
+        M.out_sets = d_sets.as<uint32_t>(); M.status = d_status.as<int32_t>(); M.alleles = d_alleles.as<uint8_t>();
+        hipLaunchKernelGGL(hp_wfa2_map_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, M);
+        HP_HIP_CHECK(hipGetLastError());
+    }
+    HP_HIP_CHECK(hipEventRecord(e3, st));
+    // ---- 5. results --------------------------------------------------------------------------------------------------------
+    HP_HIP_CHECK(hipMemcpyAsync(status.data(), d_status.p, n * 4, hipMemcpyDeviceToHost, st));
+    HP_HIP_CHECK(hipMemcpyAsync(score.data(), d_score.p, n * 8, hipMemcpyDeviceToHost, st));
+    if (allele_tot) HP_HIP_CHECK(hipMemcpyAsync(al.data(), d_alleles.p, (size_t)allele_tot, hipMemcpyDeviceToHost, st));
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
+    float ms_build = 0.f, ms_wfa = 0.f;
+    (void)hipEventElapsedTime(&ms_build, e0, e1);
+    (void)hipEventElapsedTime(&ms_wfa, e2, e3);
+    g_last_kernel_ms = (double)ms_build + (double)ms_wfa;
+    const double t_done = w2_now_ms();
+    size_t n_big = big.size();
+    for (size_t i = 0; i < n; ++i) {
+        if (status[i] == W2_ST_NEED_BIG) { if (std::find(big.begin(), big.end(), (uint32_t)i) == big.end()) { big.push_back((uint32_t)i); } continue; }
+        if (status[i] != W2_ST_OK && status[i] != W2_ST_MAX_ED) { set_error("job %zu: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
+        out[i].status = status[i] == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
+        out[i].n_nodes = info[i].n_nodes;
+        out[i].score = score[i];
+        if (alleles && alleles[i] && jobs[i].n_hets) std::memcpy(alleles[i], al.data() + dj[i].allele_off, jobs[i].n_hets);
+    }
+    if (verbose) {
+        fprintf(stderr, "[hp] wfa2: %zu jobs (classes %zu/%zu/%zu, groups %u/%u/%u, %zu to the dense-band path of which %zu by size/builder): layout+stage %.2f ms, upload+build %.2f ms (build kernel %.3f), wfa+map kernels %.3f ms, total %.2f ms\n",
+                n, cls[0].size(), cls[1].size(), cls[2].size(), groups_used[0], groups_used[1], groups_used[2], big.size(), n_big, t_stage - t0, t_built - t_stage, ms_build, ms_wfa, t_done - t0);
+        fflush(stderr);
+    }
+    // ---- 6. leftovers through the dense-band path ----------------------------------------------------------------------------
+    if (!big.empty()) {
+        const double saved_ms = g_last_kernel_ms;
+        std::sort(big.begin(), big.end());
+        std::vector<hp_wfa_job> sub(big.size());
+        std::vector<hp_wfa_result> sub_out(big.size());
+        std::vector<uint8_t*> sub_al(big.size());
+        for (size_t k = 0; k < big.size(); ++k) { sub[k] = jobs[big[k]]; sub_al[k] = alleles ? alleles[big[k]] : nullptr; }
+        rc = wfa_assign_batch_v1(sub.data(), sub.size(), prune_distance, max_ed, sub_out.data(), alleles ? sub_al.data() : nullptr, device_id);
+        if (rc != HP_OK) return rc;
+        for (size_t k = 0; k < big.size(); ++k) out[big[k]] = sub_out[k];
+        g_last_kernel_ms += saved_ms;
+    }
+    return HP_OK;
+}
+
+}  // namespace hp

@@ -1,0 +1,281 @@
+// hp_wfa2_dev.h — device-resident graph-WFA stage, second generation (round 2).
+//
+// Data layout in HBM for one batch of BAM records ("jobs", reference src/read_parsing.rs:738-780):
+//   seq[]      one byte buffer: [merged reference ranges][allele pool][read bases][pad]
+//   vars[]     W2Variant: every distinct hp_wfa_variant of the batch ONCE (the reads of a block pass slices of the
+//              block's variant vectors; the host merges their address ranges like it merges the reference windows)
+//   jobs[]     W2Job: window + variant index ranges + read + where the job's graph lives
+//   gnodes[]   W2Node (12 B): the job's graph, written by w2_build (one thread per job, hp_wfa2_build_kernel)
+//   gedges[]   u16 children lists (creation order is irrelevant to the results: injections are set unions)
+//   gtags[]    node -> (het index, allele) table (wfa_graph.rs:19 NodeAlleleMap), in node order
+// w2_build restates WFAGraph::from_reference_variants_with_hom (wfa_graph.rs:119-284) over sequence SPANS; it is plain
+// C++ that compiles for the device (hipcc) and for the host (the CPU model in tests/cpp/wfa2_model.cpp, which pins
+// this builder and the compact wavefront formulation of hp_wfa2_kernel.hip against the oracle without a GPU).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define HP_HD __host__ __device__ inline
+#else
+#define HP_HD inline
+#endif
+
+namespace hp {
+
+struct W2Variant {          // 32 B
+    int64_t  position;      // Variant::position()
+    uint32_t ref_len;       // get_ref_len()
+    uint32_t flags;         // bit0 ignored, bit1 allele0 is itself an ALT (index_allele0 != 0)
+    uint32_t a0_off, a0_len;   // truncated allele0 in the allele pool (only read when flags & 2)
+    uint32_t a1_off, a1_len;   // truncated allele1
+};
+
+struct W2Job {              // 80 B
+    uint64_t ref_off;       // byte offset in seq[] of reference base `ref_start`
+    uint64_t read_off;      // byte offset in seq[] of read[0]
+    int64_t  ref_start;     // chromosome coordinate of the window start (min_position)
+    uint32_t ref_len;       // ref_end - ref_start
+    uint32_t read_len;
+    uint32_t het_first, n_hets;   // into vars[]
+    uint32_t hom_first, n_homs;
+    uint32_t node_off, node_cap;  // into gnodes / per-node scratch
+    uint32_t edge_off, edge_cap;  // into gedges / parent scratch
+    uint32_t tag_off, tag_cap;    // into gtags
+    uint32_t allele_off;          // into the output allele pool (n_hets bytes)
+    uint32_t group;               // caller-defined (block-level path: qname group); unused by the WFA stage
+};
+
+struct W2Node {             // 12 B, the LDS copy has the same layout
+    uint32_t seq_off;       // reference node: offset inside the job's window; allele node: offset in the allele pool
+    uint32_t len_ref;       // length | is_reference << 31
+    uint32_t child;         // child_off | n_children << 16   (child_off relative to the job's edge list)
+};
+constexpr uint32_t W2_IS_REF = 0x80000000u;
+
+struct W2Info {             // builder output per job
+    uint32_t n_nodes, n_edges, n_tags;
+    int32_t  status;        // W2B_*
+};
+constexpr int32_t W2B_OK = 0;
+constexpr int32_t W2B_NEED_HOST = 1;   // outside the device builder's small fixed queues / 16-bit ids: the host path builds it
+constexpr int32_t W2B_INVARIANT = -3;  // an assert! of wfa_graph.rs:170,257,276,281 would have fired
+
+// tag word: node | het index << 16 | allele << 31
+HP_HD uint32_t w2_tag(uint32_t node, uint32_t vi, uint32_t allele) { return node | (vi << 16) | (allele << 31); }
+
+constexpr int W2B_MAXQ = 24;    // alt nodes waiting to reconnect
+constexpr int W2B_MAXRR = 32;   // reference_reconnect
+constexpr int W2B_MAXRA = 32;   // reference alleles waiting for the next reference node
+
+// WFAGraph::from_reference_variants_with_hom (wfa_graph.rs:119-284) for one job. Scratch: par[edge_cap] (u16),
+// poff[node_cap + 1] (u32), cnt[node_cap] (u32). Node ids are creation order (wfa_graph.rs:298-331).
+HP_HD void w2_build(const W2Job& J, const W2Variant* vars, W2Node* nodes, uint16_t* edges, uint32_t* tags,
+                    uint16_t* par, uint32_t* poff, uint32_t* cnt, W2Info* info) {
+    uint32_t nn = 0, ne = 0, nt = 0;
+    int32_t status = W2B_OK;
+    const int64_t ref_start = J.ref_start, ref_end = J.ref_start + (int64_t)J.ref_len;
+    int64_t previous_end = ref_start;
+    uint32_t rr[W2B_MAXRR]; int nrr = 0;      // reference_reconnect
+    uint32_t ra[W2B_MAXRA]; int nra = 0;      // pending (het index, 0) tags
+    int64_t qpos[W2B_MAXQ]; uint32_t qalt[W2B_MAXQ]; int nq = 0;   // reconnect queue, ascending position
+    poff[0] = 0;
+
+    // add_node (wfa_graph.rs:298-331); parents = the current reference_reconnect
+    auto add_node = [&](uint32_t seq_off, uint32_t len, bool is_ref) -> int {
+        if (nn == 0) { if (nrr != 0) { status = W2B_INVARIANT; return -1; } }
+        else if (nrr == 0) { status = W2B_INVARIANT; return -1; }
+        if (nn >= J.node_cap || nn >= 65535u || ne + (uint32_t)nrr > J.edge_cap || ne + (uint32_t)nrr > 65535u || len >= W2_IS_REF) {
+            status = W2B_NEED_HOST; return -1;
+        }
+        nodes[nn].seq_off = seq_off;
+        nodes[nn].len_ref = len | (is_ref ? W2_IS_REF : 0u);
+        nodes[nn].child = 0;
+        for (int k = 0; k < nrr; ++k) par[ne + k] = (uint16_t)rr[k];
+        ne += (uint32_t)nrr;
+        poff[nn + 1] = ne;
+        return (int)nn++;
+    };
+    auto flush_ref_alleles = [&](uint32_t node) {
+        for (int k = 0; k < nra; ++k) {
+            if (nt >= J.tag_cap) { status = W2B_NEED_HOST; return; }
+            tags[nt++] = w2_tag(node, ra[k], 0u);
+        }
+        nra = 0;
+    };
+    // wfa_graph.rs:168-189 and :256-272
+    auto drain_one = [&]() -> bool {
+        const int64_t alt_reconnect = qpos[0];
+        const uint32_t alt_index = qalt[0];
+        for (int k = 1; k < nq; ++k) { qpos[k - 1] = qpos[k]; qalt[k - 1] = qalt[k]; }
+        --nq;
+        if (!(alt_reconnect > previous_end)) { status = W2B_INVARIANT; return false; }
+        const int ri = add_node((uint32_t)(previous_end - ref_start), (uint32_t)(alt_reconnect - previous_end), true);
+        if (ri < 0) return false;
+        flush_ref_alleles((uint32_t)ri);
+        if (status != W2B_OK) return false;
+        previous_end = alt_reconnect;
+        nrr = 0;
+        rr[nrr++] = (uint32_t)ri;
+        rr[nrr++] = alt_index;
+        while (nq > 0 && qpos[0] == alt_reconnect) {
+            if (nrr >= W2B_MAXRR) { status = W2B_NEED_HOST; return false; }
+            rr[nrr++] = qalt[0];
+            for (int k = 1; k < nq; ++k) { qpos[k - 1] = qpos[k]; qalt[k - 1] = qalt[k]; }
+            --nq;
+        }
+        return true;
+    };
+    auto queue_insert = [&](int64_t pos, uint32_t alt) -> bool {
+        if (nq >= W2B_MAXQ) { status = W2B_NEED_HOST; return false; }
+        int k = nq;
+        while (k > 0 && qpos[k - 1] > pos) { qpos[k] = qpos[k - 1]; qalt[k] = qalt[k - 1]; --k; }
+        qpos[k] = pos; qalt[k] = alt;
+        ++nq;
+        return true;
+    };
+
+    // stable merge of hets and homs by position, hets first on ties (wfa_graph.rs:137-144); both lists must arrive
+    // sorted (they are slices of position-sorted vectors) - otherwise the host path sorts
+    uint32_t ih = 0, im = 0;
+    int64_t last_het = INT64_MIN, last_hom = INT64_MIN;
+    while (status == W2B_OK && (ih < J.n_hets || im < J.n_homs)) {
+        bool take_het;
+        if (im >= J.n_homs) take_het = true;
+        else if (ih >= J.n_hets) take_het = false;
+        else take_het = vars[J.het_first + ih].position <= vars[J.hom_first + im].position;
+        const W2Variant v = take_het ? vars[J.het_first + ih] : vars[J.hom_first + im];
+        const int64_t vi = take_het ? (int64_t)ih : -1;
+        if (take_het) { if (v.position < last_het) { status = W2B_NEED_HOST; break; } last_het = v.position; ++ih; }
+        else { if (v.position < last_hom) { status = W2B_NEED_HOST; break; } last_hom = v.position; ++im; }
+        if (vi >= 32768) { status = W2B_NEED_HOST; break; }
+        if (v.flags & 1u) continue;                                   // is_ignored (wfa_graph.rs:147-150)
+        if (v.position < ref_start) continue;                         // :155-159
+        const int64_t pos = v.position;
+        if (pos + (int64_t)v.ref_len > ref_end) continue;             // :160-164
+        bool ok = true;
+        while (ok && nq > 0 && qpos[0] <= pos) ok = drain_one();
+        if (!ok) break;
+        if (previous_end < pos || nn == 0) {                          // :196-209
+            const int ri = add_node((uint32_t)(previous_end - ref_start), (uint32_t)(pos - previous_end), true);
+            if (ri < 0) break;
+            flush_ref_alleles((uint32_t)ri);
+            if (status != W2B_OK) break;
+            nrr = 0;
+            rr[nrr++] = (uint32_t)ri;
+            previous_end = pos;
+        } else if (previous_end != pos) { status = W2B_INVARIANT; break; }
+        if (v.flags & 2u) {                                           // allele0 is itself an ALT (:217-231)
+            const int ai = add_node(v.a0_off, v.a0_len, false);
+            if (ai < 0) break;
+            if (vi >= 0) { if (nt >= J.tag_cap) { status = W2B_NEED_HOST; break; } tags[nt++] = w2_tag((uint32_t)ai, (uint32_t)vi, 0u); }
+            if (!queue_insert(pos + (int64_t)v.ref_len, (uint32_t)ai)) break;
+        } else if (vi >= 0) {
+            if (nra >= W2B_MAXRA) { status = W2B_NEED_HOST; break; }
+            ra[nra++] = (uint32_t)vi;                                 // tags the NEXT reference node (:233-237)
+        }
+        const int ai = add_node(v.a1_off, v.a1_len, false);           // :240-251
+        if (ai < 0) break;
+        if (vi >= 0) { if (nt >= J.tag_cap) { status = W2B_NEED_HOST; break; } tags[nt++] = w2_tag((uint32_t)ai, (uint32_t)vi, 1u); }
+        if (!queue_insert(pos + (int64_t)v.ref_len, (uint32_t)ai)) break;
+    }
+    while (status == W2B_OK && nq > 0) if (!drain_one()) break;
+    if (status == W2B_OK && !(previous_end <= ref_end)) status = W2B_INVARIANT;
+    if (status == W2B_OK) {
+        const int ri = add_node((uint32_t)(previous_end - ref_start), (uint32_t)(ref_end - previous_end), true);
+        if (ri >= 0 && nra != 0) status = W2B_INVARIANT;   // assert!(reference_alleles.is_empty()) (:281)
+    }
+    // children lists: count, prefix, fill (ascending child id)
+    if (status == W2B_OK) {
+        for (uint32_t n = 0; n < nn; ++n) cnt[n] = 0;
+        for (uint32_t e = 0; e < ne; ++e) cnt[par[e]]++;
+        uint32_t run = 0;
+        for (uint32_t n = 0; n < nn; ++n) {
+            const uint32_t c = cnt[n];
+            if (c > 65535u) { status = W2B_NEED_HOST; break; }
+            nodes[n].child = run | (c << 16);
+            cnt[n] = run;
+            run += c;
+        }
+        if (status == W2B_OK)
+            for (uint32_t n = 1; n < nn; ++n)
+                for (uint32_t e = poff[n]; e < poff[n + 1]; ++e) edges[cnt[par[e]]++] = (uint16_t)n;
+    }
+    info->n_nodes = nn;
+    info->n_edges = ne;
+    info->n_tags = nt;
+    info->status = status;
+}
+
+// read_parsing.rs:790-800: traversed nodes in ascending id; first assignment wins, a different one -> Ambiguous
+HP_HD void w2_map_alleles(const uint32_t* tags, uint32_t n_tags, const uint32_t* set, bool ok, uint8_t* alleles, uint32_t n_hets) {
+    for (uint32_t k = 0; k < n_hets; ++k) alleles[k] = 3;   // NoOverlap
+    if (!ok) return;
+    for (uint32_t t = 0; t < n_tags; ++t) {
+        const uint32_t w = tags[t], node = w & 0xFFFFu, vi = (w >> 16) & 0x7FFFu, a = w >> 31;
+        if (!((set[node >> 5] >> (node & 31u)) & 1u)) continue;
+        if (alleles[vi] == 3) alleles[vi] = (uint8_t)a;
+        else if (alleles[vi] != (uint8_t)a) alleles[vi] = 2;   // Ambiguous
+    }
+}
+
+// ---- compact wavefront state of hp_wfa2_kernel (per read, in LDS) ---------------------------------------------------
+// A round's waves are kept per LIVE node as a dense array over that node's hull of diagonals (slots of the round's
+// arena); the next round pulls from the previous round's arena (d+1: offset+1, d: offset+1, d-1: offset) and from
+// the same-round injection list. The only state that outlives two rounds is the set of (node, diagonal) pairs whose
+// wave reached its cap min(node length, read length - diagonal): see "capped diagonals" in hp_wfa2_kernel.hip.
+constexpr int32_t W2_ST_OK = 0;
+constexpr int32_t W2_ST_MAX_ED = 1;
+constexpr int32_t W2_ST_NEED_BIG = 2;     // outgrew the compact state: the job is re-run by the dense-band kernel
+constexpr int32_t W2_ST_PENDING = 7;
+constexpr int32_t W2_ST_INTERNAL = -3;
+
+constexpr uint32_t W2_KIND_NONE = 0;
+constexpr uint32_t W2_KIND_FINISHED = 2;       // max_offset == node_length, not the last node: the node's children take it up THIS round
+constexpr uint32_t W2_KIND_INTERIOR = 1;       // max_offset < node_length: the -1 diagonal gets a wave
+constexpr uint32_t W2_KIND_INTERIOR_READ = 3;  // ... and the read has bases left: 0 / +1 diagonals too
+constexpr uint32_t W2_KIND_END_LAST = 4;       // end of the LAST node with read left: only the +1 diagonal
+
+constexpr uint32_t W2_MAX_STEPS = 1u << 24;    // watchdog on the tiles of one job
+constexpr int W2_SET_STRIDE = 8;               // out_sets: 8 words per job (graphs of up to 256 nodes)
+constexpr int32_t W2_DIAG_LIM = 1 << 17;       // |diagonal| representable in a capped-set key
+
+template <int W> struct W2Cfg {
+    static constexpr int MAXN = 32 * W;          // nodes
+    static constexpr int MAXE = 3 * MAXN;        // edges
+    static constexpr int MAXL = W <= 2 ? 24 : (W <= 4 ? 32 : 56);     // entries (clusters of diagonals of one node) per round
+    static constexpr int SLOTS = W <= 2 ? 80 : (W <= 4 ? 112 : 144);  // (node, diagonal) slots per round
+    static constexpr int MAXP = 64;              // (child, finished parent entry) pairs per round
+    static constexpr int MAXS = 8;               // source intervals of one node in one round
+    static constexpr int a16(int x) { return (x + 15) & ~15; }
+    static constexpr int O_DESC = 0;                                  // W2Node[MAXN]
+    static constexpr int O_EDGE = O_DESC + 12 * MAXN;                 // u16[MAXE]
+    static constexpr int O_LIVE = a16(O_EDGE + 2 * MAXE);             // uint4[2][MAXL]
+    static constexpr int O_EK = O_LIVE + 2 * 16 * MAXL;               // u32[2][SLOTS]: offset << 3 | kind
+    static constexpr int O_SET = a16(O_EK + 2 * 4 * SLOTS);           // u32[2][SLOTS][W]
+    static constexpr int O_PAIR = O_SET + 2 * SLOTS * 4 * W;          // u32[MAXP]: child | parent entry << 16
+    static constexpr int O_MISC = a16(O_PAIR + 4 * MAXP);             // pend[W], outset[W]
+    static constexpr int O_SRC = a16(O_MISC + 8 * W);                 // int2[MAXS] source / item intervals, u32[MAXS] parent entries
+    static constexpr int BYTES = a16(O_SRC + 12 * MAXS);
+};
+
+struct W2Batch {
+    const W2Job* jobs;
+    const W2Info* info;
+    const uint32_t* order;     // job ids of this launch's class, longest read first
+    uint32_t n_items;
+    uint32_t tag_base;         // capped-set keys carry tag_base + job + 1 (never 0 = empty)
+    const W2Node* nodes;
+    const uint16_t* edges;
+    const uint8_t* seq;
+    uint64_t alt_off;          // byte offset of the allele pool inside seq[]
+    uint32_t* out_sets;        // [n_jobs][W2_SET_STRIDE]
+    uint64_t* out_score;
+    int32_t* status;
+    uint64_t* htab;            // [groups][1 << hcap_log2] capped-diagonal hash sets, never cleared (tagged)
+    uint32_t hcap_log2;
+    uint32_t pad;
+    uint64_t prune_distance;   // UINT64_MAX disables pruning
+    uint64_t max_ed;
+};
+
+}  // namespace hp
