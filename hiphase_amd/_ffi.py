@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhiphase_gpu.so")
+# HP_LIB names another in-tree build of the same library (e.g. the instrumented one scripts/prof_wfa2.sh makes)
+LIB_PATH = os.environ.get("HP_LIB") or os.path.join(_HERE, "libhiphase_gpu.so")
 
 
 class HpError(RuntimeError):

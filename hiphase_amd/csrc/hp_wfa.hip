@@ -561,14 +561,18 @@ int wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
 }
 using namespace hp;
 
-// The compact several-reads-per-wavefront kernel (hp_wfa2.hip) takes every job it can hold; HP_WFA_V1=1 forces the
-// dense-band path below for all of them (the path the leftovers take anyway).
+// Two kernels, one result: a batch large enough to fill the chip goes to the compact several-reads-per-wavefront kernel
+// (hp_wfa2.hip: ~5x fewer instructions per read, throughput-bound); a small batch is latency-bound and goes to the
+// one-read-per-wavefront dense-band kernel below (a lone wavefront steps ~3x faster through its read than a group that
+// shares its wavefront with seven others). HP_WFA2_MIN_JOBS moves the switch (0: always the compact kernel,
+// a huge value: never); the compact path hands whatever outgrows its state back to this one.
 extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
                                    hp_wfa_result* out, uint8_t* const* alleles, int device_id) {
     const double t0 = now_ms();
-    const char* v1 = std::getenv("HP_WFA_V1");
-    const int rc = (v1 && v1[0] == '1') ? wfa_assign_batch_v1(jobs, n, prune_distance, max_ed, out, alleles, device_id)
-                                        : wfa_assign_batch_v2(jobs, n, prune_distance, max_ed, out, alleles, device_id);
+    const char* mj = std::getenv("HP_WFA2_MIN_JOBS");
+    const size_t min_jobs = mj ? (size_t)std::strtoull(mj, nullptr, 10) : 4608;
+    const int rc = n < min_jobs ? wfa_assign_batch_v1(jobs, n, prune_distance, max_ed, out, alleles, device_id)
+                                : wfa_assign_batch_v2(jobs, n, prune_distance, max_ed, out, alleles, device_id);
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] hp_wfa_assign_batch total %.2f ms\n", now_ms() - t0); fflush(stderr); }
     return rc;
 }

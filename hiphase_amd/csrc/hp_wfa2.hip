@@ -56,11 +56,13 @@ struct PinBuf {
 };
 
 constexpr uint32_t W2_HCAP_LOG2 = 11;   // 2048 keys (16 KiB) per group
+constexpr uint32_t W2_GSET_STRIDE = W2Cfg<8>::SET_DWORDS;   // dwords per group, sized for the largest class
 
 // per-(thread, device) state that survives across calls
 struct W2Context {
     int device = -1;
     DevBuf htab;             // capped-diagonal hash sets, [groups][1 << W2_HCAP_LOG2]; zeroed once, then tagged
+    DevBuf gsets;            // [groups][W2_SET_STRIDE_MAX] the arena slots' traversed-node sets
     uint32_t htab_groups = 0;
     uint32_t tag_next = 0;   // tags handed out so far (tag 0 = empty)
     PinBuf stage;            // upload staging: seq bytes, then the tables
@@ -220,7 +222,7 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
     const int n_cu = device_cu_count(device_id);
     W2Context& cx = g_w2;
     if (cx.device != device_id) {
-        cx.htab.release(); cx.htab_groups = 0; cx.tag_next = 0;
+        cx.htab.release(); cx.gsets.release(); cx.htab_groups = 0; cx.tag_next = 0;
         if (cx.stream) { (void)hipStreamDestroy(cx.stream); cx.stream = nullptr; }
         cx.device = device_id;
     }
@@ -322,9 +324,10 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
         order.insert(order.end(), cls[k].begin(), cls[k].end());
     }
     // capped-diagonal hash sets: one per resident group, kept (and never cleared) across calls
-    const uint32_t max_groups = (uint32_t)n_cu * 32u;
+    const uint32_t max_groups = (uint32_t)n_cu * 64u;   // up to 8 resident workgroups of 8 groups per CU
     if (cx.htab_groups < max_groups) {
         if ((rc = cx.htab.alloc(((size_t)max_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
+        if ((rc = cx.gsets.alloc((size_t)max_groups * W2_GSET_STRIDE * 4)) != HP_OK) return rc;
         HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)max_groups << W2_HCAP_LOG2) * 8, st));
         cx.htab_groups = max_groups; cx.tag_next = 0;
     }
@@ -344,15 +347,19 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
     B.jobs = d_jobs.as<W2Job>(); B.info = d_info.as<W2Info>(); B.tag_base = tag_base;
     B.nodes = d_nodes.as<W2Node>(); B.edges = d_edges.as<uint16_t>(); B.seq = d_seq.as<uint8_t>(); B.alt_off = alt_off;
     B.out_sets = d_sets.as<uint32_t>(); B.out_score = d_score.as<uint64_t>(); B.status = d_status.as<int32_t>();
-    B.htab = cx.htab.as<uint64_t>(); B.hcap_log2 = W2_HCAP_LOG2; B.prune_distance = prune_distance; B.max_ed = max_ed;
+    B.htab = cx.htab.as<uint64_t>(); B.hcap_log2 = W2_HCAP_LOG2; B.gsets = cx.gsets.as<uint32_t>(); B.set_stride = W2_GSET_STRIDE; B.prune_distance = prune_distance; B.max_ed = max_ed;
     HP_HIP_CHECK(hipEventRecord(e2, st));
     uint32_t groups_used[3] = {0, 0, 0};
     for (int k = 0; k < 3; ++k) {
         if (cls[k].empty()) continue;
         B.order = d_order.as<uint32_t>() + cls_off[k];
         B.n_items = (uint32_t)cls[k].size();
+        const char* genv = std::getenv("HP_WFA2_G");   // experiment: lanes per read for the middle class
+        const int gsel = genv ? std::atoi(genv) : 8;
         if (k == 0) rc = w2_launch<8, 2>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k]);
-        else if (k == 1) rc = w2_launch<8, 4>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k]);
+        else if (k == 1) rc = gsel == 16 ? w2_launch<16, 4>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k])
+                            : gsel == 32 ? w2_launch<32, 4>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k])
+                                         : w2_launch<8, 4>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k]);
         else rc = w2_launch<16, 8>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k]);
         if (rc != HP_OK) return rc;
     }
@@ -369,6 +376,9 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
     HP_HIP_CHECK(hipMemcpyAsync(score.data(), d_score.p, n * 8, hipMemcpyDeviceToHost, st));
     if (allele_tot) HP_HIP_CHECK(hipMemcpyAsync(al.data(), d_alleles.p, (size_t)allele_tot, hipMemcpyDeviceToHost, st));
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
+#if W2_PROF
+    (void)hipDeviceSynchronize();   // flushes the instrumented kernel's printf buffer
+#endif
     float ms_build = 0.f, ms_wfa = 0.f;
     (void)hipEventElapsedTime(&ms_build, e0, e1);
     (void)hipEventElapsedTime(&ms_wfa, e2, e3);

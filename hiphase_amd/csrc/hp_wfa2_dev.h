@@ -238,24 +238,33 @@ constexpr uint32_t W2_KIND_END_LAST = 4;       // end of the LAST node with read
 constexpr uint32_t W2_MAX_STEPS = 1u << 24;    // watchdog on the tiles of one job
 constexpr int W2_SET_STRIDE = 8;               // out_sets: 8 words per job (graphs of up to 256 nodes)
 constexpr int32_t W2_DIAG_LIM = 1 << 17;       // |diagonal| representable in a capped-set key
+constexpr uint32_t W2_LDS_LEN_LIM = 1u << 18;  // node length / 1024 edges / 7 children: what the packed LDS node descriptor holds
 
+// LDS layout of one read (group). Entries ("clusters": a run of diagonals of one node that holds a wave) are uint4
+// headers: x = node | first slot << 16, y = first diagonal, z = live hull lo | hi << 8 | finished hull lo << 16 | hi << 24
+// (relative to y; lo > hi = empty), w = node length. Entries with a live wave go to the round's L list (two rounds
+// deep: the next round pulls from them); entries that only hold FINISHED waves are needed by the node's children in
+// the same round only and go to the F list. A parent entry is named by a code: L index, or 128 + F index.
 template <int W> struct W2Cfg {
     static constexpr int MAXN = 32 * W;          // nodes
-    static constexpr int MAXE = 3 * MAXN;        // edges
-    static constexpr int MAXL = W <= 2 ? 24 : (W <= 4 ? 32 : 56);     // entries (clusters of diagonals of one node) per round
+    static constexpr int MAXE = 2 * MAXN + 32;   // edges
+    static constexpr int MAXL = W <= 2 ? 24 : (W <= 4 ? 32 : 56);     // live entries per round
+    static constexpr int MAXF = W <= 2 ? 16 : (W <= 4 ? 24 : 32);     // finished-only entries per round
     static constexpr int SLOTS = W <= 2 ? 80 : (W <= 4 ? 112 : 144);  // (node, diagonal) slots per round
-    static constexpr int MAXP = 64;              // (child, finished parent entry) pairs per round
-    static constexpr int MAXS = 8;               // source intervals of one node in one round
+    static constexpr int MAXQ = 8;               // nodes waiting for their turn with waves handed over by parents
+    static constexpr int MAXPAR = 8;             // finished parent entries of one node in one round
+    static constexpr int MAXS = 12;              // source intervals of one node (slow path scratch)
+    static constexpr int MAXW = 250;             // diagonals per entry (8-bit relative hulls)
     static constexpr int a16(int x) { return (x + 15) & ~15; }
-    static constexpr int O_DESC = 0;                                  // W2Node[MAXN]
-    static constexpr int O_EDGE = O_DESC + 12 * MAXN;                 // u16[MAXE]
-    static constexpr int O_LIVE = a16(O_EDGE + 2 * MAXE);             // uint4[2][MAXL]
-    static constexpr int O_EK = O_LIVE + 2 * 16 * MAXL;               // u32[2][SLOTS]: offset << 3 | kind
-    static constexpr int O_SET = a16(O_EK + 2 * 4 * SLOTS);           // u32[2][SLOTS][W]
-    static constexpr int O_PAIR = O_SET + 2 * SLOTS * 4 * W;          // u32[MAXP]: child | parent entry << 16
-    static constexpr int O_MISC = a16(O_PAIR + 4 * MAXP);             // pend[W], outset[W]
-    static constexpr int O_SRC = a16(O_MISC + 8 * W);                 // int2[MAXS] source / item intervals, u32[MAXS] parent entries
-    static constexpr int BYTES = a16(O_SRC + 12 * MAXS);
+    static constexpr int O_DESC = 0;                                  // uint2[MAXN]: seq_off, len | is_ref << 18 | child_off << 19 | n_children << 29
+    static constexpr int O_EDGE = O_DESC + 8 * MAXN;                  // u8[MAXE]
+    static constexpr int O_LIVE = a16(O_EDGE + MAXE);                 // uint4[2][MAXL]
+    static constexpr int O_FIN = O_LIVE + 2 * 16 * MAXL;              // uint4[MAXF]
+    static constexpr int O_EK = O_FIN + 16 * MAXF;                    // u32[2][SLOTS]: offset << 3 | kind
+    static constexpr int O_MISC = a16(O_EK + 2 * 4 * SLOTS);          // outset[W]
+    static constexpr int O_SRC = a16(O_MISC + 4 * W);                 // int2[MAXS] item intervals (far-apart sources only)
+    static constexpr int BYTES = a16(O_SRC + 8 * MAXS);
+    static constexpr int SET_DWORDS = 2 * SLOTS * W;                  // per group in HBM: the slots' traversed-node sets
 };
 
 struct W2Batch {
@@ -272,8 +281,9 @@ struct W2Batch {
     uint64_t* out_score;
     int32_t* status;
     uint64_t* htab;            // [groups][1 << hcap_log2] capped-diagonal hash sets, never cleared (tagged)
+    uint32_t* gsets;           // [groups][set_stride] traversed-node sets of the arena slots (consumed off the critical path)
+    uint32_t set_stride;
     uint32_t hcap_log2;
-    uint32_t pad;
     uint64_t prune_distance;   // UINT64_MAX disables pruning
     uint64_t max_ed;
 };

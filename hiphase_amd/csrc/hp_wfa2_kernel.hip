@@ -27,21 +27,39 @@
 namespace hp {
 
 #define W2DEV __device__ __forceinline__
+#ifndef W2_PROF
+#define W2_PROF 0
+#endif
+#if W2_PROF
+#define W2PT(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); w2pc[i] += t_ - w2tl; w2tl = t_; } while (0)
+#define W2PC(i, v) do { w2pn[i] += (v); } while (0)
+#else
+#define W2PT(i)
+#define W2PC(i, v)
+#endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char w2_smem[];
 
 W2DEV uint32_t w2_lane() { return __lane_id(); }
 W2DEV uint64_t w2_ld8(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
-struct W2Pre16 { uint64_t a0, a1, b0, b1; };
-W2DEV W2Pre16 w2_pre16(const uint8_t* a, const uint8_t* b, bool on) {
-    W2Pre16 p{0, 0, 0, 0};
-    if (on) { p.a0 = w2_ld8(a); p.a1 = w2_ld8(a + 8); p.b0 = w2_ld8(b); p.b1 = w2_ld8(b + 8); }
-    return p;
+// ---- 16-byte windows -------------------------------------------------------------------------------------------------
+W2DEV uint4 w2_ld16(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+// common prefix (0..16) of two 16-byte windows
+W2DEV uint32_t w2_pfx16(const uint4& a, const uint4& b) {
+    const uint32_t x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
+    if (x0) return (uint32_t)__builtin_ctz(x0) >> 3;
+    if (x1) return 4u + ((uint32_t)__builtin_ctz(x1) >> 3);
+    if (x2) return 8u + ((uint32_t)__builtin_ctz(x2) >> 3);
+    if (x3) return 12u + ((uint32_t)__builtin_ctz(x3) >> 3);
+    return 16u;
 }
-W2DEV uint32_t w2_pre16_len(const W2Pre16& p) {
-    const uint64_t x0 = p.a0 ^ p.b0, x1 = p.a1 ^ p.b1;
-    return x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : (x1 ? 8u + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16u);
+struct W2Pre { uint4 a, b; };
+W2DEV W2Pre w2_pre(const uint8_t* a, const uint8_t* b, bool on) {
+    W2Pre p;
+    p.a = make_uint4(0, 0, 0, 0); p.b = p.a;
+    if (on) { p.a = w2_ld16(a); p.b = w2_ld16(b); }
+    return p;
 }
 
 // ---- group collectives (G consecutive lanes; every lane of the group must be active) -------------------------------
@@ -50,65 +68,64 @@ template <int G> W2DEV uint64_t w2_gballot(bool pred, uint32_t gbase) {
     if (G == 64) return b;
     return (b >> gbase) & ((1ull << (G & 63)) - 1ull);
 }
+// Reductions over the G lanes of a group on the vector ALU (DPP lane exchanges; no trip through the LDS crossbar as
+// __shfl would take): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror (i <-> 7-i), row_mirror (i <-> 15-i).
+// `old` = the lane's own value, so a lane whose partner is masked off just keeps what it has.
+#define W2_DPP(v, ctrl) __builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), 0xF, 0xF, false)
 template <int G> W2DEV int32_t w2_gmax(int32_t v) {
+    v = max(v, W2_DPP(v, 0xB1)); v = max(v, W2_DPP(v, 0x4E)); v = max(v, W2_DPP(v, 0x141));
+    if (G >= 16) v = max(v, W2_DPP(v, 0x140));
 #pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+    for (int m = 16; m < G; m <<= 1) v = max(v, __shfl_xor(v, m));
     return v;
 }
 template <int G> W2DEV int32_t w2_gmin(int32_t v) {
+    v = min(v, W2_DPP(v, 0xB1)); v = min(v, W2_DPP(v, 0x4E)); v = min(v, W2_DPP(v, 0x141));
+    if (G >= 16) v = min(v, W2_DPP(v, 0x140));
 #pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+    for (int m = 16; m < G; m <<= 1) v = min(v, __shfl_xor(v, m));
     return v;
 }
 template <int G> W2DEV uint32_t w2_gor(uint32_t v) {
+    v |= (uint32_t)W2_DPP(v, 0xB1); v |= (uint32_t)W2_DPP(v, 0x4E); v |= (uint32_t)W2_DPP(v, 0x141);
+    if (G >= 16) v |= (uint32_t)W2_DPP(v, 0x140);
 #pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v |= (uint32_t)__shfl_xor((int)v, m);
+    for (int m = 16; m < G; m <<= 1) v |= (uint32_t)__shfl_xor((int)v, m);
     return v;
 }
-W2DEV uint64_t w2_shfl64(uint64_t v, int src) {
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// common prefix of two 32-byte windows (four 8-byte words each)
-W2DEV uint32_t w2_cmp32(const uint8_t* a, const uint8_t* b) {
-    const uint64_t x0 = w2_ld8(a) ^ w2_ld8(b), x1 = w2_ld8(a + 8) ^ w2_ld8(b + 8);
-    const uint64_t x2 = w2_ld8(a + 16) ^ w2_ld8(b + 16), x3 = w2_ld8(a + 24) ^ w2_ld8(b + 24);
-    if (x0) return (uint32_t)__builtin_ctzll(x0) >> 3;
-    if (x1) return 8u + ((uint32_t)__builtin_ctzll(x1) >> 3);
-    if (x2) return 16u + ((uint32_t)__builtin_ctzll(x2) >> 3);
-    if (x3) return 24u + ((uint32_t)__builtin_ctzll(x3) >> 3);
-    return 32u;
-}
-
-// Lanes with done == false have matched their first n bytes of a / b and may match up to maxlen: the group serves
-// them one after the other, G x 32 bytes per step. `on`: this group takes part (group-uniform).
-template <int G> W2DEV uint32_t w2_match_rest(const uint8_t* a, const uint8_t* b, uint32_t maxlen, uint32_t n, bool done,
+// the value lane `L` of the group holds (L group-uniform)
+template <int G> W2DEV uint32_t w2_gsel(uint32_t v, uint32_t gl, uint32_t L) { return w2_gor<G>(gl == L ? v : 0u); }
+// Lanes with done == false have matched their first n bytes of node[o..] against read[pos..] and may match up to
+// maxlen: the group serves them one after the other, G x 32 bytes per step. Only the serving lane's two offsets travel
+// (the sequences' base addresses are group-uniform). `on`: this group takes part (group-uniform).
+template <int G> W2DEV uint32_t w2_match_rest(const uint8_t* nseq, const uint8_t* readp, uint32_t o, int32_t pos, uint32_t maxlen, uint32_t n, bool done,
                                               bool on, uint32_t gbase, uint32_t gl) {
     bool pending = on && !done;
     while (__any(pending)) {
         const uint64_t gb = w2_gballot<G>(pending, gbase);
         const bool active = gb != 0;
-        const int L = active ? __builtin_ctzll(gb) : 0;
-        const int src = (int)gbase + L;
-        const uint64_t pa = w2_shfl64((uint64_t)(a + n), src), pb = w2_shfl64((uint64_t)(b + n), src);
-        const uint32_t rem = (uint32_t)__shfl((int)(maxlen - n), src);
+        const uint32_t L = active ? (uint32_t)__builtin_ctzll(gb) : 0u;
+        const uint32_t so = w2_gsel<G>(o + n, gl, L), sp = w2_gsel<G>((uint32_t)pos + n, gl, L), rem = w2_gsel<G>(maxlen - n, gl, L);
+        const uint8_t* pa = nseq + so;
+        const uint8_t* pb = readp + sp;
         const uint32_t off = gl * 32u;
         uint32_t m = 32u;
         if (active) {
             if (off < rem) {
-                m = w2_cmp32(reinterpret_cast<const uint8_t*>(pa) + off, reinterpret_cast<const uint8_t*>(pb) + off);
+                const uint4 a0 = w2_ld16(pa + off), a1 = w2_ld16(pa + off + 16), b0 = w2_ld16(pb + off), b1 = w2_ld16(pb + off + 16);
+                m = w2_pfx16(a0, b0);
+                if (m == 16u) m += w2_pfx16(a1, b1);
                 if (m > rem - off) m = rem - off;
             } else m = 0u;   // beyond the end: acts as a stop
         }
         const uint64_t stop = w2_gballot<G>(active && m < 32u, gbase);
         uint32_t got = (uint32_t)G * 32u;
         if (stop) {
-            const int S = __builtin_ctzll(stop);
-            got = (uint32_t)S * 32u + (uint32_t)__shfl((int)m, (int)gbase + S);
+            const uint32_t S = (uint32_t)__builtin_ctzll(stop);
+            got = S * 32u + w2_gsel<G>(m, gl, S);
         }
         if (got > rem) got = rem;
-        if (active && (int)gl == L) {
+        if (active && gl == L) {
             n += got;
             if (stop || n >= maxlen) pending = false;
         }
@@ -116,9 +133,25 @@ template <int G> W2DEV uint32_t w2_match_rest(const uint8_t* a, const uint8_t* b
     return n;
 }
 
-template <int W> W2DEV void w2_ldset(const uint32_t* p, uint32_t (&s)[W]) {
+template <int W> struct W2Set { uint32_t w[W]; };
+template <int W> W2DEV W2Set<W> w2_set0() { W2Set<W> s; for (int i = 0; i < W; ++i) s.w[i] = 0; return s; }
+template <int W> W2DEV W2Set<W> w2_ldset(const uint32_t* p, bool on) {   // 16-byte aligned, global memory
+    W2Set<W> s = w2_set0<W>();
+    if (on) {
+        if (W == 2) { const uint2 v = *reinterpret_cast<const uint2*>(p); s.w[0] = v.x; s.w[1] = v.y; }
+        else {
 #pragma unroll
-    for (int w = 0; w < W; ++w) s[w] = p[w];
+            for (int i = 0; i < W; i += 4) { const uint4 v = *reinterpret_cast<const uint4*>(p + i); s.w[i] = v.x; s.w[i + 1] = v.y; s.w[i + 2] = v.z; s.w[i + 3] = v.w; }
+        }
+    }
+    return s;
+}
+template <int W> W2DEV void w2_stset(uint32_t* p, const W2Set<W>& s) {
+    if (W == 2) *reinterpret_cast<uint2*>(p) = make_uint2(s.w[0], s.w[1]);
+    else {
+#pragma unroll
+        for (int i = 0; i < W; i += 4) *reinterpret_cast<uint4*>(p + i) = make_uint4(s.w[i], s.w[i + 1], s.w[i + 2], s.w[i + 3]);
+    }
 }
 
 // =====================================================================================================================
@@ -126,82 +159,108 @@ template <int G, int W>
 __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
     using C = W2Cfg<W>;
     static_assert(G >= 8 && G <= 64 && (G & (G - 1)) == 0, "group size");
-    static_assert(C::MAXS <= G, "one lane per source interval");
+    static_assert(C::MAXQ <= G, "one lane per pending-queue entry");
     constexpr uint32_t NG = 64 / G;
     const uint32_t lane = w2_lane(), gid = lane / G, gl = lane % G, gbase = gid * G;
     unsigned char* R = w2_smem + (size_t)gid * C::BYTES;
-    W2Node* desc = reinterpret_cast<W2Node*>(R + C::O_DESC);
-    uint16_t* edg = reinterpret_cast<uint16_t*>(R + C::O_EDGE);
-    uint4* live = reinterpret_cast<uint4*>(R + C::O_LIVE);          // [parity * MAXL + i]: node | off << 16, lo, vlo|vhi<<16, flo|fhi<<16 (relative to lo)
+    const uint2* desc = reinterpret_cast<const uint2*>(R + C::O_DESC);
+    const uint8_t* edg = reinterpret_cast<const uint8_t*>(R + C::O_EDGE);
+    uint4* live = reinterpret_cast<uint4*>(R + C::O_LIVE);          // [parity * MAXL + i]
+    uint4* fin = reinterpret_cast<uint4*>(R + C::O_FIN);            // [i]
     uint32_t* ek = reinterpret_cast<uint32_t*>(R + C::O_EK);        // [parity * SLOTS + s]
-    uint32_t* sets = reinterpret_cast<uint32_t*>(R + C::O_SET);     // [(parity * SLOTS + s) * W]
-    uint32_t* pairs = reinterpret_cast<uint32_t*>(R + C::O_PAIR);   // child | entry << 16
-    uint32_t* pend = reinterpret_cast<uint32_t*>(R + C::O_MISC);
-    uint32_t* outset = pend + W;
-    // small per-node scratch, overlaid on the tail of the pairs area is NOT safe; keep separate words after outset
-    int2* srcs = reinterpret_cast<int2*>(R + C::O_SRC);             // [MAXS] source / item intervals
-    uint32_t* parli = reinterpret_cast<uint32_t*>(R + C::O_SRC + 8 * C::MAXS);   // [MAXS] parents' entries
+    uint32_t* outset = reinterpret_cast<uint32_t*>(R + C::O_MISC);
+    int2* srcs = reinterpret_cast<int2*>(R + C::O_SRC);
 
     const uint32_t TG = gridDim.x * NG, slot = blockIdx.x * NG + gid;
     uint64_t* htab = B.htab + ((size_t)slot << B.hcap_log2);
+    uint32_t* gs = B.gsets + (size_t)slot * B.set_stride;           // [(parity * SLOTS + s) * W]
     const uint32_t hmask = (1u << B.hcap_log2) - 1u;
     const uint32_t prune32 = B.prune_distance > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)B.prune_distance;
     const uint32_t maxed32 = B.max_ed > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (uint32_t)B.max_ed;
+    const uint8_t* altp = B.seq + B.alt_off;
 
     // ---- group-uniform state (every lane of a group holds the same value) ------------------------------------------
-    enum : uint32_t { S_JOB = 0, S_NODE = 1, S_ITEM = 2, S_TILE = 3, S_DONE = 4 };
+    enum : uint32_t { S_JOB = 0, S_NEXT = 1, S_TILE = 3, S_DONE = 4 };
     uint32_t state = S_JOB, jround = 0, job = 0;
     uint32_t n_nodes = 0, last = 0, other_len = 0, tag = 0;
-    const uint8_t* refp = nullptr; const uint8_t* readp = nullptr;
-    const uint8_t* altp = B.seq + B.alt_off;
-    uint32_t ed = 0, c = 0, p = 1, lcnt_prev = 0, lcnt_cur = 0, top = 0, pcnt = 0, pp = 0;
+    const uint8_t* refp = altp; const uint8_t* readp = altp;
+    uint32_t ed = 0, c = 0, p = 1, lcnt_prev = 0, lcnt_cur = 0, fcnt = 0, top = 0, pp = 0;
     uint32_t farthest = 0, min_prog = 0;
-    bool final_found = false;
+    bool final_found = false, round_live = false;
     int32_t status = W2_ST_PENDING;
-    uint32_t score = 0;
+    uint32_t score = 0, steps = 0;
+    uint4 ph = make_uint4(0xFFFFu, 0, 0, 0);   // header of the previous round's entry at pp (node 0xFFFF: none left)
+    // nodes waiting for their turn with waves handed over by parents this round: lane i of the group keeps entry i in
+    // registers (node 0xFFFF = free; up to MAXPAR parent-entry codes, one byte each)
+    uint32_t pq_node = 0xFFFFu, pq_cnt = 0, pq_c0 = 0, pq_c1 = 0;
     // current node / item
-    uint32_t n = 0, len = 0, child_off = 0, n_child = 0, p_first = 0, p_last = 0, npar = 0, n_items = 0, item = 0;
-    const uint8_t* nseq = nullptr;
+    uint32_t n = 0, len = 0, child_off = 0, n_child = 0, n_items = 0, item = 0, npar = 0, pc0 = 0, pc1 = 0;
+    const uint8_t* nseq = altp;
+    bool hp0 = false, hp1 = false, use_list = false;
+    int32_t a0 = 0, b0 = 0, o0 = 0, a1 = 0, b1 = 0, o1 = 0;   // previous entries of n: live diagonals [a, b], slot of diagonal d = o + d
     int32_t lo = 0, hi = 0, base = 0;
     uint32_t coff = 0;
     int32_t clo = 0, chi = INT32_MIN, cvlo = INT32_MAX, cvhi = INT32_MIN, cflo = INT32_MAX, cfhi = INT32_MIN;   // cluster being formed
     uint32_t lane_far = 0;   // per lane
 
+#if W2_PROF
+    uint64_t w2pc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; uint32_t w2pn[8] = {0,0,0,0,0,0,0,0};
+    uint64_t w2tl = __builtin_amdgcn_s_memtime();
+    const uint64_t w2t0 = w2tl;
+#endif
+
+    // hands the waves that finished entry `code` of the current node to child `cid` (group-uniform call)
+    auto pq_append = [&](uint32_t cid, uint32_t code) {
+        const uint64_t m = w2_gballot<G>(pq_node == cid, gbase);
+        const uint64_t f = w2_gballot<G>(pq_node == 0xFFFFu && gl < (uint32_t)C::MAXQ, gbase);
+        const uint32_t idx = m ? (uint32_t)__builtin_ctzll(m) : (f ? (uint32_t)__builtin_ctzll(f) : 0xFFu);
+        bool over = idx == 0xFFu;
+        if (gl == idx) {
+            if (!m) { pq_node = cid; pq_cnt = 0; pq_c0 = 0; pq_c1 = 0; }
+            if (pq_cnt >= (uint32_t)C::MAXPAR) over = true;
+            else {
+                if (pq_cnt < 4u) pq_c0 |= code << (8u * pq_cnt); else pq_c1 |= code << (8u * (pq_cnt - 4u));
+                ++pq_cnt;
+            }
+        }
+        if (w2_gballot<G>(over, gbase)) status = W2_ST_NEED_BIG;
+    };
     // publishes the cluster [clo, chi] of the current item as an entry of this round (group-uniform)
     auto emit_cluster = [&]() {
-        if (chi == INT32_MIN) return;
-        if (lcnt_cur >= (uint32_t)C::MAXL) { status = W2_ST_NEED_BIG; return; }
-        const bool fin = cflo <= cfhi;
-        if (fin && pcnt + n_child > (uint32_t)C::MAXP) { status = W2_ST_NEED_BIG; return; }
-        if (gl == 0) {
-            uint4 h;
-            h.x = n | ((coff + (uint32_t)(clo - lo)) << 16);
-            h.y = (uint32_t)clo;
-            h.z = (cvlo <= cvhi) ? ((uint32_t)(cvlo - clo) | ((uint32_t)(cvhi - clo) << 16)) : 0x0000FFFFu;
-            h.w = fin ? ((uint32_t)(cflo - clo) | ((uint32_t)(cfhi - clo) << 16)) : 0x0000FFFFu;
-            live[c * C::MAXL + lcnt_cur] = h;
-            if (fin)
-                for (uint32_t j = 0; j < n_child; ++j) {
-                    const uint32_t cid = edg[child_off + j];
-                    pairs[pcnt + j] = cid | (lcnt_cur << 16);
-                    pend[cid >> 5] |= 1u << (cid & 31u);
-                }
+        const bool lv = cvlo <= cvhi, fn = cflo <= cfhi;
+        uint32_t code;
+        uint4 h;
+        h.x = n | ((coff + (uint32_t)(clo - lo)) << 16);
+        h.y = (uint32_t)clo;
+        h.z = (lv ? ((uint32_t)(cvlo - clo) | ((uint32_t)(cvhi - clo) << 8)) : 0x00FFu) | ((fn ? ((uint32_t)(cflo - clo) | ((uint32_t)(cfhi - clo) << 8)) : 0x00FFu) << 16);
+        h.w = len;
+        if (lv) {
+            if (lcnt_cur >= (uint32_t)C::MAXL) { status = W2_ST_NEED_BIG; return; }
+            code = lcnt_cur;
+            if (gl == 0) live[c * C::MAXL + lcnt_cur] = h;
+            lcnt_cur++;
+            round_live = true;
+        } else {
+            if (fcnt >= (uint32_t)C::MAXF) { status = W2_ST_NEED_BIG; return; }
+            code = 128u + fcnt;
+            if (gl == 0) fin[fcnt] = h;
+            fcnt++;
         }
-        if (fin) pcnt += n_child;
-        lcnt_cur++;
+        if (fn)
+            for (uint32_t j = 0; j < n_child; ++j) pq_append(edg[child_off + j], code);
         chi = INT32_MIN; cvlo = INT32_MAX; cvhi = INT32_MIN; cflo = INT32_MAX; cfhi = INT32_MIN;
     };
 
-    uint32_t steps = 0;      // tiles of the current job (a watchdog: no input needs anywhere near W2_MAX_STEPS)
     for (;;) {
         // ============================ 1. control: advance every group to its next tile ===============================
         uint32_t spins = 0;
+        W2PT(0); W2PC(0, 1);
         while (state != S_TILE && state != S_DONE) {
+            W2PC(1, 1);
             if (++spins > (1u << 20)) { state = S_DONE; break; }   // cannot happen; never hang the device
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (state == S_JOB) {
-                // results of the job that just ended
-                if (status != W2_ST_PENDING) {
+                if (status != W2_ST_PENDING) {   // results of the job that just ended
                     if (gl == 0) { B.status[job] = status; B.out_score[job] = score; }
                     if (gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
                     status = W2_ST_PENDING;
@@ -215,36 +274,41 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                 n_nodes = ji.n_nodes; last = n_nodes - 1u; other_len = jd.read_len;
                 refp = B.seq + jd.ref_off; readp = B.seq + jd.read_off;
                 tag = B.tag_base + job + 1u;
+                if (gl < (uint32_t)W) outset[gl] = 0u;
+                score = 0;
                 if (n_nodes == 0 || n_nodes > (uint32_t)C::MAXN || ji.n_edges > (uint32_t)C::MAXE || other_len >= (uint32_t)W2_DIAG_LIM) {
-                    status = W2_ST_NEED_BIG; score = 0;
-                    if (gl < (uint32_t)W) outset[gl] = 0u;
+                    status = W2_ST_NEED_BIG;
                     continue;   // stays in S_JOB: the next pass writes this status and fetches the next job
                 }
                 {
-                    const uint32_t* gd = reinterpret_cast<const uint32_t*>(B.nodes + jd.node_off);
-                    uint32_t* ld = reinterpret_cast<uint32_t*>(desc);
-                    for (uint32_t i = gl; i < n_nodes * 3u; i += G) ld[i] = gd[i];
+                    const W2Node* gd = B.nodes + jd.node_off;
+                    uint2* ld = reinterpret_cast<uint2*>(R + C::O_DESC);
+                    bool bad = false;
+                    for (uint32_t i = gl; i < n_nodes; i += G) {
+                        const W2Node nd = gd[i];
+                        const uint32_t ln = nd.len_ref & ~W2_IS_REF, co = nd.child & 0xFFFFu, nc = nd.child >> 16;
+                        bad = bad || ln >= W2_LDS_LEN_LIM || co >= 1024u || nc >= 8u;
+                        ld[i] = make_uint2(nd.seq_off, ln | ((nd.len_ref >> 31) << 18) | (co << 19) | (nc << 29));
+                    }
                     const uint16_t* ge = B.edges + jd.edge_off;
-                    for (uint32_t i = gl; i < ji.n_edges; i += G) edg[i] = ge[i];
-                    if (gl < (uint32_t)W) { pend[gl] = gl == 0 ? 1u : 0u; outset[gl] = 0u; }   // start wave: node 0 pending in round 0
+                    uint8_t* le = reinterpret_cast<uint8_t*>(R + C::O_EDGE);
+                    for (uint32_t i = gl; i < ji.n_edges; i += G) le[i] = (uint8_t)ge[i];
+                    if (w2_gballot<G>(bad, gbase)) { status = W2_ST_NEED_BIG; continue; }
                 }
-                ed = 0; c = 0; p = 1; lcnt_prev = 0; lcnt_cur = 0; top = 0; pcnt = 0; pp = 0; steps = 0;
-                farthest = 0; min_prog = 0; final_found = false; lane_far = 0; score = 0;
-                state = S_NODE;
+                // the start wave (wfa_graph.rs:366-378): node 0 waits for its turn in round 0, with no parent
+                pq_node = gl == 0 ? 0u : 0xFFFFu; pq_cnt = 0; pq_c0 = 0; pq_c1 = 0;
+                ed = 0; c = 0; p = 1; lcnt_prev = 0; lcnt_cur = 0; fcnt = 0; top = 0; pp = 0; steps = 0;
+                ph = make_uint4(0xFFFFu, 0, 0, 0);
+                farthest = 0; min_prog = 0; final_found = false; round_live = false; lane_far = 0;
+                n_items = 0; item = 0;
+                state = S_NEXT;
                 continue;
             }
-            if (state == S_NODE) {
-                // next node of this round: the smaller of the previous round's next entry and the first pending child
-                uint32_t a = 0xFFFFu;
-                while (pp < lcnt_prev) {
-                    const uint4 h = live[p * C::MAXL + pp];
-                    if ((h.z & 0xFFFFu) <= (h.z >> 16)) { a = h.x & 0xFFFFu; break; }
-                    ++pp;   // an entry that only held finished waves
-                }
-                uint32_t bq = 0xFFFFu;
-#pragma unroll
-                for (int w = W - 1; w >= 0; --w) { const uint32_t v = pend[w]; if (v) bq = (uint32_t)w * 32u + (uint32_t)__builtin_ctz(v); }
-                n = min(a, bq);
+            // ---- state == S_NEXT: the next item of the current node, or the next node, or the end of the round ----
+            if (item >= n_items) {
+                const uint32_t na = ph.x & 0xFFFFu;
+                const uint32_t nb = (uint32_t)w2_gmin<G>((int32_t)pq_node);
+                n = min(na, nb);
                 if (n == 0xFFFFu) {
                     // ---- end of round (wfa_graph.rs:633-648) ----
                     const uint32_t far = (uint32_t)w2_gmax<G>((int32_t)lane_far);
@@ -253,80 +317,96 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                     if (far > farthest) farthest = far;
                     if (farthest > prune32) min_prog = farthest - prune32;
                     if (ed + 1u > maxed32) { status = W2_ST_MAX_ED; score = maxed32; state = S_JOB; continue; }
-                    bool any_live = false;
-                    for (uint32_t i = 0; i < lcnt_cur; ++i) { const uint4 h = live[c * C::MAXL + i]; any_live = any_live || ((h.z & 0xFFFFu) <= (h.z >> 16)); }
-                    if (!any_live) { status = W2_ST_INTERNAL; state = S_JOB; continue; }
-                    ++ed; p = c; c ^= 1u; lcnt_prev = lcnt_cur; lcnt_cur = 0; top = 0; pcnt = 0; pp = 0;
+                    if (!round_live) { status = W2_ST_INTERNAL; state = S_JOB; continue; }
+                    ++ed; p = c; c ^= 1u; lcnt_prev = lcnt_cur; lcnt_cur = 0; fcnt = 0; top = 0; pp = 0; round_live = false;
+                    ph = live[p * C::MAXL];   // lcnt_prev >= 1 here
                     continue;
                 }
-                if (bq == n && gl == 0) pend[n >> 5] &= ~(1u << (n & 31u));
                 {
-                    const W2Node nd = desc[n];
-                    len = nd.len_ref & ~W2_IS_REF;
-                    nseq = ((nd.len_ref & W2_IS_REF) ? refp : altp) + nd.seq_off;
-                    child_off = nd.child & 0xFFFFu; n_child = nd.child >> 16;
+                    const uint2 nd = desc[n];
+                    len = nd.y & (W2_LDS_LEN_LIM - 1u);
+                    nseq = (((nd.y >> 18) & 1u) ? refp : altp) + nd.x;
+                    child_off = (nd.y >> 19) & 1023u; n_child = nd.y >> 29;
                 }
-                // ---- source intervals: previous entries of n (grown by one diagonal a side), finished parents, start ----
-                uint32_t ns = 0;
-                bool over = false;
-                p_first = pp;
-                while (pp < lcnt_prev) {
-                    const uint4 h = live[p * C::MAXL + pp];
-                    if ((h.x & 0xFFFFu) != n) break;
-                    if ((h.z & 0xFFFFu) <= (h.z >> 16)) {
-                        if (ns < (uint32_t)C::MAXS) { if (gl == 0) srcs[ns] = make_int2((int32_t)h.y + (int32_t)(h.z & 0xFFFFu) - 1, (int32_t)h.y + (int32_t)(h.z >> 16) + 1); }
-                        else over = true;
-                        ++ns;
-                    }
+                // ---- sources: previous entries of n grown by one diagonal a side, finished parents, the start wave ----
+                lo = INT32_MAX; hi = INT32_MIN;
+                hp0 = false; hp1 = false;
+                if (na == n) {
+                    hp0 = true;
+                    a0 = (int32_t)ph.y + (int32_t)(ph.z & 0xFFu); b0 = (int32_t)ph.y + (int32_t)((ph.z >> 8) & 0xFFu); o0 = (int32_t)(ph.x >> 16) - (int32_t)ph.y;
+                    lo = a0 - 1; hi = b0 + 1;
                     ++pp;
-                }
-                p_last = pp;
-                npar = 0;
-                for (uint32_t i = 0; i < pcnt; ++i) {
-                    const uint32_t pr = pairs[i];
-                    if ((pr & 0xFFFFu) != n) continue;
-                    const uint4 h = live[c * C::MAXL + (pr >> 16)];
-                    const int32_t pl = (int32_t)(desc[h.x & 0xFFFFu].len_ref & ~W2_IS_REF);
-                    if (ns < (uint32_t)C::MAXS) {
-                        if (gl == 0) { srcs[ns] = make_int2((int32_t)h.y + (int32_t)(h.w & 0xFFFFu) + pl, (int32_t)h.y + (int32_t)(h.w >> 16) + pl); parli[npar] = pr >> 16; }
-                    } else over = true;
-                    ++ns; ++npar;
-                }
-                if (ed == 0 && n == 0) {
-                    if (ns < (uint32_t)C::MAXS) { if (gl == 0) srcs[ns] = make_int2(0, 0); } else over = true;
-                    ++ns;
-                }
-                if (over) { status = W2_ST_NEED_BIG; state = S_JOB; continue; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                // ---- merge overlapping / touching intervals: lane i owns source i ----
-                n_items = ns;
-                if (ns > 1) {
-                    int2 iv = gl < ns ? srcs[gl] : make_int2(INT32_MAX, INT32_MIN);
-                    for (uint32_t it = 1; it < ns; ++it)
-                        for (uint32_t j = 0; j < ns; ++j) {
-                            const int32_t lj = __shfl(iv.x, (int)(gbase + j)), hj = __shfl(iv.y, (int)(gbase + j));
-                            if (gl < ns && lj <= iv.y + 1 && iv.x <= hj + 1) { iv.x = min(iv.x, lj); iv.y = max(iv.y, hj); }
-                        }
-                    bool leader = gl < ns;
-                    for (uint32_t j = 0; j + 1 < ns; ++j) {
-                        const int32_t lj = __shfl(iv.x, (int)(gbase + j)), hj = __shfl(iv.y, (int)(gbase + j));
-                        if (gl > j && gl < ns && lj == iv.x && hj == iv.y) leader = false;
+                    ph = pp < lcnt_prev ? live[p * C::MAXL + pp] : make_uint4(0xFFFFu, 0, 0, 0);
+                    if ((ph.x & 0xFFFFu) == n) {
+                        hp1 = true;
+                        a1 = (int32_t)ph.y + (int32_t)(ph.z & 0xFFu); b1 = (int32_t)ph.y + (int32_t)((ph.z >> 8) & 0xFFu); o1 = (int32_t)(ph.x >> 16) - (int32_t)ph.y;
+                        lo = min(lo, a1 - 1); hi = max(hi, b1 + 1);
+                        ++pp;
+                        ph = pp < lcnt_prev ? live[p * C::MAXL + pp] : make_uint4(0xFFFFu, 0, 0, 0);
+                        if ((ph.x & 0xFFFFu) == n) { status = W2_ST_NEED_BIG; state = S_JOB; continue; }   // three entries of one node
                     }
-                    const uint64_t lm = w2_gballot<G>(leader, gbase);
-                    n_items = (uint32_t)__popcll(lm);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    if (leader) srcs[__popcll(lm & ((1ull << gl) - 1ull))] = iv;
                 }
-                item = 0;
-                state = S_ITEM;
-                continue;
+                npar = 0; pc0 = 0; pc1 = 0;
+                if (nb == n) {
+                    const bool mine = pq_node == n;
+                    npar = w2_gor<G>(mine ? pq_cnt : 0u); pc0 = w2_gor<G>(mine ? pq_c0 : 0u); pc1 = w2_gor<G>(mine ? pq_c1 : 0u);
+                    if (mine) pq_node = 0xFFFFu;
+                    for (uint32_t i = 0; i < npar; ++i) {
+                        const uint32_t code = ((i < 4u ? pc0 >> (8u * i) : pc1 >> (8u * (i - 4u))) & 0xFFu);
+                        const uint4 h = code < 128u ? live[c * C::MAXL + code] : fin[code - 128u];
+                        const int32_t f0 = (int32_t)h.y + (int32_t)h.w + (int32_t)((h.z >> 16) & 0xFFu), f1 = (int32_t)h.y + (int32_t)h.w + (int32_t)(h.z >> 24);
+                        lo = min(lo, f0); hi = max(hi, f1);
+                    }
+                }
+                if (ed == 0 && n == 0) { lo = min(lo, 0); hi = max(hi, 0); }
+                n_items = 1; item = 0; use_list = false;
+                if (hi - lo >= 2 * (int32_t)G) {
+                    // far-apart sources (a structural variant upstream puts two paths hundreds of diagonals apart): walk
+                    // them again, merge what overlaps or touches, every remaining interval is an item of its own
+                    uint32_t ni = 0;
+                    const uint32_t ns = (hp0 ? 1u : 0u) + (hp1 ? 1u : 0u) + npar + ((ed == 0 && n == 0) ? 1u : 0u);
+                    for (uint32_t i = 0; i < ns; ++i) {
+                        int2 iv;
+                        uint32_t q = i;
+                        if (hp0 && q == 0) iv = make_int2(a0 - 1, b0 + 1);
+                        else {
+                            q -= hp0 ? 1u : 0u;
+                            if (hp1 && q == 0) iv = make_int2(a1 - 1, b1 + 1);
+                            else {
+                                q -= hp1 ? 1u : 0u;
+                                if (q < npar) {
+                                    const uint32_t code = ((q < 4u ? pc0 >> (8u * q) : pc1 >> (8u * (q - 4u))) & 0xFFu);
+                                    const uint4 h = code < 128u ? live[c * C::MAXL + code] : fin[code - 128u];
+                                    iv = make_int2((int32_t)h.y + (int32_t)h.w + (int32_t)((h.z >> 16) & 0xFFu), (int32_t)h.y + (int32_t)h.w + (int32_t)(h.z >> 24));
+                                } else iv = make_int2(0, 0);
+                            }
+                        }
+                        uint32_t j = 0;
+                        while (j < ni) {
+                            const int2 it = srcs[j];
+                            if (it.x <= iv.y + 1 && iv.x <= it.y + 1) {
+                                iv.x = min(iv.x, it.x); iv.y = max(iv.y, it.y);
+                                --ni;
+                                const int2 mv = srcs[ni];
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                if (gl == 0) srcs[j] = mv;
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                j = 0;
+                            } else ++j;
+                        }
+                        if (ni >= (uint32_t)C::MAXS) { status = W2_ST_NEED_BIG; break; }
+                        if (gl == 0) srcs[ni] = iv;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        ++ni;
+                    }
+                    if (status != W2_ST_PENDING) { state = S_JOB; continue; }
+                    n_items = ni;
+                    use_list = true;
+                }
             }
-            // state == S_ITEM
-            if (item >= n_items) { state = S_NODE; continue; }
             {
-                const int2 iv = srcs[item];
+                if (use_list) { const int2 iv = srcs[item]; lo = iv.x; hi = iv.y; }
                 ++item;
-                lo = iv.x; hi = iv.y;
                 const uint32_t cnt = (uint32_t)(hi - lo + 1);
                 if (top + cnt > (uint32_t)C::SLOTS || lo <= -W2_DIAG_LIM || hi >= W2_DIAG_LIM) { status = W2_ST_NEED_BIG; state = S_JOB; continue; }
                 coff = top; top += cnt; base = lo;
@@ -334,8 +414,10 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                 state = S_TILE;
             }
         }
+        W2PT(1);
         if (!__any(state == S_TILE)) break;   // every group is done
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        W2PC(2, __popcll(__ballot(state == S_TILE)));
 
         // ============================ 2. one tile: G diagonals of the current item ===================================
         const bool run = state == S_TILE;
@@ -343,53 +425,57 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
         const bool act = run && d <= hi;
         // ---- candidates from the previous round: A from d+1 (offset+1), B from d (offset+1), C from d-1 (offset) ----
         int32_t oA = -1, oB = -1, oC = -1;
-        uint32_t qA[W], qB[W], qC[W], qD[W];
-#pragma unroll
-        for (int w = 0; w < W; ++w) { qA[w] = 0; qB[w] = 0; qC[w] = 0; qD[w] = 0; }
-        if (run) {
-            for (uint32_t k = p_first; k < p_last; ++k) {
-                const uint4 h = live[p * C::MAXL + k];
-                const int32_t plo = (int32_t)h.y, pvlo = plo + (int32_t)(h.z & 0xFFFFu), pvhi = plo + (int32_t)(h.z >> 16);
-                const uint32_t poff = p * C::SLOTS + (h.x >> 16);
-                if (act && d + 1 >= pvlo && d + 1 <= pvhi) {
-                    const uint32_t s = poff + (uint32_t)(d + 1 - plo), e = ek[s];
-                    if (e & 1u) { oA = (int32_t)(e >> 3) + 1; w2_ldset<W>(sets + (size_t)s * W, qA); }
-                }
-                if (act && d >= pvlo && d <= pvhi) {
-                    const uint32_t s = poff + (uint32_t)(d - plo), e = ek[s];
-                    if ((e & 7u) == W2_KIND_INTERIOR_READ) { oB = (int32_t)(e >> 3) + 1; w2_ldset<W>(sets + (size_t)s * W, qB); }
-                }
-                if (act && d - 1 >= pvlo && d - 1 <= pvhi) {
-                    const uint32_t s = poff + (uint32_t)(d - 1 - plo), e = ek[s], kk = e & 7u;
-                    if (kk == W2_KIND_INTERIOR_READ || kk == W2_KIND_END_LAST) { oC = (int32_t)(e >> 3); w2_ldset<W>(sets + (size_t)s * W, qC); }
-                }
+        int32_t sA = -1, sB = -1, sC = -1;   // their slots
+        if (act) {
+            if (hp0) {
+                if (d + 1 >= a0 && d + 1 <= b0) sA = o0 + d + 1;
+                if (d >= a0 && d <= b0) sB = o0 + d;
+                if (d - 1 >= a0 && d - 1 <= b0) sC = o0 + d - 1;
+            }
+            if (hp1) {
+                if (d + 1 >= a1 && d + 1 <= b1) sA = o1 + d + 1;
+                if (d >= a1 && d <= b1) sB = o1 + d;
+                if (d - 1 >= a1 && d - 1 <= b1) sC = o1 + d - 1;
             }
         }
+        const uint32_t pbase = p * C::SLOTS, cbase = c * C::SLOTS;
+        {
+            const uint32_t eA = ek[pbase + (uint32_t)max(sA, 0)], eB = ek[pbase + (uint32_t)max(sB, 0)], eC = ek[pbase + (uint32_t)max(sC, 0)];
+            if (sA >= 0 && (eA & 1u)) oA = (int32_t)(eA >> 3) + 1; else sA = -1;
+            if (sB >= 0 && (eB & 7u) == W2_KIND_INTERIOR_READ) oB = (int32_t)(eB >> 3) + 1; else sB = -1;
+            if (sC >= 0 && ((eC & 7u) == W2_KIND_INTERIOR_READ || (eC & 7u) == W2_KIND_END_LAST)) oC = (int32_t)(eC >> 3); else sC = -1;
+        }
+        // their traversed-node sets are only needed for the union at the end of the step: the loads go out now
+        const W2Set<W> qA = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sA, 0)) * W, sA >= 0);
+        const W2Set<W> qB = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sB, 0)) * W, sB >= 0);
+        const W2Set<W> qC = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sC, 0)) * W, sC >= 0);
         // ---- waves that finished a parent THIS round (offset 0; wfa_graph.rs:527-553) ----
         bool hinj = false;
+        W2Set<W> qD = w2_set0<W>(), qD2 = w2_set0<W>();
         if (run) {
             for (uint32_t i = 0; i < npar; ++i) {
-                const uint4 h = live[c * C::MAXL + parli[i]];
-                const int32_t pl = (int32_t)(desc[h.x & 0xFFFFu].len_ref & ~W2_IS_REF);
-                const int32_t dd = d - pl - (int32_t)h.y;   // relative to the parent entry's first diagonal
-                if (act && dd >= (int32_t)(h.w & 0xFFFFu) && dd <= (int32_t)(h.w >> 16)) {
-                    const uint32_t s = c * C::SLOTS + (h.x >> 16) + (uint32_t)dd;
-                    if ((ek[s] & 7u) == W2_KIND_FINISHED) {
-                        hinj = true;
-                        uint32_t t[W];
-                        w2_ldset<W>(sets + (size_t)s * W, t);
+                const uint32_t code = ((i < 4u ? pc0 >> (8u * i) : pc1 >> (8u * (i - 4u))) & 0xFFu);
+                const uint4 h = code < 128u ? live[c * C::MAXL + code] : fin[code - 128u];
+                const int32_t rel = d - (int32_t)h.w - (int32_t)h.y;   // relative to the parent entry's first diagonal
+                bool hit = false;
+                uint32_t s = 0;
+                if (act && rel >= (int32_t)((h.z >> 16) & 0xFFu) && rel <= (int32_t)(h.z >> 24)) {
+                    s = cbase + (h.x >> 16) + (uint32_t)rel;
+                    hit = (ek[s] & 7u) == W2_KIND_FINISHED;
+                }
+                hinj = hinj || hit;
+                if (i == 0) qD = w2_ldset<W>(gs + (size_t)s * W, hit);
+                else {
+                    const W2Set<W> t = w2_ldset<W>(gs + (size_t)s * W, hit);
 #pragma unroll
-                        for (int w = 0; w < W; ++w) qD[w] |= t[w];
-                    }
+                    for (int w = 0; w < W; ++w) qD2.w[w] |= t.w[w];
                 }
             }
             if (act && ed == 0 && n == 0 && d == 0) hinj = true;   // the start wave (wfa_graph.rs:366-378)
         }
-        if (hinj) {
-#pragma unroll
-            for (int w = 0; w < W; ++w) if ((n >> 5) == (uint32_t)w) qD[w] |= 1u << (n & 31u);   // best + the successor (:535-541)
-        }
+        W2PT(2);
         const bool has = act && (oA >= 0 || oB >= 0 || oC >= 0 || hinj);
+        W2PC(3, __popcll(__ballot(has)));
         int32_t omax = max(max(oA, oB), max(oC, hinj ? 0 : -1));
         if (!has) omax = 0;
         // ---- extend the furthest candidate; the others tie iff they match the read up to its start -----------------
@@ -407,46 +493,55 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
         // every global load of the step goes out together: the extension's first 16 bytes, the first 16 bytes of every
         // tie check, and the probe of the capped-diagonal set
         const uint8_t* ra = readp + (has ? pos0 : 0);
-        const uint8_t* na = nseq + (has ? omax : 0);
+        const uint8_t* na_ = nseq + (has ? omax : 0);
         const uint64_t key = ((uint64_t)tag << 32) | ((uint64_t)(n & 0x3FFu) << 18) | (uint64_t)((uint32_t)d & 0x3FFFFu);
-        uint32_t hpos = (n * 0x9E3779B1u + (uint32_t)d) & hmask;
+        const uint32_t home = (n * 0x9E3779B1u + (uint32_t)d) & hmask;
+        uint32_t hpos = home;
         uint64_t he = 0;
         if (has) he = htab[hpos];
-        const W2Pre16 pm = w2_pre16(na, ra, room > 0);
-        const W2Pre16 pA = w2_pre16(nseq + (nA ? oA : 0), readp + (nA ? d + oA : 0), nA);
-        const W2Pre16 pB = w2_pre16(nseq + (nB ? oB : 0), readp + (nB ? d + oB : 0), nB);
-        const W2Pre16 pC = w2_pre16(nseq + (nC ? oC : 0), readp + (nC ? d + oC : 0), nC);
-        const W2Pre16 pD = w2_pre16(nseq, readp + (nD ? d : 0), nD);
+        const W2Pre pm = w2_pre(na_, ra, room > 0);
+        const W2Pre pA = w2_pre(nseq + (nA ? oA : 0), readp + (nA ? d + oA : 0), nA);
+        const W2Pre pB = w2_pre(nseq + (nB ? oB : 0), readp + (nB ? d + oB : 0), nB);
+        const W2Pre pC = w2_pre(nseq + (nC ? oC : 0), readp + (nC ? d + oC : 0), nC);
+        const W2Pre pD = w2_pre(nseq, readp + (nD ? d : 0), nD);
+        W2PT(3);
         uint32_t E;
         {
             uint32_t n0 = 0;
             bool done = (room == 0);
             if (!done) {
-                uint32_t m = w2_pre16_len(pm);
+                uint32_t m = w2_pfx16(pm.a, pm.b);
                 if (m > room) m = room;
                 n0 = m;
                 if (m < 16 || n0 >= room) done = true;
             }
-            E = (uint32_t)omax + w2_match_rest<G>(na, ra, room, n0, done, run, gbase, gl);
+            W2PC(4, __any(!done && run) ? 1 : 0);
+            E = (uint32_t)omax + w2_match_rest<G>(nseq, readp, (uint32_t)omax, pos0, room, n0, done, run, gbase, gl);
         }
+        W2PT(4);
         {
-            auto tie = [&](const W2Pre16& pp16, bool nX, int32_t oX) -> bool {
-                const uint32_t g = nX ? (uint32_t)(omax - oX) : 0u;
-                bool res = false, pend16 = false;
-                if (nX) {
-                    const uint32_t m = w2_pre16_len(pp16);
-                    if (g <= 16) res = (m >= g);
-                    else pend16 = (m == 16);
-                }
-                if (__any(pend16)) {   // wave-uniform: every lane takes part
-                    const uint32_t mr = w2_match_rest<G>(nseq + (pend16 ? oX : 0), readp + (pend16 ? d + oX : 0), pend16 ? g : 0u, pend16 ? 16u : 0u, !pend16, run, gbase, gl);
-                    res = res || (pend16 && mr == g);
-                }
-                return res;
+            // a tie check whose gap exceeds 16 bytes and whose first 16 match goes on with the cooperative compare
+            bool pdA = false, pdB = false, pdC = false, pdD = false;
+            auto quick = [&](const W2Pre& q, bool nX, int32_t oX, bool& pend16) -> bool {
+                if (!nX) return false;
+                const uint32_t g = (uint32_t)(omax - oX), m = w2_pfx16(q.a, q.b);
+                if (g <= 16u) return m >= g;
+                pend16 = (m == 16u);
+                return false;
             };
-            const bool xA = tie(pA, nA, oA), xB = tie(pB, nB, oB), xC = tie(pC, nC, oC), xD = tie(pD, nD, 0);   // no `||`: collectives inside
+            const bool xA = quick(pA, nA, oA, pdA), xB = quick(pB, nB, oB, pdB), xC = quick(pC, nC, oC, pdC), xD = quick(pD, nD, 0, pdD);
             tA = tA || xA; tB = tB || xB; tC = tC || xC; tD = tD || xD;
+            if (__any(pdA || pdB || pdC || pdD)) {   // rare: a long alternative run onto the furthest wave's diagonal
+                auto slow = [&](bool pd, int32_t oX) -> bool {
+                    const uint32_t g = pd ? (uint32_t)(omax - oX) : 0u;
+                    const uint32_t mr = w2_match_rest<G>(nseq, readp, (uint32_t)(pd ? oX : 0), pd ? d + oX : 0, g, pd ? 16u : 0u, !pd, run, gbase, gl);
+                    return pd && mr == g;
+                };
+                const bool yA = slow(pdA, oA), yB = slow(pdB, oB), yC = slow(pdC, oC), yD = slow(pdD, 0);
+                tA = tA || yA; tB = tB || yB; tC = tC || yC; tD = tD || yD;
+            }
         }
+        W2PT(5);
         // ---- capped-diagonal set: is (n, d) recorded? (linear probing past other keys of this job; rare) -------------
         bool capped = false, hfull = false;
         if (has) {
@@ -468,7 +563,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
             const bool skip = (capped && (int32_t)E < cap) || ((uint32_t)pos_end < min_prog);
             if (!skip) {
                 if ((uint32_t)pos_end > lane_far) lane_far = (uint32_t)pos_end;
-                ins = (int32_t)E == cap && !capped;
+                ins = (int32_t)E == cap && !capped && !hfull;
                 if (E == len) {
                     if (n == last) { if ((uint32_t)pos_end < other_len) kind = W2_KIND_END_LAST; }
                     else kind = W2_KIND_FINISHED;
@@ -477,72 +572,102 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
         }
         // ---- record newly capped diagonals. A lane whose probe ended on its own home slot stores there; displaced
         // lanes (rare) go one at a time and probe again, so that two of them never take the same empty slot -----------
+        if (ins && hpos == home) htab[hpos] = key;
         {
-            const uint32_t home = (n * 0x9E3779B1u + (uint32_t)d) & hmask;
-            const bool direct = ins && hpos == home && !hfull;
-            if (direct) htab[hpos] = key;
-            bool later = ins && !direct && !hfull;
-            while (__any(later)) {
-                const uint64_t lm = __ballot(later);
-                const int L = __builtin_ctzll(lm);
-                if ((int)lane == L) {
-                    uint32_t hp = home, probes = 0;
-                    uint64_t e = htab[hp];
-                    while (e != key && (uint32_t)(e >> 32) == tag) {
-                        if (++probes > 24u) { hfull = true; break; }
-                        hp = (hp + 1u) & hmask;
-                        e = htab[hp];
+            bool later = ins && hpos != home;
+            if (__any(later)) {
+                while (__any(later)) {
+                    const uint64_t lm = __ballot(later);
+                    const int L = __builtin_ctzll(lm);
+                    if ((int)lane == L) {
+                        uint32_t hp = home, probes = 0;
+                        uint64_t e = htab[hp];
+                        while (e != key && (uint32_t)(e >> 32) == tag) {
+                            if (++probes > 24u) { hfull = true; break; }
+                            hp = (hp + 1u) & hmask;
+                            e = htab[hp];
+                        }
+                        if (!hfull) htab[hp] = key;
+                        later = false;
                     }
-                    if (!hfull) htab[hp] = key;
-                    later = false;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         }
         if (__any(hfull)) { if (w2_gballot<G>(hfull, gbase)) status = W2_ST_NEED_BIG; }
+        W2PT(6);
         // ---- write this round's slot: offset | kind and the union of the tied sets -----------------------------------
-        uint32_t best[W];
+        W2Set<W> best;
 #pragma unroll
-        for (int w = 0; w < W; ++w) best[w] = (tA ? qA[w] : 0u) | (tB ? qB[w] : 0u) | (tC ? qC[w] : 0u) | (tD ? qD[w] : 0u);
+        for (int w = 0; w < W; ++w) {
+            uint32_t dset = qD.w[w] | qD2.w[w];
+            if (hinj && (n >> 5) == (uint32_t)w) dset |= 1u << (n & 31u);   // best + the successor (wfa_graph.rs:535-541)
+            best.w[w] = (tA ? qA.w[w] : 0u) | (tB ? qB.w[w] : 0u) | (tC ? qC.w[w] : 0u) | (tD ? dset : 0u);
+        }
         if (act) {
-            const uint32_t s = c * C::SLOTS + coff + (uint32_t)(d - lo);
+            const uint32_t s = cbase + coff + (uint32_t)(d - lo);
             ek[s] = has ? ((E << 3) | kind) : 0u;
-            if (kind != W2_KIND_NONE) {
-#pragma unroll
-                for (int w = 0; w < W; ++w) sets[(size_t)s * W + w] = best[w];
-            }
+            if (kind != W2_KIND_NONE) w2_stset<W>(gs + (size_t)s * W, best);
         }
         // ---- finals (wfa_graph.rs:576-629): every wave of the last node that consumed node and read -------------------
         if (__any(is_final)) {
             const bool gf = w2_gballot<G>(is_final, gbase) != 0;
 #pragma unroll
             for (int w = 0; w < W; ++w) {
-                const uint32_t o = w2_gor<G>(is_final ? best[w] : 0u);
+                const uint32_t o = w2_gor<G>(is_final ? best.w[w] : 0u);
                 if (gf && gl == 0) outset[w] |= o;
             }
             if (gf) final_found = true;
         }
+        W2PT(7);
         // ---- clusters of non-empty diagonals become this round's entries ----------------------------------------------
         if (run) {
-            const uint64_t lm = w2_gballot<G>(kind == W2_KIND_INTERIOR || kind == W2_KIND_INTERIOR_READ || kind == W2_KIND_END_LAST, gbase);
             const uint64_t fm = w2_gballot<G>(kind == W2_KIND_FINISHED, gbase);
-            uint64_t any = lm | fm;
-            while (any) {
-                const int bpos = __builtin_ctzll(any);
-                any &= any - 1;
-                const int32_t dd = base + bpos;
-                if (chi != INT32_MIN && dd - chi >= 3) emit_cluster();
-                if (chi == INT32_MIN) clo = dd;
-                chi = dd;
-                if ((fm >> bpos) & 1ull) { cflo = min(cflo, dd); cfhi = max(cfhi, dd); }
-                else { cvlo = min(cvlo, dd); cvhi = max(cvhi, dd); }
+            uint64_t rem = fm | w2_gballot<G>(kind == W2_KIND_INTERIOR || kind == W2_KIND_INTERIOR_READ || kind == W2_KIND_END_LAST, gbase);
+            const bool item_end = base + (int32_t)G > hi;   // the item ends with this tile: flush the last cluster
+            bool simple = false;
+            if (rem) {
+                const int f = __builtin_ctzll(rem), l = 63 - __builtin_clzll(rem);
+                const uint64_t z = ~rem & (((2ull << l) - 1ull) & ~((1ull << f) - 1ull));   // empty diagonals between the first and the last
+                simple = (z & (z >> 1) & (z >> 2)) == 0;                                     // no three in a row: one run
+            }
+            if (simple) {
+                const int f = __builtin_ctzll(rem), l = 63 - __builtin_clzll(rem);
+                const uint64_t lmk = rem & ~fm;
+                if (chi != INT32_MIN && ((base + f) - chi >= 3 || (base + l) - clo >= (int32_t)C::MAXW)) emit_cluster();
+                if (chi == INT32_MIN) clo = base + f;
+                chi = base + l;
+                if (fm) { cflo = min(cflo, base + (int32_t)__builtin_ctzll(fm)); cfhi = max(cfhi, base + 63 - (int32_t)__builtin_clzll(fm)); }
+                if (lmk) { cvlo = min(cvlo, base + (int32_t)__builtin_ctzll(lmk)); cvhi = max(cvhi, base + 63 - (int32_t)__builtin_clzll(lmk)); }
+                rem = 0;
+            }
+            bool end_pending = item_end;
+            while (rem || end_pending) {
+                int32_t dd = INT32_MAX / 2;
+                int bpos = 0;
+                const bool bit = rem != 0;
+                if (bit) { bpos = __builtin_ctzll(rem); rem &= rem - 1; dd = base + bpos; } else end_pending = false;
+                if (chi != INT32_MIN && (dd - chi >= 3 || dd - clo >= (int32_t)C::MAXW)) emit_cluster();
+                if (bit) {
+                    if (chi == INT32_MIN) clo = dd;
+                    chi = dd;
+                    if ((fm >> bpos) & 1ull) { cflo = min(cflo, dd); cfhi = max(cfhi, dd); }
+                    else { cvlo = min(cvlo, dd); cvhi = max(cvhi, dd); }
+                }
             }
             base += (int32_t)G;
-            if (base > hi) { emit_cluster(); state = S_ITEM; }
+            if (base > hi) state = S_NEXT;
             if (++steps > W2_MAX_STEPS) status = W2_ST_INTERNAL;
             if (status != W2_ST_PENDING) state = S_JOB;
         }
+        W2PT(8);
     }
+#if W2_PROF
+    if (lane == 0 && (blockIdx.x % 97) == 3)
+        printf("wg %u total %llu | idle->ctl %llu control %llu cand %llu issue %llu ext %llu ties %llu hash %llu write+final %llu cluster %llu | iters %u ctlpasses %u tile-lanes %u has-lanes %u ext2 %u\n",
+               blockIdx.x, (unsigned long long)(w2tl - w2t0), (unsigned long long)w2pc[0], (unsigned long long)w2pc[1], (unsigned long long)w2pc[2], (unsigned long long)w2pc[3],
+               (unsigned long long)w2pc[4], (unsigned long long)w2pc[5], (unsigned long long)w2pc[6], (unsigned long long)w2pc[7], (unsigned long long)w2pc[8], w2pn[0], w2pn[1], w2pn[2], w2pn[3], w2pn[4]);
+#endif
 }
 
 // ---- graph construction: one thread per job (wfa_graph.rs:119-284 via w2_build) ------------------------------------

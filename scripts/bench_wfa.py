@@ -14,7 +14,10 @@ ap.add_argument("--distinct", type=int, default=64)
 ap.add_argument("--ref-len", type=int, default=17000)
 ap.add_argument("--noise", type=float, default=0.004)
 ap.add_argument("--cpu-sample", type=int, default=8)
+ap.add_argument("--kernel", choices=["auto", "compact", "dense"], default="auto")
 args = ap.parse_args()
+if args.kernel != "auto":
+    os.environ["HP_WFA2_MIN_JOBS"] = "0" if args.kernel == "compact" else "1000000000"
 base = [synth_wfa_job(1000 + s, ref_len=args.ref_len, n_vars=24, n_homs=8, noise=args.noise)[0] for s in range(args.distinct)]
 specs = [base[i % args.distinct] for i in range(args.jobs)]
 wfa_assign_batch(specs[:64])  # warm-up (module load)

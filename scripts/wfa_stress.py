@@ -11,6 +11,7 @@ from hiphase_amd.wfa_graph import WfaJobSpec, make_jobs, wfa_assign_batch
 from oracle_ffi import oracle
 from wfa_util import synth_wfa_job, _Rng
 
+os.environ.setdefault("HP_WFA2_MIN_JOBS", "0")   # the compact kernel takes every batch (its leftovers still reach the dense-band one)
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 r = _Rng(seed)

@@ -89,7 +89,7 @@ int model_wfa(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t 
         live[c].clear();
         pairs.clear();
         uint32_t top = 0;
-        size_t pp = 0;
+        size_t pp = 0, n_live_entries = 0, n_fin_entries = 0;
         bool final_found = false;
         uint64_t round_far = 0;
         for (;;) {
@@ -117,13 +117,24 @@ int model_wfa(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t 
                 src.push_back({P.flo + pl, P.fhi + pl});
             }
             if (ed == 0 && n == 0) src.push_back({0, 0});
-            if (src.size() > 8) { g_reason[4]++; return W2_ST_NEED_BIG; }
-            // merge overlapping / touching intervals
+            {   // the kernel keeps two previous entries of a node in registers and C::MAXPAR parent entries per node
+                size_t nprev = 0, npar = 0;
+                for (size_t k = p_first; k < p_last; ++k) nprev += live[p][k].vlo <= live[p][k].vhi;
+                for (auto& pr : pairs) npar += pr.child == n;
+                if (nprev > 2 || npar > (size_t)C::MAXPAR) { g_reason[4]++; return W2_ST_NEED_BIG; }
+            }
+            // one item over the whole span unless the sources are far apart; then merge overlapping / touching intervals
             std::sort(src.begin(), src.end());
             std::vector<std::pair<int32_t, int32_t>> items;
-            for (auto& iv : src) {
-                if (!items.empty() && iv.first <= items.back().second + 1) items.back().second = std::max(items.back().second, iv.second);
-                else items.push_back(iv);
+            {
+                int32_t slo = INT32_MAX, shi = INT32_MIN;
+                for (auto& iv : src) { slo = std::min(slo, iv.first); shi = std::max(shi, iv.second); }
+                if (shi - slo < 2 * 8) items.push_back({slo, shi});
+                else
+                    for (auto& iv : src) {
+                        if (!items.empty() && iv.first <= items.back().second + 1) items.back().second = std::max(items.back().second, iv.second);
+                        else items.push_back(iv);
+                    }
             }
             bool any_finished_node = false;
             for (auto& it : items) {
@@ -204,19 +215,22 @@ int model_wfa(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t 
                 int32_t clo = 0, chi = INT32_MIN;
                 auto emit = [&]() -> bool {
                     if (chi == INT32_MIN) return true;
-                    if (live[c].size() >= (size_t)C::MAXL) { g_reason[1]++; return false; }
                     Live L{n, clo, coff + (uint32_t)(clo - lo), INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN};
                     for (int32_t d = clo; d <= chi; ++d) {
                         const uint32_t k = arena[c][coff + (uint32_t)(d - lo)].ek & 7u;
                         if (k == W2_KIND_FINISHED) { L.flo = std::min(L.flo, d); L.fhi = std::max(L.fhi, d); }
                         else if (k != W2_KIND_NONE) { L.vlo = std::min(L.vlo, d); L.vhi = std::max(L.vhi, d); }
                     }
+                    if (L.vlo <= L.vhi) { if (++n_live_entries > (size_t)C::MAXL) { g_reason[1]++; return false; } }
+                    else if (++n_fin_entries > (size_t)C::MAXF) { g_reason[1]++; return false; }
                     if (L.flo <= L.fhi) {
                         any_finished_node = true;
                         for (uint32_t j = 0; j < n_child; ++j) {
-                            if (pairs.size() >= (size_t)C::MAXP) { g_reason[4]++; return false; }
                             pairs.push_back(Pair{b.edges[child_off + j], (uint32_t)live[c].size()});
                             pend[b.edges[child_off + j]] = 1;
+                            size_t waiting = 0;
+                            for (uint32_t q = 0; q < nn; ++q) waiting += pend[q];
+                            if (waiting > (size_t)C::MAXQ) { g_reason[4]++; return false; }
                         }
                     }
                     live[c].push_back(L);
@@ -224,7 +238,7 @@ int model_wfa(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t 
                 };
                 for (int32_t d = lo; d <= hi; ++d) {
                     if ((arena[c][coff + (uint32_t)(d - lo)].ek & 7u) == W2_KIND_NONE) continue;
-                    if (chi != INT32_MIN && d - chi >= 3) { if (!emit()) return W2_ST_NEED_BIG; chi = INT32_MIN; }
+                    if (chi != INT32_MIN && (d - chi >= 3 || d - clo >= C::MAXW)) { if (!emit()) return W2_ST_NEED_BIG; chi = INT32_MIN; }
                     if (chi == INT32_MIN) clo = d;
                     chi = d;
                 }

@@ -18,6 +18,14 @@ pytestmark = pytest.mark.gpu
 G = load_golden("wfa_graph.json")
 
 
+@pytest.fixture(autouse=True, params=["compact", "dense-band"])
+def wfa_kernel_path(request, monkeypatch):
+    """hp_wfa_assign_batch picks its kernel by batch size (hp_wfa.hip); every test runs through both: the compact
+    several-reads-per-wavefront kernel with the device graph builder (hp_wfa2*.hip) and the dense-band one."""
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0" if request.param == "compact" else "1000000000")
+    return request.param
+
+
 def oracle_assign(spec, prune, max_ed):
     d = oracle()
     jobs, keep = make_jobs([spec])
