@@ -168,6 +168,74 @@ class ReadStats(C.Structure):
                 tuple(self.failed_matches), tuple(self.allele0_matches), tuple(self.allele1_matches), self.local_aligned)
 
 
+class BlockRecord(C.Structure):
+    _fields_ = [
+        ("min_position", C.c_int64),
+        ("max_position", C.c_int64),
+        ("read_align", C.POINTER(C.c_uint8)),
+        ("read_len", C.c_uint32),
+        ("qname_id", C.c_uint32),
+        ("local", C.POINTER(LocalRead)),
+    ]
+
+
+class BlockInput(C.Structure):
+    _fields_ = [
+        ("block_index", C.c_uint64),
+        ("reference", C.POINTER(C.c_uint8)),
+        ("ref_base", C.c_uint64),
+        ("n_hets", C.c_uint32),
+        ("n_homs", C.c_uint32),
+        ("n_records", C.c_uint32),
+        ("n_qnames", C.c_uint32),
+        ("hets", C.POINTER(WfaVariant)),
+        ("het_types", C.POINTER(C.c_uint8)),
+        ("local_hets", C.POINTER(LocalVariant)),
+        ("homs", C.POINTER(WfaVariant)),
+        ("records", C.POINTER(BlockRecord)),
+    ]
+
+
+class BlockParams(C.Structure):
+    _fields_ = [
+        ("astar", AstarParams),
+        ("wfa_prune_distance", C.c_uint64),
+        ("max_edit_distance", C.c_uint64),
+        ("global_failure_ratio", C.c_double),
+        ("global_failure_minimum", C.c_uint64),
+        ("min_matched_alleles", C.c_uint64),
+        ("global_realignment", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class BlockOutput(C.Structure):
+    _fields_ = [
+        ("h1", C.POINTER(C.c_uint8)),
+        ("h2", C.POINTER(C.c_uint8)),
+        ("stats", PhaseStats),
+        ("span_counts", C.POINTER(C.c_uint64)),
+        ("n_segments", C.c_uint32),
+        ("n_solver", C.c_uint32),
+        ("seg_qname", C.POINTER(C.c_uint32)),
+        ("seg_start", C.POINTER(C.c_uint32)),
+        ("seg_end", C.POINTER(C.c_uint32)),
+        ("seg_solver", C.POINTER(C.c_uint8)),
+        ("seg_haplotag", C.POINTER(C.c_uint8)),
+        ("seg_first_het", C.POINTER(C.c_uint32)),
+        ("seg_row_off", C.POINTER(C.c_uint64)),
+        ("seg_alleles", C.POINTER(C.c_uint8)),
+        ("seg_quals", C.POINTER(C.c_uint8)),
+        ("seg_cell_cap", C.c_uint64),
+        ("num_reads", C.c_uint64),
+        ("skipped_reads", C.c_uint64),
+        ("global_aligned", C.c_uint64),
+        ("local_aligned", C.c_uint64),
+        ("edit_distances", C.POINTER(C.c_uint64)),
+        ("n_edit_distances", C.c_uint64),
+    ]
+
+
 # Every symbol include/hiphase_gpu.h declares; tests check the library exports all of them.
 EXPORTS = [
     "hp_astar_solve",
@@ -180,6 +248,10 @@ EXPORTS = [
     "hp_wfa_assign_batch",
     "hp_edit_distance_batch",
     "hp_local_realign_batch",
+    "hp_solve_blocks",
+    "hp_blockset_create",
+    "hp_blockset_solve",
+    "hp_blockset_destroy",
     "hp_device_count",
     "hp_default_device",
     "hp_last_error",
@@ -236,6 +308,14 @@ def lib():
     dll.hp_local_realign_batch.restype = C.c_int
     dll.hp_local_realign_batch.argtypes = [C.POINTER(LocalRead), C.c_size_t, C.POINTER(LocalVariant), C.c_size_t,
                                            C.c_void_p, C.c_void_p, C.POINTER(ReadStats), C.c_int]
+    dll.hp_solve_blocks.restype = C.c_int
+    dll.hp_solve_blocks.argtypes = [C.c_size_t, C.POINTER(BlockInput), C.POINTER(BlockParams), C.POINTER(BlockOutput), C.c_int]
+    dll.hp_blockset_create.restype = C.c_void_p
+    dll.hp_blockset_create.argtypes = [C.c_size_t, C.POINTER(BlockInput), C.POINTER(BlockParams), C.c_int, C.POINTER(C.c_int)]
+    dll.hp_blockset_solve.restype = C.c_int
+    dll.hp_blockset_solve.argtypes = [C.c_void_p, C.POINTER(BlockOutput), C.POINTER(C.c_double)]
+    dll.hp_blockset_destroy.restype = None
+    dll.hp_blockset_destroy.argtypes = [C.c_void_p]
     dll.hp_device_count.restype = C.c_int
     dll.hp_default_device.restype = C.c_int
     dll.hp_last_error.restype = C.c_char_p

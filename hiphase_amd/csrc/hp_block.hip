@@ -1,0 +1,493 @@
+// hp_block.hip — whole phase blocks behind ONE entry: phaser::solve_block from the decoded records on
+// (reference src/phaser.rs:513-630), for any number of blocks at once.
+//
+//   hp_solve_blocks / hp_blockset_* =
+//     read_parsing::load_full_read_segments (read_parsing.rs:520-637)   [or load_read_segments, :47-113]
+//        global_realignment per record (:652-867)      -> ONE graph-WFA device batch over the records of ALL blocks
+//        Err(MaxEditDistance) -> local_realignment      -> hp_local_realign_batch for the failed records (:564-575)
+//        the order-dependent `global_disabled` switch   -> replayed per block in BAM order (:556-600)
+//        quality assignment (:803-835), ReadSegment::new, collapse per read name, min_matched_alleles split (:611-629)
+//     astar_phaser::astar_solver (phaser.rs:541-543)    -> hp_batch_* (one resident batch of all blocks)
+//     get_solution_span_counts / haplotag_reads (:546, :614-630) -> hp_batch_postprocess on the resident matrix
+//
+// The quality assignment, the per-read-name collapse and the fallback replay used to exist three times ABOVE the C
+// ABI (Python mirror, C++ mirror, tests); they now live here once, behind it. They are host logic over a few bytes per
+// record (the reference's own statements, cited inline); everything that scales with bases or with the search runs in
+// the kernels. No CPU fallback: without a device the first device stage fails with HP_ERR_HIP.
+#include "hp_common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <memory>
+#include <vector>
+
+namespace hp {
+
+struct W2Session;   // hp_wfa2.hip
+W2Session* w2_session_create();
+void w2_session_destroy(W2Session* s);
+int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id);
+int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles);
+int wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
+                        uint8_t* const* alleles, int device_id);   // hp_wfa.hip
+
+namespace {
+
+double blk_now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+// read_parsing.rs:18-22: base qualities per type; global re-alignment doubles them (:815)
+int base_quality(uint32_t variant_type) {
+    switch (variant_type) {
+        case 0: return 80;                       // Snv
+        case 1: case 2: case 3: return 10;       // Insertion, Deletion, Indel
+        case 4: case 5: return 20;               // SvInsertion, SvDeletion
+        case 9: return 40;                       // TandemRepeat
+        default: return -1;                      // panic!("No implementation for matching ...") (:829)
+    }
+}
+
+struct Segment {            // a ReadSegment: clipped row (read_segments.rs:19-62)
+    uint32_t start = 0, end = 0;
+    std::vector<uint8_t> alleles, quals;
+};
+// ReadSegment::new (read_segments.rs:40-62) from a window [w0, w0 + n) of the block-length vectors (everything outside
+// the window is NoOverlap with quality 0)
+Segment segment_new(const uint8_t* alleles, const uint8_t* quals, uint32_t w0, uint32_t n, uint32_t n_hets) {
+    Segment s;
+    uint32_t first = n, last = n;
+    for (uint32_t i = 0; i < n; ++i) if (alleles[i] < HP_ALLELE_AMBIGUOUS) { first = i; break; }
+    for (uint32_t i = n; i-- > 0;) if (alleles[i] < HP_ALLELE_AMBIGUOUS) { last = i + 1; break; }
+    if (first == n) { s.start = s.end = n_hets; return s; }   // no set allele: len..len (:58-61)
+    s.start = w0 + first; s.end = w0 + last;
+    s.alleles.assign(alleles + first, alleles + last);
+    s.quals.assign(quals + first, quals + last);
+    return s;
+}
+inline uint8_t seg_allele(const Segment& s, uint32_t i) { return (i >= s.start && i < s.end) ? s.alleles[i - s.start] : (uint8_t)HP_ALLELE_NOOVERLAP; }
+inline uint8_t seg_qual(const Segment& s, uint32_t i) { return (i >= s.start && i < s.end) ? s.quals[i - s.start] : (uint8_t)0; }
+// ReadSegment::collapse (read_segments.rs:71-121). Returns false when `assert!(quals[i] > 0)` (:105) would fire.
+bool segment_collapse(const std::vector<const Segment*>& rs, uint32_t n_hets, Segment& out) {
+    if (rs.size() == 1) { out = *rs[0]; return true; }
+    uint32_t min_start = rs[0]->start, max_end = rs[0]->end;
+    for (auto* r : rs) { min_start = std::min(min_start, r->start); max_end = std::max(max_end, r->end); }
+    std::vector<uint8_t> alleles(max_end > min_start ? max_end - min_start : 0, (uint8_t)HP_ALLELE_NOOVERLAP), quals(alleles.size(), 0);
+    for (auto* r : rs)
+        for (uint32_t i = min_start; i < max_end; ++i) {
+            const uint8_t a = seg_allele(*r, i), q = seg_qual(*r, i);
+            uint8_t& ca = alleles[i - min_start];
+            uint8_t& cq = quals[i - min_start];
+            if (a == HP_ALLELE_NOOVERLAP) continue;
+            if (ca == HP_ALLELE_NOOVERLAP) { ca = a; cq = q; }
+            else if (ca == HP_ALLELE_AMBIGUOUS) {}
+            else if (ca == a) { cq = std::max(cq, q); if (cq == 0) return false; }
+            else { ca = HP_ALLELE_AMBIGUOUS; cq = 0; }
+        }
+    out = segment_new(alleles.data(), quals.data(), min_start, (uint32_t)alleles.size(), n_hets);
+    return true;
+}
+uint32_t seg_num_set(const Segment& s) {
+    uint32_t n = 0;
+    for (uint8_t a : s.alleles) n += a < HP_ALLELE_AMBIGUOUS;
+    return n;
+}
+
+struct RecMeta { int64_t job = -1; uint32_t first = 0, last = 0; };
+
+struct BlockState {         // per block, rebuilt by every solve
+    std::vector<Segment> segs;            // collapsed, >= 1 set allele, first-seen read-name order
+    std::vector<uint32_t> seg_qname;
+    std::vector<uint8_t> seg_solver;
+    std::vector<uint32_t> solver_rows;    // indices into segs
+    uint64_t num_reads = 0, skipped_reads = 0, global_aligned = 0, local_aligned = 0;
+    std::vector<uint64_t> edit_distances;
+    // the solver matrix as the C ABI takes it
+    std::vector<uint32_t> read_start, read_end;
+    std::vector<uint64_t> row_off;
+    std::vector<uint8_t> alleles_2bit, quals, var_flags;
+};
+
+}  // namespace
+}  // namespace hp
+
+using namespace hp;
+
+struct hp_blockset {
+    size_t n_blocks = 0;
+    const hp_block_input* in = nullptr;
+    hp_block_params prm{};
+    int device = 0;
+    std::vector<std::vector<RecMeta>> meta;      // per block, per record
+    std::vector<hp_wfa_job> jobs;                // records with overlaps, all blocks
+    std::vector<uint64_t> job_alloff;            // per job: offset of its allele row in `alleles`
+    std::vector<uint8_t> alleles;                // per-het AlleleTypes of every job, back to back
+    std::vector<uint8_t*> allele_ptrs;
+    std::vector<hp_wfa_result> wfa_out;
+    W2Session* wfa = nullptr;                    // resident graph-WFA inputs (large batches)
+    std::vector<BlockState> st;
+    ~hp_blockset() { if (wfa) w2_session_destroy(wfa); }
+};
+
+namespace {
+
+// indices [first, last) of the variants with lo <= position <= hi (read_parsing.rs:688-700, 721-730); the reference
+// asserts that they are contiguous (:715), which position-sorted input guarantees
+bool overlap_range(const hp_wfa_variant* v, uint32_t n, bool sorted, int64_t lo, int64_t hi, uint32_t& first, uint32_t& last, bool& contiguous) {
+    contiguous = true;
+    if (sorted) {
+        const hp_wfa_variant* a = std::lower_bound(v, v + n, lo, [](const hp_wfa_variant& x, int64_t p) { return x.position < p; });
+        const hp_wfa_variant* b = std::upper_bound(v, v + n, hi, [](int64_t p, const hp_wfa_variant& x) { return p < x.position; });
+        first = (uint32_t)(a - v); last = (uint32_t)(b - v);
+        return last > first;
+    }
+    bool any = false;
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (lo <= v[i].position && v[i].position <= hi) { if (!any) { first = i; any = true; } last = i + 1; ++cnt; }
+    if (any && cnt != last - first) contiguous = false;
+    return any;
+}
+
+int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id) {
+    if (!in || !p) { set_error("null argument"); return HP_ERR_ARG; }
+    bs->n_blocks = n_blocks; bs->in = in; bs->prm = *p;
+    bs->device = device_id < 0 ? hp_default_device() : device_id;
+    bs->meta.resize(n_blocks);
+    bs->st.resize(n_blocks);
+    uint64_t al_total = 0;
+    for (size_t b = 0; b < n_blocks; ++b) {
+        const hp_block_input& B = in[b];
+        if (B.n_hets == 0) { set_error("block %zu has no variants (phaser.rs:415-434 short-circuits those before this path)", b); return HP_ERR_ARG; }
+        if (!B.hets || !B.het_types || (B.n_homs && !B.homs) || (B.n_records && !B.records) || (p->global_realignment && !B.reference)) {
+            set_error("block %zu: null array", b); return HP_ERR_ARG;
+        }
+        for (uint32_t i = 0; i < B.n_hets; ++i)
+            if (B.het_types[i] > 10) { set_error("block %zu: invalid variant type", b); return HP_ERR_ARG; }
+        for (uint32_t r = 0; r < B.n_records; ++r) {
+            if (B.records[r].qname_id >= B.n_qnames) { set_error("block %zu record %u: qname_id out of range", b, r); return HP_ERR_ARG; }
+            if (B.records[r].max_position < B.records[r].min_position) { set_error("block %zu record %u: assert!(max_position >= min_position) (read_parsing.rs:685)", b, r); return HP_ERR_INVARIANT; }
+        }
+        bs->meta[b].assign(B.n_records, RecMeta{});
+        if (!p->global_realignment) continue;
+        bool hs = true, ms = true;
+        for (uint32_t i = 1; i < B.n_hets; ++i) hs = hs && B.hets[i - 1].position <= B.hets[i].position;
+        for (uint32_t i = 1; i < B.n_homs; ++i) ms = ms && B.homs[i - 1].position <= B.homs[i].position;
+        for (uint32_t r = 0; r < B.n_records; ++r) {
+            const hp_block_record& rec = B.records[r];
+            uint32_t f = 0, l = 0, hf = 0, hl = 0;
+            bool contig = true;
+            if (!overlap_range(B.hets, B.n_hets, hs, rec.min_position, rec.max_position, f, l, contig)) continue;   // :703-712: skipped
+            if (!contig) { set_error("block %zu: assert_eq!(num_overlaps, last_overlap - first_overlap) (read_parsing.rs:715)", b); return HP_ERR_INVARIANT; }
+            const bool homs = overlap_range(B.homs, B.n_homs, ms, rec.min_position, rec.max_position, hf, hl, contig);
+            if (rec.min_position < (int64_t)B.ref_base) { set_error("block %zu record %u: alignment starts before the reference buffer", b, r); return HP_ERR_ARG; }
+            hp_wfa_job j{};
+            j.reference = B.reference; j.ref_base = B.ref_base;
+            j.ref_start = (uint64_t)rec.min_position; j.ref_end = (uint64_t)rec.max_position + 1;   // :772-773
+            j.hets = B.hets + f; j.n_hets = l - f;
+            j.homs = homs ? B.homs + hf : nullptr; j.n_homs = homs ? hl - hf : 0;   // first_hom_overlap.unwrap_or(0) with an empty range
+            j.read = rec.read_align; j.read_len = rec.read_len;
+            RecMeta& m = bs->meta[b][r];
+            m.job = (int64_t)bs->jobs.size(); m.first = f; m.last = l;
+            bs->jobs.push_back(j);
+            bs->job_alloff.push_back(al_total);
+            al_total += l - f;
+        }
+    }
+    bs->alleles.assign((size_t)al_total + 1, (uint8_t)HP_ALLELE_NOOVERLAP);
+    bs->allele_ptrs.resize(bs->jobs.size());
+    for (size_t k = 0; k < bs->jobs.size(); ++k) bs->allele_ptrs[k] = bs->alleles.data() + bs->job_alloff[k];
+    bs->wfa_out.resize(bs->jobs.size());
+    // large batches: lay the sequences out and upload them now (resident); small ones take the latency path at solve time
+    const char* mj = std::getenv("HP_WFA2_MIN_JOBS");
+    const size_t min_jobs = mj ? (size_t)std::strtoull(mj, nullptr, 10) : 4608;
+    if (!bs->jobs.empty() && bs->jobs.size() >= min_jobs) {
+        bs->wfa = w2_session_create();
+        const int rc = w2_session_prepare(bs->wfa, bs->jobs.data(), bs->jobs.size(), bs->device);
+        if (rc != HP_OK) return rc;
+    }
+    return HP_OK;
+}
+
+// load_full_read_segments' tail for one block (read_parsing.rs:546-629) once every record's WFA outcome is known:
+// fallback to local re-alignment, the global_disabled switch in BAM order, qualities, ReadSegment::new, collapse, split
+int assemble_block(hp_blockset* bs, size_t b) {
+    const hp_block_input& B = bs->in[b];
+    const hp_block_params& P = bs->prm;
+    BlockState& S = bs->st[b];
+    S = BlockState{};
+    const uint32_t N = B.n_hets, R = B.n_records;
+    const std::vector<RecMeta>& meta = bs->meta[b];
+    // local re-alignment rows (one batch call per need; a record's local result does not depend on any other record)
+    std::vector<int64_t> local_slot(R, -1);
+    std::vector<uint8_t> loc_alleles, loc_quals;
+    std::vector<hp_read_stats> loc_stats;
+    auto solve_local = [&](const std::vector<uint32_t>& idx) -> int {
+        std::vector<uint32_t> need;
+        for (uint32_t i : idx) if (local_slot[i] < 0) need.push_back(i);
+        if (need.empty()) return HP_OK;
+        if (!B.local_hets) { set_error("block %zu: a record needs local re-alignment (read_parsing.rs:121-503) but local_hets is NULL", b); return HP_ERR_ARG; }
+        std::vector<hp_local_read> reads(need.size());
+        for (size_t k = 0; k < need.size(); ++k) {
+            if (!B.records[need[k]].local) { set_error("block %zu record %u needs local re-alignment but has no CIGAR view", b, need[k]); return HP_ERR_ARG; }
+            reads[k] = *B.records[need[k]].local;
+        }
+        const size_t base = loc_stats.size();
+        loc_alleles.resize((base + need.size()) * (size_t)N);
+        loc_quals.resize((base + need.size()) * (size_t)N);
+        loc_stats.resize(base + need.size());
+        const int rc = hp_local_realign_batch(reads.data(), reads.size(), B.local_hets, N, loc_alleles.data() + base * N, loc_quals.data() + base * N,
+                                              loc_stats.data() + base, bs->device);
+        if (rc != HP_OK) return rc;
+        for (size_t k = 0; k < need.size(); ++k) local_slot[need[k]] = (int64_t)(base + k);
+        return HP_OK;
+    };
+    int rc;
+    if (!P.global_realignment) {   // load_read_segments (read_parsing.rs:47-113): every record through local_realignment
+        std::vector<uint32_t> all(R);
+        for (uint32_t i = 0; i < R; ++i) all[i] = i;
+        if ((rc = solve_local(all)) != HP_OK) return rc;
+    } else {
+        std::vector<uint32_t> failed;
+        for (uint32_t i = 0; i < R; ++i) if (meta[i].job >= 0 && bs->wfa_out[(size_t)meta[i].job].status == HP_WFA_MAX_ED) failed.push_back(i);
+        if ((rc = solve_local(failed)) != HP_OK) return rc;
+    }
+    // per read name: the segments of its records, in BAM order
+    std::vector<std::vector<Segment>> groups(B.n_qnames);
+    std::vector<uint32_t> order;           // first-seen read names
+    std::vector<uint8_t> seen(B.n_qnames, 0);
+    bool global_disabled = false;
+    double num_global_failures = 0.0, total_parsed = 0.0;
+    std::vector<uint8_t> row_a, row_q;
+    for (uint32_t idx = 0; idx < R; ++idx) {
+        const RecMeta& m = meta[idx];
+        Segment seg;
+        uint64_t wfa_score = 0;
+        bool skipped = false;
+        double local_aligned = 0.0;
+        if (!P.global_realignment) {
+            const size_t s = (size_t)local_slot[idx];
+            skipped = loc_stats[s].skipped_reads == 1;
+            if (!skipped) seg = segment_new(loc_alleles.data() + s * N, loc_quals.data() + s * N, 0, N, N);
+            local_aligned = 1.0;
+        } else {
+            if (m.job < 0) { S.skipped_reads += 1; continue; }   // no overlaps: flagged skipped (read_parsing.rs:703-712, :602-605)
+            const hp_wfa_result& w = bs->wfa_out[(size_t)m.job];
+            if (global_disabled || w.status == HP_WFA_MAX_ED) {
+                if (local_slot[idx] < 0) {   // the switch just flipped: everything from here on is local (read_parsing.rs:556-559)
+                    std::vector<uint32_t> rest;
+                    for (uint32_t i = idx; i < R; ++i) if (meta[i].job >= 0) rest.push_back(i);
+                    if ((rc = solve_local(rest)) != HP_OK) return rc;
+                }
+                const size_t s = (size_t)local_slot[idx];
+                skipped = loc_stats[s].skipped_reads == 1;
+                if (!skipped) seg = segment_new(loc_alleles.data() + s * N, loc_quals.data() + s * N, 0, N, N);
+                wfa_score = P.max_edit_distance;   // :559 / :573: the distance carried by the error is max_edit_distance
+                local_aligned = 1.0;
+            } else {
+                const uint32_t n = m.last - m.first;
+                const uint8_t* a = bs->alleles.data() + bs->job_alloff[(size_t)m.job];
+                row_a.assign(a, a + n);
+                row_q.assign(n, 0);
+                for (uint32_t i = 0; i < n; ++i)
+                    if (row_a[i] < HP_ALLELE_AMBIGUOUS) {   // read_parsing.rs:803-835: 2 x base quality for 0/1 alleles, else 0
+                        const int q = base_quality(B.het_types[m.first + i]);
+                        if (q < 0) { set_error("block %zu: no base quality for variant type %u (read_parsing.rs:829 panics)", b, (unsigned)B.het_types[m.first + i]); return HP_ERR_INVARIANT; }
+                        row_q[i] = (uint8_t)(2 * q);
+                    }
+                seg = segment_new(row_a.data(), row_q.data(), m.first, n, N);
+                wfa_score = w.score;
+            }
+        }
+        if (skipped) { S.skipped_reads += 1; continue; }
+        S.local_aligned += (uint64_t)local_aligned;
+        S.global_aligned += 1 - (uint64_t)local_aligned;
+        const uint32_t q = B.records[idx].qname_id;
+        if (!seen[q]) { seen[q] = 1; order.push_back(q); }
+        groups[q].push_back(std::move(seg));
+        if (P.global_realignment) {
+            S.edit_distances.push_back(wfa_score);
+            num_global_failures += local_aligned;
+            total_parsed += 1.0;
+            if (!global_disabled && num_global_failures >= (double)P.global_failure_minimum && num_global_failures / total_parsed >= P.global_failure_ratio)
+                global_disabled = true;   // read_parsing.rs:597-600
+        }
+    }
+    // collapse per read name + the min_matched_alleles split (read_parsing.rs:611-629 / :95-113)
+    for (uint32_t q : order) {
+        std::vector<const Segment*> grp;
+        for (auto& s : groups[q]) grp.push_back(&s);
+        Segment col;
+        if (!segment_collapse(grp, N, col)) { set_error("block %zu: assert!(quals[i] > 0) (read_segments.rs:105)", b); return HP_ERR_INVARIANT; }
+        const uint32_t num_set = seg_num_set(col);
+        const bool solver = num_set >= P.min_matched_alleles;
+        if (solver) S.num_reads += grp.size(); else S.skipped_reads += grp.size();
+        if (!solver && num_set == 0) continue;
+        if (solver) S.solver_rows.push_back((uint32_t)S.segs.size());
+        S.segs.push_back(std::move(col));
+        S.seg_qname.push_back(q);
+        S.seg_solver.push_back(solver ? 1 : 0);
+    }
+    // the solver matrix (phaser.rs:514-533) as hp_block_view
+    S.var_flags.resize(N);
+    for (uint32_t i = 0; i < N; ++i)
+        S.var_flags[i] = (uint8_t)(((B.hets[i].flags & 1u) ? HP_VAR_IGNORED : 0) | (B.het_types[i] == 0 ? HP_VAR_SNV : 0));
+    S.row_off.push_back(0);
+    uint64_t cells = 0;
+    for (uint32_t k : S.solver_rows) cells += S.segs[k].end - S.segs[k].start;
+    S.alleles_2bit.assign((size_t)(cells + 3) / 4 + 1, 0);
+    S.quals.reserve((size_t)cells + 1);
+    uint64_t c = 0;
+    for (uint32_t k : S.solver_rows) {
+        const Segment& s = S.segs[k];
+        S.read_start.push_back(s.start);
+        S.read_end.push_back(s.end);
+        for (size_t i = 0; i < s.alleles.size(); ++i, ++c) S.alleles_2bit[(size_t)(c >> 2)] |= (uint8_t)(s.alleles[i] << (2 * (c & 3)));
+        S.quals.insert(S.quals.end(), s.quals.begin(), s.quals.end());
+        S.row_off.push_back(c);
+    }
+    if (S.quals.empty()) S.quals.push_back(0);
+    return HP_OK;
+}
+
+}  // namespace
+
+extern "C" hp_blockset* hp_blockset_create(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id, int* status) {
+    auto bs = std::unique_ptr<hp_blockset>(new hp_blockset());
+    const int rc = blockset_init(bs.get(), n_blocks, in, p, device_id);
+    if (status) *status = rc;
+    if (rc != HP_OK) return nullptr;
+    return bs.release();
+}
+
+extern "C" void hp_blockset_destroy(hp_blockset* bs) { delete bs; }
+
+extern "C" int hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* stage_ms) {
+    if (!bs || !out) { set_error("null argument"); return HP_ERR_ARG; }
+    const double t0 = blk_now_ms();
+    double wfa_kernel_ms = 0.0, astar_kernel_ms = 0.0;
+    int rc;
+    // ---- 1. graph-WFA for every record with overlaps, all blocks in one batch ----
+    if (!bs->jobs.empty()) {
+        if (bs->wfa) rc = w2_session_run(bs->wfa, bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, bs->wfa_out.data(), bs->allele_ptrs.data());
+        else rc = hp_wfa_assign_batch(bs->jobs.data(), bs->jobs.size(), bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, bs->wfa_out.data(),
+                                      bs->allele_ptrs.data(), bs->device);
+        if (rc != HP_OK) return rc;
+        wfa_kernel_ms = hp_last_kernel_ms();
+    }
+    const double t1 = blk_now_ms();
+    // ---- 2. fallback, replay, rows, collapse (host; a few bytes per record) ----
+    for (size_t b = 0; b < bs->n_blocks; ++b)
+        if ((rc = assemble_block(bs, b)) != HP_OK) return rc;
+    const double t2 = blk_now_ms();
+    // ---- 3. A* over all blocks ----
+    std::vector<hp_block_view> views(bs->n_blocks);
+    for (size_t b = 0; b < bs->n_blocks; ++b) {
+        const BlockState& S = bs->st[b];
+        hp_block_view v{};
+        v.n_variants = bs->in[b].n_hets;
+        v.n_reads = (uint32_t)S.read_start.size();
+        v.read_start = S.read_start.data(); v.read_end = S.read_end.data(); v.row_off = S.row_off.data();
+        v.alleles_2bit = S.alleles_2bit.data(); v.quals = S.quals.data(); v.var_flags = S.var_flags.data();
+        views[b] = v;
+    }
+    hp_astar_params ap = bs->prm.astar;
+    int st = HP_OK;
+    hp_batch* batch = hp_batch_create(bs->n_blocks, views.data(), &ap, bs->device, &st);
+    if (!batch) return st != HP_OK ? st : HP_ERR_HIP;
+    struct BatchGuard { hp_batch* b; ~BatchGuard() { hp_batch_destroy(b); } } guard{batch};
+    const double t3 = blk_now_ms();
+    float kms = 0.f;
+    if ((rc = hp_batch_solve(batch, nullptr, &kms)) != HP_OK) return rc;
+    astar_kernel_ms = kms;
+    uint64_t sum_n = 0, sum_rows = 0, sum_j = 0;
+    for (size_t b = 0; b < bs->n_blocks; ++b) { sum_n += bs->in[b].n_hets; sum_rows += bs->st[b].read_start.size(); sum_j += bs->in[b].n_hets - 1; }
+    std::vector<uint8_t> h1((size_t)sum_n), h2((size_t)sum_n);
+    std::vector<hp_phase_stats> stats(bs->n_blocks);
+    if ((rc = hp_batch_results(batch, h1.data(), h2.data(), stats.data(), nullptr, nullptr)) != HP_OK) return rc;
+    const double t4 = blk_now_ms();
+    // ---- 4. span counts and haplotags on the resident matrix ----
+    std::vector<uint64_t> spans((size_t)sum_j + 1);
+    std::vector<uint8_t> tag((size_t)sum_rows + 1);
+    std::vector<uint32_t> fh((size_t)sum_rows + 1);
+    if ((rc = hp_batch_postprocess(batch, spans.data(), tag.data(), fh.data())) != HP_OK) return rc;
+    // ---- 5. outputs ----
+    uint64_t on = 0, orow = 0, oj = 0;
+    for (size_t b = 0; b < bs->n_blocks; ++b) {
+        const hp_block_input& B = bs->in[b];
+        const BlockState& S = bs->st[b];
+        hp_block_output& O = out[b];
+        const uint32_t N = B.n_hets;
+        const uint8_t* H1 = h1.data() + on;
+        const uint8_t* H2 = h2.data() + on;
+        if (O.h1) std::memcpy(O.h1, H1, N);
+        if (O.h2) std::memcpy(O.h2, H2, N);
+        O.stats = stats[b];
+        if (O.span_counts && N > 1) std::memcpy(O.span_counts, spans.data() + oj, (size_t)(N - 1) * 8);
+        O.n_segments = (uint32_t)S.segs.size();
+        O.n_solver = (uint32_t)S.solver_rows.size();
+        O.num_reads = S.num_reads; O.skipped_reads = S.skipped_reads; O.global_aligned = S.global_aligned; O.local_aligned = S.local_aligned;
+        O.n_edit_distances = S.edit_distances.size();
+        if (O.edit_distances && !S.edit_distances.empty()) std::memcpy(O.edit_distances, S.edit_distances.data(), S.edit_distances.size() * 8);
+        uint64_t cells = 0;
+        uint32_t srow = 0;
+        for (size_t k = 0; k < S.segs.size(); ++k) {
+            const Segment& s = S.segs[k];
+            if (O.seg_qname) O.seg_qname[k] = S.seg_qname[k];
+            if (O.seg_start) O.seg_start[k] = s.start;
+            if (O.seg_end) O.seg_end[k] = s.end;
+            if (O.seg_solver) O.seg_solver[k] = S.seg_solver[k];
+            uint8_t ht = 2;
+            uint32_t first = UINT32_MAX;
+            if (S.seg_solver[k]) { ht = tag[(size_t)(orow + srow)]; first = fh[(size_t)(orow + srow)]; ++srow; }
+            else {
+                // a segment outside the solver matrix (fewer than min_matched_alleles set alleles) is tagged against the
+                // solution the way haplotag_reads tags any segment (phaser.rs:620-630, :714-750): a handful of cells
+                uint64_t s1 = 0, s2 = 0;
+                for (uint32_t i = s.start; i < s.end; ++i) {
+                    const uint8_t a = s.alleles[i - s.start], q = s.quals[i - s.start];
+                    if (H1[i] < HP_ALLELE_AMBIGUOUS && a != H1[i]) s1 += q;
+                    if (H2[i] < HP_ALLELE_AMBIGUOUS && a != H2[i]) s2 += q;
+                }
+                if (s1 != s2) {
+                    ht = s1 < s2 ? 0 : 1;
+                    uint32_t f = s.start;
+                    while (f < s.end && (H1[f] == H2[f] || s.alleles[f - s.start] >= HP_ALLELE_AMBIGUOUS)) ++f;
+                    first = f < s.end ? f : UINT32_MAX;
+                }
+            }
+            if (O.seg_haplotag) O.seg_haplotag[k] = ht;
+            if (O.seg_first_het) O.seg_first_het[k] = first;
+            if (O.seg_row_off) O.seg_row_off[k] = cells;
+            const uint64_t len = s.end - s.start;
+            if (O.seg_alleles || O.seg_quals) {
+                if (cells + len > O.seg_cell_cap) { set_error("block %zu: seg_cell_cap too small", b); return HP_ERR_ARG; }
+                if (O.seg_alleles) std::memcpy(O.seg_alleles + cells, s.alleles.data(), (size_t)len);
+                if (O.seg_quals) std::memcpy(O.seg_quals + cells, s.quals.data(), (size_t)len);
+            }
+            cells += len;
+        }
+        if (O.seg_row_off) O.seg_row_off[S.segs.size()] = cells;
+        on += N; orow += S.read_start.size(); oj += N - 1;
+    }
+    const double t5 = blk_now_ms();
+    if (stage_ms) {
+        stage_ms[0] = t1 - t0; stage_ms[1] = t2 - t1; stage_ms[2] = t3 - t2; stage_ms[3] = t4 - t3; stage_ms[4] = t5 - t4; stage_ms[5] = t5 - t0;
+        stage_ms[6] = wfa_kernel_ms; stage_ms[7] = astar_kernel_ms;
+    }
+    return HP_OK;
+}
+
+extern "C" int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id) {
+    if (n_blocks == 0) return HP_OK;
+    int st = HP_OK;
+    hp_blockset* bs = hp_blockset_create(n_blocks, in, p, device_id, &st);
+    if (!bs) return st != HP_OK ? st : HP_ERR_ARG;
+    const int rc = hp_blockset_solve(bs, out, nullptr);
+    hp_blockset_destroy(bs);
+    return rc;
+}

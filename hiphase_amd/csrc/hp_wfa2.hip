@@ -117,15 +117,27 @@ template <int G, int W> int w2_launch(const W2Batch& B, uint32_t n_items, int n_
 
 }  // namespace
 
-int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
-                        uint8_t* const* alleles, int device_id) {
+// A batch laid out and uploaded once (prepare) can be aligned any number of times (run): what the block-level resident
+// form (hp_block.hip) and the bench time is run(), with the sequences already in HBM.
+struct W2Session {
+    const hp_wfa_job* jobs = nullptr;
+    size_t n = 0;
+    int device_id = -1;
+    std::vector<W2Job> dj;
+    std::vector<W2Variant> vars;
+    uint64_t seq_bytes = 0, alt_off = 0, node_tot = 0, edge_tot = 0, tag_tot = 0, allele_tot = 0;
+    DevBuf d_seq, d_vars, d_jobs, d_nodes, d_edges, d_tags, d_par, d_poff, d_cnt, d_info, d_order, d_sets, d_score, d_status, d_alleles;
+    double last_prepare_ms = 0.0;
+    int prepare(const hp_wfa_job* jobs_, size_t n_, int device);
+    int run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles);
+};
+
+int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
+    jobs = jobs_; n = n_;
     if (n == 0) return HP_OK;
-    if (!jobs || !out) { set_error("null argument"); return HP_ERR_ARG; }
+    if (!jobs) { set_error("null argument"); return HP_ERR_ARG; }
     if (n > 0x3FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
-    if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
-    const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const double t0 = w2_now_ms();
-    g_last_kernel_ms = 0.0;
     for (size_t i = 0; i < n; ++i) {
         const hp_wfa_job& j = jobs[i];
         if (!j.reference || (!j.read && j.read_len)) { set_error("job %zu: null sequence", i); return HP_ERR_ARG; }
@@ -133,6 +145,7 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
         if ((j.n_hets && !j.hets) || (j.n_homs && !j.homs)) { set_error("job %zu: null variant list", i); return HP_ERR_ARG; }
         if (j.ref_end - j.ref_start >= 0x7FFFFFFFull) { set_error("job %zu: reference window too long", i); return HP_ERR_UNSUPPORTED; }
     }
+    seq_bytes = 0; node_tot = edge_tot = tag_tot = allele_tot = 0;
 
     // ---- 1. layout: merged reference windows, distinct variants, read bases ------------------------------------------
     std::vector<Range> ref_ranges, var_ranges;
@@ -149,12 +162,12 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
         }
         merge_ranges(iv, var_ranges, sizeof(hp_wfa_variant));
     }
-    uint64_t seq_bytes = 0, n_vars = 0;
+    uint64_t n_vars = 0;
     for (auto& r : ref_ranges) { r.dev = seq_bytes; seq_bytes += ((uint64_t)(r.hi - r.lo) + 15) & ~15ull; }
     for (auto& r : var_ranges) { r.dev = n_vars; n_vars += (uint64_t)(r.hi - r.lo) / sizeof(hp_wfa_variant); }
     if (n_vars >= 0xFFFFFFF0ull) { set_error("too many variants"); return HP_ERR_UNSUPPORTED; }
     // allele pool: every distinct variant's truncated alleles once
-    std::vector<W2Variant> vars((size_t)n_vars);
+    vars.assign((size_t)n_vars, W2Variant{});
     uint64_t pool_bytes = 0;
     for (auto& r : var_ranges) {
         const hp_wfa_variant* hv = reinterpret_cast<const hp_wfa_variant*>(r.lo);
@@ -172,10 +185,9 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
             if (pool_bytes >= 0xFFFFFF00ull) { set_error("allele pool exceeds 4 GiB"); return HP_ERR_UNSUPPORTED; }
         }
     }
-    const uint64_t alt_off = seq_bytes;
+    alt_off = seq_bytes;
     seq_bytes += (pool_bytes + 15) & ~15ull;
-    std::vector<W2Job> dj(n);
-    uint64_t node_tot = 0, edge_tot = 0, tag_tot = 0, allele_tot = 0;
+    dj.assign(n, W2Job{});
     for (size_t i = 0; i < n; ++i) {
         const hp_wfa_job& j = jobs[i];
         W2Job& d = dj[i];
@@ -216,10 +228,11 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
     }
     seq_bytes += 256;   // the 32-byte compares may run past the last base of the last read
 
+
     // ---- from here on a GPU is mandatory (no CPU fallback) -------------------------------------------------------------
-    if (device_id < 0) device_id = hp_default_device();
+    if (device < 0) device = hp_default_device();
+    device_id = device;
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
-    const int n_cu = device_cu_count(device_id);
     W2Context& cx = g_w2;
     if (cx.device != device_id) {
         cx.htab.release(); cx.gsets.release(); cx.htab_groups = 0; cx.tag_next = 0;
@@ -228,13 +241,6 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
     }
     if (!cx.stream) HP_HIP_CHECK(hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking));
     hipStream_t st = cx.stream;
-    // host tables that stream operations read or write; the guard below (destroyed first) drains the stream on every
-    // exit path, so none of them goes out of scope with a copy in flight
-    std::vector<W2Info> info(n);
-    std::vector<uint32_t> order;
-    std::vector<int32_t> status(n), st0(n, W2_ST_NEED_BIG);
-    std::vector<uint64_t> score(n);
-    std::vector<uint8_t> al((size_t)std::max<uint64_t>(allele_tot, 1));
     struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{st};
 
     // ---- 2. stage + upload -----------------------------------------------------------------------------------------------
@@ -271,8 +277,6 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
             }
         });
     }
-    const double t_stage = w2_now_ms();
-    DevBuf d_seq, d_vars, d_jobs, d_nodes, d_edges, d_tags, d_par, d_poff, d_cnt, d_info, d_order, d_sets, d_score, d_status, d_alleles;
     if ((rc = d_seq.alloc(seq_bytes)) || (rc = d_vars.alloc(std::max<size_t>(1, vars.size()) * sizeof(W2Variant))) || (rc = d_jobs.alloc(n * sizeof(W2Job))) ||
         (rc = d_nodes.alloc((size_t)node_tot * sizeof(W2Node))) || (rc = d_edges.alloc((size_t)edge_tot * 2)) || (rc = d_tags.alloc((size_t)tag_tot * 4)) ||
         (rc = d_par.alloc((size_t)edge_tot * 2)) || (rc = d_poff.alloc(((size_t)node_tot + n) * 4)) || (rc = d_cnt.alloc((size_t)node_tot * 4)) ||
@@ -284,6 +288,34 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
     // reads them is waited for below (hipStreamSynchronize) before they go out of scope
     if (!vars.empty()) HP_HIP_CHECK(hipMemcpyAsync(d_vars.p, vars.data(), vars.size() * sizeof(W2Variant), hipMemcpyHostToDevice, st));
     HP_HIP_CHECK(hipMemcpyAsync(d_jobs.p, dj.data(), n * sizeof(W2Job), hipMemcpyHostToDevice, st));
+
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("upload failed"); return HP_ERR_HIP; }
+    last_prepare_ms = w2_now_ms() - t0;
+    return HP_OK;
+}
+
+int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles) {
+    if (n == 0) return HP_OK;
+    if (!out) { set_error("null argument"); return HP_ERR_ARG; }
+    if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
+    const bool verbose = std::getenv("HP_DEBUG") != nullptr;
+    const double t0 = w2_now_ms();
+    g_last_kernel_ms = 0.0;
+    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
+    const int n_cu = device_cu_count(device_id);
+    W2Context& cx = g_w2;
+    if (cx.device != device_id || !cx.stream) { set_error("WFA session used from another thread or device than it was prepared on"); return HP_ERR_ARG; }
+    hipStream_t st = cx.stream;
+    int rc;
+    // host tables that stream operations read or write; the guard below (destroyed first) drains the stream on every
+    // exit path, so none of them goes out of scope with a copy in flight
+    std::vector<W2Info> info(n);
+    std::vector<uint32_t> order;
+    std::vector<int32_t> status(n), st0(n, W2_ST_NEED_BIG);
+    std::vector<uint64_t> score(n);
+    std::vector<uint8_t> al((size_t)std::max<uint64_t>(allele_tot, 1));
+    struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{st};
+    const double t_stage = t0;
 
     // ---- 3. graphs on the device ----------------------------------------------------------------------------------------
     hipEvent_t e0, e1, e2, e3;
@@ -413,5 +445,23 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
     }
     return HP_OK;
 }
+
+int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
+                        uint8_t* const* alleles, int device_id) {
+    if (n == 0) return HP_OK;
+    if (!jobs || !out) { set_error("null argument"); return HP_ERR_ARG; }
+    if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
+    W2Session ses;
+    int rc = ses.prepare(jobs, n, device_id);
+    if (rc != HP_OK) return rc;
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa2: layout + stage + upload %.2f ms\n", ses.last_prepare_ms); fflush(stderr); }
+    return ses.run(prune_distance, max_ed, out, alleles);
+}
+
+// opaque handle for hp_block.hip
+W2Session* w2_session_create() { return new W2Session(); }
+void w2_session_destroy(W2Session* s) { delete s; }
+int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id) { return s->prepare(jobs, n, device_id); }
+int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles) { return s->run(prune_distance, max_ed, out, alleles); }
 
 }  // namespace hp

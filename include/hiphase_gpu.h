@@ -229,6 +229,88 @@ typedef struct hp_read_stats {           /* ReadStats of one record (writers/pha
 int hp_local_realign_batch(const hp_local_read* reads, size_t n_reads, const hp_local_variant* variants,
                            size_t n_variants, uint8_t* alleles, uint8_t* quals, hp_read_stats* stats, int device_id);
 
+/* ---- whole blocks: phaser::solve_block from the decoded records on (phaser.rs:513-630) ------------------------------- */
+/* One entry runs, inside the library and for any number of blocks at once: graph-WFA for every record with overlaps
+ * (read_parsing.rs:652-800, one device batch over ALL blocks), local re-alignment of the records whose WFA ran into
+ * max_edit_distance and the order-dependent `global_disabled` switch (read_parsing.rs:556-600), quality assignment
+ * (:803-835), ReadSegment::new, collapse per read name, the min_matched_alleles split (:611-629), the A* solver
+ * (phaser.rs:541-543), get_solution_span_counts (:546) and haplotag_reads (:614-630). What stays with the caller is
+ * I/O: BAM decoding and filtering (filter_out_alignment_record, aligned_pairs -> min/max position), VCF loading,
+ * the PS tag lookup block_tags[first_het] and the sub-block split, which need variant positions the caller owns. */
+typedef struct hp_block_record {          /* one BAM record that passed filter_out_alignment_record (read_parsing.rs:551) */
+    int64_t              min_position;    /* first / last reference base of the alignment, inclusive (read_parsing.rs:672-685) */
+    int64_t              max_position;
+    const uint8_t*       read_align;      /* seq[read_start ..= read_end] (read_parsing.rs:738-742) */
+    uint32_t             read_len;
+    uint32_t             qname_id;        /* records of one read name share an id: 0 .. n_qnames-1 */
+    const hp_local_read* local;           /* CIGAR view of the record for local re-alignment: needed in local mode and when the
+                                             record falls back (read_parsing.rs:556-575); NULL makes such a fallback an HP_ERR_ARG */
+} hp_block_record;
+
+typedef struct hp_block_input {
+    uint64_t                block_index;  /* PhaseBlock::get_block_index() */
+    const uint8_t*          reference;    /* chromosome bytes: reference[x - ref_base] is base x */
+    uint64_t                ref_base;
+    uint32_t                n_hets, n_homs, n_records, n_qnames;
+    const hp_wfa_variant*   hets;         /* variant_calls as the graph builder reads them, position-sorted [n_hets] */
+    const uint8_t*          het_types;    /* VariantType of each het (variants.rs:10-33) [n_hets] */
+    const hp_local_variant* local_hets;   /* variant_calls as local_realignment reads them [n_hets]; may be NULL when no record
+                                             can fall back (then a fallback is an HP_ERR_ARG) */
+    const hp_wfa_variant*   homs;         /* hom_calls [n_homs] */
+    const hp_block_record*  records;      /* in BAM order: the fallback switch depends on it (read_parsing.rs:597-600) */
+} hp_block_input;
+
+typedef struct hp_block_params {
+    hp_astar_params astar;
+    uint64_t wfa_prune_distance;          /* GlobalRealignmentConfig (cli.rs:189-210); UINT64_MAX disables pruning */
+    uint64_t max_edit_distance;
+    double   global_failure_ratio;
+    uint64_t global_failure_minimum;
+    uint64_t min_matched_alleles;         /* cli.rs:145 */
+    uint32_t global_realignment;          /* 1: load_full_read_segments, 0: load_read_segments (--disable-global-realignment) */
+    uint32_t reserved;
+} hp_block_params;
+
+/* Everything is caller-allocated; any array pointer may be NULL (then that output is skipped). Segments = the collapsed
+ * ReadSegments with at least one set allele, in first-seen read-name order; seg_solver marks the ones that entered
+ * the solver (get_num_set() >= min_matched_alleles), the others are "phasable only" (read_parsing.rs:620-627). */
+typedef struct hp_block_output {
+    uint8_t*        h1;                   /* [n_hets] AstarResult haplotypes */
+    uint8_t*        h2;
+    hp_phase_stats  stats;
+    uint64_t*       span_counts;          /* [n_hets - 1] */
+    uint32_t        n_segments;           /* out */
+    uint32_t        n_solver;             /* out */
+    uint32_t*       seg_qname;            /* [n_qnames] */
+    uint32_t*       seg_start;            /* [n_qnames] region().start */
+    uint32_t*       seg_end;              /* [n_qnames] region().end */
+    uint8_t*        seg_solver;           /* [n_qnames] */
+    uint8_t*        seg_haplotag;         /* [n_qnames] 0 / 1, 2 = untagged (tie) */
+    uint32_t*       seg_first_het;        /* [n_qnames] first het the segment resolves, UINT32_MAX when untagged */
+    uint64_t*       seg_row_off;          /* [n_qnames + 1] cell offsets of the segments' rows */
+    uint8_t*        seg_alleles;          /* AlleleType per cell */
+    uint8_t*        seg_quals;
+    uint64_t        seg_cell_cap;         /* in: capacity of seg_alleles / seg_quals (HP_ERR_ARG when too small) */
+    uint64_t        num_reads;            /* ReadStats of the loader: records in solver segments */
+    uint64_t        skipped_reads;        /* records without overlaps, skipped by local re-alignment, or in dropped segments */
+    uint64_t        global_aligned;
+    uint64_t        local_aligned;
+    uint64_t*       edit_distances;       /* [n_records] wfa_score of every record that was not skipped, in BAM order */
+    uint64_t        n_edit_distances;     /* out */
+} hp_block_output;
+
+int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id);
+
+/* Resident form: hp_blockset_create lays the blocks' sequences out and uploads them (the caller's buffers must stay
+ * valid until hp_blockset_destroy); hp_blockset_solve runs the whole path on the resident data and may be called
+ * repeatedly (what bench.py times). stage_ms (may be NULL) receives 8 numbers in ms: [0] graph-WFA stage wall time
+ * (device graph build + alignment + allele rows + download), [1] fallback / replay / row assembly (host), [2] A* pack +
+ * upload, [3] A* solve, [4] post-processing, [5] total, [6] graph-WFA kernels (HIP events), [7] A* kernel (HIP events). */
+typedef struct hp_blockset hp_blockset;
+hp_blockset* hp_blockset_create(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id, int* status);
+int  hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* stage_ms);
+void hp_blockset_destroy(hp_blockset* bs);
+
 /* ---- misc --------------------------------------------------------------------------------- */
 int         hp_device_count(void);
 int         hp_default_device(void);

@@ -1,0 +1,133 @@
+"""The whole-block C entry (hp_solve_blocks / hp_blockset_*, hiphase_amd/csrc/hp_block.hip): graph-WFA over the records
+of all blocks in one device batch, fallback + `global_disabled` replay, quality assignment, collapse, A*, span counts
+and haplotags INSIDE the library - checked against (a) the same pipeline assembled record by record from the CPU
+oracle in the reference's order and (b) the stage-by-stage mirror above the ABI (hiphase_amd.phaser.solve_block)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from e2e_util import make_block
+from hiphase_amd.blocks import BlockSet, BlockSpec, solve_blocks
+from hiphase_amd.phaser import solve_block
+from hiphase_amd.read_parsing import GlobalRealignmentConfig, LocalRecord
+from hiphase_amd.read_segments import BlockMatrix
+from hiphase_amd.wfa_graph import VariantType
+from local_util import make_local_block
+from oracle_ffi import oracle, oracle_solve
+from test_e2e_gpu import oracle_pipeline
+from test_local_gpu import oracle_segments, reference_order_replay, seg_tuple, to_aligned
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["compact", "dense-band"])
+def wfa_path(request, monkeypatch):
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0" if request.param == "compact" else "1000000000")
+    return request.param
+
+
+def check_against_oracle(res, osegs, hets, ophasable=None):
+    """res (BlockResult) == the oracle-assembled solver segments -> oracle A* -> oracle post-processing"""
+    solver = [s for s in res.segments if s[5]]
+    assert [(s[0], s[1], s[2], s[3], s[4]) for s in solver] == [seg_tuple(s) for s in osegs]
+    if ophasable is not None:
+        assert [(s[0], s[1], s[2], s[3], s[4]) for s in res.segments if not s[5]] == [seg_tuple(s) for s in ophasable]
+    flags = np.asarray([(1 if v.is_ignored else 0) | (2 if v.variant_type == VariantType.Snv else 0) for v in hets], np.uint8)
+    om = BlockMatrix.from_segments(osegs, len(hets), flags)
+    h1, h2, st, _ = oracle_solve(om)
+    assert np.array_equal(res.haplotype_1, h1) and np.array_equal(res.haplotype_2, h2) and res.statistics == st
+    d = oracle()
+    v = om.view()
+    spans = np.zeros(max(len(hets) - 1, 1), np.uint64)
+    assert d.hpo_solution_span_counts(C.byref(v), h1.ctypes.data, h2.ctypes.data, spans.ctypes.data) == 0
+    assert res.span_counts.tolist() == spans[:len(hets) - 1].tolist()
+    ht = np.zeros(max(om.n_reads, 1), np.uint8)
+    pb = np.zeros(max(om.n_reads, 1), np.uint64)
+    idx = np.arange(len(hets), dtype=np.uint64)   # block_tags[i] = i: phase_block comes back as the first het index
+    assert d.hpo_haplotag_reads(C.byref(v), h1.ctypes.data, h2.ctypes.data, idx.ctypes.data, ht.ctypes.data, pb.ctypes.data) == 0
+    exp = {osegs[i].read_name: (int(pb[i]), int(ht[i])) for i in range(om.n_reads) if ht[i] != 2}
+    got = {q: t for q, t in res.haplotags.items() if q in {s.read_name for s in osegs}}
+    assert got == exp
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_block_entry_vs_oracle_pipeline(seed, wfa_path):
+    ref, hets, homs, records, truth = make_block(seed)
+    cfg = GlobalRealignmentConfig()
+    res, = solve_blocks([BlockSpec(7, ref, hets, homs, records)], config=cfg)
+    check_against_oracle(res, oracle_pipeline(ref, hets, homs, records, cfg), hets)
+    assert res.local_aligned == 0 and res.global_aligned == len(res.edit_distances)
+
+
+def test_block_entry_equals_stagewise_mirror_and_batches():
+    """several blocks in ONE call == each block alone == the stage-by-stage mirror above the ABI"""
+    specs, mirrors = [], []
+    for seed in (4, 5, 6, 7):
+        ref, hets, homs, records, _ = make_block(seed, ref_len=25000, n_hets=30, n_homs=6, n_reads=60)
+        specs.append(BlockSpec(seed, ref, hets, homs, records))
+        mirrors.append(solve_block(seed, records, hets, homs, ref))
+    together = solve_blocks(specs)
+    for spec, t, (m, matrix, segs) in zip(specs, together, mirrors):
+        alone, = solve_blocks([spec])
+        for r in (t, alone):
+            assert np.array_equal(r.haplotype_1, m.haplotype_1) and np.array_equal(r.haplotype_2, m.haplotype_2)
+            assert r.statistics == m.statistics
+            assert [(s[0], s[1], s[2], s[3], s[4]) for s in r.segments if s[5]] == [seg_tuple(s) for s in segs]
+            tags = m.block_ids
+            assert {q: (tags[f], h) for q, (f, h) in r.haplotags.items()} == m.haplotags
+        assert t.segments == alone.segments and t.span_counts.tolist() == alone.span_counts.tolist()
+
+
+@pytest.mark.parametrize("max_ed,minimum,ratio,expect_flip", [(4, 5, 0.3, True), (8, 10, 0.9, False), (3000, 1, 0.5, False)])
+def test_block_entry_fallback_replay(max_ed, minimum, ratio, expect_flip, wfa_path):
+    """Err(MaxEditDistance) -> local re-alignment and the order-dependent global_disabled switch (read_parsing.rs:556-600),
+    now replayed inside the library, against the reference's record-by-record order on the oracle."""
+    ref, variants, truth, lrecs = make_local_block(21, ref_len=20000, n_vars=100, n_reads=120, read_len=(800, 3000), noise=0.004)
+    hets = [v for v in variants if int(v.variant_type) in (0, 1, 2, 3)]
+    records = [to_aligned(r) for r in lrecs if any(op in "M=X" for op, _ in r.cigar)]
+    cfg = GlobalRealignmentConfig(max_edit_distance=max_ed, wfa_prune_distance=max_ed, global_failure_minimum=minimum, global_failure_ratio=ratio)
+    res, = solve_blocks([BlockSpec(1, ref, hets, [], records)], config=cfg)
+    osegs, n_local, n_global, flipped = reference_order_replay(oracle(), ref, hets, records, cfg)
+    assert flipped == expect_flip
+    assert (res.local_aligned, res.global_aligned) == (n_local, n_global)
+    check_against_oracle(res, osegs, hets)
+
+
+def test_block_entry_local_mode():
+    """--disable-global-realignment: load_read_segments inside the library (read_parsing.rs:47-113)"""
+    ref, variants, truth, records = make_local_block(11, ref_len=20000, n_vars=120, n_reads=200, read_len=(1500, 6000))
+    records.append(LocalRecord(records[0].qname, records[5].pos, records[5].cigar, records[5].seq, records[5].qual))
+    res, = solve_blocks([BlockSpec(3, ref, variants, [], records)], global_realignment=False)
+    osegs, ophas = oracle_segments(oracle(), records, variants)
+    check_against_oracle(res, osegs, variants, ophas)
+    assert res.global_aligned == 0 and res.local_aligned > 0
+
+
+def test_blockset_resident_resolve(wfa_path):
+    """hp_blockset_*: upload once, solve twice, same answers as the one-shot entry; stage times come back"""
+    specs = []
+    for seed in (8, 9):
+        ref, hets, homs, records, _ = make_block(seed, ref_len=25000, n_hets=30, n_homs=6, n_reads=60)
+        specs.append(BlockSpec(seed, ref, hets, homs, records))
+    once = solve_blocks(specs)
+    bs = BlockSet(specs)
+    for _ in range(2):
+        ms = bs.solve()
+        assert len(ms) == 8 and ms[5] > 0
+        again = bs.results()
+        for a, b in zip(once, again):
+            assert np.array_equal(a.haplotype_1, b.haplotype_1) and a.statistics == b.statistics and a.segments == b.segments
+            assert a.haplotags == b.haplotags and a.span_counts.tolist() == b.span_counts.tolist()
+    bs.close()
+
+
+def test_block_entry_needs_cigar_for_fallback():
+    ref, variants, truth, lrecs = make_local_block(22, n_reads=10)
+    hets = [v for v in variants if int(v.variant_type) in (0, 1, 2, 3)]
+    records = [to_aligned(r) for r in lrecs if any(op in "M=X" for op, _ in r.cigar)]
+    for r in records:
+        r.local = None
+    from hiphase_amd._ffi import HpError
+    with pytest.raises(HpError):
+        solve_blocks([BlockSpec(1, ref, hets, [], records)], config=GlobalRealignmentConfig(max_edit_distance=0, wfa_prune_distance=0))
