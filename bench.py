@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""bench.py — het variants phased / sec through the HIP A* solver (BASELINE.json metric).
+"""bench.py — het variants phased / sec (BASELINE.json metric) through the WHOLE hot path on one MI355X per rank.
 
-One "step" = one pass of the hot path (hp_batch_solve: heuristic chain + pruned A* for every block)
-over one resident batch of synthetic read x variant allele matrices. Default workload = BASELINE.json
-configs[1] shape: blocks of N=5000 hets, coverage 30, span 20 (R=7500), e=0.01, a=0.02,
-seeds 20250509+i, `--blocks` of them per GPU (independent blocks, weak scaling, no collective).
+Default workload "path": a synthetic read-bearing WGS-like block mix (hiphase_amd/synth_reads.py: heavy-tailed block
+sizes, HiFi-like 15-kb reads at 30x, het + hom small variants). One "step" = one hp_blockset_solve over the resident
+blocks: records -> graph-WFA (device graph build, alignment, allele rows) -> fallback / collapse -> A* -> span counts
+and haplotags; `value` = hets / wall time of the step, inputs already in HBM. Per-kernel rooflines in `kernels`.
+
+`--workload c2` is the solver-only figure of round 1 (BASELINE.json configs[1] shape: resident read x variant
+matrices, N=5000, C=30, S=20), `--workload wgs` the solver on a heavy-tailed block-size mix.
 
 Prints ONE JSON line (rank 0). See DESIGN.md §Measurement for the roofline accounting.
 """
@@ -148,12 +151,181 @@ def wfa_secondary(device_id):
             "parity": {"reads_compared": 4, "bit_identical": bool(ok)}}
 
 
+def so_sha256():
+    import hashlib
+    from hiphase_amd import _ffi
+    return hashlib.sha256(open(_ffi.LIB_PATH, "rb").read()).hexdigest()
+
+
+def measured_traffic(kernel, per_unit_key, units):
+    """HBM bytes per launch from the PMC counters: only a measurement taken on THIS build of the library counts
+    (profiles/round2/traffic.json records the sha256 of the .so it was measured on); otherwise null."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "round2", "traffic.json")))
+        e = tj[kernel]
+        if e["so_sha256"] != so_sha256():
+            return None, "stale: measured on another build of libhiphase_gpu.so"
+        return e[per_unit_key] * units, e["source"]
+    except Exception:
+        return None, None
+
+
+def oracle_block(spec, cfg, d):
+    """The whole path for one block on the CPU oracle, record by record in the reference's order (read_parsing.rs:545-629
+    without fallbacks - the synthetic reads never reach max_edit_distance - then astar_solver and the post-processing).
+    Returns what the parity check compares: solver segments, haplotypes, stats, span counts."""
+    import ctypes as C
+    import numpy as np
+    import oracle_ffi
+    from hiphase_amd import _ffi
+    from hiphase_amd.read_segments import BlockMatrix, ReadSegment
+    from hiphase_amd.wfa_graph import BASE_QUAL, VariantType, WfaJobSpec, make_jobs
+    hets, homs, n = spec.variant_calls, spec.hom_calls, len(spec.variant_calls)
+    pos = [v.position for v in hets]
+    hpos = [v.position for v in homs]
+    import bisect
+    groups = {}
+    for rec in spec.records:
+        first, last = bisect.bisect_left(pos, rec.min_position), bisect.bisect_right(pos, rec.max_position)
+        if last <= first:
+            continue
+        hf, hl = bisect.bisect_left(hpos, rec.min_position), bisect.bisect_right(hpos, rec.max_position)
+        jobs, keep = make_jobs([WfaJobSpec(spec.reference, rec.min_position, rec.max_position + 1, hets[first:last], homs[hf:hl], rec.read_align)])
+        out = _ffi.WfaResult()
+        al = np.full(max(1, last - first), 3, np.uint8)
+        assert d.hpo_wfa_assign(C.byref(jobs[0]), cfg.wfa_prune_distance, cfg.max_edit_distance, C.byref(out), al.ctypes.data) == 0
+        assert out.status == 0
+        alleles, quals = [3] * n, [0] * n
+        for k, i in enumerate(range(first, last)):
+            alleles[i] = int(al[k])
+            if alleles[i] < 2:
+                quals[i] = 2 * BASE_QUAL[VariantType(hets[i].variant_type)]
+        groups.setdefault(rec.qname, []).append(ReadSegment(rec.qname, alleles, quals))
+    segs = []
+    for q, grp in groups.items():
+        col = ReadSegment.collapse(grp)
+        if col.get_num_set() >= 2:
+            segs.append(col)
+    flags = np.asarray([2 if v.variant_type == VariantType.Snv else 0 for v in hets], np.uint8)
+    om = BlockMatrix.from_segments(segs, n, flags)
+    h1, h2, st, _ = oracle_ffi.oracle_solve(om)
+    spans = np.zeros(max(n - 1, 1), np.uint64)
+    v = om.view()
+    assert d.hpo_solution_span_counts(C.byref(v), h1.ctypes.data, h2.ctypes.data, spans.ctypes.data) == 0
+    return [(s_.read_name, s_.start, s_.end, list(s_.alleles), list(s_.quals)) for s_ in segs], h1, h2, st, spans[:n - 1].tolist()
+
+
+def main_path(args, rank, world, local_rank, dist, backend):
+    """Whole-path workload: value = hets / wall time of hp_blockset_solve over resident blocks."""
+    import numpy as np
+    from hiphase_amd import _ffi
+    from hiphase_amd.blocks import BlockSet
+    from hiphase_amd.read_parsing import GlobalRealignmentConfig
+    from hiphase_amd.synth_reads import synth_wgs_like_mix
+    t_gen = time.perf_counter()
+    blocks = synth_wgs_like_mix(20250928 + rank, args.total_hets, max_hets=args.max_block_hets, coverage=float(args.coverage))
+    t_gen = time.perf_counter() - t_gen
+    hets_per_step = sum(len(b.variant_calls) for b in blocks)
+    n_reads = sum(len(b.records) for b in blocks)
+    read_bases = sum(len(r.read_align) for b in blocks for r in b.records)
+    cfg = GlobalRealignmentConfig()
+    t_up = time.perf_counter()
+    bs = BlockSet(blocks, config=cfg, device_id=local_rank)   # layout + upload: sequences resident in HBM from here on
+    t_up = time.perf_counter() - t_up
+
+    def sync_all():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        bs.solve()
+    sync_all()
+    t0 = time.perf_counter()
+    stages = []
+    for _ in range(args.steps):
+        stages.append(bs.solve())          # hp_blockset_solve waits for every stream it uses before it returns
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        from hiphase_amd.shard import max_over_ranks
+        elapsed = max_over_ranks(dist, elapsed, device="cuda" if backend == "nccl" else "cpu")   # timing only; no block data crosses ranks
+    out = None
+    if rank == 0:
+        st = np.mean(np.asarray(stages), axis=0)
+        work = bs.work()
+        res = bs.results()
+        # graph-WFA kernels: algorithmic bytes = read bases + bytes of the traversed graph nodes + 8 B per (node, diagonal)
+        # wave update (SURVEY.md 8d), counted on the device for the reads the compact kernel aligned
+        b_wfa = work["wfa_read_bytes"] + work["wfa_node_bytes"] + 8 * work["wfa_updates"]
+        b_astar = BYTES_PER_CELL * work["astar_cells"]
+        k_wfa = {"kernel": "hp::hp_wfa2_kernel (+ graph build, allele rows)", "bound": "hbm", "kernel_ms": st[6],
+                 "algorithmic_bytes_per_launch": b_wfa, "achieved": b_wfa / (st[6] * 1e-3) / 1e9 if st[6] > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "reads": work["wfa_reads"], "reads_per_s": work["wfa_reads"] / (st[6] * 1e-3) if st[6] > 0 else 0.0,
+                 "bytes_per_read": b_wfa / max(1, work["wfa_reads"]), "wave_updates_per_read": work["wfa_updates"] / max(1, work["wfa_reads"])}
+        k_wfa["frac"] = k_wfa["achieved"] / HBM_PEAK_GBS
+        k_wfa["traffic"], k_wfa["traffic_source"] = measured_traffic("hp_wfa2_kernel", "bytes_per_read", work["wfa_reads"])
+        k_astar = {"kernel": "hp::hp_astar_kernel", "bound": "hbm", "kernel_ms": st[7], "algorithmic_bytes_per_launch": b_astar,
+                   "achieved": b_astar / (st[7] * 1e-3) / 1e9 if st[7] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "cells_per_het": work["astar_cells"] / max(1, hets_per_step)}
+        k_astar["frac"] = k_astar["achieved"] / HBM_PEAK_GBS
+        k_astar["traffic"], k_astar["traffic_source"] = measured_traffic("hp_astar_kernel", "bytes_per_het", hets_per_step)
+        dom = k_wfa if st[6] >= st[7] else k_astar
+        out = {
+            "metric": "het variants phased/sec, whole path (records -> graph-WFA -> rows -> A* -> span counts / haplotags)",
+            "value": hets_per_step * world * args.steps / elapsed,
+            "unit": "hets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u64", "data": "synthetic",
+            "config": {"workload": (f"synthetic read-bearing WGS-like block mix per GPU: {len(blocks)} blocks, {hets_per_step} hets "
+                                    f"(lognormal block sizes, median 15, max {args.max_block_hets}), {n_reads} HiFi-like reads "
+                                    f"({read_bases / max(1, n_reads):.0f} b mean, {args.coverage}x, 0.3% substitutions), het + hom SNV/indel calls"),
+                       "blocks": len(blocks), "hets_per_step_per_gpu": hets_per_step, "reads": n_reads, "read_bases": read_bases,
+                       "min_queue_size": 1000, "queue_increment": 3, "max_edit_distance": 500, "wfa_prune_distance": 500,
+                       "generate_s": round(t_gen, 2), "layout_upload_s": round(t_up, 3),
+                       "pcie_inclusive_hets_per_s": hets_per_step / (t_up + elapsed / args.steps)},
+            "stage_ms": {"graph_wfa": st[0], "fallback_rows_collapse_host": st[1], "astar_pack_upload": st[2], "astar_solve": st[3],
+                         "postprocess_outputs": st[4], "total": st[5], "graph_wfa_kernels": st[6], "astar_kernel": st[7]},
+            "roofline": {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms", "algorithmic_bytes_per_launch")},
+            "kernels": [k_wfa, k_astar],
+        }
+        if not args.no_cpu and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_ffi
+            d = oracle_ffi.oracle()
+            t1 = time.perf_counter()
+            done, ok, n_cmp_reads = 0, True, 0
+            order = sorted(range(len(blocks)), key=lambda i: len(blocks[i].variant_calls))   # small blocks first: a bounded sample
+            hets_cpu = 0
+            for i in order[len(order) // 4:]:    # skip the tiniest quarter, then ascending until the budget is spent
+                segs, h1, h2, stt, spans = oracle_block(blocks[i], cfg, d)
+                r = res[i]
+                ok = ok and [(q, a, b, al, ql) for (q, a, b, al, ql, so) in r.segments if so] == segs
+                ok = ok and (r.haplotype_1 == h1).all() and (r.haplotype_2 == h2).all() and r.statistics == stt and r.span_counts.tolist() == spans
+                hets_cpu += len(blocks[i].variant_calls)
+                n_cmp_reads += len(blocks[i].records)
+                done += 1
+                if time.perf_counter() - t1 > args.cpu_seconds:
+                    break
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": hets_cpu / dt, "unit": "hets/s", "cores": 1, "kind": "port",
+                                   "sample": f"{done} blocks of the same mix ({hets_cpu} hets, {n_cmp_reads} reads) through the whole path on the C++ restatement, single thread, {dt:.1f}s"}
+            out["parity"] = {"blocks_compared": done, "bit_identical": bool(ok), "what": "solver segments, haplotypes, PhaseStats, span counts"}
+        print(json.dumps(out), flush=True)
+    bs.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c2", "wgs"], default="c2")
+    ap.add_argument("--workload", choices=["path", "c2", "wgs"], default="path")
+    ap.add_argument("--total-hets", type=int, default=20000, help="path workload: hets per GPU and step")
+    ap.add_argument("--max-block-hets", type=int, default=2000)
     ap.add_argument("--blocks", type=int, default=6144, help="blocks per GPU (24 resident single-wave workgroups per CU x 256 CUs)")
     ap.add_argument("--hets", type=int, default=5000)
     ap.add_argument("--coverage", type=int, default=30)
@@ -185,6 +357,9 @@ def main():
     lib = _ffi.lib()
     if lib.hp_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libhiphase_gpu.so has no CPU fallback")
+
+    if args.workload == "path":
+        return main_path(args, rank, world, local_rank, dist, backend)
 
     blocks = make_blocks(args, rank)
     hets_per_step = sum(b.n_variants for b in blocks)
@@ -219,21 +394,15 @@ def main():
     # HBM traffic (PMC) cannot be collected from inside this process; the value measured with
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on the same workload is kept under profiles/ and scaled
     # to this launch's hets (see profiles/round1/README.md). null when no measurement matches the workload.
-    traffic, traffic_src = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "round1", "traffic.json")))
-        if tj["workload"] == args.workload and args.hets == 5000 and args.coverage == 30 and args.span == 20:
-            traffic = tj["bytes_per_het"] * hets_per_step
-            traffic_src = tj["source"]
-    except Exception:
-        pass
+    traffic, traffic_src = (measured_traffic("hp_astar_kernel", "bytes_per_het", hets_per_step)
+                            if (args.workload == "c2" and args.hets == 5000 and args.coverage == 30 and args.span == 20) else (None, None))
     out = None
     if rank == 0:
         kavg_ms = sum(kernel_ms) / len(kernel_ms)
         b_alg = BYTES_PER_CELL * cells_per_step
         achieved = b_alg / (kavg_ms * 1e-3) / 1e9
         out = {
-            "metric": "het variants phased/sec (A* MEC solver, synthetic read-allele matrices)",
+            "metric": "het variants phased/sec, A* MEC solver stage only (resident synthetic read-allele matrices)",
             "value": hets_per_step * world * args.steps / elapsed,
             "unit": "hets/s",
             "n_gpus": world,

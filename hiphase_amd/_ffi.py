@@ -251,6 +251,7 @@ EXPORTS = [
     "hp_solve_blocks",
     "hp_blockset_create",
     "hp_blockset_solve",
+    "hp_blockset_work",
     "hp_blockset_destroy",
     "hp_device_count",
     "hp_default_device",
@@ -314,6 +315,8 @@ def lib():
     dll.hp_blockset_create.argtypes = [C.c_size_t, C.POINTER(BlockInput), C.POINTER(BlockParams), C.c_int, C.POINTER(C.c_int)]
     dll.hp_blockset_solve.restype = C.c_int
     dll.hp_blockset_solve.argtypes = [C.c_void_p, C.POINTER(BlockOutput), C.POINTER(C.c_double)]
+    dll.hp_blockset_work.restype = C.c_int
+    dll.hp_blockset_work.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     dll.hp_blockset_destroy.restype = None
     dll.hp_blockset_destroy.argtypes = [C.c_void_p]
     dll.hp_device_count.restype = C.c_int

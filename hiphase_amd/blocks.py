@@ -195,6 +195,12 @@ class BlockSet:
     def results(self):
         return self.o.results(self.m)
 
+    def work(self):
+        """hp_blockset_work of the last solve -> dict"""
+        w = (C.c_uint64 * 8)()
+        _ffi.check(_ffi.lib().hp_blockset_work(self.h, w))
+        return dict(zip(("wfa_reads", "wfa_read_bytes", "wfa_node_bytes", "wfa_updates", "astar_cells", "astar_evals", "hets", "rows"), list(w)))
+
     def close(self):
         if self.h:
             _ffi.lib().hp_blockset_destroy(self.h)

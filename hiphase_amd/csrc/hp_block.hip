@@ -30,6 +30,7 @@ W2Session* w2_session_create();
 void w2_session_destroy(W2Session* s);
 int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id);
 int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles);
+void w2_session_work(const W2Session* s, uint64_t out[4]);
 int wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
                         uint8_t* const* alleles, int device_id);   // hp_wfa.hip
 
@@ -129,6 +130,7 @@ struct hp_blockset {
     std::vector<uint8_t*> allele_ptrs;
     std::vector<hp_wfa_result> wfa_out;
     W2Session* wfa = nullptr;                    // resident graph-WFA inputs (large batches)
+    uint64_t work[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // hp_blockset_work of the last solve
     std::vector<BlockState> st;
     ~hp_blockset() { if (wfa) w2_session_destroy(wfa); }
 };
@@ -408,7 +410,12 @@ extern "C" int hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* 
     for (size_t b = 0; b < bs->n_blocks; ++b) { sum_n += bs->in[b].n_hets; sum_rows += bs->st[b].read_start.size(); sum_j += bs->in[b].n_hets - 1; }
     std::vector<uint8_t> h1((size_t)sum_n), h2((size_t)sum_n);
     std::vector<hp_phase_stats> stats(bs->n_blocks);
-    if ((rc = hp_batch_results(batch, h1.data(), h2.data(), stats.data(), nullptr, nullptr)) != HP_OK) return rc;
+    std::vector<hp_work_counters> ctr(bs->n_blocks);
+    if ((rc = hp_batch_results(batch, h1.data(), h2.data(), stats.data(), ctr.data(), nullptr)) != HP_OK) return rc;
+    for (int i = 0; i < 8; ++i) bs->work[i] = 0;
+    if (bs->wfa) w2_session_work(bs->wfa, bs->work);
+    for (auto& c : ctr) { bs->work[4] += c.cells; bs->work[5] += c.evals; }
+    bs->work[6] = sum_n; bs->work[7] = sum_rows;
     const double t4 = blk_now_ms();
     // ---- 4. span counts and haplotags on the resident matrix ----
     std::vector<uint64_t> spans((size_t)sum_j + 1);
@@ -479,6 +486,12 @@ extern "C" int hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* 
         stage_ms[0] = t1 - t0; stage_ms[1] = t2 - t1; stage_ms[2] = t3 - t2; stage_ms[3] = t4 - t3; stage_ms[4] = t5 - t4; stage_ms[5] = t5 - t0;
         stage_ms[6] = wfa_kernel_ms; stage_ms[7] = astar_kernel_ms;
     }
+    return HP_OK;
+}
+
+extern "C" int hp_blockset_work(const hp_blockset* bs, uint64_t out[8]) {
+    if (!bs || !out) { set_error("null argument"); return HP_ERR_ARG; }
+    for (int i = 0; i < 8; ++i) out[i] = bs->work[i];
     return HP_OK;
 }
 

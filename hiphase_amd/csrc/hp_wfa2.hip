@@ -126,8 +126,9 @@ struct W2Session {
     std::vector<W2Job> dj;
     std::vector<W2Variant> vars;
     uint64_t seq_bytes = 0, alt_off = 0, node_tot = 0, edge_tot = 0, tag_tot = 0, allele_tot = 0;
-    DevBuf d_seq, d_vars, d_jobs, d_nodes, d_edges, d_tags, d_par, d_poff, d_cnt, d_info, d_order, d_sets, d_score, d_status, d_alleles;
+    DevBuf d_seq, d_vars, d_jobs, d_nodes, d_edges, d_tags, d_par, d_poff, d_cnt, d_info, d_order, d_sets, d_score, d_status, d_alleles, d_work;
     double last_prepare_ms = 0.0;
+    uint64_t work_updates = 0, work_node_bytes = 0, work_read_bytes = 0, work_jobs = 0;   // of the last run (compact kernel only)
     int prepare(const hp_wfa_job* jobs_, size_t n_, int device);
     int run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles);
 };
@@ -281,7 +282,7 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
         (rc = d_nodes.alloc((size_t)node_tot * sizeof(W2Node))) || (rc = d_edges.alloc((size_t)edge_tot * 2)) || (rc = d_tags.alloc((size_t)tag_tot * 4)) ||
         (rc = d_par.alloc((size_t)edge_tot * 2)) || (rc = d_poff.alloc(((size_t)node_tot + n) * 4)) || (rc = d_cnt.alloc((size_t)node_tot * 4)) ||
         (rc = d_info.alloc(n * sizeof(W2Info))) || (rc = d_order.alloc(n * 4)) || (rc = d_sets.alloc(n * W2_SET_STRIDE * 4)) ||
-        (rc = d_score.alloc(n * 8)) || (rc = d_status.alloc(n * 4)) || (rc = d_alleles.alloc(std::max<uint64_t>(allele_tot, 16))))
+        (rc = d_score.alloc(n * 8)) || (rc = d_work.alloc(n * 8 + 16)) || (rc = d_status.alloc(n * 4)) || (rc = d_alleles.alloc(std::max<uint64_t>(allele_tot, 16))))
         return rc;
     HP_HIP_CHECK(hipMemcpyAsync(d_seq.p, cx.stage.p, seq_bytes, hipMemcpyHostToDevice, st));
     // the small tables are pageable std::vectors that live until the end of this function; every stream operation that
@@ -314,6 +315,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     std::vector<int32_t> status(n), st0(n, W2_ST_NEED_BIG);
     std::vector<uint64_t> score(n);
     std::vector<uint8_t> al((size_t)std::max<uint64_t>(allele_tot, 1));
+    std::vector<uint32_t> work(n * 2);
     struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{st};
     const double t_stage = t0;
 
@@ -374,11 +376,12 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         for (int k = 0; k < 3; ++k) for (uint32_t id : cls[k]) st0[id] = W2_ST_PENDING;
         HP_HIP_CHECK(hipMemcpyAsync(d_status.p, st0.data(), n * 4, hipMemcpyHostToDevice, st));
         HP_HIP_CHECK(hipMemsetAsync(d_sets.p, 0, n * W2_SET_STRIDE * 4, st));
+        HP_HIP_CHECK(hipMemsetAsync(d_work.p, 0, n * 8, st));
     }
     W2Batch B{};
     B.jobs = d_jobs.as<W2Job>(); B.info = d_info.as<W2Info>(); B.tag_base = tag_base;
     B.nodes = d_nodes.as<W2Node>(); B.edges = d_edges.as<uint16_t>(); B.seq = d_seq.as<uint8_t>(); B.alt_off = alt_off;
-    B.out_sets = d_sets.as<uint32_t>(); B.out_score = d_score.as<uint64_t>(); B.status = d_status.as<int32_t>();
+    B.out_sets = d_sets.as<uint32_t>(); B.out_score = d_score.as<uint64_t>(); B.status = d_status.as<int32_t>(); B.out_work = d_work.as<uint32_t>();
     B.htab = cx.htab.as<uint64_t>(); B.hcap_log2 = W2_HCAP_LOG2; B.gsets = cx.gsets.as<uint32_t>(); B.set_stride = W2_GSET_STRIDE; B.prune_distance = prune_distance; B.max_ed = max_ed;
     HP_HIP_CHECK(hipEventRecord(e2, st));
     uint32_t groups_used[3] = {0, 0, 0};
@@ -399,6 +402,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         W2MapArgs M{};
         M.jobs = d_jobs.as<W2Job>(); M.info = d_info.as<W2Info>(); M.n_jobs = (uint32_t)n; M.tags = d_tags.as<uint32_t>();
         M.out_sets = d_sets.as<uint32_t>(); M.status = d_status.as<int32_t>(); M.alleles = d_alleles.as<uint8_t>();
+        M.nodes = d_nodes.as<W2Node>(); M.out_work = d_work.as<uint32_t>();
         hipLaunchKernelGGL(hp_wfa2_map_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, M);
         HP_HIP_CHECK(hipGetLastError());
     }
@@ -407,6 +411,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     HP_HIP_CHECK(hipMemcpyAsync(status.data(), d_status.p, n * 4, hipMemcpyDeviceToHost, st));
     HP_HIP_CHECK(hipMemcpyAsync(score.data(), d_score.p, n * 8, hipMemcpyDeviceToHost, st));
     if (allele_tot) HP_HIP_CHECK(hipMemcpyAsync(al.data(), d_alleles.p, (size_t)allele_tot, hipMemcpyDeviceToHost, st));
+    HP_HIP_CHECK(hipMemcpyAsync(work.data(), d_work.p, n * 8, hipMemcpyDeviceToHost, st));
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
 #if W2_PROF
     (void)hipDeviceSynchronize();   // flushes the instrumented kernel's printf buffer
@@ -417,6 +422,9 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     g_last_kernel_ms = (double)ms_build + (double)ms_wfa;
     const double t_done = w2_now_ms();
     size_t n_big = big.size();
+    work_updates = work_node_bytes = work_read_bytes = work_jobs = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (status[i] == W2_ST_OK || status[i] == W2_ST_MAX_ED) { work_updates += work[2 * i]; work_node_bytes += work[2 * i + 1]; work_read_bytes += jobs[i].read_len; ++work_jobs; }
     for (size_t i = 0; i < n; ++i) {
         if (status[i] == W2_ST_NEED_BIG) { if (std::find(big.begin(), big.end(), (uint32_t)i) == big.end()) { big.push_back((uint32_t)i); } continue; }
         if (status[i] != W2_ST_OK && status[i] != W2_ST_MAX_ED) { set_error("job %zu: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
@@ -463,5 +471,6 @@ W2Session* w2_session_create() { return new W2Session(); }
 void w2_session_destroy(W2Session* s) { delete s; }
 int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id) { return s->prepare(jobs, n, device_id); }
 int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles) { return s->run(prune_distance, max_ed, out, alleles); }
+void w2_session_work(const W2Session* s, uint64_t out[4]) { out[0] = s->work_jobs; out[1] = s->work_read_bytes; out[2] = s->work_node_bytes; out[3] = s->work_updates; }
 
 }  // namespace hp

@@ -279,6 +279,7 @@ struct W2Batch {
     uint64_t alt_off;          // byte offset of the allele pool inside seq[]
     uint32_t* out_sets;        // [n_jobs][W2_SET_STRIDE]
     uint64_t* out_score;
+    uint32_t* out_work;        // [n_jobs][2]: (node, diagonal) wave updates (the kernel), bytes of the traversed nodes (the map kernel)
     int32_t* status;
     uint64_t* htab;            // [groups][1 << hcap_log2] capped-diagonal hash sets, never cleared (tagged)
     uint32_t* gsets;           // [groups][set_stride] traversed-node sets of the arena slots (consumed off the critical path)

@@ -93,6 +93,15 @@ template <int G> W2DEV uint32_t w2_gor(uint32_t v) {
     for (int m = 16; m < G; m <<= 1) v |= (uint32_t)__shfl_xor((int)v, m);
     return v;
 }
+template <int G> W2DEV uint32_t w2_gsum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+    if (G >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+#pragma unroll
+    for (int m = 16; m < G; m <<= 1) v += (uint32_t)__shfl_xor((int)v, m);
+    return v;
+}
 // the value lane `L` of the group holds (L group-uniform)
 template <int G> W2DEV uint32_t w2_gsel(uint32_t v, uint32_t gl, uint32_t L) { return w2_gor<G>(gl == L ? v : 0u); }
 // Lanes with done == false have matched their first n bytes of node[o..] against read[pos..] and may match up to
@@ -202,6 +211,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
     uint32_t coff = 0;
     int32_t clo = 0, chi = INT32_MIN, cvlo = INT32_MAX, cvhi = INT32_MIN, cflo = INT32_MAX, cfhi = INT32_MIN;   // cluster being formed
     uint32_t lane_far = 0;   // per lane
+    uint32_t lane_upd = 0;   // per lane: (node, diagonal) wave updates of this job (work counter)
 
 #if W2_PROF
     uint64_t w2pc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; uint32_t w2pn[8] = {0,0,0,0,0,0,0,0};
@@ -261,7 +271,8 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (state == S_JOB) {
                 if (status != W2_ST_PENDING) {   // results of the job that just ended
-                    if (gl == 0) { B.status[job] = status; B.out_score[job] = score; }
+                    const uint32_t upd = w2_gsum<G>(lane_upd);
+                    if (gl == 0) { B.status[job] = status; B.out_score[job] = score; B.out_work[(size_t)job * 2] = upd; }
                     if (gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
                     status = W2_ST_PENDING;
                 }
@@ -299,7 +310,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                 pq_node = gl == 0 ? 0u : 0xFFFFu; pq_cnt = 0; pq_c0 = 0; pq_c1 = 0;
                 ed = 0; c = 0; p = 1; lcnt_prev = 0; lcnt_cur = 0; fcnt = 0; top = 0; pp = 0; steps = 0;
                 ph = make_uint4(0xFFFFu, 0, 0, 0);
-                farthest = 0; min_prog = 0; final_found = false; round_live = false; lane_far = 0;
+                farthest = 0; min_prog = 0; final_found = false; round_live = false; lane_far = 0; lane_upd = 0;
                 n_items = 0; item = 0;
                 state = S_NEXT;
                 continue;
@@ -475,6 +486,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
         }
         W2PT(2);
         const bool has = act && (oA >= 0 || oB >= 0 || oC >= 0 || hinj);
+        lane_upd += has ? 1u : 0u;
         W2PC(3, __popcll(__ballot(has)));
         int32_t omax = max(max(oA, oB), max(oC, hinj ? 0 : -1));
         if (!has) omax = 0;
@@ -700,13 +712,21 @@ struct W2MapArgs {
     const uint32_t* out_sets;
     const int32_t* status;
     uint8_t* alleles;
+    const W2Node* nodes;
+    uint32_t* out_work;
 };
 __global__ void __launch_bounds__(64) hp_wfa2_map_kernel(W2MapArgs A) {
     const uint32_t j = blockIdx.x * 64u + threadIdx.x;
     if (j >= A.n_jobs) return;
     const W2Job J = A.jobs[j];
-    w2_map_alleles(A.tags + J.tag_off, A.info[j].n_tags, A.out_sets + (size_t)j * W2_SET_STRIDE, A.status[j] == W2_ST_OK,
-                   A.alleles + J.allele_off, J.n_hets);
+    const uint32_t* set = A.out_sets + (size_t)j * W2_SET_STRIDE;
+    const bool ok = A.status[j] == W2_ST_OK;
+    w2_map_alleles(A.tags + J.tag_off, A.info[j].n_tags, set, ok, A.alleles + J.allele_off, J.n_hets);
+    uint32_t bytes = 0;   // work counter: bytes of the nodes the best alignment(s) traverse
+    if (ok && A.info[j].n_nodes <= 32u * W2_SET_STRIDE)
+        for (uint32_t n = 0; n < A.info[j].n_nodes; ++n)
+            if ((set[n >> 5] >> (n & 31u)) & 1u) bytes += A.nodes[J.node_off + n].len_ref & ~W2_IS_REF;
+    A.out_work[(size_t)j * 2 + 1] = bytes;
 }
 
 }  // namespace hp

@@ -309,6 +309,10 @@ int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const hp_block_pa
 typedef struct hp_blockset hp_blockset;
 hp_blockset* hp_blockset_create(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id, int* status);
 int  hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* stage_ms);
+/* Work counters of the last hp_blockset_solve (the roofline numerators of SURVEY.md 8d): out[0] reads aligned by the compact
+ * graph-WFA kernel, [1] their read bases, [2] bytes of the graph nodes their best alignments traverse, [3] their (node,
+ * diagonal) wave updates; [4] A* cells, [5] A* read evaluations; [6] hets, [7] solver rows. */
+int  hp_blockset_work(const hp_blockset* bs, uint64_t out[8]);
 void hp_blockset_destroy(hp_blockset* bs);
 
 /* ---- misc --------------------------------------------------------------------------------- */
