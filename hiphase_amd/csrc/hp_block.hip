@@ -17,10 +17,16 @@
 #include "hp_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace hp {
@@ -118,21 +124,76 @@ struct BlockState {         // per block, rebuilt by every solve
 
 using namespace hp;
 
-struct hp_blockset {
-    size_t n_blocks = 0;
-    const hp_block_input* in = nullptr;
-    hp_block_params prm{};
-    int device = 0;
-    std::vector<std::vector<RecMeta>> meta;      // per block, per record
-    std::vector<hp_wfa_job> jobs;                // records with overlaps, all blocks
+// The blocks of a set are split into (at most) two chunks, the largest blocks first: the A* search of a large block is a
+// long sequential chain that occupies few wavefronts, so it runs (on a helper thread, on the solver's own streams)
+// WHILE the second chunk's reads go through graph-WFA. Each chunk is one WFA batch and one resident A* batch.
+struct BlockChunk {
+    std::vector<size_t> blocks;                  // indices into hp_blockset::in
+    std::vector<hp_wfa_job> jobs;                // records with overlaps, all blocks of the chunk
     std::vector<uint64_t> job_alloff;            // per job: offset of its allele row in `alleles`
     std::vector<uint8_t> alleles;                // per-het AlleleTypes of every job, back to back
     std::vector<uint8_t*> allele_ptrs;
     std::vector<hp_wfa_result> wfa_out;
     W2Session* wfa = nullptr;                    // resident graph-WFA inputs (large batches)
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // stage times of the last solve
+    uint64_t work[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int rc = HP_OK;
+    std::string err;
+    ~BlockChunk() { if (wfa) w2_session_destroy(wfa); }
+};
+
+// One helper thread per block set, alive as long as the set: its thread-local device-buffer cache (hp_common.h) then
+// survives from one solve to the next (a fresh thread would hipMalloc every A* buffer again and hipFree it at exit).
+struct TailWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> task;
+    bool has_task = false, busy = false, quit = false;
+    void start() {
+        th = std::thread([this]() {
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv.wait(lk, [this]() { return has_task || quit; });
+                if (quit) return;
+                std::function<void()> t = std::move(task);
+                has_task = false;
+                lk.unlock();
+                t();
+                lk.lock();
+                busy = false;
+                cv.notify_all();
+            }
+        });
+    }
+    void post(std::function<void()> t) {
+        std::unique_lock<std::mutex> lk(m);
+        task = std::move(t); has_task = true; busy = true;
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this]() { return !busy; });
+    }
+    ~TailWorker() {
+        if (th.joinable()) {
+            { std::unique_lock<std::mutex> lk(m); quit = true; cv.notify_all(); }
+            th.join();
+        }
+    }
+};
+
+struct hp_blockset {
+    size_t n_blocks = 0;
+    const hp_block_input* in = nullptr;
+    hp_block_params prm{};
+    int device = 0;
+    std::vector<std::vector<RecMeta>> meta;      // per block, per record (job = index into its chunk's jobs)
+    std::vector<uint32_t> chunk_of;              // per block
+    std::vector<std::unique_ptr<BlockChunk>> chunks;
+    std::unique_ptr<TailWorker> worker;          // runs chunk 0's tail while chunk 1's graph-WFA runs on the caller's thread
     uint64_t work[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // hp_blockset_work of the last solve
     std::vector<BlockState> st;
-    ~hp_blockset() { if (wfa) w2_session_destroy(wfa); }
 };
 
 namespace {
@@ -161,7 +222,10 @@ int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, co
     bs->device = device_id < 0 ? hp_default_device() : device_id;
     bs->meta.resize(n_blocks);
     bs->st.resize(n_blocks);
-    uint64_t al_total = 0;
+    bs->chunk_of.assign(n_blocks, 0);
+    const char* mj = std::getenv("HP_WFA2_MIN_JOBS");
+    const size_t min_jobs = mj ? (size_t)std::strtoull(mj, nullptr, 10) : 4608;
+    uint64_t total_records = 0;
     for (size_t b = 0; b < n_blocks; ++b) {
         const hp_block_input& B = in[b];
         if (B.n_hets == 0) { set_error("block %zu has no variants (phaser.rs:415-434 short-circuits those before this path)", b); return HP_ERR_ARG; }
@@ -174,43 +238,67 @@ int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, co
             if (B.records[r].qname_id >= B.n_qnames) { set_error("block %zu record %u: qname_id out of range", b, r); return HP_ERR_ARG; }
             if (B.records[r].max_position < B.records[r].min_position) { set_error("block %zu record %u: assert!(max_position >= min_position) (read_parsing.rs:685)", b, r); return HP_ERR_INVARIANT; }
         }
-        bs->meta[b].assign(B.n_records, RecMeta{});
-        if (!p->global_realignment) continue;
-        bool hs = true, ms = true;
-        for (uint32_t i = 1; i < B.n_hets; ++i) hs = hs && B.hets[i - 1].position <= B.hets[i].position;
-        for (uint32_t i = 1; i < B.n_homs; ++i) ms = ms && B.homs[i - 1].position <= B.homs[i].position;
-        for (uint32_t r = 0; r < B.n_records; ++r) {
-            const hp_block_record& rec = B.records[r];
-            uint32_t f = 0, l = 0, hf = 0, hl = 0;
-            bool contig = true;
-            if (!overlap_range(B.hets, B.n_hets, hs, rec.min_position, rec.max_position, f, l, contig)) continue;   // :703-712: skipped
-            if (!contig) { set_error("block %zu: assert_eq!(num_overlaps, last_overlap - first_overlap) (read_parsing.rs:715)", b); return HP_ERR_INVARIANT; }
-            const bool homs = overlap_range(B.homs, B.n_homs, ms, rec.min_position, rec.max_position, hf, hl, contig);
-            if (rec.min_position < (int64_t)B.ref_base) { set_error("block %zu record %u: alignment starts before the reference buffer", b, r); return HP_ERR_ARG; }
-            hp_wfa_job j{};
-            j.reference = B.reference; j.ref_base = B.ref_base;
-            j.ref_start = (uint64_t)rec.min_position; j.ref_end = (uint64_t)rec.max_position + 1;   // :772-773
-            j.hets = B.hets + f; j.n_hets = l - f;
-            j.homs = homs ? B.homs + hf : nullptr; j.n_homs = homs ? hl - hf : 0;   // first_hom_overlap.unwrap_or(0) with an empty range
-            j.read = rec.read_align; j.read_len = rec.read_len;
-            RecMeta& m = bs->meta[b][r];
-            m.job = (int64_t)bs->jobs.size(); m.first = f; m.last = l;
-            bs->jobs.push_back(j);
-            bs->job_alloff.push_back(al_total);
-            al_total += l - f;
-        }
+        total_records += B.n_records;
     }
-    bs->alleles.assign((size_t)al_total + 1, (uint8_t)HP_ALLELE_NOOVERLAP);
-    bs->allele_ptrs.resize(bs->jobs.size());
-    for (size_t k = 0; k < bs->jobs.size(); ++k) bs->allele_ptrs[k] = bs->alleles.data() + bs->job_alloff[k];
-    bs->wfa_out.resize(bs->jobs.size());
-    // large batches: lay the sequences out and upload them now (resident); small ones take the latency path at solve time
-    const char* mj = std::getenv("HP_WFA2_MIN_JOBS");
-    const size_t min_jobs = mj ? (size_t)std::strtoull(mj, nullptr, 10) : 4608;
-    if (!bs->jobs.empty() && bs->jobs.size() >= min_jobs) {
-        bs->wfa = w2_session_create();
-        const int rc = w2_session_prepare(bs->wfa, bs->jobs.data(), bs->jobs.size(), bs->device);
-        if (rc != HP_OK) return rc;
+    // chunk 0: the largest blocks, about a third of the records (only when both chunks still fill the compact WFA kernel)
+    {
+        std::vector<size_t> by_size(n_blocks);
+        for (size_t b = 0; b < n_blocks; ++b) by_size[b] = b;
+        std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return in[x].n_hets > in[y].n_hets; });
+        const bool split = !std::getenv("HP_BLOCK_NO_PIPELINE") && p->global_realignment && n_blocks >= 8 && total_records >= 3 * (uint64_t)std::max<size_t>(min_jobs, 1);
+        bs->chunks.emplace_back(new BlockChunk());
+        if (split) { bs->chunks.emplace_back(new BlockChunk()); bs->worker.reset(new TailWorker()); bs->worker->start(); }
+        uint64_t acc = 0;
+        for (size_t k = 0; k < n_blocks; ++k) {
+            const size_t b = by_size[k];
+            const uint32_t c = (split && acc * 3 >= total_records) ? 1u : 0u;
+            bs->chunk_of[b] = c;
+            bs->chunks[c]->blocks.push_back(b);
+            acc += in[b].n_records;
+        }
+        for (auto& ch : bs->chunks) std::sort(ch->blocks.begin(), ch->blocks.end());
+    }
+    for (auto& chp : bs->chunks) {
+        BlockChunk& ch = *chp;
+        uint64_t al_total = 0;
+        for (size_t b : ch.blocks) {
+            const hp_block_input& B = in[b];
+            bs->meta[b].assign(B.n_records, RecMeta{});
+            if (!p->global_realignment) continue;
+            bool hs = true, ms = true;
+            for (uint32_t i = 1; i < B.n_hets; ++i) hs = hs && B.hets[i - 1].position <= B.hets[i].position;
+            for (uint32_t i = 1; i < B.n_homs; ++i) ms = ms && B.homs[i - 1].position <= B.homs[i].position;
+            for (uint32_t r = 0; r < B.n_records; ++r) {
+                const hp_block_record& rec = B.records[r];
+                uint32_t f = 0, l = 0, hf = 0, hl = 0;
+                bool contig = true;
+                if (!overlap_range(B.hets, B.n_hets, hs, rec.min_position, rec.max_position, f, l, contig)) continue;   // :703-712: skipped
+                if (!contig) { set_error("block %zu: assert_eq!(num_overlaps, last_overlap - first_overlap) (read_parsing.rs:715)", b); return HP_ERR_INVARIANT; }
+                const bool homs = overlap_range(B.homs, B.n_homs, ms, rec.min_position, rec.max_position, hf, hl, contig);
+                if (rec.min_position < (int64_t)B.ref_base) { set_error("block %zu record %u: alignment starts before the reference buffer", b, r); return HP_ERR_ARG; }
+                hp_wfa_job j{};
+                j.reference = B.reference; j.ref_base = B.ref_base;
+                j.ref_start = (uint64_t)rec.min_position; j.ref_end = (uint64_t)rec.max_position + 1;   // :772-773
+                j.hets = B.hets + f; j.n_hets = l - f;
+                j.homs = homs ? B.homs + hf : nullptr; j.n_homs = homs ? hl - hf : 0;   // first_hom_overlap.unwrap_or(0) with an empty range
+                j.read = rec.read_align; j.read_len = rec.read_len;
+                RecMeta& m = bs->meta[b][r];
+                m.job = (int64_t)ch.jobs.size(); m.first = f; m.last = l;
+                ch.jobs.push_back(j);
+                ch.job_alloff.push_back(al_total);
+                al_total += l - f;
+            }
+        }
+        ch.alleles.assign((size_t)al_total + 1, (uint8_t)HP_ALLELE_NOOVERLAP);
+        ch.allele_ptrs.resize(ch.jobs.size());
+        for (size_t k = 0; k < ch.jobs.size(); ++k) ch.allele_ptrs[k] = ch.alleles.data() + ch.job_alloff[k];
+        ch.wfa_out.resize(ch.jobs.size());
+        // large batches: lay the sequences out and upload them now (resident); small ones take the latency path at solve time
+        if (!ch.jobs.empty() && ch.jobs.size() >= min_jobs) {
+            ch.wfa = w2_session_create();
+            const int rc = w2_session_prepare(ch.wfa, ch.jobs.data(), ch.jobs.size(), bs->device);
+            if (rc != HP_OK) return rc;
+        }
     }
     return HP_OK;
 }
@@ -218,6 +306,7 @@ int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, co
 // load_full_read_segments' tail for one block (read_parsing.rs:546-629) once every record's WFA outcome is known:
 // fallback to local re-alignment, the global_disabled switch in BAM order, qualities, ReadSegment::new, collapse, split
 int assemble_block(hp_blockset* bs, size_t b) {
+    const BlockChunk& CH = *bs->chunks[bs->chunk_of[b]];
     const hp_block_input& B = bs->in[b];
     const hp_block_params& P = bs->prm;
     BlockState& S = bs->st[b];
@@ -255,7 +344,7 @@ int assemble_block(hp_blockset* bs, size_t b) {
         if ((rc = solve_local(all)) != HP_OK) return rc;
     } else {
         std::vector<uint32_t> failed;
-        for (uint32_t i = 0; i < R; ++i) if (meta[i].job >= 0 && bs->wfa_out[(size_t)meta[i].job].status == HP_WFA_MAX_ED) failed.push_back(i);
+        for (uint32_t i = 0; i < R; ++i) if (meta[i].job >= 0 && CH.wfa_out[(size_t)meta[i].job].status == HP_WFA_MAX_ED) failed.push_back(i);
         if ((rc = solve_local(failed)) != HP_OK) return rc;
     }
     // per read name: the segments of its records, in BAM order
@@ -278,7 +367,7 @@ int assemble_block(hp_blockset* bs, size_t b) {
             local_aligned = 1.0;
         } else {
             if (m.job < 0) { S.skipped_reads += 1; continue; }   // no overlaps: flagged skipped (read_parsing.rs:703-712, :602-605)
-            const hp_wfa_result& w = bs->wfa_out[(size_t)m.job];
+            const hp_wfa_result& w = CH.wfa_out[(size_t)m.job];
             if (global_disabled || w.status == HP_WFA_MAX_ED) {
                 if (local_slot[idx] < 0) {   // the switch just flipped: everything from here on is local (read_parsing.rs:556-559)
                     std::vector<uint32_t> rest;
@@ -292,7 +381,7 @@ int assemble_block(hp_blockset* bs, size_t b) {
                 local_aligned = 1.0;
             } else {
                 const uint32_t n = m.last - m.first;
-                const uint8_t* a = bs->alleles.data() + bs->job_alloff[(size_t)m.job];
+                const uint8_t* a = CH.alleles.data() + CH.job_alloff[(size_t)m.job];
                 row_a.assign(a, a + n);
                 row_q.assign(n, 0);
                 for (uint32_t i = 0; i < n; ++i)
@@ -368,63 +457,99 @@ extern "C" hp_blockset* hp_blockset_create(size_t n_blocks, const hp_block_input
 
 extern "C" void hp_blockset_destroy(hp_blockset* bs) { delete bs; }
 
-extern "C" int hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* stage_ms) {
-    if (!bs || !out) { set_error("null argument"); return HP_ERR_ARG; }
+namespace {
+
+// graph-WFA for every record with overlaps of one chunk (one device batch); runs on the calling thread
+int chunk_wfa(hp_blockset* bs, BlockChunk& ch) {
     const double t0 = blk_now_ms();
-    double wfa_kernel_ms = 0.0, astar_kernel_ms = 0.0;
-    int rc;
-    // ---- 1. graph-WFA for every record with overlaps, all blocks in one batch ----
-    if (!bs->jobs.empty()) {
-        if (bs->wfa) rc = w2_session_run(bs->wfa, bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, bs->wfa_out.data(), bs->allele_ptrs.data());
-        else rc = hp_wfa_assign_batch(bs->jobs.data(), bs->jobs.size(), bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, bs->wfa_out.data(),
-                                      bs->allele_ptrs.data(), bs->device);
+    ch.ms[6] = 0.0;
+    if (!ch.jobs.empty()) {
+        int rc;
+        if (ch.wfa) rc = w2_session_run(ch.wfa, bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(), ch.allele_ptrs.data());
+        else rc = hp_wfa_assign_batch(ch.jobs.data(), ch.jobs.size(), bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(),
+                                      ch.allele_ptrs.data(), bs->device);
         if (rc != HP_OK) return rc;
-        wfa_kernel_ms = hp_last_kernel_ms();
+        ch.ms[6] = hp_last_kernel_ms();
     }
+    ch.ms[0] = blk_now_ms() - t0;
+    return HP_OK;
+}
+
+// everything after the WFA for the blocks of one chunk: fallback / replay / rows / collapse (host threads over blocks),
+// A* (one resident batch), span counts and haplotags, outputs. May run on a helper thread.
+int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
     const double t1 = blk_now_ms();
-    // ---- 2. fallback, replay, rows, collapse (host; a few bytes per record) ----
-    for (size_t b = 0; b < bs->n_blocks; ++b)
-        if ((rc = assemble_block(bs, b)) != HP_OK) return rc;
+    int rc = HP_OK;
+    {
+        unsigned nt = std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
+        nt = (unsigned)std::min<size_t>(nt, ch.blocks.size());
+        std::vector<size_t> order(ch.blocks);
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return bs->in[x].n_records > bs->in[y].n_records; });
+        std::atomic<size_t> next{0};
+        std::atomic<int> first_rc{HP_OK};
+        std::vector<std::string> errs(std::max(1u, nt));
+        auto work = [&](unsigned t) {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= order.size() || first_rc.load() != HP_OK) return;
+                const int r = assemble_block(bs, order[k]);
+                if (r != HP_OK) { int exp = HP_OK; if (first_rc.compare_exchange_strong(exp, r)) errs[t] = hp_last_error(); return; }
+            }
+        };
+        if (nt <= 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+            for (auto& x : th) x.join();
+        }
+        if (first_rc.load() != HP_OK) {
+            for (auto& e : errs) if (!e.empty()) { set_error("%s", e.c_str()); break; }
+            return first_rc.load();
+        }
+    }
     const double t2 = blk_now_ms();
-    // ---- 3. A* over all blocks ----
-    std::vector<hp_block_view> views(bs->n_blocks);
-    for (size_t b = 0; b < bs->n_blocks; ++b) {
+    // ---- A* over the chunk's blocks ----
+    const size_t nb = ch.blocks.size();
+    std::vector<hp_block_view> views(nb);
+    for (size_t k = 0; k < nb; ++k) {
+        const size_t b = ch.blocks[k];
         const BlockState& S = bs->st[b];
         hp_block_view v{};
         v.n_variants = bs->in[b].n_hets;
         v.n_reads = (uint32_t)S.read_start.size();
         v.read_start = S.read_start.data(); v.read_end = S.read_end.data(); v.row_off = S.row_off.data();
         v.alleles_2bit = S.alleles_2bit.data(); v.quals = S.quals.data(); v.var_flags = S.var_flags.data();
-        views[b] = v;
+        views[k] = v;
     }
     hp_astar_params ap = bs->prm.astar;
     int st = HP_OK;
-    hp_batch* batch = hp_batch_create(bs->n_blocks, views.data(), &ap, bs->device, &st);
+    hp_batch* batch = hp_batch_create(nb, views.data(), &ap, bs->device, &st);
     if (!batch) return st != HP_OK ? st : HP_ERR_HIP;
     struct BatchGuard { hp_batch* b; ~BatchGuard() { hp_batch_destroy(b); } } guard{batch};
     const double t3 = blk_now_ms();
     float kms = 0.f;
     if ((rc = hp_batch_solve(batch, nullptr, &kms)) != HP_OK) return rc;
-    astar_kernel_ms = kms;
     uint64_t sum_n = 0, sum_rows = 0, sum_j = 0;
-    for (size_t b = 0; b < bs->n_blocks; ++b) { sum_n += bs->in[b].n_hets; sum_rows += bs->st[b].read_start.size(); sum_j += bs->in[b].n_hets - 1; }
+    for (size_t b : ch.blocks) { sum_n += bs->in[b].n_hets; sum_rows += bs->st[b].read_start.size(); sum_j += bs->in[b].n_hets - 1; }
     std::vector<uint8_t> h1((size_t)sum_n), h2((size_t)sum_n);
-    std::vector<hp_phase_stats> stats(bs->n_blocks);
-    std::vector<hp_work_counters> ctr(bs->n_blocks);
+    std::vector<hp_phase_stats> stats(nb);
+    std::vector<hp_work_counters> ctr(nb);
     if ((rc = hp_batch_results(batch, h1.data(), h2.data(), stats.data(), ctr.data(), nullptr)) != HP_OK) return rc;
-    for (int i = 0; i < 8; ++i) bs->work[i] = 0;
-    if (bs->wfa) w2_session_work(bs->wfa, bs->work);
-    for (auto& c : ctr) { bs->work[4] += c.cells; bs->work[5] += c.evals; }
-    bs->work[6] = sum_n; bs->work[7] = sum_rows;
+    for (int i = 0; i < 8; ++i) ch.work[i] = 0;
+    if (ch.wfa) w2_session_work(ch.wfa, ch.work);
+    for (auto& c : ctr) { ch.work[4] += c.cells; ch.work[5] += c.evals; }
+    ch.work[6] = sum_n; ch.work[7] = sum_rows;
     const double t4 = blk_now_ms();
-    // ---- 4. span counts and haplotags on the resident matrix ----
+    // ---- span counts and haplotags on the resident matrix ----
     std::vector<uint64_t> spans((size_t)sum_j + 1);
     std::vector<uint8_t> tag((size_t)sum_rows + 1);
     std::vector<uint32_t> fh((size_t)sum_rows + 1);
     if ((rc = hp_batch_postprocess(batch, spans.data(), tag.data(), fh.data())) != HP_OK) return rc;
-    // ---- 5. outputs ----
+    // ---- outputs ----
     uint64_t on = 0, orow = 0, oj = 0;
-    for (size_t b = 0; b < bs->n_blocks; ++b) {
+    for (size_t kb = 0; kb < nb; ++kb) {
+        const size_t b = ch.blocks[kb];
         const hp_block_input& B = bs->in[b];
         const BlockState& S = bs->st[b];
         hp_block_output& O = out[b];
@@ -433,7 +558,7 @@ extern "C" int hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* 
         const uint8_t* H2 = h2.data() + on;
         if (O.h1) std::memcpy(O.h1, H1, N);
         if (O.h2) std::memcpy(O.h2, H2, N);
-        O.stats = stats[b];
+        O.stats = stats[kb];
         if (O.span_counts && N > 1) std::memcpy(O.span_counts, spans.data() + oj, (size_t)(N - 1) * 8);
         O.n_segments = (uint32_t)S.segs.size();
         O.n_solver = (uint32_t)S.solver_rows.size();
@@ -482,9 +607,39 @@ extern "C" int hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* 
         on += N; orow += S.read_start.size(); oj += N - 1;
     }
     const double t5 = blk_now_ms();
+    ch.ms[1] = t2 - t1; ch.ms[2] = t3 - t2; ch.ms[3] = t4 - t3; ch.ms[4] = t5 - t4; ch.ms[7] = kms;
+    return HP_OK;
+}
+
+}  // namespace
+
+extern "C" int hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* stage_ms) {
+    if (!bs || !out) { set_error("null argument"); return HP_ERR_ARG; }
+    const double t0 = blk_now_ms();
+    int rc = HP_OK;
+    // chunk 0's graph-WFA, then its tail (rows, A*, post) on a helper thread while chunk 1's graph-WFA runs here
+    bool posted = false;
+    for (size_t c = 0; c < bs->chunks.size() && rc == HP_OK; ++c) {
+        BlockChunk& ch = *bs->chunks[c];
+        ch.rc = HP_OK; ch.err.clear();
+        if ((rc = chunk_wfa(bs, ch)) != HP_OK) break;
+        if (c + 1 < bs->chunks.size() && bs->worker) {
+            BlockChunk* chp = &ch;
+            bs->worker->post([bs, chp, out]() {
+                chp->rc = chunk_tail(bs, *chp, out);
+                if (chp->rc != HP_OK) chp->err = hp_last_error();
+            });
+            posted = true;
+        } else rc = chunk_tail(bs, ch, out);
+    }
+    if (posted) bs->worker->wait();
+    if (rc != HP_OK) return rc;
+    for (auto& ch : bs->chunks)
+        if (ch->rc != HP_OK) { set_error("%s", ch->err.c_str()); return ch->rc; }
+    for (int i = 0; i < 8; ++i) { bs->work[i] = 0; for (auto& ch : bs->chunks) bs->work[i] += ch->work[i]; }
     if (stage_ms) {
-        stage_ms[0] = t1 - t0; stage_ms[1] = t2 - t1; stage_ms[2] = t3 - t2; stage_ms[3] = t4 - t3; stage_ms[4] = t5 - t4; stage_ms[5] = t5 - t0;
-        stage_ms[6] = wfa_kernel_ms; stage_ms[7] = astar_kernel_ms;
+        for (int i = 0; i < 8; ++i) { stage_ms[i] = 0.0; for (auto& ch : bs->chunks) stage_ms[i] += ch->ms[i]; }
+        stage_ms[5] = blk_now_ms() - t0;   // wall time of the call; the stage sums exceed it by what the two chunks overlap
     }
     return HP_OK;
 }
