@@ -1352,6 +1352,7 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
 // the spill-free 4 on every workload tried (throughput batches, a single block, the heavy-tailed mix).
 template <bool SUB_LDS, int OCC, int TILES>
 __global__ void __launch_bounds__(64, OCC) hp_heur_seg_kernel(SegBatchDev S) {
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t slot = blockIdx.x, G = gridDim.x;
     for (uint32_t round = 0;; ++round) {
         const uint32_t base = round * G;
@@ -1577,6 +1578,9 @@ __global__ void __launch_bounds__(256) hp_build_ctab_kernel(CtabDev T) {
 // only used when some block of the launch has more than 64 candidate rows per variant)
 template <bool SUB_LDS, int OCC, bool PROF, int TILES>
 __global__ void __launch_bounds__(64, OCC) hp_astar_kernel(BatchDev B) {
+    // A search wavefront is one long dependent chain; when it shares a SIMD with throughput kernels of another stream
+    // (the next chunk's graph-WFA, hp_block.hip) it should win the issue arbitration: those have slack, it has none.
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t slot = blockIdx.x;
     const uint32_t G = gridDim.x;
     // Static "snake" assignment over the LPT-sorted work list: workgroup w takes ranks w, 2G-1-w, 2G+w, ...

@@ -124,9 +124,11 @@ struct BlockState {         // per block, rebuilt by every solve
 
 using namespace hp;
 
-// The blocks of a set are split into (at most) two chunks, the largest blocks first: the A* search of a large block is a
-// long sequential chain that occupies few wavefronts, so it runs (on a helper thread, on the solver's own streams)
-// WHILE the second chunk's reads go through graph-WFA. Each chunk is one WFA batch and one resident A* batch.
+// A set is one chunk (one graph-WFA batch, one resident A* batch) unless HP_BLOCK_PIPELINE=1 splits it in two, the
+// largest blocks first, so that the first chunk's rows + A* + post (on a helper thread, on the solver's own streams) run
+// WHILE the second chunk's reads go through graph-WFA. Measured on the default bench workload (137 blocks, 42 k reads):
+// 45.6 ms per step pipelined vs 42.3 ms not - the search wavefronts share their SIMDs with the WFA wavefronts and slow
+// down by about what the overlap saves, and two half-size WFA launches pay two tails. Kept for multi-step callers.
 struct BlockChunk {
     std::vector<size_t> blocks;                  // indices into hp_blockset::in
     std::vector<hp_wfa_job> jobs;                // records with overlaps, all blocks of the chunk
@@ -245,7 +247,8 @@ int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, co
         std::vector<size_t> by_size(n_blocks);
         for (size_t b = 0; b < n_blocks; ++b) by_size[b] = b;
         std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return in[x].n_hets > in[y].n_hets; });
-        const bool split = !std::getenv("HP_BLOCK_NO_PIPELINE") && p->global_realignment && n_blocks >= 8 && total_records >= 3 * (uint64_t)std::max<size_t>(min_jobs, 1);
+        const char* pe = std::getenv("HP_BLOCK_PIPELINE");
+        const bool split = pe && pe[0] == '1' && p->global_realignment && n_blocks >= 8 && total_records >= 3 * (uint64_t)std::max<size_t>(min_jobs, 1);
         bs->chunks.emplace_back(new BlockChunk());
         if (split) { bs->chunks.emplace_back(new BlockChunk()); bs->worker.reset(new TailWorker()); bs->worker->start(); }
         uint64_t acc = 0;

@@ -65,10 +65,17 @@ struct W2Context {
     DevBuf gsets;            // [groups][W2_SET_STRIDE_MAX] the arena slots' traversed-node sets
     uint32_t htab_groups = 0;
     uint32_t tag_next = 0;   // tags handed out so far (tag 0 = empty)
+    DevBuf qhead;            // work-queue heads of the class launches
+    hipStream_t cstream[3] = {nullptr, nullptr, nullptr};   // one stream per graph-size class: the three launches overlap
+    hipEvent_t cfork = nullptr, cjoin[3] = {nullptr, nullptr, nullptr};
     PinBuf stage;            // upload staging: seq bytes, then the tables
     PinBuf down;             // download staging
     hipStream_t stream = nullptr;
-    ~W2Context() { if (stream) (void)hipStreamDestroy(stream); }
+    ~W2Context() {
+        if (stream) (void)hipStreamDestroy(stream);
+        for (int k = 0; k < 3; ++k) { if (cstream[k]) (void)hipStreamDestroy(cstream[k]); if (cjoin[k]) (void)hipEventDestroy(cjoin[k]); }
+        if (cfork) (void)hipEventDestroy(cfork);
+    }
 };
 thread_local W2Context g_w2;
 
@@ -95,6 +102,7 @@ void merge_ranges(std::vector<std::pair<const uint8_t*, uint64_t>>& iv, std::vec
         else out.push_back({v.first, v.first + v.second, 0});
     }
 }
+// one region of `max_groups` groups per class in htab / gsets: the class launches run concurrently
 template <int G, int W> int w2_launch(const W2Batch& B, uint32_t n_items, int n_cu, uint32_t max_groups, hipStream_t st, uint32_t* groups_used) {
     using C = W2Cfg<W>;
     constexpr uint32_t NG = 64 / G;
@@ -125,6 +133,7 @@ struct W2Session {
     int device_id = -1;
     std::vector<W2Job> dj;
     std::vector<W2Variant> vars;
+    std::vector<uint32_t> len_order;   // job ids, longest read first (stable)
     uint64_t seq_bytes = 0, alt_off = 0, node_tot = 0, edge_tot = 0, tag_tot = 0, allele_tot = 0;
     DevBuf d_seq, d_vars, d_jobs, d_nodes, d_edges, d_tags, d_par, d_poff, d_cnt, d_info, d_order, d_sets, d_score, d_status, d_alleles, d_work;
     double last_prepare_ms = 0.0;
@@ -228,6 +237,9 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
         d.allele_off = (uint32_t)allele_tot; allele_tot += j.n_hets;
     }
     seq_bytes += 256;   // the 32-byte compares may run past the last base of the last read
+    len_order.resize(n);
+    std::iota(len_order.begin(), len_order.end(), 0u);
+    std::stable_sort(len_order.begin(), len_order.end(), [&](uint32_t a, uint32_t b) { return jobs[a].read_len > jobs[b].read_len; });
 
 
     // ---- from here on a GPU is mandatory (no CPU fallback) -------------------------------------------------------------
@@ -316,7 +328,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     std::vector<uint64_t> score(n);
     std::vector<uint8_t> al((size_t)std::max<uint64_t>(allele_tot, 1));
     std::vector<uint32_t> work(n * 2);
-    struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{st};
+    struct StreamDrain { hipStream_t s; W2Context* c; ~StreamDrain() { for (int k = 0; k < 3; ++k) if (c->cstream[k]) (void)hipStreamSynchronize(c->cstream[k]); (void)hipStreamSynchronize(s); } } drain{st, &cx};
     const double t_stage = t0;
 
     // ---- 3. graphs on the device ----------------------------------------------------------------------------------------
@@ -341,34 +353,40 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
 
     // ---- 4. classes by graph size, longest read first ----------------------------------------------------------------------
     std::vector<uint32_t> cls[3], big;
-    for (size_t i = 0; i < n; ++i) {
-        if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %zu", i); return HP_ERR_INVARIANT; }
-        if (info[i].status != W2B_OK || jobs[i].read_len >= (uint32_t)W2_DIAG_LIM) { big.push_back((uint32_t)i); continue; }
+    for (uint32_t i : len_order) {   // classes inherit the longest-read-first order
+        if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %u", i); return HP_ERR_INVARIANT; }
+        if (info[i].status != W2B_OK || jobs[i].read_len >= (uint32_t)W2_DIAG_LIM) { big.push_back(i); continue; }
         const uint32_t nn = info[i].n_nodes, ne = info[i].n_edges;
-        if (nn <= (uint32_t)W2Cfg<2>::MAXN && ne <= (uint32_t)W2Cfg<2>::MAXE) cls[0].push_back((uint32_t)i);
-        else if (nn <= (uint32_t)W2Cfg<4>::MAXN && ne <= (uint32_t)W2Cfg<4>::MAXE) cls[1].push_back((uint32_t)i);
-        else if (nn <= (uint32_t)W2Cfg<8>::MAXN && ne <= (uint32_t)W2Cfg<8>::MAXE) cls[2].push_back((uint32_t)i);
-        else big.push_back((uint32_t)i);
+        if (nn <= (uint32_t)W2Cfg<2>::MAXN && ne <= (uint32_t)W2Cfg<2>::MAXE) cls[0].push_back(i);
+        else if (nn <= (uint32_t)W2Cfg<4>::MAXN && ne <= (uint32_t)W2Cfg<4>::MAXE) cls[1].push_back(i);
+        else if (nn <= (uint32_t)W2Cfg<8>::MAXN && ne <= (uint32_t)W2Cfg<8>::MAXE) cls[2].push_back(i);
+        else big.push_back(i);
     }
     order.reserve(n);
     size_t cls_off[3];
     for (int k = 0; k < 3; ++k) {
-        std::stable_sort(cls[k].begin(), cls[k].end(), [&](uint32_t a, uint32_t b) { return jobs[a].read_len > jobs[b].read_len; });
         cls_off[k] = order.size();
         order.insert(order.end(), cls[k].begin(), cls[k].end());
     }
     // capped-diagonal hash sets: one per resident group, kept (and never cleared) across calls
-    const uint32_t max_groups = (uint32_t)n_cu * 64u;   // up to 8 resident workgroups of 8 groups per CU
+    const uint32_t max_groups = (uint32_t)n_cu * 64u;   // per class: up to 8 resident workgroups of 8 groups per CU
     if (cx.htab_groups < max_groups) {
-        if ((rc = cx.htab.alloc(((size_t)max_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
-        if ((rc = cx.gsets.alloc((size_t)max_groups * W2_GSET_STRIDE * 4)) != HP_OK) return rc;
-        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)max_groups << W2_HCAP_LOG2) * 8, st));
+        if ((rc = cx.htab.alloc(((size_t)3 * max_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
+        if ((rc = cx.gsets.alloc((size_t)3 * max_groups * W2_GSET_STRIDE * 4)) != HP_OK) return rc;
+        if ((rc = cx.qhead.alloc(256)) != HP_OK) return rc;
+        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)3 * max_groups << W2_HCAP_LOG2) * 8, st));
         cx.htab_groups = max_groups; cx.tag_next = 0;
     }
     if ((uint64_t)cx.tag_next + n + 2 >= 0xFFFFFFF0ull) {
-        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)cx.htab_groups << W2_HCAP_LOG2) * 8, st));
+        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)3 * cx.htab_groups << W2_HCAP_LOG2) * 8, st));
         cx.tag_next = 0;
     }
+    for (int k = 0; k < 3; ++k) {
+        if (!cx.cstream[k]) HP_HIP_CHECK(hipStreamCreateWithFlags(&cx.cstream[k], hipStreamNonBlocking));
+        if (!cx.cjoin[k]) HP_HIP_CHECK(hipEventCreateWithFlags(&cx.cjoin[k], hipEventDisableTiming));
+    }
+    if (!cx.cfork) HP_HIP_CHECK(hipEventCreateWithFlags(&cx.cfork, hipEventDisableTiming));
+    HP_HIP_CHECK(hipMemsetAsync(cx.qhead.p, 0, 256, st));
     const uint32_t tag_base = cx.tag_next;
     cx.tag_next += (uint32_t)n + 1;
     if (!order.empty()) HP_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
@@ -384,19 +402,27 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     B.out_sets = d_sets.as<uint32_t>(); B.out_score = d_score.as<uint64_t>(); B.status = d_status.as<int32_t>(); B.out_work = d_work.as<uint32_t>();
     B.htab = cx.htab.as<uint64_t>(); B.hcap_log2 = W2_HCAP_LOG2; B.gsets = cx.gsets.as<uint32_t>(); B.set_stride = W2_GSET_STRIDE; B.prune_distance = prune_distance; B.max_ed = max_ed;
     HP_HIP_CHECK(hipEventRecord(e2, st));
+    HP_HIP_CHECK(hipEventRecord(cx.cfork, st));
     uint32_t groups_used[3] = {0, 0, 0};
     for (int k = 0; k < 3; ++k) {
         if (cls[k].empty()) continue;
+        hipStream_t cs = cx.cstream[k];
+        HP_HIP_CHECK(hipStreamWaitEvent(cs, cx.cfork, 0));
         B.order = d_order.as<uint32_t>() + cls_off[k];
         B.n_items = (uint32_t)cls[k].size();
+        B.next = cx.qhead.as<uint32_t>() + 16 * k;
+        B.htab = cx.htab.as<uint64_t>() + (((size_t)k * cx.htab_groups) << W2_HCAP_LOG2);
+        B.gsets = cx.gsets.as<uint32_t>() + (size_t)k * cx.htab_groups * W2_GSET_STRIDE;
         const char* genv = std::getenv("HP_WFA2_G");   // experiment: lanes per read for the middle class
         const int gsel = genv ? std::atoi(genv) : 8;
-        if (k == 0) rc = w2_launch<8, 2>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k]);
-        else if (k == 1) rc = gsel == 16 ? w2_launch<16, 4>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k])
-                            : gsel == 32 ? w2_launch<32, 4>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k])
-                                         : w2_launch<8, 4>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k]);
-        else rc = w2_launch<16, 8>(B, B.n_items, n_cu, cx.htab_groups, st, &groups_used[k]);
+        if (k == 0) rc = w2_launch<8, 2>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k]);
+        else if (k == 1) rc = gsel == 16 ? w2_launch<16, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k])
+                            : gsel == 32 ? w2_launch<32, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k])
+                                         : w2_launch<8, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k]);
+        else rc = w2_launch<16, 8>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k]);
         if (rc != HP_OK) return rc;
+        HP_HIP_CHECK(hipEventRecord(cx.cjoin[k], cs));
+        HP_HIP_CHECK(hipStreamWaitEvent(st, cx.cjoin[k], 0));
     }
     {
         W2MapArgs M{};

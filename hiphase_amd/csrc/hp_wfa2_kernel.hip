@@ -30,6 +30,9 @@ namespace hp {
 #ifndef W2_PROF
 #define W2_PROF 0
 #endif
+#ifndef W2_QUEUE_ASM
+#define W2_QUEUE_ASM 0
+#endif
 #if W2_PROF
 #define W2PT(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); w2pc[i] += t_ - w2tl; w2tl = t_; } while (0)
 #define W2PC(i, v) do { w2pn[i] += (v); } while (0)
@@ -180,7 +183,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
     uint32_t* outset = reinterpret_cast<uint32_t*>(R + C::O_MISC);
     int2* srcs = reinterpret_cast<int2*>(R + C::O_SRC);
 
-    const uint32_t TG = gridDim.x * NG, slot = blockIdx.x * NG + gid;
+    const uint32_t slot = blockIdx.x * NG + gid;
     uint64_t* htab = B.htab + ((size_t)slot << B.hcap_log2);
     uint32_t* gs = B.gsets + (size_t)slot * B.set_stride;           // [(parity * SLOTS + s) * W]
     const uint32_t hmask = (1u << B.hcap_log2) - 1u;
@@ -276,7 +279,24 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                     if (gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
                     status = W2_ST_PENDING;
                 }
-                const uint32_t k = jround * TG + ((jround & 1u) ? (TG - 1u - slot) : slot);
+                // dynamic work queue: the group's first lane pulls the next index. The instruction is written out by hand:
+                // hipcc's atomic optimiser + structuriser turned an atomicAdd under a one-lane branch inside a persistent
+                // loop into a wavefront that never came back (round 1, DESIGN.md bring-up notes)
+#if W2_QUEUE_ASM
+                uint32_t mine = 0;
+                if (gl == 0) {
+                    uint32_t* qp = B.next;
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of hipcc parses kernel bodies too; gfx950 assembly means nothing to it)
+                    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(mine) : "v"(qp), "v"(1u) : "memory");
+#else
+                    (void)qp;
+#endif
+                }
+#else
+                // every lane of the group takes part (lane 0 adds one, the others nothing): no one-lane branch around the atomic
+                const uint32_t mine = atomicAdd(B.next, gl == 0 ? 1u : 0u);
+#endif
+                const uint32_t k = w2_gsel<G>(mine, gl, 0u);
                 jround++;
                 if (k >= B.n_items) { state = S_DONE; break; }
                 job = B.order[k];

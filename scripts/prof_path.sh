@@ -1,0 +1,25 @@
+#!/bin/bash
+# rocprofv3 kernel trace (+ optional PMC passes) of the default whole-path bench; summaries go to gpurun_out/prof_path_<tag>
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_path_$1; shift
+mkdir -p $OUT
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python bench.py --no-cpu "$@" > $OUT/bench.json 2> $OUT/trace.err
+if [ -n "$PMC" ]; then
+  rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/pmc1 -o pmc1 -- python bench.py --no-cpu "$@" > /dev/null 2> $OUT/pmc1.err
+  rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- python bench.py --no-cpu "$@" > /dev/null 2> $OUT/pmc3.err
+  rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc4 -o pmc4 -- python bench.py --no-cpu "$@" > /dev/null 2> $OUT/pmc4.err
+fi
+tail -c 1500 $OUT/bench.json; echo
+for f in $(find $OUT -name "*kernel_stats.csv"); do cat $f; done
+for f in $(find $OUT -name "*counter_collection.csv"); do python - "$f" <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(float); n = collections.Counter()
+for row in csv.DictReader(open(sys.argv[1])):
+    k = row.get('Kernel_Name','')
+    name = 'wfa2' if 'hp_wfa2_kernel' in k else ('astar' if 'hp_astar_kernel' in k else None)
+    if name:
+        agg[(name, row['Counter_Name'])] += float(row['Counter_Value']); n[(name, row['Counter_Name'])] += 1
+for k in sorted(agg): print(f"{k[0]:6s} {k[1]:24s} total={agg[k]:.6g} dispatches={n[k]}")
+PY
+done
