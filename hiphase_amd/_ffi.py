@@ -257,6 +257,7 @@ EXPORTS = [
     "hp_default_device",
     "hp_last_error",
     "hp_version",
+    "hp_set_coalescing",
     "hp_last_kernel_ms",
     "hp_synth_block_size",
     "hp_synth_block",
@@ -319,6 +320,8 @@ def lib():
     dll.hp_blockset_work.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     dll.hp_blockset_destroy.restype = None
     dll.hp_blockset_destroy.argtypes = [C.c_void_p]
+    dll.hp_set_coalescing.restype = C.c_int
+    dll.hp_set_coalescing.argtypes = [C.c_int]
     dll.hp_device_count.restype = C.c_int
     dll.hp_default_device.restype = C.c_int
     dll.hp_last_error.restype = C.c_char_p

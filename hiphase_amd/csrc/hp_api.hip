@@ -87,6 +87,17 @@ void dev_cache_put(void* p, size_t bytes, int dev) {   // dev: what dev_cache_ge
     c.cached += bytes;
 }
 
+static std::atomic<int> g_coalesce{-1};   // -1: ask the environment once
+bool coalescing_enabled() {
+    int v = g_coalesce.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = std::getenv("HP_COALESCE");
+        v = (e && e[0] == '0') ? 0 : 1;
+        g_coalesce.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+
 static thread_local std::string g_err;
 thread_local double g_last_kernel_ms = 0.0;
 void set_error(const char* fmt, ...) {
@@ -102,7 +113,12 @@ void set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* hp_last_error(void) { return hp::g_err.c_str(); }
-const char* hp_version(void) { return "hiphase_gpu 0.1.0 (gfx950)"; }
+const char* hp_version(void) { return "hiphase_gpu 0.2.0 (gfx950)"; }
+int hp_set_coalescing(int on) {
+    const int prev = hp::coalescing_enabled() ? 1 : 0;
+    hp::g_coalesce.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
 double hp_last_kernel_ms(void) { return hp::g_last_kernel_ms; }
 
 int hp_device_count(void) {

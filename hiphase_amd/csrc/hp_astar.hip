@@ -4,6 +4,7 @@
 // Boundary: replaces reference src/astar_phaser.rs:426-429 `astar_solver(...)` as called from
 // reference src/phaser.rs:541-543. See include/hiphase_gpu.h for the contract.
 #include "hp_astar_kernel.hip"
+#include "hp_combine.h"
 
 #include <algorithm>
 #include <atomic>
@@ -11,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <numeric>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -305,6 +307,10 @@ struct hp_batch {
     DevBuf d_row_block, d_haplotag, d_first_het, d_js, d_je, d_junc_block, d_junc_off, d_span;
     std::vector<uint32_t> row_orig, row_block_h;
     std::vector<uint64_t> caller_row_off;
+    // host tables that are uploaded with hipMemcpyAsync: they live as long as the batch, so no copy can outlive its source
+    std::vector<SegDesc> h_segs;
+    std::vector<uint32_t> h_seg_order, h_sb_first, h_sb_n, h_sb_id, h_junc_block;
+    std::vector<uint64_t> h_junc_off;
     uint64_t caller_rows = 0, n_rows_packed = 0, n_junctures = 0;
     bool solved = false;
     // segment-parallel heuristic (large blocks on an otherwise idle GPU)
@@ -353,8 +359,10 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     target = std::max<uint64_t>(64, (target + 63) / 64 * 64);
     const char* wenv = std::getenv("HP_SEG_WARM");
     const uint32_t warm = wenv ? (uint32_t)std::atoi(wenv) : 160;
-    std::vector<SegDesc> segs;
-    std::vector<uint32_t> sb_first, sb_n, sb_id;
+    std::vector<SegDesc>& segs = b->h_segs;
+    std::vector<uint32_t>&sb_first = b->h_sb_first, &sb_n = b->h_sb_n, &sb_id = b->h_sb_id;
+    (void)hipStreamSynchronize(st);   // a previous solve's uploads from these tables are long done; make it certain before they change
+    segs.clear(); sb_first.clear(); sb_n.clear(); sb_id.clear();
     for (uint32_t i = 0; i < b->desc.size(); ++i) {
         const uint32_t N = b->desc[i].n_vars;
         if ((uint64_t)N < 2 * target) continue;
@@ -372,7 +380,8 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
         }
     }
     if (segs.empty()) return HP_OK;
-    std::vector<uint32_t> order(segs.size());
+    std::vector<uint32_t>& order = b->h_seg_order;
+    order.resize(segs.size());
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return segs[x].v0 - segs[x].a > segs[y].v0 - segs[y].a; });
     const uint32_t slots = (uint32_t)std::min<uint64_t>(segs.size(), max_slots);
@@ -608,6 +617,11 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     b->caller_row_off = std::move(hpk.caller_row_off);
     b->caller_rows = hpk.caller_rows;
     b->n_rows_packed = b->row_block_h.size();
+    {   // the post-processing kernels index rows and junctures of the whole batch with 32 bits
+        uint64_t nj = 0;
+        for (size_t i = 0; i < n_blocks; ++i) nj += blks[i].n_variants ? blks[i].n_variants - 1 : 0;
+        if (b->n_rows_packed >= 0xFFFFFFF0ull || nj >= 0xFFFFFFF0ull) { set_error("batch with %llu rows / %llu junctures exceeds 2^32: split it", (unsigned long long)b->n_rows_packed, (unsigned long long)nj); return fail(HP_ERR_UNSUPPORTED); }
+    }
     b->n_cu = device_cu_count(device_id);
     {
         StreamSet ss;
@@ -800,8 +814,10 @@ int hp_batch_postprocess(hp_batch* b, uint64_t* span_counts, uint8_t* haplotag, 
     hipStream_t st = b->stream;
     int rc;
     if (!b->d_js.p) {
-        std::vector<uint32_t> junc_block;
-        std::vector<uint64_t> junc_off(b->n_blocks);
+        std::vector<uint32_t>& junc_block = b->h_junc_block;
+        std::vector<uint64_t>& junc_off = b->h_junc_off;
+        junc_block.clear();
+        junc_off.assign(b->n_blocks, 0);
         uint64_t nj = 0;
         for (size_t i = 0; i < b->n_blocks; ++i) {
             junc_off[i] = nj;
@@ -936,14 +952,58 @@ int hp_astar_solve_batch(size_t n_blocks, const hp_block_view* blks, const hp_as
     return HP_OK;
 }
 
+// hp_astar_solve calls that are in flight together (HiPhase's thread pool, main.rs:385-408) become one resident batch:
+// see hp_combine.h. Requests are grouped by (device, solver parameters); a group that fails as a batch (one block outside
+// the packed-key limits fails hp_batch_create for all) is re-run block by block so that every caller gets its own status.
+namespace {
+struct SolveReq {
+    const hp_block_view* blk; hp_astar_params prm; int device;
+    uint8_t* h1; uint8_t* h2; hp_phase_stats st{};
+    int rc = HP_OK; std::string err; bool done = false;
+};
+hp::Combiner<SolveReq> g_solve_combiner;
+void run_solve_batch(std::vector<SolveReq*>& batch) {
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); ++i) {
+        if (taken[i]) continue;
+        std::vector<SolveReq*> grp;
+        for (size_t j = i; j < batch.size(); ++j)
+            if (!taken[j] && batch[j]->device == batch[i]->device && batch[j]->prm.min_queue_size == batch[i]->prm.min_queue_size &&
+                batch[j]->prm.queue_increment == batch[i]->prm.queue_increment && batch[j]->prm.max_segment_size == batch[i]->prm.max_segment_size) {
+                taken[j] = 1; grp.push_back(batch[j]);
+            }
+        std::vector<hp_block_view> views(grp.size());
+        std::vector<uint8_t*> a1(grp.size()), a2(grp.size());
+        std::vector<hp_phase_stats> st(grp.size());
+        for (size_t k = 0; k < grp.size(); ++k) { views[k] = *grp[k]->blk; a1[k] = grp[k]->h1; a2[k] = grp[k]->h2; }
+        int rc = solve_on_device(grp.size(), views.data(), &grp[0]->prm, a1.data(), a2.data(), st.data(), grp[0]->device);
+        if (rc == HP_OK) { for (size_t k = 0; k < grp.size(); ++k) { grp[k]->st = st[k]; grp[k]->rc = HP_OK; } continue; }
+        if (grp.size() == 1) { grp[0]->rc = rc; grp[0]->err = hp_last_error(); continue; }
+        for (SolveReq* r : grp) {   // find out whose block it was
+            uint8_t* b1[1] = {r->h1};
+            uint8_t* b2[1] = {r->h2};
+            r->rc = solve_on_device(1, r->blk, &r->prm, b1, b2, &r->st, r->device);
+            if (r->rc != HP_OK) r->err = hp_last_error();
+        }
+    }
+}
+}  // namespace
+
 int hp_astar_solve(const hp_block_view* blk, const hp_astar_params* p, uint8_t* h1, uint8_t* h2, hp_phase_stats* out) {
     if (!blk || !p) { set_error("null argument"); return HP_ERR_ARG; }
-    uint8_t* a1[1] = {h1};
-    uint8_t* a2[1] = {h2};
-    hp_phase_stats st{};
-    int rc = solve_on_device(1, blk, p, a1, a2, &st, hp_default_device());
-    if (rc == HP_OK && out) *out = st;
-    return rc;
+    if (!hp::Combiner<SolveReq>::enabled()) {
+        uint8_t* a1[1] = {h1};
+        uint8_t* a2[1] = {h2};
+        hp_phase_stats st{};
+        int rc = solve_on_device(1, blk, p, a1, a2, &st, hp_default_device());
+        if (rc == HP_OK && out) *out = st;
+        return rc;
+    }
+    SolveReq r{blk, *p, hp_default_device(), h1, h2};
+    g_solve_combiner.submit(&r, run_solve_batch);
+    if (r.rc != HP_OK) set_error("%s", r.err.c_str());
+    else if (out) *out = r.st;
+    return r.rc;
 }
 
 }  // extern "C"

@@ -15,6 +15,7 @@
 // record (the reference's own statements, cited inline); everything that scales with bases or with the search runs in
 // the kernels. No CPU fallback: without a device the first device stage fails with HP_ERR_HIP.
 #include "hp_common.h"
+#include "hp_combine.h"
 
 #include <algorithm>
 #include <atomic>
@@ -653,12 +654,61 @@ extern "C" int hp_blockset_work(const hp_blockset* bs, uint64_t out[8]) {
     return HP_OK;
 }
 
-extern "C" int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id) {
-    if (n_blocks == 0) return HP_OK;
+static int solve_blocks_now(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id) {
     int st = HP_OK;
     hp_blockset* bs = hp_blockset_create(n_blocks, in, p, device_id, &st);
     if (!bs) return st != HP_OK ? st : HP_ERR_ARG;
     const int rc = hp_blockset_solve(bs, out, nullptr);
     hp_blockset_destroy(bs);
     return rc;
+}
+
+// hp_solve_blocks calls that are in flight together (HiPhase calls solve_block once per block from its thread pool,
+// main.rs:385-408) are merged into one block set: hp_combine.h.
+namespace {
+struct BlocksReq {
+    size_t n; const hp_block_input* in; hp_block_params prm; hp_block_output* out; int device;
+    int rc = HP_OK; std::string err; bool done = false;
+};
+hp::Combiner<BlocksReq> g_blocks_combiner;
+bool same_params(const hp_block_params& a, const hp_block_params& b) {
+    return a.astar.min_queue_size == b.astar.min_queue_size && a.astar.queue_increment == b.astar.queue_increment &&
+           a.astar.max_segment_size == b.astar.max_segment_size && a.wfa_prune_distance == b.wfa_prune_distance &&
+           a.max_edit_distance == b.max_edit_distance && a.global_failure_ratio == b.global_failure_ratio &&
+           a.global_failure_minimum == b.global_failure_minimum && a.min_matched_alleles == b.min_matched_alleles &&
+           a.global_realignment == b.global_realignment;
+}
+void run_blocks_batch(std::vector<BlocksReq*>& batch) {
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); ++i) {
+        if (taken[i]) continue;
+        std::vector<BlocksReq*> grp;
+        for (size_t j = i; j < batch.size(); ++j)
+            if (!taken[j] && batch[j]->device == batch[i]->device && same_params(batch[j]->prm, batch[i]->prm)) { taken[j] = 1; grp.push_back(batch[j]); }
+        if (grp.size() > 1) {
+            std::vector<hp_block_input> in;
+            std::vector<hp_block_output> out;
+            for (BlocksReq* r : grp) { in.insert(in.end(), r->in, r->in + r->n); out.insert(out.end(), r->out, r->out + r->n); }
+            if (solve_blocks_now(in.size(), in.data(), &grp[0]->prm, out.data(), grp[0]->device) == HP_OK) {
+                size_t o = 0;
+                for (BlocksReq* r : grp) { std::copy(out.begin() + o, out.begin() + o + r->n, r->out); o += r->n; r->rc = HP_OK; }
+                continue;
+            }
+        }
+        for (BlocksReq* r : grp) {   // alone, or the merged set failed: every caller gets the status of its own blocks
+            r->rc = solve_blocks_now(r->n, r->in, &r->prm, r->out, r->device);
+            if (r->rc != HP_OK) r->err = hp_last_error();
+        }
+    }
+}
+}  // namespace
+
+extern "C" int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id) {
+    if (n_blocks == 0) return HP_OK;
+    if (!in || !p || !out) { set_error("null argument"); return HP_ERR_ARG; }
+    if (!Combiner<BlocksReq>::enabled()) return solve_blocks_now(n_blocks, in, p, out, device_id);
+    BlocksReq r{n_blocks, in, *p, out, device_id < 0 ? hp_default_device() : device_id};
+    g_blocks_combiner.submit(&r, run_blocks_batch);
+    if (r.rc != HP_OK) set_error("%s", r.err.c_str());
+    return r.rc;
 }

@@ -5,6 +5,7 @@
 //
 // Boundary: hp_wfa_assign_batch replaces the two calls at reference src/read_parsing.rs:769-780.
 #include "hp_wfa_kernel.hip"
+#include "hp_combine.h"
 
 #include <algorithm>
 #include <array>
@@ -566,13 +567,75 @@ using namespace hp;
 // one-read-per-wavefront dense-band kernel below (a lone wavefront steps ~3x faster through its read than a group that
 // shares its wavefront with seven others). HP_WFA2_MIN_JOBS moves the switch (0: always the compact kernel,
 // a huge value: never); the compact path hands whatever outgrows its state back to this one.
+static int wfa_assign_dispatch(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
+                               hp_wfa_result* out, uint8_t* const* alleles, int device_id) {
+    const char* mj = std::getenv("HP_WFA2_MIN_JOBS");
+    const size_t min_jobs = mj ? (size_t)std::strtoull(mj, nullptr, 10) : 4608;
+    return n < min_jobs ? wfa_assign_batch_v1(jobs, n, prune_distance, max_ed, out, alleles, device_id)
+                        : wfa_assign_batch_v2(jobs, n, prune_distance, max_ed, out, alleles, device_id);
+}
+
+// Calls that are in flight together (one per block from HiPhase's thread pool) are merged into one batch: hp_combine.h.
+namespace {
+struct WfaReq {
+    const hp_wfa_job* jobs; size_t n; uint64_t prune, max_ed; hp_wfa_result* out; uint8_t* const* alleles; int device;
+    int rc = HP_OK; std::string err; bool done = false;
+};
+hp::Combiner<WfaReq> g_wfa_combiner;
+void run_wfa_batch(std::vector<WfaReq*>& batch) {
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); ++i) {
+        if (taken[i]) continue;
+        std::vector<WfaReq*> grp;
+        for (size_t j = i; j < batch.size(); ++j)
+            if (!taken[j] && batch[j]->device == batch[i]->device && batch[j]->prune == batch[i]->prune && batch[j]->max_ed == batch[i]->max_ed &&
+                (batch[j]->alleles != nullptr) == (batch[i]->alleles != nullptr)) { taken[j] = 1; grp.push_back(batch[j]); }
+        if (grp.size() == 1) {
+            WfaReq* r = grp[0];
+            r->rc = wfa_assign_dispatch(r->jobs, r->n, r->prune, r->max_ed, r->out, r->alleles, r->device);
+            if (r->rc != HP_OK) r->err = hp_last_error();
+            continue;
+        }
+        size_t tot = 0;
+        for (WfaReq* r : grp) tot += r->n;
+        std::vector<hp_wfa_job> jobs;
+        std::vector<hp_wfa_result> out(tot);
+        std::vector<uint8_t*> al;
+        jobs.reserve(tot); al.reserve(tot);
+        for (WfaReq* r : grp) {
+            jobs.insert(jobs.end(), r->jobs, r->jobs + r->n);
+            for (size_t k = 0; k < r->n; ++k) al.push_back(r->alleles ? r->alleles[k] : nullptr);
+        }
+        const int rc = wfa_assign_dispatch(jobs.data(), tot, grp[0]->prune, grp[0]->max_ed, out.data(), grp[0]->alleles ? al.data() : nullptr, grp[0]->device);
+        if (rc == HP_OK) {
+            size_t o = 0;
+            for (WfaReq* r : grp) { std::copy(out.begin() + o, out.begin() + o + r->n, r->out); o += r->n; r->rc = HP_OK; }
+            continue;
+        }
+        for (WfaReq* r : grp) {   // a malformed job fails the merged call: every caller gets the status of its own jobs
+            r->rc = wfa_assign_dispatch(r->jobs, r->n, r->prune, r->max_ed, r->out, r->alleles, r->device);
+            if (r->rc != HP_OK) r->err = hp_last_error();
+        }
+    }
+}
+}  // namespace
+
+// Two kernels, one result: a batch large enough to fill the chip goes to the compact several-reads-per-wavefront kernel
+// (hp_wfa2.hip: ~5x fewer instructions per read, throughput-bound); a small batch is latency-bound and goes to the
+// one-read-per-wavefront dense-band kernel below (a lone wavefront steps ~3x faster through its read than a group that
+// shares its wavefront with seven others). HP_WFA2_MIN_JOBS moves the switch (0: always the compact kernel,
+// a huge value: never); the compact path hands whatever outgrows its state back to this one.
 extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
                                    hp_wfa_result* out, uint8_t* const* alleles, int device_id) {
     const double t0 = now_ms();
-    const char* mj = std::getenv("HP_WFA2_MIN_JOBS");
-    const size_t min_jobs = mj ? (size_t)std::strtoull(mj, nullptr, 10) : 4608;
-    const int rc = n < min_jobs ? wfa_assign_batch_v1(jobs, n, prune_distance, max_ed, out, alleles, device_id)
-                                : wfa_assign_batch_v2(jobs, n, prune_distance, max_ed, out, alleles, device_id);
+    int rc;
+    if (n == 0 || !jobs || !out || !hp::Combiner<WfaReq>::enabled()) rc = wfa_assign_dispatch(jobs, n, prune_distance, max_ed, out, alleles, device_id);
+    else {
+        WfaReq r{jobs, n, prune_distance, max_ed, out, alleles, device_id < 0 ? hp_default_device() : device_id};
+        g_wfa_combiner.submit(&r, run_wfa_batch);
+        rc = r.rc;
+        if (rc != HP_OK) set_error("%s", r.err.c_str());
+    }
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] hp_wfa_assign_batch total %.2f ms\n", now_ms() - t0); fflush(stderr); }
     return rc;
 }

@@ -320,6 +320,10 @@ int         hp_device_count(void);
 int         hp_default_device(void);
 const char* hp_last_error(void);        /* thread-local, never NULL */
 const char* hp_version(void);
+/* Calls of hp_astar_solve / hp_wfa_assign_batch / hp_solve_blocks that are in flight at the same time (HiPhase's worker pool
+ * calls solve_block once per block, main.rs:385-408) are merged into one device batch behind the unchanged signatures;
+ * results are identical either way. 0 turns the merging off (also: HP_COALESCE=0), returns the previous setting. */
+int         hp_set_coalescing(int on);
 /* HIP-event time (ms) of the kernel(s) launched by the last hp_wfa_assign_batch / hp_edit_distance_batch /
  * hp_astar_solve* call made on this thread (diagnostics for bench/roofline reporting). */
 double      hp_last_kernel_ms(void);

@@ -1,0 +1,100 @@
+"""Call coalescing behind the unchanged per-block entry points (hiphase_amd/csrc/hp_combine.h): HiPhase's worker pool
+calls solve_block once per block from `--threads` threads (reference src/main.rs:385-408). 64 threads calling
+hp_astar_solve / hp_solve_blocks at the same time must get bit-identical answers to the one-call-at-a-time path, much
+faster, and nothing may hang when the threads exit."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from e2e_util import make_block
+from hiphase_amd import _ffi, astar_solver, synth_block
+from hiphase_amd.blocks import BlockSpec, solve_blocks
+
+pytestmark = pytest.mark.gpu
+
+
+def run_threads(n_threads, fn):
+    out, errs = [None] * n_threads, []
+
+    def body(t):
+        try:
+            out[t] = fn(t)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=body, args=(t,)) for t in range(n_threads)]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=300)
+    assert not any(x.is_alive() for x in th), "a caller never came back"
+    assert not errs, errs
+    return out, time.perf_counter() - t0
+
+
+def test_concurrent_astar_solve_is_merged_and_identical():
+    n_thr, reps = 64, 6
+    sizes = [15, 40, 90, 200, 25, 60, 12, 150]
+    blocks = [[synth_block(sizes[(t + r) % len(sizes)], 30, 20, 0.02, 0.02, 1000 + 97 * t + r)[0] for r in range(reps)] for t in range(n_thr)]
+    hets = sum(b.n_variants for bl in blocks for b in bl)
+    lib = _ffi.lib()
+
+    def work(t):
+        return [astar_solver(t, b) for b in blocks[t]]
+
+    prev = lib.hp_set_coalescing(0)
+    try:
+        work(0)                                   # warm-up (module load, per-thread caches)
+        alone, t_alone = run_threads(n_thr, work)
+        lib.hp_set_coalescing(1)
+        run_threads(n_thr, work)
+        merged, t_merged = run_threads(n_thr, work)
+    finally:
+        lib.hp_set_coalescing(prev)
+    for a, m in zip(alone, merged):
+        for x, y in zip(a, m):
+            assert np.array_equal(x.haplotype_1, y.haplotype_1) and np.array_equal(x.haplotype_2, y.haplotype_2)
+            assert x.statistics.as_tuple() == y.statistics.as_tuple()
+    speedup = t_alone / t_merged
+    print(f"\\n64 threads x {reps} blocks ({hets} hets): one call at a time {hets / t_alone:.0f} hets/s, merged {hets / t_merged:.0f} hets/s ({speedup:.1f}x)")
+    assert speedup > 3.0, (t_alone, t_merged)
+
+
+def test_concurrent_solve_blocks_is_merged_and_identical():
+    n_thr = 16
+    specs = []
+    for t in range(n_thr):
+        ref, hets, homs, records, _ = make_block(40 + t, ref_len=20000, n_hets=20 + t, n_homs=4, n_reads=40)
+        specs.append(BlockSpec(t, ref, hets, homs, records))
+    lib = _ffi.lib()
+    prev = lib.hp_set_coalescing(0)
+    try:
+        alone, _ = run_threads(n_thr, lambda t: solve_blocks([specs[t]])[0])
+        lib.hp_set_coalescing(1)
+        merged, _ = run_threads(n_thr, lambda t: solve_blocks([specs[t]])[0])
+    finally:
+        lib.hp_set_coalescing(prev)
+    for a, m in zip(alone, merged):
+        assert np.array_equal(a.haplotype_1, m.haplotype_1) and np.array_equal(a.haplotype_2, m.haplotype_2)
+        assert a.statistics == m.statistics and a.segments == m.segments and a.haplotags == m.haplotags
+        assert a.span_counts.tolist() == m.span_counts.tolist()
+
+
+def test_bad_block_in_a_merged_batch_only_fails_its_caller():
+    good = [synth_block(30, 30, 20, 0.02, 0.02, 5 + t)[0] for t in range(7)]
+    lib = _ffi.lib()
+    prev = lib.hp_set_coalescing(1)
+    try:
+        def work(t):
+            if t == 3:
+                with pytest.raises(_ffi.HpError):
+                    astar_solver(t, good[0], min_queue_size=10 ** 9)   # outside the packed-key limits: HP_ERR_UNSUPPORTED
+                return None
+            return astar_solver(t, good[t % len(good)])
+        out, _ = run_threads(8, work)
+    finally:
+        lib.hp_set_coalescing(prev)
+    assert sum(o is not None for o in out) == 7
