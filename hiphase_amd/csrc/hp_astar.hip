@@ -961,7 +961,9 @@ struct SolveReq {
     uint8_t* h1; uint8_t* h2; hp_phase_stats st{};
     int rc = HP_OK; std::string err; bool done = false;
 };
-hp::Combiner<SolveReq> g_solve_combiner;
+void run_solve_batch(std::vector<SolveReq*>& batch);
+// never destroyed: its service thread may outlive every static destructor
+hp::Combiner<SolveReq>& g_solve_combiner() { static auto* c = new hp::Combiner<SolveReq>(run_solve_batch); return *c; }
 void run_solve_batch(std::vector<SolveReq*>& batch) {
     std::vector<char> taken(batch.size(), 0);
     for (size_t i = 0; i < batch.size(); ++i) {
@@ -1000,7 +1002,7 @@ int hp_astar_solve(const hp_block_view* blk, const hp_astar_params* p, uint8_t* 
         return rc;
     }
     SolveReq r{blk, *p, hp_default_device(), h1, h2};
-    g_solve_combiner.submit(&r, run_solve_batch);
+    g_solve_combiner().submit(&r);
     if (r.rc != HP_OK) set_error("%s", r.err.c_str());
     else if (out) *out = r.st;
     return r.rc;

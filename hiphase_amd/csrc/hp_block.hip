@@ -654,13 +654,69 @@ extern "C" int hp_blockset_work(const hp_blockset* bs, uint64_t out[8]) {
     return HP_OK;
 }
 
-static int solve_blocks_now(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id) {
+static int solve_blocks_on_device(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id) {
     int st = HP_OK;
     hp_blockset* bs = hp_blockset_create(n_blocks, in, p, device_id, &st);
     if (!bs) return st != HP_OK ? st : HP_ERR_ARG;
     const int rc = hp_blockset_solve(bs, out, nullptr);
     hp_blockset_destroy(bs);
     return rc;
+}
+
+// device_id == -1: the node's GPUs share the blocks through a host-side work queue (the reference's own
+// fan-out is a thread pool over blocks with back-pressure, main.rs:326-462). Blocks are sorted by record count (LPT) and
+// cut into chunks of about `total / (8 x devices)` records, largest first; every device has TWO workers pulling chunks
+// dynamically, so that on each device the layout + upload of one chunk (host + PCIe) overlaps the kernels of another.
+// No collective and no device-to-device traffic: a chunk's 2 N result bytes + statistics go back over PCIe.
+static int solve_blocks_now(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id) {
+    if (device_id >= 0) return solve_blocks_on_device(n_blocks, in, p, out, device_id);
+    const int real_dev = hp_device_count();
+    if (real_dev <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return HP_ERR_HIP; }
+    const char* wenv = std::getenv("HP_QUEUE_WORKERS");   // test hook: n queue "devices" on a box with fewer GPUs (device = worker % real)
+    const int ndev = wenv ? std::max(1, std::atoi(wenv)) : real_dev;
+    if (ndev == 1 || n_blocks < 2) return solve_blocks_on_device(n_blocks, in, p, out, hp_default_device());
+    std::vector<uint32_t> order(n_blocks);
+    for (size_t i = 0; i < n_blocks; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return in[a].n_records > in[b].n_records; });
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_blocks; ++i) total += in[i].n_records + 1;
+    const uint64_t target = std::max<uint64_t>(1, total / ((uint64_t)ndev * 8));
+    std::vector<std::vector<uint32_t>> chunks;
+    {
+        uint64_t acc = 0;
+        chunks.emplace_back();
+        for (uint32_t b : order) {
+            if (acc >= target && !chunks.back().empty()) { chunks.emplace_back(); acc = 0; }
+            chunks.back().push_back(b);
+            acc += in[b].n_records + 1;
+        }
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_err{HP_OK};
+    const int n_workers = ndev * 2;
+    std::vector<std::string> errs(n_workers);
+    std::vector<std::thread> workers;
+    for (int w = 0; w < n_workers; ++w)
+        workers.emplace_back([&, w]() {
+            const int dev = (w % ndev) % real_dev;
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= chunks.size() || first_err.load() != HP_OK) break;
+                const auto& ids = chunks[c];
+                std::vector<hp_block_input> ci(ids.size());
+                std::vector<hp_block_output> co(ids.size());
+                for (size_t k = 0; k < ids.size(); ++k) { ci[k] = in[ids[k]]; co[k] = out[ids[k]]; }
+                const int rc = solve_blocks_on_device(ids.size(), ci.data(), p, co.data(), dev);
+                if (rc != HP_OK) { int exp = HP_OK; if (first_err.compare_exchange_strong(exp, rc)) errs[w] = hp_last_error(); break; }
+                for (size_t k = 0; k < ids.size(); ++k) out[ids[k]] = co[k];
+            }
+        });
+    for (auto& t : workers) t.join();
+    if (first_err.load() != HP_OK) {
+        for (auto& e : errs) if (!e.empty()) { set_error("%s", e.c_str()); break; }
+        return first_err.load();
+    }
+    return HP_OK;
 }
 
 // hp_solve_blocks calls that are in flight together (HiPhase calls solve_block once per block from its thread pool,
@@ -670,7 +726,9 @@ struct BlocksReq {
     size_t n; const hp_block_input* in; hp_block_params prm; hp_block_output* out; int device;
     int rc = HP_OK; std::string err; bool done = false;
 };
-hp::Combiner<BlocksReq> g_blocks_combiner;
+void run_blocks_batch(std::vector<BlocksReq*>& batch);
+// never destroyed: its service thread may outlive every static destructor
+hp::Combiner<BlocksReq>& g_blocks_combiner() { static auto* c = new hp::Combiner<BlocksReq>(run_blocks_batch); return *c; }
 bool same_params(const hp_block_params& a, const hp_block_params& b) {
     return a.astar.min_queue_size == b.astar.min_queue_size && a.astar.queue_increment == b.astar.queue_increment &&
            a.astar.max_segment_size == b.astar.max_segment_size && a.wfa_prune_distance == b.wfa_prune_distance &&
@@ -707,8 +765,9 @@ extern "C" int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const 
     if (n_blocks == 0) return HP_OK;
     if (!in || !p || !out) { set_error("null argument"); return HP_ERR_ARG; }
     if (!Combiner<BlocksReq>::enabled()) return solve_blocks_now(n_blocks, in, p, out, device_id);
+    if (device_id < 0 && n_blocks >= 2) return solve_blocks_now(n_blocks, in, p, out, -1);   // a whole batch for the node's GPUs: the block queue
     BlocksReq r{n_blocks, in, *p, out, device_id < 0 ? hp_default_device() : device_id};
-    g_blocks_combiner.submit(&r, run_blocks_batch);
+    g_blocks_combiner().submit(&r);
     if (r.rc != HP_OK) set_error("%s", r.err.c_str());
     return r.rc;
 }

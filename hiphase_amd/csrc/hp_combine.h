@@ -3,16 +3,21 @@
 // HiPhase submits one job per phase block to a thread pool (reference src/main.rs:385-408): with `--threads T`, T threads
 // sit in hp_astar_solve / hp_wfa_assign_batch / hp_solve_blocks at the same time, each with a block that fills a
 // fraction of a percent of the GPU. A Combiner merges the calls that are in flight together into ONE device batch:
-// every caller queues its request; the first one to find no leader becomes the leader, waits until every caller
-// currently inside the entry point has queued (or a short window has passed), takes the whole queue, runs it as one
-// batch, hands the results out and wakes the others. No service thread exists, so nothing has to be shut down at
-// thread or process exit; a lone caller never waits (it is all the in-flight callers there are).
+// every caller queues its request and sleeps; the combiner's service thread waits until every caller currently inside
+// the entry point has queued (or a short window has passed), takes the whole queue, runs it as one batch, hands the
+// results out and wakes the callers. The service thread is started by the first call and runs every batch, so the
+// per-thread device-buffer cache, streams and scratch it uses (hp_common.h) stay warm from one batch to the next - a
+// rotating "leader" among the callers would start cold every time. It owns nothing a caller could wait for at thread
+// exit; the process simply ends with it asleep (the combiner is never destroyed). A lone caller does not pay the window:
+// it is all the in-flight callers there are.
 #pragma once
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace hp {
@@ -22,43 +27,54 @@ bool coalescing_enabled();
 
 template <class Req> class Combiner {
 public:
-    // run(batch) executes on the leader's thread and fills every request's results + rc
-    template <class Run> void submit(Req* r, Run&& run) {
-        inflight_.fetch_add(1, std::memory_order_acq_rel);
-        std::unique_lock<std::mutex> lk(m_);
-        q_.push_back(r);
-        cv_.notify_all();   // a leader in its window counts arrivals
-        while (!r->done) {
-            if (!leader_active_) {
-                leader_active_ = true;
-                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us());
-                while ((int)q_.size() < inflight_.load(std::memory_order_acquire)) {
-                    if (cv_.wait_until(lk, deadline) == std::cv_status::timeout) break;
-                }
-                std::vector<Req*> batch;
-                batch.swap(q_);
-                lk.unlock();
-                run(batch);
-                lk.lock();
-                for (Req* x : batch) x->done = true;
-                leader_active_ = false;
-                cv_.notify_all();
-            } else cv_.wait(lk);
+    using Run = void (*)(std::vector<Req*>&);
+    explicit Combiner(Run run) : run_(run) {}
+    void submit(Req* r) {
+        if (inflight_.fetch_add(1, std::memory_order_acq_rel) == 0) {
+            // nobody else is inside the entry point: run on the caller's own thread (its caches are the warm ones for a
+            // single-threaded host) - whoever arrives meanwhile queues for the service thread and is merged there
+            std::vector<Req*> one(1, r);
+            run_(one);
+            inflight_.fetch_sub(1, std::memory_order_acq_rel);
+            return;
         }
-        lk.unlock();
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            if (!started_) { started_ = true; std::thread([this]() { serve(); }).detach(); }
+            q_.push_back(r);
+            cv_work_.notify_one();
+            cv_done_.wait(lk, [r]() { return r->done; });
+        }
         inflight_.fetch_sub(1, std::memory_order_acq_rel);
     }
     static bool enabled() { return coalescing_enabled(); }
 
 private:
+    void serve() {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_work_.wait(lk, [this]() { return !q_.empty(); });
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us());
+            while ((int)q_.size() < inflight_.load(std::memory_order_acquire))   // someone is still on the way in
+                if (cv_work_.wait_until(lk, deadline) == std::cv_status::timeout) break;
+            std::vector<Req*> batch;
+            batch.swap(q_);
+            lk.unlock();
+            run_(batch);
+            lk.lock();
+            for (Req* x : batch) x->done = true;
+            cv_done_.notify_all();
+        }
+    }
     static long window_us() {
         static const long w = [] { const char* e = std::getenv("HP_COALESCE_WINDOW_US"); return e ? std::max(0l, std::atol(e)) : 200l; }();
         return w;
     }
+    Run run_;
     std::mutex m_;
-    std::condition_variable cv_;
+    std::condition_variable cv_work_, cv_done_;
     std::vector<Req*> q_;
-    bool leader_active_ = false;
+    bool started_ = false;
     std::atomic<int> inflight_{0};
 };
 

@@ -581,7 +581,9 @@ struct WfaReq {
     const hp_wfa_job* jobs; size_t n; uint64_t prune, max_ed; hp_wfa_result* out; uint8_t* const* alleles; int device;
     int rc = HP_OK; std::string err; bool done = false;
 };
-hp::Combiner<WfaReq> g_wfa_combiner;
+void run_wfa_batch(std::vector<WfaReq*>& batch);
+// never destroyed: its service thread may outlive every static destructor
+hp::Combiner<WfaReq>& g_wfa_combiner() { static auto* c = new hp::Combiner<WfaReq>(run_wfa_batch); return *c; }
 void run_wfa_batch(std::vector<WfaReq*>& batch) {
     std::vector<char> taken(batch.size(), 0);
     for (size_t i = 0; i < batch.size(); ++i) {
@@ -632,7 +634,7 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
     if (n == 0 || !jobs || !out || !hp::Combiner<WfaReq>::enabled()) rc = wfa_assign_dispatch(jobs, n, prune_distance, max_ed, out, alleles, device_id);
     else {
         WfaReq r{jobs, n, prune_distance, max_ed, out, alleles, device_id < 0 ? hp_default_device() : device_id};
-        g_wfa_combiner.submit(&r, run_wfa_batch);
+        g_wfa_combiner().submit(&r);
         rc = r.rc;
         if (rc != HP_OK) set_error("%s", r.err.c_str());
     }

@@ -131,3 +131,19 @@ def test_block_entry_needs_cigar_for_fallback():
     from hiphase_amd._ffi import HpError
     with pytest.raises(HpError):
         solve_blocks([BlockSpec(1, ref, hets, [], records)], config=GlobalRealignmentConfig(max_edit_distance=0, wfa_prune_distance=0))
+
+
+def test_block_queue_over_devices(monkeypatch):
+    """hp_solve_blocks(device_id = -1): the multi-GPU block queue (LPT chunks, two workers per device pulling
+    dynamically). HP_QUEUE_WORKERS makes a 1-GPU box run it with 3 queue devices; answers equal the single-device call."""
+    specs = []
+    for seed in range(20, 32):
+        ref, hets, homs, records, _ = make_block(seed, ref_len=15000 + 1500 * (seed % 5), n_hets=12 + 3 * (seed % 7), n_homs=4, n_reads=30 + 4 * (seed % 6))
+        specs.append(BlockSpec(seed, ref, hets, homs, records))
+    one = solve_blocks(specs, device_id=0)
+    monkeypatch.setenv("HP_QUEUE_WORKERS", "3")
+    many = solve_blocks(specs, device_id=-1)
+    for a, b in zip(one, many):
+        assert np.array_equal(a.haplotype_1, b.haplotype_1) and np.array_equal(a.haplotype_2, b.haplotype_2)
+        assert a.statistics == b.statistics and a.segments == b.segments and a.haplotags == b.haplotags
+        assert a.span_counts.tolist() == b.span_counts.tolist() and a.edit_distances == b.edit_distances

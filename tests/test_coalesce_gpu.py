@@ -36,10 +36,11 @@ def run_threads(n_threads, fn):
 
 
 def test_concurrent_astar_solve_is_merged_and_identical():
-    n_thr, reps = 64, 6
+    """Python threads: identical answers with the merging on and off (the rate is measured from C++ below: here the GIL
+    and the marshalling dominate)."""
+    n_thr, reps = 32, 4
     sizes = [15, 40, 90, 200, 25, 60, 12, 150]
     blocks = [[synth_block(sizes[(t + r) % len(sizes)], 30, 20, 0.02, 0.02, 1000 + 97 * t + r)[0] for r in range(reps)] for t in range(n_thr)]
-    hets = sum(b.n_variants for bl in blocks for b in bl)
     lib = _ffi.lib()
 
     def work(t):
@@ -47,20 +48,27 @@ def test_concurrent_astar_solve_is_merged_and_identical():
 
     prev = lib.hp_set_coalescing(0)
     try:
-        work(0)                                   # warm-up (module load, per-thread caches)
-        alone, t_alone = run_threads(n_thr, work)
+        alone, _ = run_threads(n_thr, work)
         lib.hp_set_coalescing(1)
-        run_threads(n_thr, work)
-        merged, t_merged = run_threads(n_thr, work)
+        merged, _ = run_threads(n_thr, work)
     finally:
         lib.hp_set_coalescing(prev)
     for a, m in zip(alone, merged):
         for x, y in zip(a, m):
             assert np.array_equal(x.haplotype_1, y.haplotype_1) and np.array_equal(x.haplotype_2, y.haplotype_2)
             assert x.statistics.as_tuple() == y.statistics.as_tuple()
-    speedup = t_alone / t_merged
-    print(f"\\n64 threads x {reps} blocks ({hets} hets): one call at a time {hets / t_alone:.0f} hets/s, merged {hets / t_merged:.0f} hets/s ({speedup:.1f}x)")
-    assert speedup > 3.0, (t_alone, t_merged)
+
+
+def test_worker_pool_rate_from_cpp():
+    """64 std::threads x small blocks through hp_astar_solve (tests/cpp/coalesce_test.cpp): merged >= 6x one launch per call asserted (10x measured, INTEGRATION.md)"""
+    import os
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    binp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "coalesce_test")
+    r = subprocess.run([binp, "64", "12", "6"], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 def test_concurrent_solve_blocks_is_merged_and_identical():
