@@ -259,6 +259,7 @@ EXPORTS = [
     "hp_version",
     "hp_set_coalescing",
     "hp_last_kernel_ms",
+    "hp_abi_layout",
     "hp_synth_block_size",
     "hp_synth_block",
 ]
@@ -320,6 +321,7 @@ def lib():
     dll.hp_blockset_work.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     dll.hp_blockset_destroy.restype = None
     dll.hp_blockset_destroy.argtypes = [C.c_void_p]
+    dll.hp_abi_layout.restype = C.c_char_p
     dll.hp_set_coalescing.restype = C.c_int
     dll.hp_set_coalescing.argtypes = [C.c_int]
     dll.hp_device_count.restype = C.c_int

@@ -326,7 +326,7 @@ unsigned wfa_host_threads(size_t n) {
 
 // lays the jobs `ids` out for edit-distance capacity `band`: offsets first (serial prefix sums over sizes that the
 // graphs already know), then the node/edge tables and the sequence bytes are filled by host threads
-int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, uint32_t band, WfaPack& pk) {
+int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, uint32_t band, WfaPack& pk, bool big) {
     const size_t n = ids.size();
     pk.jobs.resize(n);
     // Reference slices: the reads of a block look at overlapping windows of ONE caller buffer (the chromosome), so
@@ -367,7 +367,7 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
         jd.band = band;
         jd.out_set_off = pk.out_set_words;
         pk.out_set_words += jd.set_words;
-        if (jd.n_nodes > WFA_MAX_NODES) { set_error("read overlaps a graph of %u nodes (> %u supported)", jd.n_nodes, WFA_MAX_NODES); return HP_ERR_UNSUPPORTED; }
+        if (!big && jd.n_nodes > WFA_MAX_NODES) { set_error("internal: graph of %u nodes on the LDS path", jd.n_nodes); return HP_ERR_INVARIANT; }
         node_off += g.nodes.size();
         edge_off += g.child.size();
         seq_off += g.seq_bytes - g.ref_len;
@@ -398,7 +398,7 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
                 dn.child_off = e_cur;
                 dn.n_children = (uint16_t)hn.n_child;
                 const uint32_t np = k == 0 ? 1u : hn.n_par;
-                if (np > 32 || hn.n_child > 65535) { snprintf(msg, sizeof msg, "graph node with %u parents (> 32 supported)", np); errs[t] = msg; rcs[t] = HP_ERR_UNSUPPORTED; return; }
+                if (np > WFA_MAX_PARENTS || hn.n_child > 65535) { snprintf(msg, sizeof msg, "graph node with %u parents (> %u supported)", np, WFA_MAX_PARENTS); errs[t] = msg; rcs[t] = HP_ERR_UNSUPPORTED; return; }
                 dn.n_parents = (uint16_t)(np | (is_ref ? WFA_NODE_IS_REF : 0u));
                 const int64_t width = (hn.emax - hn.emin) + 2 * (int64_t)band + 3;
                 if (width > 65535) { snprintf(msg, sizeof msg, "diagonal band of %lld exceeds 65535", (long long)width); errs[t] = msg; rcs[t] = HP_ERR_UNSUPPORTED; return; }
@@ -461,7 +461,7 @@ template <class T> int up(DevBuf& buf, const std::vector<T>& v) {
 
 // one launch over `ids` with capacity `band`; fills status/score/sets for those jobs
 int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, uint32_t band, uint64_t prune, uint64_t max_ed,
-             int n_cu, std::vector<int32_t>& status, std::vector<uint64_t>& score, std::vector<uint32_t>& sets, const std::vector<uint64_t>& set_off) {
+             int n_cu, std::vector<int32_t>& status, std::vector<uint64_t>& score, std::vector<uint32_t>& sets, const std::vector<uint64_t>& set_off, bool big) {
     WfaPack pk;
     {
         size_t tot = 0, nn = 0;
@@ -469,7 +469,7 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
         pk.jobs.reserve(ids.size());
     }
     const double t_pk0 = now_ms();
-    int rc = pack_jobs(hj, ids, band, pk);
+    int rc = pack_jobs(hj, ids, band, pk, big);
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa pack_jobs %.2f ms\n", now_ms() - t_pk0); fflush(stderr); }
     if (rc != HP_OK) return rc;
     const size_t n = ids.size();
@@ -488,7 +488,7 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     HP_HIP_CHECK(hipMemcpy(d_status.p, st0.data(), n * 4, hipMemcpyHostToDevice));
     const uint32_t lds_nodes_off = (uint32_t)(((size_t)pk.max_nodes * WFA_NODE_STATE_BYTES + 15) & ~(size_t)15);
     const uint32_t lds_edges_off = lds_nodes_off + pk.max_nodes * 32;
-    const size_t lds = (size_t)lds_edges_off + (size_t)pk.max_edges * sizeof(WfaEdge);
+    const size_t lds = big ? 0 : (size_t)lds_edges_off + (size_t)pk.max_edges * sizeof(WfaEdge);   // big graphs: state in HBM, tables read in place
     // resident single-wave workgroups per CU: the kernel is a chain of dependent memory round trips per read, so
     // throughput comes from resident reads; 113 VGPRs allow 4 per SIMD = 16 per CU (measured, 4096 x 17 kb reads:
     // 8 -> 4.6 ms, 12 -> 4.3 ms, 16 -> 2.8 ms)
@@ -520,12 +520,19 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     B.scratch = g_ctx.scratch.as<uint32_t>(); B.scratch_stride = stride; B.prune_distance = prune; B.max_ed = max_ed;
     B.lds_nodes_off = lds_nodes_off;
     B.lds_edges_off = lds_edges_off;
+    DevBuf d_big;
+    if (big) {
+        B.big_stride = ((uint64_t)pk.max_nodes * WFA_NODE_STATE_BYTES + 63) & ~63ull;
+        if ((rc = d_big.alloc((size_t)slots * B.big_stride)) != HP_OK) return rc;
+        B.big_state = d_big.as<unsigned char>();
+    }
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa launch jobs=%zu band=%u slots=%u lds=%zu scratch/slot=%zu B\n", n, band, slots, lds, per_slot); fflush(stderr); }
     hipEvent_t e0, e1;
     HP_HIP_CHECK(hipEventCreate(&e0));
     HP_HIP_CHECK(hipEventCreate(&e1));
     HP_HIP_CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(hp_wfa_kernel, dim3(slots), dim3(64), lds, 0, B);
+    if (big) hipLaunchKernelGGL(hp_wfa_big_kernel, dim3(slots), dim3(64), 0, 0, B);
+    else hipLaunchKernelGGL(hp_wfa_kernel, dim3(slots), dim3(64), lds, 0, B);
     HP_HIP_CHECK(hipGetLastError());
     HP_HIP_CHECK(hipEventRecord(e1, 0));
     if (hipDeviceSynchronize() != hipSuccess) { g_ctx.dirty = true; set_error("WFA kernel failed"); return HP_ERR_HIP; }
@@ -698,20 +705,24 @@ int hp::wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_dis
     std::vector<uint64_t> set_off(n + 1, 0);
     for (size_t i = 0; i < n; ++i) set_off[i + 1] = set_off[i] + (hj[i].nodes.size() + 31) / 32;
     std::vector<uint32_t> sets(set_off[n], 0);
-    std::vector<uint32_t> ids(n);
-    std::iota(ids.begin(), ids.end(), 0u);
-    // pass 1 with a narrow band (most reads finish within a few dozen edits); the rest re-run at full width
+    // graphs within the LDS budget and graphs beyond it (state in HBM) run as separate launches; each starts with a
+    // narrow band (most reads finish within a few dozen edits) and re-runs what needs more at full width
     const char* benv = std::getenv("HP_WFA_BAND");
-    uint32_t band = (uint32_t)std::min<uint64_t>(max_ed, benv ? (uint64_t)std::atoi(benv) : 96);
-    for (;;) {
-        int rc = run_pass(hj, ids, band, prune_distance, max_ed, n_cu, status, score, sets, set_off);
-        if (rc != HP_OK) return rc;
-        std::vector<uint32_t> again;
-        for (uint32_t id : ids) if (status[id] == WFA_ST_NEED_BAND) again.push_back(id);
-        if (again.empty()) break;
-        if (band >= max_ed) { set_error("WFA band overflow at full width (internal)"); return HP_ERR_INVARIANT; }
-        band = (uint32_t)std::min<uint64_t>(max_ed, (uint64_t)band * 6);
-        ids.swap(again);
+    for (int big = 0; big < 2; ++big) {
+        std::vector<uint32_t> ids;
+        for (size_t i = 0; i < n; ++i) if ((hj[i].nodes.size() > WFA_MAX_NODES) == (big == 1)) ids.push_back((uint32_t)i);
+        if (ids.empty()) continue;
+        uint32_t band = (uint32_t)std::min<uint64_t>(max_ed, benv ? (uint64_t)std::atoi(benv) : 96);
+        for (;;) {
+            int rc = run_pass(hj, ids, band, prune_distance, max_ed, n_cu, status, score, sets, set_off, big == 1);
+            if (rc != HP_OK) return rc;
+            std::vector<uint32_t> again;
+            for (uint32_t id : ids) if (status[id] == WFA_ST_NEED_BAND) again.push_back(id);
+            if (again.empty()) break;
+            if (band >= max_ed) { set_error("WFA band overflow at full width (internal)"); return HP_ERR_INVARIANT; }
+            band = (uint32_t)std::min<uint64_t>(max_ed, (uint64_t)band * 6);
+            ids.swap(again);
+        }
     }
     const double t_map = now_ms();
     for (size_t i = 0; i < n; ++i)

@@ -66,7 +66,8 @@ constexpr uint32_t WFA_KIND_INTERIOR = 1;       // max_offset < node_length: -1 
 constexpr uint32_t WFA_KIND_INTERIOR_READ = 3;  // ... and the read has bases left: 0 / +1 diagonals too
 constexpr uint32_t WFA_KIND_END_LAST = 4;       // end of the LAST node with read left: only the +1 diagonal
 
-constexpr uint32_t WFA_MAX_NODES = 1024;        // LDS budget: 24 B of state + a 32 B copy of the node table entry per node
+constexpr uint32_t WFA_MAX_NODES = 1024;        // LDS budget: 24 B of state + a 32 B copy of the node table entry per node; larger graphs: hp_wfa_big_kernel
+constexpr uint32_t WFA_MAX_PARENTS = 64;        // injection slots of one node (a 64-bit mask per diagonal)
 constexpr uint32_t WFA_NODE_STATE_BYTES = 24;
 constexpr uint32_t WFA_NODE_LDS_BYTES = WFA_NODE_STATE_BYTES + 32;
 
@@ -86,6 +87,8 @@ struct WfaBatchDev {
     uint64_t max_ed;
     uint32_t lds_nodes_off;  // byte offset of the node-table copy in LDS (after the NodeState array, 16-byte aligned)
     uint32_t lds_edges_off;  // byte offset of the edge-list copy (after the node table)
+    unsigned char* big_state;  // hp_wfa_big_kernel: [slots][big_stride] per-node state in HBM (graphs beyond WFA_MAX_NODES)
+    uint64_t big_stride;
 };
 
 }  // namespace hp

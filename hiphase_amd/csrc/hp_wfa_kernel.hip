@@ -167,7 +167,9 @@ WDEV WfaNodeU load_node(const WfaNode* p) {
     return u;
 }
 
-WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
+// BIG: graphs beyond the LDS budget (WFA_MAX_NODES) keep their per-node state in HBM and read the node / edge tables
+// where the host put them; everything else is the same code.
+template <bool BIG> WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
     const uint32_t lane = wlane();
     uint64_t pc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; uint32_t pn[8] = {0,0,0,0,0,0,0,0};
     uint64_t tl = __builtin_amdgcn_s_memtime();
@@ -176,20 +178,23 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
     const uint32_t n_nodes = jd.n_nodes, W = jd.set_words;
     const WfaNode* gnodes = B.nodes + jd.node_off;
     const WfaEdge* gedges = B.edges + jd.edge_off;
-    WfaEdge* edges = reinterpret_cast<WfaEdge*>(wfa_smem + (size_t)B.lds_edges_off);
+    const WfaEdge* edges = BIG ? gedges : reinterpret_cast<const WfaEdge*>(wfa_smem + (size_t)B.lds_edges_off);
     const uint8_t* seq = B.seq + jd.seq_off;
     const uint8_t* refseq = B.seq + jd.ref_off;
     const uint8_t* read = seq + jd.read_off;
     const uint32_t other_len = jd.read_len;
     uint32_t* scr = B.scratch + (size_t)slot * B.scratch_stride;
-    NodeState* ns = reinterpret_cast<NodeState*>(wfa_smem);
-    WfaNode* nodes = reinterpret_cast<WfaNode*>(wfa_smem + (size_t)B.lds_nodes_off);
+    NodeState* ns = BIG ? reinterpret_cast<NodeState*>(B.big_state + (size_t)slot * B.big_stride) : reinterpret_cast<NodeState*>(wfa_smem);
+    const WfaNode* nodes = BIG ? gnodes : reinterpret_cast<const WfaNode*>(wfa_smem + (size_t)B.lds_nodes_off);
     uint32_t* out_set = B.out_sets + jd.out_set_off;
 
     for (uint32_t i = lane; i < n_nodes; i += 64) ns[i] = NodeState{{HULL_EMPTY, HULL_EMPTY}, {0xFFFFFFFFu, 0xFFFFFFFFu}, HULL_EMPTY, HULL_EMPTY};
-    for (uint32_t i = lane; i < n_nodes * 2; i += 64)   // 32-byte node entries as 16-byte halves
-        reinterpret_cast<uint4*>(nodes)[i] = reinterpret_cast<const uint4*>(gnodes)[i];
-    for (uint32_t i = lane; i < jd.n_edges; i += 64) edges[i] = gedges[i];
+    if (!BIG) {
+        uint4* ln = reinterpret_cast<uint4*>(wfa_smem + (size_t)B.lds_nodes_off);
+        WfaEdge* le = reinterpret_cast<WfaEdge*>(wfa_smem + (size_t)B.lds_edges_off);
+        for (uint32_t i = lane; i < n_nodes * 2; i += 64) ln[i] = reinterpret_cast<const uint4*>(gnodes)[i];   // 32-byte node entries as 16-byte halves
+        for (uint32_t i = lane; i < jd.n_edges; i += 64) le[i] = gedges[i];
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (lane == 0) for (uint32_t w = 0; w < W; ++w) out_set[w] = 0;
 
@@ -287,13 +292,13 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                         if (r1 == WFA_KIND_INTERIOR_READ || r1 == WFA_KIND_END_LAST) oC = (int32_t)r0;
                     }
                 }
-                uint32_t inj_mask = 0;  // which parents injected on this diagonal (n_parents <= 32 checked by host)
+                uint64_t inj_mask = 0;  // which parents injected on this diagonal (n_parents <= 64 checked by host)
                 if (act && hull_has(ih, di)) {
                     for (uint32_t k = 0; k < nd.n_parents; ++k) {
                         const uint32_t* s = e + 5 + 2 * W + k * W;
                         uint32_t nz = 0;
                         for (uint32_t w = 0; w < W; ++w) nz |= s[w];
-                        if (nz) inj_mask |= 1u << k;
+                        if (nz) inj_mask |= 1ull << k;
                     }
                 }
                 const bool has = act && (oA >= 0 || oB >= 0 || oC >= 0 || inj_mask != 0);
@@ -416,7 +421,7 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
                     if (inj_mask) {  // consume the injections (leave the slots zeroed)
                         for (uint32_t k = 0; k < nd.n_parents; ++k) {
                             uint32_t* s = e + 5 + 2 * W + k * W;
-                            if ((inj_mask >> k) & 1u) for (uint32_t w = 0; w < W; ++w) s[w] = 0;
+                            if ((inj_mask >> k) & 1ull) for (uint32_t w = 0; w < W; ++w) s[w] = 0;
                         }
                     }
                 }
@@ -528,14 +533,16 @@ WDEV void solve_job(const WfaBatchDev& B, uint32_t job, uint32_t slot) {
 #endif
 }
 
-__global__ void __launch_bounds__(64) hp_wfa_kernel(WfaBatchDev B) {
+template <bool BIG> WDEV void wfa_kernel_body(const WfaBatchDev& B) {
     const uint32_t slot = blockIdx.x, G = gridDim.x;
     for (uint32_t round = 0;; ++round) {
         const uint32_t base = round * G;
         if (base >= B.n_items) break;
         const uint32_t i = base + ((round & 1u) ? (G - 1u - slot) : slot);
-        if (i < B.n_items) solve_job(B, B.order[i], slot);
+        if (i < B.n_items) solve_job<BIG>(B, B.order[i], slot);
     }
 }
+__global__ void __launch_bounds__(64) hp_wfa_kernel(WfaBatchDev B) { wfa_kernel_body<false>(B); }
+__global__ void __launch_bounds__(64) hp_wfa_big_kernel(WfaBatchDev B) { wfa_kernel_body<true>(B); }
 
 }  // namespace hp

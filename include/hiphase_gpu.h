@@ -327,6 +327,9 @@ int         hp_set_coalescing(int on);
 /* HIP-event time (ms) of the kernel(s) launched by the last hp_wfa_assign_batch / hp_edit_distance_batch /
  * hp_astar_solve* call made on this thread (diagnostics for bench/roofline reporting). */
 double      hp_last_kernel_ms(void);
+/* JSON: sizeof / alignof / offsetof of every struct in this header as the library was compiled (generated by
+ * scripts/gen_abi_layout.py) - diff the #[repr(C)] side of a binding against it once at start-up. */
+const char* hp_abi_layout(void);
 
 /* Deterministic synthetic block generator of SURVEY.md §8(d) (splitmix64). Fills caller-provided
  * buffers sized via hp_synth_block_size(). Used by tests and bench.py on both legs. */

@@ -125,3 +125,25 @@ def test_edit_distance_and_local_batches_fail_loudly(hp_lib):
     st = (_ffi.ReadStats * 1)()
     rc = hp_lib.hp_local_realign_batch(rd, 1, vs, 1, alleles.ctypes.data, quals.ctypes.data, st, 0)
     assert rc == -5, hp_lib.hp_last_error()                                         # HP_ERR_UNSUPPORTED
+
+
+def test_abi_layout_matches_the_ctypes_bindings(hp_lib):
+    """hp_abi_layout(): sizeof / offsetof of every struct of the C ABI as the library was compiled, diffed against the
+    ctypes structs (the same diff a #[repr(C)] binding does once at start-up)."""
+    import ctypes as C
+    import json
+    from hiphase_amd import _ffi
+    layout = json.loads(hp_lib.hp_abi_layout().decode())
+    pairs = {"hp_block_view": _ffi.BlockView, "hp_astar_params": _ffi.AstarParams, "hp_phase_stats": _ffi.PhaseStats,
+             "hp_work_counters": _ffi.WorkCounters, "hp_wfa_variant": _ffi.WfaVariant, "hp_wfa_job": _ffi.WfaJob,
+             "hp_wfa_result": _ffi.WfaResult, "hp_ed_pair": _ffi.EdPair, "hp_local_variant": _ffi.LocalVariant,
+             "hp_local_read": _ffi.LocalRead, "hp_read_stats": _ffi.ReadStats, "hp_block_record": _ffi.BlockRecord,
+             "hp_block_input": _ffi.BlockInput, "hp_block_params": _ffi.BlockParams, "hp_block_output": _ffi.BlockOutput,
+             "hp_synth_spec": _ffi.SynthSpec}
+    assert set(layout) == set(pairs)
+    for name, cls in pairs.items():
+        assert layout[name]["sizeof"] == C.sizeof(cls), name
+        fields = layout[name]["fields"]
+        assert list(fields) == [f for f, _ in cls._fields_], name
+        for f, _ in cls._fields_:
+            assert fields[f] == getattr(cls, f).offset, (name, f)

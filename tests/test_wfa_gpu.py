@@ -211,3 +211,29 @@ def test_jobs_sharing_one_reference_buffer():
     specs.append(synth_wfa_job(5151, ref_len=1200, n_vars=6)[0])   # a buffer of its own in the same batch
     check_specs(specs)
     check_specs(specs[::-1], prune=50, max_ed=40)
+
+
+# ---- graphs beyond the LDS budget / wide fan-in (round 2: no longer HP_ERR_UNSUPPORTED) ---------------------------------
+
+def test_graph_beyond_the_lds_budget():
+    """> 1024 nodes (hp_wfa_dev.h WFA_MAX_NODES): hp_wfa_big_kernel keeps the per-node state in HBM; a dense region of a
+    real genome (a 20-kb read over several hundred calls) gets there."""
+    specs = [synth_wfa_job(900 + s, ref_len=20000, n_vars=420, n_homs=60, noise=0.003, margin=30)[0] for s in range(3)]
+    got = check_specs(specs)
+    assert min(g[2] for g in got) > 1024, [g[2] for g in got]
+
+
+def test_node_with_more_than_32_parents():
+    """40 insertion alleles at one position all reconnect on the same reference node (41 parents)."""
+    from hiphase_amd.wfa_graph import Variant, WfaJobSpec
+    r = _Rng(4242)
+    ref = r.dna(1500)
+    pos = 600
+    hets = [Variant.new_insertion(0, pos, ref[pos:pos + 1], ref[pos:pos + 1] + r.dna(3 + k % 5) + bytes([b"ACGT"[k % 4]]) * (1 + k // 4), 0, 1) for k in range(40)]
+    reads = []
+    for k in (0, 7, 39):
+        reads.append(ref[100:pos] + hets[k].allele1 + ref[pos + 1:1400])
+    reads.append(ref[100:1400])
+    specs = [WfaJobSpec(reference=ref, ref_start=100, ref_end=1400, hets=hets, homs=[], read=rd) for rd in reads]
+    got = check_specs(specs, prune=0, max_ed=100)
+    assert all(g[0] == 0 for g in got) and got[0][2] >= 42
