@@ -324,7 +324,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["path", "c2", "wgs"], default="path")
-    ap.add_argument("--total-hets", type=int, default=20000, help="path workload: hets per GPU and step")
+    ap.add_argument("--total-hets", type=int, default=60000, help="path workload: hets per GPU and step")
     ap.add_argument("--max-block-hets", type=int, default=2000)
     ap.add_argument("--blocks", type=int, default=6144, help="blocks per GPU (24 resident single-wave workgroups per CU x 256 CUs)")
     ap.add_argument("--hets", type=int, default=5000)
@@ -358,6 +358,8 @@ def main():
     if lib.hp_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libhiphase_gpu.so has no CPU fallback")
 
+    if args.replay and args.workload == "path":
+        args.workload = "c2"   # a capture holds solver matrices: replay is a solver-stage run
     if args.workload == "path":
         return main_path(args, rank, world, local_rank, dist, backend)
 

@@ -233,6 +233,8 @@ class BlockOutput(C.Structure):
         ("local_aligned", C.c_uint64),
         ("edit_distances", C.POINTER(C.c_uint64)),
         ("n_edit_distances", C.c_uint64),
+        ("status", C.c_int32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -260,6 +262,7 @@ EXPORTS = [
     "hp_set_coalescing",
     "hp_last_kernel_ms",
     "hp_abi_layout",
+    "hp_hpbk_append",
     "hp_synth_block_size",
     "hp_synth_block",
 ]
@@ -322,6 +325,8 @@ def lib():
     dll.hp_blockset_destroy.restype = None
     dll.hp_blockset_destroy.argtypes = [C.c_void_p]
     dll.hp_abi_layout.restype = C.c_char_p
+    dll.hp_hpbk_append.restype = C.c_int
+    dll.hp_hpbk_append.argtypes = [C.c_char_p, C.POINTER(BlockView), C.POINTER(AstarParams), C.c_void_p, C.c_void_p, C.POINTER(PhaseStats)]
     dll.hp_set_coalescing.restype = C.c_int
     dll.hp_set_coalescing.argtypes = [C.c_int]
     dll.hp_device_count.restype = C.c_int

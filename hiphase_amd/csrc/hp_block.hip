@@ -529,13 +529,32 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
     hp_astar_params ap = bs->prm.astar;
     int st = HP_OK;
     hp_batch* batch = hp_batch_create(nb, views.data(), &ap, bs->device, &st);
+    std::vector<char> unsupported(nb, 0);
+    if (!batch && st == HP_ERR_UNSUPPORTED && nb > 1) {
+        // one block outside the solver's packed-key limits must not fail the others: find it (a create on
+        // its own tells), hand it back with the soft status HP_BLOCK_UNSUPPORTED and an empty matrix in its place
+        static const uint32_t zero32 = 0;
+        static const uint64_t zero64[2] = {0, 0};
+        static const uint8_t zero8[2] = {0, 0};
+        bool any_ok = false;
+        for (size_t k = 0; k < nb; ++k) {
+            int s1 = HP_OK;
+            hp_batch* one = hp_batch_create(1, &views[k], &ap, bs->device, &s1);
+            if (one) { hp_batch_destroy(one); any_ok = true; continue; }
+            if (s1 != HP_ERR_UNSUPPORTED) return s1;
+            unsupported[k] = 1;
+            views[k].n_reads = 0; views[k].read_start = &zero32; views[k].read_end = &zero32; views[k].row_off = zero64;
+            views[k].alleles_2bit = zero8; views[k].quals = zero8;
+        }
+        if (any_ok) batch = hp_batch_create(nb, views.data(), &ap, bs->device, &st);
+    }
     if (!batch) return st != HP_OK ? st : HP_ERR_HIP;
     struct BatchGuard { hp_batch* b; ~BatchGuard() { hp_batch_destroy(b); } } guard{batch};
     const double t3 = blk_now_ms();
     float kms = 0.f;
     if ((rc = hp_batch_solve(batch, nullptr, &kms)) != HP_OK) return rc;
     uint64_t sum_n = 0, sum_rows = 0, sum_j = 0;
-    for (size_t b : ch.blocks) { sum_n += bs->in[b].n_hets; sum_rows += bs->st[b].read_start.size(); sum_j += bs->in[b].n_hets - 1; }
+    for (size_t k = 0; k < nb; ++k) { const size_t b = ch.blocks[k]; sum_n += bs->in[b].n_hets; sum_rows += views[k].n_reads; sum_j += bs->in[b].n_hets - 1; }
     std::vector<uint8_t> h1((size_t)sum_n), h2((size_t)sum_n);
     std::vector<hp_phase_stats> stats(nb);
     std::vector<hp_work_counters> ctr(nb);
@@ -557,6 +576,7 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
         const hp_block_input& B = bs->in[b];
         const BlockState& S = bs->st[b];
         hp_block_output& O = out[b];
+        O.status = unsupported[kb] ? HP_BLOCK_UNSUPPORTED : HP_OK;
         const uint32_t N = B.n_hets;
         const uint8_t* H1 = h1.data() + on;
         const uint8_t* H2 = h2.data() + on;
@@ -579,7 +599,8 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
             if (O.seg_solver) O.seg_solver[k] = S.seg_solver[k];
             uint8_t ht = 2;
             uint32_t first = UINT32_MAX;
-            if (S.seg_solver[k]) { ht = tag[(size_t)(orow + srow)]; first = fh[(size_t)(orow + srow)]; ++srow; }
+            if (unsupported[kb]) {}
+            else if (S.seg_solver[k]) { ht = tag[(size_t)(orow + srow)]; first = fh[(size_t)(orow + srow)]; ++srow; }
             else {
                 // a segment outside the solver matrix (fewer than min_matched_alleles set alleles) is tagged against the
                 // solution the way haplotag_reads tags any segment (phaser.rs:620-630, :714-750): a handful of cells
@@ -608,7 +629,7 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
             cells += len;
         }
         if (O.seg_row_off) O.seg_row_off[S.segs.size()] = cells;
-        on += N; orow += S.read_start.size(); oj += N - 1;
+        on += N; orow += views[kb].n_reads; oj += N - 1;
     }
     const double t5 = blk_now_ms();
     ch.ms[1] = t2 - t1; ch.ms[2] = t3 - t2; ch.ms[3] = t4 - t3; ch.ms[4] = t5 - t4; ch.ms[7] = kms;

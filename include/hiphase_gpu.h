@@ -30,6 +30,8 @@ extern "C" {
 /* ---- status codes ------------------------------------------------------------------------- */
 #define HP_OK                 0
 #define HP_WFA_MAX_ED         1   /* per-job: WFAGraphError::MaxEditDistance (wfa_graph.rs:13-17,645-648) */
+#define HP_BLOCK_UNSUPPORTED  2   /* per-block (hp_block_output.status): outside the device solver's packed-key limits;
+                                     the other blocks of the call are solved, the caller runs its own solve_block for this one */
 #define HP_ERR_HIP           -1   /* HIP runtime error / no device / kernel image missing */
 #define HP_ERR_OOM           -2   /* host or device allocation failed */
 #define HP_ERR_INVARIANT     -3   /* an `assert!`/`panic!` of the reference would have fired */
@@ -297,6 +299,8 @@ typedef struct hp_block_output {
     uint64_t        local_aligned;
     uint64_t*       edit_distances;       /* [n_records] wfa_score of every record that was not skipped, in BAM order */
     uint64_t        n_edit_distances;     /* out */
+    int32_t         status;               /* out: HP_OK, or HP_BLOCK_UNSUPPORTED (segments are filled, h1/h2/stats/spans/tags are not) */
+    uint32_t        reserved;
 } hp_block_output;
 
 int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id);
@@ -327,6 +331,11 @@ int         hp_set_coalescing(int on);
 /* HIP-event time (ms) of the kernel(s) launched by the last hp_wfa_assign_batch / hp_edit_distance_batch /
  * hp_astar_solve* call made on this thread (diagnostics for bench/roofline reporting). */
 double      hp_last_kernel_ms(void);
+/* Appends one block in the .hpbk capture format (hiphase_amd/block_io.py) to `path`: the solver's exact
+ * input and - when h1, h2 and stats are given - the output the caller's own astar_solver produced for it. A HiPhase
+ * built with this call at src/phaser.rs:541-543 writes the real HG002 blocks this repository cannot produce. */
+int         hp_hpbk_append(const char* path, const hp_block_view* blk, const hp_astar_params* p, const uint8_t* h1,
+                           const uint8_t* h2, const hp_phase_stats* stats);
 /* JSON: sizeof / alignof / offsetof of every struct in this header as the library was compiled (generated by
  * scripts/gen_abi_layout.py) - diff the #[repr(C)] side of a binding against it once at start-up. */
 const char* hp_abi_layout(void);
