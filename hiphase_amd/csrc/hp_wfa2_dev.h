@@ -256,9 +256,14 @@ template <int W> struct W2Cfg {
     static constexpr int MAXS = 12;              // source intervals of one node (slow path scratch)
     static constexpr int MAXW = 250;             // diagonals per entry (8-bit relative hulls)
     static constexpr int a16(int x) { return (x + 15) & ~15; }
+    // The node table stays in LDS only for the smallest class; for the others it is read from HBM (L2-resident: one 12-byte
+    // descriptor per node visit, the children of a node when one of its waves finishes) - that takes a read's LDS below
+    // 2.5 KB, i.e. 8 workgroups of 8 reads per CU = two wavefronts per SIMD. One wavefront per SIMD issues at most one
+    // instruction every ~5 cycles (profiles/round2/issue_ceiling.txt); the second one hides that and the memory latency.
+    static constexpr bool DESC_LDS = W <= 2;
     static constexpr int O_DESC = 0;                                  // uint2[MAXN]: seq_off, len | is_ref << 18 | child_off << 19 | n_children << 29
-    static constexpr int O_EDGE = O_DESC + 8 * MAXN;                  // u8[MAXE]
-    static constexpr int O_LIVE = a16(O_EDGE + MAXE);                 // uint4[2][MAXL]
+    static constexpr int O_EDGE = O_DESC + (DESC_LDS ? 8 * MAXN : 0); // u8[MAXE]
+    static constexpr int O_LIVE = a16(O_EDGE + (DESC_LDS ? MAXE : 0)); // uint4[2][MAXL]
     static constexpr int O_FIN = O_LIVE + 2 * 16 * MAXL;              // uint4[MAXF]
     static constexpr int O_EK = O_FIN + 16 * MAXF;                    // u32[2][SLOTS]: offset << 3 | kind
     static constexpr int O_MISC = a16(O_EK + 2 * 4 * SLOTS);          // outset[W]

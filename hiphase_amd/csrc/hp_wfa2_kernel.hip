@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
     uint32_t state = S_JOB, jround = 0, job = 0;
     uint32_t n_nodes = 0, last = 0, other_len = 0, tag = 0;
     const uint8_t* refp = altp; const uint8_t* readp = altp;
+    const W2Node* gnode = B.nodes; const uint16_t* gedge = B.edges;   // the job's node / edge tables in HBM
     uint32_t ed = 0, c = 0, p = 1, lcnt_prev = 0, lcnt_cur = 0, fcnt = 0, top = 0, pp = 0;
     uint32_t farthest = 0, min_prog = 0;
     bool final_found = false, round_live = false;
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
             fcnt++;
         }
         if (fn)
-            for (uint32_t j = 0; j < n_child; ++j) pq_append(edg[child_off + j], code);
+            for (uint32_t j = 0; j < n_child; ++j) pq_append(C::DESC_LDS ? (uint32_t)edg[child_off + j] : (uint32_t)gedge[child_off + j], code);
         chi = INT32_MIN; cvlo = INT32_MAX; cvhi = INT32_MIN; cflo = INT32_MAX; cfhi = INT32_MIN;
     };
 
@@ -311,19 +312,19 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                     status = W2_ST_NEED_BIG;
                     continue;   // stays in S_JOB: the next pass writes this status and fetches the next job
                 }
-                {
-                    const W2Node* gd = B.nodes + jd.node_off;
+                gnode = B.nodes + jd.node_off;
+                gedge = B.edges + jd.edge_off;
+                if (C::DESC_LDS) {
                     uint2* ld = reinterpret_cast<uint2*>(R + C::O_DESC);
                     bool bad = false;
                     for (uint32_t i = gl; i < n_nodes; i += G) {
-                        const W2Node nd = gd[i];
+                        const W2Node nd = gnode[i];
                         const uint32_t ln = nd.len_ref & ~W2_IS_REF, co = nd.child & 0xFFFFu, nc = nd.child >> 16;
                         bad = bad || ln >= W2_LDS_LEN_LIM || co >= 1024u || nc >= 8u;
                         ld[i] = make_uint2(nd.seq_off, ln | ((nd.len_ref >> 31) << 18) | (co << 19) | (nc << 29));
                     }
-                    const uint16_t* ge = B.edges + jd.edge_off;
                     uint8_t* le = reinterpret_cast<uint8_t*>(R + C::O_EDGE);
-                    for (uint32_t i = gl; i < ji.n_edges; i += G) le[i] = (uint8_t)ge[i];
+                    for (uint32_t i = gl; i < ji.n_edges; i += G) le[i] = (uint8_t)gedge[i];
                     if (w2_gballot<G>(bad, gbase)) { status = W2_ST_NEED_BIG; continue; }
                 }
                 // the start wave (wfa_graph.rs:366-378): node 0 waits for its turn in round 0, with no parent
@@ -354,10 +355,17 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                     continue;
                 }
                 {
-                    const uint2 nd = desc[n];
-                    len = nd.y & (W2_LDS_LEN_LIM - 1u);
-                    nseq = (((nd.y >> 18) & 1u) ? refp : altp) + nd.x;
-                    child_off = (nd.y >> 19) & 1023u; n_child = nd.y >> 29;
+                    if (C::DESC_LDS) {
+                        const uint2 nd = desc[n];
+                        len = nd.y & (W2_LDS_LEN_LIM - 1u);
+                        nseq = (((nd.y >> 18) & 1u) ? refp : altp) + nd.x;
+                        child_off = (nd.y >> 19) & 1023u; n_child = nd.y >> 29;
+                    } else {
+                        const W2Node nd = gnode[n];
+                        len = nd.len_ref & ~W2_IS_REF;
+                        nseq = ((nd.len_ref & W2_IS_REF) ? refp : altp) + nd.seq_off;
+                        child_off = nd.child & 0xFFFFu; n_child = nd.child >> 16;
+                    }
                 }
                 // ---- sources: previous entries of n grown by one diagonal a side, finished parents, the start wave ----
                 lo = INT32_MAX; hi = INT32_MIN;

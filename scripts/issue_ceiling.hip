@@ -18,10 +18,10 @@ template <int MODE> __global__ void __launch_bounds__(64) k(uint32_t* out, int i
                                : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));)
         } else if (MODE == 1) {   // 128 independent SALU
             REP16(asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1"
-                               : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3));)
+                               : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");)
         } else {   // 64 VALU + 64 SALU interleaved (the A* kernel's mix is 195 : 153)
             REP16(asm volatile("v_add_u32 %0, %0, 1\n s_add_u32 %4, %4, 1\n v_add_u32 %1, %1, 1\n s_add_u32 %5, %5, 1\n v_add_u32 %2, %2, 1\n s_add_u32 %6, %6, 1\n v_add_u32 %3, %3, 1\n s_add_u32 %7, %7, 1"
-                               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3));)
+                               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");)
         }
     }
     out[blockIdx.x * 64 + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + s0 + s1 + s2 + s3;
@@ -42,6 +42,7 @@ template <int MODE> double run(uint32_t* d, int grid, int iters) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
