@@ -352,12 +352,15 @@ int assemble_block(hp_blockset* bs, size_t b) {
         if ((rc = solve_local(failed)) != HP_OK) return rc;
     }
     // per read name: the segments of its records, in BAM order
-    std::vector<std::vector<Segment>> groups(B.n_qnames);
+    // (a linked list per read name through the records' own segments: almost every read name has one record, and a
+    // vector per name would cost an allocation per read)
+    std::vector<Segment> recseg(R);
+    std::vector<uint32_t> qfirst(B.n_qnames, UINT32_MAX), qlast(B.n_qnames, UINT32_MAX), qcount(B.n_qnames, 0), next_rec(R, UINT32_MAX);
     std::vector<uint32_t> order;           // first-seen read names
+    order.reserve(B.n_qnames);
     std::vector<uint8_t> seen(B.n_qnames, 0);
     bool global_disabled = false;
     double num_global_failures = 0.0, total_parsed = 0.0;
-    std::vector<uint8_t> row_a, row_q;
     for (uint32_t idx = 0; idx < R; ++idx) {
         const RecMeta& m = meta[idx];
         Segment seg;
@@ -386,15 +389,25 @@ int assemble_block(hp_blockset* bs, size_t b) {
             } else {
                 const uint32_t n = m.last - m.first;
                 const uint8_t* a = CH.alleles.data() + CH.job_alloff[(size_t)m.job];
-                row_a.assign(a, a + n);
-                row_q.assign(n, 0);
-                for (uint32_t i = 0; i < n; ++i)
-                    if (row_a[i] < HP_ALLELE_AMBIGUOUS) {   // read_parsing.rs:803-835: 2 x base quality for 0/1 alleles, else 0
-                        const int q = base_quality(B.het_types[m.first + i]);
-                        if (q < 0) { set_error("block %zu: no base quality for variant type %u (read_parsing.rs:829 panics)", b, (unsigned)B.het_types[m.first + i]); return HP_ERR_INVARIANT; }
-                        row_q[i] = (uint8_t)(2 * q);
-                    }
-                seg = segment_new(row_a.data(), row_q.data(), m.first, n, N);
+                // ReadSegment::new on the window [first, last): clip to the set alleles, then read_parsing.rs:803-835 for the
+                // qualities of what is left (2 x base quality for 0/1 alleles, else 0)
+                uint32_t f0 = n, l0 = n;
+                for (uint32_t i = 0; i < n; ++i) if (a[i] < HP_ALLELE_AMBIGUOUS) { f0 = i; break; }
+                for (uint32_t i = n; i-- > 0;) if (a[i] < HP_ALLELE_AMBIGUOUS) { l0 = i + 1; break; }
+                if (f0 == n) { seg.start = seg.end = N; }
+                else {
+                    seg.start = m.first + f0; seg.end = m.first + l0;
+                    seg.alleles.assign(a + f0, a + l0);
+                    seg.quals.assign(l0 - f0, 0);
+                    for (uint32_t i = f0; i < l0; ++i)
+                        if (a[i] < HP_ALLELE_AMBIGUOUS) {
+                            const int q = base_quality(B.het_types[m.first + i]);
+                            if (q < 0) { set_error("block %zu: no base quality for variant type %u (read_parsing.rs:829 panics)", b, (unsigned)B.het_types[m.first + i]); return HP_ERR_INVARIANT; }
+                            seg.quals[i - f0] = (uint8_t)(2 * q);
+                        }
+                }
+                // (a het outside [f0, l0) is NoOverlap / Ambiguous with quality 0 either way; the reference panics on an
+                // unknown type only for a 0/1 allele, :803-829, which all lie inside the clip)
                 wfa_score = w.score;
             }
         }
@@ -402,8 +415,9 @@ int assemble_block(hp_blockset* bs, size_t b) {
         S.local_aligned += (uint64_t)local_aligned;
         S.global_aligned += 1 - (uint64_t)local_aligned;
         const uint32_t q = B.records[idx].qname_id;
-        if (!seen[q]) { seen[q] = 1; order.push_back(q); }
-        groups[q].push_back(std::move(seg));
+        if (!seen[q]) { seen[q] = 1; order.push_back(q); qfirst[q] = idx; } else next_rec[qlast[q]] = idx;
+        qlast[q] = idx; qcount[q]++;
+        recseg[idx] = std::move(seg);
         if (P.global_realignment) {
             S.edit_distances.push_back(wfa_score);
             num_global_failures += local_aligned;
@@ -413,14 +427,19 @@ int assemble_block(hp_blockset* bs, size_t b) {
         }
     }
     // collapse per read name + the min_matched_alleles split (read_parsing.rs:611-629 / :95-113)
+    S.segs.reserve(order.size()); S.seg_qname.reserve(order.size()); S.seg_solver.reserve(order.size()); S.solver_rows.reserve(order.size());
+    std::vector<const Segment*> grp;
     for (uint32_t q : order) {
-        std::vector<const Segment*> grp;
-        for (auto& s : groups[q]) grp.push_back(&s);
         Segment col;
-        if (!segment_collapse(grp, N, col)) { set_error("block %zu: assert!(quals[i] > 0) (read_segments.rs:105)", b); return HP_ERR_INVARIANT; }
+        if (qcount[q] == 1) col = std::move(recseg[qfirst[q]]);   // collapse of one segment is that segment (read_segments.rs:72-75)
+        else {
+            grp.clear();
+            for (uint32_t i = qfirst[q]; i != UINT32_MAX; i = next_rec[i]) grp.push_back(&recseg[i]);
+            if (!segment_collapse(grp, N, col)) { set_error("block %zu: assert!(quals[i] > 0) (read_segments.rs:105)", b); return HP_ERR_INVARIANT; }
+        }
         const uint32_t num_set = seg_num_set(col);
         const bool solver = num_set >= P.min_matched_alleles;
-        if (solver) S.num_reads += grp.size(); else S.skipped_reads += grp.size();
+        if (solver) S.num_reads += qcount[q]; else S.skipped_reads += qcount[q];
         if (!solver && num_set == 0) continue;
         if (solver) S.solver_rows.push_back((uint32_t)S.segs.size());
         S.segs.push_back(std::move(col));
@@ -485,7 +504,7 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
     const double t1 = blk_now_ms();
     int rc = HP_OK;
     {
-        unsigned nt = std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+        unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
         if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
         nt = (unsigned)std::min<size_t>(nt, ch.blocks.size());
         std::vector<size_t> order(ch.blocks);
