@@ -55,7 +55,11 @@ struct PinBuf {
     }
 };
 
-constexpr uint32_t W2_HCAP_LOG2 = 11;   // 2048 keys (16 KiB) per group
+inline uint32_t w2_hcap_log2() {   // keys per group's capped-diagonal set: 2^n x 8 B (HP_WFA2_HCAP_LOG2 for experiments)
+    static const uint32_t v = [] { const char* e = std::getenv("HP_WFA2_HCAP_LOG2"); const int x = e ? std::atoi(e) : 11; return (uint32_t)std::min(14, std::max(6, x)); }();
+    return v;
+}
+#define W2_HCAP_LOG2 (w2_hcap_log2())
 constexpr uint32_t W2_GSET_STRIDE = W2Cfg<8>::SET_DWORDS;   // dwords per group, sized for the largest class
 
 // per-(thread, device) state that survives across calls

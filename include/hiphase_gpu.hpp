@@ -13,9 +13,10 @@
 //   variants.rs        VariantType, Variant (constructors, truncated / padded alleles, match_allele), closest_allele_clip
 //   wfa_graph.rs +     global_realignment_batch: WFAGraph::from_reference_variants_with_hom +
 //   read_parsing.rs      edit_distance_with_pruning + the node->allele mapping, for all records of a block at once;
-//                      local_realignment_batch; load_read_segments; load_full_read_segments (incl. the
-//                      order-dependent fallback replay); sequence_alignment::edit_distance
-//   phaser.rs          get_solution_span_counts, haplotag_reads, solve_block (from decoded records on)
+//                      local_realignment_batch; sequence_alignment::edit_distance
+//   phaser.rs          get_solution_span_counts, haplotag_reads; solve_block (from decoded records on) = ONE call into the
+//                      library (hp_solve_blocks): load_full_read_segments / load_read_segments with the fallback replay,
+//                      quality assignment, collapse, A*, span counts and haplotags run behind the C ABI
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -440,145 +441,6 @@ inline std::vector<LocalResult> local_realignment_batch(const std::vector<const 
     return out;
 }
 
-struct LoadedSegments {
-    std::vector<ReadSegment> read_segments, phasable_segments;   // first-seen qname order
-    LoadStats stats;
-};
-namespace detail {
-// collapse per qname + the min_matched_alleles split (read_parsing.rs:611-629 / :95-113)
-inline void finish_groups(const std::vector<std::string>& order, std::map<std::string, std::vector<ReadSegment>>& groups,
-                          size_t min_matched_alleles, LoadedSegments& out) {
-    for (const auto& q : order) {
-        auto& grp = groups[q];
-        ReadSegment col = ReadSegment::collapse(grp);
-        const size_t num_set = col.get_num_set();
-        if (num_set >= min_matched_alleles) { out.read_segments.push_back(col); out.stats.num_reads += grp.size(); }
-        else { out.stats.skipped_reads += grp.size(); if (num_set > 0) out.phasable_segments.push_back(col); }
-    }
-}
-inline void add_to_group(const std::string& q, ReadSegment seg, std::vector<std::string>& order, std::map<std::string, std::vector<ReadSegment>>& groups) {
-    auto it = groups.find(q);
-    if (it == groups.end()) { order.push_back(q); groups[q].push_back(std::move(seg)); }
-    else it->second.push_back(std::move(seg));
-}
-}  // namespace detail
-
-// load_read_segments (read_parsing.rs:47-113, --disable-global-realignment) over decoded records
-inline LoadedSegments load_read_segments(const std::vector<LocalRecord>& records, const std::vector<Variant>& variant_calls, size_t min_matched_alleles = 2) {
-    std::vector<const LocalRecord*> ptrs;
-    for (const auto& r : records) ptrs.push_back(&r);
-    const auto res = local_realignment_batch(ptrs, variant_calls);
-    LoadedSegments out;
-    std::vector<std::string> order;
-    std::map<std::string, std::vector<ReadSegment>> groups;
-    for (size_t i = 0; i < records.size(); ++i) {
-        if (res[i].stats.skipped_reads == 0) {
-            detail::add_to_group(records[i].qname, ReadSegment(records[i].qname, res[i].alleles, res[i].quals), order, groups);
-            out.stats.local_aligned += 1;
-        } else out.stats.skipped_reads += 1;
-    }
-    detail::finish_groups(order, groups, min_matched_alleles, out);
-    return out;
-}
-
-// load_full_read_segments (read_parsing.rs:520-637): one WFA batch for the block, then the order-dependent tail
-// replayed exactly as the reference runs it — Err(MaxEditDistance) -> local re-alignment of that record (:564-575);
-// the `global_disabled` switch (:597-600), whose counters advance only for records that were not skipped; qualities
-// 2 x base(type) for 0/1 alleles (:803-835); ReadSegment::new; collapse per qname; min_matched_alleles split.
-inline LoadedSegments load_full_read_segments(const std::vector<AlignedRecord>& records, const std::vector<Variant>& variant_calls,
-                                              const std::vector<Variant>& hom_calls, const Bytes& reference, uint64_t ref_base = 0,
-                                              size_t min_matched_alleles = 2, const GlobalRealignmentConfig& config = GlobalRealignmentConfig()) {
-    const size_t n_var = variant_calls.size(), n_rec = records.size();
-    struct Meta { bool any = false; size_t job = 0, first = 0, last = 0; };
-    std::vector<Meta> meta(n_rec);
-    std::vector<WfaJob> jobs;
-    for (size_t i = 0; i < n_rec; ++i) {
-        const AlignedRecord& rec = records[i];
-        size_t first = 0, last = 0;
-        if (!detail::overlap_range(variant_calls, rec.min_position, rec.max_position, first, last)) continue;   // :703-712
-        size_t hf = 0, hl = 0;
-        const bool homs = detail::overlap_range(hom_calls, rec.min_position, rec.max_position, hf, hl);
-        WfaJob j;
-        j.reference = &reference; j.ref_base = ref_base;
-        j.ref_start = (uint64_t)rec.min_position; j.ref_end = (uint64_t)rec.max_position + 1;
-        j.hets = variant_calls.data() + first; j.n_hets = last - first;
-        j.homs = homs ? hom_calls.data() + hf : nullptr; j.n_homs = homs ? hl - hf : 0;
-        j.read = &rec.read_align;
-        meta[i] = Meta{true, jobs.size(), first, last};
-        jobs.push_back(j);
-    }
-    const auto results = global_realignment_batch(jobs, config.wfa_prune_distance, config.max_edit_distance);
-
-    // A record's local result does not depend on any other record: the WFA failures are solved up front in one
-    // batch, everything after the `global_disabled` flip the first time the replay needs it.
-    std::map<size_t, LocalResult> local_rows;
-    auto solve_local = [&](std::vector<size_t> idx) {
-        std::vector<size_t> need;
-        std::vector<const LocalRecord*> ptrs;
-        for (size_t i : idx) {
-            if (local_rows.count(i)) continue;
-            if (!records[i].has_local) throw std::logic_error("record needs local re-alignment (read_parsing.rs:121-503), which needs its CIGAR: set AlignedRecord::local");
-            need.push_back(i);
-            ptrs.push_back(&records[i].local);
-        }
-        auto res = local_realignment_batch(ptrs, variant_calls);
-        for (size_t k = 0; k < need.size(); ++k) local_rows[need[k]] = std::move(res[k]);
-    };
-    {
-        std::vector<size_t> failed;
-        for (size_t i = 0; i < n_rec; ++i) if (meta[i].any && results[meta[i].job].max_edit_distance) failed.push_back(i);
-        solve_local(failed);
-    }
-    LoadedSegments out;
-    std::vector<std::string> order;
-    std::map<std::string, std::vector<ReadSegment>> groups;
-    bool global_disabled = false;
-    double num_global_failures = 0.0, total_parsed = 0.0;
-    for (size_t idx = 0; idx < n_rec; ++idx) {
-        const Meta& m = meta[idx];
-        if (!m.any) { out.stats.skipped_reads += 1; continue; }
-        const WfaOutcome& w = results[m.job];
-        Bytes alleles, quals;
-        uint64_t wfa_score;
-        bool skipped;
-        double local_aligned;
-        if (global_disabled || w.max_edit_distance) {
-            if (!local_rows.count(idx)) {
-                std::vector<size_t> rest;
-                for (size_t i = idx; i < n_rec; ++i) if (meta[i].any) rest.push_back(i);
-                solve_local(rest);
-            }
-            const LocalResult& l = local_rows[idx];
-            alleles = l.alleles; quals = l.quals;
-            wfa_score = config.max_edit_distance;
-            skipped = l.stats.skipped_reads == 1;
-            local_aligned = 1.0;
-        } else {
-            alleles.assign(n_var, (uint8_t)AlleleType::NoOverlap);
-            quals.assign(n_var, 0);
-            for (size_t i = m.first; i < m.last; ++i) {
-                alleles[i] = w.alleles[i - m.first];
-                if (alleles[i] < 2) quals[i] = (uint8_t)(2 * base_quality(variant_calls[i].variant_type));
-            }
-            wfa_score = w.score;
-            skipped = false;
-            local_aligned = 0.0;
-        }
-        if (skipped) { out.stats.skipped_reads += 1; continue; }
-        out.stats.local_aligned += (uint64_t)local_aligned;
-        out.stats.global_aligned += 1 - (uint64_t)local_aligned;
-        detail::add_to_group(records[idx].qname, ReadSegment(records[idx].qname, alleles, quals), order, groups);
-        out.stats.edit_distances.push_back(wfa_score);
-        num_global_failures += local_aligned;
-        total_parsed += 1.0;
-        if (!global_disabled && num_global_failures >= (double)config.global_failure_minimum &&
-            num_global_failures / total_parsed >= config.global_failure_ratio)
-            global_disabled = true;   // read_parsing.rs:597-600
-    }
-    detail::finish_groups(order, groups, min_matched_alleles, out);
-    return out;
-}
-
 // ---- phaser.rs -----------------------------------------------------------------------------------------------
 // get_solution_span_counts (phaser.rs:350-388): per juncture, the reads spanning it after trimming the ends of the
 // read that the solution leaves homozygous
@@ -623,36 +485,100 @@ struct PhaseResult {  // phaser.rs:326-343 (the solver-facing fields)
     LoadStats load_stats;
     std::vector<ReadSegment> read_segments;
 };
-// solve_block (phaser.rs:406-649) from the decoded records on: allele assignment (global: WFA batch + fallback
-// replay; else local re-alignment) -> matrix -> A* -> span counts -> sub-block split (:546-611) -> haplotags
+// solve_block (phaser.rs:406-649) from the decoded records on. ONE call into the library (hp_solve_blocks): graph-WFA for
+// every record with overlaps, the local fallback and the order-dependent `global_disabled` replay (read_parsing.rs:
+// 556-600), quality assignment, collapse per read name, the min_matched_alleles split, A*, span counts and haplotags
+// all run behind the C ABI; what is left here is marshalling, the PS tag walk (phaser.rs:557-565) and the sub-block
+// split (:569-611), which need the variant positions this side owns.
 inline PhaseResult solve_block(uint64_t block_index, const std::vector<AlignedRecord>& records, const std::vector<Variant>& variant_calls,
                                const std::vector<Variant>& hom_calls, const Bytes& reference, uint64_t ref_base = 0,
                                size_t min_matched_alleles = 2, uint64_t min_queue_size = 1000, uint64_t queue_increment = 3,
                                const GlobalRealignmentConfig* global_config = nullptr, bool global_realignment = true) {
     require(!variant_calls.empty(), "solve_block needs at least one variant");
-    LoadedSegments ls;
-    if (global_realignment) {
-        ls = load_full_read_segments(records, variant_calls, hom_calls, reference, ref_base, min_matched_alleles,
-                                     global_config ? *global_config : GlobalRealignmentConfig());
-    } else {
-        std::vector<LocalRecord> loc;
-        for (const auto& r : records) { require(r.has_local, "local mode needs the CIGAR view of every record"); loc.push_back(r.local); }
-        ls = load_read_segments(loc, variant_calls, min_matched_alleles);
+    const GlobalRealignmentConfig cfg = global_config ? *global_config : GlobalRealignmentConfig();
+    const size_t N = variant_calls.size(), R = records.size();
+    static const uint8_t none = 0;
+    static const uint32_t none32 = 0;
+    std::vector<hp_wfa_variant> hv, mv;
+    detail::pack_variants(variant_calls.data(), N, hv);
+    detail::pack_variants(hom_calls.data(), hom_calls.size(), mv);
+    Bytes types(N);
+    std::vector<Bytes> a0(N), a1(N);
+    std::vector<hp_local_variant> lv(N);
+    for (size_t i = 0; i < N; ++i) {
+        const Variant& v = variant_calls[i];
+        types[i] = (uint8_t)v.variant_type;
+        a0[i] = v.get_allele0(); a1[i] = v.get_allele1();
+        hp_local_variant w{};
+        w.position = v.position; w.ref_len = v.ref_len; w.variant_type = (uint32_t)v.variant_type;
+        w.prefix_len = (uint32_t)v.prefix.size(); w.postfix_len = (uint32_t)v.postfix.size();
+        w.allele0 = a0[i].empty() ? &none : a0[i].data(); w.allele1 = a1[i].empty() ? &none : a1[i].data();
+        w.allele0_len = (uint32_t)a0[i].size(); w.allele1_len = (uint32_t)a1[i].size();
+        w.flags = v.is_ignored ? HP_VAR_IGNORED : 0;
+        lv[i] = w;
     }
+    std::map<std::string, uint32_t> ids;
+    std::vector<std::string> names;
+    std::vector<hp_block_record> recs(std::max<size_t>(R, 1));
+    std::vector<hp_local_read> locs(std::max<size_t>(R, 1));
+    for (size_t i = 0; i < R; ++i) {
+        const AlignedRecord& r = records[i];
+        auto it = ids.find(r.qname);
+        if (it == ids.end()) { it = ids.emplace(r.qname, (uint32_t)names.size()).first; names.push_back(r.qname); }
+        hp_block_record& o = recs[i];
+        o = hp_block_record{};
+        o.qname_id = it->second;
+        if (global_realignment) {
+            o.min_position = r.min_position; o.max_position = r.max_position;
+            o.read_align = r.read_align.empty() ? &none : r.read_align.data(); o.read_len = (uint32_t)r.read_align.size();
+        } else {
+            require(r.has_local, "local mode needs the CIGAR view of every record");
+            o.min_position = o.max_position = r.local.pos;
+            o.read_align = &none;
+        }
+        if (r.has_local) {
+            const LocalRecord& l = r.local;
+            require(l.seq.size() == l.qual.size(), "assert_eq!(sequence length, quality length) (read_parsing.rs:155)");
+            hp_local_read& lr = locs[i];
+            lr = hp_local_read{};
+            lr.pos = l.pos; lr.cigar = l.cigar.empty() ? &none32 : l.cigar.data(); lr.n_cigar = (uint32_t)l.cigar.size();
+            lr.seq_len = (uint32_t)l.seq.size(); lr.seq = l.seq.empty() ? &none : l.seq.data(); lr.qual = l.qual.empty() ? &none : l.qual.data();
+            o.local = &lr;
+        }
+    }
+    hp_block_input in{};
+    in.block_index = block_index; in.reference = reference.empty() ? &none : reference.data(); in.ref_base = ref_base;
+    in.n_hets = (uint32_t)N; in.n_homs = (uint32_t)hom_calls.size(); in.n_records = (uint32_t)R; in.n_qnames = (uint32_t)names.size();
+    in.hets = hv.data(); in.het_types = types.data(); in.local_hets = lv.data(); in.homs = mv.empty() ? nullptr : mv.data(); in.records = recs.data();
+    hp_block_params prm{};
+    prm.astar = hp_astar_params{min_queue_size, queue_increment, 0, block_index};
+    prm.wfa_prune_distance = cfg.wfa_prune_distance == 0 ? UINT64_MAX : cfg.wfa_prune_distance;
+    prm.max_edit_distance = cfg.max_edit_distance;
+    prm.global_failure_ratio = cfg.global_failure_ratio; prm.global_failure_minimum = cfg.global_failure_minimum;
+    prm.min_matched_alleles = min_matched_alleles; prm.global_realignment = global_realignment ? 1u : 0u;
+    const size_t Q = std::max<size_t>(names.size(), 1);
     PhaseResult pr;
-    const AstarResult res = astar_solver(block_index, variant_calls, ls.read_segments, min_queue_size, queue_increment);
-    pr.haplotype_1 = res.haplotype_1;
-    pr.haplotype_2 = res.haplotype_2;
-    pr.statistics = res.statistics;
-    const auto spans = get_solution_span_counts(ls.read_segments, pr.haplotype_1, pr.haplotype_2);
+    pr.haplotype_1.assign(N, 0); pr.haplotype_2.assign(N, 0);
+    std::vector<uint64_t> spans(std::max<size_t>(N, 2) - 1), row_off(Q + 1), eds(std::max<size_t>(R, 1));
+    std::vector<uint32_t> qn(Q), st(Q), en(Q), fh(Q);
+    Bytes so(Q), ht(Q), al(Q * N + 1), ql(Q * N + 1);
+    hp_block_output out{};
+    out.h1 = pr.haplotype_1.data(); out.h2 = pr.haplotype_2.data(); out.span_counts = spans.data();
+    out.seg_qname = qn.data(); out.seg_start = st.data(); out.seg_end = en.data(); out.seg_solver = so.data();
+    out.seg_haplotag = ht.data(); out.seg_first_het = fh.data(); out.seg_row_off = row_off.data();
+    out.seg_alleles = al.data(); out.seg_quals = ql.data(); out.seg_cell_cap = Q * N + 1; out.edit_distances = eds.data();
+    check(hp_solve_blocks(1, &in, &prm, &out, -1), "hp_solve_blocks");
+    require(out.status == HP_OK, "block outside the device solver's limits (HP_BLOCK_UNSUPPORTED): solve it with the reference's own solve_block");
+    pr.statistics = PhaseStats{out.stats.pruned_solutions, out.stats.estimated_cost, out.stats.actual_cost, out.stats.phased_variants,
+                               out.stats.phased_snvs, out.stats.homozygous_variants, out.stats.skipped_variants};
     int64_t cur = variant_calls[0].position;
-    for (size_t i = 0; i < variant_calls.size(); ++i) {   // phaser.rs:557-565
+    for (size_t i = 0; i < N; ++i) {   // phaser.rs:557-565
         if (i > 0 && spans[i - 1] == 0) cur = variant_calls[i].position;
         pr.block_ids.push_back(cur);
     }
     std::vector<size_t> block;                            // phaser.rs:569-611
     int64_t cur_tag = pr.block_ids[0];
-    for (size_t i = 0; i < variant_calls.size(); ++i) {
+    for (size_t i = 0; i < N; ++i) {
         const uint8_t a = pr.haplotype_1[i], b = pr.haplotype_2[i];
         if (a < 2 && b < 2 && a != b) {
             if (cur_tag != pr.block_ids[i]) {
@@ -663,11 +589,22 @@ inline PhaseResult solve_block(uint64_t block_index, const std::vector<AlignedRe
         }
     }
     if (!block.empty()) pr.sub_phase_blocks.push_back(block);
-    pr.haplotags = haplotag_reads(ls.read_segments, pr.haplotype_1, pr.haplotype_2, pr.block_ids);
-    // reads with too few alleles to enter the solver are still tagged against the solution (phaser.rs:620-630)
-    for (auto& t : haplotag_reads(ls.phasable_segments, pr.haplotype_1, pr.haplotype_2, pr.block_ids)) pr.haplotags.push_back(t);
-    pr.load_stats = ls.stats;
-    pr.read_segments = std::move(ls.read_segments);
+    // solver segments first, then the phasable-only ones (the order haplotag_reads is called in, phaser.rs:614-630)
+    for (int pass = 0; pass < 2; ++pass)
+        for (uint32_t k = 0; k < out.n_segments; ++k) {
+            if ((so[k] != 0) != (pass == 0)) continue;
+            const Bytes a(al.begin() + row_off[k], al.begin() + row_off[k + 1]), q(ql.begin() + row_off[k], ql.begin() + row_off[k + 1]);
+            if (pass == 0) {
+                Bytes fa(N, (uint8_t)AlleleType::NoOverlap), fq(N, 0);
+                std::copy(a.begin(), a.end(), fa.begin() + st[k]);
+                std::copy(q.begin(), q.end(), fq.begin() + st[k]);
+                pr.read_segments.push_back(ReadSegment(names[qn[k]], fa, fq));
+            }
+            if (ht[k] != 2) pr.haplotags.push_back(Haplotag{names[qn[k]], pr.block_ids[fh[k]], ht[k]});
+        }
+    pr.load_stats.num_reads = out.num_reads; pr.load_stats.skipped_reads = out.skipped_reads;
+    pr.load_stats.global_aligned = out.global_aligned; pr.load_stats.local_aligned = out.local_aligned;
+    pr.load_stats.edit_distances.assign(eds.begin(), eds.begin() + out.n_edit_distances);
     return pr;
 }
 
