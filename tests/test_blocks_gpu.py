@@ -147,3 +147,38 @@ def test_block_queue_over_devices(monkeypatch):
         assert np.array_equal(a.haplotype_1, b.haplotype_1) and np.array_equal(a.haplotype_2, b.haplotype_2)
         assert a.statistics == b.statistics and a.segments == b.segments and a.haplotags == b.haplotags
         assert a.span_counts.tolist() == b.span_counts.tolist() and a.edit_distances == b.edit_distances
+
+
+@pytest.mark.timeout(900)
+def test_bench_path_two_ranks_gloo():
+    """bench.py's N > 1 control flow for the whole-path workload (one process per rank, own blocks per rank, barrier +
+    max-over-ranks timing, no block data between ranks), on this 1-GPU box with the gloo backend and both ranks on GPU 0."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--total-hets", "2500", "--no-cpu"], capture_output=True, text=True, timeout=800, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["hets_per_step_per_gpu"] == 2500
+
+
+@pytest.mark.skipif(False, reason="")
+def test_rank_workloads_are_disjoint_and_deterministic():
+    from hiphase_amd.synth_reads import synth_wgs_like_mix
+    a0 = synth_wgs_like_mix(20250928 + 0, 300)
+    a1 = synth_wgs_like_mix(20250928 + 1, 300)
+    b0 = synth_wgs_like_mix(20250928 + 0, 300)
+    assert [blk.reference for blk in a0] == [blk.reference for blk in b0]
+    assert [r.read_align for blk in a0 for r in blk.records] == [r.read_align for blk in b0 for r in blk.records]
+    assert {blk.reference for blk in a0}.isdisjoint({blk.reference for blk in a1})
