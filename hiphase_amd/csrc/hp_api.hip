@@ -76,6 +76,37 @@ int device_cu_count(int device_id) {
     return v;
 }
 
+thread_local int g_cu_partition = 0;
+
+// bit i of a CU mask: row a = i / 32, column b = i % 32. Whether the driver deals mask bits to the XCDs in blocks or
+// round-robin is not documented; "(a + b) % 8 == 0" selects four CUs of every XCD either way (256 CUs, 8 XCDs).
+static bool cu_in_search_partition(int i) {
+    static const int mod = [] { const char* e = std::getenv("HP_SEARCH_CU_MOD"); const int v = e ? std::atoi(e) : 8; return (v == 2 || v == 4 || v == 8) ? v : 8; }();
+    return ((i / 32 + i % 32) % mod) == 0;
+}
+
+int partition_cu_count(int device_id) {
+    const int n = device_cu_count(device_id);
+    if (g_cu_partition == 0) return n;
+    int s = 0;
+    for (int i = 0; i < n; ++i) s += cu_in_search_partition(i) ? 1 : 0;
+    return g_cu_partition == 1 ? std::max(1, s) : std::max(1, n - s);
+}
+
+hipError_t hp_stream_create(hipStream_t* s, int device_id, bool high_priority) {
+    if (g_cu_partition == 0) {
+        if (!high_priority) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_hi);
+    }
+    const int n = device_cu_count(device_id);
+    std::vector<uint32_t> mask((size_t)(n + 31) / 32, 0u);
+    for (int i = 0; i < n; ++i)
+        if (cu_in_search_partition(i) == (g_cu_partition == 1)) mask[(size_t)i / 32] |= 1u << (i % 32);
+    return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
+}
+
 void dev_cache_put(void* p, size_t bytes, int dev) {   // dev: what dev_cache_get reported for this block
     if (g_dev_cache_dead) { (void)hipFree(p); return; }
     DevCache& c = g_dev_cache;

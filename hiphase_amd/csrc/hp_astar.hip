@@ -247,17 +247,14 @@ using namespace hp;
 // Streams and events of a batch come from a per-thread pool (creating two streams and four events costs milliseconds,
 // which matters when a caller solves one small block per call).
 struct StreamSet {
-    int device = -1;
+    int device = -1, partition = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     bool create(int dev) {
-        device = dev;
+        device = dev; partition = g_cu_partition;
         // the segment stream carries the critical path: a high-priority stream also gets a hardware queue of its own
         // (streams of equal priority may share one when the host process has created many, e.g. under PyTorch)
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        return hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
-               hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+        return hp_stream_create(&stream, dev) == hipSuccess && hp_stream_create(&stream2, dev, true) == hipSuccess &&
                hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess &&
                hipEventCreate(&ev_fork) == hipSuccess && hipEventCreate(&ev_join) == hipSuccess;
     }
@@ -277,7 +274,7 @@ struct StreamPool {
     ~StreamPool() { for (auto& s : free_) s.destroy(); free_.clear(); g_stream_pool_dead = true; }
     bool get(int dev, StreamSet& out) {
         for (size_t i = 0; i < free_.size(); ++i)
-            if (free_[i].device == dev) { out = free_[i]; free_.erase(free_.begin() + i); return true; }
+            if (free_[i].device == dev && free_[i].partition == g_cu_partition) { out = free_[i]; free_.erase(free_.begin() + i); return true; }
         return out.create(dev);
     }
     void put(StreamSet& s) {
@@ -289,6 +286,7 @@ thread_local StreamPool g_stream_pool;
 
 struct hp_batch {
     int device = 0;
+    int partition = 0;   // CU partition its streams were created in (hp_common.h)
     hipStream_t stream = nullptr;
     size_t n_blocks = 0;
     hp_astar_params params{};
@@ -314,7 +312,7 @@ struct hp_batch {
     uint64_t caller_rows = 0, n_rows_packed = 0, n_junctures = 0;
     bool solved = false;
     // segment-parallel heuristic (large blocks on an otherwise idle GPU)
-    DevBuf d_segs, d_seg_order, d_seg_out, d_seg_off, d_sb_first, d_sb_n, d_sb_id, s_seg_pool;
+    DevBuf d_segs, d_seg_order, d_seg_out, d_seg_off, d_seg_retry, d_sb_first, d_sb_n, d_sb_id, s_seg_pool;
     uint32_t last_n_segs = 0;
     // second stream + scratch: segmented blocks run beside the sequential pass of all the others
     hipStream_t stream2 = nullptr;
@@ -332,7 +330,7 @@ struct hp_batch {
         if (stream2) (void)hipStreamSynchronize(stream2);
         if (stream) (void)hipStreamSynchronize(stream);
         StreamSet ss;
-        ss.device = device; ss.stream = stream; ss.stream2 = stream2; ss.ev0 = ev0; ss.ev1 = ev1; ss.ev_fork = ev_fork; ss.ev_join = ev_join;
+        ss.device = device; ss.partition = partition; ss.stream = stream; ss.stream2 = stream2; ss.ev0 = ev0; ss.ev1 = ev1; ss.ev_fork = ev_fork; ss.ev_join = ev_join;
         if (stream && stream2 && ev0 && ev1 && ev_fork && ev_join) g_stream_pool.put(ss); else ss.destroy();
     }
 };
@@ -357,8 +355,15 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     const char* tenv = std::getenv("HP_SEG_TARGET");
     uint64_t target = tenv ? (uint64_t)std::atoll(tenv) : std::max<uint64_t>(64, total / max_slots);
     target = std::max<uint64_t>(64, (target + 63) / 64 * 64);
+    // Two rounds: a short warm-up first (64 variants close every seam of the synthetic mixes; the chain forgets its start
+    // after a few dozen variants), then only the segments below a seam that stayed open are solved again with the long
+    // one (160: scripts/spec_converge.py found 120 sufficient at 1 % and 15 % error). The seam check decides, so both
+    // lengths only matter for speed. HP_SEG_WARM / HP_SEG_WARM2 override them; WARM >= WARM2 means one round.
     const char* wenv = std::getenv("HP_SEG_WARM");
-    const uint32_t warm = wenv ? (uint32_t)std::atoi(wenv) : 160;
+    const char* wenv2 = std::getenv("HP_SEG_WARM2");
+    const uint32_t warm = wenv ? (uint32_t)std::atoi(wenv) : 64;
+    const uint32_t warm2 = wenv2 ? (uint32_t)std::atoi(wenv2) : 160;
+    const bool two_rounds = warm < warm2;
     std::vector<SegDesc>& segs = b->h_segs;
     std::vector<uint32_t>&sb_first = b->h_sb_first, &sb_n = b->h_sb_n, &sb_id = b->h_sb_id;
     (void)hipStreamSynchronize(st);   // a previous solve's uploads from these tables are long done; make it certain before they change
@@ -375,7 +380,7 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
             sd.blk = i;
             sd.a = (uint32_t)(k * target);
             sd.b = (k + 1 == ns) ? N : (uint32_t)((k + 1) * target);
-            sd.v0 = (k + 1 == ns) ? N : std::min<uint32_t>(N, sd.b + warm);
+            sd.v0 = (k + 1 == ns) ? N : std::min<uint32_t>(N, sd.b + std::max(warm, 1u));
             segs.push_back(sd);
         }
     }
@@ -393,8 +398,9 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     if ((rc = upload(b->d_segs, segs, st)) || (rc = upload(b->d_seg_order, order, st)) || (rc = upload(b->d_sb_first, sb_first, st)) ||
         (rc = upload(b->d_sb_n, sb_n, st)) || (rc = upload(b->d_sb_id, sb_id, st)))
         return rc;
-    if ((rc = b->d_seg_out.alloc(segs.size() * sizeof(SegOut))) || (rc = b->d_seg_off.alloc(segs.size() * 8))) return rc;
+    if ((rc = b->d_seg_out.alloc(segs.size() * sizeof(SegOut))) || (rc = b->d_seg_off.alloc(segs.size() * 8)) || (rc = b->d_seg_retry.alloc(segs.size()))) return rc;
     HP_HIP_CHECK(hipMemsetAsync(b->d_seg_off.p, 0, segs.size() * 8, st));
+    HP_HIP_CHECK(hipMemsetAsync(b->d_seg_retry.p, 0, segs.size(), st));
     SegBatchDev S{};
     BatchDev& B = S.B;
     B.desc = b->d_desc.as<BlockDesc>();
@@ -407,15 +413,21 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     B.prm = prm;
     S.segs = b->d_segs.as<SegDesc>(); S.seg_order = b->d_seg_order.as<uint32_t>(); S.n_segs = (uint32_t)segs.size();
     S.out = b->d_seg_out.as<SegOut>();
-    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] segment-parallel heuristic: %zu segments of ~%llu hets (+%u warm-up) over %zu blocks, slots=%u\n", segs.size(), (unsigned long long)target, warm, sb_id.size(), slots); fflush(stderr); }
-    if (b->tiles == 2) hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 2>), dim3(slots), dim3(64), lds_bytes, st, S);
-    else hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 1>), dim3(slots), dim3(64), lds_bytes, st, S);
+    S.run_flag = nullptr; S.warm = 0;
+    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] segment-parallel heuristic: %zu segments of ~%llu hets (+%u warm-up, open seams again with +%u) over %zu blocks, slots=%u\n", segs.size(), (unsigned long long)target, warm, two_rounds ? warm2 : warm, sb_id.size(), slots); fflush(stderr); }
     StitchDev T{};
     T.desc = B.desc; T.segs = S.segs; T.out = S.out;
     T.blk_first_seg = b->d_sb_first.as<uint32_t>(); T.blk_n_seg = b->d_sb_n.as<uint32_t>(); T.blk_id = b->d_sb_id.as<uint32_t>();
     T.n_seg_blocks = (uint32_t)sb_id.size(); T.H = B.H; T.seg_offset = b->d_seg_off.as<uint64_t>();
     T.status = b->d_status.as<int32_t>(); T.counters = b->d_counters.as<hp_work_counters>();
-    hipLaunchKernelGGL(hp_heur_stitch_kernel, dim3((T.n_seg_blocks + 63) / 64), dim3(64), 0, st, T);
+    T.retry = b->d_seg_retry.as<uint8_t>();
+    for (int round = 0; round < (two_rounds ? 2 : 1); ++round) {
+        if (round == 1) { S.run_flag = T.retry; S.warm = warm2; }
+        T.final_round = (round == 1 || !two_rounds) ? 1u : 0u;
+        if (b->tiles == 2) hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 2>), dim3(slots), dim3(64), lds_bytes, st, S);
+        else hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 1>), dim3(slots), dim3(64), lds_bytes, st, S);
+        hipLaunchKernelGGL(hp_heur_stitch_kernel, dim3((T.n_seg_blocks + 63) / 64), dim3(64), 0, st, T);
+    }
     ApplyDev A{};
     A.segs = S.segs; A.seg_offset = T.seg_offset; A.desc = B.desc; A.n_segs = S.n_segs; A.H = B.H;
     hipLaunchKernelGGL(hp_heur_apply_kernel, dim3(S.n_segs), dim3(256), 0, st, A);
@@ -622,11 +634,11 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
         for (size_t i = 0; i < n_blocks; ++i) nj += blks[i].n_variants ? blks[i].n_variants - 1 : 0;
         if (b->n_rows_packed >= 0xFFFFFFF0ull || nj >= 0xFFFFFFF0ull) { set_error("batch with %llu rows / %llu junctures exceeds 2^32: split it", (unsigned long long)b->n_rows_packed, (unsigned long long)nj); return fail(HP_ERR_UNSUPPORTED); }
     }
-    b->n_cu = device_cu_count(device_id);
+    b->n_cu = partition_cu_count(device_id);
     {
         StreamSet ss;
         const bool ok = g_stream_pool.get(device_id, ss);
-        b->stream = ss.stream; b->stream2 = ss.stream2; b->ev0 = ss.ev0; b->ev1 = ss.ev1; b->ev_fork = ss.ev_fork; b->ev_join = ss.ev_join;
+        b->partition = ss.partition; b->stream = ss.stream; b->stream2 = ss.stream2; b->ev0 = ss.ev0; b->ev1 = ss.ev1; b->ev_fork = ss.ev_fork; b->ev_join = ss.ev_join;
         if (!ok) { set_error("creating the streams/events of a batch failed"); return fail(HP_ERR_HIP); }
     }
 

@@ -1266,13 +1266,17 @@ struct SegBatchDev {
     const uint32_t* seg_order;
     uint32_t n_segs;
     SegOut* out;
+    const uint8_t* run_flag;   // second round: only the segments below a seam the first round's warm-up did not close
+    uint32_t warm;             // second round: warm-up length that replaces SegDesc::v0 (0 = first round)
 };
 
 template <bool SUB_LDS, int TILES>
 DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
+    if (S.run_flag && !S.run_flag[seg]) return;
     const BatchDev& B = S.B;
     const SolveParams& prm = B.prm;
-    const SegDesc sd = S.segs[seg];
+    SegDesc sd = S.segs[seg];
+    if (S.warm) sd.v0 = min(B.desc[sd.blk].n_vars, sd.b + S.warm);   // (the top segment ends at N: it has no warm-up)
     const BlockDesc d = B.desc[sd.blk];
     const uint32_t N = d.n_vars;
     const uint32_t lane = lane_id();
@@ -1377,23 +1381,32 @@ struct StitchDev {
     uint64_t* seg_offset;            // per segment: what to add to its owned H values
     int32_t* status;
     hp_work_counters* counters;
+    uint8_t* retry;                  // first of two rounds: flags the segment below every seam that did not close
+    uint32_t final_round;            // 1: a seam that does not close sends the block down the sequential path
 };
 __global__ void __launch_bounds__(64) hp_heur_stitch_kernel(StitchDev T) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T.n_seg_blocks) return;
     const uint32_t blk = T.blk_id[t], s0 = T.blk_first_seg[t], ns = T.blk_n_seg[t];
+    if (T.status[blk] == ST_H_READY) return;   // accepted by the first round
     const BlockDesc d = T.desc[blk];
     const uint64_t* H = T.H + d.h_off;
     bool ok = T.out[s0 + ns - 1].status == ST_OK;
     hp_work_counters tot = T.out[s0 + ns - 1].ctr;
     T.seg_offset[s0 + ns - 1] = 0;
-    for (uint32_t k = ns - 1; ok && k-- > 0;) {
+    // every seam is checked on its own in the first round (a segment is solved again with the long warm-up iff ITS
+    // seam is open); in the final round the first open seam ends the walk
+    for (uint32_t k = ns - 1; (ok || !T.final_round) && k-- > 0;) {
         const uint32_t seg = s0 + k, above = seg + 1;
         const SegOut& o = T.out[seg];
         const uint32_t b = T.segs[seg].b;
-        ok = ok && o.status == ST_OK && o.clip_at_b == T.out[above].clip_out;
-        for (uint32_t j = 1; ok && j < SEG_STATE && b + j <= d.n_vars; ++j)
-            ok = (o.seam[j] - o.seam[0]) == (H[b + j] - H[b]);   // identical look-ahead state (differences)
+        bool closed = o.status == ST_OK && o.clip_at_b == T.out[above].clip_out;
+        for (uint32_t j = 1; closed && j < SEG_STATE && b + j <= d.n_vars; ++j)
+            closed = (o.seam[j] - o.seam[0]) == (H[b + j] - H[b]);   // identical look-ahead state (differences)
+        if (!closed) {
+            ok = false;
+            if (!T.final_round) T.retry[seg] = 1;
+        }
         if (ok) {
             T.seg_offset[seg] = T.seg_offset[above] + H[b] - o.seam[0];
             tot.sub_pops += o.ctr.sub_pops; tot.evals += o.ctr.evals; tot.cells += o.ctr.cells; tot.nodes_created += o.ctr.nodes_created;
@@ -1403,7 +1416,7 @@ __global__ void __launch_bounds__(64) hp_heur_stitch_kernel(StitchDev T) {
         T.counters[blk] = tot;
         T.status[blk] = ST_H_READY;
     } else {
-        for (uint32_t k = 0; k < ns; ++k) T.seg_offset[s0 + k] = 0;   // block falls back to the sequential chain
+        for (uint32_t k = 0; k < ns; ++k) T.seg_offset[s0 + k] = 0;   // final round: the block falls back to the sequential chain
     }
 }
 struct ApplyDev {

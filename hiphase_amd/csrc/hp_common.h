@@ -32,6 +32,14 @@ void dev_cache_put(void* p, size_t bytes, int dev);
 // number of compute units of a device, queried once (hipGetDeviceProperties costs milliseconds per call)
 int device_cu_count(int device_id);
 
+// CU partitions (block pipeline, hp_block.hip): while the graph-WFA of one chunk of blocks runs, the search of the chunk
+// before it runs on compute units of its own. 0 = the whole device; 1 = the search partition (one CU in eight, the same
+// number in every XCD); 2 = the other seven. The setting is per thread: a stream created while it is set is bound to
+// that partition's CUs (and gets a hardware queue of its own), and the persistent kernels size their grids to it.
+extern thread_local int g_cu_partition;
+hipError_t hp_stream_create(hipStream_t* s, int device_id, bool high_priority = false);
+int partition_cu_count(int device_id);   // CUs of the calling thread's current partition
+
 // RAII device buffer
 struct DevBuf {
     void* p = nullptr;

@@ -70,14 +70,27 @@ struct W2Context {
     uint32_t htab_groups = 0;
     uint32_t tag_next = 0;   // tags handed out so far (tag 0 = empty)
     DevBuf qhead;            // work-queue heads of the class launches
-    hipStream_t cstream[3] = {nullptr, nullptr, nullptr};   // one stream per graph-size class: the three launches overlap
+    // streams per CU partition (hp_common.h): the main stream, and one per graph-size class (the three launches overlap)
+    struct Streams { hipStream_t stream = nullptr; hipStream_t cstream[3] = {nullptr, nullptr, nullptr}; } ps[3];
     hipEvent_t cfork = nullptr, cjoin[3] = {nullptr, nullptr, nullptr};
     PinBuf stage;            // upload staging: seq bytes, then the tables
     PinBuf down;             // download staging
-    hipStream_t stream = nullptr;
+    void drop_streams() {
+        for (auto& s : ps) {
+            if (s.stream) { (void)hipStreamDestroy(s.stream); s.stream = nullptr; }
+            for (int k = 0; k < 3; ++k) if (s.cstream[k]) { (void)hipStreamDestroy(s.cstream[k]); s.cstream[k] = nullptr; }
+        }
+    }
+    int streams(int part, Streams** out) {   // created on first use in that partition
+        Streams& s = ps[part];
+        if (!s.stream) HP_HIP_CHECK(hp_stream_create(&s.stream, device));
+        for (int k = 0; k < 3; ++k) if (!s.cstream[k]) HP_HIP_CHECK(hp_stream_create(&s.cstream[k], device));
+        *out = &s;
+        return HP_OK;
+    }
     ~W2Context() {
-        if (stream) (void)hipStreamDestroy(stream);
-        for (int k = 0; k < 3; ++k) { if (cstream[k]) (void)hipStreamDestroy(cstream[k]); if (cjoin[k]) (void)hipEventDestroy(cjoin[k]); }
+        drop_streams();
+        for (int k = 0; k < 3; ++k) if (cjoin[k]) (void)hipEventDestroy(cjoin[k]);
         if (cfork) (void)hipEventDestroy(cfork);
     }
 };
@@ -253,11 +266,12 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     W2Context& cx = g_w2;
     if (cx.device != device_id) {
         cx.htab.release(); cx.gsets.release(); cx.htab_groups = 0; cx.tag_next = 0;
-        if (cx.stream) { (void)hipStreamDestroy(cx.stream); cx.stream = nullptr; }
+        cx.drop_streams();
         cx.device = device_id;
     }
-    if (!cx.stream) HP_HIP_CHECK(hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking));
-    hipStream_t st = cx.stream;
+    W2Context::Streams* cs_ = nullptr;
+    { const int rc0 = cx.streams(g_cu_partition, &cs_); if (rc0 != HP_OK) return rc0; }
+    hipStream_t st = cs_->stream;
     struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{st};
 
     // ---- 2. stage + upload -----------------------------------------------------------------------------------------------
@@ -319,10 +333,12 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     const double t0 = w2_now_ms();
     g_last_kernel_ms = 0.0;
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
-    const int n_cu = device_cu_count(device_id);
+    const int n_cu = partition_cu_count(device_id);
     W2Context& cx = g_w2;
-    if (cx.device != device_id || !cx.stream) { set_error("WFA session used from another thread or device than it was prepared on"); return HP_ERR_ARG; }
-    hipStream_t st = cx.stream;
+    if (cx.device != device_id) { set_error("WFA session used from another thread or device than it was prepared on"); return HP_ERR_ARG; }
+    W2Context::Streams* cs_ = nullptr;
+    { const int rc0 = cx.streams(g_cu_partition, &cs_); if (rc0 != HP_OK) return rc0; }
+    hipStream_t st = cs_->stream;
     int rc;
     // host tables that stream operations read or write; the guard below (destroyed first) drains the stream on every
     // exit path, so none of them goes out of scope with a copy in flight
@@ -332,7 +348,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     std::vector<uint64_t> score(n);
     std::vector<uint8_t> al((size_t)std::max<uint64_t>(allele_tot, 1));
     std::vector<uint32_t> work(n * 2);
-    struct StreamDrain { hipStream_t s; W2Context* c; ~StreamDrain() { for (int k = 0; k < 3; ++k) if (c->cstream[k]) (void)hipStreamSynchronize(c->cstream[k]); (void)hipStreamSynchronize(s); } } drain{st, &cx};
+    struct StreamDrain { hipStream_t s; W2Context::Streams* c; ~StreamDrain() { for (int k = 0; k < 3; ++k) if (c->cstream[k]) (void)hipStreamSynchronize(c->cstream[k]); (void)hipStreamSynchronize(s); } } drain{st, cs_};
     const double t_stage = t0;
 
     // ---- 3. graphs on the device ----------------------------------------------------------------------------------------
@@ -386,7 +402,6 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         cx.tag_next = 0;
     }
     for (int k = 0; k < 3; ++k) {
-        if (!cx.cstream[k]) HP_HIP_CHECK(hipStreamCreateWithFlags(&cx.cstream[k], hipStreamNonBlocking));
         if (!cx.cjoin[k]) HP_HIP_CHECK(hipEventCreateWithFlags(&cx.cjoin[k], hipEventDisableTiming));
     }
     if (!cx.cfork) HP_HIP_CHECK(hipEventCreateWithFlags(&cx.cfork, hipEventDisableTiming));
@@ -410,7 +425,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     uint32_t groups_used[3] = {0, 0, 0};
     for (int k = 0; k < 3; ++k) {
         if (cls[k].empty()) continue;
-        hipStream_t cs = cx.cstream[k];
+        hipStream_t cs = cs_->cstream[k];
         HP_HIP_CHECK(hipStreamWaitEvent(cs, cx.cfork, 0));
         B.order = d_order.as<uint32_t>() + cls_off[k];
         B.n_items = (uint32_t)cls[k].size();

@@ -5,7 +5,7 @@
 //   vars[]     W2Variant: every distinct hp_wfa_variant of the batch ONCE (the reads of a block pass slices of the
 //              block's variant vectors; the host merges their address ranges like it merges the reference windows)
 //   jobs[]     W2Job: window + variant index ranges + read + where the job's graph lives
-//   gnodes[]   W2Node (12 B): the job's graph, written by w2_build (one thread per job, hp_wfa2_build_kernel)
+//   gnodes[]   W2Node (16 B): the job's graph, written by w2_build (one thread per job, hp_wfa2_build_kernel)
 //   gedges[]   u16 children lists (creation order is irrelevant to the results: injections are set unions)
 //   gtags[]    node -> (het index, allele) table (wfa_graph.rs:19 NodeAlleleMap), in node order
 // w2_build restates WFAGraph::from_reference_variants_with_hom (wfa_graph.rs:119-284) over sequence SPANS; it is plain
@@ -45,10 +45,12 @@ struct W2Job {              // 80 B
     uint32_t group;               // caller-defined (block-level path: qname group); unused by the WFA stage
 };
 
-struct W2Node {             // 12 B, the LDS copy has the same layout
+struct W2Node {             // 16 B: one aligned 16-byte load per node visit
     uint32_t seq_off;       // reference node: offset inside the job's window; allele node: offset in the allele pool
     uint32_t len_ref;       // length | is_reference << 31
     uint32_t child;         // child_off | n_children << 16   (child_off relative to the job's edge list)
+    uint32_t c01;           // the first two children inline (child 0 | child 1 << 16): most nodes have at most two, and a
+                            // wave that finishes the node needs them at once (the edge list is a dependent load away)
 };
 constexpr uint32_t W2_IS_REF = 0x80000000u;
 
@@ -90,6 +92,7 @@ HP_HD void w2_build(const W2Job& J, const W2Variant* vars, W2Node* nodes, uint16
         nodes[nn].seq_off = seq_off;
         nodes[nn].len_ref = len | (is_ref ? W2_IS_REF : 0u);
         nodes[nn].child = 0;
+        nodes[nn].c01 = 0;
         for (int k = 0; k < nrr; ++k) par[ne + k] = (uint16_t)rr[k];
         ne += (uint32_t)nrr;
         poff[nn + 1] = ne;
@@ -196,9 +199,14 @@ HP_HD void w2_build(const W2Job& J, const W2Variant* vars, W2Node* nodes, uint16
             cnt[n] = run;
             run += c;
         }
-        if (status == W2B_OK)
+        if (status == W2B_OK) {
             for (uint32_t n = 1; n < nn; ++n)
                 for (uint32_t e = poff[n]; e < poff[n + 1]; ++e) edges[cnt[par[e]]++] = (uint16_t)n;
+            for (uint32_t n = 0; n < nn; ++n) {
+                const uint32_t co = nodes[n].child & 0xFFFFu, nc = nodes[n].child >> 16;
+                nodes[n].c01 = (nc > 0 ? (uint32_t)edges[co] : 0u) | (nc > 1 ? (uint32_t)edges[co + 1] << 16 : 0u);
+            }
+        }
     }
     info->n_nodes = nn;
     info->n_edges = ne;

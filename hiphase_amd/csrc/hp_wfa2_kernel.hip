@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
     // registers (node 0xFFFF = free; up to MAXPAR parent-entry codes, one byte each)
     uint32_t pq_node = 0xFFFFu, pq_cnt = 0, pq_c0 = 0, pq_c1 = 0;
     // current node / item
-    uint32_t n = 0, len = 0, child_off = 0, n_child = 0, n_items = 0, item = 0, npar = 0, pc0 = 0, pc1 = 0;
+    uint32_t n = 0, len = 0, child_off = 0, n_child = 0, c01 = 0, n_items = 0, item = 0, npar = 0, pc0 = 0, pc1 = 0;
     const uint8_t* nseq = altp;
     bool hp0 = false, hp1 = false, use_list = false;
     int32_t a0 = 0, b0 = 0, o0 = 0, a1 = 0, b1 = 0, o1 = 0;   // previous entries of n: live diagonals [a, b], slot of diagonal d = o + d
@@ -261,7 +261,8 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
             fcnt++;
         }
         if (fn)
-            for (uint32_t j = 0; j < n_child; ++j) pq_append(C::DESC_LDS ? (uint32_t)edg[child_off + j] : (uint32_t)gedge[child_off + j], code);
+            for (uint32_t j = 0; j < n_child; ++j)
+                pq_append(C::DESC_LDS ? (uint32_t)edg[child_off + j] : (j == 0 ? (c01 & 0xFFFFu) : (j == 1 ? (c01 >> 16) : (uint32_t)gedge[child_off + j])), code);
         chi = INT32_MIN; cvlo = INT32_MAX; cvhi = INT32_MIN; cflo = INT32_MAX; cfhi = INT32_MIN;
     };
 
@@ -361,10 +362,10 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                         nseq = (((nd.y >> 18) & 1u) ? refp : altp) + nd.x;
                         child_off = (nd.y >> 19) & 1023u; n_child = nd.y >> 29;
                     } else {
-                        const W2Node nd = gnode[n];
-                        len = nd.len_ref & ~W2_IS_REF;
-                        nseq = ((nd.len_ref & W2_IS_REF) ? refp : altp) + nd.seq_off;
-                        child_off = nd.child & 0xFFFFu; n_child = nd.child >> 16;
+                        const uint4 nd = *reinterpret_cast<const uint4*>(gnode + n);   // seq_off, len | is_ref, children, first two children
+                        len = nd.y & ~W2_IS_REF;
+                        nseq = ((nd.y & W2_IS_REF) ? refp : altp) + nd.x;
+                        child_off = nd.z & 0xFFFFu; n_child = nd.z >> 16; c01 = nd.w;
                     }
                 }
                 // ---- sources: previous entries of n grown by one diagonal a side, finished parents, the start wave ----
@@ -664,35 +665,27 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
         if (run) {
             const uint64_t fm = w2_gballot<G>(kind == W2_KIND_FINISHED, gbase);
             uint64_t rem = fm | w2_gballot<G>(kind == W2_KIND_INTERIOR || kind == W2_KIND_INTERIOR_READ || kind == W2_KIND_END_LAST, gbase);
-            const bool item_end = base + (int32_t)G > hi;   // the item ends with this tile: flush the last cluster
-            bool simple = false;
-            if (rem) {
-                const int f = __builtin_ctzll(rem), l = 63 - __builtin_clzll(rem);
-                const uint64_t z = ~rem & (((2ull << l) - 1ull) & ~((1ull << f) - 1ull));   // empty diagonals between the first and the last
-                simple = (z & (z >> 1) & (z >> 2)) == 0;                                     // no three in a row: one run
-            }
-            if (simple) {
-                const int f = __builtin_ctzll(rem), l = 63 - __builtin_clzll(rem);
-                const uint64_t lmk = rem & ~fm;
-                if (chi != INT32_MIN && ((base + f) - chi >= 3 || (base + l) - clo >= (int32_t)C::MAXW)) emit_cluster();
-                if (chi == INT32_MIN) clo = base + f;
-                chi = base + l;
-                if (fm) { cflo = min(cflo, base + (int32_t)__builtin_ctzll(fm)); cfhi = max(cfhi, base + 63 - (int32_t)__builtin_clzll(fm)); }
-                if (lmk) { cvlo = min(cvlo, base + (int32_t)__builtin_ctzll(lmk)); cvhi = max(cvhi, base + 63 - (int32_t)__builtin_clzll(lmk)); }
-                rem = 0;
-            }
-            bool end_pending = item_end;
+            // one pass per run of diagonals (gaps of at most two inside a run); the item's last tile flushes the open cluster
+            bool end_pending = base + (int32_t)G > hi;
             while (rem || end_pending) {
-                int32_t dd = INT32_MAX / 2;
-                int bpos = 0;
+                int32_t first = INT32_MAX / 2, lastd = INT32_MAX / 2;
+                uint64_t rm = 0;
                 const bool bit = rem != 0;
-                if (bit) { bpos = __builtin_ctzll(rem); rem &= rem - 1; dd = base + bpos; } else end_pending = false;
-                if (chi != INT32_MIN && (dd - chi >= 3 || dd - clo >= (int32_t)C::MAXW)) emit_cluster();
                 if (bit) {
-                    if (chi == INT32_MIN) clo = dd;
-                    chi = dd;
-                    if ((fm >> bpos) & 1ull) { cflo = min(cflo, dd); cfhi = max(cfhi, dd); }
-                    else { cvlo = min(cvlo, dd); cvhi = max(cvhi, dd); }
+                    const int f = __builtin_ctzll(rem);
+                    const uint64_t z = ~(rem >> f);
+                    const int e = __builtin_ctzll(z & (z >> 1) & (z >> 2));   // the run is bits [f, f + e)
+                    rm = rem & ((1ull << (f + e)) - 1ull);
+                    rem &= ~rm;
+                    first = base + f; lastd = base + f + e - 1;
+                } else end_pending = false;
+                if (chi != INT32_MIN && (first - chi >= 3 || lastd - clo >= (int32_t)C::MAXW)) emit_cluster();
+                if (bit) {
+                    if (chi == INT32_MIN) clo = first;
+                    chi = lastd;
+                    const uint64_t fr = fm & rm, lr = rm & ~fm;
+                    if (fr) { cflo = min(cflo, base + (int32_t)__builtin_ctzll(fr)); cfhi = max(cfhi, base + 63 - (int32_t)__builtin_clzll(fr)); }
+                    if (lr) { cvlo = min(cvlo, base + (int32_t)__builtin_ctzll(lr)); cvhi = max(cvhi, base + 63 - (int32_t)__builtin_clzll(lr)); }
                 }
             }
             base += (int32_t)G;

@@ -282,13 +282,16 @@ def test_postprocess_span_counts_and_haplotags():
         assert (fh[~tagged] == 0xFFFFFFFF).all()
 
 
-@pytest.mark.parametrize("target,warm", [(64, 160), (128, 200), (64, 8)])
-def test_segment_parallel_heuristic_is_exact(monkeypatch, target, warm):
+@pytest.mark.parametrize("target,warm,warm2", [(64, 64, 160), (64, 160, 160), (128, 200, 100), (64, 8, 160), (64, 48, 56), (64, 8, 8)])
+def test_segment_parallel_heuristic_is_exact(monkeypatch, target, warm, warm2):
     """Large blocks are cut into concurrently solved segments with a cold warm-up; seams are accepted only when the
-    40-value look-ahead state matches exactly, otherwise the block falls back to the sequential chain (warm=8
-    forces that). Either way H[], haplotypes, stats and work counters equal the oracle's."""
+    40-value look-ahead state matches exactly. Segments below a seam that stays open are solved again with the long
+    warm-up (warm=8 leaves every seam open: the second round does all the work), and a block with a seam that is still
+    open falls back to the sequential chain (warm = warm2 = 8 forces that). Either way H[], haplotypes, stats and work
+    counters equal the oracle's."""
     monkeypatch.setenv("HP_SEG_TARGET", str(target))
     monkeypatch.setenv("HP_SEG_WARM", str(warm))
+    monkeypatch.setenv("HP_SEG_WARM2", str(warm2))
     blocks = [synth_block(n, c, s, e, 0.02, 8100 + i, ignored_permille=ign)[0]
               for i, (n, c, s, e, ign) in enumerate([(700, 30, 20, 0.01, 0), (513, 30, 20, 0.15, 0), (900, 60, 40, 0.05, 20),
                                                      (130, 30, 20, 0.01, 0), (40, 30, 20, 0.01, 0), (1300, 12, 150, 0.03, 0)])]
