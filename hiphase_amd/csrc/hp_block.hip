@@ -38,6 +38,7 @@ void w2_session_destroy(W2Session* s);
 int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id);
 int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles);
 void w2_session_work(const W2Session* s, uint64_t out[4]);
+double w2_session_span_ms(const W2Session* s);
 int wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
                         uint8_t* const* alleles, int device_id);   // hp_wfa.hip
 
@@ -145,46 +146,6 @@ struct BlockChunk {
     ~BlockChunk() { if (wfa) w2_session_destroy(wfa); }
 };
 
-// One helper thread per block set, alive as long as the set: its thread-local device-buffer cache (hp_common.h) then
-// survives from one solve to the next (a fresh thread would hipMalloc every A* buffer again and hipFree it at exit).
-struct TailWorker {
-    std::thread th;
-    std::mutex m;
-    std::condition_variable cv;
-    std::function<void()> task;
-    bool has_task = false, busy = false, quit = false;
-    void start() {
-        th = std::thread([this]() {
-            std::unique_lock<std::mutex> lk(m);
-            for (;;) {
-                cv.wait(lk, [this]() { return has_task || quit; });
-                if (quit) return;
-                std::function<void()> t = std::move(task);
-                has_task = false;
-                lk.unlock();
-                t();
-                lk.lock();
-                busy = false;
-                cv.notify_all();
-            }
-        });
-    }
-    void post(std::function<void()> t) {
-        std::unique_lock<std::mutex> lk(m);
-        task = std::move(t); has_task = true; busy = true;
-        cv.notify_all();
-    }
-    void wait() {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [this]() { return !busy; });
-    }
-    ~TailWorker() {
-        if (th.joinable()) {
-            { std::unique_lock<std::mutex> lk(m); quit = true; cv.notify_all(); }
-            th.join();
-        }
-    }
-};
 
 struct hp_blockset {
     size_t n_blocks = 0;
@@ -194,7 +155,7 @@ struct hp_blockset {
     std::vector<std::vector<RecMeta>> meta;      // per block, per record (job = index into its chunk's jobs)
     std::vector<uint32_t> chunk_of;              // per block
     std::vector<std::unique_ptr<BlockChunk>> chunks;
-    std::unique_ptr<TailWorker> worker;          // runs chunk 0's tail while chunk 1's graph-WFA runs on the caller's thread
+    std::unique_ptr<HelperThread> worker;          // runs chunk 0's tail while chunk 1's graph-WFA runs on the caller's thread
     uint64_t work[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // hp_blockset_work of the last solve
     std::vector<BlockState> st;
 };
@@ -251,7 +212,7 @@ int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, co
         const char* pe = std::getenv("HP_BLOCK_PIPELINE");
         const bool split = pe && pe[0] == '1' && p->global_realignment && n_blocks >= 8 && total_records >= 3 * (uint64_t)std::max<size_t>(min_jobs, 1);
         bs->chunks.emplace_back(new BlockChunk());
-        if (split) { bs->chunks.emplace_back(new BlockChunk()); bs->worker.reset(new TailWorker()); bs->worker->start(); }
+        if (split) { bs->chunks.emplace_back(new BlockChunk()); bs->worker.reset(new HelperThread()); bs->worker->start(); }
         uint64_t acc = 0;
         for (size_t k = 0; k < n_blocks; ++k) {
             const size_t b = by_size[k];
@@ -492,7 +453,8 @@ int chunk_wfa(hp_blockset* bs, BlockChunk& ch) {
         else rc = hp_wfa_assign_batch(ch.jobs.data(), ch.jobs.size(), bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(),
                                       ch.allele_ptrs.data(), bs->device);
         if (rc != HP_OK) return rc;
-        ch.ms[6] = hp_last_kernel_ms();
+        // the three class instantiations of hp_wfa2_kernel run concurrently: their span is the kernel time of the stage
+        ch.ms[6] = ch.wfa ? w2_session_span_ms(ch.wfa) : hp_last_kernel_ms();
     }
     ch.ms[0] = blk_now_ms() - t0;
     return HP_OK;

@@ -2,9 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "../../include/hiphase_gpu.h"
 
@@ -39,6 +43,47 @@ int device_cu_count(int device_id);
 extern thread_local int g_cu_partition;
 hipError_t hp_stream_create(hipStream_t* s, int device_id, bool high_priority = false);
 int partition_cu_count(int device_id);   // CUs of the calling thread's current partition
+
+// A helper thread that lives as long as its owner: its thread-local device-buffer cache (below) then survives from one
+// task to the next (a fresh thread would hipMalloc every buffer again and hipFree it at exit, synchronising the device).
+struct HelperThread {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> task;
+    bool has_task = false, busy = false, quit = false;
+    void start() {
+        th = std::thread([this]() {
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv.wait(lk, [this]() { return has_task || quit; });
+                if (quit) return;
+                std::function<void()> t = std::move(task);
+                has_task = false;
+                lk.unlock();
+                t();
+                lk.lock();
+                busy = false;
+                cv.notify_all();
+            }
+        });
+    }
+    void post(std::function<void()> t) {
+        std::unique_lock<std::mutex> lk(m);
+        task = std::move(t); has_task = true; busy = true;
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this]() { return !busy; });
+    }
+    ~HelperThread() {
+        if (th.joinable()) {
+            { std::unique_lock<std::mutex> lk(m); quit = true; cv.notify_all(); }
+            th.join();
+        }
+    }
+};
 
 // RAII device buffer
 struct DevBuf {

@@ -12,6 +12,7 @@
 #include "hp_wfa2_kernel.hip"
 
 #include <algorithm>
+#include <memory>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -75,6 +76,7 @@ struct W2Context {
     hipEvent_t cfork = nullptr, cjoin[3] = {nullptr, nullptr, nullptr};
     PinBuf stage;            // upload staging: seq bytes, then the tables
     PinBuf down;             // download staging
+    std::unique_ptr<HelperThread> helper;   // runs the leftovers' dense-band pass beside the scatter of the other results
     void drop_streams() {
         for (auto& s : ps) {
             if (s.stream) { (void)hipStreamDestroy(s.stream); s.stream = nullptr; }
@@ -152,8 +154,9 @@ struct W2Session {
     std::vector<W2Variant> vars;
     std::vector<uint32_t> len_order;   // job ids, longest read first (stable)
     uint64_t seq_bytes = 0, alt_off = 0, node_tot = 0, edge_tot = 0, tag_tot = 0, allele_tot = 0;
-    DevBuf d_seq, d_vars, d_jobs, d_nodes, d_edges, d_tags, d_par, d_poff, d_cnt, d_info, d_order, d_sets, d_score, d_status, d_alleles, d_work;
+    DevBuf d_seq, d_vars, d_jobs, d_nodes, d_edges, d_tags, d_par, d_poff, d_cnt, d_info, d_order, d_len_order, d_cls, d_blockcnt, d_sets, d_score, d_status, d_alleles, d_work;
     double last_prepare_ms = 0.0;
+    double last_span_ms = 0.0;   // of the last run: first class launch .. last class kernel done (the three run concurrently)
     uint64_t work_updates = 0, work_node_bytes = 0, work_read_bytes = 0, work_jobs = 0;   // of the last run (compact kernel only)
     int prepare(const hp_wfa_job* jobs_, size_t n_, int device);
     int run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles);
@@ -311,7 +314,7 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     if ((rc = d_seq.alloc(seq_bytes)) || (rc = d_vars.alloc(std::max<size_t>(1, vars.size()) * sizeof(W2Variant))) || (rc = d_jobs.alloc(n * sizeof(W2Job))) ||
         (rc = d_nodes.alloc((size_t)node_tot * sizeof(W2Node))) || (rc = d_edges.alloc((size_t)edge_tot * 2)) || (rc = d_tags.alloc((size_t)tag_tot * 4)) ||
         (rc = d_par.alloc((size_t)edge_tot * 2)) || (rc = d_poff.alloc(((size_t)node_tot + n) * 4)) || (rc = d_cnt.alloc((size_t)node_tot * 4)) ||
-        (rc = d_info.alloc(n * sizeof(W2Info))) || (rc = d_order.alloc(n * 4)) || (rc = d_sets.alloc(n * W2_SET_STRIDE * 4)) ||
+        (rc = d_info.alloc(n * sizeof(W2Info))) || (rc = d_order.alloc(n * 12)) || (rc = d_len_order.alloc(n * 4)) || (rc = d_cls.alloc(n + 16)) || (rc = d_blockcnt.alloc(((n + 255) / 256 + 1) * 16)) || (rc = d_sets.alloc(n * W2_SET_STRIDE * 4)) ||
         (rc = d_score.alloc(n * 8)) || (rc = d_work.alloc(n * 8 + 16)) || (rc = d_status.alloc(n * 4)) || (rc = d_alleles.alloc(std::max<uint64_t>(allele_tot, 16))))
         return rc;
     HP_HIP_CHECK(hipMemcpyAsync(d_seq.p, cx.stage.p, seq_bytes, hipMemcpyHostToDevice, st));
@@ -319,6 +322,7 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     // reads them is waited for below (hipStreamSynchronize) before they go out of scope
     if (!vars.empty()) HP_HIP_CHECK(hipMemcpyAsync(d_vars.p, vars.data(), vars.size() * sizeof(W2Variant), hipMemcpyHostToDevice, st));
     HP_HIP_CHECK(hipMemcpyAsync(d_jobs.p, dj.data(), n * sizeof(W2Job), hipMemcpyHostToDevice, st));
+    HP_HIP_CHECK(hipMemcpyAsync(d_len_order.p, len_order.data(), n * 4, hipMemcpyHostToDevice, st));
 
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("upload failed"); return HP_ERR_HIP; }
     last_prepare_ms = w2_now_ms() - t0;
@@ -339,15 +343,19 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     W2Context::Streams* cs_ = nullptr;
     { const int rc0 = cx.streams(g_cu_partition, &cs_); if (rc0 != HP_OK) return rc0; }
     hipStream_t st = cs_->stream;
-    int rc;
+    int rc = HP_OK;
     // host tables that stream operations read or write; the guard below (destroyed first) drains the stream on every
     // exit path, so none of them goes out of scope with a copy in flight
-    std::vector<W2Info> info(n);
-    std::vector<uint32_t> order;
-    std::vector<int32_t> status(n), st0(n, W2_ST_NEED_BIG);
-    std::vector<uint64_t> score(n);
-    std::vector<uint8_t> al((size_t)std::max<uint64_t>(allele_tot, 1));
-    std::vector<uint32_t> work(n * 2);
+    // results come back into pinned staging (a pageable destination costs a bounce through the runtime's own buffers)
+    const size_t dn_score = (n * 4 + 15) / 16 * 16, dn_work = dn_score + n * 8, dn_info = dn_work + n * 8, dn_cnt = dn_info + n * sizeof(W2Info), dn_al = dn_cnt + 16;
+    if ((rc = cx.down.reserve(dn_al + (size_t)allele_tot + 16)) != HP_OK) return rc;
+    const int32_t* status = reinterpret_cast<const int32_t*>(cx.down.p);
+    const uint64_t* score = reinterpret_cast<const uint64_t*>(cx.down.p + dn_score);
+    const uint32_t* work = reinterpret_cast<const uint32_t*>(cx.down.p + dn_work);
+    W2Info* info_pin = reinterpret_cast<W2Info*>(cx.down.p + dn_info);
+    const W2Info* info = info_pin;
+    const uint32_t* cls_n = reinterpret_cast<const uint32_t*>(cx.down.p + dn_cnt);
+    const uint8_t* al = cx.down.p + dn_al;
     struct StreamDrain { hipStream_t s; W2Context::Streams* c; ~StreamDrain() { for (int k = 0; k < 3; ++k) if (c->cstream[k]) (void)hipStreamSynchronize(c->cstream[k]); (void)hipStreamSynchronize(s); } } drain{st, cs_};
     const double t_stage = t0;
 
@@ -367,36 +375,16 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         HP_HIP_CHECK(hipGetLastError());
         HP_HIP_CHECK(hipEventRecord(e1, st));
     }
-    HP_HIP_CHECK(hipMemcpyAsync(info.data(), d_info.p, n * sizeof(W2Info), hipMemcpyDeviceToHost, st));
-    if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA graph-build kernel failed"); return HP_ERR_HIP; }
-    const double t_built = w2_now_ms();
-
-    // ---- 4. classes by graph size, longest read first ----------------------------------------------------------------------
-    std::vector<uint32_t> cls[3], big;
-    for (uint32_t i : len_order) {   // classes inherit the longest-read-first order
-        if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %u", i); return HP_ERR_INVARIANT; }
-        if (info[i].status != W2B_OK || jobs[i].read_len >= (uint32_t)W2_DIAG_LIM) { big.push_back(i); continue; }
-        const uint32_t nn = info[i].n_nodes, ne = info[i].n_edges;
-        if (nn <= (uint32_t)W2Cfg<2>::MAXN && ne <= (uint32_t)W2Cfg<2>::MAXE) cls[0].push_back(i);
-        else if (nn <= (uint32_t)W2Cfg<4>::MAXN && ne <= (uint32_t)W2Cfg<4>::MAXE) cls[1].push_back(i);
-        else if (nn <= (uint32_t)W2Cfg<8>::MAXN && ne <= (uint32_t)W2Cfg<8>::MAXE) cls[2].push_back(i);
-        else big.push_back(i);
-    }
-    order.reserve(n);
-    size_t cls_off[3];
-    for (int k = 0; k < 3; ++k) {
-        cls_off[k] = order.size();
-        order.insert(order.end(), cls[k].begin(), cls[k].end());
-    }
+    // ---- 4. classes by graph size, longest read first: on the device, nothing comes back to the host in between --------------
     // capped-diagonal hash sets: one per resident group, kept (and never cleared) across calls
     const uint32_t max_groups = (uint32_t)n_cu * 64u;   // per class: up to 8 resident workgroups of 8 groups per CU
     if (cx.htab_groups < max_groups) {
         if ((rc = cx.htab.alloc(((size_t)3 * max_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
         if ((rc = cx.gsets.alloc((size_t)3 * max_groups * W2_GSET_STRIDE * 4)) != HP_OK) return rc;
-        if ((rc = cx.qhead.alloc(256)) != HP_OK) return rc;
         HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)3 * max_groups << W2_HCAP_LOG2) * 8, st));
         cx.htab_groups = max_groups; cx.tag_next = 0;
     }
+    if ((rc = cx.qhead.alloc(512)) != HP_OK) return rc;
     if ((uint64_t)cx.tag_next + n + 2 >= 0xFFFFFFF0ull) {
         HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)3 * cx.htab_groups << W2_HCAP_LOG2) * 8, st));
         cx.tag_next = 0;
@@ -405,30 +393,44 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         if (!cx.cjoin[k]) HP_HIP_CHECK(hipEventCreateWithFlags(&cx.cjoin[k], hipEventDisableTiming));
     }
     if (!cx.cfork) HP_HIP_CHECK(hipEventCreateWithFlags(&cx.cfork, hipEventDisableTiming));
-    HP_HIP_CHECK(hipMemsetAsync(cx.qhead.p, 0, 256, st));
+    HP_HIP_CHECK(hipMemsetAsync(cx.qhead.p, 0, 512, st));   // work-queue heads at dword 16 k, class counts at dwords 64..67
     const uint32_t tag_base = cx.tag_next;
     cx.tag_next += (uint32_t)n + 1;
-    if (!order.empty()) HP_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
-    {   // status of the jobs no class takes: NEED_BIG (the map kernel leaves their rows NoOverlap; the host path fills them)
-        for (int k = 0; k < 3; ++k) for (uint32_t id : cls[k]) st0[id] = W2_ST_PENDING;
-        HP_HIP_CHECK(hipMemcpyAsync(d_status.p, st0.data(), n * 4, hipMemcpyHostToDevice, st));
+    uint32_t* d_counts = cx.qhead.as<uint32_t>() + 64;
+    {
         HP_HIP_CHECK(hipMemsetAsync(d_sets.p, 0, n * W2_SET_STRIDE * 4, st));
         HP_HIP_CHECK(hipMemsetAsync(d_work.p, 0, n * 8, st));
+        W2ClassArgs CA{};
+        CA.jobs = d_jobs.as<W2Job>(); CA.info = d_info.as<W2Info>(); CA.len_order = d_len_order.as<uint32_t>(); CA.n_jobs = (uint32_t)n;
+        CA.order = d_order.as<uint32_t>(); CA.counts = d_counts; CA.status = d_status.as<int32_t>();
+        CA.cls = d_cls.as<uint8_t>(); CA.blockcnt = d_blockcnt.as<uint32_t>();
+        hipLaunchKernelGGL(hp_wfa2_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CA);
+        hipLaunchKernelGGL(hp_wfa2_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CA);
+        HP_HIP_CHECK(hipGetLastError());
     }
+    // the class sizes come back (16 bytes, one short wait): a grid sized for the class fills every workgroup's groups, and
+    // an empty class is not launched. Measured: launching each class with the whole batch's grid instead (no wait) cost
+    // 3-4 ms of 22 - the W=8 class then spreads its few long jobs one per workgroup and holds LDS for idle groups.
+    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_cnt, d_counts, 16, hipMemcpyDeviceToHost, st));
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA graph-build kernel failed"); return HP_ERR_HIP; }
+    const double t_built = w2_now_ms();
     W2Batch B{};
     B.jobs = d_jobs.as<W2Job>(); B.info = d_info.as<W2Info>(); B.tag_base = tag_base;
     B.nodes = d_nodes.as<W2Node>(); B.edges = d_edges.as<uint16_t>(); B.seq = d_seq.as<uint8_t>(); B.alt_off = alt_off;
     B.out_sets = d_sets.as<uint32_t>(); B.out_score = d_score.as<uint64_t>(); B.status = d_status.as<int32_t>(); B.out_work = d_work.as<uint32_t>();
     B.htab = cx.htab.as<uint64_t>(); B.hcap_log2 = W2_HCAP_LOG2; B.gsets = cx.gsets.as<uint32_t>(); B.set_stride = W2_GSET_STRIDE; B.prune_distance = prune_distance; B.max_ed = max_ed;
+    const double t_cls = w2_now_ms();
     HP_HIP_CHECK(hipEventRecord(e2, st));
     HP_HIP_CHECK(hipEventRecord(cx.cfork, st));
     uint32_t groups_used[3] = {0, 0, 0};
+    const uint32_t cls_cnt[3] = {cls_n[0], cls_n[1], cls_n[2]};
     for (int k = 0; k < 3; ++k) {
-        if (cls[k].empty()) continue;
+        if (cls_cnt[k] == 0) continue;
         hipStream_t cs = cs_->cstream[k];
         HP_HIP_CHECK(hipStreamWaitEvent(cs, cx.cfork, 0));
-        B.order = d_order.as<uint32_t>() + cls_off[k];
-        B.n_items = (uint32_t)cls[k].size();
+        B.order = d_order.as<uint32_t>() + (size_t)k * n;
+        B.n_items = cls_cnt[k];
+        B.n_items_dev = d_counts + k;
         B.next = cx.qhead.as<uint32_t>() + 16 * k;
         B.htab = cx.htab.as<uint64_t>() + (((size_t)k * cx.htab_groups) << W2_HCAP_LOG2);
         B.gsets = cx.gsets.as<uint32_t>() + (size_t)k * cx.htab_groups * W2_GSET_STRIDE;
@@ -443,6 +445,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         HP_HIP_CHECK(hipEventRecord(cx.cjoin[k], cs));
         HP_HIP_CHECK(hipStreamWaitEvent(st, cx.cjoin[k], 0));
     }
+    HP_HIP_CHECK(hipEventRecord(e3, st));
     {
         W2MapArgs M{};
         M.jobs = d_jobs.as<W2Job>(); M.info = d_info.as<W2Info>(); M.n_jobs = (uint32_t)n; M.tags = d_tags.as<uint32_t>();
@@ -451,12 +454,12 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         hipLaunchKernelGGL(hp_wfa2_map_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, M);
         HP_HIP_CHECK(hipGetLastError());
     }
-    HP_HIP_CHECK(hipEventRecord(e3, st));
     // ---- 5. results --------------------------------------------------------------------------------------------------------
-    HP_HIP_CHECK(hipMemcpyAsync(status.data(), d_status.p, n * 4, hipMemcpyDeviceToHost, st));
-    HP_HIP_CHECK(hipMemcpyAsync(score.data(), d_score.p, n * 8, hipMemcpyDeviceToHost, st));
-    if (allele_tot) HP_HIP_CHECK(hipMemcpyAsync(al.data(), d_alleles.p, (size_t)allele_tot, hipMemcpyDeviceToHost, st));
-    HP_HIP_CHECK(hipMemcpyAsync(work.data(), d_work.p, n * 8, hipMemcpyDeviceToHost, st));
+    HP_HIP_CHECK(hipMemcpyAsync(info_pin, d_info.p, n * sizeof(W2Info), hipMemcpyDeviceToHost, st));
+    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p, d_status.p, n * 4, hipMemcpyDeviceToHost, st));
+    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_score, d_score.p, n * 8, hipMemcpyDeviceToHost, st));
+    if (allele_tot) HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_al, d_alleles.p, (size_t)allele_tot, hipMemcpyDeviceToHost, st));
+    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_work, d_work.p, n * 8, hipMemcpyDeviceToHost, st));
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
 #if W2_PROF
     (void)hipDeviceSynchronize();   // flushes the instrumented kernel's printf buffer
@@ -465,36 +468,70 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     (void)hipEventElapsedTime(&ms_build, e0, e1);
     (void)hipEventElapsedTime(&ms_wfa, e2, e3);
     g_last_kernel_ms = (double)ms_build + (double)ms_wfa;
+    last_span_ms = (double)ms_wfa;
     const double t_done = w2_now_ms();
-    size_t n_big = big.size();
-    work_updates = work_node_bytes = work_read_bytes = work_jobs = 0;
-    for (size_t i = 0; i < n; ++i)
-        if (status[i] == W2_ST_OK || status[i] == W2_ST_MAX_ED) { work_updates += work[2 * i]; work_node_bytes += work[2 * i + 1]; work_read_bytes += jobs[i].read_len; ++work_jobs; }
+    // jobs no class took (builder limits, graph size, read length) and jobs the compact kernel handed back (a limit of its class)
+    std::vector<uint32_t> big;
     for (size_t i = 0; i < n; ++i) {
-        if (status[i] == W2_ST_NEED_BIG) { if (std::find(big.begin(), big.end(), (uint32_t)i) == big.end()) { big.push_back((uint32_t)i); } continue; }
-        if (status[i] != W2_ST_OK && status[i] != W2_ST_MAX_ED) { set_error("job %zu: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
-        out[i].status = status[i] == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
-        out[i].n_nodes = info[i].n_nodes;
-        out[i].score = score[i];
-        if (alleles && alleles[i] && jobs[i].n_hets) std::memcpy(alleles[i], al.data() + dj[i].allele_off, jobs[i].n_hets);
+        if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %zu", i); return HP_ERR_INVARIANT; }
+        if (status[i] == W2_ST_NEED_BIG) big.push_back((uint32_t)i);
     }
+    const size_t n_big = cls_n[3];
+    // ---- 6. leftovers go through the dense-band path on a helper thread WHILE the results of the others are scattered ----
+    std::vector<hp_wfa_job> sub(big.size());
+    std::vector<hp_wfa_result> sub_out(big.size());
+    std::vector<uint8_t*> sub_al(big.size());
+    int rc_big = HP_OK;
+    std::string err_big;
+    double ms_big = 0.0;
+    bool big_posted = false;
+    if (!big.empty()) {
+        for (size_t k = 0; k < big.size(); ++k) { sub[k] = jobs[big[k]]; sub_al[k] = alleles ? alleles[big[k]] : nullptr; }
+        const int part = g_cu_partition;
+        if (!cx.helper) { cx.helper.reset(new HelperThread()); cx.helper->start(); }
+        big_posted = true;
+        cx.helper->post([&, part]() {
+            g_cu_partition = part;
+            rc_big = wfa_assign_batch_v1(sub.data(), sub.size(), prune_distance, max_ed, sub_out.data(), alleles ? sub_al.data() : nullptr, device_id);
+            if (rc_big != HP_OK) err_big = hp_last_error();
+            ms_big = g_last_kernel_ms;
+        });
+    }
+    struct Joiner { HelperThread* h; bool& on; ~Joiner() { if (on) h->wait(); } } joiner{cx.helper.get(), big_posted};
+    std::atomic<int64_t> bad{-1};
+    {
+        const unsigned nt = w2_host_threads(n, 8192);
+        std::vector<uint64_t> acc((size_t)nt * 4, 0);
+        w2_parallel(nt, [&](unsigned tid, unsigned nth) {
+            const size_t lo = n * tid / nth, hi = n * (tid + 1) / nth;
+            uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (size_t i = lo; i < hi; ++i) {
+                if (status[i] == W2_ST_NEED_BIG) continue;
+                if (status[i] != W2_ST_OK && status[i] != W2_ST_MAX_ED) { bad.store((int64_t)i); return; }
+                a0 += work[2 * i]; a1 += work[2 * i + 1]; a2 += jobs[i].read_len; ++a3;
+                out[i].status = status[i] == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
+                out[i].n_nodes = info[i].n_nodes;
+                out[i].score = score[i];
+                if (alleles && alleles[i] && jobs[i].n_hets) std::memcpy(alleles[i], al + dj[i].allele_off, jobs[i].n_hets);
+            }
+            acc[(size_t)tid * 4] = a0; acc[(size_t)tid * 4 + 1] = a1; acc[(size_t)tid * 4 + 2] = a2; acc[(size_t)tid * 4 + 3] = a3;
+        });
+        work_updates = work_node_bytes = work_read_bytes = work_jobs = 0;
+        for (unsigned k = 0; k < nt; ++k) { work_updates += acc[(size_t)k * 4]; work_node_bytes += acc[(size_t)k * 4 + 1]; work_read_bytes += acc[(size_t)k * 4 + 2]; work_jobs += acc[(size_t)k * 4 + 3]; }
+    }
+    if (bad.load() >= 0) { set_error("job %lld: device status %d", (long long)bad.load(), status[bad.load()]); return HP_ERR_INVARIANT; }
     if (verbose) {
-        fprintf(stderr, "[hp] wfa2: %zu jobs (classes %zu/%zu/%zu, groups %u/%u/%u, %zu to the dense-band path of which %zu by size/builder): layout+stage %.2f ms, upload+build %.2f ms (build kernel %.3f), wfa+map kernels %.3f ms, total %.2f ms\n",
-                n, cls[0].size(), cls[1].size(), cls[2].size(), groups_used[0], groups_used[1], groups_used[2], big.size(), n_big, t_stage - t0, t_built - t_stage, ms_build, ms_wfa, t_done - t0);
+        fprintf(stderr, "[hp] wfa2: %zu jobs (classes %zu/%zu/%zu, groups %u/%u/%u, %zu to the dense-band path of which %zu by size/builder): layout+stage %.2f ms, upload+build %.2f ms (build kernel %.3f), queueing the classes %.2f ms, class kernels %.3f ms, total to results on the host %.2f ms\n",
+                n, (size_t)cls_n[0], (size_t)cls_n[1], (size_t)cls_n[2], groups_used[0], groups_used[1], groups_used[2], big.size(), n_big, t_stage - t0, t_built - t_stage, ms_build, t_cls - t_built, ms_wfa, t_done - t0);
         fflush(stderr);
     }
-    // ---- 6. leftovers through the dense-band path ----------------------------------------------------------------------------
+    const double t_scat = w2_now_ms();
+    if (big_posted) { cx.helper->wait(); big_posted = false; }
+    if (verbose) { fprintf(stderr, "[hp] wfa2: scatter %.2f ms, then %.2f ms more for the %zu leftovers\n", t_scat - t_done, w2_now_ms() - t_scat, big.size()); fflush(stderr); }
     if (!big.empty()) {
-        const double saved_ms = g_last_kernel_ms;
-        std::sort(big.begin(), big.end());
-        std::vector<hp_wfa_job> sub(big.size());
-        std::vector<hp_wfa_result> sub_out(big.size());
-        std::vector<uint8_t*> sub_al(big.size());
-        for (size_t k = 0; k < big.size(); ++k) { sub[k] = jobs[big[k]]; sub_al[k] = alleles ? alleles[big[k]] : nullptr; }
-        rc = wfa_assign_batch_v1(sub.data(), sub.size(), prune_distance, max_ed, sub_out.data(), alleles ? sub_al.data() : nullptr, device_id);
-        if (rc != HP_OK) return rc;
+        if (rc_big != HP_OK) { set_error("%s", err_big.c_str()); return rc_big; }
         for (size_t k = 0; k < big.size(); ++k) out[big[k]] = sub_out[k];
-        g_last_kernel_ms += saved_ms;
+        g_last_kernel_ms += ms_big;
     }
     return HP_OK;
 }
@@ -516,6 +553,7 @@ W2Session* w2_session_create() { return new W2Session(); }
 void w2_session_destroy(W2Session* s) { delete s; }
 int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id) { return s->prepare(jobs, n, device_id); }
 int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles) { return s->run(prune_distance, max_ed, out, alleles); }
+double w2_session_span_ms(const W2Session* s) { return s->last_span_ms; }
 void w2_session_work(const W2Session* s, uint64_t out[4]) { out[0] = s->work_jobs; out[1] = s->work_read_bytes; out[2] = s->work_node_bytes; out[3] = s->work_updates; }
 
 }  // namespace hp

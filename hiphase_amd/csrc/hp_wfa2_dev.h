@@ -285,7 +285,8 @@ struct W2Batch {
     const W2Info* info;
     const uint32_t* order;     // job ids of this launch's class, longest read first
     uint32_t* next;            // work queue head of this launch (zeroed before the launch): groups pull jobs from `order`
-    uint32_t n_items;
+    uint32_t n_items;        // jobs of this class (= *n_items_dev)
+    const uint32_t* n_items_dev;   // written by hp_wfa2_scatter_kernel
     uint32_t tag_base;         // capped-set keys carry tag_base + job + 1 (never 0 = empty)
     const W2Node* nodes;
     const uint16_t* edges;

@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
     bool hp0 = false, hp1 = false, use_list = false;
     int32_t a0 = 0, b0 = 0, o0 = 0, a1 = 0, b1 = 0, o1 = 0;   // previous entries of n: live diagonals [a, b], slot of diagonal d = o + d
     int32_t lo = 0, hi = 0, base = 0;
+    const uint32_t n_class = *B.n_items_dev;   // jobs of this graph-size class
     uint32_t coff = 0;
     int32_t clo = 0, chi = INT32_MIN, cvlo = INT32_MAX, cvhi = INT32_MIN, cflo = INT32_MAX, cfhi = INT32_MIN;   // cluster being formed
     uint32_t lane_far = 0;   // per lane
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
 #endif
                 const uint32_t k = w2_gsel<G>(mine, gl, 0u);
                 jround++;
-                if (k >= B.n_items) { state = S_DONE; break; }
+                if (k >= n_class) { state = S_DONE; break; }
                 job = B.order[k];
                 const W2Job jd = B.jobs[job];
                 const W2Info ji = B.info[job];
@@ -701,6 +702,78 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                blockIdx.x, (unsigned long long)(w2tl - w2t0), (unsigned long long)w2pc[0], (unsigned long long)w2pc[1], (unsigned long long)w2pc[2], (unsigned long long)w2pc[3],
                (unsigned long long)w2pc[4], (unsigned long long)w2pc[5], (unsigned long long)w2pc[6], (unsigned long long)w2pc[7], (unsigned long long)w2pc[8], w2pn[0], w2pn[1], w2pn[2], w2pn[3], w2pn[4]);
 #endif
+}
+
+// ---- graph-size classes: one thread per job, in longest-read-first order --------------------------------------------
+// A job goes to the smallest class whose tables hold its graph (W2Cfg<2/4/8>), or stays NEED_BIG for the dense-band
+// path. The class lists keep the longest-read-first order exactly (it steers the work queues: longest jobs first keeps
+// the tail of the persistent kernels short - a list in atomic-arrival order cost 6 ms of 22): kernel 1 classifies and
+// counts per workgroup of 256 jobs, kernel 2 turns the counts into offsets and scatters.
+struct W2ClassArgs {
+    const W2Job* jobs;
+    const W2Info* info;
+    const uint32_t* len_order;
+    uint32_t n_jobs;
+    uint8_t* cls;         // [n_jobs] class of the job at each position of len_order (3 = no class)
+    uint32_t* blockcnt;   // [workgroups][4]
+    uint32_t* order;      // [3][n_jobs]
+    uint32_t* counts;     // [4]: jobs per class, [3] = jobs no class takes
+    int32_t* status;
+};
+__global__ void __launch_bounds__(256) hp_wfa2_classify_kernel(W2ClassArgs A) {
+    __shared__ uint32_t wcnt[4][4];
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool on = t < A.n_jobs;
+    int k = 3;
+    if (on) {
+        const uint32_t i = A.len_order[t];
+        const W2Info in = A.info[i];
+        if (in.status == W2B_OK && A.jobs[i].read_len < (uint32_t)W2_DIAG_LIM) {
+            if (in.n_nodes <= (uint32_t)W2Cfg<2>::MAXN && in.n_edges <= (uint32_t)W2Cfg<2>::MAXE) k = 0;
+            else if (in.n_nodes <= (uint32_t)W2Cfg<4>::MAXN && in.n_edges <= (uint32_t)W2Cfg<4>::MAXE) k = 1;
+            else if (in.n_nodes <= (uint32_t)W2Cfg<8>::MAXN && in.n_edges <= (uint32_t)W2Cfg<8>::MAXE) k = 2;
+        }
+        A.status[i] = k < 3 ? W2_ST_PENDING : W2_ST_NEED_BIG;
+        A.cls[t] = (uint8_t)k;
+    }
+    for (int c = 0; c < 4; ++c) {
+        const uint64_t m = __ballot(on && k == c);
+        if (lane == 0) wcnt[wave][c] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) A.blockcnt[(size_t)blockIdx.x * 4 + threadIdx.x] = wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+}
+__global__ void __launch_bounds__(256) hp_wfa2_scatter_kernel(W2ClassArgs A) {
+    __shared__ uint32_t part[4][4];    // per wave: partial sums of the counts of the workgroups before this one
+    __shared__ uint32_t wcnt[4][4];    // per wave: members of each class in this workgroup
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t s[4] = {0, 0, 0, 0};
+    const uint32_t upto = blockIdx.x + ((blockIdx.x + 1 == gridDim.x) ? 1u : 0u);   // the last workgroup also totals the counts
+    for (uint32_t b = threadIdx.x; b < upto; b += 256u) {
+        const uint4 c = *reinterpret_cast<const uint4*>(A.blockcnt + (size_t)b * 4);
+        s[0] += c.x; s[1] += c.y; s[2] += c.z; s[3] += c.w;
+    }
+    for (int c = 0; c < 4; ++c) {
+        uint32_t v = s[c];
+        for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m);
+        if (lane == 0) part[wave][c] = v;
+    }
+    const bool on = t < A.n_jobs;
+    const int k = on ? (int)A.cls[t] : 3;
+    uint32_t pre = 0;
+    for (int c = 0; c < 4; ++c) {
+        const uint64_t m = __ballot(on && k == c);
+        if (lane == 0) wcnt[wave][c] = (uint32_t)__popcll(m);
+        if (k == c) pre = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (blockIdx.x + 1 == gridDim.x && threadIdx.x < 4) A.counts[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (on && k < 3) {
+        uint32_t base = part[0][k] + part[1][k] + part[2][k] + part[3][k];
+        if (blockIdx.x + 1 == gridDim.x) base -= A.blockcnt[(size_t)blockIdx.x * 4 + k];   // (its own count went into the total)
+        for (uint32_t w = 0; w < wave; ++w) base += wcnt[w][k];
+        A.order[(size_t)k * A.n_jobs + base + pre] = A.len_order[t];
+    }
 }
 
 // ---- graph construction: one thread per job (wfa_graph.rs:119-284 via w2_build) ------------------------------------
