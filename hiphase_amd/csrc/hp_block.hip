@@ -36,7 +36,9 @@ struct W2Session;   // hp_wfa2.hip
 W2Session* w2_session_create();
 void w2_session_destroy(W2Session* s);
 int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id);
-int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles);
+int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer);
+int w2_session_finish(W2Session* s);
+void w2_session_pending(const W2Session* s, const uint32_t** ids, size_t* n);
 void w2_session_work(const W2Session* s, uint64_t out[4]);
 double w2_session_span_ms(const W2Session* s);
 int wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
@@ -135,6 +137,7 @@ struct BlockChunk {
     std::vector<size_t> blocks;                  // indices into hp_blockset::in
     std::vector<hp_wfa_job> jobs;                // records with overlaps, all blocks of the chunk
     std::vector<uint64_t> job_alloff;            // per job: offset of its allele row in `alleles`
+    std::vector<uint32_t> job_block;             // per job: its block
     std::vector<uint8_t> alleles;                // per-het AlleleTypes of every job, back to back
     std::vector<uint8_t*> allele_ptrs;
     std::vector<hp_wfa_result> wfa_out;
@@ -250,6 +253,7 @@ int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, co
                 RecMeta& m = bs->meta[b][r];
                 m.job = (int64_t)ch.jobs.size(); m.first = f; m.last = l;
                 ch.jobs.push_back(j);
+                ch.job_block.push_back((uint32_t)b);
                 ch.job_alloff.push_back(al_total);
                 al_total += l - f;
             }
@@ -449,7 +453,8 @@ int chunk_wfa(hp_blockset* bs, BlockChunk& ch) {
     ch.ms[6] = 0.0;
     if (!ch.jobs.empty()) {
         int rc;
-        if (ch.wfa) rc = w2_session_run(ch.wfa, bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(), ch.allele_ptrs.data());
+        // (the few reads the compact kernel hands back are still in the dense-band pass when this returns: chunk_tail)
+        if (ch.wfa) rc = w2_session_run(ch.wfa, bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(), ch.allele_ptrs.data(), 1);
         else rc = hp_wfa_assign_batch(ch.jobs.data(), ch.jobs.size(), bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(),
                                       ch.allele_ptrs.data(), bs->device);
         if (rc != HP_OK) return rc;
@@ -471,6 +476,22 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
         nt = (unsigned)std::min<size_t>(nt, ch.blocks.size());
         std::vector<size_t> order(ch.blocks);
         std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return bs->in[x].n_records > bs->in[y].n_records; });
+        // blocks that hold a read whose alignment is still in the dense-band pass go last; whoever reaches the first of
+        // them waits for that pass (it has had the other blocks' assembly to finish in)
+        size_t n_free = order.size();
+        if (ch.wfa) {
+            const uint32_t* ids = nullptr; size_t n_ids = 0;
+            w2_session_pending(ch.wfa, &ids, &n_ids);
+            if (n_ids) {
+                std::vector<uint8_t> held(bs->n_blocks, 0);
+                for (size_t k = 0; k < n_ids; ++k) held[ch.job_block[ids[k]]] = 1;
+                std::stable_partition(order.begin(), order.end(), [&](size_t b) { return !held[b]; });
+                n_free = 0;
+                while (n_free < order.size() && !held[order[n_free]]) ++n_free;
+            }
+        }
+        std::mutex gate_m;
+        bool gate_open = false;
         std::atomic<size_t> next{0};
         std::atomic<int> first_rc{HP_OK};
         std::vector<std::string> errs(std::max(1u, nt));
@@ -478,6 +499,14 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
             for (;;) {
                 const size_t k = next.fetch_add(1);
                 if (k >= order.size() || first_rc.load() != HP_OK) return;
+                if (k >= n_free) {
+                    std::lock_guard<std::mutex> lk(gate_m);
+                    if (!gate_open) {
+                        const int r = w2_session_finish(ch.wfa);
+                        gate_open = true;
+                        if (r != HP_OK) { int exp = HP_OK; if (first_rc.compare_exchange_strong(exp, r)) errs[t] = hp_last_error(); return; }
+                    }
+                }
                 const int r = assemble_block(bs, order[k]);
                 if (r != HP_OK) { int exp = HP_OK; if (first_rc.compare_exchange_strong(exp, r)) errs[t] = hp_last_error(); return; }
             }
@@ -492,6 +521,7 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
             for (auto& e : errs) if (!e.empty()) { set_error("%s", e.c_str()); break; }
             return first_rc.load();
         }
+        if (ch.wfa && (rc = w2_session_finish(ch.wfa)) != HP_OK) return rc;   // (already done unless no block was held)
     }
     const double t2 = blk_now_ms();
     // ---- A* over the chunk's blocks ----

@@ -158,8 +158,25 @@ struct W2Session {
     double last_prepare_ms = 0.0;
     double last_span_ms = 0.0;   // of the last run: first class launch .. last class kernel done (the three run concurrently)
     uint64_t work_updates = 0, work_node_bytes = 0, work_read_bytes = 0, work_jobs = 0;   // of the last run (compact kernel only)
+    // leftovers of the last run (jobs the dense-band path aligns): their pass runs on the context's helper thread; with
+    // defer = true run() returns while it is still going and finish() waits for it (hp_block.hip assembles the blocks
+    // that do not hold a leftover read in the meantime)
+    struct Pending {
+        bool on = false;
+        HelperThread* helper = nullptr;
+        std::vector<uint32_t> ids;
+        std::vector<hp_wfa_job> sub;
+        std::vector<hp_wfa_result> sub_out;
+        std::vector<uint8_t*> sub_al;
+        hp_wfa_result* dst = nullptr;
+        int rc = HP_OK;
+        std::string err;
+        double ms = 0.0;
+    } pend;
     int prepare(const hp_wfa_job* jobs_, size_t n_, int device);
-    int run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles);
+    int run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, bool defer = false);
+    int finish();
+    ~W2Session() { if (pend.on && pend.helper) pend.helper->wait(); }
 };
 
 int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
@@ -329,8 +346,9 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     return HP_OK;
 }
 
-int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles) {
+int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, bool defer) {
     if (n == 0) return HP_OK;
+    if (pend.on) { const int rcp = finish(); if (rcp != HP_OK) return rcp; }
     if (!out) { set_error("null argument"); return HP_ERR_ARG; }
     if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
@@ -477,27 +495,40 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         if (status[i] == W2_ST_NEED_BIG) big.push_back((uint32_t)i);
     }
     const size_t n_big = cls_n[3];
+    if (verbose && !big.empty()) {   // which class handed jobs back, and which of its limits (hp_wfa2_kernel's `why`)
+        uint32_t hist[3][10] = {};
+        for (uint32_t i : big) {
+            const uint32_t nn = info[i].n_nodes, ne = info[i].n_edges;
+            if (info[i].status != W2B_OK || score[i] == 0 || score[i] > 9) continue;
+            const int k = (nn <= (uint32_t)W2Cfg<2>::MAXN && ne <= (uint32_t)W2Cfg<2>::MAXE) ? 0 : (nn <= (uint32_t)W2Cfg<4>::MAXN && ne <= (uint32_t)W2Cfg<4>::MAXE) ? 1 : 2;
+            hist[k][score[i]]++;
+        }
+        for (int k = 0; k < 3; ++k) {
+            fprintf(stderr, "[hp] wfa2: class %d handed back:", k);
+            for (int r = 1; r < 10; ++r) if (hist[k][r]) fprintf(stderr, " reason %d x %u", r, hist[k][r]);
+            fprintf(stderr, "\n");
+        }
+    }
     // ---- 6. leftovers go through the dense-band path on a helper thread WHILE the results of the others are scattered ----
-    std::vector<hp_wfa_job> sub(big.size());
-    std::vector<hp_wfa_result> sub_out(big.size());
-    std::vector<uint8_t*> sub_al(big.size());
-    int rc_big = HP_OK;
-    std::string err_big;
-    double ms_big = 0.0;
-    bool big_posted = false;
+    pend.ids = big; pend.dst = out; pend.rc = HP_OK; pend.err.clear(); pend.ms = 0.0;
+    pend.sub.resize(big.size()); pend.sub_out.resize(big.size()); pend.sub_al.resize(big.size());
     if (!big.empty()) {
-        for (size_t k = 0; k < big.size(); ++k) { sub[k] = jobs[big[k]]; sub_al[k] = alleles ? alleles[big[k]] : nullptr; }
+        for (size_t k = 0; k < big.size(); ++k) { pend.sub[k] = jobs[big[k]]; pend.sub_al[k] = alleles ? alleles[big[k]] : nullptr; }
         const int part = g_cu_partition;
         if (!cx.helper) { cx.helper.reset(new HelperThread()); cx.helper->start(); }
-        big_posted = true;
-        cx.helper->post([&, part]() {
+        pend.helper = cx.helper.get();
+        pend.on = true;
+        Pending* P = &pend;
+        const bool with_alleles = alleles != nullptr;
+        const int dev = device_id;
+        cx.helper->post([P, part, prune_distance, max_ed, with_alleles, dev]() {
             g_cu_partition = part;
-            rc_big = wfa_assign_batch_v1(sub.data(), sub.size(), prune_distance, max_ed, sub_out.data(), alleles ? sub_al.data() : nullptr, device_id);
-            if (rc_big != HP_OK) err_big = hp_last_error();
-            ms_big = g_last_kernel_ms;
+            P->rc = wfa_assign_batch_v1(P->sub.data(), P->sub.size(), prune_distance, max_ed, P->sub_out.data(), with_alleles ? P->sub_al.data() : nullptr, dev);
+            if (P->rc != HP_OK) P->err = hp_last_error();
+            P->ms = g_last_kernel_ms;
         });
     }
-    struct Joiner { HelperThread* h; bool& on; ~Joiner() { if (on) h->wait(); } } joiner{cx.helper.get(), big_posted};
+    struct Joiner { W2Session* s; bool armed; ~Joiner() { if (armed && s->pend.on) { s->pend.helper->wait(); s->pend.on = false; } } } joiner{this, true};
     std::atomic<int64_t> bad{-1};
     {
         const unsigned nt = w2_host_threads(n, 8192);
@@ -525,14 +556,21 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
                 n, (size_t)cls_n[0], (size_t)cls_n[1], (size_t)cls_n[2], groups_used[0], groups_used[1], groups_used[2], big.size(), n_big, t_stage - t0, t_built - t_stage, ms_build, t_cls - t_built, ms_wfa, t_done - t0);
         fflush(stderr);
     }
+    joiner.armed = false;
+    if (defer) return HP_OK;
     const double t_scat = w2_now_ms();
-    if (big_posted) { cx.helper->wait(); big_posted = false; }
+    const int rcf = finish();
     if (verbose) { fprintf(stderr, "[hp] wfa2: scatter %.2f ms, then %.2f ms more for the %zu leftovers\n", t_scat - t_done, w2_now_ms() - t_scat, big.size()); fflush(stderr); }
-    if (!big.empty()) {
-        if (rc_big != HP_OK) { set_error("%s", err_big.c_str()); return rc_big; }
-        for (size_t k = 0; k < big.size(); ++k) out[big[k]] = sub_out[k];
-        g_last_kernel_ms += ms_big;
-    }
+    return rcf;
+}
+
+int W2Session::finish() {
+    if (!pend.on) return HP_OK;
+    pend.helper->wait();
+    pend.on = false;
+    if (pend.rc != HP_OK) { set_error("%s", pend.err.c_str()); return pend.rc; }
+    for (size_t k = 0; k < pend.ids.size(); ++k) pend.dst[pend.ids[k]] = pend.sub_out[k];
+    g_last_kernel_ms += pend.ms;
     return HP_OK;
 }
 
@@ -552,7 +590,10 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
 W2Session* w2_session_create() { return new W2Session(); }
 void w2_session_destroy(W2Session* s) { delete s; }
 int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id) { return s->prepare(jobs, n, device_id); }
-int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles) { return s->run(prune_distance, max_ed, out, alleles); }
+int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer) { return s->run(prune_distance, max_ed, out, alleles, defer != 0); }
+int w2_session_finish(W2Session* s) { return s->finish(); }
+// jobs whose results finish() delivers (valid until the next run)
+void w2_session_pending(const W2Session* s, const uint32_t** ids, size_t* n) { *ids = s->pend.on ? s->pend.ids.data() : nullptr; *n = s->pend.on ? s->pend.ids.size() : 0; }
 double w2_session_span_ms(const W2Session* s) { return s->last_span_ms; }
 void w2_session_work(const W2Session* s, uint64_t out[4]) { out[0] = s->work_jobs; out[1] = s->work_read_bytes; out[2] = s->work_node_bytes; out[3] = s->work_updates; }
 

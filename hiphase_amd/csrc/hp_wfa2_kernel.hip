@@ -216,6 +216,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
     uint32_t coff = 0;
     int32_t clo = 0, chi = INT32_MIN, cvlo = INT32_MAX, cvhi = INT32_MIN, cflo = INT32_MAX, cfhi = INT32_MIN;   // cluster being formed
     uint32_t lane_far = 0;   // per lane
+    uint32_t why = 0;        // which limit handed the job back (reported in place of the score; HP_DEBUG prints the histogram)
     uint32_t lane_upd = 0;   // per lane: (node, diagonal) wave updates of this job (work counter)
 
 #if W2_PROF
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                 ++pq_cnt;
             }
         }
-        if (w2_gballot<G>(over, gbase)) status = W2_ST_NEED_BIG;
+        if (w2_gballot<G>(over, gbase)) status = W2_ST_NEED_BIG, why = 1u;
     };
     // publishes the cluster [clo, chi] of the current item as an entry of this round (group-uniform)
     auto emit_cluster = [&]() {
@@ -250,13 +251,13 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
         h.z = (lv ? ((uint32_t)(cvlo - clo) | ((uint32_t)(cvhi - clo) << 8)) : 0x00FFu) | ((fn ? ((uint32_t)(cflo - clo) | ((uint32_t)(cfhi - clo) << 8)) : 0x00FFu) << 16);
         h.w = len;
         if (lv) {
-            if (lcnt_cur >= (uint32_t)C::MAXL) { status = W2_ST_NEED_BIG; return; }
+            if (lcnt_cur >= (uint32_t)C::MAXL) { status = W2_ST_NEED_BIG, why = 2u; return; }
             code = lcnt_cur;
             if (gl == 0) live[c * C::MAXL + lcnt_cur] = h;
             lcnt_cur++;
             round_live = true;
         } else {
-            if (fcnt >= (uint32_t)C::MAXF) { status = W2_ST_NEED_BIG; return; }
+            if (fcnt >= (uint32_t)C::MAXF) { status = W2_ST_NEED_BIG, why = 3u; return; }
             code = 128u + fcnt;
             if (gl == 0) fin[fcnt] = h;
             fcnt++;
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
             if (state == S_JOB) {
                 if (status != W2_ST_PENDING) {   // results of the job that just ended
                     const uint32_t upd = w2_gsum<G>(lane_upd);
-                    if (gl == 0) { B.status[job] = status; B.out_score[job] = score; B.out_work[(size_t)job * 2] = upd; }
+                    if (gl == 0) { B.status[job] = status; B.out_score[job] = status == W2_ST_NEED_BIG ? (uint64_t)why : score; B.out_work[(size_t)job * 2] = upd; }
                     if (gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
                     status = W2_ST_PENDING;
                 }
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                 if (gl < (uint32_t)W) outset[gl] = 0u;
                 score = 0;
                 if (n_nodes == 0 || n_nodes > (uint32_t)C::MAXN || ji.n_edges > (uint32_t)C::MAXE || other_len >= (uint32_t)W2_DIAG_LIM) {
-                    status = W2_ST_NEED_BIG;
+                    status = W2_ST_NEED_BIG, why = 4u;
                     continue;   // stays in S_JOB: the next pass writes this status and fetches the next job
                 }
                 gnode = B.nodes + jd.node_off;
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                     }
                     uint8_t* le = reinterpret_cast<uint8_t*>(R + C::O_EDGE);
                     for (uint32_t i = gl; i < ji.n_edges; i += G) le[i] = (uint8_t)gedge[i];
-                    if (w2_gballot<G>(bad, gbase)) { status = W2_ST_NEED_BIG; continue; }
+                    if (w2_gballot<G>(bad, gbase)) { status = W2_ST_NEED_BIG, why = 5u; continue; }
                 }
                 // the start wave (wfa_graph.rs:366-378): node 0 waits for its turn in round 0, with no parent
                 pq_node = gl == 0 ? 0u : 0xFFFFu; pq_cnt = 0; pq_c0 = 0; pq_c1 = 0;
@@ -384,7 +385,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                         lo = min(lo, a1 - 1); hi = max(hi, b1 + 1);
                         ++pp;
                         ph = pp < lcnt_prev ? live[p * C::MAXL + pp] : make_uint4(0xFFFFu, 0, 0, 0);
-                        if ((ph.x & 0xFFFFu) == n) { status = W2_ST_NEED_BIG; state = S_JOB; continue; }   // three entries of one node
+                        if ((ph.x & 0xFFFFu) == n) { status = W2_ST_NEED_BIG, why = 6u; state = S_JOB; continue; }   // three entries of one node
                     }
                 }
                 npar = 0; pc0 = 0; pc1 = 0;
@@ -435,7 +436,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                                 j = 0;
                             } else ++j;
                         }
-                        if (ni >= (uint32_t)C::MAXS) { status = W2_ST_NEED_BIG; break; }
+                        if (ni >= (uint32_t)C::MAXS) { status = W2_ST_NEED_BIG, why = 7u; break; }
                         if (gl == 0) srcs[ni] = iv;
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         ++ni;
@@ -449,7 +450,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                 if (use_list) { const int2 iv = srcs[item]; lo = iv.x; hi = iv.y; }
                 ++item;
                 const uint32_t cnt = (uint32_t)(hi - lo + 1);
-                if (top + cnt > (uint32_t)C::SLOTS || lo <= -W2_DIAG_LIM || hi >= W2_DIAG_LIM) { status = W2_ST_NEED_BIG; state = S_JOB; continue; }
+                if (top + cnt > (uint32_t)C::SLOTS || lo <= -W2_DIAG_LIM || hi >= W2_DIAG_LIM) { status = W2_ST_NEED_BIG, why = 8u; state = S_JOB; continue; }
                 coff = top; top += cnt; base = lo;
                 chi = INT32_MIN; cvlo = INT32_MAX; cvhi = INT32_MIN; cflo = INT32_MAX; cfhi = INT32_MIN;
                 state = S_TILE;
@@ -636,7 +637,7 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                 }
             }
         }
-        if (__any(hfull)) { if (w2_gballot<G>(hfull, gbase)) status = W2_ST_NEED_BIG; }
+        if (__any(hfull)) { if (w2_gballot<G>(hfull, gbase)) status = W2_ST_NEED_BIG, why = 9u; }
         W2PT(6);
         // ---- write this round's slot: offset | kind and the union of the tied sets -----------------------------------
         W2Set<W> best;
