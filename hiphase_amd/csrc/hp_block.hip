@@ -490,6 +490,9 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
                 while (n_free < order.size() && !held[order[n_free]]) ++n_free;
             }
         }
+        const bool dbg = std::getenv("HP_DEBUG") != nullptr;
+        std::vector<double> dbg_sum(std::max(1u, nt), 0.0), dbg_max(std::max(1u, nt), 0.0);
+        std::vector<size_t> dbg_arg(std::max(1u, nt), 0);
         std::mutex gate_m;
         bool gate_open = false;
         std::atomic<size_t> next{0};
@@ -507,7 +510,9 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
                         if (r != HP_OK) { int exp = HP_OK; if (first_rc.compare_exchange_strong(exp, r)) errs[t] = hp_last_error(); return; }
                     }
                 }
+                const double ta = dbg ? blk_now_ms() : 0.0;
                 const int r = assemble_block(bs, order[k]);
+                if (dbg) { const double d = blk_now_ms() - ta; dbg_sum[t] += d; if (d > dbg_max[t]) { dbg_max[t] = d; dbg_arg[t] = order[k]; } }
                 if (r != HP_OK) { int exp = HP_OK; if (first_rc.compare_exchange_strong(exp, r)) errs[t] = hp_last_error(); return; }
             }
         };
@@ -522,6 +527,12 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
             return first_rc.load();
         }
         if (ch.wfa && (rc = w2_session_finish(ch.wfa)) != HP_OK) return rc;   // (already done unless no block was held)
+        if (dbg) {
+            double s = 0.0, m = 0.0; size_t arg = 0;
+            for (unsigned i = 0; i < std::max(1u, nt); ++i) { s += dbg_sum[i]; if (dbg_max[i] > m) { m = dbg_max[i]; arg = dbg_arg[i]; } }
+            fprintf(stderr, "[hp] rows: %zu blocks on %u threads, %.2f ms of assembly in total, the slowest block (%u hets, %u records) %.2f ms, %zu blocks held for leftovers\n",
+                    order.size(), nt, s, bs->in[arg].n_hets, bs->in[arg].n_records, m, order.size() - n_free);
+        }
     }
     const double t2 = blk_now_ms();
     // ---- A* over the chunk's blocks ----
@@ -580,9 +591,15 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
     std::vector<uint8_t> tag((size_t)sum_rows + 1);
     std::vector<uint32_t> fh((size_t)sum_rows + 1);
     if ((rc = hp_batch_postprocess(batch, spans.data(), tag.data(), fh.data())) != HP_OK) return rc;
-    // ---- outputs ----
-    uint64_t on = 0, orow = 0, oj = 0;
+    // ---- outputs (blocks are independent: host threads over blocks) ----
+    std::vector<uint64_t> on_of(nb + 1, 0), orow_of(nb + 1, 0), oj_of(nb + 1, 0);
     for (size_t kb = 0; kb < nb; ++kb) {
+        const uint32_t N = bs->in[ch.blocks[kb]].n_hets;
+        on_of[kb + 1] = on_of[kb] + N; orow_of[kb + 1] = orow_of[kb] + views[kb].n_reads; oj_of[kb + 1] = oj_of[kb] + N - 1;
+    }
+    std::atomic<int64_t> cap_fail{-1};
+    auto emit_block = [&](size_t kb) {
+        const uint64_t on = on_of[kb], orow = orow_of[kb], oj = oj_of[kb];
         const size_t b = ch.blocks[kb];
         const hp_block_input& B = bs->in[b];
         const BlockState& S = bs->st[b];
@@ -633,14 +650,27 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
             if (O.seg_row_off) O.seg_row_off[k] = cells;
             const uint64_t len = s.end - s.start;
             if (O.seg_alleles || O.seg_quals) {
-                if (cells + len > O.seg_cell_cap) { set_error("block %zu: seg_cell_cap too small", b); return HP_ERR_ARG; }
+                if (cells + len > O.seg_cell_cap) { cap_fail.store((int64_t)b); return; }
                 if (O.seg_alleles) std::memcpy(O.seg_alleles + cells, s.alleles.data(), (size_t)len);
                 if (O.seg_quals) std::memcpy(O.seg_quals + cells, s.quals.data(), (size_t)len);
             }
             cells += len;
         }
         if (O.seg_row_off) O.seg_row_off[S.segs.size()] = cells;
-        on += N; orow += views[kb].n_reads; oj += N - 1;
+    };
+    {
+        unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
+        nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, nb / 8));
+        std::atomic<size_t> next{0};
+        auto work = [&]() { for (;;) { const size_t kb = next.fetch_add(1); if (kb >= nb) return; emit_block(kb); } };
+        if (nt <= 1) work();
+        else {
+            std::vector<std::thread> th;
+            for (unsigned i = 0; i < nt; ++i) th.emplace_back(work);
+            for (auto& x : th) x.join();
+        }
+        if (cap_fail.load() >= 0) { set_error("block %lld: seg_cell_cap too small", (long long)cap_fail.load()); return HP_ERR_ARG; }
     }
     const double t5 = blk_now_ms();
     ch.ms[1] = t2 - t1; ch.ms[2] = t3 - t2; ch.ms[3] = t4 - t3; ch.ms[4] = t5 - t4; ch.ms[7] = kms;
