@@ -63,27 +63,50 @@ int base_quality(uint32_t variant_type) {
     }
 }
 
-struct Segment {            // a ReadSegment: clipped row (read_segments.rs:19-62)
+// Cells of a block's segments: one bump allocator per block, kept from solve to solve (two heap allocations per record
+// from 32 threads at once were most of the row stage)
+struct Arena {
+    std::vector<std::unique_ptr<uint8_t[]>> chunks;
+    std::vector<size_t> caps;
+    size_t cur = 0, used = 0;
+    void reset() { cur = 0; used = 0; }
+    uint8_t* get(size_t n) {
+        while (cur < chunks.size() && used + n > caps[cur]) { ++cur; used = 0; }
+        if (cur == chunks.size()) {
+            const size_t c = std::max<size_t>(n, (size_t)1 << 16);
+            chunks.emplace_back(new uint8_t[c]);
+            caps.push_back(c);
+        }
+        uint8_t* p = chunks[cur].get() + used;
+        used += n;
+        return p;
+    }
+};
+struct Segment {            // a ReadSegment: clipped row (read_segments.rs:19-62); end - start cells each in the block's arena
     uint32_t start = 0, end = 0;
-    std::vector<uint8_t> alleles, quals;
+    const uint8_t* alleles = nullptr;
+    const uint8_t* quals = nullptr;
 };
 // ReadSegment::new (read_segments.rs:40-62) from a window [w0, w0 + n) of the block-length vectors (everything outside
 // the window is NoOverlap with quality 0)
-Segment segment_new(const uint8_t* alleles, const uint8_t* quals, uint32_t w0, uint32_t n, uint32_t n_hets) {
+Segment segment_new(Arena& ar, const uint8_t* alleles, const uint8_t* quals, uint32_t w0, uint32_t n, uint32_t n_hets) {
     Segment s;
     uint32_t first = n, last = n;
     for (uint32_t i = 0; i < n; ++i) if (alleles[i] < HP_ALLELE_AMBIGUOUS) { first = i; break; }
     for (uint32_t i = n; i-- > 0;) if (alleles[i] < HP_ALLELE_AMBIGUOUS) { last = i + 1; break; }
     if (first == n) { s.start = s.end = n_hets; return s; }   // no set allele: len..len (:58-61)
     s.start = w0 + first; s.end = w0 + last;
-    s.alleles.assign(alleles + first, alleles + last);
-    s.quals.assign(quals + first, quals + last);
+    uint8_t* a = ar.get(last - first);
+    uint8_t* q = ar.get(last - first);
+    std::memcpy(a, alleles + first, last - first);
+    std::memcpy(q, quals + first, last - first);
+    s.alleles = a; s.quals = q;
     return s;
 }
 inline uint8_t seg_allele(const Segment& s, uint32_t i) { return (i >= s.start && i < s.end) ? s.alleles[i - s.start] : (uint8_t)HP_ALLELE_NOOVERLAP; }
 inline uint8_t seg_qual(const Segment& s, uint32_t i) { return (i >= s.start && i < s.end) ? s.quals[i - s.start] : (uint8_t)0; }
 // ReadSegment::collapse (read_segments.rs:71-121). Returns false when `assert!(quals[i] > 0)` (:105) would fire.
-bool segment_collapse(const std::vector<const Segment*>& rs, uint32_t n_hets, Segment& out) {
+bool segment_collapse(Arena& ar, const std::vector<const Segment*>& rs, uint32_t n_hets, Segment& out) {
     if (rs.size() == 1) { out = *rs[0]; return true; }
     uint32_t min_start = rs[0]->start, max_end = rs[0]->end;
     for (auto* r : rs) { min_start = std::min(min_start, r->start); max_end = std::max(max_end, r->end); }
@@ -99,12 +122,12 @@ bool segment_collapse(const std::vector<const Segment*>& rs, uint32_t n_hets, Se
             else if (ca == a) { cq = std::max(cq, q); if (cq == 0) return false; }
             else { ca = HP_ALLELE_AMBIGUOUS; cq = 0; }
         }
-    out = segment_new(alleles.data(), quals.data(), min_start, (uint32_t)alleles.size(), n_hets);
+    out = segment_new(ar, alleles.data(), quals.data(), min_start, (uint32_t)alleles.size(), n_hets);
     return true;
 }
 uint32_t seg_num_set(const Segment& s) {
     uint32_t n = 0;
-    for (uint8_t a : s.alleles) n += a < HP_ALLELE_AMBIGUOUS;
+    for (uint32_t i = 0; i < s.end - s.start; ++i) n += s.alleles[i] < HP_ALLELE_AMBIGUOUS;
     return n;
 }
 
@@ -121,6 +144,14 @@ struct BlockState {         // per block, rebuilt by every solve
     std::vector<uint32_t> read_start, read_end;
     std::vector<uint64_t> row_off;
     std::vector<uint8_t> alleles_2bit, quals, var_flags;
+    Arena arena;
+    void reset() {   // keeps every capacity
+        segs.clear(); seg_qname.clear(); seg_solver.clear(); solver_rows.clear();
+        num_reads = skipped_reads = global_aligned = local_aligned = 0;
+        edit_distances.clear(); read_start.clear(); read_end.clear(); row_off.clear();
+        alleles_2bit.clear(); quals.clear(); var_flags.clear();
+        arena.reset();
+    }
 };
 
 }  // namespace
@@ -279,7 +310,7 @@ int assemble_block(hp_blockset* bs, size_t b) {
     const hp_block_input& B = bs->in[b];
     const hp_block_params& P = bs->prm;
     BlockState& S = bs->st[b];
-    S = BlockState{};
+    S.reset();
     const uint32_t N = B.n_hets, R = B.n_records;
     const std::vector<RecMeta>& meta = bs->meta[b];
     // local re-alignment rows (one batch call per need; a record's local result does not depend on any other record)
@@ -335,7 +366,7 @@ int assemble_block(hp_blockset* bs, size_t b) {
         if (!P.global_realignment) {
             const size_t s = (size_t)local_slot[idx];
             skipped = loc_stats[s].skipped_reads == 1;
-            if (!skipped) seg = segment_new(loc_alleles.data() + s * N, loc_quals.data() + s * N, 0, N, N);
+            if (!skipped) seg = segment_new(S.arena, loc_alleles.data() + s * N, loc_quals.data() + s * N, 0, N, N);
             local_aligned = 1.0;
         } else {
             if (m.job < 0) { S.skipped_reads += 1; continue; }   // no overlaps: flagged skipped (read_parsing.rs:703-712, :602-605)
@@ -348,7 +379,7 @@ int assemble_block(hp_blockset* bs, size_t b) {
                 }
                 const size_t s = (size_t)local_slot[idx];
                 skipped = loc_stats[s].skipped_reads == 1;
-                if (!skipped) seg = segment_new(loc_alleles.data() + s * N, loc_quals.data() + s * N, 0, N, N);
+                if (!skipped) seg = segment_new(S.arena, loc_alleles.data() + s * N, loc_quals.data() + s * N, 0, N, N);
                 wfa_score = P.max_edit_distance;   // :559 / :573: the distance carried by the error is max_edit_distance
                 local_aligned = 1.0;
             } else {
@@ -362,14 +393,18 @@ int assemble_block(hp_blockset* bs, size_t b) {
                 if (f0 == n) { seg.start = seg.end = N; }
                 else {
                     seg.start = m.first + f0; seg.end = m.first + l0;
-                    seg.alleles.assign(a + f0, a + l0);
-                    seg.quals.assign(l0 - f0, 0);
-                    for (uint32_t i = f0; i < l0; ++i)
+                    uint8_t* sa = S.arena.get(l0 - f0);
+                    uint8_t* sq = S.arena.get(l0 - f0);
+                    std::memcpy(sa, a + f0, l0 - f0);
+                    for (uint32_t i = f0; i < l0; ++i) {
+                        sq[i - f0] = 0;
                         if (a[i] < HP_ALLELE_AMBIGUOUS) {
                             const int q = base_quality(B.het_types[m.first + i]);
                             if (q < 0) { set_error("block %zu: no base quality for variant type %u (read_parsing.rs:829 panics)", b, (unsigned)B.het_types[m.first + i]); return HP_ERR_INVARIANT; }
-                            seg.quals[i - f0] = (uint8_t)(2 * q);
+                            sq[i - f0] = (uint8_t)(2 * q);
                         }
+                    }
+                    seg.alleles = sa; seg.quals = sq;
                 }
                 // (a het outside [f0, l0) is NoOverlap / Ambiguous with quality 0 either way; the reference panics on an
                 // unknown type only for a 0/1 allele, :803-829, which all lie inside the clip)
@@ -382,7 +417,7 @@ int assemble_block(hp_blockset* bs, size_t b) {
         const uint32_t q = B.records[idx].qname_id;
         if (!seen[q]) { seen[q] = 1; order.push_back(q); qfirst[q] = idx; } else next_rec[qlast[q]] = idx;
         qlast[q] = idx; qcount[q]++;
-        recseg[idx] = std::move(seg);
+        recseg[idx] = seg;
         if (P.global_realignment) {
             S.edit_distances.push_back(wfa_score);
             num_global_failures += local_aligned;
@@ -396,18 +431,18 @@ int assemble_block(hp_blockset* bs, size_t b) {
     std::vector<const Segment*> grp;
     for (uint32_t q : order) {
         Segment col;
-        if (qcount[q] == 1) col = std::move(recseg[qfirst[q]]);   // collapse of one segment is that segment (read_segments.rs:72-75)
+        if (qcount[q] == 1) col = recseg[qfirst[q]];   // collapse of one segment is that segment (read_segments.rs:72-75)
         else {
             grp.clear();
             for (uint32_t i = qfirst[q]; i != UINT32_MAX; i = next_rec[i]) grp.push_back(&recseg[i]);
-            if (!segment_collapse(grp, N, col)) { set_error("block %zu: assert!(quals[i] > 0) (read_segments.rs:105)", b); return HP_ERR_INVARIANT; }
+            if (!segment_collapse(S.arena, grp, N, col)) { set_error("block %zu: assert!(quals[i] > 0) (read_segments.rs:105)", b); return HP_ERR_INVARIANT; }
         }
         const uint32_t num_set = seg_num_set(col);
         const bool solver = num_set >= P.min_matched_alleles;
         if (solver) S.num_reads += qcount[q]; else S.skipped_reads += qcount[q];
         if (!solver && num_set == 0) continue;
         if (solver) S.solver_rows.push_back((uint32_t)S.segs.size());
-        S.segs.push_back(std::move(col));
+        S.segs.push_back(col);
         S.seg_qname.push_back(q);
         S.seg_solver.push_back(solver ? 1 : 0);
     }
@@ -425,8 +460,9 @@ int assemble_block(hp_blockset* bs, size_t b) {
         const Segment& s = S.segs[k];
         S.read_start.push_back(s.start);
         S.read_end.push_back(s.end);
-        for (size_t i = 0; i < s.alleles.size(); ++i, ++c) S.alleles_2bit[(size_t)(c >> 2)] |= (uint8_t)(s.alleles[i] << (2 * (c & 3)));
-        S.quals.insert(S.quals.end(), s.quals.begin(), s.quals.end());
+        const uint32_t len = s.end - s.start;
+        for (uint32_t i = 0; i < len; ++i, ++c) S.alleles_2bit[(size_t)(c >> 2)] |= (uint8_t)(s.alleles[i] << (2 * (c & 3)));
+        S.quals.insert(S.quals.end(), s.quals, s.quals + len);
         S.row_off.push_back(c);
     }
     if (S.quals.empty()) S.quals.push_back(0);
@@ -651,8 +687,8 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
             const uint64_t len = s.end - s.start;
             if (O.seg_alleles || O.seg_quals) {
                 if (cells + len > O.seg_cell_cap) { cap_fail.store((int64_t)b); return; }
-                if (O.seg_alleles) std::memcpy(O.seg_alleles + cells, s.alleles.data(), (size_t)len);
-                if (O.seg_quals) std::memcpy(O.seg_quals + cells, s.quals.data(), (size_t)len);
+                if (O.seg_alleles && len) std::memcpy(O.seg_alleles + cells, s.alleles, (size_t)len);
+                if (O.seg_quals && len) std::memcpy(O.seg_quals + cells, s.quals, (size_t)len);
             }
             cells += len;
         }
