@@ -122,7 +122,7 @@ void merge_ranges(std::vector<std::pair<const uint8_t*, uint64_t>>& iv, std::vec
     }
 }
 // one region of `max_groups` groups per class in htab / gsets: the class launches run concurrently
-template <int G, int W> int w2_launch(const W2Batch& B, uint32_t n_items, int n_cu, uint32_t max_groups, hipStream_t st, uint32_t* groups_used) {
+template <int G, int W> uint32_t w2_grid(uint32_t n_items, int n_cu, uint32_t max_groups) {
     using C = W2Cfg<W>;
     constexpr uint32_t NG = 64 / G;
     const size_t lds = (size_t)C::BYTES * NG;
@@ -131,7 +131,13 @@ template <int G, int W> int w2_launch(const W2Batch& B, uint32_t n_items, int n_
     if (const char* e = std::getenv("HP_WFA2_PER_CU")) per_cu = std::max(1, std::min((int)per_cu, std::atoi(e)));
     uint32_t grid = std::min<uint32_t>((n_items + NG - 1) / NG, (uint32_t)n_cu * per_cu);
     grid = std::min<uint32_t>(grid, max_groups / NG);
-    if (grid == 0) grid = 1;
+    return grid == 0 ? 1u : grid;
+}
+template <int G, int W> int w2_launch(const W2Batch& B, uint32_t n_items, int n_cu, uint32_t max_groups, hipStream_t st, uint32_t* groups_used) {
+    using C = W2Cfg<W>;
+    constexpr uint32_t NG = 64 / G;
+    const size_t lds = (size_t)C::BYTES * NG;
+    const uint32_t grid = w2_grid<G, W>(n_items, n_cu, max_groups);
     static std::atomic<bool> attr_set{false};
     if (lds > 64 * 1024 || !attr_set.load()) {
         HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_kernel<G, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -365,7 +371,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     // host tables that stream operations read or write; the guard below (destroyed first) drains the stream on every
     // exit path, so none of them goes out of scope with a copy in flight
     // results come back into pinned staging (a pageable destination costs a bounce through the runtime's own buffers)
-    const size_t dn_score = (n * 4 + 15) / 16 * 16, dn_work = dn_score + n * 8, dn_info = dn_work + n * 8, dn_cnt = dn_info + n * sizeof(W2Info), dn_al = dn_cnt + 16;
+    const size_t dn_score = (n * 4 + 15) / 16 * 16, dn_work = dn_score + n * 8, dn_info = dn_work + n * 8, dn_cnt = dn_info + n * sizeof(W2Info), dn_esc = dn_cnt + 16, dn_al = dn_esc + 16;
     if ((rc = cx.down.reserve(dn_al + (size_t)allele_tot + 16)) != HP_OK) return rc;
     const int32_t* status = reinterpret_cast<const int32_t*>(cx.down.p);
     const uint64_t* score = reinterpret_cast<const uint64_t*>(cx.down.p + dn_score);
@@ -415,13 +421,14 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     const uint32_t tag_base = cx.tag_next;
     cx.tag_next += (uint32_t)n + 1;
     uint32_t* d_counts = cx.qhead.as<uint32_t>() + 64;
+    uint32_t* d_esc = cx.qhead.as<uint32_t>() + 96;   // a cache line of its own
     {
         HP_HIP_CHECK(hipMemsetAsync(d_sets.p, 0, n * W2_SET_STRIDE * 4, st));
         HP_HIP_CHECK(hipMemsetAsync(d_work.p, 0, n * 8, st));
         W2ClassArgs CA{};
         CA.jobs = d_jobs.as<W2Job>(); CA.info = d_info.as<W2Info>(); CA.len_order = d_len_order.as<uint32_t>(); CA.n_jobs = (uint32_t)n;
         CA.order = d_order.as<uint32_t>(); CA.counts = d_counts; CA.status = d_status.as<int32_t>();
-        CA.cls = d_cls.as<uint8_t>(); CA.blockcnt = d_blockcnt.as<uint32_t>();
+        CA.cls = d_cls.as<uint8_t>(); CA.blockcnt = d_blockcnt.as<uint32_t>(); CA.esc = d_esc;
         hipLaunchKernelGGL(hp_wfa2_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CA);
         hipLaunchKernelGGL(hp_wfa2_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CA);
         HP_HIP_CHECK(hipGetLastError());
@@ -442,8 +449,21 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     HP_HIP_CHECK(hipEventRecord(cx.cfork, st));
     uint32_t groups_used[3] = {0, 0, 0};
     const uint32_t cls_cnt[3] = {cls_n[0], cls_n[1], cls_n[2]};
-    for (int k = 0; k < 3; ++k) {
-        if (cls_cnt[k] == 0) continue;
+    const char* genv = std::getenv("HP_WFA2_G");   // experiment: lanes per read for the middle class
+    const int gsel = genv ? std::atoi(genv) : 8;
+    // escalation (W2Batch::esc): the two smaller classes hand jobs that outgrow their tables to the largest one, whose
+    // kernel stays until both are gone. It is launched first, and with room for such jobs even when it has none of its own.
+    const char* eenv = std::getenv("HP_WFA2_ESCALATE");
+    const bool escalate = !(eenv && eenv[0] == '0') && (cls_cnt[0] || cls_cnt[1]);
+    uint32_t grid_wg[3] = {0, 0, 0};
+    if (cls_cnt[0]) grid_wg[0] = w2_grid<8, 2>(cls_cnt[0], n_cu, cx.htab_groups);
+    if (cls_cnt[1]) grid_wg[1] = gsel == 16 ? w2_grid<16, 4>(cls_cnt[1], n_cu, cx.htab_groups) : gsel == 32 ? w2_grid<32, 4>(cls_cnt[1], n_cu, cx.htab_groups) : w2_grid<8, 4>(cls_cnt[1], n_cu, cx.htab_groups);
+    const uint32_t items2 = escalate ? std::max<uint32_t>(cls_cnt[2], 4u * 48u) : cls_cnt[2];
+    int launch_order[3] = {1, 0, 2};   // measured on the default bench (ms of the span): 102 22.5, 120 22.6, 012 22.8, 201 23.2
+    if (const char* e = std::getenv("HP_WFA2_ORDER")) { if (std::strlen(e) == 3) for (int i = 0; i < 3; ++i) launch_order[i] = std::min(2, std::max(0, e[i] - '0')); }
+    for (int li = 0; li < 3; ++li) {
+        const int k = launch_order[li];
+        if (cls_cnt[k] == 0 && !(k == 2 && escalate)) continue;
         hipStream_t cs = cs_->cstream[k];
         HP_HIP_CHECK(hipStreamWaitEvent(cs, cx.cfork, 0));
         B.order = d_order.as<uint32_t>() + (size_t)k * n;
@@ -452,13 +472,14 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         B.next = cx.qhead.as<uint32_t>() + 16 * k;
         B.htab = cx.htab.as<uint64_t>() + (((size_t)k * cx.htab_groups) << W2_HCAP_LOG2);
         B.gsets = cx.gsets.as<uint32_t>() + (size_t)k * cx.htab_groups * W2_GSET_STRIDE;
-        const char* genv = std::getenv("HP_WFA2_G");   // experiment: lanes per read for the middle class
-        const int gsel = genv ? std::atoi(genv) : 8;
+        B.esc = d_esc; B.esc_order = d_order.as<uint32_t>() + (size_t)2 * n;
+        B.esc_role = !escalate ? 0u : (k == 2 ? 2u : 1u);
+        B.esc_producers = grid_wg[0] + grid_wg[1];
         if (k == 0) rc = w2_launch<8, 2>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k]);
         else if (k == 1) rc = gsel == 16 ? w2_launch<16, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k])
                             : gsel == 32 ? w2_launch<32, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k])
                                          : w2_launch<8, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k]);
-        else rc = w2_launch<16, 8>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k]);
+        else rc = w2_launch<16, 8>(B, items2, n_cu, cx.htab_groups, cs, &groups_used[k]);
         if (rc != HP_OK) return rc;
         HP_HIP_CHECK(hipEventRecord(cx.cjoin[k], cs));
         HP_HIP_CHECK(hipStreamWaitEvent(st, cx.cjoin[k], 0));
@@ -474,6 +495,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     }
     // ---- 5. results --------------------------------------------------------------------------------------------------------
     HP_HIP_CHECK(hipMemcpyAsync(info_pin, d_info.p, n * sizeof(W2Info), hipMemcpyDeviceToHost, st));
+    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_esc, d_esc, 16, hipMemcpyDeviceToHost, st));
     HP_HIP_CHECK(hipMemcpyAsync(cx.down.p, d_status.p, n * 4, hipMemcpyDeviceToHost, st));
     HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_score, d_score.p, n * 8, hipMemcpyDeviceToHost, st));
     if (allele_tot) HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_al, d_alleles.p, (size_t)allele_tot, hipMemcpyDeviceToHost, st));
@@ -492,7 +514,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     std::vector<uint32_t> big;
     for (size_t i = 0; i < n; ++i) {
         if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %zu", i); return HP_ERR_INVARIANT; }
-        if (status[i] == W2_ST_NEED_BIG) big.push_back((uint32_t)i);
+        if (status[i] == W2_ST_NEED_BIG || status[i] == W2_ST_PENDING) big.push_back((uint32_t)i);   // (PENDING: handed over, never claimed)
     }
     const size_t n_big = cls_n[3];
     if (verbose && !big.empty()) {   // which class handed jobs back, and which of its limits (hp_wfa2_kernel's `why`)
@@ -537,7 +559,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
             const size_t lo = n * tid / nth, hi = n * (tid + 1) / nth;
             uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             for (size_t i = lo; i < hi; ++i) {
-                if (status[i] == W2_ST_NEED_BIG) continue;
+                if (status[i] == W2_ST_NEED_BIG || status[i] == W2_ST_PENDING) continue;
                 if (status[i] != W2_ST_OK && status[i] != W2_ST_MAX_ED) { bad.store((int64_t)i); return; }
                 a0 += work[2 * i]; a1 += work[2 * i + 1]; a2 += jobs[i].read_len; ++a3;
                 out[i].status = status[i] == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
@@ -552,8 +574,8 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     }
     if (bad.load() >= 0) { set_error("job %lld: device status %d", (long long)bad.load(), status[bad.load()]); return HP_ERR_INVARIANT; }
     if (verbose) {
-        fprintf(stderr, "[hp] wfa2: %zu jobs (classes %zu/%zu/%zu, groups %u/%u/%u, %zu to the dense-band path of which %zu by size/builder): layout+stage %.2f ms, upload+build %.2f ms (build kernel %.3f), queueing the classes %.2f ms, class kernels %.3f ms, total to results on the host %.2f ms\n",
-                n, (size_t)cls_n[0], (size_t)cls_n[1], (size_t)cls_n[2], groups_used[0], groups_used[1], groups_used[2], big.size(), n_big, t_stage - t0, t_built - t_stage, ms_build, t_cls - t_built, ms_wfa, t_done - t0);
+        fprintf(stderr, "[hp] wfa2: %zu jobs (classes %zu/%zu/%zu, groups %u/%u/%u, %zu to the dense-band path of which %zu by size/builder, %u handed to the largest class on the device): layout+stage %.2f ms, upload+build %.2f ms (build kernel %.3f), queueing the classes %.2f ms, class kernels %.3f ms, total to results on the host %.2f ms\n",
+                n, (size_t)cls_n[0], (size_t)cls_n[1], (size_t)cls_n[2], groups_used[0], groups_used[1], groups_used[2], big.size(), n_big, reinterpret_cast<const uint32_t*>(cx.down.p + dn_esc)[1] - cls_n[2], t_stage - t0, t_built - t_stage, ms_build, t_cls - t_built, ms_wfa, t_done - t0);
         fflush(stderr);
     }
     joiner.armed = false;

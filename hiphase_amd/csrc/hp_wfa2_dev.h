@@ -302,6 +302,15 @@ struct W2Batch {
     uint32_t hcap_log2;
     uint64_t prune_distance;   // UINT64_MAX disables pruning
     uint64_t max_ed;
+    // Escalation: a job that outgrows the tables of its class is handed to the largest class WHILE that class's kernel is
+    // still running (its groups keep a ticket for the next list position and wait for it to be published), instead of
+    // waiting for a pass of its own after all three. esc[0] = list positions reserved, esc[1] = positions published
+    // (in order), esc[2] = producer workgroups that have exited, esc[3] = scratch. Every access is an atomic RMW: the
+    // L2s of different XCDs are not coherent for plain loads and stores inside a kernel.
+    uint32_t* esc;
+    uint32_t* esc_order;       // the largest class's job list (capacity: the whole batch)
+    uint32_t esc_role;         // 0 none, 1 producer, 2 consumer (the largest class)
+    uint32_t esc_producers;    // consumer: producer workgroups to wait for
 };
 
 }  // namespace hp

@@ -41,6 +41,12 @@ namespace hp {
 #define W2PC(i, v)
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define W2_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")   // the atomics above have returned (= been performed)
+#else
+#define W2_WAIT_VM()
+#endif
+
 extern __shared__ __attribute__((aligned(16))) unsigned char w2_smem[];
 
 W2DEV uint32_t w2_lane() { return __lane_id(); }
@@ -192,8 +198,10 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
     const uint8_t* altp = B.seq + B.alt_off;
 
     // ---- group-uniform state (every lane of a group holds the same value) ------------------------------------------
-    enum : uint32_t { S_JOB = 0, S_NEXT = 1, S_TILE = 3, S_DONE = 4 };
-    uint32_t state = S_JOB, jround = 0, job = 0;
+    enum : uint32_t { S_JOB = 0, S_NEXT = 1, S_WAIT = 2, S_TILE = 3, S_DONE = 4 };   // S_WAIT: holds a ticket for a list position not yet published
+    uint32_t state = S_JOB, jround = 0, job = 0, ticket = 0, idle_polls = 0;
+    bool have_ticket = false;
+    uint32_t poll_div = 0;
     uint32_t n_nodes = 0, last = 0, other_len = 0, tag = 0;
     const uint8_t* refp = altp; const uint8_t* readp = altp;
     const W2Node* gnode = B.nodes; const uint16_t* gedge = B.edges;   // the job's node / edge tables in HBM
@@ -272,15 +280,42 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
         // ============================ 1. control: advance every group to its next tile ===============================
         uint32_t spins = 0;
         W2PT(0); W2PC(0, 1);
-        while (state != S_TILE && state != S_DONE) {
+        if (B.esc_role == 2u && __any(state == S_WAIT) && (!__any(state == S_TILE) || (++poll_div & 15u) == 0u)) {   // (busy wavefronts look less often)
+            // producers publish before they exit: a ticket still unpublished once every producer workgroup is gone stays so
+            const uint32_t gone = atomicAdd(B.esc + 2, 0u);
+            W2_WAIT_VM();
+            const uint32_t pub = atomicAdd(B.esc + 1, 0u);
+            if (state == S_WAIT) {
+                if (pub > ticket) { state = S_JOB; have_ticket = true; }
+                else if (gone >= B.esc_producers) state = S_DONE;
+            }
+        }
+        while (state != S_TILE && state != S_DONE && state != S_WAIT) {
             W2PC(1, 1);
             if (++spins > (1u << 20)) { state = S_DONE; break; }   // cannot happen; never hang the device
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (state == S_JOB) {
                 if (status != W2_ST_PENDING) {   // results of the job that just ended
                     const uint32_t upd = w2_gsum<G>(lane_upd);
-                    if (gl == 0) { B.status[job] = status; B.out_score[job] = status == W2_ST_NEED_BIG ? (uint64_t)why : score; B.out_work[(size_t)job * 2] = upd; }
-                    if (gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
+                    bool handed_over = false;
+                    if (B.esc_role == 1u && __any(status == W2_ST_NEED_BIG)) {
+                        // hand the job to the largest class: reserve a list position, store the job there, publish positions in
+                        // order. Every lane takes part in every atomic (idle ones on a scratch word): no one-lane branches.
+                        const bool me = status == W2_ST_NEED_BIG && gl == 0;
+                        const uint32_t pos = atomicAdd(B.esc, me ? 1u : 0u);
+                        (void)atomicExch(me ? B.esc_order + pos : B.esc + 3, me ? job : 0u);
+                        W2_WAIT_VM();
+                        bool pend = me;
+                        for (uint32_t s = 0; s < (1u << 16) && __any(pend); ++s) {
+                            const uint32_t seen = atomicCAS(pend ? B.esc + 1 : B.esc + 3, pend ? pos : 0xFFFFFFFFu, pend ? pos + 1u : 0xFFFFFFFFu);
+                            if (pend && seen == pos) pend = false;
+                        }
+                        // its results are the consumer's to write (two XCDs' L2s must not both hold dirty copies of one word).
+                        // A position that could not be published leaves the job PENDING: the host's dense-band pass takes it.
+                        handed_over = status == W2_ST_NEED_BIG;
+                    }
+                    if (!handed_over && gl == 0) { B.status[job] = status; B.out_score[job] = status == W2_ST_NEED_BIG ? (uint64_t)why : score; B.out_work[(size_t)job * 2] = upd; }
+                    if (!handed_over && gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
                     status = W2_ST_PENDING;
                 }
                 // dynamic work queue: the group's first lane pulls the next index. The instruction is written out by hand:
@@ -298,12 +333,21 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                 }
 #else
                 // every lane of the group takes part (lane 0 adds one, the others nothing): no one-lane branch around the atomic
-                const uint32_t mine = atomicAdd(B.next, gl == 0 ? 1u : 0u);
+                const uint32_t mine = atomicAdd(B.next, (gl == 0 && !have_ticket) ? 1u : 0u);
 #endif
-                const uint32_t k = w2_gsel<G>(mine, gl, 0u);
+                const uint32_t k = have_ticket ? ticket : w2_gsel<G>(mine, gl, 0u);
                 jround++;
-                if (k >= n_class) { state = S_DONE; break; }
-                job = B.order[k];
+                if (B.esc_role == 2u) {
+                    if (!have_ticket && k >= n_class) {   // past the class's own jobs: a ticket for a job another class may hand over
+                        const uint32_t pub = atomicAdd(B.esc + 1, 0u);
+                        if (k >= pub) { ticket = k; state = S_WAIT; break; }
+                    }
+                    have_ticket = false;
+                    job = k < n_class ? B.order[k] : atomicAdd(B.esc_order + k, 0u);
+                } else {
+                    if (k >= n_class) { state = S_DONE; break; }
+                    job = B.order[k];
+                }
                 const W2Job jd = B.jobs[job];
                 const W2Info ji = B.info[job];
                 n_nodes = ji.n_nodes; last = n_nodes - 1u; other_len = jd.read_len;
@@ -457,7 +501,12 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
             }
         }
         W2PT(1);
-        if (!__any(state == S_TILE)) break;   // every group is done
+        if (!__any(state == S_TILE)) {
+            if (!__any(state == S_WAIT)) break;   // every group is done
+            if (++idle_polls > 8000u) break;      // (~0.2 s: never hang the device; unclaimed jobs stay for the host's pass)
+            for (int z = 0; z < 8; ++z) __builtin_amdgcn_s_sleep(127);
+            continue;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         W2PC(2, __popcll(__ballot(state == S_TILE)));
 
@@ -697,6 +746,10 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
         }
         W2PT(8);
     }
+    if (B.esc_role == 1u) {   // a producer workgroup is gone (everything it hands over has been published)
+        W2_WAIT_VM();
+        (void)atomicAdd(B.esc + 2, lane == 0 ? 1u : 0u);
+    }
 #if W2_PROF
     if (lane == 0 && (blockIdx.x % 97) == 3)
         printf("wg %u total %llu | idle->ctl %llu control %llu cand %llu issue %llu ext %llu ties %llu hash %llu write+final %llu cluster %llu | iters %u ctlpasses %u tile-lanes %u has-lanes %u ext2 %u\n",
@@ -720,6 +773,7 @@ struct W2ClassArgs {
     uint32_t* order;      // [3][n_jobs]
     uint32_t* counts;     // [4]: jobs per class, [3] = jobs no class takes
     int32_t* status;
+    uint32_t* esc;        // W2Batch::esc: [0] = [1] = jobs of the largest class, [2] = [3] = 0
 };
 __global__ void __launch_bounds__(256) hp_wfa2_classify_kernel(W2ClassArgs A) {
     __shared__ uint32_t wcnt[4][4];
@@ -768,7 +822,11 @@ __global__ void __launch_bounds__(256) hp_wfa2_scatter_kernel(W2ClassArgs A) {
         if (k == c) pre = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     }
     __syncthreads();
-    if (blockIdx.x + 1 == gridDim.x && threadIdx.x < 4) A.counts[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (blockIdx.x + 1 == gridDim.x && threadIdx.x < 4) {
+        const uint32_t tot = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        A.counts[threadIdx.x] = tot;
+        if (threadIdx.x == 2) { A.esc[0] = tot; A.esc[1] = tot; A.esc[2] = 0; A.esc[3] = 0; }
+    }
     if (on && k < 3) {
         uint32_t base = part[0][k] + part[1][k] + part[2][k] + part[3][k];
         if (blockIdx.x + 1 == gridDim.x) base -= A.blockcnt[(size_t)blockIdx.x * 4 + k];   // (its own count went into the total)
