@@ -260,7 +260,9 @@ def main_path(args, rank, world, local_rank, dist, backend):
         # wave update, counted on the device for the reads the compact kernel aligned
         b_wfa = work["wfa_read_bytes"] + work["wfa_node_bytes"] + 8 * work["wfa_updates"]
         b_astar = BYTES_PER_CELL * work["astar_cells"]
-        k_wfa = {"kernel": "hp::hp_wfa2_kernel (+ graph build, allele rows)", "bound": "hbm", "kernel_ms": st[6],
+        # kernel_ms: the three graph-size instantiations run concurrently on three streams; HIP events around the launch set give
+        # their span (the <16,8> instantiation stays resident until the other two are gone, so its rocprof duration is that span)
+        k_wfa = {"kernel": "hp::hp_wfa2_kernel<8,2> + <8,4> + <16,8> (concurrent; span of the launch set)", "bound": "hbm", "kernel_ms": st[6],
                  "algorithmic_bytes_per_launch": b_wfa, "achieved": b_wfa / (st[6] * 1e-3) / 1e9 if st[6] > 0 else 0.0, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "reads": work["wfa_reads"], "reads_per_s": work["wfa_reads"] / (st[6] * 1e-3) if st[6] > 0 else 0.0,
                  "bytes_per_read": b_wfa / max(1, work["wfa_reads"]), "wave_updates_per_read": work["wfa_updates"] / max(1, work["wfa_reads"])}

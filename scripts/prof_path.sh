@@ -10,16 +10,6 @@ if [ -n "$PMC" ]; then
   rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- python bench.py --no-cpu "$@" > /dev/null 2> $OUT/pmc3.err
   rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc4 -o pmc4 -- python bench.py --no-cpu "$@" > /dev/null 2> $OUT/pmc4.err
 fi
-tail -c 1500 $OUT/bench.json; echo
-for f in $(find $OUT -name "*kernel_stats.csv"); do cat $f; done
-for f in $(find $OUT -name "*counter_collection.csv"); do python - "$f" <<'PY'
-import csv, sys, collections
-agg = collections.defaultdict(float); n = collections.Counter()
-for row in csv.DictReader(open(sys.argv[1])):
-    k = row.get('Kernel_Name','')
-    name = 'wfa2' if 'hp_wfa2_kernel' in k else ('astar' if 'hp_astar_kernel' in k else None)
-    if name:
-        agg[(name, row['Counter_Name'])] += float(row['Counter_Value']); n[(name, row['Counter_Name'])] += 1
-for k in sorted(agg): print(f"{k[0]:6s} {k[1]:24s} total={agg[k]:.6g} dispatches={n[k]}")
-PY
-done
+tail -c 1200 $OUT/bench.json; echo
+for f in $(find $OUT/trace -name "*kernel_stats.csv"); do cat $f; done
+if [ -n "$PMC" ]; then python scripts/make_traffic_json.py $OUT; fi
