@@ -401,7 +401,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     }
     // ---- 4. classes by graph size, longest read first: on the device, nothing comes back to the host in between --------------
     // capped-diagonal hash sets: one per resident group, kept (and never cleared) across calls
-    const uint32_t max_groups = (uint32_t)n_cu * 64u;   // per class: up to 8 resident workgroups of 8 groups per CU
+    const uint32_t max_groups = (uint32_t)n_cu * 96u;   // per class: up to 12 resident workgroups of 8 groups per CU
     if (cx.htab_groups < max_groups) {
         if ((rc = cx.htab.alloc(((size_t)3 * max_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
         if ((rc = cx.gsets.alloc((size_t)3 * max_groups * W2_GSET_STRIDE * 4)) != HP_OK) return rc;
@@ -429,6 +429,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         CA.jobs = d_jobs.as<W2Job>(); CA.info = d_info.as<W2Info>(); CA.len_order = d_len_order.as<uint32_t>(); CA.n_jobs = (uint32_t)n;
         CA.order = d_order.as<uint32_t>(); CA.counts = d_counts; CA.status = d_status.as<int32_t>();
         CA.cls = d_cls.as<uint8_t>(); CA.blockcnt = d_blockcnt.as<uint32_t>(); CA.esc = d_esc;
+        { const char* e = std::getenv("HP_WFA2_USE_W2"); CA.use_w2 = (e && e[0] == '0') ? 0u : 1u; }
         hipLaunchKernelGGL(hp_wfa2_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CA);
         hipLaunchKernelGGL(hp_wfa2_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CA);
         HP_HIP_CHECK(hipGetLastError());
@@ -458,7 +459,10 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     uint32_t grid_wg[3] = {0, 0, 0};
     if (cls_cnt[0]) grid_wg[0] = w2_grid<8, 2>(cls_cnt[0], n_cu, cx.htab_groups);
     if (cls_cnt[1]) grid_wg[1] = gsel == 16 ? w2_grid<16, 4>(cls_cnt[1], n_cu, cx.htab_groups) : gsel == 32 ? w2_grid<32, 4>(cls_cnt[1], n_cu, cx.htab_groups) : w2_grid<8, 4>(cls_cnt[1], n_cu, cx.htab_groups);
-    const uint32_t items2 = escalate ? std::max<uint32_t>(cls_cnt[2], 4u * 48u) : cls_cnt[2];
+    // (room for the jobs handed over: about 0.3 % of the two smaller classes on the default bench; HP_WFA2_ESC_DIV to experiment)
+    const char* denv = std::getenv("HP_WFA2_ESC_DIV");
+    const uint32_t esc_div = denv ? (uint32_t)std::max(1, std::atoi(denv)) : 128u;
+    const uint32_t items2 = escalate ? cls_cnt[2] + std::max<uint32_t>(4u * 48u, (cls_cnt[0] + cls_cnt[1]) / esc_div) : cls_cnt[2];
     int launch_order[3] = {1, 0, 2};   // measured on the default bench (ms of the span): 102 22.5, 120 22.6, 012 22.8, 201 23.2
     if (const char* e = std::getenv("HP_WFA2_ORDER")) { if (std::strlen(e) == 3) for (int i = 0; i < 3; ++i) launch_order[i] = std::min(2, std::max(0, e[i] - '0')); }
     for (int li = 0; li < 3; ++li) {
@@ -517,6 +521,27 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         if (status[i] == W2_ST_NEED_BIG || status[i] == W2_ST_PENDING) big.push_back((uint32_t)i);   // (PENDING: handed over, never claimed)
     }
     const size_t n_big = cls_n[3];
+#if W2_STATS
+    {   // sizing study: how far the jobs of the two smaller classes fill their tables
+        std::vector<uint32_t> sets(n * W2_SET_STRIDE);
+        (void)hipMemcpy(sets.data(), d_sets.p, n * W2_SET_STRIDE * 4, hipMemcpyDeviceToHost);
+        std::vector<uint32_t> hl(64, 0), hf(64, 0), ht(40, 0);
+        size_t cnt = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (status[i] != W2_ST_OK || info[i].n_nodes > (uint32_t)W2Cfg<4>::MAXN) continue;
+            const uint32_t v = sets[i * W2_SET_STRIDE + 6];
+            hl[std::min<uint32_t>(63, v & 0xFF)]++; hf[std::min<uint32_t>(63, (v >> 8) & 0xFF)]++; ht[std::min<uint32_t>(39, (v >> 16) / 8)]++;
+            ++cnt;
+        }
+        auto tail = [&](const std::vector<uint32_t>& h, const char* name, int scale) {
+            fprintf(stderr, "[hp] wfa2 stats %s (jobs above the value, per 10000):", name);
+            size_t above = cnt;
+            for (size_t k = 0; k < h.size(); ++k) { above -= h[k]; if (k % 2 == 1 || scale > 1) fprintf(stderr, " >%zu:%zu", k * scale + (scale - 1), above * 10000 / std::max<size_t>(cnt, 1)); }
+            fprintf(stderr, "\n");
+        };
+        tail(hl, "live entries", 1); tail(hf, "finished-only entries", 1); tail(ht, "arena slots", 8);
+    }
+#endif
     if (verbose && !big.empty()) {   // which class handed jobs back, and which of its limits (hp_wfa2_kernel's `why`)
         uint32_t hist[3][10] = {};
         for (uint32_t i : big) {

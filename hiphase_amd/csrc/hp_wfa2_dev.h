@@ -256,19 +256,23 @@ constexpr uint32_t W2_LDS_LEN_LIM = 1u << 18;  // node length / 1024 edges / 7 c
 template <int W> struct W2Cfg {
     static constexpr int MAXN = 32 * W;          // nodes
     static constexpr int MAXE = 2 * MAXN + 32;   // edges
-    static constexpr int MAXL = W <= 2 ? 24 : (W <= 4 ? 32 : 56);     // live entries per round
-    static constexpr int MAXF = W <= 2 ? 16 : (W <= 4 ? 24 : 32);     // finished-only entries per round
-    static constexpr int SLOTS = W <= 2 ? 80 : (W <= 4 ? 112 : 144);  // (node, diagonal) slots per round
+    // Table sizes of the two smaller classes follow what jobs actually use (W2_STATS build on the default bench, jobs per
+    // 10 000 that need more: live entries > 15: 2, finished-only entries > 19: 8, slots > 79: 17); the jobs that outgrow
+    // them (about 0.3 %) are handed to the largest class on the device (W2Batch::esc)
+    static constexpr int MAXL = W <= 4 ? 16 : 56;     // live entries per round
+    static constexpr int MAXF = W <= 4 ? 20 : 32;     // finished-only entries per round
+    static constexpr int SLOTS = W <= 4 ? 80 : 144;   // (node, diagonal) slots per round
     static constexpr int MAXQ = 8;               // nodes waiting for their turn with waves handed over by parents
     static constexpr int MAXPAR = 8;             // finished parent entries of one node in one round
     static constexpr int MAXS = 12;              // source intervals of one node (slow path scratch)
     static constexpr int MAXW = 250;             // diagonals per entry (8-bit relative hulls)
     static constexpr int a16(int x) { return (x + 15) & ~15; }
-    // The node table stays in LDS only for the smallest class; for the others it is read from HBM (L2-resident: one 12-byte
-    // descriptor per node visit, the children of a node when one of its waves finishes) - that takes a read's LDS below
-    // 2.5 KB, i.e. 8 workgroups of 8 reads per CU = two wavefronts per SIMD. One wavefront per SIMD issues at most one
-    // instruction every ~5 cycles (profiles/round2/issue_ceiling.txt); the second one hides that and the memory latency.
-    static constexpr bool DESC_LDS = W <= 2;
+    // The node table is read from HBM (L2-resident: one 16-byte descriptor per node visit, with the first two children
+    // inline) - with the table sizes above that takes a read's LDS to 1 584 bytes, i.e. 12 workgroups of 8 reads per CU =
+    // three wavefronts per SIMD for the two smaller classes. The kernel waits on memory half of the time; its throughput
+    // follows the resident wavefronts almost linearly (4 / 6 / 8 workgroups per CU: 2.6 / 3.9 / 5.1 M reads/s).
+    static constexpr bool DESC_LDS = false;
+    static constexpr int WAVES_PER_SIMD = W <= 4 ? 3 : 2;   // the register budget the kernel is compiled for (512 / waves)
     static constexpr int O_DESC = 0;                                  // uint2[MAXN]: seq_off, len | is_ref << 18 | child_off << 19 | n_children << 29
     static constexpr int O_EDGE = O_DESC + (DESC_LDS ? 8 * MAXN : 0); // u8[MAXE]
     static constexpr int O_LIVE = a16(O_EDGE + (DESC_LDS ? MAXE : 0)); // uint4[2][MAXL]

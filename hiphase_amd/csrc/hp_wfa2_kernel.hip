@@ -30,6 +30,9 @@ namespace hp {
 #ifndef W2_PROF
 #define W2_PROF 0
 #endif
+#ifndef W2_STATS
+#define W2_STATS 0
+#endif
 #ifndef W2_QUEUE_ASM
 #define W2_QUEUE_ASM 0
 #endif
@@ -174,7 +177,7 @@ template <int W> W2DEV void w2_stset(uint32_t* p, const W2Set<W>& s) {
 
 // =====================================================================================================================
 template <int G, int W>
-__global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W>::WAVES_PER_SIMD, W2Cfg<W>::WAVES_PER_SIMD))) hp_wfa2_kernel(W2Batch B) {
     using C = W2Cfg<W>;
     static_assert(G >= 8 && G <= 64 && (G & (G - 1)) == 0, "group size");
     static_assert(C::MAXQ <= G, "one lane per pending-queue entry");
@@ -202,6 +205,9 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
     uint32_t state = S_JOB, jround = 0, job = 0, ticket = 0, idle_polls = 0;
     bool have_ticket = false;
     uint32_t poll_div = 0;
+#if W2_STATS
+    uint32_t mx_l = 0, mx_f = 0, mx_top = 0;   // how far a job fills its tables (sizing study, scripts/prof_wfa2.sh)
+#endif
     uint32_t n_nodes = 0, last = 0, other_len = 0, tag = 0;
     const uint8_t* refp = altp; const uint8_t* readp = altp;
     const W2Node* gnode = B.nodes; const uint16_t* gedge = B.edges;   // the job's node / edge tables in HBM
@@ -264,11 +270,17 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
             if (gl == 0) live[c * C::MAXL + lcnt_cur] = h;
             lcnt_cur++;
             round_live = true;
+#if W2_STATS
+            mx_l = max(mx_l, lcnt_cur);
+#endif
         } else {
             if (fcnt >= (uint32_t)C::MAXF) { status = W2_ST_NEED_BIG, why = 3u; return; }
             code = 128u + fcnt;
             if (gl == 0) fin[fcnt] = h;
             fcnt++;
+#if W2_STATS
+            mx_f = max(mx_f, fcnt);
+#endif
         }
         if (fn)
             for (uint32_t j = 0; j < n_child; ++j)
@@ -316,6 +328,10 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                     }
                     if (!handed_over && gl == 0) { B.status[job] = status; B.out_score[job] = status == W2_ST_NEED_BIG ? (uint64_t)why : score; B.out_work[(size_t)job * 2] = upd; }
                     if (!handed_over && gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
+#if W2_STATS
+                    if (W <= 4 && gl == 0) { B.out_sets[(size_t)job * W2_SET_STRIDE + 6] = mx_l | (mx_f << 8) | (mx_top << 16); }
+                    mx_l = 0; mx_f = 0; mx_top = 0;
+#endif
                     status = W2_ST_PENDING;
                 }
                 // dynamic work queue: the group's first lane pulls the next index. The instruction is written out by hand:
@@ -496,6 +512,9 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
                 const uint32_t cnt = (uint32_t)(hi - lo + 1);
                 if (top + cnt > (uint32_t)C::SLOTS || lo <= -W2_DIAG_LIM || hi >= W2_DIAG_LIM) { status = W2_ST_NEED_BIG, why = 8u; state = S_JOB; continue; }
                 coff = top; top += cnt; base = lo;
+#if W2_STATS
+                mx_top = max(mx_top, top);
+#endif
                 chi = INT32_MIN; cvlo = INT32_MAX; cvhi = INT32_MIN; cflo = INT32_MAX; cfhi = INT32_MIN;
                 state = S_TILE;
             }
@@ -536,7 +555,8 @@ __global__ void __launch_bounds__(64) hp_wfa2_kernel(W2Batch B) {
             if (sB >= 0 && (eB & 7u) == W2_KIND_INTERIOR_READ) oB = (int32_t)(eB >> 3) + 1; else sB = -1;
             if (sC >= 0 && ((eC & 7u) == W2_KIND_INTERIOR_READ || (eC & 7u) == W2_KIND_END_LAST)) oC = (int32_t)(eC >> 3); else sC = -1;
         }
-        // their traversed-node sets are only needed for the union at the end of the step: the loads go out now
+        // their traversed-node sets are only needed for the union at the end of the step: the loads go out now (issued after
+        // the tie checks instead they save 7 spilled registers at 3 wavefronts per SIMD but expose their latency: 3 % slower)
         const W2Set<W> qA = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sA, 0)) * W, sA >= 0);
         const W2Set<W> qB = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sB, 0)) * W, sB >= 0);
         const W2Set<W> qC = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sC, 0)) * W, sC >= 0);
@@ -774,6 +794,7 @@ struct W2ClassArgs {
     uint32_t* counts;     // [4]: jobs per class, [3] = jobs no class takes
     int32_t* status;
     uint32_t* esc;        // W2Batch::esc: [0] = [1] = jobs of the largest class, [2] = [3] = 0
+    uint32_t use_w2;      // 0: graphs of at most 64 nodes join the middle class (one queue, one tail)
 };
 __global__ void __launch_bounds__(256) hp_wfa2_classify_kernel(W2ClassArgs A) {
     __shared__ uint32_t wcnt[4][4];
@@ -784,7 +805,7 @@ __global__ void __launch_bounds__(256) hp_wfa2_classify_kernel(W2ClassArgs A) {
         const uint32_t i = A.len_order[t];
         const W2Info in = A.info[i];
         if (in.status == W2B_OK && A.jobs[i].read_len < (uint32_t)W2_DIAG_LIM) {
-            if (in.n_nodes <= (uint32_t)W2Cfg<2>::MAXN && in.n_edges <= (uint32_t)W2Cfg<2>::MAXE) k = 0;
+            if (A.use_w2 && in.n_nodes <= (uint32_t)W2Cfg<2>::MAXN && in.n_edges <= (uint32_t)W2Cfg<2>::MAXE) k = 0;
             else if (in.n_nodes <= (uint32_t)W2Cfg<4>::MAXN && in.n_edges <= (uint32_t)W2Cfg<4>::MAXE) k = 1;
             else if (in.n_nodes <= (uint32_t)W2Cfg<8>::MAXN && in.n_edges <= (uint32_t)W2Cfg<8>::MAXE) k = 2;
         }
