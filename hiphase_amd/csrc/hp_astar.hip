@@ -353,8 +353,10 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     uint64_t total = 0;
     for (auto& d : b->desc) total += d.n_vars;
     const char* tenv = std::getenv("HP_SEG_TARGET");
-    uint64_t target = tenv ? (uint64_t)std::atoll(tenv) : std::max<uint64_t>(64, total / max_slots);
-    target = std::max<uint64_t>(64, (target + 63) / 64 * 64);
+    // segments of 32 owned variants (+ the warm-up) unless that makes more segments than resident slots: up to two
+    // single-wave workgroups per SIMD run at the speed of one (profiles/round2/issue_ceiling.txt), so the shorter chain is free
+    uint64_t target = tenv ? (uint64_t)std::atoll(tenv) : std::max<uint64_t>(32, total / max_slots);
+    target = std::max<uint64_t>(32, (target + 31) / 32 * 32);
     // Two rounds: a short warm-up first (64 variants close every seam of the synthetic mixes; the chain forgets its start
     // after a few dozen variants), then only the segments below a seam that stayed open are solved again with the long
     // one (160: scripts/spec_converge.py found 120 sufficient at 1 % and 15 % error). The seam check decides, so both
@@ -426,12 +428,24 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
         T.final_round = (round == 1 || !two_rounds) ? 1u : 0u;
         if (b->tiles == 2) hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 2>), dim3(slots), dim3(64), lds_bytes, st, S);
         else hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 1>), dim3(slots), dim3(64), lds_bytes, st, S);
-        hipLaunchKernelGGL(hp_heur_stitch_kernel, dim3((T.n_seg_blocks + 63) / 64), dim3(64), 0, st, T);
+        hipLaunchKernelGGL(hp_heur_stitch_kernel, dim3(T.n_seg_blocks), dim3(64), 0, st, T);
     }
     ApplyDev A{};
     A.segs = S.segs; A.seg_offset = T.seg_offset; A.desc = B.desc; A.n_segs = S.n_segs; A.H = B.H;
     hipLaunchKernelGGL(hp_heur_apply_kernel, dim3(S.n_segs), dim3(256), 0, st, A);
     HP_HIP_CHECK(hipGetLastError());
+    if (std::getenv("HP_DEBUG")) {   // how the seams went (costs a wait: debug only)
+        std::vector<int32_t> stt(b->n_blocks);
+        std::vector<uint8_t> rf(segs.size());
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(stt.data(), b->d_status.p, stt.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(rf.data(), b->d_seg_retry.p, rf.size(), hipMemcpyDeviceToHost);
+        size_t ready = 0, again = 0;
+        for (uint32_t i : sb_id) ready += stt[i] == ST_H_READY;
+        for (uint8_t f : rf) again += f;
+        fprintf(stderr, "[hp] segment-parallel heuristic: %zu of %zu blocks stitched, %zu segments solved again with the long warm-up\n", ready, sb_id.size(), again);
+        fflush(stderr);
+    }
     b->last_n_segs = S.n_segs;
     seg_blocks = sb_id;
     return HP_OK;

@@ -1308,6 +1308,7 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
     int32_t st = ST_OK;
     if (sd.v0 == N && lane == 0) H[N] = 0;
     ringH_set(sd.v0, 0);   // cold start (for the top segment this IS heuristic_costs[N] = 0)
+    if (lane == 0 && sd.v0 - sd.b < SEG_STATE) out->seam[sd.v0 - sd.b] = 0;   // (a warm-up that starts at the block's end, fewer than 40 variants up)
     uint32_t clip = 1, clip_at_b = 1;
     for (uint32_t v = sd.v0; v-- > sd.a;) {
         if (v + 1 == sd.b) {   // entering the owned range: only owned work is counted (== the sequential chain's work)
@@ -1384,8 +1385,10 @@ struct StitchDev {
     uint8_t* retry;                  // first of two rounds: flags the segment below every seam that did not close
     uint32_t final_round;            // 1: a seam that does not close sends the block down the sequential path
 };
+// One wavefront per segmented block: the seams are walked from the top (each offset builds on the one above), the 40
+// look-ahead values of a seam are compared by 40 lanes at once.
 __global__ void __launch_bounds__(64) hp_heur_stitch_kernel(StitchDev T) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = blockIdx.x, lane = threadIdx.x;
     if (t >= T.n_seg_blocks) return;
     const uint32_t blk = T.blk_id[t], s0 = T.blk_first_seg[t], ns = T.blk_n_seg[t];
     if (T.status[blk] == ST_H_READY) return;   // accepted by the first round
@@ -1393,30 +1396,37 @@ __global__ void __launch_bounds__(64) hp_heur_stitch_kernel(StitchDev T) {
     const uint64_t* H = T.H + d.h_off;
     bool ok = T.out[s0 + ns - 1].status == ST_OK;
     hp_work_counters tot = T.out[s0 + ns - 1].ctr;
-    T.seg_offset[s0 + ns - 1] = 0;
-    // every seam is checked on its own in the first round (a segment is solved again with the long warm-up iff ITS
-    // seam is open); in the final round the first open seam ends the walk
+    if (lane == 0) T.seg_offset[s0 + ns - 1] = 0;
+    // offsets of the segment above the seam and of the one above that: a segment is at least 32 variants long, so the 40
+    // look-ahead values of a seam lie in those two. In the first of two rounds every segment below an open seam is solved
+    // again with the long warm-up (its seam cannot be judged against values that are themselves in doubt).
+    uint64_t off0 = 0, off1 = 0;
     for (uint32_t k = ns - 1; (ok || !T.final_round) && k-- > 0;) {
         const uint32_t seg = s0 + k, above = seg + 1;
+        if (!ok) { if (lane == 0) T.retry[seg] = 1; continue; }
         const SegOut& o = T.out[seg];
-        const uint32_t b = T.segs[seg].b;
-        bool closed = o.status == ST_OK && o.clip_at_b == T.out[above].clip_out;
-        for (uint32_t j = 1; closed && j < SEG_STATE && b + j <= d.n_vars; ++j)
-            closed = (o.seam[j] - o.seam[0]) == (H[b + j] - H[b]);   // identical look-ahead state (differences)
+        const uint32_t b = T.segs[seg].b, b_above = T.segs[above].b;
+        const uint64_t hb = H[b], s00 = o.seam[0];
+        bool cj = true;
+        if (lane >= 1 && lane < SEG_STATE && b + lane <= d.n_vars) {
+            const uint32_t x = b + lane;
+            cj = (o.seam[lane] - s00) == ((H[x] + (x < b_above ? off0 : off1)) - (hb + off0));   // identical look-ahead state (differences)
+        }
+        const bool closed = o.status == ST_OK && o.clip_at_b == T.out[above].clip_out && __all(cj);
         if (!closed) {
             ok = false;
-            if (!T.final_round) T.retry[seg] = 1;
+            if (!T.final_round && lane == 0) T.retry[seg] = 1;
+            continue;
         }
-        if (ok) {
-            T.seg_offset[seg] = T.seg_offset[above] + H[b] - o.seam[0];
-            tot.sub_pops += o.ctr.sub_pops; tot.evals += o.ctr.evals; tot.cells += o.ctr.cells; tot.nodes_created += o.ctr.nodes_created;
-        }
+        const uint64_t off = off0 + hb - s00;
+        if (lane == 0) T.seg_offset[seg] = off;
+        off1 = off0; off0 = off;
+        tot.sub_pops += o.ctr.sub_pops; tot.evals += o.ctr.evals; tot.cells += o.ctr.cells; tot.nodes_created += o.ctr.nodes_created;
     }
     if (ok) {
-        T.counters[blk] = tot;
-        T.status[blk] = ST_H_READY;
+        if (lane == 0) { T.counters[blk] = tot; T.status[blk] = ST_H_READY; }
     } else {
-        for (uint32_t k = 0; k < ns; ++k) T.seg_offset[s0 + k] = 0;   // final round: the block falls back to the sequential chain
+        for (uint32_t k = lane; k < ns; k += 64) T.seg_offset[s0 + k] = 0;   // final round: the block falls back to the sequential chain
     }
 }
 struct ApplyDev {
