@@ -533,14 +533,30 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     if (max_seg < 2 || max_seg > 62) { set_error("max_segment_size %llu outside [2,62]", (unsigned long long)max_seg); return fail(HP_ERR_UNSUPPORTED); }
     if (p->min_queue_size > (1u << 26) || p->queue_increment > (1u << 20)) { set_error("queue parameters too large"); return fail(HP_ERR_UNSUPPORTED); }
 
-    // Validation + packing is independent per block: host threads (HP_PACK_THREADS, default min(16, cores)) each
+    // Validation + packing is independent per block: host threads (HP_PACK_THREADS, default min(8, cores)) each
     // pack a contiguous range of blocks into their own arrays; the parts are uploaded side by side and only the
     // small per-block tables are merged.
     const double t_pack0 = wall_ms();
-    unsigned nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    // (8: measured 1.9 ms for the default bench's 452 blocks; 4: 2.0, 16: 2.9, 32: 4.8 - every part costs nine uploads)
+    unsigned nt = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* e = std::getenv("HP_PACK_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
     nt = (unsigned)std::min<size_t>(nt, n_blocks / 8 + 1);
     std::vector<HostPack> parts(nt);
+    // contiguous ranges of blocks with about the same number of cells each (block sizes are heavy-tailed: equal COUNTS left
+    // one thread with the 2 000-variant block and its neighbours)
+    std::vector<size_t> cut(nt + 1, n_blocks);
+    {
+        std::vector<uint64_t> cum(n_blocks + 1, 0);
+        for (size_t i = 0; i < n_blocks; ++i) {
+            const hp_block_view& v = blks[i];
+            const uint64_t c = (v.row_off && v.n_reads && v.n_reads <= (1u << 28)) ? v.row_off[v.n_reads] : 0;
+            cum[i + 1] = cum[i] + std::min<uint64_t>(c, 1ull << 40) + 64u * v.n_reads + 256u;
+        }
+        cut[0] = 0;
+        for (unsigned t = 1; t < nt; ++t)
+            cut[t] = std::max<size_t>(cut[t - 1], (size_t)(std::lower_bound(cum.begin(), cum.end(), cum[n_blocks] / nt * t) - cum.begin()));
+        for (unsigned t = 1; t < nt; ++t) cut[t] = std::min(cut[t], n_blocks);
+    }
     {
         std::vector<int> rcs(nt, HP_OK);
         std::vector<std::string> errs(nt);
@@ -548,7 +564,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
             {   // exact capacities up front: no reallocation copies while packing (rows with an empty region are dropped,
                 // so the row tables may end up a little shorter; malformed views are rejected by pack_block)
                 uint64_t rows = 0, cells = 0, vars = 0, abytes = 0;
-                for (size_t i = n_blocks * t / nt; i < n_blocks * (t + 1) / nt; ++i) {
+                for (size_t i = cut[t]; i < cut[t + 1]; ++i) {
                     const hp_block_view& v = blks[i];
                     if (!v.row_off || v.n_reads > (1u << 28) || v.n_variants > (1u << 24)) { rows = 0; cells = 0; vars = 0; abytes = 0; break; }
                     const uint64_t c = v.n_reads ? v.row_off[v.n_reads] : 0;
@@ -563,7 +579,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
                     q.raw_alleles.reserve(abytes); q.raw_quals.reserve(cells);
                 } catch (...) {}   // a hint only: a view with absurd sizes is reported by pack_block, not here
             }
-            for (size_t i = n_blocks * t / nt; i < n_blocks * (t + 1) / nt; ++i) {
+            for (size_t i = cut[t]; i < cut[t + 1]; ++i) {
                 const int rc = pack_block(&blks[i], parts[t]);
                 if (rc != HP_OK) {
                     rcs[t] = rc;

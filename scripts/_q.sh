@@ -1,6 +1,4 @@
 run() { echo "== $*"; env "$@" timeout 200 python bench.py --no-cpu --steps 10 --warmup 3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],2), {k:round(v,1) for k,v in d['stage_ms'].items()})"; }
-timeout 600 python -m pytest tests/test_astar_gpu.py -x -q 2>&1 | tail -2
-run A=1
-run HP_SEG_WARM=48
-run HP_SEG_WARM=40
-HP_DEBUG=1 timeout 100 python bench.py --no-cpu --steps 1 --warmup 1 2>&1 | grep "segment-parallel" | tail -1
+run HP_PACK_THREADS=16
+run HP_PACK_THREADS=8
+run HP_PACK_THREADS=4
