@@ -66,6 +66,15 @@ W2DEV uint32_t w2_pfx16(const uint4& a, const uint4& b) {
     if (x3) return 12u + ((uint32_t)__builtin_ctz(x3) >> 3);
     return 16u;
 }
+// 8-byte windows for the tie checks (the gap to the furthest candidate is one or two bytes almost always; 16-byte windows
+// for the four of them kept 16 more registers live through the extension)
+struct W2Pre8 { uint64_t a, b; };
+W2DEV W2Pre8 w2_pre8(const uint8_t* a, const uint8_t* b, bool on) {
+    W2Pre8 p; p.a = 0; p.b = 0;
+    if (on) { p.a = w2_ld8(a); p.b = w2_ld8(b); }
+    return p;
+}
+W2DEV uint32_t w2_pfx8(uint64_t a, uint64_t b) { const uint64_t x = a ^ b; return x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u; }
 struct W2Pre { uint4 a, b; };
 W2DEV W2Pre w2_pre(const uint8_t* a, const uint8_t* b, bool on) {
     W2Pre p;
@@ -562,7 +571,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         const W2Set<W> qC = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sC, 0)) * W, sC >= 0);
         // ---- waves that finished a parent THIS round (offset 0; wfa_graph.rs:527-553) ----
         bool hinj = false;
-        W2Set<W> qD = w2_set0<W>(), qD2 = w2_set0<W>();
+        W2Set<W> qD = w2_set0<W>();   // (a second or later finished parent is ORed in at once: rare, and it saves W registers)
         if (run) {
             for (uint32_t i = 0; i < npar; ++i) {
                 const uint32_t code = ((i < 4u ? pc0 >> (8u * i) : pc1 >> (8u * (i - 4u))) & 0xFFu);
@@ -579,7 +588,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                 else {
                     const W2Set<W> t = w2_ldset<W>(gs + (size_t)s * W, hit);
 #pragma unroll
-                    for (int w = 0; w < W; ++w) qD2.w[w] |= t.w[w];
+                    for (int w = 0; w < W; ++w) qD.w[w] |= t.w[w];
                 }
             }
             if (act && ed == 0 && n == 0 && d == 0) hinj = true;   // the start wave (wfa_graph.rs:366-378)
@@ -612,10 +621,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         uint64_t he = 0;
         if (has) he = htab[hpos];
         const W2Pre pm = w2_pre(na_, ra, room > 0);
-        const W2Pre pA = w2_pre(nseq + (nA ? oA : 0), readp + (nA ? d + oA : 0), nA);
-        const W2Pre pB = w2_pre(nseq + (nB ? oB : 0), readp + (nB ? d + oB : 0), nB);
-        const W2Pre pC = w2_pre(nseq + (nC ? oC : 0), readp + (nC ? d + oC : 0), nC);
-        const W2Pre pD = w2_pre(nseq, readp + (nD ? d : 0), nD);
+        const W2Pre8 pA = w2_pre8(nseq + (nA ? oA : 0), readp + (nA ? d + oA : 0), nA);
+        const W2Pre8 pB = w2_pre8(nseq + (nB ? oB : 0), readp + (nB ? d + oB : 0), nB);
+        const W2Pre8 pC = w2_pre8(nseq + (nC ? oC : 0), readp + (nC ? d + oC : 0), nC);
+        const W2Pre8 pD = w2_pre8(nseq, readp + (nD ? d : 0), nD);
         W2PT(3);
         uint32_t E;
         {
@@ -632,13 +641,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         }
         W2PT(4);
         {
-            // a tie check whose gap exceeds 16 bytes and whose first 16 match goes on with the cooperative compare
+            // a tie check whose gap exceeds 8 bytes and whose first 8 match goes on with the cooperative compare
             bool pdA = false, pdB = false, pdC = false, pdD = false;
-            auto quick = [&](const W2Pre& q, bool nX, int32_t oX, bool& pend16) -> bool {
+            auto quick = [&](const W2Pre8& q, bool nX, int32_t oX, bool& pend8) -> bool {
                 if (!nX) return false;
-                const uint32_t g = (uint32_t)(omax - oX), m = w2_pfx16(q.a, q.b);
-                if (g <= 16u) return m >= g;
-                pend16 = (m == 16u);
+                const uint32_t g = (uint32_t)(omax - oX), m = w2_pfx8(q.a, q.b);
+                if (g <= 8u) return m >= g;
+                pend8 = (m == 8u);
                 return false;
             };
             const bool xA = quick(pA, nA, oA, pdA), xB = quick(pB, nB, oB, pdB), xC = quick(pC, nC, oC, pdC), xD = quick(pD, nD, 0, pdD);
@@ -646,7 +655,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
             if (__any(pdA || pdB || pdC || pdD)) {   // rare: a long alternative run onto the furthest wave's diagonal
                 auto slow = [&](bool pd, int32_t oX) -> bool {
                     const uint32_t g = pd ? (uint32_t)(omax - oX) : 0u;
-                    const uint32_t mr = w2_match_rest<G>(nseq, readp, (uint32_t)(pd ? oX : 0), pd ? d + oX : 0, g, pd ? 16u : 0u, !pd, run, gbase, gl);
+                    const uint32_t mr = w2_match_rest<G>(nseq, readp, (uint32_t)(pd ? oX : 0), pd ? d + oX : 0, g, pd ? 8u : 0u, !pd, run, gbase, gl);
                     return pd && mr == g;
                 };
                 const bool yA = slow(pdA, oA), yB = slow(pdB, oB), yC = slow(pdC, oC), yD = slow(pdD, 0);
@@ -712,7 +721,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         W2Set<W> best;
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            uint32_t dset = qD.w[w] | qD2.w[w];
+            uint32_t dset = qD.w[w];
             if (hinj && (n >> 5) == (uint32_t)w) dset |= 1u << (n & 31u);   // best + the successor (wfa_graph.rs:535-541)
             best.w[w] = (tA ? qA.w[w] : 0u) | (tB ? qB.w[w] : 0u) | (tC ? qC.w[w] : 0u) | (tD ? dset : 0u);
         }
