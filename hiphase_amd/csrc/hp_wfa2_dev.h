@@ -261,10 +261,10 @@ template <int W> struct W2Cfg {
     // them (about 0.3 %) are handed to the largest class on the device (W2Batch::esc)
     static constexpr int MAXL = W <= 4 ? 16 : 56;     // live entries per round
     static constexpr int MAXF = W <= 4 ? 20 : 32;     // finished-only entries per round
-    static constexpr int SLOTS = W <= 4 ? 80 : 144;   // (node, diagonal) slots per round
+    static constexpr int SLOTS = W <= 4 ? 86 : 144;   // (node, diagonal) slots per round (86: what is left of 1 600 bytes)
     static constexpr int MAXQ = 8;               // nodes waiting for their turn with waves handed over by parents
     static constexpr int MAXPAR = 8;             // finished parent entries of one node in one round
-    static constexpr int MAXS = 12;              // source intervals of one node (slow path scratch)
+    static constexpr int MAXS = W <= 4 ? 8 : 12; // source intervals of one node (slow path scratch)
     static constexpr int MAXW = 250;             // diagonals per entry (8-bit relative hulls)
     static constexpr int a16(int x) { return (x + 15) & ~15; }
     // The node table is read from HBM (L2-resident: one 16-byte descriptor per node visit, with the first two children
