@@ -160,7 +160,7 @@ struct W2Session {
     std::vector<W2Variant> vars;
     std::vector<uint32_t> len_order;   // job ids, longest read first (stable)
     uint64_t seq_bytes = 0, alt_off = 0, node_tot = 0, edge_tot = 0, tag_tot = 0, allele_tot = 0;
-    DevBuf d_seq, d_vars, d_jobs, d_nodes, d_edges, d_tags, d_par, d_poff, d_cnt, d_info, d_order, d_len_order, d_cls, d_blockcnt, d_sets, d_score, d_status, d_alleles, d_work;
+    DevBuf d_seq, d_vars, d_jobs, d_nodes, d_edges, d_tags, d_info, d_order, d_len_order, d_cls, d_blockcnt, d_sets, d_score, d_status, d_alleles, d_work;
     double last_prepare_ms = 0.0;
     double last_span_ms = 0.0;   // of the last run: first class launch .. last class kernel done (the three run concurrently)
     uint64_t work_updates = 0, work_node_bytes = 0, work_read_bytes = 0, work_jobs = 0;   // of the last run (compact kernel only)
@@ -272,7 +272,7 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
         d.read_off = seq_bytes; d.read_len = j.read_len;
         seq_bytes += ((uint64_t)j.read_len + 15) & ~15ull;
         const uint64_t V = (uint64_t)j.n_hets + j.n_homs;
-        const uint64_t ncap = 5 * V + 2, ecap = 4 * ncap, tcap = 2 * (uint64_t)j.n_hets + 2;
+        const uint64_t ncap = 5 * V + 2, ecap = 2 * ncap, tcap = 2 * (uint64_t)j.n_hets + 2;   // (ecap: u16 units of the overflow list)
         if (node_tot + ncap >= 0xFFFFFFF0ull || edge_tot + ecap >= 0xFFFFFFF0ull || allele_tot + j.n_hets >= 0xFFFFFFF0ull) { set_error("batch too large"); return HP_ERR_UNSUPPORTED; }
         d.node_off = (uint32_t)node_tot; d.node_cap = (uint32_t)ncap; node_tot += ncap;
         d.edge_off = (uint32_t)edge_tot; d.edge_cap = (uint32_t)ecap; edge_tot += ecap;
@@ -336,7 +336,6 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     }
     if ((rc = d_seq.alloc(seq_bytes)) || (rc = d_vars.alloc(std::max<size_t>(1, vars.size()) * sizeof(W2Variant))) || (rc = d_jobs.alloc(n * sizeof(W2Job))) ||
         (rc = d_nodes.alloc((size_t)node_tot * sizeof(W2Node))) || (rc = d_edges.alloc((size_t)edge_tot * 2)) || (rc = d_tags.alloc((size_t)tag_tot * 4)) ||
-        (rc = d_par.alloc((size_t)edge_tot * 2)) || (rc = d_poff.alloc(((size_t)node_tot + n) * 4)) || (rc = d_cnt.alloc((size_t)node_tot * 4)) ||
         (rc = d_info.alloc(n * sizeof(W2Info))) || (rc = d_order.alloc(n * 12)) || (rc = d_len_order.alloc(n * 4)) || (rc = d_cls.alloc(n + 16)) || (rc = d_blockcnt.alloc(((n + 255) / 256 + 1) * 16)) || (rc = d_sets.alloc(n * W2_SET_STRIDE * 4)) ||
         (rc = d_score.alloc(n * 8)) || (rc = d_work.alloc(n * 8 + 16)) || (rc = d_status.alloc(n * 4)) || (rc = d_alleles.alloc(std::max<uint64_t>(allele_tot, 16))))
         return rc;
@@ -393,7 +392,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         W2BuildArgs A{};
         A.jobs = d_jobs.as<W2Job>(); A.n_jobs = (uint32_t)n; A.vars = d_vars.as<W2Variant>();
         A.nodes = d_nodes.as<W2Node>(); A.edges = d_edges.as<uint16_t>(); A.tags = d_tags.as<uint32_t>();
-        A.par = d_par.as<uint16_t>(); A.poff = d_poff.as<uint32_t>(); A.cnt = d_cnt.as<uint32_t>(); A.info = d_info.as<W2Info>();
+        A.info = d_info.as<W2Info>();
         HP_HIP_CHECK(hipEventRecord(e0, st));
         hipLaunchKernelGGL(hp_wfa2_build_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, A);
         HP_HIP_CHECK(hipGetLastError());

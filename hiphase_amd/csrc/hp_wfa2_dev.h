@@ -39,7 +39,7 @@ struct W2Job {              // 80 B
     uint32_t het_first, n_hets;   // into vars[]
     uint32_t hom_first, n_homs;
     uint32_t node_off, node_cap;  // into gnodes / per-node scratch
-    uint32_t edge_off, edge_cap;  // into gedges / parent scratch
+    uint32_t edge_off, edge_cap;  // into gedges (u16 units: two per overflow entry)
     uint32_t tag_off, tag_cap;    // into gtags
     uint32_t allele_off;          // into the output allele pool (n_hets bytes)
     uint32_t group;               // caller-defined (block-level path: qname group); unused by the WFA stage
@@ -48,10 +48,18 @@ struct W2Job {              // 80 B
 struct W2Node {             // 16 B: one aligned 16-byte load per node visit
     uint32_t seq_off;       // reference node: offset inside the job's window; allele node: offset in the allele pool
     uint32_t len_ref;       // length | is_reference << 31
-    uint32_t child;         // child_off | n_children << 16   (child_off relative to the job's edge list)
-    uint32_t c01;           // the first two children inline (child 0 | child 1 << 16): most nodes have at most two, and a
-                            // wave that finishes the node needs them at once (the edge list is a dependent load away)
+    uint32_t child;         // n_children | first overflow entry << 16
+    uint32_t c01;           // the first two children (child 0 | child 1 << 16): most nodes have at most two. A third and later
+                            // child is an entry (parent, child) of the job's overflow list edges[], in creation order = ascending
+                            // child id; a node's entries are found by scanning on from its first one (w2_next_child)
 };
+// child j >= 2 of node n: the next overflow entry of n at or after `scan` (which moves past it)
+HP_HD uint32_t w2_next_child(const uint16_t* edges, uint32_t n, uint32_t& scan) {
+    while ((uint32_t)edges[2u * scan] != n && scan < 32767u) ++scan;
+    const uint32_t c = edges[2u * scan + 1u];
+    ++scan;
+    return c;
+}
 constexpr uint32_t W2_IS_REF = 0x80000000u;
 
 struct W2Info {             // builder output per job
@@ -69,33 +77,44 @@ constexpr int W2B_MAXQ = 24;    // alt nodes waiting to reconnect
 constexpr int W2B_MAXRR = 32;   // reference_reconnect
 constexpr int W2B_MAXRA = 32;   // reference alleles waiting for the next reference node
 
-// WFAGraph::from_reference_variants_with_hom (wfa_graph.rs:119-284) for one job. Scratch: par[edge_cap] (u16),
-// poff[node_cap + 1] (u32), cnt[node_cap] (u32). Node ids are creation order (wfa_graph.rs:298-331).
-HP_HD void w2_build(const W2Job& J, const W2Variant* vars, W2Node* nodes, uint16_t* edges, uint32_t* tags,
-                    uint16_t* par, uint32_t* poff, uint32_t* cnt, W2Info* info) {
-    uint32_t nn = 0, ne = 0, nt = 0;
+// WFAGraph::from_reference_variants_with_hom (wfa_graph.rs:119-284) for one job, in one pass: a new node is entered into
+// its parents' child lists as it is created (the parents are the handful of nodes of reference_reconnect). Node ids are
+// creation order (wfa_graph.rs:298-331).
+HP_HD void w2_build(const W2Job& J, const W2Variant* vars, W2Node* nodes, uint16_t* edges, uint32_t* tags, W2Info* info) {
+    uint32_t nn = 0, ne = 0, nt = 0, no = 0;   // nodes, edges, tags, overflow entries
     int32_t status = W2B_OK;
     const int64_t ref_start = J.ref_start, ref_end = J.ref_start + (int64_t)J.ref_len;
     int64_t previous_end = ref_start;
     uint32_t rr[W2B_MAXRR]; int nrr = 0;      // reference_reconnect
     uint32_t ra[W2B_MAXRA]; int nra = 0;      // pending (het index, 0) tags
     int64_t qpos[W2B_MAXQ]; uint32_t qalt[W2B_MAXQ]; int nq = 0;   // reconnect queue, ascending position
-    poff[0] = 0;
 
     // add_node (wfa_graph.rs:298-331); parents = the current reference_reconnect
     auto add_node = [&](uint32_t seq_off, uint32_t len, bool is_ref) -> int {
         if (nn == 0) { if (nrr != 0) { status = W2B_INVARIANT; return -1; } }
         else if (nrr == 0) { status = W2B_INVARIANT; return -1; }
-        if (nn >= J.node_cap || nn >= 65535u || ne + (uint32_t)nrr > J.edge_cap || ne + (uint32_t)nrr > 65535u || len >= W2_IS_REF) {
+        if (nn >= J.node_cap || nn >= 65535u || ne + (uint32_t)nrr > 65535u || len >= W2_IS_REF) {
             status = W2B_NEED_HOST; return -1;
         }
         nodes[nn].seq_off = seq_off;
         nodes[nn].len_ref = len | (is_ref ? W2_IS_REF : 0u);
         nodes[nn].child = 0;
         nodes[nn].c01 = 0;
-        for (int k = 0; k < nrr; ++k) par[ne + k] = (uint16_t)rr[k];
+        for (int k = 0; k < nrr; ++k) {
+            const uint32_t p = rr[k];
+            uint32_t ch = nodes[p].child;
+            const uint32_t c = ch & 0xFFFFu;
+            if (c == 0) nodes[p].c01 = nn;
+            else if (c == 1) nodes[p].c01 |= nn << 16;
+            else {
+                if (c >= 65535u || 2u * (no + 1u) > J.edge_cap || no >= 32767u) { status = W2B_NEED_HOST; return -1; }
+                if (c == 2) ch |= no << 16;
+                edges[2u * no] = (uint16_t)p; edges[2u * no + 1u] = (uint16_t)nn;
+                ++no;
+            }
+            nodes[p].child = ch + 1u;
+        }
         ne += (uint32_t)nrr;
-        poff[nn + 1] = ne;
         return (int)nn++;
     };
     auto flush_ref_alleles = [&](uint32_t node) {
@@ -187,27 +206,6 @@ HP_HD void w2_build(const W2Job& J, const W2Variant* vars, W2Node* nodes, uint16
         const int ri = add_node((uint32_t)(previous_end - ref_start), (uint32_t)(ref_end - previous_end), true);
         if (ri >= 0 && nra != 0) status = W2B_INVARIANT;   // assert!(reference_alleles.is_empty()) (:281)
     }
-    // children lists: count, prefix, fill (ascending child id)
-    if (status == W2B_OK) {
-        for (uint32_t n = 0; n < nn; ++n) cnt[n] = 0;
-        for (uint32_t e = 0; e < ne; ++e) cnt[par[e]]++;
-        uint32_t run = 0;
-        for (uint32_t n = 0; n < nn; ++n) {
-            const uint32_t c = cnt[n];
-            if (c > 65535u) { status = W2B_NEED_HOST; break; }
-            nodes[n].child = run | (c << 16);
-            cnt[n] = run;
-            run += c;
-        }
-        if (status == W2B_OK) {
-            for (uint32_t n = 1; n < nn; ++n)
-                for (uint32_t e = poff[n]; e < poff[n + 1]; ++e) edges[cnt[par[e]]++] = (uint16_t)n;
-            for (uint32_t n = 0; n < nn; ++n) {
-                const uint32_t co = nodes[n].child & 0xFFFFu, nc = nodes[n].child >> 16;
-                nodes[n].c01 = (nc > 0 ? (uint32_t)edges[co] : 0u) | (nc > 1 ? (uint32_t)edges[co + 1] << 16 : 0u);
-            }
-        }
-    }
     info->n_nodes = nn;
     info->n_edges = ne;
     info->n_tags = nt;
@@ -268,14 +266,11 @@ template <int W> struct W2Cfg {
     static constexpr int MAXW = 250;             // diagonals per entry (8-bit relative hulls)
     static constexpr int a16(int x) { return (x + 15) & ~15; }
     // The node table is read from HBM (L2-resident: one 16-byte descriptor per node visit, with the first two children
-    // inline) - with the table sizes above that takes a read's LDS to 1 584 bytes, i.e. 12 workgroups of 8 reads per CU =
+    // inline) - with the table sizes above that takes a read's LDS to 1 600 bytes, i.e. 12 workgroups of 8 reads per CU =
     // three wavefronts per SIMD for the two smaller classes. The kernel waits on memory half of the time; its throughput
     // follows the resident wavefronts almost linearly (4 / 6 / 8 workgroups per CU: 2.6 / 3.9 / 5.1 M reads/s).
-    static constexpr bool DESC_LDS = false;
     static constexpr int WAVES_PER_SIMD = W <= 4 ? 3 : 2;   // the register budget the kernel is compiled for (512 / waves)
-    static constexpr int O_DESC = 0;                                  // uint2[MAXN]: seq_off, len | is_ref << 18 | child_off << 19 | n_children << 29
-    static constexpr int O_EDGE = O_DESC + (DESC_LDS ? 8 * MAXN : 0); // u8[MAXE]
-    static constexpr int O_LIVE = a16(O_EDGE + (DESC_LDS ? MAXE : 0)); // uint4[2][MAXL]
+    static constexpr int O_LIVE = 0;                                  // uint4[2][MAXL]
     static constexpr int O_FIN = O_LIVE + 2 * 16 * MAXL;              // uint4[MAXF]
     static constexpr int O_EK = O_FIN + 16 * MAXF;                    // u32[2][SLOTS]: offset << 3 | kind
     static constexpr int O_MISC = a16(O_EK + 2 * 4 * SLOTS);          // outset[W]

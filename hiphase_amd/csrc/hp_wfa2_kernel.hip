@@ -193,8 +193,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
     constexpr uint32_t NG = 64 / G;
     const uint32_t lane = w2_lane(), gid = lane / G, gl = lane % G, gbase = gid * G;
     unsigned char* R = w2_smem + (size_t)gid * C::BYTES;
-    const uint2* desc = reinterpret_cast<const uint2*>(R + C::O_DESC);
-    const uint8_t* edg = reinterpret_cast<const uint8_t*>(R + C::O_EDGE);
     uint4* live = reinterpret_cast<uint4*>(R + C::O_LIVE);          // [parity * MAXL + i]
     uint4* fin = reinterpret_cast<uint4*>(R + C::O_FIN);            // [i]
     uint32_t* ek = reinterpret_cast<uint32_t*>(R + C::O_EK);        // [parity * SLOTS + s]
@@ -292,8 +290,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
 #endif
         }
         if (fn)
-            for (uint32_t j = 0; j < n_child; ++j)
-                pq_append(C::DESC_LDS ? (uint32_t)edg[child_off + j] : (j == 0 ? (c01 & 0xFFFFu) : (j == 1 ? (c01 >> 16) : (uint32_t)gedge[child_off + j])), code);
+            for (uint32_t j = 0, scan = child_off; j < n_child; ++j)
+                pq_append(j == 0 ? (c01 & 0xFFFFu) : (j == 1 ? (c01 >> 16) : w2_next_child(gedge, n, scan)), code);
         chi = INT32_MIN; cvlo = INT32_MAX; cvhi = INT32_MIN; cflo = INT32_MAX; cfhi = INT32_MIN;
     };
 
@@ -386,19 +384,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                 }
                 gnode = B.nodes + jd.node_off;
                 gedge = B.edges + jd.edge_off;
-                if (C::DESC_LDS) {
-                    uint2* ld = reinterpret_cast<uint2*>(R + C::O_DESC);
-                    bool bad = false;
-                    for (uint32_t i = gl; i < n_nodes; i += G) {
-                        const W2Node nd = gnode[i];
-                        const uint32_t ln = nd.len_ref & ~W2_IS_REF, co = nd.child & 0xFFFFu, nc = nd.child >> 16;
-                        bad = bad || ln >= W2_LDS_LEN_LIM || co >= 1024u || nc >= 8u;
-                        ld[i] = make_uint2(nd.seq_off, ln | ((nd.len_ref >> 31) << 18) | (co << 19) | (nc << 29));
-                    }
-                    uint8_t* le = reinterpret_cast<uint8_t*>(R + C::O_EDGE);
-                    for (uint32_t i = gl; i < ji.n_edges; i += G) le[i] = (uint8_t)gedge[i];
-                    if (w2_gballot<G>(bad, gbase)) { status = W2_ST_NEED_BIG, why = 5u; continue; }
-                }
                 // the start wave (wfa_graph.rs:366-378): node 0 waits for its turn in round 0, with no parent
                 pq_node = gl == 0 ? 0u : 0xFFFFu; pq_cnt = 0; pq_c0 = 0; pq_c1 = 0;
                 ed = 0; c = 0; p = 1; lcnt_prev = 0; lcnt_cur = 0; fcnt = 0; top = 0; pp = 0; steps = 0;
@@ -427,17 +412,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                     continue;
                 }
                 {
-                    if (C::DESC_LDS) {
-                        const uint2 nd = desc[n];
-                        len = nd.y & (W2_LDS_LEN_LIM - 1u);
-                        nseq = (((nd.y >> 18) & 1u) ? refp : altp) + nd.x;
-                        child_off = (nd.y >> 19) & 1023u; n_child = nd.y >> 29;
-                    } else {
-                        const uint4 nd = *reinterpret_cast<const uint4*>(gnode + n);   // seq_off, len | is_ref, children, first two children
-                        len = nd.y & ~W2_IS_REF;
-                        nseq = ((nd.y & W2_IS_REF) ? refp : altp) + nd.x;
-                        child_off = nd.z & 0xFFFFu; n_child = nd.z >> 16; c01 = nd.w;
-                    }
+                    const uint4 nd = *reinterpret_cast<const uint4*>(gnode + n);   // seq_off, len | is_ref, children, first two children
+                    len = nd.y & ~W2_IS_REF;
+                    nseq = ((nd.y & W2_IS_REF) ? refp : altp) + nd.x;
+                    n_child = nd.z & 0xFFFFu; child_off = nd.z >> 16; c01 = nd.w;   // (child_off: first overflow entry)
                 }
                 // ---- sources: previous entries of n grown by one diagonal a side, finished parents, the start wave ----
                 lo = INT32_MAX; hi = INT32_MIN;
@@ -873,17 +851,13 @@ struct W2BuildArgs {
     W2Node* nodes;
     uint16_t* edges;
     uint32_t* tags;
-    uint16_t* par;      // [sum edge_cap] scratch
-    uint32_t* poff;     // [sum node_cap + n_jobs] scratch (job j: at node_off + j)
-    uint32_t* cnt;      // [sum node_cap] scratch
     W2Info* info;
 };
 __global__ void __launch_bounds__(64) hp_wfa2_build_kernel(W2BuildArgs A) {
     const uint32_t j = blockIdx.x * 64u + threadIdx.x;
     if (j >= A.n_jobs) return;
     const W2Job J = A.jobs[j];
-    w2_build(J, A.vars, A.nodes + J.node_off, A.edges + J.edge_off, A.tags + J.tag_off, A.par + J.edge_off,
-             A.poff + J.node_off + j, A.cnt + J.node_off, A.info + j);
+    w2_build(J, A.vars, A.nodes + J.node_off, A.edges + J.edge_off, A.tags + J.tag_off, A.info + j);
 }
 
 // ---- traversed nodes -> per-het AlleleType (read_parsing.rs:790-800): one thread per job ---------------------------

@@ -53,11 +53,9 @@ void build_from_job(const hp_wfa_job* j, Built& b) {
     J.read_len = j->read_len;
     J.het_first = 0; J.n_hets = j->n_hets; J.hom_first = j->n_hets; J.n_homs = j->n_homs;
     const uint32_t V = j->n_hets + j->n_homs;
-    J.node_cap = 5 * V + 2; J.edge_cap = 4 * J.node_cap; J.tag_cap = 2 * j->n_hets + 2;
+    J.node_cap = 5 * V + 2; J.edge_cap = 2 * J.node_cap; J.tag_cap = 2 * j->n_hets + 2;
     b.nodes.resize(J.node_cap); b.edges.resize(J.edge_cap); b.tags.resize(J.tag_cap);
-    std::vector<uint16_t> par(J.edge_cap);
-    std::vector<uint32_t> poff(J.node_cap + 1), cnt(J.node_cap);
-    w2_build(J, b.vars.data(), b.nodes.data(), b.edges.data(), b.tags.data(), par.data(), poff.data(), cnt.data(), &b.info);
+    w2_build(J, b.vars.data(), b.nodes.data(), b.edges.data(), b.tags.data(), &b.info);
 }
 
 template <int W> struct Slot { uint32_t ek = 0; uint32_t set[W]; };
@@ -102,7 +100,8 @@ int model_wfa(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t 
             const W2Node nd = b.nodes[n];
             const uint32_t len = nd.len_ref & ~W2_IS_REF;
             const uint8_t* nseq = (nd.len_ref & W2_IS_REF) ? ref + nd.seq_off : b.pool.data() + nd.seq_off;
-            const uint32_t child_off = nd.child & 0xFFFFu, n_child = nd.child >> 16;
+            const uint32_t n_child = nd.child & 0xFFFFu;
+            uint32_t scan = nd.child >> 16;   // first overflow entry (children 2 and later)
             // ---- sources ----
             const size_t p_first = pp;
             std::vector<std::pair<int32_t, int32_t>> src;
@@ -225,9 +224,11 @@ int model_wfa(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t 
                     else if (++n_fin_entries > (size_t)C::MAXF) { g_reason[1]++; return false; }
                     if (L.flo <= L.fhi) {
                         any_finished_node = true;
+                        uint32_t sc = scan;
                         for (uint32_t j = 0; j < n_child; ++j) {
-                            pairs.push_back(Pair{b.edges[child_off + j], (uint32_t)live[c].size()});
-                            pend[b.edges[child_off + j]] = 1;
+                            const uint32_t cid = j == 0 ? (nd.c01 & 0xFFFFu) : (j == 1 ? (nd.c01 >> 16) : w2_next_child(b.edges.data(), n, sc));
+                            pairs.push_back(Pair{cid, (uint32_t)live[c].size()});
+                            pend[cid] = 1;
                             size_t waiting = 0;
                             for (uint32_t q = 0; q < nn; ++q) waiting += pend[q];
                             if (waiting > (size_t)C::MAXQ) { g_reason[4]++; return false; }
