@@ -588,12 +588,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
                 }
             }
         };
-        if (nt == 1) work(0);
-        else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
-            for (auto& x : th) x.join();
-        }
+        WorkerPool::get().run(nt, work);
         for (unsigned t = 0; t < nt; ++t) if (rcs[t] != HP_OK) { set_error("%s", errs[t].c_str()); return fail(rcs[t]); }
     }
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] host pack of %zu blocks on %u threads: %.1f ms\n", n_blocks, nt, wall_ms() - t_pack0); fflush(stderr); }

@@ -552,12 +552,7 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
                 if (r != HP_OK) { int exp = HP_OK; if (first_rc.compare_exchange_strong(exp, r)) errs[t] = hp_last_error(); return; }
             }
         };
-        if (nt <= 1) work(0);
-        else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
-            for (auto& x : th) x.join();
-        }
+        WorkerPool::get().run(std::max(1u, nt), work);
         if (first_rc.load() != HP_OK) {
             for (auto& e : errs) if (!e.empty()) { set_error("%s", e.c_str()); break; }
             return first_rc.load();
@@ -699,13 +694,7 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
         if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
         nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, nb / 8));
         std::atomic<size_t> next{0};
-        auto work = [&]() { for (;;) { const size_t kb = next.fetch_add(1); if (kb >= nb) return; emit_block(kb); } };
-        if (nt <= 1) work();
-        else {
-            std::vector<std::thread> th;
-            for (unsigned i = 0; i < nt; ++i) th.emplace_back(work);
-            for (auto& x : th) x.join();
-        }
+        WorkerPool::get().run(std::max(1u, nt), [&](unsigned) { for (;;) { const size_t kb = next.fetch_add(1); if (kb >= nb) return; emit_block(kb); } });
         if (cap_fail.load() >= 0) { set_error("block %lld: seg_cell_cap too small", (long long)cap_fail.load()); return HP_ERR_ARG; }
     }
     const double t5 = blk_now_ms();

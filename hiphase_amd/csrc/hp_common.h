@@ -9,6 +9,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "../../include/hiphase_gpu.h"
 
@@ -82,6 +83,58 @@ struct HelperThread {
             { std::unique_lock<std::mutex> lk(m); quit = true; cv.notify_all(); }
             th.join();
         }
+    }
+};
+
+// Host worker threads shared by the stages that fan out over blocks / jobs (row assembly, outputs, result scatter, A*
+// pack): a stage used to start and join its own std::threads, which cost more than the work on a 40 ms step. The pool is
+// created on first use and never destroyed (its threads may be parked in a condition variable at exit). One parallel
+// region at a time: a caller that finds the pool busy (another host thread's region, or a nested one) starts threads of
+// its own as before. A worker's thread-local caches (device buffers, error slot) live as long as the process.
+class WorkerPool {
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    std::vector<std::thread> th;
+    std::function<void(unsigned)> job;
+    unsigned want = 0, started = 0, done = 0;
+    bool busy = false;
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [this]() { return started < want; });
+            const unsigned id = started++;
+            lk.unlock();
+            job(id);
+            lk.lock();
+            if (++done == want) cv_done.notify_all();
+        }
+    }
+public:
+    static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }
+    // f(0) .. f(nt - 1), each on a thread of its own (the caller runs f(nt - 1)); returns when all are done
+    template <class F> void run(unsigned nt, F&& f) {
+        if (nt <= 1) { f(0u); return; }
+        std::unique_lock<std::mutex> lk(m);
+        if (busy) {
+            lk.unlock();
+            std::vector<std::thread> own;
+            for (unsigned t = 0; t + 1 < nt; ++t) own.emplace_back([&f, t]() { f(t); });
+            f(nt - 1);
+            for (auto& x : own) x.join();
+            return;
+        }
+        busy = true;
+        while (th.size() + 1 < nt) th.emplace_back([this]() { loop(); });
+        for (auto& x : th) if (x.joinable()) x.detach();
+        job = [&f](unsigned t) { f(t); };
+        want = nt - 1; started = 0; done = 0;
+        cv.notify_all();
+        lk.unlock();
+        f(nt - 1);
+        lk.lock();
+        cv_done.wait(lk, [this]() { return done == want; });
+        want = 0; started = 0; done = 0;
+        busy = false;
     }
 };
 

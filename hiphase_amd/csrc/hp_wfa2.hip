@@ -104,10 +104,7 @@ unsigned w2_host_threads(size_t n, size_t per_thread) {
     return (unsigned)std::min<size_t>(std::max(1u, nt), std::max<size_t>(1, n / per_thread));
 }
 template <class F> void w2_parallel(unsigned nt, F&& f) {
-    if (nt <= 1) { f(0u, 1u); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t) th.emplace_back([&f, t, nt]() { f(t, nt); });
-    for (auto& x : th) x.join();
+    WorkerPool::get().run(std::max(1u, nt), [&f, nt](unsigned t) { f(t, std::max(1u, nt)); });
 }
 
 // union of address ranges [p, p + len): sorted, merged where they overlap or touch

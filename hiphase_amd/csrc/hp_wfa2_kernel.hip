@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
     uint32_t state = S_JOB, jround = 0, job = 0, ticket = 0, idle_polls = 0;
     bool have_ticket = false;
     uint32_t poll_div = 0;
+    uint32_t n_live_node = 0;   // live entries the current node has got this round
 #if W2_STATS
     uint32_t mx_l = 0, mx_f = 0, mx_top = 0;   // how far a job fills its tables (sizing study, scripts/prof_wfa2.sh)
 #endif
@@ -276,6 +277,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
             code = lcnt_cur;
             if (gl == 0) live[c * C::MAXL + lcnt_cur] = h;
             lcnt_cur++;
+            ++n_live_node;
             round_live = true;
 #if W2_STATS
             mx_l = max(mx_l, lcnt_cur);
@@ -448,7 +450,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                     }
                 }
                 if (ed == 0 && n == 0) { lo = min(lo, 0); hi = max(hi, 0); }
-                n_items = 1; item = 0; use_list = false;
+                n_items = 1; item = 0; use_list = false; n_live_node = 0;
                 if (hi - lo >= 2 * (int32_t)G) {
                     // far-apart sources (a structural variant upstream puts two paths hundreds of diagonals apart): walk
                     // them again, merge what overlaps or touches, every remaining interval is an item of its own
@@ -737,7 +739,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                     rem &= ~rm;
                     first = base + f; lastd = base + f + e - 1;
                 } else end_pending = false;
-                if (chi != INT32_MIN && (first - chi >= 3 || lastd - clo >= (int32_t)C::MAXW)) emit_cluster();
+                // (a node keeps at most two live entries per round - the next round reads at most two: once it has one, the
+                // rest of its diagonals stay one cluster, gaps included)
+                if (chi != INT32_MIN && ((first - chi >= 3 && n_live_node == 0u) || lastd - clo >= (int32_t)C::MAXW)) emit_cluster();
                 if (bit) {
                     if (chi == INT32_MIN) clo = first;
                     chi = lastd;
