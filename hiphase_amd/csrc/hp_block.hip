@@ -490,12 +490,12 @@ int chunk_wfa(hp_blockset* bs, BlockChunk& ch) {
     if (!ch.jobs.empty()) {
         int rc;
         // (the few reads the compact kernel hands back are still in the dense-band pass when this returns: chunk_tail)
-        if (ch.wfa) rc = w2_session_run(ch.wfa, bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(), ch.allele_ptrs.data(), 1);
+        if (ch.wfa) rc = w2_session_run(ch.wfa, bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(), ch.allele_ptrs.data(), bs->chunks.size() == 1 ? 2 : 1);
         else rc = hp_wfa_assign_batch(ch.jobs.data(), ch.jobs.size(), bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(),
                                       ch.allele_ptrs.data(), bs->device);
         if (rc != HP_OK) return rc;
         // the three class instantiations of hp_wfa2_kernel run concurrently: their span is the kernel time of the stage
-        ch.ms[6] = ch.wfa ? w2_session_span_ms(ch.wfa) : hp_last_kernel_ms();
+        ch.ms[6] = ch.wfa ? 0.0 : hp_last_kernel_ms();   // (resident session: known once its second collection is done, chunk_tail)
     }
     ch.ms[0] = blk_now_ms() - t0;
     return HP_OK;
@@ -558,6 +558,7 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
             return first_rc.load();
         }
         if (ch.wfa && (rc = w2_session_finish(ch.wfa)) != HP_OK) return rc;   // (already done unless no block was held)
+        if (ch.wfa) ch.ms[6] = w2_session_span_ms(ch.wfa);
         if (dbg) {
             double s = 0.0, m = 0.0; size_t arg = 0;
             for (unsigned i = 0; i < std::max(1u, nt); ++i) { s += dbg_sum[i]; if (dbg_max[i] > m) { m = dbg_max[i]; arg = dbg_arg[i]; } }

@@ -165,21 +165,38 @@ struct W2Session {
     // defer = true run() returns while it is still going and finish() waits for it (hp_block.hip assembles the blocks
     // that do not hold a leftover read in the meantime)
     struct Pending {
-        bool on = false;
-        HelperThread* helper = nullptr;
-        std::vector<uint32_t> ids;
+        bool on = false, posted = false, two_phase = false;
+        std::vector<uint32_t> ids;      // every job whose result finish() delivers: held + big
+        std::vector<uint32_t> held;     // still with the largest class's kernel when run() collected the others
+        std::vector<uint32_t> held_nodes;   // their graphs' node counts (hp_wfa_result::n_nodes)
+        std::vector<uint32_t> big;      // for the dense-band pass
         std::vector<hp_wfa_job> sub;
         std::vector<hp_wfa_result> sub_out;
         std::vector<uint8_t*> sub_al;
         hp_wfa_result* dst = nullptr;
+        uint8_t* const* alleles = nullptr;
+        uint64_t prune = 0, max_ed = 0;
+        hipStream_t stream2 = nullptr;  // the largest class's stream
+        float ms_build = 0.f;
         int rc = HP_OK;
         std::string err;
-        double ms = 0.0;
     } pend;
+    DevBuf d_job_cls, d_handed, d_seen;
+    PinBuf late_down;                      // results of the held jobs
+    std::unique_ptr<HelperThread> helper;  // runs late() when run() defers
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build start / end, class launches start / end
+    int late();                            // second collection + dense-band pass; on the helper thread when deferred
+    double late_kernel_ms = 0.0;
+    std::mutex work_m;
     int prepare(const hp_wfa_job* jobs_, size_t n_, int device);
-    int run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, bool defer = false);
+    // defer: 0 = everything is in `out` on return; 1 = the dense-band pass of the leftovers may still run (finish() waits);
+    // 2 = also the largest class's kernel (two phases) - the caller must not start another run on this thread before finish()
+    int run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer = 0);
     int finish();
-    ~W2Session() { if (pend.on && pend.helper) pend.helper->wait(); }
+    ~W2Session() {
+        if (pend.on && pend.posted && helper) helper->wait();
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    }
 };
 
 int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
@@ -333,7 +350,7 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     }
     if ((rc = d_seq.alloc(seq_bytes)) || (rc = d_vars.alloc(std::max<size_t>(1, vars.size()) * sizeof(W2Variant))) || (rc = d_jobs.alloc(n * sizeof(W2Job))) ||
         (rc = d_nodes.alloc((size_t)node_tot * sizeof(W2Node))) || (rc = d_edges.alloc((size_t)edge_tot * 2)) || (rc = d_tags.alloc((size_t)tag_tot * 4)) ||
-        (rc = d_info.alloc(n * sizeof(W2Info))) || (rc = d_order.alloc(n * 12)) || (rc = d_len_order.alloc(n * 4)) || (rc = d_cls.alloc(n + 16)) || (rc = d_blockcnt.alloc(((n + 255) / 256 + 1) * 16)) || (rc = d_sets.alloc(n * W2_SET_STRIDE * 4)) ||
+        (rc = d_info.alloc(n * sizeof(W2Info))) || (rc = d_order.alloc(n * 12)) || (rc = d_len_order.alloc(n * 4)) || (rc = d_cls.alloc(n + 16)) || (rc = d_job_cls.alloc(n + 16)) || (rc = d_handed.alloc(n + 16)) || (rc = d_seen.alloc(n * 4 + 16)) || (rc = d_blockcnt.alloc(((n + 255) / 256 + 1) * 16)) || (rc = d_sets.alloc(n * W2_SET_STRIDE * 4)) ||
         (rc = d_score.alloc(n * 8)) || (rc = d_work.alloc(n * 8 + 16)) || (rc = d_status.alloc(n * 4)) || (rc = d_alleles.alloc(std::max<uint64_t>(allele_tot, 16))))
         return rc;
     HP_HIP_CHECK(hipMemcpyAsync(d_seq.p, cx.stage.p, seq_bytes, hipMemcpyHostToDevice, st));
@@ -348,7 +365,7 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     return HP_OK;
 }
 
-int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, bool defer) {
+int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer) {
     if (n == 0) return HP_OK;
     if (pend.on) { const int rcp = finish(); if (rcp != HP_OK) return rcp; }
     if (!out) { set_error("null argument"); return HP_ERR_ARG; }
@@ -356,6 +373,8 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const double t0 = w2_now_ms();
     g_last_kernel_ms = 0.0;
+    work_updates = work_node_bytes = work_read_bytes = work_jobs = 0;
+    late_kernel_ms = 0.0;
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
     const int n_cu = partition_cu_count(device_id);
     W2Context& cx = g_w2;
@@ -376,15 +395,12 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     const W2Info* info = info_pin;
     const uint32_t* cls_n = reinterpret_cast<const uint32_t*>(cx.down.p + dn_cnt);
     const uint8_t* al = cx.down.p + dn_al;
-    struct StreamDrain { hipStream_t s; W2Context::Streams* c; ~StreamDrain() { for (int k = 0; k < 3; ++k) if (c->cstream[k]) (void)hipStreamSynchronize(c->cstream[k]); (void)hipStreamSynchronize(s); } } drain{st, cs_};
+    struct StreamDrain { hipStream_t s; W2Context::Streams* c; bool skip2; ~StreamDrain() { for (int k = 0; k < 3; ++k) if (c->cstream[k] && !(skip2 && k == 2)) (void)hipStreamSynchronize(c->cstream[k]); (void)hipStreamSynchronize(s); } } drain{st, cs_, false};
     const double t_stage = t0;
 
     // ---- 3. graphs on the device ----------------------------------------------------------------------------------------
-    hipEvent_t e0, e1, e2, e3;
-    HP_HIP_CHECK(hipEventCreate(&e0)); HP_HIP_CHECK(hipEventCreate(&e1)); HP_HIP_CHECK(hipEventCreate(&e2)); HP_HIP_CHECK(hipEventCreate(&e3));
-    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 4; ++i) (void)hipEventDestroy(e[i]); } };
-    hipEvent_t evs[4] = {e0, e1, e2, e3};
-    EvGuard evg{evs};
+    for (auto& e : ev) if (!e) HP_HIP_CHECK(hipEventCreate(&e));
+    hipEvent_t e0 = ev[0], e1 = ev[1], e2 = ev[2], e3 = ev[3];
     {
         W2BuildArgs A{};
         A.jobs = d_jobs.as<W2Job>(); A.n_jobs = (uint32_t)n; A.vars = d_vars.as<W2Variant>();
@@ -424,7 +440,8 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         W2ClassArgs CA{};
         CA.jobs = d_jobs.as<W2Job>(); CA.info = d_info.as<W2Info>(); CA.len_order = d_len_order.as<uint32_t>(); CA.n_jobs = (uint32_t)n;
         CA.order = d_order.as<uint32_t>(); CA.counts = d_counts; CA.status = d_status.as<int32_t>();
-        CA.cls = d_cls.as<uint8_t>(); CA.blockcnt = d_blockcnt.as<uint32_t>(); CA.esc = d_esc;
+        CA.cls = d_cls.as<uint8_t>(); CA.blockcnt = d_blockcnt.as<uint32_t>(); CA.esc = d_esc; CA.job_cls = d_job_cls.as<uint8_t>();
+        HP_HIP_CHECK(hipMemsetAsync(d_handed.p, 0, n, st));
         { const char* e = std::getenv("HP_WFA2_USE_W2"); CA.use_w2 = (e && e[0] == '0') ? 0u : 1u; }
         hipLaunchKernelGGL(hp_wfa2_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CA);
         hipLaunchKernelGGL(hp_wfa2_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CA);
@@ -459,6 +476,11 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     const char* denv = std::getenv("HP_WFA2_ESC_DIV");
     const uint32_t esc_div = denv ? (uint32_t)std::max(1, std::atoi(denv)) : 128u;
     const uint32_t items2 = escalate ? cls_cnt[2] + std::max<uint32_t>(4u * 48u, (cls_cnt[0] + cls_cnt[1]) / esc_div) : cls_cnt[2];
+    // two phases: the results of everything the two smaller classes finished themselves are collected as soon as THEIR
+    // kernels are done; the largest class (its own jobs + what was handed over, the tail of the launch set) is collected
+    // by late(), which the block layer overlaps with the row assembly of the blocks that do not wait for it
+    const char* tpenv = std::getenv("HP_WFA2_TWO_PHASE");
+    const bool two_phase = defer >= 2 && escalate && !(tpenv && tpenv[0] == '0');
     int launch_order[3] = {1, 0, 2};   // measured on the default bench (ms of the span): 102 22.5, 120 22.6, 012 22.8, 201 23.2
     if (const char* e = std::getenv("HP_WFA2_ORDER")) { if (std::strlen(e) == 3) for (int i = 0; i < 3; ++i) launch_order[i] = std::min(2, std::max(0, e[i] - '0')); }
     for (int li = 0; li < 3; ++li) {
@@ -472,7 +494,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         B.next = cx.qhead.as<uint32_t>() + 16 * k;
         B.htab = cx.htab.as<uint64_t>() + (((size_t)k * cx.htab_groups) << W2_HCAP_LOG2);
         B.gsets = cx.gsets.as<uint32_t>() + (size_t)k * cx.htab_groups * W2_GSET_STRIDE;
-        B.esc = d_esc; B.esc_order = d_order.as<uint32_t>() + (size_t)2 * n;
+        B.esc = d_esc; B.esc_order = d_order.as<uint32_t>() + (size_t)2 * n; B.handed = d_handed.as<uint8_t>();
         B.esc_role = !escalate ? 0u : (k == 2 ? 2u : 1u);
         B.esc_producers = grid_wg[0] + grid_wg[1];
         if (k == 0) rc = w2_launch<8, 2>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k]);
@@ -481,22 +503,24 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
                                          : w2_launch<8, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k]);
         else rc = w2_launch<16, 8>(B, items2, n_cu, cx.htab_groups, cs, &groups_used[k]);
         if (rc != HP_OK) return rc;
+        if (two_phase && k == 2) { HP_HIP_CHECK(hipEventRecord(e3, cs)); continue; }   // collected later (late())
         HP_HIP_CHECK(hipEventRecord(cx.cjoin[k], cs));
         HP_HIP_CHECK(hipStreamWaitEvent(st, cx.cjoin[k], 0));
     }
-    HP_HIP_CHECK(hipEventRecord(e3, st));
+    if (!two_phase) HP_HIP_CHECK(hipEventRecord(e3, st));
     {
         W2MapArgs M{};
         M.jobs = d_jobs.as<W2Job>(); M.info = d_info.as<W2Info>(); M.n_jobs = (uint32_t)n; M.tags = d_tags.as<uint32_t>();
         M.out_sets = d_sets.as<uint32_t>(); M.status = d_status.as<int32_t>(); M.alleles = d_alleles.as<uint8_t>();
         M.nodes = d_nodes.as<W2Node>(); M.out_work = d_work.as<uint32_t>();
+        M.job_cls = d_job_cls.as<uint8_t>(); M.handed = d_handed.as<uint8_t>(); M.seen = d_seen.as<int32_t>(); M.first = two_phase ? 1u : 0u;
         hipLaunchKernelGGL(hp_wfa2_map_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, M);
         HP_HIP_CHECK(hipGetLastError());
     }
     // ---- 5. results --------------------------------------------------------------------------------------------------------
     HP_HIP_CHECK(hipMemcpyAsync(info_pin, d_info.p, n * sizeof(W2Info), hipMemcpyDeviceToHost, st));
     HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_esc, d_esc, 16, hipMemcpyDeviceToHost, st));
-    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p, d_status.p, n * 4, hipMemcpyDeviceToHost, st));
+    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p, d_seen.p, n * 4, hipMemcpyDeviceToHost, st));
     HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_score, d_score.p, n * 8, hipMemcpyDeviceToHost, st));
     if (allele_tot) HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_al, d_alleles.p, (size_t)allele_tot, hipMemcpyDeviceToHost, st));
     HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_work, d_work.p, n * 8, hipMemcpyDeviceToHost, st));
@@ -506,15 +530,19 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
 #endif
     float ms_build = 0.f, ms_wfa = 0.f;
     (void)hipEventElapsedTime(&ms_build, e0, e1);
-    (void)hipEventElapsedTime(&ms_wfa, e2, e3);
+    if (!two_phase) (void)hipEventElapsedTime(&ms_wfa, e2, e3);
     g_last_kernel_ms = (double)ms_build + (double)ms_wfa;
     last_span_ms = (double)ms_wfa;
     const double t_done = w2_now_ms();
-    // jobs no class took (builder limits, graph size, read length) and jobs the compact kernel handed back (a limit of its class)
-    std::vector<uint32_t> big;
+    // held: still with the largest class's kernel (two phases). big: no class took them (builder limits, graph size, read
+    // length), or the largest class handed them back, or (one phase) nobody claimed them - the dense-band pass aligns those.
+    pend = Pending{};
+    pend.two_phase = two_phase; pend.dst = out; pend.alleles = alleles; pend.prune = prune_distance; pend.max_ed = max_ed;
+    pend.stream2 = cs_->cstream[2]; pend.ms_build = ms_build;
     for (size_t i = 0; i < n; ++i) {
         if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %zu", i); return HP_ERR_INVARIANT; }
-        if (status[i] == W2_ST_NEED_BIG || status[i] == W2_ST_PENDING) big.push_back((uint32_t)i);   // (PENDING: handed over, never claimed)
+        if (status[i] == W2_ST_PENDING) { if (two_phase) { pend.held.push_back((uint32_t)i); pend.held_nodes.push_back(info[i].n_nodes); } else pend.big.push_back((uint32_t)i); }
+        else if (status[i] == W2_ST_NEED_BIG) pend.big.push_back((uint32_t)i);
     }
     const size_t n_big = cls_n[3];
 #if W2_STATS
@@ -538,9 +566,9 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         tail(hl, "live entries", 1); tail(hf, "finished-only entries", 1); tail(ht, "arena slots", 8);
     }
 #endif
-    if (verbose && !big.empty()) {   // which class handed jobs back, and which of its limits (hp_wfa2_kernel's `why`)
+    if (verbose && !pend.big.empty()) {   // which class handed jobs back, and which of its limits (hp_wfa2_kernel's `why`)
         uint32_t hist[3][10] = {};
-        for (uint32_t i : big) {
+        for (uint32_t i : pend.big) {
             const uint32_t nn = info[i].n_nodes, ne = info[i].n_edges;
             if (info[i].status != W2B_OK || score[i] == 0 || score[i] > 9) continue;
             const int k = (nn <= (uint32_t)W2Cfg<2>::MAXN && ne <= (uint32_t)W2Cfg<2>::MAXE) ? 0 : (nn <= (uint32_t)W2Cfg<4>::MAXN && ne <= (uint32_t)W2Cfg<4>::MAXE) ? 1 : 2;
@@ -552,26 +580,23 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
             fprintf(stderr, "\n");
         }
     }
-    // ---- 6. leftovers go through the dense-band path on a helper thread WHILE the results of the others are scattered ----
-    pend.ids = big; pend.dst = out; pend.rc = HP_OK; pend.err.clear(); pend.ms = 0.0;
-    pend.sub.resize(big.size()); pend.sub_out.resize(big.size()); pend.sub_al.resize(big.size());
-    if (!big.empty()) {
-        for (size_t k = 0; k < big.size(); ++k) { pend.sub[k] = jobs[big[k]]; pend.sub_al[k] = alleles ? alleles[big[k]] : nullptr; }
+    // ---- 6. what is not here yet (late()): on the session's helper thread when the caller defers, else right below ----
+    pend.ids = pend.held;
+    pend.ids.insert(pend.ids.end(), pend.big.begin(), pend.big.end());
+    pend.on = !pend.ids.empty() || two_phase;
+    if (pend.on && defer) {
+        if (!helper) { helper.reset(new HelperThread()); helper->start(); }
         const int part = g_cu_partition;
-        if (!cx.helper) { cx.helper.reset(new HelperThread()); cx.helper->start(); }
-        pend.helper = cx.helper.get();
-        pend.on = true;
-        Pending* P = &pend;
-        const bool with_alleles = alleles != nullptr;
-        const int dev = device_id;
-        cx.helper->post([P, part, prune_distance, max_ed, with_alleles, dev]() {
+        W2Session* self = this;
+        pend.posted = true;
+        helper->post([self, part]() {
             g_cu_partition = part;
-            P->rc = wfa_assign_batch_v1(P->sub.data(), P->sub.size(), prune_distance, max_ed, P->sub_out.data(), with_alleles ? P->sub_al.data() : nullptr, dev);
-            if (P->rc != HP_OK) P->err = hp_last_error();
-            P->ms = g_last_kernel_ms;
+            self->pend.rc = self->late();
+            if (self->pend.rc != HP_OK) self->pend.err = hp_last_error();
         });
+        drain.skip2 = true;
     }
-    struct Joiner { W2Session* s; bool armed; ~Joiner() { if (armed && s->pend.on) { s->pend.helper->wait(); s->pend.on = false; } } } joiner{this, true};
+    struct Joiner { W2Session* s; bool armed; ~Joiner() { if (armed && s->pend.on && s->pend.posted) { s->helper->wait(); s->pend.on = false; } } } joiner{this, true};
     std::atomic<int64_t> bad{-1};
     {
         const unsigned nt = w2_host_threads(n, 8192);
@@ -590,30 +615,82 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
             }
             acc[(size_t)tid * 4] = a0; acc[(size_t)tid * 4 + 1] = a1; acc[(size_t)tid * 4 + 2] = a2; acc[(size_t)tid * 4 + 3] = a3;
         });
-        work_updates = work_node_bytes = work_read_bytes = work_jobs = 0;
-        for (unsigned k = 0; k < nt; ++k) { work_updates += acc[(size_t)k * 4]; work_node_bytes += acc[(size_t)k * 4 + 1]; work_read_bytes += acc[(size_t)k * 4 + 2]; work_jobs += acc[(size_t)k * 4 + 3]; }
+        uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (unsigned k = 0; k < nt; ++k) { s0 += acc[(size_t)k * 4]; s1 += acc[(size_t)k * 4 + 1]; s2 += acc[(size_t)k * 4 + 2]; s3 += acc[(size_t)k * 4 + 3]; }
+        std::lock_guard<std::mutex> lk(work_m);   // (late() adds the held jobs' share, possibly at the same time)
+        work_updates += s0; work_node_bytes += s1; work_read_bytes += s2; work_jobs += s3;
     }
     if (bad.load() >= 0) { set_error("job %lld: device status %d", (long long)bad.load(), status[bad.load()]); return HP_ERR_INVARIANT; }
     if (verbose) {
-        fprintf(stderr, "[hp] wfa2: %zu jobs (classes %zu/%zu/%zu, groups %u/%u/%u, %zu to the dense-band path of which %zu by size/builder, %u handed to the largest class on the device): layout+stage %.2f ms, upload+build %.2f ms (build kernel %.3f), queueing the classes %.2f ms, class kernels %.3f ms, total to results on the host %.2f ms\n",
-                n, (size_t)cls_n[0], (size_t)cls_n[1], (size_t)cls_n[2], groups_used[0], groups_used[1], groups_used[2], big.size(), n_big, reinterpret_cast<const uint32_t*>(cx.down.p + dn_esc)[1] - cls_n[2], t_stage - t0, t_built - t_stage, ms_build, t_cls - t_built, ms_wfa, t_done - t0);
+        fprintf(stderr, "[hp] wfa2: %zu jobs (classes %zu/%zu/%zu, groups %u/%u/%u, %zu for the dense-band path of which %zu by size/builder, %zu collected later with the largest class): layout+stage %.2f ms, upload+build %.2f ms (build kernel %.3f), queueing the classes %.2f ms, class kernels %.3f ms%s, first results on the host after %.2f ms, scattered after %.2f ms\n",
+                n, (size_t)cls_n[0], (size_t)cls_n[1], (size_t)cls_n[2], groups_used[0], groups_used[1], groups_used[2], pend.big.size(), n_big, pend.held.size(), t_stage - t0, t_built - t_stage, ms_build, t_cls - t_built, ms_wfa, two_phase ? " (span known after the second collection)" : "", t_done - t0, w2_now_ms() - t0);
         fflush(stderr);
     }
     joiner.armed = false;
     if (defer) return HP_OK;
-    const double t_scat = w2_now_ms();
-    const int rcf = finish();
-    if (verbose) { fprintf(stderr, "[hp] wfa2: scatter %.2f ms, then %.2f ms more for the %zu leftovers\n", t_scat - t_done, w2_now_ms() - t_scat, big.size()); fflush(stderr); }
-    return rcf;
+    return finish();
+}
+
+// The second collection (two phases) and the dense-band pass. Runs on the session's helper thread when run() deferred.
+int W2Session::late() {
+    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
+    if (pend.two_phase) {
+        hipStream_t s2 = pend.stream2;
+        const size_t dn_score = (n * 4 + 15) / 16 * 16, dn_work = dn_score + n * 8, dn_esc = dn_work + n * 8, dn_al = dn_esc + 16;
+        int rc;
+        if ((rc = late_down.reserve(dn_al + (size_t)allele_tot + 16)) != HP_OK) return rc;
+        W2MapArgs M{};
+        M.jobs = d_jobs.as<W2Job>(); M.info = d_info.as<W2Info>(); M.n_jobs = (uint32_t)n; M.tags = d_tags.as<uint32_t>();
+        M.out_sets = d_sets.as<uint32_t>(); M.status = d_status.as<int32_t>(); M.alleles = d_alleles.as<uint8_t>();
+        M.nodes = d_nodes.as<W2Node>(); M.out_work = d_work.as<uint32_t>();
+        M.job_cls = d_job_cls.as<uint8_t>(); M.handed = d_handed.as<uint8_t>(); M.seen = d_seen.as<int32_t>(); M.first = 0u;
+        hipLaunchKernelGGL(hp_wfa2_map_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s2, M);
+        HP_HIP_CHECK(hipGetLastError());
+        HP_HIP_CHECK(hipMemcpyAsync(late_down.p, d_seen.p, n * 4, hipMemcpyDeviceToHost, s2));
+        HP_HIP_CHECK(hipMemcpyAsync(late_down.p + dn_score, d_score.p, n * 8, hipMemcpyDeviceToHost, s2));
+        HP_HIP_CHECK(hipMemcpyAsync(late_down.p + dn_work, d_work.p, n * 8, hipMemcpyDeviceToHost, s2));
+        if (allele_tot) HP_HIP_CHECK(hipMemcpyAsync(late_down.p + dn_al, d_alleles.p, (size_t)allele_tot, hipMemcpyDeviceToHost, s2));
+        if (hipStreamSynchronize(s2) != hipSuccess) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
+        float ms_wfa = 0.f;
+        (void)hipEventElapsedTime(&ms_wfa, ev[2], ev[3]);
+        last_span_ms = (double)ms_wfa;
+        late_kernel_ms = (double)pend.ms_build + (double)ms_wfa;
+        const int32_t* status = reinterpret_cast<const int32_t*>(late_down.p);
+        const uint64_t* score = reinterpret_cast<const uint64_t*>(late_down.p + dn_score);
+        const uint32_t* work = reinterpret_cast<const uint32_t*>(late_down.p + dn_work);
+        const uint8_t* al = late_down.p + dn_al;
+        uint64_t s0 = 0, s1 = 0, s2w = 0, s3 = 0;
+        for (size_t hk = 0; hk < pend.held.size(); ++hk) {
+            const uint32_t i = pend.held[hk];
+            if (status[i] == W2_ST_NEED_BIG || status[i] == W2_ST_PENDING) { pend.big.push_back(i); continue; }   // (PENDING: handed over, never claimed)
+            if (status[i] != W2_ST_OK && status[i] != W2_ST_MAX_ED) { set_error("job %u: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
+            s0 += work[2 * (size_t)i]; s1 += work[2 * (size_t)i + 1]; s2w += jobs[i].read_len; ++s3;
+            pend.dst[i].status = status[i] == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
+            pend.dst[i].n_nodes = pend.held_nodes[hk];
+            pend.dst[i].score = score[i];
+            if (pend.alleles && pend.alleles[i] && jobs[i].n_hets) std::memcpy(pend.alleles[i], al + dj[i].allele_off, jobs[i].n_hets);
+        }
+        std::lock_guard<std::mutex> lk(work_m);
+        work_updates += s0; work_node_bytes += s1; work_read_bytes += s2w; work_jobs += s3;
+    }
+    if (!pend.big.empty()) {
+        std::sort(pend.big.begin(), pend.big.end());
+        pend.sub.resize(pend.big.size()); pend.sub_out.resize(pend.big.size()); pend.sub_al.resize(pend.big.size());
+        for (size_t k = 0; k < pend.big.size(); ++k) { pend.sub[k] = jobs[pend.big[k]]; pend.sub_al[k] = pend.alleles ? pend.alleles[pend.big[k]] : nullptr; }
+        const int rc = wfa_assign_batch_v1(pend.sub.data(), pend.sub.size(), pend.prune, pend.max_ed, pend.sub_out.data(), pend.alleles ? pend.sub_al.data() : nullptr, device_id);
+        if (rc != HP_OK) return rc;
+        late_kernel_ms += g_last_kernel_ms;
+        for (size_t k = 0; k < pend.big.size(); ++k) pend.dst[pend.big[k]] = pend.sub_out[k];
+    }
+    return HP_OK;
 }
 
 int W2Session::finish() {
     if (!pend.on) return HP_OK;
-    pend.helper->wait();
+    if (pend.posted) helper->wait(); else pend.rc = late();
     pend.on = false;
-    if (pend.rc != HP_OK) { set_error("%s", pend.err.c_str()); return pend.rc; }
-    for (size_t k = 0; k < pend.ids.size(); ++k) pend.dst[pend.ids[k]] = pend.sub_out[k];
-    g_last_kernel_ms += pend.ms;
+    if (pend.rc != HP_OK) { if (pend.posted) set_error("%s", pend.err.c_str()); return pend.rc; }
+    g_last_kernel_ms = (pend.two_phase ? 0.0 : g_last_kernel_ms) + late_kernel_ms;
     return HP_OK;
 }
 
@@ -633,7 +710,7 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
 W2Session* w2_session_create() { return new W2Session(); }
 void w2_session_destroy(W2Session* s) { delete s; }
 int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id) { return s->prepare(jobs, n, device_id); }
-int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer) { return s->run(prune_distance, max_ed, out, alleles, defer != 0); }
+int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer) { return s->run(prune_distance, max_ed, out, alleles, defer); }
 int w2_session_finish(W2Session* s) { return s->finish(); }
 // jobs whose results finish() delivers (valid until the next run)
 void w2_session_pending(const W2Session* s, const uint32_t** ids, size_t* n) { *ids = s->pend.on ? s->pend.ids.data() : nullptr; *n = s->pend.on ? s->pend.ids.size() : 0; }

@@ -325,6 +325,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                         const bool me = status == W2_ST_NEED_BIG && gl == 0;
                         const uint32_t pos = atomicAdd(B.esc, me ? 1u : 0u);
                         (void)atomicExch(me ? B.esc_order + pos : B.esc + 3, me ? job : 0u);
+                        if (me) B.handed[job] = 1;   // (never written by anyone else: hp_wfa2_map_kernel)
                         W2_WAIT_VM();
                         bool pend = me;
                         for (uint32_t s = 0; s < (1u << 16) && __any(pend); ++s) {
@@ -786,6 +787,7 @@ struct W2ClassArgs {
     int32_t* status;
     uint32_t* esc;        // W2Batch::esc: [0] = [1] = jobs of the largest class, [2] = [3] = 0
     uint32_t use_w2;      // 0: graphs of at most 64 nodes join the middle class (one queue, one tail)
+    uint8_t* job_cls;     // [n_jobs] by job id: 0..2, 3 = no class
 };
 __global__ void __launch_bounds__(256) hp_wfa2_classify_kernel(W2ClassArgs A) {
     __shared__ uint32_t wcnt[4][4];
@@ -802,6 +804,7 @@ __global__ void __launch_bounds__(256) hp_wfa2_classify_kernel(W2ClassArgs A) {
         }
         A.status[i] = k < 3 ? W2_ST_PENDING : W2_ST_NEED_BIG;
         A.cls[t] = (uint8_t)k;
+        A.job_cls[i] = (uint8_t)k;
     }
     for (int c = 0; c < 4; ++c) {
         const uint64_t m = __ballot(on && k == c);
@@ -875,13 +878,23 @@ struct W2MapArgs {
     uint8_t* alleles;
     const W2Node* nodes;
     uint32_t* out_work;
+    // first == 1: the largest class's kernel may still be running (it aligns its own jobs and the ones handed over). Only
+    // what a kernel that has COMPLETED wrote is read: jobs of the two smaller classes that were not handed over, and jobs
+    // no class took. The others are reported PENDING in `seen` and mapped by the second launch.
+    const uint8_t* job_cls;
+    const uint8_t* handed;
+    int32_t* seen;        // the status this launch acted on
+    uint32_t first;
 };
 __global__ void __launch_bounds__(64) hp_wfa2_map_kernel(W2MapArgs A) {
     const uint32_t j = blockIdx.x * 64u + threadIdx.x;
     if (j >= A.n_jobs) return;
+    if (A.first && (A.job_cls[j] == 2u || A.handed[j])) { A.seen[j] = W2_ST_PENDING; return; }
+    const int32_t st = A.status[j];
+    A.seen[j] = st;
     const W2Job J = A.jobs[j];
     const uint32_t* set = A.out_sets + (size_t)j * W2_SET_STRIDE;
-    const bool ok = A.status[j] == W2_ST_OK;
+    const bool ok = st == W2_ST_OK;
     w2_map_alleles(A.tags + J.tag_off, A.info[j].n_tags, set, ok, A.alleles + J.allele_off, J.n_hets);
     uint32_t bytes = 0;   // work counter: bytes of the nodes the best alignment(s) traverse
     if (ok && A.info[j].n_nodes <= 32u * W2_SET_STRIDE)
