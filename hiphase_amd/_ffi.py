@@ -112,6 +112,18 @@ class WfaResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_nodes", C.c_uint32), ("score", C.c_uint64)]
 
 
+class GraphNode(C.Structure):
+    _fields_ = [("seq", C.POINTER(C.c_uint8)), ("seq_len", C.c_uint32), ("n_parents", C.c_uint32), ("parents", C.POINTER(C.c_uint32))]
+
+
+class GraphJob(C.Structure):
+    _fields_ = [("nodes", C.POINTER(GraphNode)), ("n_nodes", C.c_uint32), ("read_len", C.c_uint32), ("read", C.POINTER(C.c_uint8))]
+
+
+class GraphResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_traversed", C.c_uint32), ("score", C.c_uint64)]
+
+
 class EdPair(C.Structure):
     _fields_ = [
         ("a", C.POINTER(C.c_uint8)),
@@ -248,6 +260,7 @@ EXPORTS = [
     "hp_batch_postprocess",
     "hp_batch_destroy",
     "hp_wfa_assign_batch",
+    "hp_wfa_align_graphs",
     "hp_edit_distance_batch",
     "hp_local_realign_batch",
     "hp_solve_blocks",
@@ -309,6 +322,9 @@ def lib():
     dll.hp_wfa_assign_batch.restype = C.c_int
     dll.hp_wfa_assign_batch.argtypes = [C.POINTER(WfaJob), C.c_size_t, C.c_uint64, C.c_uint64,
                                         C.POINTER(WfaResult), C.POINTER(C.c_void_p), C.c_int]
+    dll.hp_wfa_align_graphs.restype = C.c_int
+    dll.hp_wfa_align_graphs.argtypes = [C.POINTER(GraphJob), C.c_size_t, C.c_uint64, C.c_uint64, C.POINTER(GraphResult),
+                                        C.POINTER(C.c_void_p), C.c_int]
     dll.hp_edit_distance_batch.restype = C.c_int
     dll.hp_edit_distance_batch.argtypes = [C.POINTER(EdPair), C.c_size_t, C.POINTER(C.c_uint64), C.c_int]
     dll.hp_local_realign_batch.restype = C.c_int

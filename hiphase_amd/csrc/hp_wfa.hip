@@ -648,6 +648,45 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] hp_wfa_assign_batch total %.2f ms\n", now_ms() - t0); fflush(stderr); }
     return rc;
 }
+// edit_distance_with_pruning (wfa_graph.rs:350-650) for finished host graphs on the dense-band kernels: status, score and
+// the traversed-node bitsets ((n_nodes + 31) / 32 words per job at set_off[job]).
+static int run_graphs(const std::vector<HostJob>& hj, uint64_t prune_distance, uint64_t max_ed, int device_id,
+                      std::vector<int32_t>& status, std::vector<uint64_t>& score, std::vector<uint32_t>& sets, std::vector<uint64_t>& set_off) {
+    const size_t n = hj.size();
+    // host-side work is done; from here on a GPU is mandatory (no CPU fallback)
+    if (device_id < 0) device_id = hp_default_device();
+    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
+    const int n_cu = device_cu_count(device_id);
+    status.assign(n, WFA_ST_PENDING);
+    score.assign(n, 0);
+    // traversed-node bitsets of all jobs in one flat array ((n_nodes + 31) / 32 words per job)
+    set_off.assign(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) set_off[i + 1] = set_off[i] + (hj[i].nodes.size() + 31) / 32;
+    sets.assign(set_off[n], 0);
+    // graphs within the LDS budget and graphs beyond it (state in HBM) run as separate launches; each starts with a
+    // narrow band (most reads finish within a few dozen edits) and re-runs what needs more at full width
+    const char* benv = std::getenv("HP_WFA_BAND");
+    for (int big = 0; big < 2; ++big) {
+        std::vector<uint32_t> ids;
+        for (size_t i = 0; i < n; ++i) if ((hj[i].nodes.size() > WFA_MAX_NODES) == (big == 1)) ids.push_back((uint32_t)i);
+        if (ids.empty()) continue;
+        uint32_t band = (uint32_t)std::min<uint64_t>(max_ed, benv ? (uint64_t)std::atoi(benv) : 96);
+        for (;;) {
+            int rc = run_pass(hj, ids, band, prune_distance, max_ed, n_cu, status, score, sets, set_off, big == 1);
+            if (rc != HP_OK) return rc;
+            std::vector<uint32_t> again;
+            for (uint32_t id : ids) if (status[id] == WFA_ST_NEED_BAND) again.push_back(id);
+            if (again.empty()) break;
+            if (band >= max_ed) { set_error("WFA band overflow at full width (internal)"); return HP_ERR_INVARIANT; }
+            band = (uint32_t)std::min<uint64_t>(max_ed, (uint64_t)band * 6);
+            ids.swap(again);
+        }
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (status[i] != WFA_ST_OK && status[i] != WFA_ST_MAX_ED) { set_error("job %zu: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
+    return HP_OK;
+}
+
 int hp::wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
                             hp_wfa_result* out, uint8_t* const* alleles, int device_id) {
     if (n == 0) return HP_OK;
@@ -694,39 +733,14 @@ int hp::wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_dis
         }
     }
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa graph build %.2f ms for %zu jobs\n", now_ms() - t_build, n); fflush(stderr); }
-    // host-side work is done; from here on a GPU is mandatory (no CPU fallback)
-    if (device_id < 0) device_id = hp_default_device();
-    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
-    const int n_cu = device_cu_count(device_id);
-
-    std::vector<int32_t> status(n, WFA_ST_PENDING);
-    std::vector<uint64_t> score(n, 0);
-    // traversed-node bitsets of all jobs in one flat array ((n_nodes + 31) / 32 words per job)
-    std::vector<uint64_t> set_off(n + 1, 0);
-    for (size_t i = 0; i < n; ++i) set_off[i + 1] = set_off[i] + (hj[i].nodes.size() + 31) / 32;
-    std::vector<uint32_t> sets(set_off[n], 0);
-    // graphs within the LDS budget and graphs beyond it (state in HBM) run as separate launches; each starts with a
-    // narrow band (most reads finish within a few dozen edits) and re-runs what needs more at full width
-    const char* benv = std::getenv("HP_WFA_BAND");
-    for (int big = 0; big < 2; ++big) {
-        std::vector<uint32_t> ids;
-        for (size_t i = 0; i < n; ++i) if ((hj[i].nodes.size() > WFA_MAX_NODES) == (big == 1)) ids.push_back((uint32_t)i);
-        if (ids.empty()) continue;
-        uint32_t band = (uint32_t)std::min<uint64_t>(max_ed, benv ? (uint64_t)std::atoi(benv) : 96);
-        for (;;) {
-            int rc = run_pass(hj, ids, band, prune_distance, max_ed, n_cu, status, score, sets, set_off, big == 1);
-            if (rc != HP_OK) return rc;
-            std::vector<uint32_t> again;
-            for (uint32_t id : ids) if (status[id] == WFA_ST_NEED_BAND) again.push_back(id);
-            if (again.empty()) break;
-            if (band >= max_ed) { set_error("WFA band overflow at full width (internal)"); return HP_ERR_INVARIANT; }
-            band = (uint32_t)std::min<uint64_t>(max_ed, (uint64_t)band * 6);
-            ids.swap(again);
-        }
+    std::vector<int32_t> status;
+    std::vector<uint64_t> score, set_off;
+    std::vector<uint32_t> sets;
+    {
+        const int rc = run_graphs(hj, prune_distance, max_ed, device_id, status, score, sets, set_off);
+        if (rc != HP_OK) return rc;
     }
     const double t_map = now_ms();
-    for (size_t i = 0; i < n; ++i)
-        if (status[i] != WFA_ST_OK && status[i] != WFA_ST_MAX_ED) { set_error("job %zu: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
     auto map_jobs = [&](unsigned t, unsigned nt) {
         for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
             out[i].status = status[i] == WFA_ST_OK ? HP_OK : HP_WFA_MAX_ED;
@@ -757,5 +771,61 @@ int hp::wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_dis
         }
     }
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa allele mapping %.2f ms (function body so far %.2f ms)\n", now_ms() - t_map, now_ms() - t_build); fflush(stderr); }
+    return HP_OK;
+}
+
+
+// WFAGraph::new + add_node (wfa_graph.rs:100-117, :298-331) + edit_distance_with_pruning (:350) for caller-built graphs:
+// the reference's API below from_reference_variants_with_hom, which its own tests drive with hand-built topologies
+// (nested / overlapping / triple splits, :677-839) that no variant set produces. Dense-band kernels.
+extern "C" int hp_wfa_align_graphs(const hp_graph_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_graph_result* out,
+                                   uint32_t* const* traversed, int device_id) {
+    if (n == 0) return HP_OK;
+    if (!jobs || !out) { set_error("null argument"); return HP_ERR_ARG; }
+    if (n > 0x7FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
+    if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
+    GraphArena arena;
+    std::vector<HostJob> hj(n);
+    GraphBuild g;
+    std::vector<uint32_t> parents;
+    for (size_t i = 0; i < n; ++i) {
+        const hp_graph_job& J = jobs[i];
+        if (!J.nodes || J.n_nodes == 0 || (!J.read && J.read_len)) { set_error("job %zu: null graph or read", i); return HP_ERR_ARG; }
+        g.clear();
+        for (uint32_t k = 0; k < J.n_nodes; ++k) {
+            const hp_graph_node& nd = J.nodes[k];
+            if ((!nd.seq && nd.seq_len) || (!nd.parents && nd.n_parents)) { set_error("job %zu node %u: null array", i, k); return HP_ERR_ARG; }
+            parents.assign(nd.parents, nd.parents + nd.n_parents);
+            const uint32_t off = (uint32_t)g.alt.size();
+            g.alt.insert(g.alt.end(), nd.seq, nd.seq + nd.seq_len);
+            // the reference asserts: the first node has no parents, every other node has some, all of them earlier (:305-312)
+            if (add_node(g, off, nd.seq_len, parents) < 0) { set_error("job %zu node %u: assert of WFAGraph::add_node (wfa_graph.rs:305-312)", i, k); return HP_ERR_INVARIANT; }
+        }
+        g.ref_ptr = nullptr; g.ref_len = 0;
+        g.read_off = (uint32_t)g.alt.size();
+        g.read_len = J.read_len;
+        g.read_ptr = J.read;
+        g.seq_bytes = (g.read_off + g.read_len + 16 + 15) & ~15u;
+        finish_graph(g);
+        hj[i].stash(g, arena);
+    }
+    for (size_t i = 0; i < n; ++i) hj[i].bind(arena);
+    std::vector<int32_t> status;
+    std::vector<uint64_t> score, set_off;
+    std::vector<uint32_t> sets;
+    const int rc = run_graphs(hj, prune_distance, max_ed, device_id, status, score, sets, set_off);
+    if (rc != HP_OK) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        out[i].status = status[i] == WFA_ST_OK ? HP_OK : HP_WFA_MAX_ED;
+        out[i].score = score[i];
+        const uint32_t words = (jobs[i].n_nodes + 31) / 32;
+        uint32_t cnt = 0;
+        for (uint32_t w = 0; w < words; ++w) {
+            const uint32_t v = status[i] == WFA_ST_OK ? sets[set_off[i] + w] : 0u;
+            cnt += (uint32_t)__builtin_popcount(v);
+            if (traversed && traversed[i]) traversed[i][w] = v;
+        }
+        out[i].n_traversed = cnt;
+    }
     return HP_OK;
 }

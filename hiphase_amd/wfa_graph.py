@@ -214,6 +214,54 @@ def wfa_assign_batch(specs, prune_distance=500, max_edit_distance=500, device_id
     return [(out[i].status, out[i].score, out[i].n_nodes, alleles[i][:len(specs[i].hets)]) for i in range(n)]
 
 
+class WFAGraph:
+    """WFAGraph::new / add_node / edit_distance_with_pruning (wfa_graph.rs:100-117, 298-331, 350-650) over
+    hp_wfa_align_graphs: the layer under from_reference_variants_with_hom, for caller-built topologies."""
+
+    def __init__(self):
+        self.nodes = []   # (sequence bytes, sorted parents)
+
+    def add_node(self, sequence, parents):
+        """Returns the new node's index (creation order). The reference's asserts (the first node has no parents, every
+        later one has some, all of them earlier nodes, :305-312) are checked by the library at alignment time."""
+        self.nodes.append((np.ascontiguousarray(sequence, dtype=np.uint8), np.ascontiguousarray(sorted(parents), dtype=np.uint32)))
+        return len(self.nodes) - 1
+
+    def edit_distance_with_pruning(self, reads, prune_distance=None, max_edit_distance=500, device_id=0):
+        """One call for a list of reads. Returns [(score, traversed node indices)] - WFAResult (:654-670); a read that
+        exceeds max_edit_distance raises like the reference's WFAGraphError::MaxEditDistance would be matched: (None, [])."""
+        dll = _ffi.lib()
+        n = len(reads)
+        gnodes = (_ffi.GraphNode * len(self.nodes))()
+        for k, (seq, par) in enumerate(self.nodes):
+            gnodes[k].seq = seq.ctypes.data_as(C.POINTER(C.c_uint8))
+            gnodes[k].seq_len = len(seq)
+            gnodes[k].n_parents = len(par)
+            gnodes[k].parents = par.ctypes.data_as(C.POINTER(C.c_uint32))
+        rd = [np.ascontiguousarray(r, dtype=np.uint8) for r in reads]
+        jobs = (_ffi.GraphJob * max(n, 1))()
+        for i, r in enumerate(rd):
+            jobs[i].nodes = gnodes
+            jobs[i].n_nodes = len(self.nodes)
+            jobs[i].read = r.ctypes.data_as(C.POINTER(C.c_uint8))
+            jobs[i].read_len = len(r)
+        words = (len(self.nodes) + 31) // 32
+        sets = [np.zeros(max(words, 1), np.uint32) for _ in range(n)]
+        ptrs = (C.c_void_p * max(n, 1))(*[s.ctypes.data for s in sets])
+        out = (_ffi.GraphResult * max(n, 1))()
+        prune = (2 ** 64 - 1) if prune_distance in (0, None) else prune_distance
+        _ffi.check(dll.hp_wfa_align_graphs(jobs, n, prune, max_edit_distance, out, ptrs, device_id))
+        res = []
+        for i in range(n):
+            if out[i].status != 0:
+                res.append((None, []))
+                continue
+            trav = [k for k in range(len(self.nodes)) if (int(sets[i][k >> 5]) >> (k & 31)) & 1]
+            assert len(trav) == out[i].n_traversed
+            res.append((int(out[i].score), trav))
+        return res
+
+
 def global_quals(alleles, variant_types):
     """read_parsing.rs:803-835: qual = 2 x base(type) for cells that ended 0/1, else 0."""
     q = np.zeros(len(alleles), np.uint8)

@@ -179,6 +179,18 @@ typedef struct hp_wfa_result {
 int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
                         hp_wfa_result* out, uint8_t* const* alleles, int device_id);
 
+/* Caller-built graphs: WFAGraph::new + add_node (src/wfa_graph.rs:100-117, 298-331: node k is added with its sequence and
+ * the indices of its parents, all of them earlier nodes; node 0 has none) and edit_distance_with_pruning (:350-650) ->
+ * WFAResult { score, traversed_nodes } (:654-670). This is the layer under from_reference_variants_with_hom that the
+ * reference's own tests drive with hand-built topologies (:677-839). traversed[i], when not NULL, receives the
+ * traversed-node bitset of job i, (n_nodes + 31) / 32 words (bit k = node k lies on a best alignment); status is HP_OK or
+ * HP_WFA_MAX_ED (score = max_ed, nothing traversed). An add_node assert maps to HP_ERR_INVARIANT. */
+typedef struct hp_graph_node { const uint8_t* seq; uint32_t seq_len; uint32_t n_parents; const uint32_t* parents; } hp_graph_node;
+typedef struct hp_graph_job { const hp_graph_node* nodes; uint32_t n_nodes; uint32_t read_len; const uint8_t* read; } hp_graph_job;
+typedef struct hp_graph_result { int32_t status; uint32_t n_traversed; uint64_t score; } hp_graph_result;
+int hp_wfa_align_graphs(const hp_graph_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_graph_result* out,
+                        uint32_t* const* traversed, int device_id);
+
 /* ---- Levenshtein (sequence_alignment.rs:7-38) --------------------------------------------- */
 typedef struct hp_ed_pair { const uint8_t* a; const uint8_t* b; uint32_t a_len; uint32_t b_len; } hp_ed_pair;
 int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_t* out, int device_id);

@@ -136,7 +136,8 @@ def test_abi_layout_matches_the_ctypes_bindings(hp_lib):
     layout = json.loads(hp_lib.hp_abi_layout().decode())
     pairs = {"hp_block_view": _ffi.BlockView, "hp_astar_params": _ffi.AstarParams, "hp_phase_stats": _ffi.PhaseStats,
              "hp_work_counters": _ffi.WorkCounters, "hp_wfa_variant": _ffi.WfaVariant, "hp_wfa_job": _ffi.WfaJob,
-             "hp_wfa_result": _ffi.WfaResult, "hp_ed_pair": _ffi.EdPair, "hp_local_variant": _ffi.LocalVariant,
+             "hp_wfa_result": _ffi.WfaResult, "hp_graph_node": _ffi.GraphNode, "hp_graph_job": _ffi.GraphJob,
+             "hp_graph_result": _ffi.GraphResult, "hp_ed_pair": _ffi.EdPair, "hp_local_variant": _ffi.LocalVariant,
              "hp_local_read": _ffi.LocalRead, "hp_read_stats": _ffi.ReadStats, "hp_block_record": _ffi.BlockRecord,
              "hp_block_input": _ffi.BlockInput, "hp_block_params": _ffi.BlockParams, "hp_block_output": _ffi.BlockOutput,
              "hp_synth_spec": _ffi.SynthSpec}

@@ -237,3 +237,38 @@ def test_node_with_more_than_32_parents():
     specs = [WfaJobSpec(reference=ref, ref_start=100, ref_end=1400, hets=hets, homs=[], read=rd) for rd in reads]
     got = check_specs(specs, prune=0, max_ed=100)
     assert all(g[0] == 0 for g in got) and got[0][2] >= 42
+
+
+@pytest.mark.parametrize("case", G["hand_built"], ids=lambda c: c["name"])
+def test_golden_hand_built_graphs(case):
+    """The reference's hand-built topologies (wfa_graph.rs:677-839: single node, two-node splits, basic variant, triple /
+    nested / double / overlapping split) through WFAGraph::add_node + edit_distance_with_pruning on the device
+    (hp_wfa_align_graphs): exact (score, traversed_nodes) - no variant set builds the nested and overlapping ones."""
+    from hiphase_amd.wfa_graph import WFAGraph
+    g = WFAGraph()
+    for i, nd in enumerate(case["nodes"]):
+        assert g.add_node(nd["seq"], nd["parents"]) == i
+    res = g.edit_distance_with_pruning([q["seq"] for q in case["queries"]], prune_distance=None, max_edit_distance=500)
+    for q, (score, nodes) in zip(case["queries"], res):
+        assert score == q["score"], (case["name"], q)
+        if q["nodes"] is not None:
+            assert nodes == q["nodes"], (case["name"], q)
+
+
+def test_hand_built_graph_errors_and_max_ed():
+    """add_node's asserts (wfa_graph.rs:305-312) and the MaxEditDistance status on caller-built graphs."""
+    from hiphase_amd.wfa_graph import WFAGraph
+    g = WFAGraph()
+    g.add_node([0, 1, 2, 3], [])
+    g.add_node([0, 1], [0])
+    assert g.edit_distance_with_pruning([[3, 3, 3, 3, 3, 3, 3, 3, 3]], max_edit_distance=2) == [(None, [])]
+    bad = WFAGraph()
+    bad.add_node([1], [])
+    bad.add_node([2], [])            # a later node without parents
+    with pytest.raises(Exception):
+        bad.edit_distance_with_pruning([[1, 2]])
+    bad2 = WFAGraph()
+    bad2.add_node([1], [])
+    bad2.add_node([2], [1])          # parent must precede
+    with pytest.raises(Exception):
+        bad2.edit_distance_with_pruning([[1, 2]])
