@@ -359,6 +359,49 @@ inline bool overlap_range(const std::vector<Variant>& v, int64_t lo, int64_t hi,
 }
 }  // namespace detail
 
+// WFAGraph (wfa_graph.rs:93-117), add_node (:298-331), edit_distance_with_pruning (:350-650) -> WFAResult (:654-670) for a
+// caller-built graph: the layer under from_reference_variants_with_hom (hp_wfa_align_graphs)
+struct WFAResult {
+    uint64_t score = 0;
+    std::vector<size_t> traversed_nodes;   // ascending
+};
+class WFAGraph {
+    std::vector<Bytes> seqs_;
+    std::vector<std::vector<uint32_t>> parents_;
+public:
+    // returns the node's index; the reference's asserts (:305-312) are reported by the alignment call
+    size_t add_node(const Bytes& sequence, std::vector<size_t> parents) {
+        std::sort(parents.begin(), parents.end());
+        seqs_.push_back(sequence);
+        parents_.emplace_back(parents.begin(), parents.end());
+        return seqs_.size() - 1;
+    }
+    size_t get_num_nodes() const { return seqs_.size(); }
+    // Err(MaxEditDistance) <=> `max_edit_distance_reached` is set (the result is then empty)
+    WFAResult edit_distance_with_pruning(const Bytes& other, uint64_t prune_distance, uint64_t max_edit_distance, bool* max_edit_distance_reached = nullptr) const {
+        std::vector<hp_graph_node> nodes(seqs_.size());
+        static const uint8_t none8 = 0;
+        static const uint32_t none32 = 0;
+        for (size_t k = 0; k < seqs_.size(); ++k) {
+            nodes[k].seq = seqs_[k].empty() ? &none8 : seqs_[k].data(); nodes[k].seq_len = (uint32_t)seqs_[k].size();
+            nodes[k].parents = parents_[k].empty() ? &none32 : parents_[k].data(); nodes[k].n_parents = (uint32_t)parents_[k].size();
+        }
+        hp_graph_job job{};
+        job.nodes = nodes.data(); job.n_nodes = (uint32_t)nodes.size();
+        job.read = other.empty() ? &none8 : other.data(); job.read_len = (uint32_t)other.size();
+        std::vector<uint32_t> set((nodes.size() + 31) / 32 + 1, 0);
+        uint32_t* ptr = set.data();
+        hp_graph_result res{};
+        check(hp_wfa_align_graphs(&job, 1, prune_distance == 0 ? UINT64_MAX : prune_distance, max_edit_distance, &res, &ptr, -1), "hp_wfa_align_graphs");
+        WFAResult r;
+        if (max_edit_distance_reached) *max_edit_distance_reached = res.status == HP_WFA_MAX_ED;
+        if (res.status != HP_OK) return r;
+        r.score = res.score;
+        for (size_t k = 0; k < nodes.size(); ++k) if ((set[k >> 5] >> (k & 31)) & 1u) r.traversed_nodes.push_back(k);
+        return r;
+    }
+};
+
 // read_parsing.rs:769-800 for a batch of records: one hp_wfa_assign_batch call
 inline std::vector<WfaOutcome> global_realignment_batch(const std::vector<WfaJob>& jobs, uint64_t prune_distance, uint64_t max_edit_distance) {
     const size_t n = jobs.size();

@@ -183,6 +183,43 @@ static void test_astar_solver_against_oracle() {
         CHECK(got.statistics.phased_variants + got.statistics.homozygous_variants + got.statistics.skipped_variants == cf.n);
     }
 }
+// ---- wfa_graph.rs:747-787, 814-838: hand-built graphs through WFAGraph::add_node + edit_distance_with_pruning -------
+static void test_wfa_hand_built_graphs() {
+    {   // fn test_triple_split
+        WFAGraph g;
+        const size_t n0 = g.add_node({0, 1}, {});
+        const size_t n1 = g.add_node({2, 3}, {n0}), n2 = g.add_node({2, 4}, {n0}), n3 = g.add_node({4}, {n0});
+        const size_t n4 = g.add_node({4, 5}, {n1, n2, n3});
+        WFAResult r = g.edit_distance_with_pruning({0, 1, 2, 3, 4, 5}, UINT64_MAX, 500);
+        CHECK(r.score == 0 && r.traversed_nodes == std::vector<size_t>({n0, n1, n4}));
+        r = g.edit_distance_with_pruning({0, 1, 2, 4, 4, 5}, UINT64_MAX, 500);
+        CHECK(r.score == 0 && r.traversed_nodes == std::vector<size_t>({n0, n2, n4}));
+        r = g.edit_distance_with_pruning({0, 1, 4, 4, 5}, UINT64_MAX, 500);
+        CHECK(r.score == 0 && r.traversed_nodes == std::vector<size_t>({n0, n3, n4}));
+    }
+    {   // fn test_nested_split
+        WFAGraph g;
+        g.add_node({0, 1}, {}); g.add_node({2, 3}, {0}); g.add_node({2}, {0}); g.add_node({4}, {0, 2}); g.add_node({4, 5}, {1, 3});
+        WFAResult r = g.edit_distance_with_pruning({0, 1, 2, 4, 4, 5}, UINT64_MAX, 500);
+        CHECK(r.score == 0 && r.traversed_nodes == std::vector<size_t>({0, 2, 3, 4}));
+        r = g.edit_distance_with_pruning({0, 1, 4, 4, 5}, UINT64_MAX, 500);
+        CHECK(r.score == 0 && r.traversed_nodes == std::vector<size_t>({0, 3, 4}));
+    }
+    {   // fn test_overlapping_split
+        WFAGraph g;
+        g.add_node({0}, {}); g.add_node({1}, {0}); g.add_node({2}, {1}); g.add_node({3}, {0, 2}); g.add_node({4, 5}, {1, 3});
+        WFAResult r = g.edit_distance_with_pruning({0, 1, 2, 3, 4, 5}, UINT64_MAX, 500);
+        CHECK(r.score == 0 && r.traversed_nodes == std::vector<size_t>({0, 1, 2, 3, 4}));
+        r = g.edit_distance_with_pruning({0, 3, 4, 5}, UINT64_MAX, 500);
+        CHECK(r.score == 0 && r.traversed_nodes == std::vector<size_t>({0, 3, 4}));
+        r = g.edit_distance_with_pruning({0, 1, 4, 5}, UINT64_MAX, 500);
+        CHECK(r.score == 0 && r.traversed_nodes == std::vector<size_t>({0, 1, 4}));
+        bool hit = false;
+        r = g.edit_distance_with_pruning({7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7}, UINT64_MAX, 3, &hit);
+        CHECK(hit && r.traversed_nodes.empty());
+    }
+}
+
 static void test_errors() {
     bool threw = false;
     try { (void)astar_solver(0, Bytes{}, {}, 1000, 3); } catch (const Error& e) { threw = e.code < 0; }   // N == 0: malformed view
@@ -269,6 +306,7 @@ int main(int argc, char** argv) {
         test_simple_snv();
         test_span_counts_and_haplotags();
         test_astar_solver_against_oracle();
+        test_wfa_hand_built_graphs();
         test_errors();
     } catch (const std::exception& e) {
         std::printf("EXCEPTION: %s\n", e.what());
