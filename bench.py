@@ -223,7 +223,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
     from hiphase_amd.read_parsing import GlobalRealignmentConfig
     from hiphase_amd.synth_reads import synth_wgs_like_mix
     t_gen = time.perf_counter()
-    blocks = synth_wgs_like_mix(20250928 + rank, args.total_hets, max_hets=args.max_block_hets, coverage=float(args.coverage))
+    blocks = synth_wgs_like_mix(args.seed + rank, args.total_hets, max_hets=args.max_block_hets, coverage=float(args.coverage))
     t_gen = time.perf_counter() - t_gen
     hets_per_step = sum(len(b.variant_calls) for b in blocks)
     n_reads = sum(len(b.records) for b in blocks)
@@ -328,6 +328,7 @@ def main():
     ap.add_argument("--workload", choices=["path", "c2", "wgs"], default="path")
     ap.add_argument("--total-hets", type=int, default=60000, help="path workload: hets per GPU and step")
     ap.add_argument("--max-block-hets", type=int, default=2000)
+    ap.add_argument("--seed", type=int, default=20250928, help="path workload: seed of the synthetic block mix (rank r uses seed + r)")
     ap.add_argument("--blocks", type=int, default=6144, help="blocks per GPU (24 resident single-wave workgroups per CU x 256 CUs)")
     ap.add_argument("--hets", type=int, default=5000)
     ap.add_argument("--coverage", type=int, default=30)
