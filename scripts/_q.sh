@@ -1,9 +1,4 @@
-echo "== default bench"; timeout 300 python bench.py 2>&1 | tail -1 > gpurun_out/bench_default_final.json; python -c "
-import json; d=json.load(open('gpurun_out/bench_default_final.json')); print(d['value'], d['ms_per_step'], d['stage_ms']); print(d['roofline']); print(d['kernels'][1]); print(d['cpu_baseline'], d.get('parity'))"
-echo "== 20k hets"; timeout 300 python bench.py --no-cpu --total-hets 20000 --steps 10 --warmup 3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],2), {k:round(v,1) for k,v in d['stage_ms'].items()}, d['config']['reads'])"
-echo "== 180k hets"; timeout 400 python bench.py --no-cpu --total-hets 180000 --steps 5 --warmup 2 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],2), {k:round(v,1) for k,v in d['stage_ms'].items()}, d['config']['reads'])"
-for j in 8192 16384 32768 65536; do echo "== bench_wfa $j"; timeout 250 python scripts/bench_wfa.py --jobs $j --cpu-sample 1 --kernel compact 2>&1 | tail -1 | cut -c1-170; done
-echo "== bench_wfa dense 4096"; timeout 250 python scripts/bench_wfa.py --jobs 4096 --cpu-sample 1 --kernel dense 2>&1 | tail -1 | cut -c1-170
-echo "== c2"; timeout 600 python bench.py --workload c2 --no-cpu --no-secondary --steps 3 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],2))"
-echo "== wgs"; timeout 600 python bench.py --workload wgs --no-cpu --steps 3 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],2))"
-echo "== coalesce"; timeout 300 python -m pytest tests/test_coalesce_gpu.py -x -q -s 2>&1 | grep -i "hets/s\|passed\|x)" | tail -5
+run() { echo "== $*"; env "$@" timeout 200 python bench.py --no-cpu --steps 10 --warmup 3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],2), {k:round(v,1) for k,v in d['stage_ms'].items()})"; }
+run HP_WFA2_HCAP_LOG2=11
+run HP_WFA2_HCAP_LOG2=10
+run HP_WFA2_HCAP_LOG2=12
