@@ -211,3 +211,29 @@ def test_block_set_with_large_graphs_hand_over_and_two_phases(monkeypatch):
                 assert r.span_counts.tolist() == spans
     finally:
         bs.close()
+
+
+@pytest.mark.timeout(900)
+def test_block_set_in_two_overlapped_chunks(monkeypatch):
+    """HP_BLOCK_PIPELINE=1: the largest blocks form a first chunk whose rows + A* + post run on a helper thread (on compute
+    units of their own) while the second chunk's reads go through graph-WFA. Same results as the oracle's whole path."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from hiphase_amd.synth_reads import synth_read_block
+    monkeypatch.setenv("HP_BLOCK_PIPELINE", "1")
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "16")
+    specs = [synth_read_block(5200 + i, 14 + 9 * (i % 5), block_index=i, coverage=12.0)[0] for i in range(12)]
+    cfg = GlobalRealignmentConfig()
+    d = oracle()
+    bs = BlockSet(specs, config=cfg)
+    try:
+        for _ in range(2):
+            bs.solve()
+            for spec, r in zip(specs, bs.results()):
+                segs, h1, h2, stt, spans = bench.oracle_block(spec, cfg, d)
+                assert [(q, a, b, al, ql) for (q, a, b, al, ql, so) in r.segments if so] == segs
+                assert (r.haplotype_1 == h1).all() and (r.haplotype_2 == h2).all() and r.statistics == stt
+                assert r.span_counts.tolist() == spans
+    finally:
+        bs.close()
