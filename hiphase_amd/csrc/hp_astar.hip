@@ -696,19 +696,46 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     if ((rc = d_rcell.alloc(tot_rows * 8)) || (rc = d_ral.alloc(tot_ral + 16)) || (rc = d_rq.alloc(tot_rq + 16)) ||
         (rc = upload(d_raw, hpk.raw, s)))
         return fail(rc);
-    for (unsigned t = 0; t < nt; ++t) {
-        const HostPack& q = parts[t];
-        const PartBase& o = base[t];
-        auto put = [&](DevBuf& dst, uint64_t off_bytes, const void* src, size_t bytes) {
-            return bytes == 0 || hipMemcpyAsync(dst.as<unsigned char>() + off_bytes, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
-        };
-        if (!put(b->d_vlo, o.var * 4, q.vlo.data(), q.vlo.size() * 4) || !put(b->d_vhi, o.var * 4, q.vhi.data(), q.vhi.size() * 4) ||
-            !put(b->d_vflags, o.var, q.vflags.data(), q.vflags.size()) || !put(b->d_rstart, o.read * 4, q.rstart.data(), q.rstart.size() * 4) ||
-            !put(b->d_rend, o.read * 4, q.rend.data(), q.rend.size() * 4) || !put(b->d_rword, o.read * 4, q.rword.data(), q.rword.size() * 4) ||
-            !put(d_rcell, o.read * 8, q.rcell.data(), q.rcell.size() * 8) || !put(d_ral, o.ral, q.raw_alleles.data(), q.raw_alleles.size()) ||
-            !put(d_rq, o.rq, q.raw_quals.data(), q.raw_quals.size())) {
-            set_error("upload failed: %s", hipGetErrorString(hipGetLastError()));
-            return fail(HP_ERR_HIP);
+    {
+        // the parts go into ONE pinned staging buffer at their final offsets (host threads), then nine uploads: a pageable
+        // source costs a synchronous bounce per call, and there were nine per part
+        static thread_local PinBuf pin;
+        const uint64_t sz[9] = {tot_vars * 4, tot_vars * 4, tot_vars, tot_rows * 4, tot_rows * 4, tot_rows * 4, tot_rows * 8, tot_ral, tot_rq};
+        uint64_t off9[10]; off9[0] = 0;
+        for (int k = 0; k < 9; ++k) off9[k + 1] = (off9[k] + sz[k] + 63) / 64 * 64;
+        void* dst9[9] = {b->d_vlo.p, b->d_vhi.p, b->d_vflags.p, b->d_rstart.p, b->d_rend.p, b->d_rword.p, d_rcell.p, d_ral.p, d_rq.p};
+        if (off9[9] > (256ull << 20)) {
+            // a batch of gigabytes (thousands of large blocks): straight from the parts, no second copy in host memory
+            for (unsigned t = 0; t < nt; ++t) {
+                const HostPack& q = parts[t];
+                const PartBase& o = base[t];
+                const void* src9[9] = {q.vlo.data(), q.vhi.data(), q.vflags.data(), q.rstart.data(), q.rend.data(), q.rword.data(), q.rcell.data(), q.raw_alleles.data(), q.raw_quals.data()};
+                const uint64_t at9[9] = {o.var * 4, o.var * 4, o.var, o.read * 4, o.read * 4, o.read * 4, o.read * 8, o.ral, o.rq};
+                const size_t n9[9] = {q.vlo.size() * 4, q.vhi.size() * 4, q.vflags.size(), q.rstart.size() * 4, q.rend.size() * 4, q.rword.size() * 4, q.rcell.size() * 8, q.raw_alleles.size(), q.raw_quals.size()};
+                for (int k = 0; k < 9; ++k)
+                    if (n9[k] && hipMemcpyAsync(static_cast<unsigned char*>(dst9[k]) + at9[k], src9[k], n9[k], hipMemcpyHostToDevice, s) != hipSuccess) {
+                        set_error("upload failed: %s", hipGetErrorString(hipGetLastError()));
+                        return fail(HP_ERR_HIP);
+                    }
+            }
+        } else {
+        if ((rc = pin.reserve((size_t)off9[9] + 64)) != HP_OK) return fail(rc);
+        uint8_t* P = pin.p;
+        WorkerPool::get().run(nt, [&](unsigned t) {
+            const HostPack& q = parts[t];
+            const PartBase& o = base[t];
+            auto put = [&](int k, uint64_t off_bytes, const void* src, size_t bytes) { if (bytes) std::memcpy(P + off9[k] + off_bytes, src, bytes); };
+            put(0, o.var * 4, q.vlo.data(), q.vlo.size() * 4); put(1, o.var * 4, q.vhi.data(), q.vhi.size() * 4);
+            put(2, o.var, q.vflags.data(), q.vflags.size()); put(3, o.read * 4, q.rstart.data(), q.rstart.size() * 4);
+            put(4, o.read * 4, q.rend.data(), q.rend.size() * 4); put(5, o.read * 4, q.rword.data(), q.rword.size() * 4);
+            put(6, o.read * 8, q.rcell.data(), q.rcell.size() * 8); put(7, o.ral, q.raw_alleles.data(), q.raw_alleles.size());
+            put(8, o.rq, q.raw_quals.data(), q.raw_quals.size());
+        });
+        for (int k = 0; k < 9; ++k)
+            if (sz[k] && hipMemcpyAsync(dst9[k], P + off9[k], sz[k], hipMemcpyHostToDevice, s) != hipSuccess) {
+                set_error("upload failed: %s", hipGetErrorString(hipGetLastError()));
+                return fail(HP_ERR_HIP);
+            }
         }
     }
     if ((rc = upload(b->d_row_block, b->row_block_h, s)) != HP_OK) return fail(rc);

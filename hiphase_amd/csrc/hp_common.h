@@ -138,6 +138,26 @@ public:
     }
 };
 
+// grow-only pinned staging (DMA straight from it; never value-initialised)
+struct PinBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    int reserve(size_t n) {
+        if (n <= cap) return HP_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 4 + 4096;
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
+            p = nullptr;
+            set_error("hipHostMalloc(%zu) failed", want);
+            return HP_ERR_OOM;
+        }
+        cap = want;
+        return HP_OK;
+    }
+};
+
 // RAII device buffer
 struct DevBuf {
     void* p = nullptr;

@@ -36,25 +36,6 @@ double w2_now_ms() {
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-// grow-only pinned staging (DMA straight from it; never value-initialised)
-struct PinBuf {
-    uint8_t* p = nullptr;
-    size_t cap = 0;
-    ~PinBuf() { if (p) (void)hipHostFree(p); }
-    int reserve(size_t n) {
-        if (n <= cap) return HP_OK;
-        if (p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
-        const size_t want = n + n / 4 + 4096;
-        if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
-            p = nullptr;
-            set_error("hipHostMalloc(%zu) failed", want);
-            return HP_ERR_OOM;
-        }
-        cap = want;
-        return HP_OK;
-    }
-};
 
 inline uint32_t w2_hcap_log2() {   // keys per group's capped-diagonal set: 2^n x 8 B (HP_WFA2_HCAP_LOG2 for experiments)
     static const uint32_t v = [] { const char* e = std::getenv("HP_WFA2_HCAP_LOG2"); const int x = e ? std::atoi(e) : 11; return (uint32_t)std::min(14, std::max(6, x)); }();
