@@ -478,6 +478,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         B.esc = d_esc; B.esc_order = d_order.as<uint32_t>() + (size_t)2 * n; B.handed = d_handed.as<uint8_t>();
         B.esc_role = !escalate ? 0u : (k == 2 ? 2u : 1u);
         B.esc_producers = grid_wg[0] + grid_wg[1];
+        B.esc_limit = cls_cnt[2] + 2u * (items2 - cls_cnt[2]);   // two jobs for each group reserved for hand-overs
         if (k == 0) rc = w2_launch<8, 2>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k]);
         else if (k == 1) rc = gsel == 16 ? w2_launch<16, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k])
                             : gsel == 32 ? w2_launch<32, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k])

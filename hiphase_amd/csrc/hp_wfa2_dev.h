@@ -310,6 +310,7 @@ struct W2Batch {
     uint32_t* esc_order;       // the largest class's job list (capacity: the whole batch)
     uint32_t esc_role;         // 0 none, 1 producer, 2 consumer (the largest class)
     uint32_t esc_producers;    // consumer: producer workgroups to wait for
+    uint32_t esc_limit;        // producer: no hand-over once this many list positions are taken (the class's own jobs + a budget)
     uint8_t* handed;           // [n_jobs]: set by the producer that hands a job over (zeroed before the launch)
 };
 

@@ -319,10 +319,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                 if (status != W2_ST_PENDING) {   // results of the job that just ended
                     const uint32_t upd = w2_gsum<G>(lane_upd);
                     bool handed_over = false;
-                    if (B.esc_role == 1u && __any(status == W2_ST_NEED_BIG)) {
+                    // Worth handing over: what the largest class's bigger tables fix (pending queue, live / finished-only entries,
+                    // source intervals, slots) - not a full capped set or three entries of one node, which it shares. And only
+                    // while that class has room: reads with a few per cent of noise fail by the thousand, and a few hundred
+                    // groups working through them one after the other (to fail again) took a second; those go straight
+                    // to the dense-band pass, as does everything past the budget.
+                    const bool hand = status == W2_ST_NEED_BIG && (why == 1u || why == 2u || why == 3u || why == 7u || why == 8u);
+                    if (B.esc_role == 1u && __any(hand)) {
                         // hand the job to the largest class: reserve a list position, store the job there, publish positions in
                         // order. Every lane takes part in every atomic (idle ones on a scratch word): no one-lane branches.
-                        const bool me = status == W2_ST_NEED_BIG && gl == 0;
+                        const uint32_t taken = atomicAdd(B.esc, 0u);
+                        const bool me = hand && gl == 0 && taken < B.esc_limit;
                         const uint32_t pos = atomicAdd(B.esc, me ? 1u : 0u);
                         (void)atomicExch(me ? B.esc_order + pos : B.esc + 3, me ? job : 0u);
                         if (me) B.handed[job] = 1;   // (never written by anyone else: hp_wfa2_map_kernel)
@@ -334,7 +341,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                         }
                         // its results are the consumer's to write (two XCDs' L2s must not both hold dirty copies of one word).
                         // A position that could not be published leaves the job PENDING: the host's dense-band pass takes it.
-                        handed_over = status == W2_ST_NEED_BIG;
+                        handed_over = w2_gballot<G>(me, gbase) != 0;
                     }
                     if (!handed_over && gl == 0) { B.status[job] = status; B.out_score[job] = status == W2_ST_NEED_BIG ? (uint64_t)why : score; B.out_work[(size_t)job * 2] = upd; }
                     if (!handed_over && gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
