@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         W2PT(1);
         if (!__any(state == S_TILE)) {
             if (!__any(state == S_WAIT)) break;   // every group is done
-            if (++idle_polls > 8000u) break;      // (~0.2 s: never hang the device; unclaimed jobs stay for the host's pass)
+            if (++idle_polls > 60000u) break;     // (~1.5 s of nothing to do: never hang the device; unclaimed jobs stay for the host's pass)
             for (int z = 0; z < 8; ++z) __builtin_amdgcn_s_sleep(127);
             continue;
         }
