@@ -237,3 +237,44 @@ def test_block_set_in_two_overlapped_chunks(monkeypatch):
                 assert r.span_counts.tolist() == spans
     finally:
         bs.close()
+
+
+def test_block_sets_from_several_host_threads(monkeypatch):
+    """Three host threads, each with block sets of its own through the compact kernels (per-thread device context, the
+    sessions' helper threads, the shared worker pool): every solve equals the single-threaded result."""
+    import threading
+    from hiphase_amd.synth_reads import synth_read_block
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0")
+    cfg = GlobalRealignmentConfig()
+
+    def make(seed):
+        return [synth_read_block(seed * 100 + i, 20 + 15 * (i % 4), block_index=i, coverage=15.0)[0] for i in range(6)]
+
+    ref = {}
+    for s in (1, 2, 3):
+        bs = BlockSet(make(s), config=cfg)
+        bs.solve()
+        ref[s] = bs.results()
+        bs.close()
+    bad = []
+
+    def work(s):
+        try:
+            for rep in range(3):
+                bs = BlockSet(make(s), config=cfg)
+                for _ in range(3):
+                    bs.solve()
+                    for a, b in zip(bs.results(), ref[s]):
+                        if not (np.array_equal(a.haplotype_1, b.haplotype_1) and np.array_equal(a.haplotype_2, b.haplotype_2)
+                                and a.segments == b.segments and a.span_counts.tolist() == b.span_counts.tolist() and a.statistics == b.statistics):
+                            bad.append((s, rep))
+                bs.close()
+        except Exception as e:   # noqa: BLE001
+            bad.append((s, repr(e)))
+
+    th = [threading.Thread(target=work, args=(s,)) for s in (1, 2, 3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert bad == []
