@@ -652,6 +652,18 @@ int W2Session::late() {
             pend.dst[i].score = score[i];
             if (pend.alleles && pend.alleles[i] && jobs[i].n_hets) std::memcpy(pend.alleles[i], al + dj[i].allele_off, jobs[i].n_hets);
         }
+#if W2_STATS
+        {   // sizing study: how far into its alignment a job was when it was handed over (round it gave up in / final score)
+            std::vector<uint8_t> hd(n);
+            (void)hipMemcpy(hd.data(), d_handed.p, n, hipMemcpyDeviceToHost);
+            uint32_t hist[11] = {};
+            for (uint32_t i : pend.held)
+                if (hd[i] && status[i] == W2_ST_OK && score[i] > 0) hist[std::min<uint64_t>(10, (uint64_t)(hd[i] - 1) * 2 * 10 / score[i])]++;
+            fprintf(stderr, "[hp] wfa2 stats handed over at (tenths of the final edit distance):");
+            for (int k = 0; k <= 10; ++k) fprintf(stderr, " %d:%u", k, hist[k]);
+            fprintf(stderr, "\n");
+        }
+#endif
         std::lock_guard<std::mutex> lk(work_m);
         work_updates += s0; work_node_bytes += s1; work_read_bytes += s2w; work_jobs += s3;
     }

@@ -332,7 +332,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                         const bool me = hand && gl == 0 && taken < B.esc_limit;
                         const uint32_t pos = atomicAdd(B.esc, me ? 1u : 0u);
                         (void)atomicExch(me ? B.esc_order + pos : B.esc + 3, me ? job : 0u);
+#if W2_STATS
+                        if (me) B.handed[job] = (uint8_t)(1u + min(254u, ed / 2u));   // sizing study: the round it gave up in
+#else
                         if (me) B.handed[job] = 1;   // (never written by anyone else: hp_wfa2_map_kernel)
+#endif
                         W2_WAIT_VM();
                         bool pend = me;
                         for (uint32_t s = 0; s < (1u << 16) && __any(pend); ++s) {
