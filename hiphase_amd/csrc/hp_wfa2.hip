@@ -162,7 +162,7 @@ struct W2Session {
         int rc = HP_OK;
         std::string err;
     } pend;
-    DevBuf d_job_cls, d_handed, d_seen;
+    DevBuf d_job_cls, d_handed, d_seen, d_held, d_hoff, d_hrec, d_hrows;
     PinBuf late_down;                      // results of the held jobs
     std::unique_ptr<HelperThread> helper;  // runs late() when run() defers
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build start / end, class launches start / end
@@ -618,47 +618,57 @@ int W2Session::late() {
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
     if (pend.two_phase) {
         hipStream_t s2 = pend.stream2;
-        const size_t dn_score = (n * 4 + 15) / 16 * 16, dn_work = dn_score + n * 8, dn_esc = dn_work + n * 8, dn_al = dn_esc + 16;
+        // the held jobs' results, gathered on the device: ids + row offsets up, one record + the allele row per job down
+        const size_t h = pend.held.size();
         int rc;
-        if ((rc = late_down.reserve(dn_al + (size_t)allele_tot + 16)) != HP_OK) return rc;
-        W2MapArgs M{};
-        M.jobs = d_jobs.as<W2Job>(); M.info = d_info.as<W2Info>(); M.n_jobs = (uint32_t)n; M.tags = d_tags.as<uint32_t>();
-        M.out_sets = d_sets.as<uint32_t>(); M.status = d_status.as<int32_t>(); M.alleles = d_alleles.as<uint8_t>();
-        M.nodes = d_nodes.as<W2Node>(); M.out_work = d_work.as<uint32_t>();
-        M.job_cls = d_job_cls.as<uint8_t>(); M.handed = d_handed.as<uint8_t>(); M.seen = d_seen.as<int32_t>(); M.first = 0u;
-        hipLaunchKernelGGL(hp_wfa2_map_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s2, M);
-        HP_HIP_CHECK(hipGetLastError());
-        HP_HIP_CHECK(hipMemcpyAsync(late_down.p, d_seen.p, n * 4, hipMemcpyDeviceToHost, s2));
-        HP_HIP_CHECK(hipMemcpyAsync(late_down.p + dn_score, d_score.p, n * 8, hipMemcpyDeviceToHost, s2));
-        HP_HIP_CHECK(hipMemcpyAsync(late_down.p + dn_work, d_work.p, n * 8, hipMemcpyDeviceToHost, s2));
-        if (allele_tot) HP_HIP_CHECK(hipMemcpyAsync(late_down.p + dn_al, d_alleles.p, (size_t)allele_tot, hipMemcpyDeviceToHost, s2));
+        std::vector<uint32_t> hoff(h + 1, 0);
+        for (size_t k = 0; k < h; ++k) hoff[k + 1] = hoff[k] + jobs[pend.held[k]].n_hets;
+        const size_t up_off = (h * 4 + 15) / 16 * 16, dn_rec = (up_off + (h + 1) * 4 + 63) / 64 * 64, dn_rows = dn_rec + h * sizeof(W2HeldRec);
+        if ((rc = late_down.reserve(dn_rows + hoff[h] + 64)) != HP_OK) return rc;
+        if ((rc = d_held.alloc(h * 4 + 16)) || (rc = d_hoff.alloc((h + 1) * 4 + 16)) || (rc = d_hrec.alloc(h * sizeof(W2HeldRec) + 16)) || (rc = d_hrows.alloc((size_t)hoff[h] + 16))) return rc;
+        if (h) {
+            std::memcpy(late_down.p, pend.held.data(), h * 4);
+            std::memcpy(late_down.p + up_off, hoff.data(), (h + 1) * 4);
+            HP_HIP_CHECK(hipMemcpyAsync(d_held.p, late_down.p, h * 4, hipMemcpyHostToDevice, s2));
+            HP_HIP_CHECK(hipMemcpyAsync(d_hoff.p, late_down.p + up_off, (h + 1) * 4, hipMemcpyHostToDevice, s2));
+            W2MapHeldArgs A{};
+            W2MapArgs& M = A.M;
+            M.jobs = d_jobs.as<W2Job>(); M.info = d_info.as<W2Info>(); M.n_jobs = (uint32_t)n; M.tags = d_tags.as<uint32_t>();
+            M.out_sets = d_sets.as<uint32_t>(); M.status = d_status.as<int32_t>(); M.alleles = d_alleles.as<uint8_t>();
+            M.nodes = d_nodes.as<W2Node>(); M.out_work = d_work.as<uint32_t>();
+            A.held = d_held.as<uint32_t>(); A.hoff = d_hoff.as<uint32_t>(); A.n_held = (uint32_t)h;
+            A.rec = d_hrec.as<W2HeldRec>(); A.rows = d_hrows.as<uint8_t>(); A.out_score = d_score.as<uint64_t>();
+            hipLaunchKernelGGL(hp_wfa2_map_held_kernel, dim3((unsigned)((h + 63) / 64)), dim3(64), 0, s2, A);
+            HP_HIP_CHECK(hipGetLastError());
+            HP_HIP_CHECK(hipMemcpyAsync(late_down.p + dn_rec, d_hrec.p, h * sizeof(W2HeldRec), hipMemcpyDeviceToHost, s2));
+            if (hoff[h]) HP_HIP_CHECK(hipMemcpyAsync(late_down.p + dn_rows, d_hrows.p, hoff[h], hipMemcpyDeviceToHost, s2));
+        }
         if (hipStreamSynchronize(s2) != hipSuccess) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
         float ms_wfa = 0.f;
         (void)hipEventElapsedTime(&ms_wfa, ev[2], ev[3]);
         last_span_ms = (double)ms_wfa;
         late_kernel_ms = (double)pend.ms_build + (double)ms_wfa;
-        const int32_t* status = reinterpret_cast<const int32_t*>(late_down.p);
-        const uint64_t* score = reinterpret_cast<const uint64_t*>(late_down.p + dn_score);
-        const uint32_t* work = reinterpret_cast<const uint32_t*>(late_down.p + dn_work);
-        const uint8_t* al = late_down.p + dn_al;
+        const W2HeldRec* rec = reinterpret_cast<const W2HeldRec*>(late_down.p + dn_rec);
+        const uint8_t* rows = late_down.p + dn_rows;
         uint64_t s0 = 0, s1 = 0, s2w = 0, s3 = 0;
-        for (size_t hk = 0; hk < pend.held.size(); ++hk) {
+        for (size_t hk = 0; hk < h; ++hk) {
             const uint32_t i = pend.held[hk];
-            if (status[i] == W2_ST_NEED_BIG || status[i] == W2_ST_PENDING) { pend.big.push_back(i); continue; }   // (PENDING: handed over, never claimed)
-            if (status[i] != W2_ST_OK && status[i] != W2_ST_MAX_ED) { set_error("job %u: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
-            s0 += work[2 * (size_t)i]; s1 += work[2 * (size_t)i + 1]; s2w += jobs[i].read_len; ++s3;
-            pend.dst[i].status = status[i] == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
+            const int32_t sti = rec[hk].status;
+            if (sti == W2_ST_NEED_BIG || sti == W2_ST_PENDING) { pend.big.push_back(i); continue; }   // (PENDING: handed over, never claimed)
+            if (sti != W2_ST_OK && sti != W2_ST_MAX_ED) { set_error("job %u: device status %d", i, sti); return HP_ERR_INVARIANT; }
+            s0 += rec[hk].work_updates; s1 += rec[hk].work_bytes; s2w += jobs[i].read_len; ++s3;
+            pend.dst[i].status = sti == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
             pend.dst[i].n_nodes = pend.held_nodes[hk];
-            pend.dst[i].score = score[i];
-            if (pend.alleles && pend.alleles[i] && jobs[i].n_hets) std::memcpy(pend.alleles[i], al + dj[i].allele_off, jobs[i].n_hets);
+            pend.dst[i].score = rec[hk].score;
+            if (pend.alleles && pend.alleles[i] && jobs[i].n_hets) std::memcpy(pend.alleles[i], rows + hoff[hk], jobs[i].n_hets);
         }
 #if W2_STATS
         {   // sizing study: how far into its alignment a job was when it was handed over (round it gave up in / final score)
             std::vector<uint8_t> hd(n);
             (void)hipMemcpy(hd.data(), d_handed.p, n, hipMemcpyDeviceToHost);
             uint32_t hist[11] = {};
-            for (uint32_t i : pend.held)
-                if (hd[i] && status[i] == W2_ST_OK && score[i] > 0) hist[std::min<uint64_t>(10, (uint64_t)(hd[i] - 1) * 2 * 10 / score[i])]++;
+            for (size_t hk = 0; hk < h; ++hk)
+                if (hd[pend.held[hk]] && rec[hk].status == W2_ST_OK && rec[hk].score > 0) hist[std::min<uint64_t>(10, (uint64_t)(hd[pend.held[hk]] - 1) * 2 * 10 / rec[hk].score)]++;
             fprintf(stderr, "[hp] wfa2 stats handed over at (tenths of the final edit distance):");
             for (int k = 0; k <= 10; ++k) fprintf(stderr, " %d:%u", k, hist[k]);
             fprintf(stderr, "\n");

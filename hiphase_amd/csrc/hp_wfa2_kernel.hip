@@ -914,4 +914,34 @@ __global__ void __launch_bounds__(64) hp_wfa2_map_kernel(W2MapArgs A) {
     A.out_work[(size_t)j * 2 + 1] = bytes;
 }
 
+// The second collection (two phases): the same mapping for the few jobs the largest class's kernel delivered, gathered - one
+// 32-byte record and the allele row per job, back to back - so that what crosses PCIe is kilobytes, not the whole batch again.
+struct W2HeldRec { int32_t status; uint32_t work_updates; uint64_t score; uint32_t work_bytes; uint32_t pad[3]; };
+struct W2MapHeldArgs {
+    W2MapArgs M;
+    const uint32_t* held;    // job ids
+    const uint32_t* hoff;    // [n_held + 1] offsets of their allele rows in `rows`
+    uint32_t n_held;
+    W2HeldRec* rec;
+    uint8_t* rows;
+    const uint64_t* out_score;
+};
+__global__ void __launch_bounds__(64) hp_wfa2_map_held_kernel(W2MapHeldArgs A) {
+    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+    if (k >= A.n_held) return;
+    const uint32_t j = A.held[k];
+    const int32_t st = A.M.status[j];
+    const W2Job J = A.M.jobs[j];
+    const uint32_t* set = A.M.out_sets + (size_t)j * W2_SET_STRIDE;
+    const bool ok = st == W2_ST_OK;
+    w2_map_alleles(A.M.tags + J.tag_off, A.M.info[j].n_tags, set, ok, A.rows + A.hoff[k], J.n_hets);
+    uint32_t bytes = 0;
+    if (ok && A.M.info[j].n_nodes <= 32u * W2_SET_STRIDE)
+        for (uint32_t n = 0; n < A.M.info[j].n_nodes; ++n)
+            if ((set[n >> 5] >> (n & 31u)) & 1u) bytes += A.M.nodes[J.node_off + n].len_ref & ~W2_IS_REF;
+    W2HeldRec r{};
+    r.status = st; r.work_updates = A.M.out_work[(size_t)j * 2]; r.score = A.out_score[j]; r.work_bytes = bytes;
+    A.rec[k] = r;
+}
+
 }  // namespace hp
