@@ -160,10 +160,11 @@ struct BlockState {         // per block, rebuilt by every solve
 using namespace hp;
 
 // A set is one chunk (one graph-WFA batch, one resident A* batch) unless HP_BLOCK_PIPELINE=1 splits it in two, the
-// largest blocks first, so that the first chunk's rows + A* + post (on a helper thread, on the solver's own streams) run
-// WHILE the second chunk's reads go through graph-WFA. Measured on the default bench workload (137 blocks, 42 k reads):
-// 45.6 ms per step pipelined vs 42.3 ms not - the search wavefronts share their SIMDs with the WFA wavefronts and slow
-// down by about what the overlap saves, and two half-size WFA launches pay two tails. Kept for multi-step callers.
+// largest blocks first, so that the first chunk's rows + A* + post (on a helper thread, on streams bound to compute units
+// of their own: hp_common.h) run WHILE the second chunk's reads go through graph-WFA. Measured on the default bench
+// workload, three times over the round (plain streams 45.6 vs 42.3 ms, a CU partition 59.7 vs 57.1, the final build
+// 35.8 vs 32.2): the heuristic segments want the whole machine for a few milliseconds, two WFA launches pay two tails, and
+// the one-chunk form already overlaps the row assembly with the tail of its launch set. Kept for multi-step callers.
 struct BlockChunk {
     std::vector<size_t> blocks;                  // indices into hp_blockset::in
     std::vector<hp_wfa_job> jobs;                // records with overlaps, all blocks of the chunk
