@@ -42,7 +42,7 @@ inline uint32_t w2_hcap_log2() {   // keys per group's capped-diagonal set: 2^n 
     return v;
 }
 #define W2_HCAP_LOG2 (w2_hcap_log2())
-constexpr uint32_t W2_GSET_STRIDE = W2Cfg<8>::SET_DWORDS;   // dwords per group, sized for the largest class
+constexpr uint32_t W2_GSET_STRIDE = W2Cfg<8>::GROUP_DWORDS;   // dwords per group (node sets + capped records), sized for the largest class
 
 // per-(thread, device) state that survives across calls
 struct W2Context {
@@ -399,11 +399,13 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         if ((rc = cx.htab.alloc(((size_t)3 * max_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
         if ((rc = cx.gsets.alloc((size_t)3 * max_groups * W2_GSET_STRIDE * 4)) != HP_OK) return rc;
         HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)3 * max_groups << W2_HCAP_LOG2) * 8, st));
+        HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, (size_t)3 * max_groups * W2_GSET_STRIDE * 4, st));   // (the capped records carry tags too)
         cx.htab_groups = max_groups; cx.tag_next = 0;
     }
     if ((rc = cx.qhead.alloc(512)) != HP_OK) return rc;
     if ((uint64_t)cx.tag_next + n + 2 >= 0xFFFFFFF0ull) {
         HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)3 * cx.htab_groups << W2_HCAP_LOG2) * 8, st));
+        HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, (size_t)3 * cx.htab_groups * W2_GSET_STRIDE * 4, st));
         cx.tag_next = 0;
     }
     for (int k = 0; k < 3; ++k) {
@@ -475,6 +477,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         B.next = cx.qhead.as<uint32_t>() + 16 * k;
         B.htab = cx.htab.as<uint64_t>() + (((size_t)k * cx.htab_groups) << W2_HCAP_LOG2);
         B.gsets = cx.gsets.as<uint32_t>() + (size_t)k * cx.htab_groups * W2_GSET_STRIDE;
+        B.set_stride = k == 0 ? (uint32_t)W2Cfg<2>::GROUP_DWORDS : k == 1 ? (uint32_t)W2Cfg<4>::GROUP_DWORDS : (uint32_t)W2Cfg<8>::GROUP_DWORDS;
         B.esc = d_esc; B.esc_order = d_order.as<uint32_t>() + (size_t)2 * n; B.handed = d_handed.as<uint8_t>();
         B.esc_role = !escalate ? 0u : (k == 2 ? 2u : 1u);
         B.esc_producers = grid_wg[0] + grid_wg[1];

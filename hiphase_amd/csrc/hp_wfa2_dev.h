@@ -277,6 +277,10 @@ template <int W> struct W2Cfg {
     static constexpr int O_SRC = a16(O_MISC + 4 * W);                 // int2[MAXS] item intervals (far-apart sources only)
     static constexpr int BYTES = a16(O_SRC + 8 * MAXS);
     static constexpr int SET_DWORDS = 2 * SLOTS * W;                  // per group in HBM: the slots' traversed-node sets
+    // ... followed by one 16-byte capped-diagonal record per node (tag, anchor diagonal, 64 bits: diagonal anchor - 32 + k
+    // has reached its cap); diagonals outside a node's window go to the group's hash set
+    static constexpr int REC_DWORDS = 4 * MAXN;
+    static constexpr int GROUP_DWORDS = SET_DWORDS + REC_DWORDS;
 };
 
 struct W2Batch {

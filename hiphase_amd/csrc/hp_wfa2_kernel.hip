@@ -607,11 +607,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         // tie check, and the probe of the capped-diagonal set
         const uint8_t* ra = readp + (has ? pos0 : 0);
         const uint8_t* na_ = nseq + (has ? omax : 0);
-        const uint64_t key = ((uint64_t)tag << 32) | ((uint64_t)(n & 0x3FFu) << 18) | (uint64_t)((uint32_t)d & 0x3FFFFu);
-        const uint32_t home = (n * 0x9E3779B1u + (uint32_t)d) & hmask;
-        uint32_t hpos = home;
-        uint64_t he = 0;
-        if (has) he = htab[hpos];
+        // the node's capped-diagonal record: one 16-byte load per group (neighbouring nodes share a line); the hash set is only
+        // probed for a diagonal outside the record's window
+        uint4 crec = make_uint4(0, 0, 0, 0);
+        if (run) crec = *reinterpret_cast<const uint4*>(gs + C::SET_DWORDS + 4u * n);   // (every lane of the group: the first lane writes it back)
         const W2Pre pm = w2_pre(na_, ra, room > 0);
         const W2Pre8 pA = w2_pre8(nseq + (nA ? oA : 0), readp + (nA ? d + oA : 0), nA);
         const W2Pre8 pB = w2_pre8(nseq + (nB ? oB : 0), readp + (nB ? d + oB : 0), nB);
@@ -655,16 +654,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
             }
         }
         W2PT(5);
-        // ---- capped-diagonal set: is (n, d) recorded? (linear probing past other keys of this job; rare) -------------
-        bool capped = false, hfull = false;
-        if (has) {
-            uint32_t probes = 0;
-            while (he != key && (uint32_t)(he >> 32) == tag) {
-                if (++probes > 24u) { hfull = true; break; }
-                hpos = (hpos + 1u) & hmask;
-                he = htab[hpos];
+        // ---- capped-diagonal set: is (n, d) recorded? ---------------------------------------------------------------------
+        const uint64_t key = ((uint64_t)tag << 32) | ((uint64_t)(n & 0x3FFu) << 18) | (uint64_t)((uint32_t)d & 0x3FFFFu);
+        const uint32_t home = (n * 0x9E3779B1u + (uint32_t)d) & hmask;
+        const bool rec_live = crec.x == tag;                       // (else: nothing of this job recorded for the node yet)
+        const uint32_t rel = (uint32_t)(d - (int32_t)crec.y + 32);   // bit of diagonal d in the record's window
+        const bool in_win = rec_live && rel < 64u;
+        bool capped = in_win && (((rel < 32u ? crec.z : crec.w) >> (rel & 31u)) & 1u);
+        bool hfull = false;
+        const bool use_hash = has && rec_live && !in_win;          // out of the window: the hash set (rare)
+        if (__any(use_hash)) {
+            if (use_hash) {
+                uint32_t hp = home, probes = 0;
+                uint64_t e = htab[hp];
+                while (e != key && (uint32_t)(e >> 32) == tag) {
+                    if (++probes > 24u) { hfull = true; break; }
+                    hp = (hp + 1u) & hmask;
+                    e = htab[hp];
+                }
+                capped = e == key;
             }
-            capped = he == key;
         }
         // ---- decide (wfa_graph.rs:463-474) ---------------------------------------------------------------------------
         const int32_t pos_end = has ? d + (int32_t)E : 0;
@@ -683,28 +692,38 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                 } else kind = ((uint32_t)pos_end < other_len) ? W2_KIND_INTERIOR_READ : W2_KIND_INTERIOR;
             }
         }
-        // ---- record newly capped diagonals. A lane whose probe ended on its own home slot stores there; displaced
-        // lanes (rare) go one at a time and probe again, so that two of them never take the same empty slot -----------
-        if (ins && hpos == home) htab[hpos] = key;
-        {
-            bool later = ins && hpos != home;
-            if (__any(later)) {
-                while (__any(later)) {
-                    const uint64_t lm = __ballot(later);
-                    const int L = __builtin_ctzll(lm);
-                    if ((int)lane == L) {
-                        uint32_t hp = home, probes = 0;
-                        uint64_t e = htab[hp];
-                        while (e != key && (uint32_t)(e >> 32) == tag) {
-                            if (++probes > 24u) { hfull = true; break; }
-                            hp = (hp + 1u) & hmask;
-                            e = htab[hp];
-                        }
-                        if (!hfull) htab[hp] = key;
-                        later = false;
+        // ---- record newly capped diagonals: in the node's record (the group's first lane stores it; an empty record takes
+        // the first such diagonal as its anchor), or - outside its window - in the hash set, one lane at a time so that
+        // two of them never take the same empty slot --------------------------------------------------------------------
+        bool later = false;
+        if (__any(ins)) {
+            const uint64_t im = w2_gballot<G>(ins, gbase);
+            if (im) {   // (group-uniform)
+                int32_t anchor = (int32_t)crec.y;
+                if (!rec_live) anchor = (int32_t)w2_gsel<G>((uint32_t)d, gl, (uint32_t)__builtin_ctzll(im));
+                const uint32_t r2 = (uint32_t)(d - anchor + 32);
+                const bool mine = ins && r2 < 64u;
+                later = ins && !mine;
+                const uint32_t lo = w2_gor<G>(mine && r2 < 32u ? 1u << r2 : 0u), hi = w2_gor<G>(mine && r2 >= 32u ? 1u << (r2 - 32u) : 0u);
+                if (gl == 0) *reinterpret_cast<uint4*>(gs + C::SET_DWORDS + 4u * n) = make_uint4(tag, (uint32_t)anchor, (rec_live ? crec.z : 0u) | lo, (rec_live ? crec.w : 0u) | hi);
+            }
+        }
+        if (__any(later)) {
+            while (__any(later)) {
+                const uint64_t lm = __ballot(later);
+                const int L = __builtin_ctzll(lm);
+                if ((int)lane == L) {
+                    uint32_t hp = home, probes = 0;
+                    uint64_t e = htab[hp];
+                    while (e != key && (uint32_t)(e >> 32) == tag) {
+                        if (++probes > 24u) { hfull = true; break; }
+                        hp = (hp + 1u) & hmask;
+                        e = htab[hp];
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (!hfull) htab[hp] = key;
+                    later = false;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         }
         if (__any(hfull)) { if (w2_gballot<G>(hfull, gbase)) status = W2_ST_NEED_BIG, why = 9u; }
