@@ -308,7 +308,7 @@ struct W2Batch {
     // Escalation: a job that outgrows the tables of its class is handed to the largest class WHILE that class's kernel is
     // still running (its groups keep a ticket for the next list position and wait for it to be published), instead of
     // waiting for a pass of its own after all three. esc[0] = list positions reserved, esc[1] = positions published
-    // (in order), esc[2] = producer workgroups that have exited, esc[3] = scratch. Every access is an atomic RMW: the
+    // (in order), esc[2] = producer workgroups that have exited, esc[3] = scratch, esc[4] = producer workgroups that have started. Every access is an atomic RMW: the
     // L2s of different XCDs are not coherent for plain loads and stores inside a kernel.
     uint32_t* esc;
     uint32_t* esc_order;       // the largest class's job list (capacity: the whole batch)

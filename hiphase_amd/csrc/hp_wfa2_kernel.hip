@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
     int32_t a0 = 0, b0 = 0, o0 = 0, a1 = 0, b1 = 0, o1 = 0;   // previous entries of n: live diagonals [a, b], slot of diagonal d = o + d
     int32_t lo = 0, hi = 0, base = 0;
     const uint32_t n_class = *B.n_items_dev;   // jobs of this graph-size class
+    if (B.esc_role == 1u) (void)atomicAdd(B.esc + 4, lane == 0 ? 1u : 0u);   // a producer workgroup has started
     uint32_t coff = 0;
     int32_t clo = 0, chi = INT32_MIN, cvlo = INT32_MAX, cvhi = INT32_MIN, cflo = INT32_MAX, cfhi = INT32_MIN;   // cluster being formed
     uint32_t lane_far = 0;   // per lane
@@ -306,9 +307,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
             const uint32_t gone = atomicAdd(B.esc + 2, 0u);
             W2_WAIT_VM();
             const uint32_t pub = atomicAdd(B.esc + 1, 0u);
+            // (a profiler or a shared hardware queue may run the kernels one after the other, this one first: when no producer
+            // workgroup has so much as started after ~20 ms of idling, leave - what they hand over then stays for the host's pass)
+            bool alone = false;
+            if (idle_polls > 750u && gone == 0u) alone = atomicAdd(B.esc + 4, 0u) == 0u;
             if (state == S_WAIT) {
                 if (pub > ticket) { state = S_JOB; have_ticket = true; }
-                else if (gone >= B.esc_producers) state = S_DONE;
+                else if (gone >= B.esc_producers || alone) state = S_DONE;
             }
         }
         while (state != S_TILE && state != S_DONE && state != S_WAIT) {

@@ -32,14 +32,21 @@ def group(name):
         return "hp_wfa2_build_kernel"
     return None
 
-tot = collections.defaultdict(float)
-disp = collections.Counter()
+# per exact kernel name and counter: median over its dispatches x number of dispatches (one dispatch of a profiled run can be
+# an outlier: the passes with counters serialise the kernels, and a kernel that waits for another one then waits in vain)
+vals = collections.defaultdict(list)
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         g = group(row.get("Kernel_Name", ""))
         if g:
-            tot[(g, row["Counter_Name"])] += float(row["Counter_Value"])
-            disp[(g, row["Counter_Name"])] += 1
+            vals[(g, row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
+tot = collections.defaultdict(float)
+disp = collections.Counter()
+for (g, _name, c), v in vals.items():
+    v = sorted(v)
+    med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+    tot[(g, c)] += med * len(v)
+    disp[(g, c)] += len(v)
 
 lines = [f"workload: {bench['config']['workload']}", f"launches per pass: {launches} (warm-up {bench['warmup']} + {bench['steps']} steps), {reads} reads and {hets} hets per step", ""]
 for k in sorted(tot):
