@@ -13,8 +13,8 @@
 //     the previous round's slots; waves that finish a node are picked up by its children in the same round through
 //     (child, finished entry) pairs (wfa_graph.rs:527-553) - the only global-memory traffic of a step is the sequence
 //     bytes themselves and one probe of the capped-diagonal set;
-//   * the reference's max_wavefronts map (:360, :464-470) is replaced by the set of CAPPED diagonals, a small tagged
-//     hash set per group in HBM: a wave on (node, d) is stale <=> (node, d) once reached cap = min(node length,
+//   * the reference's max_wavefronts map (:360, :464-470) is replaced by the set of CAPPED diagonals (a tagged 16-byte
+//     record per node in HBM, a tagged hash set for the odd diagonal far from a node's others): a wave on (node, d) is stale <=> (node, d) once reached cap = min(node length,
 //     read length - d) and this wave stops short of it. (A diagonal whose wave is interior with read left gets
 //     offset + 1 on itself next round, so it stays ahead of its own record until it is pruned by min_progression -
 //     after which any later, shorter wave on it is pruned too - or reaches its cap.) tests/cpp/wfa2_model.cpp pins
