@@ -660,8 +660,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         }
         W2PT(5);
         // ---- capped-diagonal set: is (n, d) recorded? ---------------------------------------------------------------------
-        const uint64_t key = ((uint64_t)tag << 32) | ((uint64_t)(n & 0x3FFu) << 18) | (uint64_t)((uint32_t)d & 0x3FFFFu);
-        const uint32_t home = (n * 0x9E3779B1u + (uint32_t)d) & hmask;
         const bool rec_live = crec.x == tag;                       // (else: nothing of this job recorded for the node yet)
         const uint32_t rel = (uint32_t)(d - (int32_t)crec.y + 32);   // bit of diagonal d in the record's window
         const bool in_win = rec_live && rel < 64u;
@@ -670,7 +668,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         const bool use_hash = has && rec_live && !in_win;          // out of the window: the hash set (rare)
         if (__any(use_hash)) {
             if (use_hash) {
-                uint32_t hp = home, probes = 0;
+                const uint64_t key = ((uint64_t)tag << 32) | ((uint64_t)(n & 0x3FFu) << 18) | (uint64_t)((uint32_t)d & 0x3FFFFu);
+                uint32_t hp = (n * 0x9E3779B1u + (uint32_t)d) & hmask, probes = 0;
                 uint64_t e = htab[hp];
                 while (e != key && (uint32_t)(e >> 32) == tag) {
                     if (++probes > 24u) { hfull = true; break; }
@@ -718,7 +717,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                 const uint64_t lm = __ballot(later);
                 const int L = __builtin_ctzll(lm);
                 if ((int)lane == L) {
-                    uint32_t hp = home, probes = 0;
+                    const uint64_t key = ((uint64_t)tag << 32) | ((uint64_t)(n & 0x3FFu) << 18) | (uint64_t)((uint32_t)d & 0x3FFFFu);
+                    uint32_t hp = (n * 0x9E3779B1u + (uint32_t)d) & hmask, probes = 0;
                     uint64_t e = htab[hp];
                     while (e != key && (uint32_t)(e >> 32) == tag) {
                         if (++probes > 24u) { hfull = true; break; }
