@@ -402,8 +402,9 @@ def main():
     # HBM traffic (PMC) cannot be collected from inside this process; the value measured with
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on the same workload is kept under profiles/ and scaled
     # to this launch's hets (see profiles/round1/README.md). null when no measurement matches the workload.
-    traffic, traffic_src = (measured_traffic("hp_astar_kernel", "bytes_per_het", hets_per_step)
-                            if (args.workload == "c2" and args.hets == 5000 and args.coverage == 30 and args.span == 20) else (None, None))
+    # (profiles/round2/traffic.json was measured on the whole-path workload, where the blocks' matrices stay in L2: it says
+    # nothing about this one - 14.7 KB per het in round 1, profiles/round1/traffic.json, on another build)
+    traffic, traffic_src = None, "not measured for this workload on this build"
     out = None
     if rank == 0:
         kavg_ms = sum(kernel_ms) / len(kernel_ms)
