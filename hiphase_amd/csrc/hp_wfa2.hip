@@ -37,8 +37,9 @@ double w2_now_ms() {
 }
 
 
-inline uint32_t w2_hcap_log2() {   // keys per group's capped-diagonal set: 2^n x 8 B (HP_WFA2_HCAP_LOG2 for experiments)
-    static const uint32_t v = [] { const char* e = std::getenv("HP_WFA2_HCAP_LOG2"); const int x = e ? std::atoi(e) : 11; return (uint32_t)std::min(14, std::max(6, x)); }();
+inline uint32_t w2_hcap_log2() {   // keys per group's overflow hash set: 2^n x 8 B (HP_WFA2_HCAP_LOG2 for experiments; 2 048 before the
+                                     // per-node records took over - 128 serve the bench and 2-4 % noise just as well)
+    static const uint32_t v = [] { const char* e = std::getenv("HP_WFA2_HCAP_LOG2"); const int x = e ? std::atoi(e) : 8; return (uint32_t)std::min(14, std::max(6, x)); }();
     return v;
 }
 #define W2_HCAP_LOG2 (w2_hcap_log2())
