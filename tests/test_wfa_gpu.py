@@ -10,7 +10,7 @@ import pytest
 from conftest import load_golden
 from hiphase_amd import _ffi
 from hiphase_amd.sequence_alignment import closest_allele_clip, edit_distance_batch
-from hiphase_amd.wfa_graph import make_jobs, wfa_assign_batch
+from hiphase_amd.wfa_graph import Variant, WfaJobSpec, make_jobs, wfa_assign_batch
 from oracle_ffi import oracle
 from wfa_util import spec_from_golden, synth_wfa_job, _Rng
 
@@ -123,6 +123,39 @@ def test_ignored_and_multiallelic():
     spec, _ = synth_wfa_job(600, ref_len=3000, n_vars=14, multiallelic=0.6)
     spec.hets[2].is_ignored = True
     check_specs([spec])
+
+
+def test_structural_variants_put_paths_far_apart():
+    """A 140-base deletion and a 90-base insertion upstream: the reference-allele and the alternate-allele path reach the
+    nodes behind them 140 / 90 diagonals apart, so a node's capped diagonals do not fit one record window (the overflow
+    hash set of the compact kernels) and its sources are far-apart items. Reads of both haplotypes, with noise, pruning
+    off (both paths stay alive) and on."""
+    import random
+    rng = random.Random(77)
+    ref = bytes(rng.choice(b"ACGT") for _ in range(3200))
+    hets = [Variant.new_sv_deletion(0, 400, 141, ref[400:541], ref[400:401]),
+            Variant.new_snv(1, 700, ref[700:701], bytes([b"ACGT"[(b"ACGT".index(ref[700]) + 1) % 4]]), 0, 1),
+            Variant.new_sv_insertion(2, 1100, 1, ref[1100:1101], ref[1100:1101] + bytes(rng.choice(b"ACGT") for _ in range(90))),
+            Variant.new_snv(3, 1500, ref[1500:1501], bytes([b"ACGT"[(b"ACGT".index(ref[1500]) + 2) % 4]]), 0, 1),
+            Variant.new_snv(4, 2300, ref[2300:2301], bytes([b"ACGT"[(b"ACGT".index(ref[2300]) + 3) % 4]]), 0, 1)]
+    specs = []
+    for hap in range(4):
+        seq = bytearray()
+        pos = 100
+        for k, v in enumerate(hets):
+            seq += ref[pos:v.position]
+            seq += v.allele1 if (hap >> (k % 2)) & 1 else v.allele0
+            pos = v.position + v.ref_len
+        seq += ref[pos:3100]
+        for noise in (0.0, 0.004, 0.012):
+            s = bytearray(seq)
+            for i in range(len(s)):
+                if rng.random() < noise:
+                    s[i] = rng.choice(b"ACGT")
+            specs.append(WfaJobSpec(ref, 100, 3100, hets, [], bytes(s)))
+    check_specs(specs, prune=0, max_ed=500)
+    check_specs(specs, prune=500, max_ed=500)
+    check_specs(specs, prune=60, max_ed=500)
 
 
 # ---- Levenshtein -------------------------------------------------------------------------------------------
