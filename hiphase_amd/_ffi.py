@@ -157,9 +157,12 @@ class LocalRead(C.Structure):
         ("seq_len", C.c_uint32),
         ("seq", C.POINTER(C.c_uint8)),
         ("qual", C.POINTER(C.c_uint8)),
+        ("seq_format", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
+SEQ_ASCII, SEQ_BAM4 = 0, 1
 N_VARIANT_TYPES = 11
 
 
@@ -188,6 +191,8 @@ class BlockRecord(C.Structure):
         ("read_len", C.c_uint32),
         ("qname_id", C.c_uint32),
         ("local", C.POINTER(LocalRead)),
+        ("read_offset", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -205,6 +210,8 @@ class BlockInput(C.Structure):
         ("local_hets", C.POINTER(LocalVariant)),
         ("homs", C.POINTER(WfaVariant)),
         ("records", C.POINTER(BlockRecord)),
+        ("seq_format", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -268,6 +275,10 @@ EXPORTS = [
     "hp_blockset_solve",
     "hp_blockset_work",
     "hp_blockset_destroy",
+    "hp_blockstream_create",
+    "hp_blockstream_submit",
+    "hp_blockstream_wait",
+    "hp_blockstream_destroy",
     "hp_device_count",
     "hp_default_device",
     "hp_last_error",
@@ -340,6 +351,14 @@ def lib():
     dll.hp_blockset_work.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     dll.hp_blockset_destroy.restype = None
     dll.hp_blockset_destroy.argtypes = [C.c_void_p]
+    dll.hp_blockstream_create.restype = C.c_void_p
+    dll.hp_blockstream_create.argtypes = [C.POINTER(BlockParams), C.c_int, C.c_uint32, C.POINTER(C.c_int)]
+    dll.hp_blockstream_submit.restype = C.c_int
+    dll.hp_blockstream_submit.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(BlockInput), C.POINTER(BlockOutput), C.POINTER(C.c_uint64)]
+    dll.hp_blockstream_wait.restype = C.c_int
+    dll.hp_blockstream_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    dll.hp_blockstream_destroy.restype = None
+    dll.hp_blockstream_destroy.argtypes = [C.c_void_p]
     dll.hp_abi_layout.restype = C.c_char_p
     dll.hp_hpbk_append.restype = C.c_int
     dll.hp_hpbk_append.argtypes = [C.c_char_p, C.POINTER(BlockView), C.POINTER(AstarParams), C.c_void_p, C.c_void_p, C.POINTER(PhaseStats)]

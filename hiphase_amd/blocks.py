@@ -41,11 +41,26 @@ class BlockResult:
     status: int = 0             # 0, or 2 = HP_BLOCK_UNSUPPORTED (outside the device solver's limits: the caller solves it)
 
 
-class _Marshalled:
-    """ctypes views of a list of BlockSpec (keeps every buffer alive)."""
+_BAM4_CODE = np.full(256, 15, np.uint8)          # htslib's seq_nt16_table: anything that is not an IUPAC code -> N
+for _i, _c in enumerate(b"=ACMGRSVTWYHKDBN"):
+    _BAM4_CODE[_c] = _i
 
-    def __init__(self, blocks, need_local):
+
+def pack_bam4(seq, offset=0):
+    """bytes -> the BAM record encoding of the bases (4 bits per base, high nibble first), after `offset` filler bases: what
+    rust-htslib's `read.seq().encoded` holds. Only IUPAC upper-case bases survive the BAM encoding (as in a real BAM)."""
+    codes = _BAM4_CODE[np.frombuffer(bytes(seq), np.uint8)] if len(seq) else np.zeros(0, np.uint8)
+    codes = np.concatenate([np.full(offset, 15, np.uint8), codes, np.zeros((offset + len(codes)) & 1, np.uint8)])
+    return ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8)
+
+
+class _Marshalled:
+    """ctypes views of a list of BlockSpec (keeps every buffer alive). seq_format = _ffi.SEQ_BAM4 hands the reads over in the
+    BAM's own 4-bit encoding (every other record behind an odd number of filler bases, as a clipped record's read_start is)."""
+
+    def __init__(self, blocks, need_local, seq_format=_ffi.SEQ_ASCII):
         self.keep = []
+        self.seq_format = seq_format
         self.n = len(blocks)
         self.inputs = (_ffi.BlockInput * max(self.n, 1))()
         self.qnames = []
@@ -98,7 +113,11 @@ class _Marshalled:
             loc = getattr(r, "local", None)
             if hasattr(r, "min_position"):
                 recs[i].min_position, recs[i].max_position = r.min_position, r.max_position
-                recs[i].read_align, recs[i].read_len = self._u8(r.read_align), len(r.read_align)
+                if self.seq_format == _ffi.SEQ_BAM4:
+                    off = (i * 7) % 5   # 0, 2, 4, 1, 3: even and odd read_start
+                    recs[i].read_align, recs[i].read_len, recs[i].read_offset = self._u8(pack_bam4(r.read_align, off).tobytes()), len(r.read_align), off
+                else:
+                    recs[i].read_align, recs[i].read_len = self._u8(r.read_align), len(r.read_align)
             else:           # a LocalRecord on its own (local mode)
                 loc = r
                 recs[i].min_position = recs[i].max_position = r.pos
@@ -108,10 +127,14 @@ class _Marshalled:
                 cg = np.array([(int(n) << 4) | (CIGAR_OPS.index(op) if isinstance(op, str) else int(op)) for op, n in loc.cigar] or [0], np.uint32)
                 self.keep.append(cg)
                 locs[i].pos, locs[i].cigar, locs[i].n_cigar = loc.pos, cg.ctypes.data_as(C.POINTER(C.c_uint32)), len(loc.cigar)
-                locs[i].seq_len, locs[i].seq, locs[i].qual = len(loc.seq), self._u8(loc.seq), self._u8(loc.qual)
+                locs[i].seq_len, locs[i].qual = len(loc.seq), self._u8(loc.qual)
+                if self.seq_format == _ffi.SEQ_BAM4:
+                    locs[i].seq, locs[i].seq_format = self._u8(pack_bam4(loc.seq).tobytes()), _ffi.SEQ_BAM4
+                else:
+                    locs[i].seq = self._u8(loc.seq)
                 recs[i].local = C.pointer(locs[i])
         self.keep += [recs, locs]
-        I.records, I.n_qnames = recs, len(names)
+        I.records, I.n_qnames, I.seq_format = recs, len(names), self.seq_format
         self.qnames.append(names)
 
 
@@ -166,9 +189,9 @@ def _params(min_matched_alleles, min_queue_size, queue_increment, config, global
 
 
 def solve_blocks(blocks, min_matched_alleles=2, min_queue_size=1000, queue_increment=3, config=None, global_realignment=True,
-                 device_id=-1):
+                 device_id=-1, seq_format=_ffi.SEQ_ASCII):
     """hp_solve_blocks for a list of BlockSpec -> [BlockResult]."""
-    m = _Marshalled(blocks, need_local=not global_realignment)
+    m = _Marshalled(blocks, need_local=not global_realignment, seq_format=seq_format)
     o = _Outputs(m)
     p = _params(min_matched_alleles, min_queue_size, queue_increment, config, global_realignment)
     _ffi.check(_ffi.lib().hp_solve_blocks(m.n, m.inputs, C.byref(p), o.arr, device_id))
@@ -179,8 +202,8 @@ class BlockSet:
     """Resident form (hp_blockset_*): sequences uploaded once, `solve()` any number of times."""
 
     def __init__(self, blocks, min_matched_alleles=2, min_queue_size=1000, queue_increment=3, config=None,
-                 global_realignment=True, device_id=-1):
-        self.m = _Marshalled(blocks, need_local=not global_realignment)
+                 global_realignment=True, device_id=-1, seq_format=_ffi.SEQ_ASCII):
+        self.m = _Marshalled(blocks, need_local=not global_realignment, seq_format=seq_format)
         self.o = _Outputs(self.m)
         self.p = _params(min_matched_alleles, min_queue_size, queue_increment, config, global_realignment)
         st = C.c_int(0)
@@ -205,6 +228,43 @@ class BlockSet:
     def close(self):
         if self.h:
             _ffi.lib().hp_blockset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class BlockStream:
+    """Pipelined form (hp_blockstream_*): `submit` a list of BlockSpec, `wait` for its results; sets complete in order."""
+
+    def __init__(self, min_matched_alleles=2, min_queue_size=1000, queue_increment=3, config=None, global_realignment=True,
+                 device_id=-1, depth=0, seq_format=_ffi.SEQ_ASCII):
+        self.p = _params(min_matched_alleles, min_queue_size, queue_increment, config, global_realignment)
+        self.need_local, self.seq_format = not global_realignment, seq_format
+        st = C.c_int(0)
+        self.h = _ffi.lib().hp_blockstream_create(C.byref(self.p), device_id, depth, C.byref(st))
+        if not self.h:
+            raise _ffi.HpError(st.value, _ffi.lib().hp_last_error().decode())
+        self.inflight = {}
+
+    def submit(self, blocks):
+        m = _Marshalled(blocks, need_local=self.need_local, seq_format=self.seq_format)
+        o = _Outputs(m)
+        t = C.c_uint64(0)
+        _ffi.check(_ffi.lib().hp_blockstream_submit(self.h, m.n, m.inputs, o.arr, C.byref(t)))
+        self.inflight[t.value] = (m, o)
+        return t.value
+
+    def wait(self, ticket):
+        """-> ([BlockResult], stage_ms[16], work[8])"""
+        m, o = self.inflight.pop(ticket)
+        ms, work = (C.c_double * 16)(), (C.c_uint64 * 8)()
+        _ffi.check(_ffi.lib().hp_blockstream_wait(self.h, ticket, ms, work))
+        return o.results(m), list(ms), list(work)
+
+    def close(self):
+        if self.h:
+            _ffi.lib().hp_blockstream_destroy(self.h)
             self.h = None
 
     def __del__(self):

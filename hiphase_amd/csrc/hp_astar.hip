@@ -51,6 +51,11 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     const uint32_t N = v->n_variants, R = v->n_reads;
     if (N == 0) { set_error("block with 0 variants (phaser.rs:415-434 short-circuits those before the solver)"); return HP_ERR_ARG; }
     if (N >= (1u << 24)) { set_error("N=%u >= 2^24 exceeds the packed priority-key limit", N); return HP_ERR_UNSUPPORTED; }
+    {   // test hook: blocks of exactly this many variants count as beyond the limits (the real ones need > 10^8 cells in one block)
+        const char* e = std::getenv("HP_TEST_UNSUPPORTED_N");
+        const long test_n = e ? std::atol(e) : -1l;
+        if (test_n >= 0 && (long)N == test_n) { set_error("N=%u: HP_TEST_UNSUPPORTED_N", N); return HP_ERR_UNSUPPORTED; }
+    }
     if (R && (!v->read_start || !v->read_end || !v->row_off || !v->alleles_2bit || !v->quals)) {
         set_error("null array in hp_block_view"); return HP_ERR_ARG;
     }

@@ -1,0 +1,94 @@
+// hp_block.h — state of a block set on its way through the path (hp_block.hip), shared with the pipelined form (hp_stream.hip).
+#pragma once
+#include "hp_common.h"
+#include "hp_wfa2_host.h"
+
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace hp {
+
+// Cells of a block's segments: one bump allocator per block, kept from solve to solve (two heap allocations per record
+// from 32 threads at once were most of the row stage)
+struct Arena {
+    std::vector<std::unique_ptr<uint8_t[]>> chunks;
+    std::vector<size_t> caps;
+    size_t cur = 0, used = 0;
+    void reset() { cur = 0; used = 0; }
+    uint8_t* get(size_t n) {
+        while (cur < chunks.size() && used + n > caps[cur]) { ++cur; used = 0; }
+        if (cur == chunks.size()) {
+            const size_t c = std::max<size_t>(n, (size_t)1 << 16);
+            chunks.emplace_back(new uint8_t[c]);
+            caps.push_back(c);
+        }
+        uint8_t* p = chunks[cur].get() + used;
+        used += n;
+        return p;
+    }
+};
+struct Segment {            // a ReadSegment: clipped row (read_segments.rs:19-62); end - start cells each in the block's arena
+    uint32_t start = 0, end = 0;
+    const uint8_t* alleles = nullptr;
+    const uint8_t* quals = nullptr;
+};
+struct RecMeta { int64_t job = -1; uint32_t first = 0, last = 0; };
+
+struct BlockState {         // per block, rebuilt by every solve
+    std::vector<Segment> segs;            // collapsed, >= 1 set allele, first-seen read-name order
+    std::vector<uint32_t> seg_qname;
+    std::vector<uint8_t> seg_solver;
+    std::vector<uint32_t> solver_rows;    // indices into segs
+    uint64_t num_reads = 0, skipped_reads = 0, global_aligned = 0, local_aligned = 0;
+    std::vector<uint64_t> edit_distances;
+    // the solver matrix as the C ABI takes it
+    std::vector<uint32_t> read_start, read_end;
+    std::vector<uint64_t> row_off;
+    std::vector<uint8_t> alleles_2bit, quals, var_flags;
+    Arena arena;
+    void reset() {   // keeps every capacity
+        segs.clear(); seg_qname.clear(); seg_solver.clear(); solver_rows.clear();
+        num_reads = skipped_reads = global_aligned = local_aligned = 0;
+        edit_distances.clear(); read_start.clear(); read_end.clear(); row_off.clear();
+        alleles_2bit.clear(); quals.clear(); var_flags.clear();
+        arena.reset();
+    }
+};
+
+}  // namespace hp
+
+// One block set on its way through the path: ONE graph-WFA batch over the records of all its blocks, one resident A* batch.
+// (Round 2 could split a set in two overlapped halves, HP_BLOCK_PIPELINE=1; measured three times, it lost every time - two
+// launch sets pay two tails - and the pipelined form across sets, hp_stream.hip, is what overlaps the stages now.)
+// The object is reusable: init() on a used set keeps every host and device allocation (a stream's slots are solved over and
+// over; hipMalloc / hipFree synchronise the device).
+struct hp_blockset {
+    size_t n_blocks = 0;
+    const hp_block_input* in = nullptr;
+    hp_block_params prm{};
+    int device = 0;
+    std::vector<std::vector<hp::RecMeta>> meta;  // per block, per record (job = index into jobs)
+    std::vector<uint32_t> job_first;             // per block: its first job (a block's jobs are contiguous, in record order)
+    std::vector<hp::W2JobIn> jobs;               // records with overlaps, all blocks
+    std::vector<uint64_t> job_alloff;            // per job: offset of its allele row in `alleles`
+    std::vector<uint8_t> alleles;                // per-het AlleleTypes of every job, back to back
+    std::vector<uint8_t*> allele_ptrs;
+    std::vector<hp_wfa_result> wfa_out;
+    hp::W2Session* wfa = nullptr;                // graph-WFA inputs resident on the device (sets of >= HP_WFA2_MIN_JOBS records)
+    bool wfa_ready = false;                      // ... laid out and uploaded for the current blocks
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // stage times of the last solve
+    double prep[4] = {0, 0, 0, 0};               // of the last init: layout ms, fill + upload ms, total ms, bytes host -> device
+    uint64_t work[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // hp_blockset_work of the last solve
+    std::vector<hp::BlockState> st;
+    ~hp_blockset() { if (wfa) hp::w2_session_destroy(wfa); }
+};
+
+namespace hp {
+// lays the set out and uploads its sequences (host threads + PCIe; no kernel but the expansion of the read bases)
+int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id);
+// graph-WFA over every record with overlaps: device graph build, alignment, allele rows (returns after the first collection)
+int blockset_wfa(hp_blockset* bs);
+// fallback / replay / rows / collapse, A*, span counts and haplotags, outputs
+int blockset_tail(hp_blockset* bs, hp_block_output* out);
+}  // namespace hp

@@ -16,6 +16,8 @@
 // the kernels. No CPU fallback: without a device the first device stage fails with HP_ERR_HIP.
 #include "hp_common.h"
 #include "hp_combine.h"
+#include "hp_wfa2_host.h"
+#include "hp_block.h"
 
 #include <algorithm>
 #include <atomic>
@@ -31,18 +33,6 @@
 #include <vector>
 
 namespace hp {
-
-struct W2Session;   // hp_wfa2.hip
-W2Session* w2_session_create();
-void w2_session_destroy(W2Session* s);
-int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id);
-int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer);
-int w2_session_finish(W2Session* s);
-void w2_session_pending(const W2Session* s, const uint32_t** ids, size_t* n);
-void w2_session_work(const W2Session* s, uint64_t out[4]);
-double w2_session_span_ms(const W2Session* s);
-int wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
-                        uint8_t* const* alleles, int device_id);   // hp_wfa.hip
 
 namespace {
 
@@ -63,30 +53,6 @@ int base_quality(uint32_t variant_type) {
     }
 }
 
-// Cells of a block's segments: one bump allocator per block, kept from solve to solve (two heap allocations per record
-// from 32 threads at once were most of the row stage)
-struct Arena {
-    std::vector<std::unique_ptr<uint8_t[]>> chunks;
-    std::vector<size_t> caps;
-    size_t cur = 0, used = 0;
-    void reset() { cur = 0; used = 0; }
-    uint8_t* get(size_t n) {
-        while (cur < chunks.size() && used + n > caps[cur]) { ++cur; used = 0; }
-        if (cur == chunks.size()) {
-            const size_t c = std::max<size_t>(n, (size_t)1 << 16);
-            chunks.emplace_back(new uint8_t[c]);
-            caps.push_back(c);
-        }
-        uint8_t* p = chunks[cur].get() + used;
-        used += n;
-        return p;
-    }
-};
-struct Segment {            // a ReadSegment: clipped row (read_segments.rs:19-62); end - start cells each in the block's arena
-    uint32_t start = 0, end = 0;
-    const uint8_t* alleles = nullptr;
-    const uint8_t* quals = nullptr;
-};
 // ReadSegment::new (read_segments.rs:40-62) from a window [w0, w0 + n) of the block-length vectors (everything outside
 // the window is NoOverlap with quality 0)
 Segment segment_new(Arena& ar, const uint8_t* alleles, const uint8_t* quals, uint32_t w0, uint32_t n, uint32_t n_hets) {
@@ -131,69 +97,10 @@ uint32_t seg_num_set(const Segment& s) {
     return n;
 }
 
-struct RecMeta { int64_t job = -1; uint32_t first = 0, last = 0; };
-
-struct BlockState {         // per block, rebuilt by every solve
-    std::vector<Segment> segs;            // collapsed, >= 1 set allele, first-seen read-name order
-    std::vector<uint32_t> seg_qname;
-    std::vector<uint8_t> seg_solver;
-    std::vector<uint32_t> solver_rows;    // indices into segs
-    uint64_t num_reads = 0, skipped_reads = 0, global_aligned = 0, local_aligned = 0;
-    std::vector<uint64_t> edit_distances;
-    // the solver matrix as the C ABI takes it
-    std::vector<uint32_t> read_start, read_end;
-    std::vector<uint64_t> row_off;
-    std::vector<uint8_t> alleles_2bit, quals, var_flags;
-    Arena arena;
-    void reset() {   // keeps every capacity
-        segs.clear(); seg_qname.clear(); seg_solver.clear(); solver_rows.clear();
-        num_reads = skipped_reads = global_aligned = local_aligned = 0;
-        edit_distances.clear(); read_start.clear(); read_end.clear(); row_off.clear();
-        alleles_2bit.clear(); quals.clear(); var_flags.clear();
-        arena.reset();
-    }
-};
-
 }  // namespace
 }  // namespace hp
 
 using namespace hp;
-
-// A set is one chunk (one graph-WFA batch, one resident A* batch) unless HP_BLOCK_PIPELINE=1 splits it in two, the
-// largest blocks first, so that the first chunk's rows + A* + post (on a helper thread, on streams bound to compute units
-// of their own: hp_common.h) run WHILE the second chunk's reads go through graph-WFA. Measured on the default bench
-// workload, three times over the round (plain streams 45.6 vs 42.3 ms, a CU partition 59.7 vs 57.1, the final build
-// 35.8 vs 32.2): the heuristic segments want the whole machine for a few milliseconds, two WFA launches pay two tails, and
-// the one-chunk form already overlaps the row assembly with the tail of its launch set. Kept for multi-step callers.
-struct BlockChunk {
-    std::vector<size_t> blocks;                  // indices into hp_blockset::in
-    std::vector<hp_wfa_job> jobs;                // records with overlaps, all blocks of the chunk
-    std::vector<uint64_t> job_alloff;            // per job: offset of its allele row in `alleles`
-    std::vector<uint32_t> job_block;             // per job: its block
-    std::vector<uint8_t> alleles;                // per-het AlleleTypes of every job, back to back
-    std::vector<uint8_t*> allele_ptrs;
-    std::vector<hp_wfa_result> wfa_out;
-    W2Session* wfa = nullptr;                    // resident graph-WFA inputs (large batches)
-    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // stage times of the last solve
-    uint64_t work[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int rc = HP_OK;
-    std::string err;
-    ~BlockChunk() { if (wfa) w2_session_destroy(wfa); }
-};
-
-
-struct hp_blockset {
-    size_t n_blocks = 0;
-    const hp_block_input* in = nullptr;
-    hp_block_params prm{};
-    int device = 0;
-    std::vector<std::vector<RecMeta>> meta;      // per block, per record (job = index into its chunk's jobs)
-    std::vector<uint32_t> chunk_of;              // per block
-    std::vector<std::unique_ptr<BlockChunk>> chunks;
-    std::unique_ptr<HelperThread> worker;          // runs chunk 0's tail while chunk 1's graph-WFA runs on the caller's thread
-    uint64_t work[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // hp_blockset_work of the last solve
-    std::vector<BlockState> st;
-};
 
 namespace {
 
@@ -215,99 +122,128 @@ bool overlap_range(const hp_wfa_variant* v, uint32_t n, bool sorted, int64_t lo,
     return any;
 }
 
-int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id) {
+}  // namespace
+
+int hp::blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id) {
     if (!in || !p) { set_error("null argument"); return HP_ERR_ARG; }
+    const double t0 = blk_now_ms();
     bs->n_blocks = n_blocks; bs->in = in; bs->prm = *p;
     bs->device = device_id < 0 ? hp_default_device() : device_id;
-    bs->meta.resize(n_blocks);
-    bs->st.resize(n_blocks);
-    bs->chunk_of.assign(n_blocks, 0);
+    bs->wfa_ready = false;
+    bs->prep[0] = bs->prep[1] = bs->prep[2] = bs->prep[3] = 0.0;
+    if (bs->meta.size() < n_blocks) bs->meta.resize(n_blocks);
+    if (bs->st.size() < n_blocks) bs->st.resize(n_blocks);
+    bs->job_first.assign(n_blocks + 1, 0);
     const char* mj = std::getenv("HP_WFA2_MIN_JOBS");
     const size_t min_jobs = mj ? (size_t)std::strtoull(mj, nullptr, 10) : 4608;
-    uint64_t total_records = 0;
-    for (size_t b = 0; b < n_blocks; ++b) {
-        const hp_block_input& B = in[b];
-        if (B.n_hets == 0) { set_error("block %zu has no variants (phaser.rs:415-434 short-circuits those before this path)", b); return HP_ERR_ARG; }
-        if (!B.hets || !B.het_types || (B.n_homs && !B.homs) || (B.n_records && !B.records) || (p->global_realignment && !B.reference)) {
-            set_error("block %zu: null array", b); return HP_ERR_ARG;
-        }
-        for (uint32_t i = 0; i < B.n_hets; ++i)
-            if (B.het_types[i] > 10) { set_error("block %zu: invalid variant type", b); return HP_ERR_ARG; }
-        for (uint32_t r = 0; r < B.n_records; ++r) {
-            if (B.records[r].qname_id >= B.n_qnames) { set_error("block %zu record %u: qname_id out of range", b, r); return HP_ERR_ARG; }
-            if (B.records[r].max_position < B.records[r].min_position) { set_error("block %zu record %u: assert!(max_position >= min_position) (read_parsing.rs:685)", b, r); return HP_ERR_INVARIANT; }
-        }
-        total_records += B.n_records;
-    }
-    // chunk 0: the largest blocks, about a third of the records (only when both chunks still fill the compact WFA kernel)
+    // per block (host threads over blocks): validation, and for every record its overlaps (read_parsing.rs:688-730)
+    std::vector<uint32_t> njobs(n_blocks, 0);
     {
-        std::vector<size_t> by_size(n_blocks);
-        for (size_t b = 0; b < n_blocks; ++b) by_size[b] = b;
-        std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return in[x].n_hets > in[y].n_hets; });
-        const char* pe = std::getenv("HP_BLOCK_PIPELINE");
-        const bool split = pe && pe[0] == '1' && p->global_realignment && n_blocks >= 8 && total_records >= 3 * (uint64_t)std::max<size_t>(min_jobs, 1);
-        bs->chunks.emplace_back(new BlockChunk());
-        if (split) { bs->chunks.emplace_back(new BlockChunk()); bs->worker.reset(new HelperThread()); bs->worker->start(); }
-        uint64_t acc = 0;
-        for (size_t k = 0; k < n_blocks; ++k) {
-            const size_t b = by_size[k];
-            const uint32_t c = (split && acc * 3 >= total_records) ? 1u : 0u;
-            bs->chunk_of[b] = c;
-            bs->chunks[c]->blocks.push_back(b);
-            acc += in[b].n_records;
-        }
-        for (auto& ch : bs->chunks) std::sort(ch->blocks.begin(), ch->blocks.end());
-    }
-    for (auto& chp : bs->chunks) {
-        BlockChunk& ch = *chp;
-        uint64_t al_total = 0;
-        for (size_t b : ch.blocks) {
-            const hp_block_input& B = in[b];
-            bs->meta[b].assign(B.n_records, RecMeta{});
-            if (!p->global_realignment) continue;
-            bool hs = true, ms = true;
-            for (uint32_t i = 1; i < B.n_hets; ++i) hs = hs && B.hets[i - 1].position <= B.hets[i].position;
-            for (uint32_t i = 1; i < B.n_homs; ++i) ms = ms && B.homs[i - 1].position <= B.homs[i].position;
-            for (uint32_t r = 0; r < B.n_records; ++r) {
-                const hp_block_record& rec = B.records[r];
-                uint32_t f = 0, l = 0, hf = 0, hl = 0;
-                bool contig = true;
-                if (!overlap_range(B.hets, B.n_hets, hs, rec.min_position, rec.max_position, f, l, contig)) continue;   // :703-712: skipped
-                if (!contig) { set_error("block %zu: assert_eq!(num_overlaps, last_overlap - first_overlap) (read_parsing.rs:715)", b); return HP_ERR_INVARIANT; }
-                const bool homs = overlap_range(B.homs, B.n_homs, ms, rec.min_position, rec.max_position, hf, hl, contig);
-                if (rec.min_position < (int64_t)B.ref_base) { set_error("block %zu record %u: alignment starts before the reference buffer", b, r); return HP_ERR_ARG; }
-                hp_wfa_job j{};
-                j.reference = B.reference; j.ref_base = B.ref_base;
-                j.ref_start = (uint64_t)rec.min_position; j.ref_end = (uint64_t)rec.max_position + 1;   // :772-773
-                j.hets = B.hets + f; j.n_hets = l - f;
-                j.homs = homs ? B.homs + hf : nullptr; j.n_homs = homs ? hl - hf : 0;   // first_hom_overlap.unwrap_or(0) with an empty range
-                j.read = rec.read_align; j.read_len = rec.read_len;
-                RecMeta& m = bs->meta[b][r];
-                m.job = (int64_t)ch.jobs.size(); m.first = f; m.last = l;
-                ch.jobs.push_back(j);
-                ch.job_block.push_back((uint32_t)b);
-                ch.job_alloff.push_back(al_total);
-                al_total += l - f;
+        std::atomic<size_t> next{0};
+        std::atomic<int> first_rc{HP_OK};
+        unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
+        nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n_blocks / 4));
+        std::vector<std::string> errs(nt);
+        auto fail = [&](unsigned t, int rc) { int exp = HP_OK; if (first_rc.compare_exchange_strong(exp, rc)) errs[t] = hp_last_error(); };
+        WorkerPool::get().run(nt, [&](unsigned t) {
+            for (;;) {
+                const size_t b = next.fetch_add(1);
+                if (b >= n_blocks || first_rc.load() != HP_OK) return;
+                const hp_block_input& B = in[b];
+                if (B.n_hets == 0) { set_error("block %zu has no variants (phaser.rs:415-434 short-circuits those before this path)", b); return fail(t, HP_ERR_ARG); }
+                if (!B.hets || !B.het_types || (B.n_homs && !B.homs) || (B.n_records && !B.records) || (p->global_realignment && !B.reference)) {
+                    set_error("block %zu: null array", b); return fail(t, HP_ERR_ARG);
+                }
+                if (B.seq_format != HP_SEQ_ASCII && B.seq_format != HP_SEQ_BAM4) { set_error("block %zu: unknown seq_format %u", b, B.seq_format); return fail(t, HP_ERR_ARG); }
+                for (uint32_t i = 0; i < B.n_hets; ++i)
+                    if (B.het_types[i] > 10) { set_error("block %zu: invalid variant type", b); return fail(t, HP_ERR_ARG); }
+                std::vector<RecMeta>& meta = bs->meta[b];
+                meta.assign(B.n_records, RecMeta{});
+                bool hs = true;
+                for (uint32_t i = 1; i < B.n_hets; ++i) hs = hs && B.hets[i - 1].position <= B.hets[i].position;
+                uint32_t nj = 0;
+                for (uint32_t r = 0; r < B.n_records; ++r) {
+                    const hp_block_record& rec = B.records[r];
+                    if (rec.qname_id >= B.n_qnames) { set_error("block %zu record %u: qname_id out of range", b, r); return fail(t, HP_ERR_ARG); }
+                    if (rec.max_position < rec.min_position) { set_error("block %zu record %u: assert!(max_position >= min_position) (read_parsing.rs:685)", b, r); return fail(t, HP_ERR_INVARIANT); }
+                    if (!p->global_realignment) continue;
+                    uint32_t f = 0, l = 0;
+                    bool contig = true;
+                    if (!overlap_range(B.hets, B.n_hets, hs, rec.min_position, rec.max_position, f, l, contig)) continue;   // :703-712: skipped
+                    if (!contig) { set_error("block %zu: assert_eq!(num_overlaps, last_overlap - first_overlap) (read_parsing.rs:715)", b); return fail(t, HP_ERR_INVARIANT); }
+                    if (rec.min_position < (int64_t)B.ref_base) { set_error("block %zu record %u: alignment starts before the reference buffer", b, r); return fail(t, HP_ERR_ARG); }
+                    meta[r].job = (int64_t)nj++; meta[r].first = f; meta[r].last = l;   // (job: block-local until the offsets are known)
+                }
+                njobs[b] = nj;
             }
-        }
-        ch.alleles.assign((size_t)al_total + 1, (uint8_t)HP_ALLELE_NOOVERLAP);
-        ch.allele_ptrs.resize(ch.jobs.size());
-        for (size_t k = 0; k < ch.jobs.size(); ++k) ch.allele_ptrs[k] = ch.alleles.data() + ch.job_alloff[k];
-        ch.wfa_out.resize(ch.jobs.size());
-        // large batches: lay the sequences out and upload them now (resident); small ones take the latency path at solve time
-        if (!ch.jobs.empty() && ch.jobs.size() >= min_jobs) {
-            ch.wfa = w2_session_create();
-            const int rc = w2_session_prepare(ch.wfa, ch.jobs.data(), ch.jobs.size(), bs->device);
-            if (rc != HP_OK) return rc;
+        });
+        if (first_rc.load() != HP_OK) {
+            for (auto& e : errs) if (!e.empty()) { set_error("%s", e.c_str()); break; }
+            return first_rc.load();
         }
     }
+    for (size_t b = 0; b < n_blocks; ++b) bs->job_first[b + 1] = bs->job_first[b] + njobs[b];
+    const size_t n_jobs = bs->job_first[n_blocks];
+    bs->jobs.resize(n_jobs);
+    bs->job_alloff.resize(n_jobs + 1);
+    {   // the jobs (host threads over blocks): the hom overlaps of a record are only looked up for records that have het overlaps
+        std::atomic<size_t> next{0};
+        unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
+        nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n_blocks / 4));
+        WorkerPool::get().run(nt, [&](unsigned) {
+            for (;;) {
+                const size_t b = next.fetch_add(1);
+                if (b >= n_blocks) return;
+                const hp_block_input& B = in[b];
+                bool ms = true;
+                for (uint32_t i = 1; i < B.n_homs; ++i) ms = ms && B.homs[i - 1].position <= B.homs[i].position;
+                const uint32_t j0 = bs->job_first[b];
+                for (uint32_t r = 0; r < B.n_records; ++r) {
+                    RecMeta& m = bs->meta[b][r];
+                    if (m.job < 0) continue;
+                    const hp_block_record& rec = B.records[r];
+                    uint32_t hf = 0, hl = 0;
+                    bool contig = true;
+                    const bool homs = overlap_range(B.homs, B.n_homs, ms, rec.min_position, rec.max_position, hf, hl, contig);
+                    m.job += j0;
+                    W2JobIn& j = bs->jobs[(size_t)m.job];
+                    j.block = (uint32_t)b; j.rec = r;
+                    j.het_first = m.first; j.n_hets = m.last - m.first;
+                    j.hom_first = homs ? hf : 0; j.n_homs = homs ? hl - hf : 0;   // first_hom_overlap.unwrap_or(0) with an empty range
+                }
+            }
+        });
+    }
+    uint64_t al_total = 0;
+    for (size_t k = 0; k < n_jobs; ++k) { bs->job_alloff[k] = al_total; al_total += bs->jobs[k].n_hets; }
+    bs->job_alloff[n_jobs] = al_total;
+    bs->alleles.assign((size_t)al_total + 1, (uint8_t)HP_ALLELE_NOOVERLAP);
+    bs->allele_ptrs.resize(n_jobs);
+    for (size_t k = 0; k < n_jobs; ++k) bs->allele_ptrs[k] = bs->alleles.data() + bs->job_alloff[k];
+    bs->wfa_out.resize(n_jobs);
+    bs->prep[0] = blk_now_ms() - t0;
+    // large sets: lay the sequences out and upload them now (resident); small ones take the latency path at solve time
+    if (n_jobs && n_jobs >= min_jobs) {
+        if (!bs->wfa) bs->wfa = w2_session_create();
+        const int rc = w2_session_prepare_blocks(bs->wfa, in, n_blocks, bs->jobs.data(), n_jobs, bs->device);
+        if (rc != HP_OK) return rc;
+        bs->wfa_ready = true;
+        double pr[4];
+        w2_session_prepare_stats(bs->wfa, pr);
+        bs->prep[0] += pr[0]; bs->prep[1] = pr[1]; bs->prep[3] = pr[3];
+    }
+    bs->prep[2] = blk_now_ms() - t0;
     return HP_OK;
 }
+
+namespace {
 
 // load_full_read_segments' tail for one block (read_parsing.rs:546-629) once every record's WFA outcome is known:
 // fallback to local re-alignment, the global_disabled switch in BAM order, qualities, ReadSegment::new, collapse, split
 int assemble_block(hp_blockset* bs, size_t b) {
-    const BlockChunk& CH = *bs->chunks[bs->chunk_of[b]];
+    const hp_blockset& CH = *bs;
     const hp_block_input& B = bs->in[b];
     const hp_block_params& P = bs->prm;
     BlockState& S = bs->st[b];
@@ -482,46 +418,72 @@ extern "C" hp_blockset* hp_blockset_create(size_t n_blocks, const hp_block_input
 
 extern "C" void hp_blockset_destroy(hp_blockset* bs) { delete bs; }
 
-namespace {
-
-// graph-WFA for every record with overlaps of one chunk (one device batch); runs on the calling thread
-int chunk_wfa(hp_blockset* bs, BlockChunk& ch) {
+// graph-WFA for every record with overlaps (one device batch); runs on the calling thread
+int hp::blockset_wfa(hp_blockset* bs) {
+    hp_blockset& ch = *bs;
     const double t0 = blk_now_ms();
     ch.ms[6] = 0.0;
     if (!ch.jobs.empty()) {
         int rc;
-        // (the few reads the compact kernel hands back are still in the dense-band pass when this returns: chunk_tail)
-        if (ch.wfa) rc = w2_session_run(ch.wfa, bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(), ch.allele_ptrs.data(), bs->chunks.size() == 1 ? 2 : 1);
-        else rc = hp_wfa_assign_batch(ch.jobs.data(), ch.jobs.size(), bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(),
-                                      ch.allele_ptrs.data(), bs->device);
+        // (the few reads the compact kernel hands back are still in the dense-band pass when this returns: blockset_tail)
+        if (ch.wfa_ready) rc = w2_session_run(ch.wfa, bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(), ch.allele_ptrs.data(), 2);
+        else {
+            // a small set takes the latency path (dense-band kernel, one wavefront per read): the jobs as hp_wfa_assign_batch takes
+            // them, BAM 4-bit reads decoded on the host (a few thousand reads at most)
+            std::vector<hp_wfa_job> jobs(ch.jobs.size());
+            std::vector<std::vector<uint8_t>> ascii;
+            for (size_t k = 0; k < ch.jobs.size(); ++k) {
+                const W2JobIn& ji = ch.jobs[k];
+                const hp_block_input& B = bs->in[ji.block];
+                const hp_block_record& rec = B.records[ji.rec];
+                hp_wfa_job& j = jobs[k];
+                j = hp_wfa_job{};
+                j.reference = B.reference; j.ref_base = B.ref_base;
+                j.ref_start = (uint64_t)rec.min_position; j.ref_end = (uint64_t)rec.max_position + 1;   // read_parsing.rs:772-773
+                j.hets = B.hets + ji.het_first; j.n_hets = ji.n_hets;
+                j.homs = ji.n_homs ? B.homs + ji.hom_first : nullptr; j.n_homs = ji.n_homs;
+                j.read_len = rec.read_len;
+                if (B.seq_format == HP_SEQ_BAM4) {
+                    ascii.emplace_back((size_t)rec.read_len + 1);
+                    decode_bam4(rec.read_align, rec.read_offset, rec.read_len, ascii.back().data());
+                    j.read = ascii.back().data();
+                } else j.read = rec.read_align + rec.read_offset;
+            }
+            // (straight to the dense-band implementation, on this thread: the public entry would queue behind the call combiner)
+            rc = wfa_assign_batch_v1(jobs.data(), jobs.size(), bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(),
+                                     ch.allele_ptrs.data(), bs->device);
+        }
         if (rc != HP_OK) return rc;
         // the three class instantiations of hp_wfa2_kernel run concurrently: their span is the kernel time of the stage
-        ch.ms[6] = ch.wfa ? 0.0 : hp_last_kernel_ms();   // (resident session: known once its second collection is done, chunk_tail)
+        ch.ms[6] = ch.wfa_ready ? 0.0 : g_last_kernel_ms;   // (resident session: known once its second collection is done, blockset_tail)
     }
     ch.ms[0] = blk_now_ms() - t0;
     return HP_OK;
 }
 
-// everything after the WFA for the blocks of one chunk: fallback / replay / rows / collapse (host threads over blocks),
-// A* (one resident batch), span counts and haplotags, outputs. May run on a helper thread.
-int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
+// everything after the WFA: fallback / replay / rows / collapse (host threads over blocks), A* (one resident batch), span
+// counts and haplotags, outputs. May run on another thread than blockset_wfa did.
+int hp::blockset_tail(hp_blockset* bs, hp_block_output* out) {
+    hp_blockset& ch = *bs;
+    const bool has_wfa = ch.wfa_ready;
     const double t1 = blk_now_ms();
     int rc = HP_OK;
     {
         unsigned nt = std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));   // measured: 16 -> 32 threads 6.0 -> 4.1 ms, 64 no better
         if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
-        nt = (unsigned)std::min<size_t>(nt, ch.blocks.size());
-        std::vector<size_t> order(ch.blocks);
+        nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, bs->n_blocks));
+        std::vector<size_t> order(bs->n_blocks);
+        for (size_t b = 0; b < bs->n_blocks; ++b) order[b] = b;
         std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return bs->in[x].n_records > bs->in[y].n_records; });
         // blocks that hold a read whose alignment is still in the dense-band pass go last; whoever reaches the first of
         // them waits for that pass (it has had the other blocks' assembly to finish in)
         size_t n_free = order.size();
-        if (ch.wfa) {
+        if (has_wfa) {
             const uint32_t* ids = nullptr; size_t n_ids = 0;
             w2_session_pending(ch.wfa, &ids, &n_ids);
             if (n_ids) {
                 std::vector<uint8_t> held(bs->n_blocks, 0);
-                for (size_t k = 0; k < n_ids; ++k) held[ch.job_block[ids[k]]] = 1;
+                for (size_t k = 0; k < n_ids; ++k) held[ch.jobs[ids[k]].block] = 1;
                 std::stable_partition(order.begin(), order.end(), [&](size_t b) { return !held[b]; });
                 n_free = 0;
                 while (n_free < order.size() && !held[order[n_free]]) ++n_free;
@@ -558,8 +520,8 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
             for (auto& e : errs) if (!e.empty()) { set_error("%s", e.c_str()); break; }
             return first_rc.load();
         }
-        if (ch.wfa && (rc = w2_session_finish(ch.wfa)) != HP_OK) return rc;   // (already done unless no block was held)
-        if (ch.wfa) ch.ms[6] = w2_session_span_ms(ch.wfa);
+        if (has_wfa && (rc = w2_session_finish(ch.wfa)) != HP_OK) return rc;   // (already done unless no block was held)
+        if (has_wfa) ch.ms[6] = w2_session_span_ms(ch.wfa);
         if (dbg) {
             double s = 0.0, m = 0.0; size_t arg = 0;
             for (unsigned i = 0; i < std::max(1u, nt); ++i) { s += dbg_sum[i]; if (dbg_max[i] > m) { m = dbg_max[i]; arg = dbg_arg[i]; } }
@@ -569,10 +531,10 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
     }
     const double t2 = blk_now_ms();
     // ---- A* over the chunk's blocks ----
-    const size_t nb = ch.blocks.size();
+    const size_t nb = bs->n_blocks;
     std::vector<hp_block_view> views(nb);
     for (size_t k = 0; k < nb; ++k) {
-        const size_t b = ch.blocks[k];
+        const size_t b = k;
         const BlockState& S = bs->st[b];
         hp_block_view v{};
         v.n_variants = bs->in[b].n_hets;
@@ -583,39 +545,45 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
     }
     hp_astar_params ap = bs->prm.astar;
     int st = HP_OK;
-    hp_batch* batch = hp_batch_create(nb, views.data(), &ap, bs->device, &st);
+    // kept[j] = index (into views) of the j-th block of the A* batch. A block outside the solver's packed-key
+    // limits must not fail the others - nor the call when it is alone: it is left out of the batch and handed back
+    // with the soft status HP_BLOCK_UNSUPPORTED (segments filled; h1 / h2 / stats / spans / tags untouched), whether it came
+    // alone, with others, or merged with other callers' blocks
+    std::vector<size_t> kept(nb);
+    for (size_t k = 0; k < nb; ++k) kept[k] = k;
     std::vector<char> unsupported(nb, 0);
-    if (!batch && st == HP_ERR_UNSUPPORTED && nb > 1) {
-        // one block outside the solver's packed-key limits must not fail the others: find it (a create on
-        // its own tells), hand it back with the soft status HP_BLOCK_UNSUPPORTED and an empty matrix in its place
-        static const uint32_t zero32 = 0;
-        static const uint64_t zero64[2] = {0, 0};
-        static const uint8_t zero8[2] = {0, 0};
-        bool any_ok = false;
-        for (size_t k = 0; k < nb; ++k) {
+    hp_batch* batch = hp_batch_create(nb, views.data(), &ap, bs->device, &st);
+    if (!batch && st == HP_ERR_UNSUPPORTED) {
+        kept.clear();
+        for (size_t k = 0; k < nb; ++k) {   // a create on its own tells which
             int s1 = HP_OK;
             hp_batch* one = hp_batch_create(1, &views[k], &ap, bs->device, &s1);
-            if (one) { hp_batch_destroy(one); any_ok = true; continue; }
+            if (one) { hp_batch_destroy(one); kept.push_back(k); continue; }
             if (s1 != HP_ERR_UNSUPPORTED) return s1;
             unsupported[k] = 1;
-            views[k].n_reads = 0; views[k].read_start = &zero32; views[k].read_end = &zero32; views[k].row_off = zero64;
-            views[k].alleles_2bit = zero8; views[k].quals = zero8;
         }
-        if (any_ok) batch = hp_batch_create(nb, views.data(), &ap, bs->device, &st);
-    }
-    if (!batch) return st != HP_OK ? st : HP_ERR_HIP;
-    struct BatchGuard { hp_batch* b; ~BatchGuard() { hp_batch_destroy(b); } } guard{batch};
+        if (!kept.empty() && kept.size() < nb) {
+            std::vector<hp_block_view> kv(kept.size());
+            for (size_t j = 0; j < kept.size(); ++j) kv[j] = views[kept[j]];
+            batch = hp_batch_create(kept.size(), kv.data(), &ap, bs->device, &st);
+            if (!batch) return st != HP_OK ? st : HP_ERR_HIP;
+        } else if (!kept.empty()) return HP_ERR_UNSUPPORTED;   // every block packs alone but not together: the batch limits (split the call)
+    } else if (!batch) return st != HP_OK ? st : HP_ERR_HIP;
+    struct BatchGuard { hp_batch* b; ~BatchGuard() { if (b) hp_batch_destroy(b); } } guard{batch};
+    const size_t nk = kept.size();
     const double t3 = blk_now_ms();
     float kms = 0.f;
-    if ((rc = hp_batch_solve(batch, nullptr, &kms)) != HP_OK) return rc;
     uint64_t sum_n = 0, sum_rows = 0, sum_j = 0;
-    for (size_t k = 0; k < nb; ++k) { const size_t b = ch.blocks[k]; sum_n += bs->in[b].n_hets; sum_rows += views[k].n_reads; sum_j += bs->in[b].n_hets - 1; }
-    std::vector<uint8_t> h1((size_t)sum_n), h2((size_t)sum_n);
-    std::vector<hp_phase_stats> stats(nb);
-    std::vector<hp_work_counters> ctr(nb);
-    if ((rc = hp_batch_results(batch, h1.data(), h2.data(), stats.data(), ctr.data(), nullptr)) != HP_OK) return rc;
+    for (size_t j = 0; j < nk; ++j) { const size_t k = kept[j]; sum_n += bs->in[k].n_hets; sum_rows += views[k].n_reads; sum_j += bs->in[k].n_hets - 1; }
+    std::vector<uint8_t> h1((size_t)sum_n + 1), h2((size_t)sum_n + 1);
+    std::vector<hp_phase_stats> stats(nk + 1);
+    std::vector<hp_work_counters> ctr(nk);
+    if (batch) {
+        if ((rc = hp_batch_solve(batch, nullptr, &kms)) != HP_OK) return rc;
+        if ((rc = hp_batch_results(batch, h1.data(), h2.data(), stats.data(), ctr.data(), nullptr)) != HP_OK) return rc;
+    }
     for (int i = 0; i < 8; ++i) ch.work[i] = 0;
-    if (ch.wfa) w2_session_work(ch.wfa, ch.work);
+    if (has_wfa) w2_session_work(ch.wfa, ch.work);
     for (auto& c : ctr) { ch.work[4] += c.cells; ch.work[5] += c.evals; }
     ch.work[6] = sum_n; ch.work[7] = sum_rows;
     const double t4 = blk_now_ms();
@@ -623,28 +591,36 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
     std::vector<uint64_t> spans((size_t)sum_j + 1);
     std::vector<uint8_t> tag((size_t)sum_rows + 1);
     std::vector<uint32_t> fh((size_t)sum_rows + 1);
-    if ((rc = hp_batch_postprocess(batch, spans.data(), tag.data(), fh.data())) != HP_OK) return rc;
+    if (batch && (rc = hp_batch_postprocess(batch, spans.data(), tag.data(), fh.data())) != HP_OK) return rc;
     // ---- outputs (blocks are independent: host threads over blocks) ----
-    std::vector<uint64_t> on_of(nb + 1, 0), orow_of(nb + 1, 0), oj_of(nb + 1, 0);
-    for (size_t kb = 0; kb < nb; ++kb) {
-        const uint32_t N = bs->in[ch.blocks[kb]].n_hets;
-        on_of[kb + 1] = on_of[kb] + N; orow_of[kb + 1] = orow_of[kb] + views[kb].n_reads; oj_of[kb + 1] = oj_of[kb] + N - 1;
+    std::vector<uint64_t> on_of(nb + 1, 0), orow_of(nb + 1, 0), oj_of(nb + 1, 0), slot_of(nb, 0);   // offsets in the batch's results
+    {
+        uint64_t on = 0, orow = 0, oj = 0;
+        for (size_t j = 0; j < nk; ++j) {
+            const size_t kb = kept[j];
+            const uint32_t N = bs->in[kb].n_hets;
+            on_of[kb] = on; orow_of[kb] = orow; oj_of[kb] = oj; slot_of[kb] = j;
+            on += N; orow += views[kb].n_reads; oj += N - 1;
+        }
     }
     std::atomic<int64_t> cap_fail{-1};
     auto emit_block = [&](size_t kb) {
         const uint64_t on = on_of[kb], orow = orow_of[kb], oj = oj_of[kb];
-        const size_t b = ch.blocks[kb];
+        const size_t b = kb;
         const hp_block_input& B = bs->in[b];
         const BlockState& S = bs->st[b];
         hp_block_output& O = out[b];
-        O.status = unsupported[kb] ? HP_BLOCK_UNSUPPORTED : HP_OK;
+        const bool unsup = unsupported[kb] != 0;
+        O.status = unsup ? HP_BLOCK_UNSUPPORTED : HP_OK;
         const uint32_t N = B.n_hets;
         const uint8_t* H1 = h1.data() + on;
         const uint8_t* H2 = h2.data() + on;
-        if (O.h1) std::memcpy(O.h1, H1, N);
-        if (O.h2) std::memcpy(O.h2, H2, N);
-        O.stats = stats[kb];
-        if (O.span_counts && N > 1) std::memcpy(O.span_counts, spans.data() + oj, (size_t)(N - 1) * 8);
+        if (!unsup) {   // (an unsupported block's h1 / h2 / stats / spans stay as the caller left them: hiphase_gpu.h)
+            if (O.h1) std::memcpy(O.h1, H1, N);
+            if (O.h2) std::memcpy(O.h2, H2, N);
+            O.stats = stats[slot_of[kb]];
+            if (O.span_counts && N > 1) std::memcpy(O.span_counts, spans.data() + oj, (size_t)(N - 1) * 8);
+        }
         O.n_segments = (uint32_t)S.segs.size();
         O.n_solver = (uint32_t)S.solver_rows.size();
         O.num_reads = S.num_reads; O.skipped_reads = S.skipped_reads; O.global_aligned = S.global_aligned; O.local_aligned = S.local_aligned;
@@ -660,7 +636,7 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
             if (O.seg_solver) O.seg_solver[k] = S.seg_solver[k];
             uint8_t ht = 2;
             uint32_t first = UINT32_MAX;
-            if (unsupported[kb]) {}
+            if (unsup) {}
             else if (S.seg_solver[k]) { ht = tag[(size_t)(orow + srow)]; first = fh[(size_t)(orow + srow)]; ++srow; }
             else {
                 // a segment outside the solver matrix (fewer than min_matched_alleles set alleles) is tagged against the
@@ -704,40 +680,15 @@ int chunk_tail(hp_blockset* bs, BlockChunk& ch, hp_block_output* out) {
     return HP_OK;
 }
 
-}  // namespace
-
 extern "C" int hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* stage_ms) {
     if (!bs || !out) { set_error("null argument"); return HP_ERR_ARG; }
     const double t0 = blk_now_ms();
-    int rc = HP_OK;
-    // chunk 0's graph-WFA, then its tail (rows, A*, post) on a helper thread while chunk 1's graph-WFA runs here
-    bool posted = false;
-    for (size_t c = 0; c < bs->chunks.size() && rc == HP_OK; ++c) {
-        BlockChunk& ch = *bs->chunks[c];
-        ch.rc = HP_OK; ch.err.clear();
-        // while an earlier chunk's search runs on the helper thread, this chunk's graph-WFA keeps to the other CUs
-        g_cu_partition = (bs->worker && c > 0) ? 2 : 0;
-        rc = chunk_wfa(bs, ch);
-        g_cu_partition = 0;
-        if (rc != HP_OK) break;
-        if (c + 1 < bs->chunks.size() && bs->worker) {
-            BlockChunk* chp = &ch;
-            bs->worker->post([bs, chp, out]() {
-                g_cu_partition = 1;   // the helper thread's streams live on the search partition
-                chp->rc = chunk_tail(bs, *chp, out);
-                if (chp->rc != HP_OK) chp->err = hp_last_error();
-            });
-            posted = true;
-        } else rc = chunk_tail(bs, ch, out);
-    }
-    if (posted) bs->worker->wait();
+    int rc = blockset_wfa(bs);
+    if (rc == HP_OK) rc = blockset_tail(bs, out);
     if (rc != HP_OK) return rc;
-    for (auto& ch : bs->chunks)
-        if (ch->rc != HP_OK) { set_error("%s", ch->err.c_str()); return ch->rc; }
-    for (int i = 0; i < 8; ++i) { bs->work[i] = 0; for (auto& ch : bs->chunks) bs->work[i] += ch->work[i]; }
     if (stage_ms) {
-        for (int i = 0; i < 8; ++i) { stage_ms[i] = 0.0; for (auto& ch : bs->chunks) stage_ms[i] += ch->ms[i]; }
-        stage_ms[5] = blk_now_ms() - t0;   // wall time of the call; the stage sums exceed it by what the two chunks overlap
+        for (int i = 0; i < 8; ++i) stage_ms[i] = bs->ms[i];
+        stage_ms[5] = blk_now_ms() - t0;   // wall time of the call
     }
     return HP_OK;
 }

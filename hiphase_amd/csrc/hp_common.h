@@ -97,11 +97,12 @@ class WorkerPool {
     std::vector<std::thread> th;
     std::function<void(unsigned)> job;
     unsigned want = 0, started = 0, done = 0;
-    bool busy = false;
+    bool busy = false, quit = false;
     void loop() {
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
-            cv.wait(lk, [this]() { return started < want; });
+            cv.wait(lk, [this]() { return started < want || quit; });
+            if (quit) return;
             const unsigned id = started++;
             lk.unlock();
             job(id);
@@ -109,8 +110,19 @@ class WorkerPool {
             if (++done == want) cv_done.notify_all();
         }
     }
+    static WorkerPool*& tl_pool() { static thread_local WorkerPool* p = nullptr; return p; }
 public:
-    static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }
+    WorkerPool() = default;
+    WorkerPool(const WorkerPool&) = delete;
+    // (only pools owned by a block stream are ever destroyed; the process-wide one lives as long as the process)
+    ~WorkerPool() {
+        { std::unique_lock<std::mutex> lk(m); quit = true; cv.notify_all(); }
+        for (auto& x : th) if (x.joinable()) x.join();
+    }
+    // The pool of the calling thread: a pipeline stage of a block stream (hp_stream.hip) brings its own, so that the stages'
+    // parallel regions do not queue behind each other; everyone else shares the process-wide one.
+    static WorkerPool& get() { if (tl_pool()) return *tl_pool(); static WorkerPool* p = new WorkerPool(); return *p; }
+    static void set_thread_pool(WorkerPool* p) { tl_pool() = p; }
     // f(0) .. f(nt - 1), each on a thread of its own (the caller runs f(nt - 1)); returns when all are done
     template <class F> void run(unsigned nt, F&& f) {
         if (nt <= 1) { f(0u); return; }
@@ -125,7 +137,6 @@ public:
         }
         busy = true;
         while (th.size() + 1 < nt) th.emplace_back([this]() { loop(); });
-        for (auto& x : th) if (x.joinable()) x.detach();
         job = [&f](unsigned t) { f(t); };
         want = nt - 1; started = 0; done = 0;
         cv.notify_all();
@@ -137,6 +148,18 @@ public:
         busy = false;
     }
 };
+
+// HP_SEQ_BAM4 -> one byte per base, htslib's table (what read.seq().as_bytes() returns): base k of the record sits in byte
+// k / 2, high nibble first. Host-side decode for the few reads that leave the device paths (dense-band leftovers, local
+// re-alignment); the bulk of the reads is expanded on the device (hp_wfa2_unpack_kernel).
+inline void decode_bam4(const uint8_t* src, uint64_t first_base, uint64_t n, uint8_t* dst) {
+    static const char tab[17] = "=ACMGRSVTWYHKDBN";
+    for (uint64_t k = 0; k < n; ++k) {
+        const uint64_t b = first_base + k;
+        const uint8_t byte = src[b >> 1];
+        dst[k] = (uint8_t)tab[(b & 1u) ? (byte & 15u) : (byte >> 4)];
+    }
+}
 
 // grow-only pinned staging (DMA straight from it; never value-initialised)
 struct PinBuf {

@@ -204,10 +204,26 @@ int realign_one(const hp_local_read& rd, uint32_t ri, const hp_local_variant* va
 
 using namespace hp;
 
-extern "C" int hp_local_realign_batch(const hp_local_read* reads, size_t n_reads, const hp_local_variant* variants,
+extern "C" int hp_local_realign_batch(const hp_local_read* reads_in, size_t n_reads, const hp_local_variant* variants,
                                       size_t n_variants, uint8_t* alleles, uint8_t* quals, hp_read_stats* stats, int device_id) {
     if (n_reads == 0) return HP_OK;
-    if (!reads || (n_variants && (!variants || !alleles || !quals))) { set_error("null argument"); return HP_ERR_ARG; }
+    if (!reads_in || (n_variants && (!variants || !alleles || !quals))) { set_error("null argument"); return HP_ERR_ARG; }
+    // records handed over in the BAM's own 4-bit encoding (HP_SEQ_BAM4) are decoded here, exactly as read.seq().as_bytes() does
+    // (read_parsing.rs:151): local re-alignment sees a few records per block (the fallbacks) or runs in local mode
+    const hp_local_read* reads = reads_in;
+    std::vector<hp_local_read> decoded_reads;
+    std::vector<std::vector<uint8_t>> decoded_seq;
+    for (size_t r = 0; r < n_reads; ++r) {
+        if (reads_in[r].seq_format == HP_SEQ_ASCII) continue;
+        if (reads_in[r].seq_format != HP_SEQ_BAM4) { set_error("record %zu: unknown seq_format %u", r, reads_in[r].seq_format); return HP_ERR_ARG; }
+        if (decoded_reads.empty()) decoded_reads.assign(reads_in, reads_in + n_reads);
+        if (reads_in[r].seq_len && !reads_in[r].seq) { set_error("record %zu: null buffer", r); return HP_ERR_ARG; }
+        decoded_seq.emplace_back((size_t)reads_in[r].seq_len + 1);
+        decode_bam4(reads_in[r].seq, 0, reads_in[r].seq_len, decoded_seq.back().data());
+        decoded_reads[r].seq = decoded_seq.back().data();
+        decoded_reads[r].seq_format = HP_SEQ_ASCII;
+    }
+    if (!decoded_reads.empty()) reads = decoded_reads.data();
     if (n_reads > 0x7FFFFFFFull || n_variants > 0x7FFFFFFFull) { set_error("batch too large"); return HP_ERR_ARG; }
     for (size_t i = 0; i < n_variants; ++i) {
         const hp_local_variant& v = variants[i];

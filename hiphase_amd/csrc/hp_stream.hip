@@ -1,0 +1,177 @@
+// hp_stream.hip — block sets through the path as a PIPELINE (hp_blockstream_*).
+//
+// HiPhase sees every phase block once (reference src/main.rs:337-408: blocks are generated, queued to the worker pool and
+// written in order; src/phaser.rs:513-543: a block's reads are loaded, then it is solved). A caller that hands over one block
+// set after the other therefore wants set k + 2 to be laid out and cross PCIe while set k + 1 is being aligned and set k is
+// being solved - not the three in a row. Three stages, one thread each, every stage with its own HIP streams, device-buffer
+// cache, pinned staging and host worker pool (all of them per-thread state of the library), so they overlap on the host and
+// on the device:
+//
+//   stage 1 (hp::blockset_init)   overlaps of every record, layout, reads staged piece by piece as the caller holds them
+//                                 (ASCII or the BAM's own 4-bit codes) while the previous piece crosses PCIe, expanded on the device
+//   stage 2 (hp::blockset_wfa)    device graph build + graph-WFA launch set + allele rows + first collection
+//   stage 3 (hp::blockset_tail)   fallback replay / qualities / collapse on host threads, A* pack + solve, span counts and
+//                                 haplotags, outputs into the caller's buffers
+//
+// Sets complete in submission order. `depth` slots hold the sets in flight; a slot keeps its host vectors and device buffers
+// from one set to the next (hipMalloc / hipFree synchronise the device). submit() blocks while every slot is taken - the
+// back-pressure the reference's bounded job queue applies (main.rs:362-383).
+#include "hp_block.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace hp;
+
+namespace {
+
+double st_now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+struct Slot {
+    hp_blockset bs;
+    enum State { FREE, QUEUED, DONE } state = FREE;
+    uint64_t ticket = 0;
+    size_t n_blocks = 0;
+    const hp_block_input* in = nullptr;
+    hp_block_output* out = nullptr;
+    int rc = HP_OK;
+    std::string err;
+    double t_submit = 0, t_begin[3] = {0, 0, 0}, t_end[3] = {0, 0, 0};
+};
+
+}  // namespace
+
+struct hp_blockstream {
+    hp_block_params prm{};
+    int device = 0;
+    std::vector<std::unique_ptr<Slot>> slots;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Slot*> q[3];            // waiting for stage 1 / 2 / 3
+    uint64_t next_ticket = 1;
+    bool quit = false;
+    std::thread th[3];
+    std::unique_ptr<WorkerPool> pool[3];
+    void stage_loop(int k);
+};
+
+void hp_blockstream::stage_loop(int k) {
+    WorkerPool::set_thread_pool(pool[k].get());
+    (void)hipSetDevice(device);
+    for (;;) {
+        Slot* s = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&]() { return quit || !q[k].empty(); });
+            if (q[k].empty()) return;   // quit, nothing left to do
+            s = q[k].front();
+            q[k].pop_front();
+        }
+        s->t_begin[k] = st_now_ms();
+        if (s->rc == HP_OK) {   // (a set that failed an earlier stage just travels on, so that tickets complete in order)
+            int rc = HP_OK;
+            if (k == 0) rc = blockset_init(&s->bs, s->n_blocks, s->in, &prm, device);
+            else if (k == 1) rc = blockset_wfa(&s->bs);
+            else rc = blockset_tail(&s->bs, s->out);
+            if (rc != HP_OK) { s->rc = rc; s->err = hp_last_error(); }
+        }
+        s->t_end[k] = st_now_ms();
+        {
+            std::unique_lock<std::mutex> lk(m);
+            if (k < 2) q[k + 1].push_back(s); else s->state = Slot::DONE;
+            cv.notify_all();
+        }
+    }
+}
+
+extern "C" hp_blockstream* hp_blockstream_create(const hp_block_params* p, int device_id, uint32_t depth, int* status) {
+    auto fail = [&](int rc) -> hp_blockstream* { if (status) *status = rc; return nullptr; };
+    if (!p) { set_error("null argument"); return fail(HP_ERR_ARG); }
+    if (hp_device_count() <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return fail(HP_ERR_HIP); }
+    if (depth == 0) depth = 4;
+    if (depth > 16) { set_error("depth %u: at most 16 block sets in flight", depth); return fail(HP_ERR_ARG); }
+    auto s = std::unique_ptr<hp_blockstream>(new hp_blockstream());
+    s->prm = *p;
+    s->device = device_id < 0 ? hp_default_device() : device_id;
+    if (hipSetDevice(s->device) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", s->device); return fail(HP_ERR_HIP); }
+    for (uint32_t i = 0; i < depth; ++i) s->slots.emplace_back(new Slot());
+    for (int k = 0; k < 3; ++k) s->pool[k].reset(new WorkerPool());
+    hp_blockstream* raw = s.get();
+    for (int k = 0; k < 3; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_loop(k); });
+    if (status) *status = HP_OK;
+    return s.release();
+}
+
+extern "C" int hp_blockstream_submit(hp_blockstream* s, size_t n_blocks, const hp_block_input* in, hp_block_output* out, uint64_t* ticket) {
+    if (!s || !ticket || (n_blocks && (!in || !out))) { set_error("null argument"); return HP_ERR_ARG; }
+    std::unique_lock<std::mutex> lk(s->m);
+    Slot* slot = nullptr;
+    s->cv.wait(lk, [&]() {
+        for (auto& x : s->slots) if (x->state == Slot::FREE) { slot = x.get(); return true; }
+        return false;
+    });
+    slot->state = Slot::QUEUED;
+    slot->ticket = s->next_ticket++;
+    slot->n_blocks = n_blocks; slot->in = in; slot->out = out;
+    slot->rc = HP_OK; slot->err.clear();
+    slot->t_submit = st_now_ms();
+    *ticket = slot->ticket;
+    s->q[0].push_back(slot);
+    s->cv.notify_all();
+    return HP_OK;
+}
+
+extern "C" int hp_blockstream_wait(hp_blockstream* s, uint64_t ticket, double* stage_ms, uint64_t* work) {
+    if (!s) { set_error("null argument"); return HP_ERR_ARG; }
+    std::unique_lock<std::mutex> lk(s->m);
+    Slot* slot = nullptr;
+    for (auto& x : s->slots) if (x->state != Slot::FREE && x->ticket == ticket) slot = x.get();
+    if (!slot) { set_error("hp_blockstream_wait: ticket %llu is not in flight", (unsigned long long)ticket); return HP_ERR_ARG; }
+    s->cv.wait(lk, [&]() { return slot->state == Slot::DONE; });
+    const int rc = slot->rc;
+    if (rc != HP_OK) set_error("%s", slot->err.c_str());
+    if (stage_ms) {
+        const hp_blockset& B = slot->bs;
+        stage_ms[0] = B.prep[0]; stage_ms[1] = B.prep[1];
+        stage_ms[2] = B.ms[0]; stage_ms[3] = B.ms[1]; stage_ms[4] = B.ms[2]; stage_ms[5] = B.ms[3]; stage_ms[6] = B.ms[4];
+        stage_ms[7] = slot->t_end[2] - slot->t_submit;
+        stage_ms[8] = B.ms[6]; stage_ms[9] = B.ms[7];
+        stage_ms[10] = B.prep[3];
+        stage_ms[11] = (slot->t_begin[0] - slot->t_submit) + (slot->t_begin[1] - slot->t_end[0]) + (slot->t_begin[2] - slot->t_end[1]);
+        stage_ms[12] = slot->t_end[0] - slot->t_begin[0]; stage_ms[13] = slot->t_end[1] - slot->t_begin[1]; stage_ms[14] = slot->t_end[2] - slot->t_begin[2];
+        stage_ms[15] = 0.0;
+    }
+    if (work) for (int i = 0; i < 8; ++i) work[i] = slot->bs.work[i];
+    slot->state = Slot::FREE;
+    s->cv.notify_all();
+    return rc;
+}
+
+extern "C" void hp_blockstream_destroy(hp_blockstream* s) {
+    if (!s) return;
+    {
+        std::unique_lock<std::mutex> lk(s->m);
+        // sets still in flight are finished first (their buffers belong to the caller)
+        s->cv.wait(lk, [&]() {
+            for (auto& x : s->slots) if (x->state == Slot::QUEUED) return false;
+            return true;
+        });
+        s->quit = true;
+        s->cv.notify_all();
+    }
+    for (auto& t : s->th) if (t.joinable()) t.join();
+    delete s;
+}

@@ -10,6 +10,7 @@
 //   5. reads that outgrow the compact state or the device builder's fixed queues (W2_ST_NEED_BIG / W2B_NEED_HOST)
 //      are re-run by the dense-band path of hp_wfa.hip (host graph build + hp_wfa_kernel). Same results either way.
 #include "hp_wfa2_kernel.hip"
+#include "hp_wfa2_host.h"
 
 #include <algorithm>
 #include <memory>
@@ -23,10 +24,6 @@
 #include <vector>
 
 namespace hp {
-
-// hp_wfa.hip: the dense-band implementation (host graph build + hp_wfa_kernel), used for the leftovers
-int wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
-                        uint8_t* const* alleles, int device_id);
 
 namespace {
 
@@ -52,7 +49,6 @@ struct W2Context {
     DevBuf gsets;            // [groups][W2_SET_STRIDE_MAX] the arena slots' traversed-node sets
     uint32_t htab_groups = 0;
     uint32_t tag_next = 0;   // tags handed out so far (tag 0 = empty)
-    DevBuf qhead;            // work-queue heads of the class launches
     // streams per CU partition (hp_common.h): the main stream, and one per graph-size class (the three launches overlap)
     struct Streams { hipStream_t stream = nullptr; hipStream_t cstream[3] = {nullptr, nullptr, nullptr}; } ps[3];
     hipEvent_t cfork = nullptr, cjoin[3] = {nullptr, nullptr, nullptr};
@@ -79,6 +75,17 @@ struct W2Context {
     }
 };
 thread_local W2Context g_w2;
+// the calling thread's context, (re)bound to `device`: a session may be prepared on one thread and run on another (a block
+// stream's stages, a caller's thread pool) - every thread brings its own streams, scratch sets and staging
+W2Context& w2_context(int device) {
+    W2Context& cx = g_w2;
+    if (cx.device != device) {
+        cx.htab.release(); cx.gsets.release(); cx.htab_groups = 0; cx.tag_next = 0;
+        cx.drop_streams();
+        cx.device = device;
+    }
+    return cx;
+}
 
 unsigned w2_host_threads(size_t n, size_t per_thread) {
     const char* tenv = std::getenv("HP_WFA_HOST_THREADS");
@@ -132,9 +139,36 @@ template <int G, int W> int w2_launch(const W2Batch& B, uint32_t n_items, int n_
 // A batch laid out and uploaded once (prepare) can be aligned any number of times (run): what the block-level resident
 // form (hp_block.hip) and the bench time is run(), with the sequences already in HBM.
 struct W2Session {
-    const hp_wfa_job* jobs = nullptr;
+    const hp_wfa_job* jobs = nullptr;    // generic mode (hp_wfa_assign_batch): the caller's jobs
+    const hp_block_input* bl_in = nullptr;   // block mode (hp_block.hip): jobs are records of these blocks
+    const W2JobIn* bl_jobs = nullptr;
     size_t n = 0;
     int device_id = -1;
+    DevBuf d_qhead;                      // work-queue heads, class counts, hand-over words of the last run
+    DevBuf d_packed, d_src_off, d_fmt;   // block mode: the reads as the caller holds them (ASCII or BAM 4-bit), expanded by hp_wfa2_unpack_kernel
+    uint64_t h2d_bytes = 0;              // of the last prepare
+    double prep_ms[4] = {0, 0, 0, 0};    // of the last prepare: layout, fill + upload, total, -
+    std::vector<std::vector<uint8_t>> ascii_scratch;   // block mode: decoded reads of the jobs that leave the compact path
+    // job i as the dense-band path takes it (generic mode: the caller's; block mode: assembled from the block, a BAM 4-bit read
+    // decoded on the host - a handful of jobs per batch)
+    hp_wfa_job materialize(size_t i) {
+        if (jobs) return jobs[i];
+        const W2JobIn& ji = bl_jobs[i];
+        const hp_block_input& B = bl_in[ji.block];
+        const hp_block_record& rec = B.records[ji.rec];
+        hp_wfa_job j{};
+        j.reference = B.reference; j.ref_base = B.ref_base;
+        j.ref_start = (uint64_t)rec.min_position; j.ref_end = (uint64_t)rec.max_position + 1;   // read_parsing.rs:772-773
+        j.hets = B.hets + ji.het_first; j.n_hets = ji.n_hets;
+        j.homs = ji.n_homs ? B.homs + ji.hom_first : nullptr; j.n_homs = ji.n_homs;
+        j.read_len = rec.read_len;
+        if (B.seq_format == HP_SEQ_BAM4) {
+            ascii_scratch.emplace_back((size_t)rec.read_len + 1);
+            decode_bam4(rec.read_align, rec.read_offset, rec.read_len, ascii_scratch.back().data());
+            j.read = ascii_scratch.back().data();
+        } else j.read = rec.read_align + rec.read_offset;
+        return j;
+    }
     std::vector<W2Job> dj;
     std::vector<W2Variant> vars;
     std::vector<uint32_t> len_order;   // job ids, longest read first (stable)
@@ -171,6 +205,7 @@ struct W2Session {
     double late_kernel_ms = 0.0;
     std::mutex work_m;
     int prepare(const hp_wfa_job* jobs_, size_t n_, int device);
+    int prepare_blocks(const hp_block_input* in, size_t n_in, const W2JobIn* jin, size_t n_, int device);
     // defer: 0 = everything is in `out` on return; 1 = the dense-band pass of the leftovers may still run (finish() waits);
     // 2 = also the largest class's kernel (two phases) - the caller must not start another run on this thread before finish()
     int run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer = 0);
@@ -182,7 +217,7 @@ struct W2Session {
 };
 
 int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
-    jobs = jobs_; n = n_;
+    jobs = jobs_; n = n_; bl_in = nullptr; bl_jobs = nullptr;
     if (n == 0) return HP_OK;
     if (!jobs) { set_error("null argument"); return HP_ERR_ARG; }
     if (n > 0x3FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
@@ -285,12 +320,7 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     if (device < 0) device = hp_default_device();
     device_id = device;
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
-    W2Context& cx = g_w2;
-    if (cx.device != device_id) {
-        cx.htab.release(); cx.gsets.release(); cx.htab_groups = 0; cx.tag_next = 0;
-        cx.drop_streams();
-        cx.device = device_id;
-    }
+    W2Context& cx = w2_context(device_id);
     W2Context::Streams* cs_ = nullptr;
     { const int rc0 = cx.streams(g_cu_partition, &cs_); if (rc0 != HP_OK) return rc0; }
     hipStream_t st = cs_->stream;
@@ -347,6 +377,218 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     return HP_OK;
 }
 
+// Block mode. What prepare() finds out by sorting and merging address ranges is known here by construction: a block's jobs
+// read windows of ONE reference buffer (their hull is uploaded once) and slices of the block's two variant vectors (uploaded
+// once, hets then homs). Everything per job is independent of every other job, so layout, table fill and the staging copy
+// run on host threads; the reads are staged in pieces and each piece's DMA runs while the next one is being filled.
+int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2JobIn* jin, size_t n_, int device) {
+    jobs = nullptr; bl_in = in; bl_jobs = jin; n = n_;
+    h2d_bytes = 0; prep_ms[0] = prep_ms[1] = prep_ms[2] = prep_ms[3] = 0.0;
+    if (n == 0) return HP_OK;
+    if (!in || !jin) { set_error("null argument"); return HP_ERR_ARG; }
+    if (n > 0x3FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
+    const double t0 = w2_now_ms();
+    seq_bytes = 0; node_tot = edge_tot = tag_tot = allele_tot = 0;
+    // ---- 1. per block: hull of its jobs' windows, variant base, allele pool -------------------------------------------------
+    struct BlockLay { int64_t lo = INT64_MAX, hi = INT64_MIN; uint64_t ref_dev = 0, pool_off = 0; uint32_t var_base = 0; };
+    std::vector<BlockLay> bl(n_in);
+    for (size_t i = 0; i < n; ++i) {
+        const W2JobIn& ji = jin[i];
+        if (ji.block >= n_in || ji.rec >= in[ji.block].n_records) { set_error("job %zu: bad block / record index", i); return HP_ERR_ARG; }
+        const hp_block_record& rec = in[ji.block].records[ji.rec];
+        if (!rec.read_align && rec.read_len) { set_error("job %zu: null sequence", i); return HP_ERR_ARG; }
+        if (rec.max_position - rec.min_position >= 0x7FFFFFF0ll) { set_error("job %zu: reference window too long", i); return HP_ERR_UNSUPPORTED; }
+        BlockLay& L = bl[ji.block];
+        L.lo = std::min(L.lo, rec.min_position); L.hi = std::max(L.hi, rec.max_position + 1);
+    }
+    uint64_t n_vars = 0, pool_bytes = 0, ref_bytes = 0;
+    for (size_t b = 0; b < n_in; ++b) {
+        BlockLay& L = bl[b];
+        if (L.lo > L.hi) continue;   // no job of this block
+        const hp_block_input& B = in[b];
+        if (B.seq_format != HP_SEQ_ASCII && B.seq_format != HP_SEQ_BAM4) { set_error("block %zu: unknown seq_format %u", b, B.seq_format); return HP_ERR_ARG; }
+        L.ref_dev = ref_bytes; ref_bytes += ((uint64_t)(L.hi - L.lo) + 15) & ~15ull;
+        L.var_base = (uint32_t)n_vars; n_vars += (uint64_t)B.n_hets + B.n_homs;
+        L.pool_off = pool_bytes;
+        for (int pass = 0; pass < 2; ++pass) {
+            const hp_wfa_variant* hv = pass ? B.homs : B.hets;
+            const uint32_t cnt = pass ? B.n_homs : B.n_hets;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                if ((hv[k].flags & 2u) && !hv[k].allele0 && hv[k].allele0_len) { set_error("variant with null allele0"); return HP_ERR_ARG; }
+                if (!hv[k].allele1 && hv[k].allele1_len) { set_error("variant with null allele1"); return HP_ERR_ARG; }
+                pool_bytes += ((hv[k].flags & 2u) ? hv[k].allele0_len : 0u) + (uint64_t)hv[k].allele1_len;
+            }
+        }
+        if (n_vars >= 0xFFFFFFF0ull || pool_bytes >= 0xFFFFFF00ull) { set_error("too many variants / allele pool exceeds 4 GiB"); return HP_ERR_UNSUPPORTED; }
+    }
+    alt_off = ref_bytes;
+    const uint64_t reads_dev = ref_bytes + ((pool_bytes + 15) & ~15ull);   // device: [reference hulls][allele pool][one byte per base][pad]
+    // ---- 2. per job: offsets (serial prefix sums, a few bytes per job) ------------------------------------------------------------
+    dj.assign(n, W2Job{});
+    std::vector<uint64_t> src_off(n + 1);
+    std::vector<uint8_t> fmt(n);
+    uint64_t dev_reads = 0, packed = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const W2JobIn& ji = jin[i];
+        const hp_block_input& B = in[ji.block];
+        const hp_block_record& rec = B.records[ji.rec];
+        W2Job& d = dj[i];
+        d.read_off = reads_dev + dev_reads; d.read_len = rec.read_len;
+        dev_reads += ((uint64_t)rec.read_len + 15) & ~15ull;
+        const uint32_t odd = B.seq_format == HP_SEQ_BAM4 ? (rec.read_offset & 1u) : 0u;
+        const uint64_t pb = B.seq_format == HP_SEQ_BAM4 ? ((uint64_t)odd + rec.read_len + 1) / 2 : rec.read_len;
+        src_off[i] = packed; fmt[i] = (uint8_t)(B.seq_format | (odd << 4));
+        packed += ((pb + 15) & ~15ull) + 16;   // (the expansion reads 16 bytes at a time)
+        const uint64_t V = (uint64_t)ji.n_hets + ji.n_homs;
+        const uint64_t ncap = 5 * V + 2, ecap = 2 * ncap, tcap = 2 * (uint64_t)ji.n_hets + 2;
+        if (node_tot + ncap >= 0xFFFFFFF0ull || edge_tot + ecap >= 0xFFFFFFF0ull || allele_tot + ji.n_hets >= 0xFFFFFFF0ull) { set_error("batch too large"); return HP_ERR_UNSUPPORTED; }
+        d.node_off = (uint32_t)node_tot; d.node_cap = (uint32_t)ncap; node_tot += ncap;
+        d.edge_off = (uint32_t)edge_tot; d.edge_cap = (uint32_t)ecap; edge_tot += ecap;
+        d.tag_off = (uint32_t)tag_tot; d.tag_cap = (uint32_t)tcap; tag_tot += tcap;
+        d.allele_off = (uint32_t)allele_tot; allele_tot += ji.n_hets;
+    }
+    src_off[n] = packed;
+    seq_bytes = reads_dev + dev_reads + 256;
+    // longest read first (stable counting sort; reads beyond 64 k bases share the first bucket - the order only steers the work queues)
+    len_order.resize(n);
+    {
+        std::vector<uint32_t> cnt(65537, 0);
+        for (size_t i = 0; i < n; ++i) cnt[65535u - std::min<uint32_t>(dj[i].read_len, 65535u) + 1u]++;
+        for (size_t k = 1; k <= 65536; ++k) cnt[k] += cnt[k - 1];
+        for (size_t i = 0; i < n; ++i) len_order[cnt[65535u - std::min<uint32_t>(dj[i].read_len, 65535u)]++] = (uint32_t)i;
+    }
+    vars.clear();
+    const double t_lay = w2_now_ms();
+
+    // ---- from here on a GPU is mandatory (no CPU fallback) -------------------------------------------------------------
+    if (device < 0) device = hp_default_device();
+    device_id = device;
+    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
+    W2Context& cx = w2_context(device_id);
+    W2Context::Streams* cs_ = nullptr;
+    { const int rc0 = cx.streams(g_cu_partition, &cs_); if (rc0 != HP_OK) return rc0; }
+    hipStream_t st = cs_->stream;
+    struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{st};
+    int rc;
+    // pinned staging: [reference hulls][allele pool][W2Variant][W2Job][len_order][src_off][fmt][reads as the caller holds them]
+    auto a64 = [](uint64_t x) { return (x + 63) & ~63ull; };
+    const uint64_t o_vars = a64(reads_dev), o_jobs = a64(o_vars + n_vars * sizeof(W2Variant)), o_len = a64(o_jobs + n * sizeof(W2Job)),
+                   o_src = a64(o_len + n * 4), o_fmt = a64(o_src + n * 8), o_packed = a64(o_fmt + n);
+    if ((rc = cx.stage.reserve(o_packed + packed + 64)) != HP_OK) return rc;
+    if ((rc = d_seq.alloc(seq_bytes)) || (rc = d_packed.alloc(packed + 64)) || (rc = d_src_off.alloc(n * 8)) || (rc = d_fmt.alloc(n + 16)) ||
+        (rc = d_vars.alloc(std::max<size_t>(1, vars.size()) * sizeof(W2Variant))) || (rc = d_jobs.alloc(n * sizeof(W2Job))) ||
+        (rc = d_nodes.alloc((size_t)node_tot * sizeof(W2Node))) || (rc = d_edges.alloc((size_t)edge_tot * 2)) || (rc = d_tags.alloc((size_t)tag_tot * 4)) ||
+        (rc = d_info.alloc(n * sizeof(W2Info))) || (rc = d_order.alloc(n * 12)) || (rc = d_len_order.alloc(n * 4)) || (rc = d_cls.alloc(n + 16)) || (rc = d_job_cls.alloc(n + 16)) || (rc = d_handed.alloc(n + 16)) || (rc = d_seen.alloc(n * 4 + 16)) || (rc = d_blockcnt.alloc(((n + 255) / 256 + 1) * 16)) || (rc = d_sets.alloc(n * W2_SET_STRIDE * 4)) ||
+        (rc = d_score.alloc(n * 8)) || (rc = d_work.alloc(n * 8 + 16)) || (rc = d_status.alloc(n * 4)) || (rc = d_alleles.alloc(std::max<uint64_t>(allele_tot, 16))))
+        return rc;
+    uint8_t* sb = cx.stage.p;
+    const unsigned nt = [&] {
+        const char* tenv = std::getenv("HP_WFA_HOST_THREADS");
+        const unsigned want = tenv ? (unsigned)std::max(1, std::atoi(tenv)) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        return (unsigned)std::min<uint64_t>(want, std::max<uint64_t>(1, (packed + ref_bytes) >> 20));
+    }();
+    // ---- 3a. blocks: reference hulls, variants, allele pool; jobs: the device job table -----------------------------------------
+    {
+        std::atomic<size_t> next_b{0};
+        W2Variant* sv = reinterpret_cast<W2Variant*>(sb + o_vars);
+        W2Job* sj = reinterpret_cast<W2Job*>(sb + o_jobs);
+        w2_parallel(nt, [&](unsigned t, unsigned T) {
+            for (;;) {
+                const size_t b = next_b.fetch_add(1);
+                if (b >= n_in) break;
+                const BlockLay& L = bl[b];
+                if (L.lo > L.hi) continue;
+                const hp_block_input& B = in[b];
+                std::memcpy(sb + L.ref_dev, B.reference + ((uint64_t)L.lo - B.ref_base), (size_t)(L.hi - L.lo));
+                uint64_t po = L.pool_off;
+                for (int pass = 0; pass < 2; ++pass) {
+                    const hp_wfa_variant* hv = pass ? B.homs : B.hets;
+                    const uint32_t cnt = pass ? B.n_homs : B.n_hets;
+                    W2Variant* w = sv + L.var_base + (pass ? B.n_hets : 0u);
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        w[k].position = hv[k].position; w[k].ref_len = hv[k].ref_len; w[k].flags = hv[k].flags;
+                        w[k].a0_off = w[k].a0_len = 0;
+                        if (hv[k].flags & 2u) {
+                            w[k].a0_off = (uint32_t)po; w[k].a0_len = hv[k].allele0_len;
+                            if (hv[k].allele0_len) std::memcpy(sb + alt_off + po, hv[k].allele0, hv[k].allele0_len);
+                            po += hv[k].allele0_len;
+                        }
+                        w[k].a1_off = (uint32_t)po; w[k].a1_len = hv[k].allele1_len;
+                        if (hv[k].allele1_len) std::memcpy(sb + alt_off + po, hv[k].allele1, hv[k].allele1_len);
+                        po += hv[k].allele1_len;
+                    }
+                }
+            }
+            for (size_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+                const W2JobIn& ji = jin[i];
+                const hp_block_input& B = in[ji.block];
+                const hp_block_record& rec = B.records[ji.rec];
+                const BlockLay& L = bl[ji.block];
+                W2Job& d = dj[i];
+                d.ref_start = rec.min_position;
+                d.ref_len = (uint32_t)(rec.max_position + 1 - rec.min_position);
+                d.ref_off = L.ref_dev + (uint64_t)(rec.min_position - L.lo);
+                d.het_first = L.var_base + ji.het_first; d.n_hets = ji.n_hets;
+                d.hom_first = L.var_base + B.n_hets + ji.hom_first; d.n_homs = ji.n_homs;
+                sj[i] = d;
+            }
+            if (t == 0) {
+                std::memcpy(sb + o_len, len_order.data(), n * 4);
+                std::memcpy(sb + o_src, src_off.data(), n * 8);
+                std::memcpy(sb + o_fmt, fmt.data(), n);
+            }
+        });
+    }
+    if (reads_dev) HP_HIP_CHECK(hipMemcpyAsync(d_seq.p, sb, reads_dev, hipMemcpyHostToDevice, st));
+    if (n_vars) HP_HIP_CHECK(hipMemcpyAsync(d_vars.p, sb + o_vars, n_vars * sizeof(W2Variant), hipMemcpyHostToDevice, st));
+    HP_HIP_CHECK(hipMemcpyAsync(d_jobs.p, sb + o_jobs, n * sizeof(W2Job), hipMemcpyHostToDevice, st));
+    HP_HIP_CHECK(hipMemcpyAsync(d_len_order.p, sb + o_len, n * 4, hipMemcpyHostToDevice, st));
+    HP_HIP_CHECK(hipMemcpyAsync(d_src_off.p, sb + o_src, n * 8, hipMemcpyHostToDevice, st));
+    HP_HIP_CHECK(hipMemcpyAsync(d_fmt.p, sb + o_fmt, n, hipMemcpyHostToDevice, st));
+    HP_HIP_CHECK(hipMemsetAsync(reinterpret_cast<uint8_t*>(d_seq.p) + seq_bytes - 256, 0, 256, st));
+    h2d_bytes = reads_dev + n_vars * sizeof(W2Variant) + n * (sizeof(W2Job) + 13);
+    // ---- 3b. the reads, piece by piece: piece k crosses PCIe while the host threads fill piece k + 1 ----------------------------
+    {
+        const char* penv = std::getenv("HP_STAGE_PIECE_MB");
+        const uint64_t piece = (uint64_t)std::max(1, penv ? std::atoi(penv) : 48) << 20;
+        size_t j0 = 0;
+        while (j0 < n) {
+            size_t j1 = j0;
+            while (j1 < n && src_off[j1] - src_off[j0] < piece) ++j1;
+            std::atomic<size_t> next_j{j0};
+            w2_parallel(nt, [&](unsigned, unsigned) {
+                for (;;) {
+                    const size_t a = next_j.fetch_add(64);
+                    if (a >= j1) break;
+                    for (size_t i = a; i < std::min(j1, a + 64); ++i) {
+                        const hp_block_input& B = in[jin[i].block];
+                        const hp_block_record& rec = B.records[jin[i].rec];
+                        if (!rec.read_len) continue;
+                        if (B.seq_format == HP_SEQ_BAM4) {
+                            const uint32_t odd = rec.read_offset & 1u;
+                            std::memcpy(sb + o_packed + src_off[i], rec.read_align + (rec.read_offset >> 1), ((size_t)odd + rec.read_len + 1) / 2);
+                        } else std::memcpy(sb + o_packed + src_off[i], rec.read_align + rec.read_offset, rec.read_len);
+                    }
+                }
+            });
+            const uint64_t lo = src_off[j0], hi = src_off[j1];
+            HP_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(d_packed.p) + lo, sb + o_packed + lo, hi - lo, hipMemcpyHostToDevice, st));
+            h2d_bytes += hi - lo;
+            j0 = j1;
+        }
+        W2UnpackArgs U{};
+        U.jobs = d_jobs.as<W2Job>(); U.src_off = d_src_off.as<uint64_t>(); U.fmt_nib = d_fmt.as<uint8_t>(); U.n_jobs = (uint32_t)n;
+        U.packed = d_packed.as<uint8_t>(); U.seq = d_seq.as<uint8_t>();
+        hipLaunchKernelGGL(hp_wfa2_unpack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, U);
+        HP_HIP_CHECK(hipGetLastError());
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("upload failed"); return HP_ERR_HIP; }
+    const double t1 = w2_now_ms();
+    prep_ms[0] = t_lay - t0; prep_ms[1] = t1 - t_lay; prep_ms[2] = t1 - t0; prep_ms[3] = (double)h2d_bytes;
+    last_prepare_ms = t1 - t0;
+    return HP_OK;
+}
+
 int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer) {
     if (n == 0) return HP_OK;
     if (pend.on) { const int rcp = finish(); if (rcp != HP_OK) return rcp; }
@@ -359,8 +601,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     late_kernel_ms = 0.0;
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
     const int n_cu = partition_cu_count(device_id);
-    W2Context& cx = g_w2;
-    if (cx.device != device_id) { set_error("WFA session used from another thread or device than it was prepared on"); return HP_ERR_ARG; }
+    W2Context& cx = w2_context(device_id);   // (the calling thread's: need not be the thread that prepared the session)
     W2Context::Streams* cs_ = nullptr;
     { const int rc0 = cx.streams(g_cu_partition, &cs_); if (rc0 != HP_OK) return rc0; }
     hipStream_t st = cs_->stream;
@@ -403,7 +644,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, (size_t)3 * max_groups * W2_GSET_STRIDE * 4, st));   // (the capped records carry tags too)
         cx.htab_groups = max_groups; cx.tag_next = 0;
     }
-    if ((rc = cx.qhead.alloc(512)) != HP_OK) return rc;
+    if ((rc = d_qhead.alloc(512)) != HP_OK) return rc;
     if ((uint64_t)cx.tag_next + n + 2 >= 0xFFFFFFF0ull) {
         HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)3 * cx.htab_groups << W2_HCAP_LOG2) * 8, st));
         HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, (size_t)3 * cx.htab_groups * W2_GSET_STRIDE * 4, st));
@@ -413,11 +654,11 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         if (!cx.cjoin[k]) HP_HIP_CHECK(hipEventCreateWithFlags(&cx.cjoin[k], hipEventDisableTiming));
     }
     if (!cx.cfork) HP_HIP_CHECK(hipEventCreateWithFlags(&cx.cfork, hipEventDisableTiming));
-    HP_HIP_CHECK(hipMemsetAsync(cx.qhead.p, 0, 512, st));   // work-queue heads at dword 16 k, class counts at dwords 64..67
+    HP_HIP_CHECK(hipMemsetAsync(d_qhead.p, 0, 512, st));   // work-queue heads at dword 16 k, class counts at dwords 64..67
     const uint32_t tag_base = cx.tag_next;
     cx.tag_next += (uint32_t)n + 1;
-    uint32_t* d_counts = cx.qhead.as<uint32_t>() + 64;
-    uint32_t* d_esc = cx.qhead.as<uint32_t>() + 96;   // a cache line of its own
+    uint32_t* d_counts = d_qhead.as<uint32_t>() + 64;
+    uint32_t* d_esc = d_qhead.as<uint32_t>() + 96;   // a cache line of its own
     {
         HP_HIP_CHECK(hipMemsetAsync(d_sets.p, 0, n * W2_SET_STRIDE * 4, st));
         HP_HIP_CHECK(hipMemsetAsync(d_work.p, 0, n * 8, st));
@@ -475,7 +716,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         B.order = d_order.as<uint32_t>() + (size_t)k * n;
         B.n_items = cls_cnt[k];
         B.n_items_dev = d_counts + k;
-        B.next = cx.qhead.as<uint32_t>() + 16 * k;
+        B.next = d_qhead.as<uint32_t>() + 16 * k;
         B.htab = cx.htab.as<uint64_t>() + (((size_t)k * cx.htab_groups) << W2_HCAP_LOG2);
         B.gsets = cx.gsets.as<uint32_t>() + (size_t)k * cx.htab_groups * W2_GSET_STRIDE;
         B.set_stride = k == 0 ? (uint32_t)W2Cfg<2>::GROUP_DWORDS : k == 1 ? (uint32_t)W2Cfg<4>::GROUP_DWORDS : (uint32_t)W2Cfg<8>::GROUP_DWORDS;
@@ -593,11 +834,11 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
             for (size_t i = lo; i < hi; ++i) {
                 if (status[i] == W2_ST_NEED_BIG || status[i] == W2_ST_PENDING) continue;
                 if (status[i] != W2_ST_OK && status[i] != W2_ST_MAX_ED) { bad.store((int64_t)i); return; }
-                a0 += work[2 * i]; a1 += work[2 * i + 1]; a2 += jobs[i].read_len; ++a3;
+                a0 += work[2 * i]; a1 += work[2 * i + 1]; a2 += dj[i].read_len; ++a3;
                 out[i].status = status[i] == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
                 out[i].n_nodes = info[i].n_nodes;
                 out[i].score = score[i];
-                if (alleles && alleles[i] && jobs[i].n_hets) std::memcpy(alleles[i], al + dj[i].allele_off, jobs[i].n_hets);
+                if (alleles && alleles[i] && dj[i].n_hets) std::memcpy(alleles[i], al + dj[i].allele_off, dj[i].n_hets);
             }
             acc[(size_t)tid * 4] = a0; acc[(size_t)tid * 4 + 1] = a1; acc[(size_t)tid * 4 + 2] = a2; acc[(size_t)tid * 4 + 3] = a3;
         });
@@ -626,7 +867,7 @@ int W2Session::late() {
         const size_t h = pend.held.size();
         int rc;
         std::vector<uint32_t> hoff(h + 1, 0);
-        for (size_t k = 0; k < h; ++k) hoff[k + 1] = hoff[k] + jobs[pend.held[k]].n_hets;
+        for (size_t k = 0; k < h; ++k) hoff[k + 1] = hoff[k] + dj[pend.held[k]].n_hets;
         const size_t up_off = (h * 4 + 15) / 16 * 16, dn_rec = (up_off + (h + 1) * 4 + 63) / 64 * 64, dn_rows = dn_rec + h * sizeof(W2HeldRec);
         if ((rc = late_down.reserve(dn_rows + hoff[h] + 64)) != HP_OK) return rc;
         if ((rc = d_held.alloc(h * 4 + 16)) || (rc = d_hoff.alloc((h + 1) * 4 + 16)) || (rc = d_hrec.alloc(h * sizeof(W2HeldRec) + 16)) || (rc = d_hrows.alloc((size_t)hoff[h] + 16))) return rc;
@@ -660,11 +901,11 @@ int W2Session::late() {
             const int32_t sti = rec[hk].status;
             if (sti == W2_ST_NEED_BIG || sti == W2_ST_PENDING) { pend.big.push_back(i); continue; }   // (PENDING: handed over, never claimed)
             if (sti != W2_ST_OK && sti != W2_ST_MAX_ED) { set_error("job %u: device status %d", i, sti); return HP_ERR_INVARIANT; }
-            s0 += rec[hk].work_updates; s1 += rec[hk].work_bytes; s2w += jobs[i].read_len; ++s3;
+            s0 += rec[hk].work_updates; s1 += rec[hk].work_bytes; s2w += dj[i].read_len; ++s3;
             pend.dst[i].status = sti == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
             pend.dst[i].n_nodes = pend.held_nodes[hk];
             pend.dst[i].score = rec[hk].score;
-            if (pend.alleles && pend.alleles[i] && jobs[i].n_hets) std::memcpy(pend.alleles[i], rows + hoff[hk], jobs[i].n_hets);
+            if (pend.alleles && pend.alleles[i] && dj[i].n_hets) std::memcpy(pend.alleles[i], rows + hoff[hk], dj[i].n_hets);
         }
 #if W2_STATS
         {   // sizing study: how far into its alignment a job was when it was handed over (round it gave up in / final score)
@@ -684,7 +925,8 @@ int W2Session::late() {
     if (!pend.big.empty()) {
         std::sort(pend.big.begin(), pend.big.end());
         pend.sub.resize(pend.big.size()); pend.sub_out.resize(pend.big.size()); pend.sub_al.resize(pend.big.size());
-        for (size_t k = 0; k < pend.big.size(); ++k) { pend.sub[k] = jobs[pend.big[k]]; pend.sub_al[k] = pend.alleles ? pend.alleles[pend.big[k]] : nullptr; }
+        ascii_scratch.clear();
+        for (size_t k = 0; k < pend.big.size(); ++k) { pend.sub[k] = materialize(pend.big[k]); pend.sub_al[k] = pend.alleles ? pend.alleles[pend.big[k]] : nullptr; }
         const int rc = wfa_assign_batch_v1(pend.sub.data(), pend.sub.size(), pend.prune, pend.max_ed, pend.sub_out.data(), pend.alleles ? pend.sub_al.data() : nullptr, device_id);
         if (rc != HP_OK) return rc;
         late_kernel_ms += g_last_kernel_ms;
@@ -718,6 +960,8 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
 W2Session* w2_session_create() { return new W2Session(); }
 void w2_session_destroy(W2Session* s) { delete s; }
 int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id) { return s->prepare(jobs, n, device_id); }
+int w2_session_prepare_blocks(W2Session* s, const hp_block_input* in, size_t n_in, const W2JobIn* jobs, size_t n, int device_id) { return s->prepare_blocks(in, n_in, jobs, n, device_id); }
+void w2_session_prepare_stats(const W2Session* s, double prep[4]) { for (int i = 0; i < 4; ++i) prep[i] = s->prep_ms[i]; }
 int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer) { return s->run(prune_distance, max_ed, out, alleles, defer); }
 int w2_session_finish(W2Session* s) { return s->finish(); }
 // jobs whose results finish() delivers (valid until the next run)

@@ -969,3 +969,62 @@ __global__ void __launch_bounds__(64) hp_wfa2_map_held_kernel(W2MapHeldArgs A) {
 }
 
 }  // namespace hp
+
+namespace hp {
+
+// ---- read bases into the layout the alignment kernels read: one wavefront per read -----------------------------------
+// The host stages every read as the caller holds it (HP_SEQ_ASCII bytes, or the BAM record's 4-bit codes, HP_SEQ_BAM4:
+// half the bytes across PCIe and no decode on the host); this kernel writes one byte per base at the job's read_off,
+// decoding 4-bit codes with htslib's table "=ACMGRSVTWYHKDBN" (what read.seq().as_bytes() yields, read_parsing.rs:738).
+// A lane expands 8 source bytes to 16 bases per iteration; a read's first base may sit in a low nibble (odd read_offset).
+struct W2UnpackArgs {
+    const W2Job* jobs;
+    const uint64_t* src_off;    // [n_jobs] byte offset in `packed` of the byte that holds the read's first base
+    const uint8_t* fmt_nib;     // [n_jobs] seq_format | first base in the low nibble << 4
+    uint32_t n_jobs;
+    const uint8_t* packed;
+    uint8_t* seq;
+};
+__global__ void __launch_bounds__(256) hp_wfa2_unpack_kernel(W2UnpackArgs A) {
+    __shared__ uint16_t lut[256];   // source byte -> two bases (first base = high nibble = low byte of the pair)
+    {
+        const char* tab = "=ACMGRSVTWYHKDBN";
+        const uint32_t t = threadIdx.x;
+        lut[t] = (uint16_t)((uint32_t)(uint8_t)tab[t >> 4] | ((uint32_t)(uint8_t)tab[t & 15u] << 8));
+    }
+    __syncthreads();
+    const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (j >= A.n_jobs) return;
+    const W2Job J = A.jobs[j];
+    const uint8_t* src = A.packed + A.src_off[j];
+    uint8_t* dst = A.seq + J.read_off;
+    const uint32_t fm = A.fmt_nib[j], len = J.read_len;
+    if ((fm & 15u) == HP_SEQ_ASCII) {
+        for (uint32_t o = lane * 16u; o < len; o += 64u * 16u) {   // (source and destination slots are both padded to 16 bytes)
+            uint4 v; __builtin_memcpy(&v, src + o, 16);
+            *reinterpret_cast<uint4*>(dst + o) = v;
+        }
+        return;
+    }
+    const uint32_t odd = fm >> 4;
+    for (uint32_t o = lane * 16u; o < len; o += 64u * 16u) {
+        uint64_t lo, hi;
+        __builtin_memcpy(&lo, src + (o >> 1), 8);
+        __builtin_memcpy(&hi, src + (o >> 1) + 8, 8);
+        // odd: the first base is the low nibble of byte 0: drop a nibble - within each byte the high nibble comes first, so base
+        // k pairs with base k + 1 of the NEXT byte's high nibble: byte' = (byte << 4) | (next byte >> 4)
+        if (odd) {
+            const uint64_t nx = (lo >> 8) | (hi << 56);
+            lo = ((lo << 4) & 0xF0F0F0F0F0F0F0F0ull) | ((nx >> 4) & 0x0F0F0F0F0F0F0F0Full);
+        }
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t b0 = (uint32_t)(lo >> (16 * k)) & 0xFFu, b1 = (uint32_t)(lo >> (16 * k + 8)) & 0xFFu;
+            w[k] = (uint32_t)lut[b0] | ((uint32_t)lut[b1] << 16);
+        }
+        *reinterpret_cast<uint4*>(dst + o) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+}  // namespace hp

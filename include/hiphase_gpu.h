@@ -38,6 +38,15 @@ extern "C" {
 #define HP_ERR_ARG           -4   /* malformed view (row_off not monotone, N==0, ...) */
 #define HP_ERR_UNSUPPORTED   -5   /* outside the packed-key limits documented in DESIGN.md */
 
+/* ---- read sequence encodings ---------------------------------------------------------------------------------------
+ * HP_SEQ_ASCII: one byte per base, what `read.seq().as_bytes()` returns (read_parsing.rs:738).
+ * HP_SEQ_BAM4:  the BAM record's own 4-bit encoding, what rust-htslib's `read.seq().encoded` points at: base k sits in byte
+ *               k / 2, the HIGH nibble for even k, code -> base "=ACMGRSVTWYHKDBN". The caller hands the record's bytes over as
+ *               they are (no decode on the host, half the bytes across PCIe); the library expands them on the device with exactly
+ *               that table, so every comparison sees the bytes `as_bytes()` would have produced. */
+#define HP_SEQ_ASCII 0
+#define HP_SEQ_BAM4  1
+
 /* ---- AlleleType (src/data_types/read_segments.rs:5-16) ----------------------------------- */
 #define HP_ALLELE_REFERENCE 0
 #define HP_ALLELE_ALTERNATE 1
@@ -219,9 +228,11 @@ typedef struct hp_local_read {           /* what local_realignment reads from a 
     int64_t         pos;                 /* read.pos() */
     const uint32_t* cigar;               /* BAM encoding: op_len << 4 | op (MIDNSHP=X = 0..8) */
     uint32_t        n_cigar;
-    uint32_t        seq_len;
-    const uint8_t*  seq;                 /* read.seq().as_bytes() (ASCII) */
+    uint32_t        seq_len;             /* bases */
+    const uint8_t*  seq;                 /* HP_SEQ_ASCII: read.seq().as_bytes(); HP_SEQ_BAM4: read.seq().encoded (base k in nibble k) */
     const uint8_t*  qual;                /* read.qual() */
+    uint32_t        seq_format;          /* HP_SEQ_* */
+    uint32_t        reserved;
 } hp_local_read;
 
 #define HP_N_VARIANT_TYPES 11            /* VariantType::Unknown as usize + 1 */
@@ -254,11 +265,15 @@ int hp_local_realign_batch(const hp_local_read* reads, size_t n_reads, const hp_
 typedef struct hp_block_record {          /* one BAM record that passed filter_out_alignment_record (read_parsing.rs:551) */
     int64_t              min_position;    /* first / last reference base of the alignment, inclusive (read_parsing.rs:672-685) */
     int64_t              max_position;
-    const uint8_t*       read_align;      /* seq[read_start ..= read_end] (read_parsing.rs:738-742) */
-    uint32_t             read_len;
+    const uint8_t*       read_align;      /* seq[read_start ..= read_end] (read_parsing.rs:738-742): base k of it is base
+                                             read_offset + k of this buffer, in the block's seq_format (HP_SEQ_BAM4: pass
+                                             read.seq().encoded and read_offset = read_start) */
+    uint32_t             read_len;        /* bases */
     uint32_t             qname_id;        /* records of one read name share an id: 0 .. n_qnames-1 */
     const hp_local_read* local;           /* CIGAR view of the record for local re-alignment: needed in local mode and when the
                                              record falls back (read_parsing.rs:556-575); NULL makes such a fallback an HP_ERR_ARG */
+    uint32_t             read_offset;     /* bases to skip at read_align (0 for a buffer that starts at read_start) */
+    uint32_t             reserved;
 } hp_block_record;
 
 typedef struct hp_block_input {
@@ -272,6 +287,8 @@ typedef struct hp_block_input {
                                              can fall back (then a fallback is an HP_ERR_ARG) */
     const hp_wfa_variant*   homs;         /* hom_calls [n_homs] */
     const hp_block_record*  records;      /* in BAM order: the fallback switch depends on it (read_parsing.rs:597-600) */
+    uint32_t                seq_format;   /* HP_SEQ_* of every records[i].read_align of this block */
+    uint32_t                reserved;
 } hp_block_input;
 
 typedef struct hp_block_params {
@@ -319,7 +336,7 @@ int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const hp_block_pa
 
 /* Resident form: hp_blockset_create lays the blocks' sequences out and uploads them (the caller's buffers must stay
  * valid until hp_blockset_destroy); hp_blockset_solve runs the whole path on the resident data and may be called
- * repeatedly (what bench.py times). stage_ms (may be NULL) receives 8 numbers in ms: [0] graph-WFA stage wall time
+ * repeatedly, from any thread (bench.py's secondary, inputs-in-HBM figure). stage_ms (may be NULL) receives 8 numbers in ms: [0] graph-WFA stage wall time
  * (device graph build + alignment + allele rows + download), [1] fallback / replay / row assembly (host), [2] A* pack +
  * upload, [3] A* solve, [4] post-processing, [5] total, [6] graph-WFA kernels (HIP events), [7] A* kernel (HIP events). */
 typedef struct hp_blockset hp_blockset;
@@ -330,6 +347,22 @@ int  hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* stage_ms);
  * diagonal) wave updates; [4] A* cells, [5] A* read evaluations; [6] hets, [7] solver rows. */
 int  hp_blockset_work(const hp_blockset* bs, uint64_t out[8]);
 void hp_blockset_destroy(hp_blockset* bs);
+
+/* Pipelined form: HiPhase sees every block once (src/main.rs:337-408; src/phaser.rs:513-543 loads a block's reads, then solves it),
+ * so a caller that hands over one block set after the other wants set k + 2 laid out and crossing PCIe while set k + 1 is aligned
+ * and set k is solved. hp_blockstream_submit queues a set and returns its ticket at once (it blocks only while `depth` sets are in
+ * flight: the back-pressure of the reference's bounded job queue, main.rs:362-383); hp_blockstream_wait returns when that set's
+ * results are in its `out` array. Sets complete in submission order; results are identical to hp_solve_blocks on the same set.
+ * `in`, everything it points at, and `out` must stay valid until the wait for that ticket returns. Submit and wait may be called
+ * from different threads. depth: 0 = 4. stage_ms (16 doubles, may be NULL): [0] overlaps + layout (host), [1] staging copy + PCIe
+ * + base expansion, [2] graph-WFA stage, [3] fallback / replay / rows (host), [4] A* pack + upload, [5] A* solve, [6] post-processing
+ * + outputs, [7] latency submit -> done, [8] graph-WFA kernels (HIP events), [9] A* kernels (HIP events), [10] bytes host -> device,
+ * [11] time spent waiting between stages, [12..14] wall time of stage 1 / 2 / 3. work (8 values, may be NULL): as hp_blockset_work. */
+typedef struct hp_blockstream hp_blockstream;
+hp_blockstream* hp_blockstream_create(const hp_block_params* p, int device_id, uint32_t depth, int* status);
+int  hp_blockstream_submit(hp_blockstream* s, size_t n_blocks, const hp_block_input* in, hp_block_output* out, uint64_t* ticket);
+int  hp_blockstream_wait(hp_blockstream* s, uint64_t ticket, double* stage_ms, uint64_t* work);
+void hp_blockstream_destroy(hp_blockstream* s);   /* finishes the sets still in flight first */
 
 /* ---- misc --------------------------------------------------------------------------------- */
 int         hp_device_count(void);

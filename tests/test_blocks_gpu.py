@@ -213,30 +213,125 @@ def test_block_set_with_large_graphs_hand_over_and_two_phases(monkeypatch):
         bs.close()
 
 
+def same_result(a, b):
+    return (np.array_equal(a.haplotype_1, b.haplotype_1) and np.array_equal(a.haplotype_2, b.haplotype_2) and a.statistics == b.statistics
+            and a.segments == b.segments and a.haplotags == b.haplotags and a.span_counts.tolist() == b.span_counts.tolist()
+            and a.edit_distances == b.edit_distances and (a.num_reads, a.skipped_reads, a.global_aligned, a.local_aligned) ==
+            (b.num_reads, b.skipped_reads, b.global_aligned, b.local_aligned) and a.status == b.status)
+
+
+def test_block_entry_bam4_reads_equal_ascii(wfa_path):
+    """HP_SEQ_BAM4: the records' bases handed over in the BAM's own 4-bit encoding (even and odd read_offset), expanded on the
+    device (compact path) or decoded on the host (dense-band path) - same results as the ASCII hand-over, which is held to the
+    oracle above. Includes forced MaxEditDistance fallbacks, whose local re-alignment reads the 4-bit record too."""
+    from hiphase_amd import _ffi
+    specs = []
+    for seed in (31, 32, 33):
+        ref, hets, homs, records, _ = make_block(seed, ref_len=25000, n_hets=30, n_homs=6, n_reads=60)
+        specs.append(BlockSpec(seed, ref, hets, homs, records))
+    a = solve_blocks(specs)
+    b = solve_blocks(specs, seq_format=_ffi.SEQ_BAM4)
+    assert all(same_result(x, y) for x, y in zip(a, b))
+    ref, variants, truth, lrecs = make_local_block(21, ref_len=20000, n_vars=100, n_reads=120, read_len=(800, 3000), noise=0.004)
+    hets = [v for v in variants if int(v.variant_type) in (0, 1, 2, 3)]
+    records = [to_aligned(r) for r in lrecs if any(op in "M=X" for op, _ in r.cigar)]
+    cfg = GlobalRealignmentConfig(max_edit_distance=4, wfa_prune_distance=4, global_failure_minimum=5, global_failure_ratio=0.3)
+    a, = solve_blocks([BlockSpec(1, ref, hets, [], records)], config=cfg)
+    b, = solve_blocks([BlockSpec(1, ref, hets, [], records)], config=cfg, seq_format=_ffi.SEQ_BAM4)
+    assert a.local_aligned > 0 and same_result(a, b)
+
+
+def test_block_entry_bam4_local_mode():
+    from hiphase_amd import _ffi
+    ref, variants, truth, records = make_local_block(11, ref_len=20000, n_vars=120, n_reads=200, read_len=(1500, 6000))
+    a, = solve_blocks([BlockSpec(3, ref, variants, [], records)], global_realignment=False)
+    b, = solve_blocks([BlockSpec(3, ref, variants, [], records)], global_realignment=False, seq_format=_ffi.SEQ_BAM4)
+    assert same_result(a, b)
+
+
 @pytest.mark.timeout(900)
-def test_block_set_in_two_overlapped_chunks(monkeypatch):
-    """HP_BLOCK_PIPELINE=1: the largest blocks form a first chunk whose rows + A* + post run on a helper thread (on compute
-    units of their own) while the second chunk's reads go through graph-WFA. Same results as the oracle's whole path."""
-    import sys, os
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
+@pytest.mark.parametrize("fmt", ["ascii", "bam4"])
+def test_blockstream_equals_one_shot_entry(fmt, monkeypatch):
+    """hp_blockstream_*: seven block sets in flight three deep (layout + PCIe of one, graph-WFA of another, rows + A* + post of
+    a third at the same time), through the compact kernels; every set's results equal hp_solve_blocks on that set, in order.
+    Set 3 is too small for the compact path (latency path inside the pipeline), set 5 is empty."""
+    from hiphase_amd import _ffi
+    from hiphase_amd.blocks import BlockStream
     from hiphase_amd.synth_reads import synth_read_block
-    monkeypatch.setenv("HP_BLOCK_PIPELINE", "1")
-    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "16")
-    specs = [synth_read_block(5200 + i, 14 + 9 * (i % 5), block_index=i, coverage=12.0)[0] for i in range(12)]
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "64")
+    seq_format = _ffi.SEQ_BAM4 if fmt == "bam4" else _ffi.SEQ_ASCII
     cfg = GlobalRealignmentConfig()
-    d = oracle()
-    bs = BlockSet(specs, config=cfg)
+    sets = []
+    for k in range(7):
+        nb = [5, 3, 6, 1, 4, 0, 5][k]
+        sets.append([synth_read_block(7000 + 10 * k + i, 10 + 7 * ((i + k) % 4), block_index=i, coverage=(3.0 if k == 3 else 14.0))[0] for i in range(nb)])
+    expect = [solve_blocks(s, config=cfg, device_id=0) if s else [] for s in sets]
+    st = BlockStream(config=cfg, device_id=0, depth=3, seq_format=seq_format)
     try:
-        for _ in range(2):
-            bs.solve()
-            for spec, r in zip(specs, bs.results()):
-                segs, h1, h2, stt, spans = bench.oracle_block(spec, cfg, d)
-                assert [(q, a, b, al, ql) for (q, a, b, al, ql, so) in r.segments if so] == segs
-                assert (r.haplotype_1 == h1).all() and (r.haplotype_2 == h2).all() and r.statistics == stt
-                assert r.span_counts.tolist() == spans
+        for rep in range(2):
+            tickets = [st.submit(s) for s in sets[:3]]
+            for k in range(3, len(sets)):
+                res, ms, work = st.wait(tickets[k - 3])
+                assert len(ms) == 16 and ms[7] > 0
+                assert all(same_result(x, y) for x, y in zip(res, expect[k - 3])) and len(res) == len(expect[k - 3])
+                tickets.append(st.submit(sets[k]))
+            for k in range(len(sets) - 3, len(sets)):
+                res, ms, work = st.wait(tickets[k])
+                assert all(same_result(x, y) for x, y in zip(res, expect[k])) and len(res) == len(expect[k])
     finally:
-        bs.close()
+        st.close()
+
+
+def test_blockstream_reports_a_failed_set_and_goes_on():
+    """a malformed set (a record whose alignment ends before it starts) fails ITS wait with the reference's assert
+    (read_parsing.rs:685) - the sets around it are solved"""
+    from hiphase_amd._ffi import HpError
+    from hiphase_amd.blocks import BlockStream
+    from hiphase_amd.synth_reads import synth_read_block
+    good = [synth_read_block(7300 + i, 12, block_index=i, coverage=8.0)[0] for i in range(3)]
+    bad = [synth_read_block(7400, 12, coverage=8.0)[0]]
+    bad[0].records[2].max_position = bad[0].records[2].min_position - 5
+    expect = solve_blocks(good, device_id=0)
+    st = BlockStream(device_id=0, depth=2)
+    try:
+        t1, t2 = st.submit(good), st.submit(bad)
+        r1, _, _ = st.wait(t1)
+        t3 = st.submit(good)
+        with pytest.raises(HpError):
+            st.wait(t2)
+        r3, _, _ = st.wait(t3)
+        assert all(same_result(x, y) for x, y in zip(r1, expect)) and all(same_result(x, y) for x, y in zip(r3, expect))
+    finally:
+        st.close()
+
+
+def test_unsupported_block_is_soft_alone_together_and_on_the_queue(monkeypatch):
+    """HP_BLOCK_UNSUPPORTED: a block outside the device solver's packed-key limits comes back with the soft status (segments
+    filled, haplotypes untouched) whether it is submitted alone, with other blocks, or through the multi-device queue - and the
+    other blocks are solved. HP_TEST_UNSUPPORTED_N makes the A* pack treat blocks of that many hets as beyond the limits."""
+    specs = []
+    for seed in (41, 42, 43, 44):
+        ref, hets, homs, records, _ = make_block(seed, ref_len=20000, n_hets=20 + seed % 3, n_homs=4, n_reads=40)
+        specs.append(BlockSpec(seed, ref, hets, homs, records))
+    normal = solve_blocks(specs, device_id=0)
+    victim = 2
+    monkeypatch.setenv("HP_TEST_UNSUPPORTED_N", str(len(specs[victim].variant_calls)))
+    assert len({len(s.variant_calls) for s in specs}) > 1 and sum(len(s.variant_calls) == len(specs[victim].variant_calls) for s in specs) >= 1
+    flagged = [len(s.variant_calls) == len(specs[victim].variant_calls) for s in specs]
+    alone, = solve_blocks([specs[victim]], device_id=0)
+    assert alone.status == 2 and alone.segments == normal[victim].segments and not alone.haplotype_1.any() and alone.haplotags == {}
+    together = solve_blocks(specs, device_id=0)
+    monkeypatch.setenv("HP_QUEUE_WORKERS", "3")
+    queued = solve_blocks(specs, device_id=-1)
+    for res in (together, queued):
+        for r, n, f in zip(res, normal, flagged):
+            if f:
+                assert r.status == 2 and r.segments == n.segments and not r.haplotype_1.any()
+            else:
+                assert same_result(r, n)
+    # parameters the device solver cannot hold are a property of the call: every block is handed back
+    allb = solve_blocks(specs[:2], device_id=0, min_queue_size=10 ** 9)
+    assert [r.status for r in allb] == [2, 2]
 
 
 def test_block_sets_from_several_host_threads(monkeypatch):
