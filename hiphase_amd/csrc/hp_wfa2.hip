@@ -476,7 +476,7 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
                    o_src = a64(o_len + n * 4), o_fmt = a64(o_src + n * 8), o_packed = a64(o_fmt + n);
     if ((rc = cx.stage.reserve(o_packed + packed + 64)) != HP_OK) return rc;
     if ((rc = d_seq.alloc(seq_bytes)) || (rc = d_packed.alloc(packed + 64)) || (rc = d_src_off.alloc(n * 8)) || (rc = d_fmt.alloc(n + 16)) ||
-        (rc = d_vars.alloc(std::max<size_t>(1, vars.size()) * sizeof(W2Variant))) || (rc = d_jobs.alloc(n * sizeof(W2Job))) ||
+        (rc = d_vars.alloc(std::max<size_t>(1, (size_t)n_vars) * sizeof(W2Variant))) || (rc = d_jobs.alloc(n * sizeof(W2Job))) ||
         (rc = d_nodes.alloc((size_t)node_tot * sizeof(W2Node))) || (rc = d_edges.alloc((size_t)edge_tot * 2)) || (rc = d_tags.alloc((size_t)tag_tot * 4)) ||
         (rc = d_info.alloc(n * sizeof(W2Info))) || (rc = d_order.alloc(n * 12)) || (rc = d_len_order.alloc(n * 4)) || (rc = d_cls.alloc(n + 16)) || (rc = d_job_cls.alloc(n + 16)) || (rc = d_handed.alloc(n + 16)) || (rc = d_seen.alloc(n * 4 + 16)) || (rc = d_blockcnt.alloc(((n + 255) / 256 + 1) * 16)) || (rc = d_sets.alloc(n * W2_SET_STRIDE * 4)) ||
         (rc = d_score.alloc(n * 8)) || (rc = d_work.alloc(n * 8 + 16)) || (rc = d_status.alloc(n * 4)) || (rc = d_alleles.alloc(std::max<uint64_t>(allele_tot, 16))))

@@ -100,6 +100,12 @@ int        hpo_graph_edit_distance(const hpo_graph* g, const uint8_t* other, siz
 int        hpo_wfa_assign(const hp_wfa_job* job, uint64_t prune_distance, uint64_t max_ed,
                           hp_wfa_result* out, uint8_t* alleles);
 
+/* ---- the whole path for one block (hp_oracle_block.cpp): phaser::solve_block from the decoded records on ------------
+ * (phaser.rs:513-630 = load_full_read_segments / load_read_segments, astar_solver, get_solution_span_counts, haplotag_reads).
+ * Same structs in and out as the product's hp_solve_blocks; segments in first-seen read-name order. PARITY UNPINNED upstream
+ * (no read-bearing fixture exists): assembled from the pinned pieces above in the reference's statement order. */
+int hpo_solve_block(const hp_block_input* block, const hp_block_params* params, hp_block_output* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,8 @@ def oracle():
                                           C.c_void_p, C.POINTER(C.c_size_t)]
     d.hpo_wfa_assign.restype = C.c_int
     d.hpo_wfa_assign.argtypes = [C.POINTER(_ffi.WfaJob), C.c_uint64, C.c_uint64, C.POINTER(_ffi.WfaResult), C.c_void_p]
+    d.hpo_solve_block.restype = C.c_int
+    d.hpo_solve_block.argtypes = [C.POINTER(_ffi.BlockInput), C.POINTER(_ffi.BlockParams), C.POINTER(_ffi.BlockOutput)]
     _lib = d
     return d
 
@@ -111,6 +113,22 @@ def oracle_solve(block, min_queue_size=1000, queue_increment=3, max_segment_size
     if want_heuristics:
         return h1, h2, st.as_tuple(), ctr.as_tuple(), heur
     return h1, h2, st.as_tuple(), ctr.as_tuple()
+
+
+def oracle_solve_blocks(blocks, min_matched_alleles=2, min_queue_size=1000, queue_increment=3, config=None, global_realignment=True,
+                        seq_format=_ffi.SEQ_ASCII):
+    """The whole path on the CPU oracle (hpo_solve_block, one block at a time) for a list of hiphase_amd.blocks.BlockSpec,
+    marshalled exactly as hiphase_amd.blocks.solve_blocks marshals them -> [BlockResult]."""
+    from hiphase_amd import blocks as B
+    d = oracle()
+    m = B._Marshalled(blocks, need_local=not global_realignment, seq_format=seq_format)
+    o = B._Outputs(m)
+    p = B._params(min_matched_alleles, min_queue_size, queue_increment, config, global_realignment)
+    for b in range(m.n):
+        rc = d.hpo_solve_block(C.byref(m.inputs[b]), C.byref(p), C.byref(o.arr[b]))
+        if rc != 0:
+            raise _ffi.HpError(rc, f"oracle hpo_solve_block, block {b}")
+    return o.results(m)
 
 
 def oracle_synth(n_variants, coverage, span, error_rate, ambig_rate, seed, ignored_permille=0):
