@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — het variants phased / sec (BASELINE.json metric) through the WHOLE hot path on one MI355X per rank.
 
-Default workload "path": a synthetic read-bearing WGS-like block mix (hiphase_amd/synth_reads.py: heavy-tailed block
-sizes, HiFi-like 15-kb reads at 30x, het + hom small variants). One "step" = one hp_blockset_solve over the resident
-blocks: records -> graph-WFA (device graph build, alignment, allele rows) -> fallback / collapse -> A* -> span counts
-and haplotags; `value` = hets / wall time of the step, inputs already in HBM. Per-kernel rooflines in `kernels`.
+Default workload "path": synthetic read-bearing WGS-like block sets (hiphase_amd/csrc/hp_synth_reads.cpp: heavy-tailed block
+sizes up to 4 165 hets, HiFi-like 15-kb reads at 30x with edit noise, a noisy tail that falls back to local re-alignment,
+supplementary records, SNV / indel / SV / tandem-repeat calls, het + hom), STREAMED: one "step" = one NEW block set through
+hp_blockstream_* (layout + PCIe of one set, graph-WFA of another and rows / A* / post-processing of a third overlap), its
+bytes crossing PCIe inside the timed region; `value` = hets of all timed steps / wall time. `resident` is the secondary
+inputs-already-in-HBM figure. Per-kernel rooflines in `kernels`, the CPU restatement on one and on all host cores beside it.
 
 `--workload c2` is the solver-only figure of round 1 (BASELINE.json configs[1] shape: resident read x variant
 matrices, N=5000, C=30, S=20), `--workload wgs` the solver on a heavy-tailed block-size mix.
@@ -159,9 +161,9 @@ def so_sha256():
 
 def measured_traffic(kernel, per_unit_key, units):
     """HBM bytes per launch from the PMC counters: only a measurement taken on THIS build of the library counts
-    (profiles/round2/traffic.json records the sha256 of the .so it was measured on); otherwise null."""
+    (profiles/round3/traffic.json records the sha256 of the .so it was measured on); otherwise null."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "round2", "traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "round3", "traffic.json")))
         e = tj[kernel]
         if e["so_sha256"] != so_sha256():
             return None, "stale: measured on another build of libhiphase_gpu.so"
@@ -170,68 +172,87 @@ def measured_traffic(kernel, per_unit_key, units):
         return None, None
 
 
-def oracle_block(spec, cfg, d):
-    """The whole path for one block on the CPU oracle, record by record in the reference's order (read_parsing.rs:545-629
-    without fallbacks - the synthetic reads never reach max_edit_distance - then astar_solver and the post-processing).
-    Returns what the parity check compares: solver segments, haplotypes, stats, span counts."""
+def block_params(cfg=None):
+    from hiphase_amd.blocks import _params
+    return _params(2, 1000, 3, cfg, True)
+
+
+def cpu_whole_path(sset, oracle_out, prm, seconds, threads, order):
+    """hpo_solve_block (the C++ restatement of the reference's whole path) over blocks of `sset` in `order` on `threads`
+    host threads (independent blocks on independent threads, as the reference's own worker pool runs them, main.rs:385;
+    ctypes releases the GIL for each call) until `seconds` are spent or the blocks run out. -> (hets, records, blocks done, s)"""
     import ctypes as C
-    import numpy as np
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi
-    from hiphase_amd import _ffi
-    from hiphase_amd.read_segments import BlockMatrix, ReadSegment
-    from hiphase_amd.wfa_graph import BASE_QUAL, VariantType, WfaJobSpec, make_jobs
-    hets, homs, n = spec.variant_calls, spec.hom_calls, len(spec.variant_calls)
-    pos = [v.position for v in hets]
-    hpos = [v.position for v in homs]
-    import bisect
-    groups = {}
-    for rec in spec.records:
-        first, last = bisect.bisect_left(pos, rec.min_position), bisect.bisect_right(pos, rec.max_position)
-        if last <= first:
-            continue
-        hf, hl = bisect.bisect_left(hpos, rec.min_position), bisect.bisect_right(hpos, rec.max_position)
-        jobs, keep = make_jobs([WfaJobSpec(spec.reference, rec.min_position, rec.max_position + 1, hets[first:last], homs[hf:hl], rec.read_align)])
-        out = _ffi.WfaResult()
-        al = np.full(max(1, last - first), 3, np.uint8)
-        assert d.hpo_wfa_assign(C.byref(jobs[0]), cfg.wfa_prune_distance, cfg.max_edit_distance, C.byref(out), al.ctypes.data) == 0
-        assert out.status == 0
-        alleles, quals = [3] * n, [0] * n
-        for k, i in enumerate(range(first, last)):
-            alleles[i] = int(al[k])
-            if alleles[i] < 2:
-                quals[i] = 2 * BASE_QUAL[VariantType(hets[i].variant_type)]
-        groups.setdefault(rec.qname, []).append(ReadSegment(rec.qname, alleles, quals))
-    segs = []
-    for q, grp in groups.items():
-        col = ReadSegment.collapse(grp)
-        if col.get_num_set() >= 2:
-            segs.append(col)
-    flags = np.asarray([2 if v.variant_type == VariantType.Snv else 0 for v in hets], np.uint8)
-    om = BlockMatrix.from_segments(segs, n, flags)
-    h1, h2, st, _ = oracle_ffi.oracle_solve(om)
-    spans = np.zeros(max(n - 1, 1), np.uint64)
-    v = om.view()
-    assert d.hpo_solution_span_counts(C.byref(v), h1.ctypes.data, h2.ctypes.data, spans.ctypes.data) == 0
-    return [(s_.read_name, s_.start, s_.end, list(s_.alleles), list(s_.quals)) for s_ in segs], h1, h2, st, spans[:n - 1].tolist()
+    d = oracle_ffi.oracle()
+    lock = threading.Lock()
+    state = {"next": 0, "hets": 0, "records": 0, "done": [], "err": None}
+    t0 = time.perf_counter()
+
+    def work():
+        while True:
+            with lock:
+                k = state["next"]
+                if k >= len(order) or time.perf_counter() - t0 > seconds or state["err"]:
+                    return
+                state["next"] = k + 1
+            b = order[k]
+            rc = d.hpo_solve_block(C.byref(sset.inputs[b]), C.byref(prm), C.byref(oracle_out.arr[b]))
+            with lock:
+                if rc != 0:
+                    state["err"] = (b, rc)
+                    return
+                state["hets"] += sset.inputs[b].n_hets
+                state["records"] += sset.inputs[b].n_records
+                state["done"].append(b)
+
+    th = [threading.Thread(target=work) for _ in range(max(1, threads))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    if state["err"]:
+        raise RuntimeError(f"oracle hpo_solve_block failed on block {state['err'][0]}: {state['err'][1]}")
+    return state["hets"], state["records"], state["done"], time.perf_counter() - t0
+
+
+def host_cores():
+    """Hardware threads this process may use (affinity mask, clipped by a cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def main_path(args, rank, world, local_rank, dist, backend):
-    """Whole-path workload: value = hets / wall time of hp_blockset_solve over resident blocks."""
+    """Whole-path workload, streamed: every timed step submits a DIFFERENT block set to hp_blockstream_submit - its reads,
+    references and variants cross PCIe inside the timed region - and `value` = hets of all steps / wall time from the first
+    submit to the last result. The sets are generated (C generator, C layout) before the clock starts."""
+    import ctypes as C
     import numpy as np
     from hiphase_amd import _ffi
-    from hiphase_amd.blocks import BlockSet
-    from hiphase_amd.read_parsing import GlobalRealignmentConfig
-    from hiphase_amd.synth_reads import synth_wgs_like_mix
+    from hiphase_amd.synth_sets import SynthSet, default_spec
+    lib = _ffi.lib()
+    fmt = _ffi.SEQ_BAM4 if args.seq_format == "bam4" else _ffi.SEQ_ASCII
+    n_sets = max(1, min(args.steps + args.warmup, args.distinct_sets))
+    gen_threads = max(2, min(32, host_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     t_gen = time.perf_counter()
-    blocks = synth_wgs_like_mix(args.seed + rank, args.total_hets, max_hets=args.max_block_hets, coverage=float(args.coverage))
+    sets = []
+    for k in range(n_sets):   # rank r, set k: seed + 1000 r + k (disjoint over ranks and steps)
+        sets.append(SynthSet(default_spec(lib, seed=args.seed + 1000 * rank + k, total_hets=args.total_hets, max_block_hets=args.max_block_hets,
+                                          coverage=float(args.coverage), seq_format=fmt, threads=gen_threads)))
+    outs = [s.outputs() for s in sets]
     t_gen = time.perf_counter() - t_gen
-    hets_per_step = sum(len(b.variant_calls) for b in blocks)
-    n_reads = sum(len(b.records) for b in blocks)
-    read_bases = sum(len(r.read_align) for b in blocks for r in b.records)
-    cfg = GlobalRealignmentConfig()
-    t_up = time.perf_counter()
-    bs = BlockSet(blocks, config=cfg, device_id=local_rank)   # layout + upload: sequences resident in HBM from here on
-    t_up = time.perf_counter() - t_up
+    prm = block_params()
+    st = C.c_int(0)
+    stream = lib.hp_blockstream_create(C.byref(prm), local_rank, args.depth, C.byref(st))
+    if not stream:
+        raise SystemExit(f"hp_blockstream_create failed: {st.value} {lib.hp_last_error().decode()}")
 
     def sync_all():
         if dist is not None:
@@ -239,86 +260,136 @@ def main_path(args, rank, world, local_rank, dist, backend):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        bs.solve()
+    def run(first, count):
+        """submits sets first .. first + count - 1 (cycling over the generated ones), at most `depth` in flight; -> per-set stage_ms, work"""
+        pending, stages, works = [], [], []
+        ms, work = (C.c_double * 16)(), (C.c_uint64 * 8)()
+
+        def wait_oldest():
+            _ffi.check(lib.hp_blockstream_wait(stream, pending.pop(0), ms, work))
+            stages.append(list(ms))
+            works.append(list(work))
+
+        for k in range(first, first + count):
+            if len(pending) >= args.depth:
+                wait_oldest()
+            i = k % n_sets
+            t = C.c_uint64(0)
+            _ffi.check(lib.hp_blockstream_submit(stream, sets[i].n, sets[i].inputs, outs[i].arr, C.byref(t)))
+            pending.append(t.value)
+        while pending:
+            wait_oldest()
+        return stages, works
+
+    run(0, args.warmup)
     sync_all()
     t0 = time.perf_counter()
-    stages = []
-    for _ in range(args.steps):
-        stages.append(bs.solve())          # hp_blockset_solve waits for every stream it uses before it returns
+    stages, works = run(args.warmup, args.steps)      # every wait returns with that set's results in the caller's buffers
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         from hiphase_amd.shard import max_over_ranks
         elapsed = max_over_ranks(dist, elapsed, device="cuda" if backend == "nccl" else "cpu")   # timing only; no block data crosses ranks
-    out = None
+    hets_timed = sum(sets[k % n_sets].info["hets"] for k in range(args.warmup, args.warmup + args.steps))
     if rank == 0:
-        st = np.mean(np.asarray(stages), axis=0)
-        work = bs.work()
-        res = bs.results()
-        # graph-WFA kernels: algorithmic bytes = read bases + bytes of the traversed graph nodes + 8 B per (node, diagonal)
-        # wave update, counted on the device for the reads the compact kernel aligned
+        st_mean = np.mean(np.asarray(stages), axis=0)
+        work = dict(zip(("wfa_reads", "wfa_read_bytes", "wfa_node_bytes", "wfa_updates", "astar_cells", "astar_evals", "hets", "rows"),
+                        np.mean(np.asarray(works, dtype=np.float64), axis=0)))
+        info = sets[args.warmup % n_sets].info
+        k_wfa_ms, k_astar_ms = st_mean[8], st_mean[9]
+        # graph-WFA kernels: algorithmic bytes = read bases + bytes of the traversed graph nodes + 8 B per (node, diagonal) wave update
+        # (SURVEY.md 8d), counted on the device for the reads the compact kernels aligned. kernel_ms: the three graph-size
+        # instantiations run concurrently on three streams; HIP events around the launch set give their span per set
         b_wfa = work["wfa_read_bytes"] + work["wfa_node_bytes"] + 8 * work["wfa_updates"]
         b_astar = BYTES_PER_CELL * work["astar_cells"]
-        # kernel_ms: the three graph-size instantiations run concurrently on three streams; HIP events around the launch set give
-        # their span (the <16,8> instantiation stays resident until the other two are gone, so its rocprof duration is that span)
-        k_wfa = {"kernel": "hp::hp_wfa2_kernel<8,2> + <8,4> + <16,8> (concurrent; span of the launch set)", "bound": "hbm", "kernel_ms": st[6],
-                 "algorithmic_bytes_per_launch": b_wfa, "achieved": b_wfa / (st[6] * 1e-3) / 1e9 if st[6] > 0 else 0.0, "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "reads": work["wfa_reads"], "reads_per_s": work["wfa_reads"] / (st[6] * 1e-3) if st[6] > 0 else 0.0,
-                 "bytes_per_read": b_wfa / max(1, work["wfa_reads"]), "wave_updates_per_read": work["wfa_updates"] / max(1, work["wfa_reads"])}
+        k_wfa = {"kernel": "hp::hp_wfa2_kernel<8,2> + <8,4> + <16,8> (concurrent; span of the launch set, mean over the timed sets)", "bound": "hbm",
+                 "kernel_ms": k_wfa_ms, "algorithmic_bytes_per_launch": b_wfa, "achieved": b_wfa / (k_wfa_ms * 1e-3) / 1e9 if k_wfa_ms > 0 else 0.0,
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "reads": work["wfa_reads"], "reads_per_s": work["wfa_reads"] / (k_wfa_ms * 1e-3) if k_wfa_ms > 0 else 0.0,
+                 "bytes_per_read": b_wfa / max(1.0, work["wfa_reads"]), "wave_updates_per_read": work["wfa_updates"] / max(1.0, work["wfa_reads"]),
+                 "reads_left_compact_path": info["records"] - work["wfa_reads"]}
         k_wfa["frac"] = k_wfa["achieved"] / HBM_PEAK_GBS
         k_wfa["traffic"], k_wfa["traffic_source"] = measured_traffic("hp_wfa2_kernel", "bytes_per_read", work["wfa_reads"])
-        k_astar = {"kernel": "hp::hp_astar_kernel", "bound": "hbm", "kernel_ms": st[7], "algorithmic_bytes_per_launch": b_astar,
-                   "achieved": b_astar / (st[7] * 1e-3) / 1e9 if st[7] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "cells_per_het": work["astar_cells"] / max(1, hets_per_step)}
+        k_astar = {"kernel": "hp::hp_astar_kernel", "bound": "hbm", "kernel_ms": k_astar_ms, "algorithmic_bytes_per_launch": b_astar,
+                   "achieved": b_astar / (k_astar_ms * 1e-3) / 1e9 if k_astar_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "cells_per_het": work["astar_cells"] / max(1, info["hets"])}
         k_astar["frac"] = k_astar["achieved"] / HBM_PEAK_GBS
-        k_astar["traffic"], k_astar["traffic_source"] = measured_traffic("hp_astar_kernel", "bytes_per_het", hets_per_step)
+        k_astar["traffic"], k_astar["traffic_source"] = measured_traffic("hp_astar_kernel", "bytes_per_het", info["hets"])
         for k in (k_wfa, k_astar):   # what actually crossed the HBM interface, next to the algorithmic figure
             k["traffic_gbs"] = k["traffic"] / (k["kernel_ms"] * 1e-3) / 1e9 if k["traffic"] and k["kernel_ms"] > 0 else None
             k["traffic_frac"] = k["traffic_gbs"] / HBM_PEAK_GBS if k["traffic_gbs"] else None
-        dom = k_wfa if st[6] >= st[7] else k_astar
+        dom = k_wfa if k_wfa_ms >= k_astar_ms else k_astar
+        ms_step = elapsed / args.steps * 1e3
         out = {
-            "metric": "het variants phased/sec, whole path (records -> graph-WFA -> rows -> A* -> span counts / haplotags)",
-            "value": hets_per_step * world * args.steps / elapsed,
+            "metric": "het variants phased/sec, whole path, streamed (every step a new block set: records over PCIe -> graph-WFA -> rows -> A* -> span counts / haplotags)",
+            "value": hets_timed * world / elapsed,
             "unit": "hets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u64", "data": "synthetic",
-            "config": {"workload": (f"synthetic read-bearing WGS-like block mix per GPU: {len(blocks)} blocks, {hets_per_step} hets "
-                                    f"(lognormal block sizes, median 15, max {args.max_block_hets}), {n_reads} HiFi-like reads "
-                                    f"({read_bases / max(1, n_reads):.0f} b mean, {args.coverage}x, 0.3% substitutions), het + hom SNV/indel calls"),
-                       "blocks": len(blocks), "hets_per_step_per_gpu": hets_per_step, "reads": n_reads, "read_bases": read_bases,
+            "config": {"workload": (f"synthetic read-bearing WGS-like block sets, one NEW set per step and GPU through hp_blockstream_* ({args.depth} sets in flight): "
+                                    f"{info['blocks']} blocks, {info['hets']} hets (lognormal block sizes, median 15, max {info['max_block_hets']}), "
+                                    f"{info['records']} records of {info['read_bases'] / max(1, info['records']):.0f} b mean at {args.coverage}x "
+                                    f"(0.5% edit noise: sub / ins / del; 0.3% of the reads at 5%: they exceed max_edit_distance; 2% supplementary), "
+                                    f"het + hom calls SNV .85 / indel .12 / SV .01 / tandem repeat .02, reads handed over as {args.seq_format}"),
+                       "blocks": info["blocks"], "hets_per_step_per_gpu": info["hets"], "records": info["records"], "read_bases": info["read_bases"],
+                       "distinct_sets": n_sets, "depth": args.depth, "seq_format": args.seq_format,
+                       "host_to_device_bytes_per_step": st_mean[10], "host_to_device_gbs": st_mean[10] / (ms_step * 1e-3) / 1e9,
                        "min_queue_size": 1000, "queue_increment": 3, "max_edit_distance": 500, "wfa_prune_distance": 500,
-                       "generate_s": round(t_gen, 2), "layout_upload_s": round(t_up, 3),
-                       "pcie_inclusive_hets_per_s": hets_per_step / (t_up + elapsed / args.steps)},
-            "stage_ms": {"graph_wfa": st[0], "fallback_rows_collapse_host": st[1], "astar_pack_upload": st[2], "astar_solve": st[3],
-                         "postprocess_outputs": st[4], "total": st[5], "graph_wfa_kernels": st[6], "astar_kernel": st[7]},
+                       "generate_s": round(t_gen, 2)},
+            "stage_ms": {"overlaps_layout_host": st_mean[0], "staging_pcie_expand": st_mean[1], "graph_wfa": st_mean[2], "fallback_rows_collapse_host": st_mean[3],
+                         "astar_pack_upload": st_mean[4], "astar_solve": st_mean[5], "postprocess_outputs": st_mean[6], "latency_submit_to_done": st_mean[7],
+                         "graph_wfa_kernels": st_mean[8], "astar_kernel": st_mean[9], "waiting_between_stages": st_mean[11],
+                         "stage1_wall": st_mean[12], "stage2_wall": st_mean[13], "stage3_wall": st_mean[14]},
             "roofline": {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_gbs", "traffic_frac", "kernel", "kernel_ms", "algorithmic_bytes_per_launch")},
             "kernels": [k_wfa, k_astar],
         }
+        lib.hp_blockstream_destroy(stream)
+        stream = None
+        if world == 1 and not args.no_resident:
+            # secondary: the same path over ONE set whose inputs are already in HBM (hp_blockset_solve again and again): what the
+            # pipeline would do if PCIe and the host stages were free and nothing overlapped
+            s0 = sets[args.warmup % n_sets]
+            stc = C.c_int(0)
+            t_up = time.perf_counter()
+            bs = lib.hp_blockset_create(s0.n, s0.inputs, C.byref(prm), local_rank, C.byref(stc))
+            t_up = time.perf_counter() - t_up
+            if bs:
+                ms8 = (C.c_double * 8)()
+                ro = s0.outputs()
+                for _ in range(2):
+                    _ffi.check(lib.hp_blockset_solve(bs, ro.arr, ms8))
+                t1 = time.perf_counter()
+                reps = max(3, args.steps // 2)
+                for _ in range(reps):
+                    _ffi.check(lib.hp_blockset_solve(bs, ro.arr, ms8))
+                dt = (time.perf_counter() - t1) / reps
+                lib.hp_blockset_destroy(bs)
+                out["resident"] = {"hets_per_s": s0.info["hets"] / dt, "ms_per_step": dt * 1e3, "layout_upload_ms": t_up * 1e3,
+                                   "note": "hp_blockset_solve over one resident set (inputs in HBM, no overlap between stages)"}
+                out["streamed_over_resident"] = out["value"] / out["resident"]["hets_per_s"]
         if not args.no_cpu and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_ffi
-            d = oracle_ffi.oracle()
-            t1 = time.perf_counter()
-            done, ok, n_cmp_reads = 0, True, 0
-            order = sorted(range(len(blocks)), key=lambda i: len(blocks[i].variant_calls))   # small blocks first: a bounded sample
-            hets_cpu = 0
-            for i in order[len(order) // 4:]:    # skip the tiniest quarter, then ascending until the budget is spent
-                segs, h1, h2, stt, spans = oracle_block(blocks[i], cfg, d)
-                r = res[i]
-                ok = ok and [(q, a, b, al, ql) for (q, a, b, al, ql, so) in r.segments if so] == segs
-                ok = ok and (r.haplotype_1 == h1).all() and (r.haplotype_2 == h2).all() and r.statistics == stt and r.span_counts.tolist() == spans
-                hets_cpu += len(blocks[i].variant_calls)
-                n_cmp_reads += len(blocks[i].records)
-                done += 1
-                if time.perf_counter() - t1 > args.cpu_seconds:
-                    break
-            dt = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": hets_cpu / dt, "unit": "hets/s", "cores": 1, "kind": "port",
-                                   "sample": f"{done} blocks of the same mix ({hets_cpu} hets, {n_cmp_reads} reads) through the whole path on the C++ restatement, single thread, {dt:.1f}s"}
-            out["parity"] = {"blocks_compared": done, "bit_identical": bool(ok), "what": "solver segments, haplotypes, PhaseStats, span counts"}
+            # CPU leg + parity, on the first timed set: the oracle's whole path (hpo_solve_block) on every host core over ALL its
+            # blocks - that is also the parity check of every block - and on one thread over a random sample of them
+            i0 = args.warmup % n_sets
+            s0, gpu_out = sets[i0], outs[i0]
+            cores = host_cores()
+            rng = np.random.default_rng(12345)
+            order = sorted(range(s0.n), key=lambda b: -s0.inputs[b].n_records)   # largest first: the tail of the all-cores run is one block
+            oo = s0.outputs()
+            h, r, done, dt = cpu_whole_path(s0, oo, prm, 10.0 * args.cpu_seconds, cores, order)
+            out["cpu_baseline_all_cores"] = {"value": h / dt, "unit": "hets/s", "cores": cores, "kind": "port",
+                                             "sample": f"{len(done)} of {s0.n} blocks of the first timed set ({h} hets, {r} records) through the whole path on the C++ restatement, "
+                                                       f"one block per thread at a time on {cores} threads, {dt:.1f}s"}
+            ok = all(gpu_out.equal(oo, b) for b in done)
+            out["parity"] = {"blocks_compared": len(done), "of": s0.n, "hets_compared": h, "bit_identical": bool(ok),
+                             "what": "every field hp_solve_blocks fills: segments (alleles, quals, regions), haplotypes, PhaseStats, span counts, haplotags, read statistics, edit distances"}
+            o1 = s0.outputs()
+            h1, r1, done1, dt1 = cpu_whole_path(s0, o1, prm, args.cpu_seconds, 1, [int(b) for b in rng.permutation(s0.n)])
+            out["cpu_baseline"] = {"value": h1 / dt1, "unit": "hets/s", "cores": 1, "kind": "port",
+                                   "sample": f"{len(done1)} blocks drawn at random from the first timed set ({h1} hets, {r1} records) through the whole path on the C++ restatement, single thread, {dt1:.1f}s"}
+            out["fallbacks"] = {"local_aligned": int(sum(gpu_out.arr[b].local_aligned for b in range(s0.n))), "global_aligned": int(sum(gpu_out.arr[b].global_aligned for b in range(s0.n)))}
         print(json.dumps(out), flush=True)
-    bs.close()
+    if stream:
+        lib.hp_blockstream_destroy(stream)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -330,14 +401,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["path", "c2", "wgs"], default="path")
     ap.add_argument("--total-hets", type=int, default=60000, help="path workload: hets per GPU and step")
-    ap.add_argument("--max-block-hets", type=int, default=2000)
+    ap.add_argument("--max-block-hets", type=int, default=4165, help="largest block HiPhase reports on HG002 (docs/user_guide.md:258)")
+    ap.add_argument("--seq-format", choices=["bam4", "ascii"], default="bam4", help="path workload: how the reads are handed over")
+    ap.add_argument("--depth", type=int, default=4, help="path workload: block sets in flight in the stream")
+    ap.add_argument("--distinct-sets", type=int, default=16, help="path workload: generated sets (steps + warm-up if fewer; cycled if more are needed)")
+    ap.add_argument("--no-resident", action="store_true", help="path workload: skip the secondary resident (inputs-in-HBM) figure")
     ap.add_argument("--seed", type=int, default=20250928, help="path workload: seed of the synthetic block mix (rank r uses seed + r)")
     ap.add_argument("--blocks", type=int, default=6144, help="blocks per GPU (24 resident single-wave workgroups per CU x 256 CUs)")
     ap.add_argument("--hets", type=int, default=5000)
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--span", type=int, default=20)
     ap.add_argument("--error", type=float, default=0.01)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the WGS-like secondary measurement")
     ap.add_argument("--replay", default=None, help=".hpbk capture of real phase blocks (strong scaling over ranks)")

@@ -257,6 +257,19 @@ class BlockOutput(C.Structure):
     ]
 
 
+class SynthReadsSpec(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("total_hets", C.c_uint32),
+        ("max_block_hets", C.c_uint32),
+        ("coverage", C.c_double), ("read_mean", C.c_double), ("read_sd", C.c_double), ("het_spacing", C.c_double), ("hom_ratio", C.c_double),
+        ("frac_snv", C.c_double), ("frac_indel", C.c_double), ("frac_sv", C.c_double), ("frac_multiallelic", C.c_double),
+        ("edit_noise", C.c_double), ("noisy_fraction", C.c_double), ("noisy_noise", C.c_double), ("supplementary_fraction", C.c_double),
+        ("seq_format", C.c_uint32),
+        ("threads", C.c_uint32),
+    ]
+
+
 # Every symbol include/hiphase_gpu.h declares; tests check the library exports all of them.
 EXPORTS = [
     "hp_astar_solve",
@@ -289,6 +302,16 @@ EXPORTS = [
     "hp_hpbk_append",
     "hp_synth_block_size",
     "hp_synth_block",
+    "hp_synth_reads_defaults",
+    "hp_synth_reads_create",
+    "hp_synth_reads_inputs",
+    "hp_synth_reads_info",
+    "hp_synth_reads_truth",
+    "hp_synth_reads_destroy",
+    "hp_synth_outputs_create",
+    "hp_synth_outputs_array",
+    "hp_synth_outputs_destroy",
+    "hp_block_output_equal",
 ]
 
 
@@ -298,6 +321,26 @@ def declare_common(dll):
     dll.hp_synth_block_size.argtypes = [C.POINTER(SynthSpec), C.POINTER(C.c_uint64)]
     dll.hp_synth_block.restype = C.c_int
     dll.hp_synth_block.argtypes = [C.POINTER(SynthSpec)] + [C.c_void_p] * 7
+    dll.hp_synth_reads_defaults.restype = None
+    dll.hp_synth_reads_defaults.argtypes = [C.POINTER(SynthReadsSpec)]
+    dll.hp_synth_reads_create.restype = C.c_void_p
+    dll.hp_synth_reads_create.argtypes = [C.POINTER(SynthReadsSpec), C.POINTER(C.c_int)]
+    dll.hp_synth_reads_inputs.restype = C.POINTER(BlockInput)
+    dll.hp_synth_reads_inputs.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    dll.hp_synth_reads_info.restype = None
+    dll.hp_synth_reads_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    dll.hp_synth_reads_truth.restype = C.POINTER(C.c_uint8)
+    dll.hp_synth_reads_truth.argtypes = [C.c_void_p, C.c_size_t]
+    dll.hp_synth_reads_destroy.restype = None
+    dll.hp_synth_reads_destroy.argtypes = [C.c_void_p]
+    dll.hp_synth_outputs_create.restype = C.c_void_p
+    dll.hp_synth_outputs_create.argtypes = [C.c_void_p]
+    dll.hp_synth_outputs_array.restype = C.POINTER(BlockOutput)
+    dll.hp_synth_outputs_array.argtypes = [C.c_void_p]
+    dll.hp_synth_outputs_destroy.restype = None
+    dll.hp_synth_outputs_destroy.argtypes = [C.c_void_p]
+    dll.hp_block_output_equal.restype = C.c_int
+    dll.hp_block_output_equal.argtypes = [C.POINTER(BlockInput), C.POINTER(BlockOutput), C.POINTER(BlockOutput)]
 
 
 _lib = None

@@ -76,6 +76,17 @@ int device_cu_count(int device_id) {
     return v;
 }
 
+unsigned host_threads(unsigned want) {
+    static const unsigned share = [] {
+        if (const char* e = std::getenv("HP_HOST_THREADS")) return (unsigned)std::max(1, std::atoi(e));
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        unsigned procs = 1;
+        if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) procs = (unsigned)std::max(1, std::atoi(e));
+        return std::max(2u, hw / procs);
+    }();
+    return std::max(1u, std::min(want, share));
+}
+
 thread_local int g_cu_partition = 0;
 
 // bit i of a CU mask: row a = i / 32, column b = i % 32. Whether the driver deals mask bits to the XCDs in blocks or

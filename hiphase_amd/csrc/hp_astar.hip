@@ -543,7 +543,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     // small per-block tables are merged.
     const double t_pack0 = wall_ms();
     // (8: measured 1.9 ms for the default bench's 452 blocks; 4: 2.0, 16: 2.9, 32: 4.8 - every part costs nine uploads)
-    unsigned nt = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned nt = host_threads(8u);
     if (const char* e = std::getenv("HP_PACK_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
     nt = (unsigned)std::min<size_t>(nt, n_blocks / 8 + 1);
     std::vector<HostPack> parts(nt);

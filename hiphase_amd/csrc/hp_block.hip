@@ -141,7 +141,7 @@ int hp::blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in
     {
         std::atomic<size_t> next{0};
         std::atomic<int> first_rc{HP_OK};
-        unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        unsigned nt = host_threads(16u);
         if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
         nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n_blocks / 4));
         std::vector<std::string> errs(nt);
@@ -189,7 +189,7 @@ int hp::blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in
     bs->job_alloff.resize(n_jobs + 1);
     {   // the jobs (host threads over blocks): the hom overlaps of a record are only looked up for records that have het overlaps
         std::atomic<size_t> next{0};
-        unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        unsigned nt = host_threads(16u);
         if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
         nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n_blocks / 4));
         WorkerPool::get().run(nt, [&](unsigned) {
@@ -469,7 +469,7 @@ int hp::blockset_tail(hp_blockset* bs, hp_block_output* out) {
     const double t1 = blk_now_ms();
     int rc = HP_OK;
     {
-        unsigned nt = std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));   // measured: 16 -> 32 threads 6.0 -> 4.1 ms, 64 no better
+        unsigned nt = host_threads(32u);   // measured: 16 -> 32 threads 6.0 -> 4.1 ms, 64 no better
         if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
         nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, bs->n_blocks));
         std::vector<size_t> order(bs->n_blocks);
@@ -668,7 +668,7 @@ int hp::blockset_tail(hp_blockset* bs, hp_block_output* out) {
         if (O.seg_row_off) O.seg_row_off[S.segs.size()] = cells;
     };
     {
-        unsigned nt = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        unsigned nt = host_threads(16u);
         if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
         nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, nb / 8));
         std::atomic<size_t> next{0};

@@ -34,6 +34,11 @@ extern thread_local double g_last_kernel_ms;  // see hp_last_kernel_ms()  // thr
 void* dev_cache_get(size_t bytes, size_t* got, int* dev);   // nullptr on failure (error set); *dev = the device it lives on
 void dev_cache_put(void* p, size_t bytes, int dev);
 
+// Host threads a parallel region of the library may use: min(want, the process's share of the host). The share is
+// HP_HOST_THREADS if set, else hardware threads / processes per node (LOCAL_WORLD_SIZE as torchrun and friends export it: one
+// process per GPU, eight of them on one host must not each assume the whole machine), never below 2.
+unsigned host_threads(unsigned want);
+
 // number of compute units of a device, queried once (hipGetDeviceProperties costs milliseconds per call)
 int device_cu_count(int device_id);
 

@@ -244,7 +244,7 @@ extern "C" int hp_local_realign_batch(const hp_local_read* reads_in, size_t n_re
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t0 = now_ms();
     std::vector<uint8_t> flags(n_reads * n_variants);
-    unsigned nt = std::thread::hardware_concurrency();
+    unsigned nt = host_threads(16u);
     if (const char* e = std::getenv("HP_LOCAL_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
     nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)nt, (size_t)16, n_reads / 32 + 1}));
     std::vector<Worker> workers(nt);

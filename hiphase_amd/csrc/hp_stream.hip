@@ -81,7 +81,7 @@ void hp_blockstream::stage_loop(int k) {
             q[k].pop_front();
         }
         s->t_begin[k] = st_now_ms();
-        if (s->rc == HP_OK) {   // (a set that failed an earlier stage just travels on, so that tickets complete in order)
+        if (s->rc == HP_OK && s->n_blocks) {   // (an empty set, or one that failed an earlier stage, just travels on: tickets complete in order)
             int rc = HP_OK;
             if (k == 0) rc = blockset_init(&s->bs, s->n_blocks, s->in, &prm, device);
             else if (k == 1) rc = blockset_wfa(&s->bs);

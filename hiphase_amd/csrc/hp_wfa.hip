@@ -320,7 +320,7 @@ struct WfaPack {
 
 unsigned wfa_host_threads(size_t n) {
     const char* tenv = std::getenv("HP_WFA_HOST_THREADS");
-    unsigned nt = tenv ? (unsigned)std::atoi(tenv) : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned nt = tenv ? (unsigned)std::atoi(tenv) : host_threads(8u);
     return (unsigned)std::min<size_t>(std::max(1u, nt), std::max<size_t>(1, n / 64));
 }
 

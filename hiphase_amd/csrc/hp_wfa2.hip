@@ -89,7 +89,7 @@ W2Context& w2_context(int device) {
 
 unsigned w2_host_threads(size_t n, size_t per_thread) {
     const char* tenv = std::getenv("HP_WFA_HOST_THREADS");
-    unsigned nt = tenv ? (unsigned)std::atoi(tenv) : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned nt = tenv ? (unsigned)std::atoi(tenv) : host_threads(8u);
     return (unsigned)std::min<size_t>(std::max(1u, nt), std::max<size_t>(1, n / per_thread));
 }
 template <class F> void w2_parallel(unsigned nt, F&& f) {
@@ -484,7 +484,7 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
     uint8_t* sb = cx.stage.p;
     const unsigned nt = [&] {
         const char* tenv = std::getenv("HP_WFA_HOST_THREADS");
-        const unsigned want = tenv ? (unsigned)std::max(1, std::atoi(tenv)) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        const unsigned want = tenv ? (unsigned)std::max(1, std::atoi(tenv)) : host_threads(16u);
         return (unsigned)std::min<uint64_t>(want, std::max<uint64_t>(1, (packed + ref_bytes) >> 20));
     }();
     // ---- 3a. blocks: reference hulls, variants, allele pool; jobs: the device job table -----------------------------------------

@@ -1,0 +1,67 @@
+"""Synthetic read-bearing block sets straight in the C layout (include/hiphase_gpu.h `hp_synth_reads_*`,
+hiphase_amd/csrc/hp_synth_reads.cpp): generated, solved and compared without any Python marshalling in between.
+`dll` is the library that generates (the product library by default; the test oracle carries the same generator)."""
+import ctypes as C
+
+from . import _ffi
+
+
+def default_spec(dll=None, **kw):
+    dll = dll or _ffi.lib()
+    s = _ffi.SynthReadsSpec()
+    dll.hp_synth_reads_defaults(C.byref(s))
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise AttributeError(k)
+        setattr(s, k, v)
+    return s
+
+
+class SynthSet:
+    """One generated block set: `.inputs` (hp_block_input array), `.n`, `.info`; `.outputs()` makes caller-side result buffers."""
+
+    def __init__(self, spec, dll=None):
+        self.dll = dll or _ffi.lib()
+        st = C.c_int(0)
+        self.h = self.dll.hp_synth_reads_create(C.byref(spec), C.byref(st))
+        if not self.h:
+            raise _ffi.HpError(st.value, "hp_synth_reads_create")
+        n = C.c_size_t(0)
+        self.inputs = self.dll.hp_synth_reads_inputs(self.h, C.byref(n))
+        self.n = n.value
+        info = (C.c_uint64 * 8)()
+        self.dll.hp_synth_reads_info(self.h, info)
+        self.info = dict(zip(("blocks", "hets", "records", "read_bases", "qnames", "input_bytes", "max_block_hets"), list(info)))
+
+    def outputs(self):
+        return SynthOutputs(self)
+
+    def truth(self, b):
+        p = self.dll.hp_synth_reads_truth(self.h, b)
+        return [p[i] for i in range(self.inputs[b].n_hets)]
+
+    def close(self):
+        if self.h:
+            self.dll.hp_synth_reads_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class SynthOutputs:
+    def __init__(self, sset):
+        self.sset = sset
+        self.h = sset.dll.hp_synth_outputs_create(sset.h)
+        self.arr = sset.dll.hp_synth_outputs_array(self.h)
+
+    def equal(self, other, b):
+        return bool(self.sset.dll.hp_block_output_equal(C.byref(self.sset.inputs[b]), C.byref(self.arr[b]), C.byref(other.arr[b])))
+
+    def close(self):
+        if self.h:
+            self.sset.dll.hp_synth_outputs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

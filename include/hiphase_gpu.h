@@ -403,6 +403,39 @@ uint32_t hp_synth_block_size(const hp_synth_spec* s, uint64_t* n_cells);
 int hp_synth_block(const hp_synth_spec* s, uint32_t* read_start, uint32_t* read_end, uint64_t* row_off,
                    uint8_t* alleles_2bit, uint8_t* quals, uint8_t* var_flags, uint8_t* truth);
 
+/* Deterministic synthetic READ-BEARING block sets (hp_synth_reads.cpp): the whole-path workload of bench.py and of the block-level
+ * tests, produced in the C layout hp_solve_blocks / hp_blockstream_submit take - what BASELINE.json configs[2-4] would decode
+ * from a BAM + VCF + FASTA. Per block: a random reference; het + hom calls in the SURVEY.md 8(d) type mix (the rest after
+ * frac_snv + frac_indel + frac_sv is tandem repeats; frac_multiallelic of the het tandem repeats are 1|2 genotypes); HiFi-like
+ * reads carrying one haplotype with uniform edit noise; a noisy tail (noisy_fraction of the reads at noisy_noise: they exceed
+ * max_edit_distance and fall back to local re-alignment); supplementary_fraction of the reads as two records of one read name.
+ * Block sizes are lognormal (median 15 hets) capped at max_block_hets (docs/user_guide.md:257-260). A pure function of the spec. */
+typedef struct hp_synth_reads_spec {
+    uint64_t seed;
+    uint32_t total_hets;        /* blocks are drawn until this many hets are reached */
+    uint32_t max_block_hets;
+    double   coverage, read_mean, read_sd, het_spacing, hom_ratio;
+    double   frac_snv, frac_indel, frac_sv, frac_multiallelic;
+    double   edit_noise, noisy_fraction, noisy_noise, supplementary_fraction;
+    uint32_t seq_format;        /* HP_SEQ_* of the records' bases */
+    uint32_t threads;           /* host threads for the generation; 0 = up to 32 */
+} hp_synth_reads_spec;
+typedef struct hp_synth_set hp_synth_set;
+typedef struct hp_synth_outputs hp_synth_outputs;
+void hp_synth_reads_defaults(hp_synth_reads_spec* s);   /* the bench workload: 60 000 hets, 30x, 15 kb reads, 0.5 % edit noise, BAM 4-bit */
+hp_synth_set* hp_synth_reads_create(const hp_synth_reads_spec* s, int* status);
+const hp_block_input* hp_synth_reads_inputs(const hp_synth_set* s, size_t* n_blocks);
+/* out[0] blocks, [1] hets, [2] records, [3] read bases, [4] read names, [5] bytes of reads + references as handed over, [6] largest block (hets) */
+void hp_synth_reads_info(const hp_synth_set* s, uint64_t out[8]);
+const uint8_t* hp_synth_reads_truth(const hp_synth_set* s, size_t block);   /* [n_hets] the allele haplotype 0 carries */
+void hp_synth_reads_destroy(hp_synth_set* s);
+/* caller-side output buffers for every block of a set, sized from the inputs */
+hp_synth_outputs* hp_synth_outputs_create(const hp_synth_set* s);
+hp_block_output* hp_synth_outputs_array(hp_synth_outputs* o);
+void hp_synth_outputs_destroy(hp_synth_outputs* o);
+/* 1 when two outputs of the same block hold the same results in every field hp_solve_blocks fills, else 0 */
+int hp_block_output_equal(const hp_block_input* in, const hp_block_output* a, const hp_block_output* b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,7 +140,7 @@ def test_abi_layout_matches_the_ctypes_bindings(hp_lib):
              "hp_graph_result": _ffi.GraphResult, "hp_ed_pair": _ffi.EdPair, "hp_local_variant": _ffi.LocalVariant,
              "hp_local_read": _ffi.LocalRead, "hp_read_stats": _ffi.ReadStats, "hp_block_record": _ffi.BlockRecord,
              "hp_block_input": _ffi.BlockInput, "hp_block_params": _ffi.BlockParams, "hp_block_output": _ffi.BlockOutput,
-             "hp_synth_spec": _ffi.SynthSpec}
+             "hp_synth_spec": _ffi.SynthSpec, "hp_synth_reads_spec": _ffi.SynthReadsSpec}
     assert set(layout) == set(pairs)
     for name, cls in pairs.items():
         assert layout[name]["sizeof"] == C.sizeof(cls), name

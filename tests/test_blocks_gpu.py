@@ -173,42 +173,24 @@ def test_bench_path_two_ranks_gloo():
     assert out["config"]["hets_per_step_per_gpu"] == 2500
 
 
-@pytest.mark.skipif(False, reason="")
-def test_rank_workloads_are_disjoint_and_deterministic():
-    from hiphase_amd.synth_reads import synth_wgs_like_mix
-    a0 = synth_wgs_like_mix(20250928 + 0, 300)
-    a1 = synth_wgs_like_mix(20250928 + 1, 300)
-    b0 = synth_wgs_like_mix(20250928 + 0, 300)
-    assert [blk.reference for blk in a0] == [blk.reference for blk in b0]
-    assert [r.read_align for blk in a0 for r in blk.records] == [r.read_align for blk in b0 for r in blk.records]
-    assert {blk.reference for blk in a0}.isdisjoint({blk.reference for blk in a1})
-
-
 @pytest.mark.timeout(900)
 def test_block_set_with_large_graphs_hand_over_and_two_phases(monkeypatch):
     """Resident block set through the compact kernels where every mechanism is busy: dense variants put most reads'
     graphs in the largest class (> 128 nodes) and some beyond it (> 256: dense-band pass), 1 % noise makes reads of
     the smaller classes outgrow their tables (handed over on the device), and the results come back in two phases.
-    Compared block by block with the whole path on the oracle (bench.oracle_block), twice (re-solve of the resident set)."""
-    import sys, os
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
+    Compared block by block with the whole path on the oracle (hpo_solve_block), twice (re-solve of the resident set)."""
+    from oracle_ffi import oracle_solve_blocks
     from hiphase_amd.synth_reads import synth_read_block
     monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0")
     specs = [synth_read_block(4100 + i, n, block_index=i, het_spacing=sp, coverage=20.0, noise=nz)[0]
              for i, (n, sp, nz) in enumerate([(60, 300.0, 0.01), (25, 700.0, 0.003), (90, 220.0, 0.006), (12, 1000.0, 0.01), (150, 450.0, 0.01)])]
     cfg = GlobalRealignmentConfig()
-    d = oracle()
+    expect = oracle_solve_blocks(specs, config=cfg)
     bs = BlockSet(specs, config=cfg)
     try:
         for _ in range(2):
             bs.solve()
-            res = bs.results()
-            for spec, r in zip(specs, res):
-                segs, h1, h2, stt, spans = bench.oracle_block(spec, cfg, d)
-                assert [(q, a, b, al, ql) for (q, a, b, al, ql, so) in r.segments if so] == segs
-                assert (r.haplotype_1 == h1).all() and (r.haplotype_2 == h2).all() and r.statistics == stt
-                assert r.span_counts.tolist() == spans
+            assert all(same_result(r, e) for r, e in zip(bs.results(), expect))
     finally:
         bs.close()
 

@@ -1,0 +1,70 @@
+"""Generated block sets (C generator, C layout, no marshalling) through the product's entries against the oracle's whole path
+(hpo_solve_block) on the same inputs: hp_solve_blocks and hp_blockstream_*, reads as ASCII and as BAM 4-bit, through the
+compact graph-WFA kernels and the dense-band ones. The sets carry everything the bench workload does: SV / tandem-repeat /
+multi-allelic calls, edit noise, reads that exceed max_edit_distance (local re-alignment fallback), supplementary records."""
+import ctypes as C
+
+import pytest
+
+from hiphase_amd import _ffi
+from hiphase_amd.blocks import _params
+from hiphase_amd.synth_sets import SynthSet, default_spec
+from oracle_ffi import oracle
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(max_block_hets=150, noisy_fraction=0.02, supplementary_fraction=0.05, frac_snv=0.75, frac_indel=0.13, frac_sv=0.04)
+
+
+def oracle_outputs(sset, prm):
+    d = oracle()
+    out = sset.outputs()
+    for b in range(sset.n):
+        assert d.hpo_solve_block(C.byref(sset.inputs[b]), C.byref(prm), C.byref(out.arr[b])) == 0
+    return out
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("fmt", [_ffi.SEQ_ASCII, _ffi.SEQ_BAM4])
+@pytest.mark.parametrize("path", ["compact", "dense-band"])
+def test_solve_blocks_on_generated_sets_vs_oracle(fmt, path, monkeypatch):
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0" if path == "compact" else "1000000000")
+    lib = _ffi.lib()
+    prm = _params(2, 1000, 3, None, True)
+    s = SynthSet(default_spec(lib, total_hets=600, seed=11, seq_format=fmt, **KW))
+    exp = oracle_outputs(s, prm)
+    got = s.outputs()
+    _ffi.check(lib.hp_solve_blocks(s.n, s.inputs, C.byref(prm), got.arr, 0))
+    bad = [b for b in range(s.n) if not got.equal(exp, b)]
+    assert bad == []
+    assert sum(got.arr[b].local_aligned for b in range(s.n)) > 0
+
+
+@pytest.mark.timeout(1200)
+def test_blockstream_on_generated_sets_vs_oracle(monkeypatch):
+    """six different sets, three in flight, twice around: every set's results equal the oracle's"""
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "256")
+    lib = _ffi.lib()
+    prm = _params(2, 1000, 3, None, True)
+    sets = [SynthSet(default_spec(lib, total_hets=300 + 80 * k, seed=100 + k, seq_format=_ffi.SEQ_BAM4 if k % 2 else _ffi.SEQ_ASCII, **KW)) for k in range(6)]
+    exps = [oracle_outputs(s, prm) for s in sets]
+    st = C.c_int(0)
+    stream = lib.hp_blockstream_create(C.byref(prm), 0, 3, C.byref(st))
+    assert stream, lib.hp_last_error()
+    try:
+        for rep in range(2):
+            outs = [s.outputs() for s in sets]
+            pending = []
+            for k, s in enumerate(sets):
+                if len(pending) == 3:
+                    kk, t = pending.pop(0)
+                    _ffi.check(lib.hp_blockstream_wait(stream, t, None, None))
+                    assert [b for b in range(sets[kk].n) if not outs[kk].equal(exps[kk], b)] == []
+                t = C.c_uint64(0)
+                _ffi.check(lib.hp_blockstream_submit(stream, s.n, s.inputs, outs[k].arr, C.byref(t)))
+                pending.append((k, t.value))
+            for kk, t in pending:
+                _ffi.check(lib.hp_blockstream_wait(stream, t, None, None))
+                assert [b for b in range(sets[kk].n) if not outs[kk].equal(exps[kk], b)] == []
+    finally:
+        lib.hp_blockstream_destroy(stream)

@@ -1,0 +1,77 @@
+"""The C generator of read-bearing block sets (hiphase_amd/csrc/hp_synth_reads.cpp) and the oracle's whole path on its output
+(no GPU): the set is a pure function of the spec, the BAM 4-bit hand-over decodes to the ASCII one, every mechanism the bench
+workload is meant to exercise shows up (fallbacks to local re-alignment, supplementary records collapsed, SV / tandem-repeat /
+multi-allelic calls), and the planted phase comes back."""
+import ctypes as C
+
+import numpy as np
+
+from hiphase_amd import _ffi
+from hiphase_amd.blocks import _params
+from hiphase_amd.synth_sets import SynthSet, default_spec
+from oracle_ffi import oracle
+
+KW = dict(total_hets=350, max_block_hets=90, seed=7, noisy_fraction=0.03, supplementary_fraction=0.06, frac_snv=0.70, frac_indel=0.15, frac_sv=0.05)
+
+
+def solve_all(d, sset, prm=None):
+    prm = prm or _params(2, 1000, 3, None, True)
+    out = sset.outputs()
+    for b in range(sset.n):
+        assert d.hpo_solve_block(C.byref(sset.inputs[b]), C.byref(prm), C.byref(out.arr[b])) == 0
+    return out
+
+
+def test_generator_is_deterministic_and_formats_agree():
+    d = oracle()
+    a = SynthSet(default_spec(d, seq_format=_ffi.SEQ_ASCII, **KW), d)
+    b = SynthSet(default_spec(d, seq_format=_ffi.SEQ_ASCII, threads=1, **KW), d)
+    p = SynthSet(default_spec(d, seq_format=_ffi.SEQ_BAM4, **KW), d)
+    assert a.info == b.info and a.n == p.n and a.info["hets"] == p.info["hets"] == 350
+    lut = np.frombuffer(b"=ACMGRSVTWYHKDBN", np.uint8)
+    for blk in range(a.n):
+        A, B, P = a.inputs[blk], b.inputs[blk], p.inputs[blk]
+        assert (A.n_hets, A.n_homs, A.n_records, A.n_qnames) == (B.n_hets, B.n_homs, B.n_records, B.n_qnames) == (P.n_hets, P.n_homs, P.n_records, P.n_qnames)
+        assert P.seq_format == _ffi.SEQ_BAM4 and A.seq_format == _ffi.SEQ_ASCII
+        for r in range(0, A.n_records, 7):
+            ra, rb, rp = A.records[r], B.records[r], P.records[r]
+            sa = np.ctypeslib.as_array(ra.read_align, (ra.read_len,))
+            assert np.array_equal(sa, np.ctypeslib.as_array(rb.read_align, (rb.read_len,)))
+            packed = np.ctypeslib.as_array(rp.read_align, ((rp.read_len + 1) // 2,))
+            codes = np.stack([packed >> 4, packed & 15], axis=1).reshape(-1)[:rp.read_len]
+            assert rp.read_len == ra.read_len and np.array_equal(lut[codes], sa)
+            # the CIGAR consumes exactly the read and the reference span
+            cg = np.ctypeslib.as_array(ra.local.contents.cigar, (ra.local.contents.n_cigar,))
+            ops, lens = cg & 15, cg >> 4
+            assert lens[(ops == 0) | (ops == 1)].sum() == ra.read_len
+            assert lens[(ops == 0) | (ops == 2)].sum() == ra.max_position - ra.min_position + 1 and ops[0] == 0 and ops[-1] == 0
+    oa, op = solve_all(d, a), solve_all(d, p)
+    assert all(oa.equal(op, blk) for blk in range(a.n))
+
+
+def test_workload_exercises_the_path_and_recovers_the_planted_phase():
+    d = oracle()
+    s = SynthSet(default_spec(d, **KW), d)
+    out = solve_all(d, s)
+    types = np.concatenate([np.ctypeslib.as_array(s.inputs[b].het_types, (s.inputs[b].n_hets,)) for b in range(s.n)])
+    assert {0, 1, 2, 9} <= set(types.tolist()) and ({4, 5} & set(types.tolist()))          # SNV, ins, del, TR and an SV
+    assert any(s.inputs[b].hets[i].flags & 2 for b in range(s.n) for i in range(s.inputs[b].n_hets))   # a 1|2 genotype
+    assert sum(out.arr[b].local_aligned for b in range(s.n)) > 0                              # the noisy tail fell back
+    assert any(s.inputs[b].n_records > s.inputs[b].n_qnames for b in range(s.n))             # supplementary records
+    wrong = total = 0
+    for b in range(s.n):
+        n = s.inputs[b].n_hets
+        h1, h2 = np.ctypeslib.as_array(out.arr[b].h1, (n,)), np.ctypeslib.as_array(out.arr[b].h2, (n,))
+        tr = np.asarray(s.truth(b))
+        ph = (h1 != h2) & (h1 < 2) & (h2 < 2)
+        # within a phase set (no juncture without spanning reads) the planted phase comes back up to the global swap
+        spans = np.ctypeslib.as_array(out.arr[b].span_counts, (max(n - 1, 1),))[:n - 1]
+        start = 0
+        for cut in list(np.flatnonzero(spans == 0) + 1) + [n]:
+            sel = ph[start:cut]
+            if sel.sum() > 1:
+                agree = (h1[start:cut][sel] == tr[start:cut][sel]).sum()
+                wrong += min(agree, sel.sum() - agree)
+                total += sel.sum()
+            start = cut
+    assert total > 200 and wrong <= 0.02 * total
