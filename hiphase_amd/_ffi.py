@@ -308,10 +308,17 @@ EXPORTS = [
     "hp_synth_reads_info",
     "hp_synth_reads_truth",
     "hp_synth_reads_destroy",
-    "hp_synth_outputs_create",
-    "hp_synth_outputs_array",
-    "hp_synth_outputs_destroy",
+    "hp_outputs_create",
+    "hp_outputs_array",
+    "hp_outputs_destroy",
     "hp_block_output_equal",
+    "hp_hpbr_append",
+    "hp_hpbr_open",
+    "hp_hpbr_inputs",
+    "hp_hpbr_params",
+    "hp_hpbr_expected",
+    "hp_hpbr_close",
+    "hp_hpbr_last_error",
 ]
 
 
@@ -333,12 +340,25 @@ def declare_common(dll):
     dll.hp_synth_reads_truth.argtypes = [C.c_void_p, C.c_size_t]
     dll.hp_synth_reads_destroy.restype = None
     dll.hp_synth_reads_destroy.argtypes = [C.c_void_p]
-    dll.hp_synth_outputs_create.restype = C.c_void_p
-    dll.hp_synth_outputs_create.argtypes = [C.c_void_p]
-    dll.hp_synth_outputs_array.restype = C.POINTER(BlockOutput)
-    dll.hp_synth_outputs_array.argtypes = [C.c_void_p]
-    dll.hp_synth_outputs_destroy.restype = None
-    dll.hp_synth_outputs_destroy.argtypes = [C.c_void_p]
+    dll.hp_outputs_create.restype = C.c_void_p
+    dll.hp_outputs_create.argtypes = [C.POINTER(BlockInput), C.c_size_t]
+    dll.hp_outputs_array.restype = C.POINTER(BlockOutput)
+    dll.hp_outputs_array.argtypes = [C.c_void_p]
+    dll.hp_outputs_destroy.restype = None
+    dll.hp_outputs_destroy.argtypes = [C.c_void_p]
+    dll.hp_hpbr_append.restype = C.c_int
+    dll.hp_hpbr_append.argtypes = [C.c_char_p, C.POINTER(BlockInput), C.POINTER(BlockParams), C.POINTER(BlockOutput)]
+    dll.hp_hpbr_open.restype = C.c_void_p
+    dll.hp_hpbr_open.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    dll.hp_hpbr_inputs.restype = C.POINTER(BlockInput)
+    dll.hp_hpbr_inputs.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    dll.hp_hpbr_params.restype = C.POINTER(BlockParams)
+    dll.hp_hpbr_params.argtypes = [C.c_void_p]
+    dll.hp_hpbr_expected.restype = C.POINTER(BlockOutput)
+    dll.hp_hpbr_expected.argtypes = [C.c_void_p]
+    dll.hp_hpbr_close.restype = None
+    dll.hp_hpbr_close.argtypes = [C.c_void_p]
+    dll.hp_hpbr_last_error.restype = C.c_char_p
     dll.hp_block_output_equal.restype = C.c_int
     dll.hp_block_output_equal.argtypes = [C.POINTER(BlockInput), C.POINTER(BlockOutput), C.POINTER(BlockOutput)]
 

@@ -76,6 +76,7 @@ int device_cu_count(int device_id) {
     return v;
 }
 
+thread_local unsigned g_host_share_div = 0;
 unsigned host_threads(unsigned want) {
     static const unsigned share = [] {
         if (const char* e = std::getenv("HP_HOST_THREADS")) return (unsigned)std::max(1, std::atoi(e));
@@ -84,7 +85,8 @@ unsigned host_threads(unsigned want) {
         if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) procs = (unsigned)std::max(1, std::atoi(e));
         return std::max(2u, hw / procs);
     }();
-    return std::max(1u, std::min(want, share));
+    const unsigned mine = g_host_share_div ? std::max(2u, share / g_host_share_div) : share;
+    return std::max(1u, std::min(want, mine));
 }
 
 thread_local int g_cu_partition = 0;
@@ -92,7 +94,7 @@ thread_local int g_cu_partition = 0;
 // bit i of a CU mask: row a = i / 32, column b = i % 32. Whether the driver deals mask bits to the XCDs in blocks or
 // round-robin is not documented; "(a + b) % 8 == 0" selects four CUs of every XCD either way (256 CUs, 8 XCDs).
 static bool cu_in_search_partition(int i) {
-    static const int mod = [] { const char* e = std::getenv("HP_SEARCH_CU_MOD"); const int v = e ? std::atoi(e) : 8; return (v == 2 || v == 4 || v == 8) ? v : 8; }();
+    static const int mod = [] { const char* e = std::getenv("HP_SEARCH_CU_MOD"); const int v = e ? std::atoi(e) : 8; return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 8; }();
     return ((i / 32 + i % 32) % mod) == 0;
 }
 
@@ -116,6 +118,18 @@ hipError_t hp_stream_create(hipStream_t* s, int device_id, bool high_priority) {
     for (int i = 0; i < n; ++i)
         if (cu_in_search_partition(i) == (g_cu_partition == 1)) mask[(size_t)i / 32] |= 1u << (i % 32);
     return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
+}
+
+hipStream_t thread_stream(int device_id) {
+    struct Slot { int device = -1; hipStream_t s = nullptr; };
+    struct Holder { Slot part[3]; ~Holder() { for (auto& x : part) if (x.s) (void)hipStreamDestroy(x.s); } };
+    static thread_local Holder h;
+    Slot& x = h.part[g_cu_partition];
+    if (x.s && x.device == device_id) return x.s;
+    if (x.s) { (void)hipStreamDestroy(x.s); x.s = nullptr; }
+    if (hp_stream_create(&x.s, device_id) != hipSuccess) { x.s = nullptr; return nullptr; }
+    x.device = device_id;
+    return x.s;
 }
 
 void dev_cache_put(void* p, size_t bytes, int dev) {   // dev: what dev_cache_get reported for this block

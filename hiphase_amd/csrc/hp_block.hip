@@ -23,6 +23,8 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <deque>
 #include <ctime>
 #include <condition_variable>
 #include <functional>
@@ -699,81 +701,36 @@ extern "C" int hp_blockset_work(const hp_blockset* bs, uint64_t out[8]) {
     return HP_OK;
 }
 
+// One set on one device, on the calling thread. The thread keeps its block-set object from call to call (host vectors,
+// device buffers, the graph-WFA session and its helper thread): a service thread or a caller's worker solves set after set.
 static int solve_blocks_on_device(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id) {
-    int st = HP_OK;
-    hp_blockset* bs = hp_blockset_create(n_blocks, in, p, device_id, &st);
-    if (!bs) return st != HP_OK ? st : HP_ERR_ARG;
-    const int rc = hp_blockset_solve(bs, out, nullptr);
-    hp_blockset_destroy(bs);
+    static thread_local std::unique_ptr<hp_blockset> tl_bs;
+    if (!tl_bs) tl_bs.reset(new hp_blockset());
+    hp_blockset* bs = tl_bs.get();
+    int rc = blockset_init(bs, n_blocks, in, p, device_id);
+    if (rc == HP_OK) rc = hp_blockset_solve(bs, out, nullptr);
+    bs->in = nullptr;   // (nothing of the caller's is kept)
     return rc;
 }
 
-// device_id == -1: the node's GPUs share the blocks through a host-side work queue (the reference's own
-// fan-out is a thread pool over blocks with back-pressure, main.rs:326-462). Blocks are sorted by record count (LPT) and
-// cut into chunks of about `total / (8 x devices)` records, largest first; every device has TWO workers pulling chunks
-// dynamically, so that on each device the layout + upload of one chunk (host + PCIe) overlaps the kernels of another.
-// No collective and no device-to-device traffic: a chunk's 2 N result bytes + statistics go back over PCIe.
-static int solve_blocks_now(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id) {
-    if (device_id >= 0) return solve_blocks_on_device(n_blocks, in, p, out, device_id);
-    const int real_dev = hp_device_count();
-    if (real_dev <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return HP_ERR_HIP; }
-    const char* wenv = std::getenv("HP_QUEUE_WORKERS");   // test hook: n queue "devices" on a box with fewer GPUs (device = worker % real)
-    const int ndev = wenv ? std::max(1, std::atoi(wenv)) : real_dev;
-    if (ndev == 1 || n_blocks < 2) return solve_blocks_on_device(n_blocks, in, p, out, hp_default_device());
-    std::vector<uint32_t> order(n_blocks);
-    for (size_t i = 0; i < n_blocks; ++i) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return in[a].n_records > in[b].n_records; });
-    uint64_t total = 0;
-    for (size_t i = 0; i < n_blocks; ++i) total += in[i].n_records + 1;
-    const uint64_t target = std::max<uint64_t>(1, total / ((uint64_t)ndev * 8));
-    std::vector<std::vector<uint32_t>> chunks;
-    {
-        uint64_t acc = 0;
-        chunks.emplace_back();
-        for (uint32_t b : order) {
-            if (acc >= target && !chunks.back().empty()) { chunks.emplace_back(); acc = 0; }
-            chunks.back().push_back(b);
-            acc += in[b].n_records + 1;
-        }
-    }
-    std::atomic<size_t> next{0};
-    std::atomic<int> first_err{HP_OK};
-    const int n_workers = ndev * 2;
-    std::vector<std::string> errs(n_workers);
-    std::vector<std::thread> workers;
-    for (int w = 0; w < n_workers; ++w)
-        workers.emplace_back([&, w]() {
-            const int dev = (w % ndev) % real_dev;
-            for (;;) {
-                const size_t c = next.fetch_add(1);
-                if (c >= chunks.size() || first_err.load() != HP_OK) break;
-                const auto& ids = chunks[c];
-                std::vector<hp_block_input> ci(ids.size());
-                std::vector<hp_block_output> co(ids.size());
-                for (size_t k = 0; k < ids.size(); ++k) { ci[k] = in[ids[k]]; co[k] = out[ids[k]]; }
-                const int rc = solve_blocks_on_device(ids.size(), ci.data(), p, co.data(), dev);
-                if (rc != HP_OK) { int exp = HP_OK; if (first_err.compare_exchange_strong(exp, rc)) errs[w] = hp_last_error(); break; }
-                for (size_t k = 0; k < ids.size(); ++k) out[ids[k]] = co[k];
-            }
-        });
-    for (auto& t : workers) t.join();
-    if (first_err.load() != HP_OK) {
-        for (auto& e : errs) if (!e.empty()) { set_error("%s", e.c_str()); break; }
-        return first_err.load();
-    }
-    return HP_OK;
-}
-
-// hp_solve_blocks calls that are in flight together (HiPhase calls solve_block once per block from its thread pool,
-// main.rs:385-408) are merged into one block set: hp_combine.h.
+// ---- the node's GPUs behind the unchanged per-block entry -----------------------------------------------------------------------
+// HiPhase calls solve_block once per phase block from its `--threads` pool (reference src/main.rs:326-462: a bounded queue of
+// blocks, T workers, results written in order). With the one-call-site patch of INTEGRATION.md that is T threads sitting in
+// hp_solve_blocks(1, ..., device_id = -1) at once. Requests go into ONE queue; every visible device has service threads pulling
+// from it (two per device: the layout + upload of one merged set overlaps the kernels of the other); a service thread takes its
+// share of what is queued (queued / idle service threads, so that a burst spreads over the devices), merges it into one block
+// set, solves it on its device, hands the results out. A call with many blocks (device_id = -1) is cut into chunks of about
+// total / (8 x devices) records, largest blocks first (LPT: sizes are heavy-tailed), which travel through the same
+// queue. No collective, no device-to-device traffic: a block's 2 N result bytes + statistics go back over PCIe.
+// A request that names its device goes to that device's own queue. The service threads are started by the first call that
+// needs them and live as long as the process (their device-buffer caches, streams and block-set objects stay warm).
 namespace {
+
 struct BlocksReq {
-    size_t n; const hp_block_input* in; hp_block_params prm; hp_block_output* out; int device;
+    size_t n; const hp_block_input* in; hp_block_params prm; hp_block_output* out; int device;   // device: -1 = any
+    bool counted = false;   // its caller is counted in BlockDispatcher::entering (a coalescing caller, not a chunk of a large call)
     int rc = HP_OK; std::string err; bool done = false;
 };
-void run_blocks_batch(std::vector<BlocksReq*>& batch);
-// never destroyed: its service thread may outlive every static destructor
-hp::Combiner<BlocksReq>& g_blocks_combiner() { static auto* c = new hp::Combiner<BlocksReq>(run_blocks_batch); return *c; }
 bool same_params(const hp_block_params& a, const hp_block_params& b) {
     return a.astar.min_queue_size == b.astar.min_queue_size && a.astar.queue_increment == b.astar.queue_increment &&
            a.astar.max_segment_size == b.astar.max_segment_size && a.wfa_prune_distance == b.wfa_prune_distance &&
@@ -781,38 +738,175 @@ bool same_params(const hp_block_params& a, const hp_block_params& b) {
            a.global_failure_minimum == b.global_failure_minimum && a.min_matched_alleles == b.min_matched_alleles &&
            a.global_realignment == b.global_realignment;
 }
-void run_blocks_batch(std::vector<BlocksReq*>& batch) {
+// requests that share their parameters are solved as one set; a merged set that fails is re-run request by request so that
+// every caller gets the status of its own blocks
+void run_requests(std::vector<BlocksReq*>& batch, int device) {
     std::vector<char> taken(batch.size(), 0);
     for (size_t i = 0; i < batch.size(); ++i) {
         if (taken[i]) continue;
         std::vector<BlocksReq*> grp;
         for (size_t j = i; j < batch.size(); ++j)
-            if (!taken[j] && batch[j]->device == batch[i]->device && same_params(batch[j]->prm, batch[i]->prm)) { taken[j] = 1; grp.push_back(batch[j]); }
-        if (grp.size() > 1) {
-            std::vector<hp_block_input> in;
-            std::vector<hp_block_output> out;
-            for (BlocksReq* r : grp) { in.insert(in.end(), r->in, r->in + r->n); out.insert(out.end(), r->out, r->out + r->n); }
-            if (solve_blocks_now(in.size(), in.data(), &grp[0]->prm, out.data(), grp[0]->device) == HP_OK) {
-                size_t o = 0;
-                for (BlocksReq* r : grp) { std::copy(out.begin() + o, out.begin() + o + r->n, r->out); o += r->n; r->rc = HP_OK; }
-                continue;
+            if (!taken[j] && same_params(batch[j]->prm, batch[i]->prm)) { taken[j] = 1; grp.push_back(batch[j]); }
+        try {
+            if (grp.size() > 1) {
+                std::vector<hp_block_input> in;
+                std::vector<hp_block_output> out;
+                for (BlocksReq* r : grp) { in.insert(in.end(), r->in, r->in + r->n); out.insert(out.end(), r->out, r->out + r->n); }
+                if (solve_blocks_on_device(in.size(), in.data(), &grp[0]->prm, out.data(), device) == HP_OK) {
+                    size_t o = 0;
+                    for (BlocksReq* r : grp) { std::copy(out.begin() + o, out.begin() + o + r->n, r->out); o += r->n; r->rc = HP_OK; }
+                    continue;
+                }
             }
-        }
-        for (BlocksReq* r : grp) {   // alone, or the merged set failed: every caller gets the status of its own blocks
-            r->rc = solve_blocks_now(r->n, r->in, &r->prm, r->out, r->device);
-            if (r->rc != HP_OK) r->err = hp_last_error();
+            for (BlocksReq* r : grp) {
+                r->rc = solve_blocks_on_device(r->n, r->in, &r->prm, r->out, device);
+                if (r->rc != HP_OK) r->err = hp_last_error();
+            }
+        } catch (const std::exception& e) {   // (std::bad_alloc of a host vector: nobody may be left waiting)
+            for (BlocksReq* r : grp) if (r->rc == HP_OK) { r->rc = HP_ERR_OOM; r->err = std::string("host allocation failed: ") + e.what(); }
         }
     }
 }
+
+class BlockDispatcher {
+public:
+    static BlockDispatcher& get() { static auto* d = new BlockDispatcher(); return *d; }   // never destroyed
+    int devices() { std::lock_guard<std::mutex> lk(m_); start_locked(); return n_vdev_; }
+    // queues the requests and waits for all of them; `expected` more single-block callers may be on their way in (call coalescing)
+    void submit(BlocksReq* const* reqs, size_t n) {
+        std::unique_lock<std::mutex> lk(m_);
+        start_locked();
+        for (size_t i = 0; i < n; ++i) {
+            BlocksReq* r = reqs[i];
+            if (r->device >= 0) dev_q_[(size_t)r->device % dev_q_.size()].push_back(r); else any_q_.push_back(r);
+            if (r->counted) ++counted_here_;
+        }
+        cv_work_.notify_all();
+        cv_done_.wait(lk, [&]() { for (size_t i = 0; i < n; ++i) if (!reqs[i]->done) return false; return true; });
+    }
+    std::atomic<int> entering{0};     // callers inside the coalescing entry that have not queued yet (+ lone runners)
+    std::atomic<int> lone{0};         // callers that took the lone fast path and will never queue
+
+private:
+    void start_locked() {
+        if (started_) return;
+        started_ = true;
+        real_dev_ = std::max(1, hp_device_count());
+        const char* wenv = std::getenv("HP_QUEUE_WORKERS");   // test hook: n queue "devices" on a box with fewer GPUs (device = worker % real)
+        n_vdev_ = wenv ? std::max(1, std::atoi(wenv)) : real_dev_;
+        dev_q_.resize((size_t)real_dev_);
+        const char* tenv = std::getenv("HP_SERVICE_THREADS");
+        const int per_dev = tenv ? std::max(1, std::atoi(tenv)) : 2;
+        for (int v = 0; v < n_vdev_; ++v)
+            for (int k = 0; k < per_dev; ++k) std::thread([this, v]() { serve(v % real_dev_); }).detach();
+    }
+    void serve(int device) {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            ++idle_;
+            cv_work_.wait(lk, [&]() { return !any_q_.empty() || !dev_q_[(size_t)device].empty(); });
+            // callers that are inside the entry point but have not queued yet are about to: a short window collects them
+            // (a lone runner never queues and is not waited for)
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us());
+            // (counted_here_: coalescing callers whose request is queued or being served.) Callers that have just been handed
+            // their results are on their way back with the next block, one by one: the window stays open until as many callers
+            // are here as have ever been inside at once - or it runs out. Without this a pool of 64 threads degenerates into
+            // batches of one or two blocks (measured: 4 k instead of 60 k hets/s).
+            for (;;) {
+                const int inside = entering.load(std::memory_order_acquire) - lone.load(std::memory_order_acquire);
+                peak_ = std::max(peak_, inside);
+                if (counted_here_ >= peak_) break;
+                if (cv_work_.wait_until(lk, deadline) == std::cv_status::timeout) break;
+            }
+            std::vector<BlocksReq*> batch(dev_q_[(size_t)device].begin(), dev_q_[(size_t)device].end());
+            dev_q_[(size_t)device].clear();
+            // a share of the common queue: what is there, over the service threads that are free to take it
+            size_t take = (any_q_.size() + (size_t)idle_ - 1) / (size_t)std::max(1, idle_);
+            --idle_;
+            for (; take > 0 && !any_q_.empty(); --take) { batch.push_back(any_q_.front()); any_q_.pop_front(); }
+            if (batch.empty()) continue;   // (another service thread was quicker)
+            lk.unlock();
+            run_requests(batch, device);
+            lk.lock();
+            for (BlocksReq* r : batch) { r->done = true; if (r->counted) --counted_here_; }
+            cv_done_.notify_all();
+        }
+    }
+    static long window_us() {
+        static const long w = [] { const char* e = std::getenv("HP_COALESCE_WINDOW_US"); return e ? std::max(0l, std::atol(e)) : 200l; }();
+        return w;
+    }
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::deque<BlocksReq*> any_q_;
+    std::vector<std::deque<BlocksReq*>> dev_q_;
+    bool started_ = false;
+    int real_dev_ = 1, n_vdev_ = 1, idle_ = 0, counted_here_ = 0, peak_ = 0;
+};
+
+// a call with many blocks for the node's GPUs: LPT chunks through the dispatcher's queue
+int solve_blocks_over_devices(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out) {
+    BlockDispatcher& D = BlockDispatcher::get();
+    const int ndev = D.devices();
+    std::vector<uint32_t> order(n_blocks);
+    for (size_t i = 0; i < n_blocks; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return in[a].n_records > in[b].n_records; });
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_blocks; ++i) total += in[i].n_records + 1;
+    const uint64_t target = std::max<uint64_t>(1, total / ((uint64_t)ndev * 8));
+    struct Chunk { std::vector<uint32_t> ids; std::vector<hp_block_input> ci; std::vector<hp_block_output> co; BlocksReq req; };
+    std::vector<std::unique_ptr<Chunk>> chunks;
+    {
+        uint64_t acc = 0;
+        for (uint32_t b : order) {
+            if (chunks.empty() || (acc >= target && !chunks.back()->ids.empty())) { chunks.emplace_back(new Chunk()); acc = 0; }
+            chunks.back()->ids.push_back(b);
+            acc += in[b].n_records + 1;
+        }
+    }
+    std::vector<BlocksReq*> reqs;
+    for (auto& c : chunks) {
+        for (uint32_t b : c->ids) { c->ci.push_back(in[b]); c->co.push_back(out[b]); }
+        c->req = BlocksReq{c->ids.size(), c->ci.data(), *p, c->co.data(), -1};
+        reqs.push_back(&c->req);
+    }
+    D.submit(reqs.data(), reqs.size());
+    int rc = HP_OK;
+    for (auto& c : chunks) {
+        if (c->req.rc != HP_OK) { if (rc == HP_OK) { rc = c->req.rc; set_error("%s", c->req.err.c_str()); } continue; }
+        for (size_t k = 0; k < c->ids.size(); ++k) out[c->ids[k]] = c->co[k];
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id) {
     if (n_blocks == 0) return HP_OK;
     if (!in || !p || !out) { set_error("null argument"); return HP_ERR_ARG; }
-    if (!Combiner<BlocksReq>::enabled()) return solve_blocks_now(n_blocks, in, p, out, device_id);
-    if (device_id < 0 && n_blocks >= 2) return solve_blocks_now(n_blocks, in, p, out, -1);   // a whole batch for the node's GPUs: the block queue
-    BlocksReq r{n_blocks, in, *p, out, device_id < 0 ? hp_default_device() : device_id};
-    g_blocks_combiner().submit(&r);
+    if (hp_device_count() <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return HP_ERR_HIP; }
+    BlockDispatcher& D = BlockDispatcher::get();
+    if (device_id < 0 && n_blocks >= 2) {   // a whole batch for the node's GPUs
+        if (D.devices() == 1) return solve_blocks_on_device(n_blocks, in, p, out, hp_default_device());
+        return solve_blocks_over_devices(n_blocks, in, p, out);
+    }
+    if (!coalescing_enabled()) return solve_blocks_on_device(n_blocks, in, p, out, device_id < 0 ? hp_default_device() : device_id);
+    // one block (or a set for a named device) from one of many caller threads: merged with what else is in flight
+    if (D.entering.fetch_add(1, std::memory_order_acq_rel) == 0) {
+        // nobody else is inside: run on the caller's own thread (its caches are the warm ones for a single-threaded host);
+        // whoever arrives meanwhile queues for the service threads
+        D.lone.fetch_add(1, std::memory_order_acq_rel);
+        const int rc = solve_blocks_on_device(n_blocks, in, p, out, device_id < 0 ? hp_default_device() : device_id);
+        D.lone.fetch_sub(1, std::memory_order_acq_rel);
+        D.entering.fetch_sub(1, std::memory_order_acq_rel);
+        return rc;
+    }
+    BlocksReq r{n_blocks, in, *p, out, device_id};
+    r.counted = true;
+    BlocksReq* rp = &r;
+    D.submit(&rp, 1);
+    D.entering.fetch_sub(1, std::memory_order_acq_rel);
     if (r.rc != HP_OK) set_error("%s", r.err.c_str());
     return r.rc;
 }

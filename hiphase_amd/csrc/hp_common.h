@@ -38,6 +38,8 @@ void dev_cache_put(void* p, size_t bytes, int dev);
 // HP_HOST_THREADS if set, else hardware threads / processes per node (LOCAL_WORLD_SIZE as torchrun and friends export it: one
 // process per GPU, eight of them on one host must not each assume the whole machine), never below 2.
 unsigned host_threads(unsigned want);
+// a pipeline stage (hp_stream.hip) runs beside two others: its parallel regions take this fraction of the share (per thread; 0 = all)
+extern thread_local unsigned g_host_share_div;
 
 // number of compute units of a device, queried once (hipGetDeviceProperties costs milliseconds per call)
 int device_cu_count(int device_id);
@@ -49,6 +51,10 @@ int device_cu_count(int device_id);
 extern thread_local int g_cu_partition;
 hipError_t hp_stream_create(hipStream_t* s, int device_id, bool high_priority = false);
 int partition_cu_count(int device_id);   // CUs of the calling thread's current partition
+// The calling thread's own stream on `device` in its current CU partition (created on first use, lives as long as the thread):
+// what the small entry points launch on. Nothing in the library uses the NULL stream or hipDeviceSynchronize - a stage of a block
+// stream must never wait for another stage's kernels.
+hipStream_t thread_stream(int device_id);
 
 // A helper thread that lives as long as its owner: its thread-local device-buffer cache (below) then survives from one
 // task to the next (a fresh thread would hipMalloc every buffer again and hipFree it at exit, synchronising the device).

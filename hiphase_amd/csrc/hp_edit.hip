@@ -128,7 +128,7 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
     bytes.resize(bytes.size() + 16, 0);
     if (device_id < 0) device_id = hp_default_device();
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
-    const int n_cu = device_cu_count(device_id);
+    const int n_cu = partition_cu_count(device_id);
     // largest tables first (LPT). The order only balances the work list, so a counting sort over 65536 size classes
     // (O(n)) does as well as an exact sort
     std::vector<uint32_t> order(n);
@@ -151,9 +151,13 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
         (rc = d_out.alloc(n * 8)))
         return rc;
     if (max_short + 1 > lds_row_cap && (rc = d_scratch.alloc((size_t)slots * 2 * row_stride * 4)) != HP_OK) return rc;
-    HP_HIP_CHECK(hipMemcpy(d_pairs.p, dp.data(), n * sizeof(EdPairDev), hipMemcpyHostToDevice));
-    HP_HIP_CHECK(hipMemcpy(d_order.p, order.data(), n * 4, hipMemcpyHostToDevice));
-    HP_HIP_CHECK(hipMemcpy(d_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    // the calling thread's own stream; the call waits for that stream only (a block stream's other stages keep running)
+    hipStream_t stm = thread_stream(device_id);
+    if (!stm) { set_error("stream creation failed"); return HP_ERR_HIP; }
+    struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{stm};
+    HP_HIP_CHECK(hipMemcpyAsync(d_pairs.p, dp.data(), n * sizeof(EdPairDev), hipMemcpyHostToDevice, stm));
+    HP_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), n * 4, hipMemcpyHostToDevice, stm));
+    HP_HIP_CHECK(hipMemcpyAsync(d_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice, stm));
     EdBatchDev B{};
     B.pairs = d_pairs.as<EdPairDev>(); B.order = d_order.as<uint32_t>(); B.n_items = (uint32_t)n;
     B.bytes = d_bytes.as<uint8_t>(); B.out = d_out.as<uint64_t>(); B.scratch = d_scratch.as<uint32_t>();
@@ -161,16 +165,17 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
     hipEvent_t e0, e1;
     HP_HIP_CHECK(hipEventCreate(&e0));
     HP_HIP_CHECK(hipEventCreate(&e1));
-    HP_HIP_CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(hp_edit_kernel, dim3(slots), dim3(64), (size_t)lds_row_cap * 2 * 4, 0, B);
+    HP_HIP_CHECK(hipEventRecord(e0, stm));
+    hipLaunchKernelGGL(hp_edit_kernel, dim3(slots), dim3(64), (size_t)lds_row_cap * 2 * 4, stm, B);
     HP_HIP_CHECK(hipGetLastError());
-    HP_HIP_CHECK(hipEventRecord(e1, 0));
-    HP_HIP_CHECK(hipDeviceSynchronize());
+    HP_HIP_CHECK(hipEventRecord(e1, stm));
+    HP_HIP_CHECK(hipStreamSynchronize(stm));
     float kms = 0.f;
     HP_HIP_CHECK(hipEventElapsedTime(&kms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     g_last_kernel_ms = kms;
-    HP_HIP_CHECK(hipMemcpy(out, d_out.p, n * 8, hipMemcpyDeviceToHost));
+    HP_HIP_CHECK(hipMemcpyAsync(out, d_out.p, n * 8, hipMemcpyDeviceToHost, stm));
+    HP_HIP_CHECK(hipStreamSynchronize(stm));
     return HP_OK;
 }

@@ -71,6 +71,14 @@ struct hp_blockstream {
 void hp_blockstream::stage_loop(int k) {
     WorkerPool::set_thread_pool(pool[k].get());
     (void)hipSetDevice(device);
+    // The graph-WFA kernels are persistent and fill every compute unit they may use (three wavefronts per SIMD is all their
+    // registers allow): a kernel of another stage launched beside them waits until one of their workgroups leaves - the base
+    // expansion of the NEXT set, the A* and post-processing kernels of the PREVIOUS one. So the stages get compute units of
+    // their own (hp_common.h: CU partitions): graph-WFA seven CUs in eight, the other two stages share the eighth - the search
+    // is latency-bound (a block's heuristic chain is sequential) and only has to finish within the period of the WFA stage.
+    static const bool part = [] { const char* e = std::getenv("HP_STREAM_PARTITION"); return !(e && e[0] == '0'); }();
+    if (part) g_cu_partition = k == 1 ? 2 : 1;
+    g_host_share_div = k == 1 ? 4 : 2;   // the three stages' host threads together: about the process's share of the host
     for (;;) {
         Slot* s = nullptr;
         {

@@ -310,17 +310,6 @@ struct hp_synth_set {
     uint64_t hets = 0, records = 0, read_bases = 0, qnames = 0, input_bytes = 0;
 };
 
-struct hp_synth_outputs {
-    size_t n = 0;
-    std::vector<hp_block_output> out;
-    struct Store {
-        std::vector<uint8_t> h1, h2, seg_solver, seg_haplotag, seg_alleles, seg_quals;
-        std::vector<uint64_t> span_counts, seg_row_off, edit_distances;
-        std::vector<uint32_t> seg_qname, seg_start, seg_end, seg_first_het;
-    };
-    std::vector<Store> store;
-};
-
 extern "C" void hp_synth_reads_defaults(hp_synth_reads_spec* s) {
     if (!s) return;
     std::memset(s, 0, sizeof *s);
@@ -411,49 +400,3 @@ extern "C" const uint8_t* hp_synth_reads_truth(const hp_synth_set* s, size_t blo
 
 extern "C" void hp_synth_reads_destroy(hp_synth_set* s) { delete s; }
 
-extern "C" hp_synth_outputs* hp_synth_outputs_create(const hp_synth_set* s) {
-    if (!s) return nullptr;
-    auto o = std::unique_ptr<hp_synth_outputs>(new hp_synth_outputs());
-    o->n = s->inputs.size();
-    o->out.resize(o->n); o->store.resize(o->n);
-    for (size_t b = 0; b < o->n; ++b) {
-        const hp_block_input& I = s->inputs[b];
-        auto& st = o->store[b];
-        const size_t n = I.n_hets, q = std::max<uint32_t>(I.n_qnames, 1), cap = (size_t)s->blocks[b]->seg_cell_cap;
-        st.h1.assign(n, 0); st.h2.assign(n, 0); st.span_counts.assign(std::max<size_t>(n, 2) - 1, 0);
-        st.seg_qname.assign(q, 0); st.seg_start.assign(q, 0); st.seg_end.assign(q, 0); st.seg_solver.assign(q, 0); st.seg_haplotag.assign(q, 0);
-        st.seg_first_het.assign(q, 0); st.seg_row_off.assign(q + 1, 0); st.seg_alleles.assign(cap, 0); st.seg_quals.assign(cap, 0);
-        st.edit_distances.assign(std::max<uint32_t>(I.n_records, 1), 0);
-        hp_block_output& O = o->out[b];
-        O = hp_block_output{};
-        O.h1 = st.h1.data(); O.h2 = st.h2.data(); O.span_counts = st.span_counts.data();
-        O.seg_qname = st.seg_qname.data(); O.seg_start = st.seg_start.data(); O.seg_end = st.seg_end.data(); O.seg_solver = st.seg_solver.data();
-        O.seg_haplotag = st.seg_haplotag.data(); O.seg_first_het = st.seg_first_het.data(); O.seg_row_off = st.seg_row_off.data();
-        O.seg_alleles = st.seg_alleles.data(); O.seg_quals = st.seg_quals.data(); O.seg_cell_cap = cap;
-        O.edit_distances = st.edit_distances.data();
-    }
-    return o.release();
-}
-
-extern "C" hp_block_output* hp_synth_outputs_array(hp_synth_outputs* o) { return o ? o->out.data() : nullptr; }
-extern "C" void hp_synth_outputs_destroy(hp_synth_outputs* o) { delete o; }
-
-// every field hp_solve_blocks fills, block `b` of two output sets over the same inputs: 1 = identical
-extern "C" int hp_block_output_equal(const hp_block_input* in, const hp_block_output* a, const hp_block_output* b) {
-    if (!in || !a || !b) return 0;
-    const size_t N = in->n_hets;
-    if (a->status != b->status) return 0;
-    if (a->n_segments != b->n_segments || a->n_solver != b->n_solver || a->num_reads != b->num_reads || a->skipped_reads != b->skipped_reads ||
-        a->global_aligned != b->global_aligned || a->local_aligned != b->local_aligned || a->n_edit_distances != b->n_edit_distances) return 0;
-    if (a->n_edit_distances && std::memcmp(a->edit_distances, b->edit_distances, a->n_edit_distances * 8)) return 0;
-    const size_t ns = a->n_segments;
-    if (ns && (std::memcmp(a->seg_qname, b->seg_qname, ns * 4) || std::memcmp(a->seg_start, b->seg_start, ns * 4) || std::memcmp(a->seg_end, b->seg_end, ns * 4) ||
-               std::memcmp(a->seg_solver, b->seg_solver, ns) || std::memcmp(a->seg_row_off, b->seg_row_off, (ns + 1) * 8))) return 0;
-    const uint64_t cells = ns ? a->seg_row_off[ns] : 0;
-    if (cells && (std::memcmp(a->seg_alleles, b->seg_alleles, cells) || std::memcmp(a->seg_quals, b->seg_quals, cells))) return 0;
-    if (a->status != HP_OK) return 1;   // (an unsupported block carries segments only)
-    if (std::memcmp(a->h1, b->h1, N) || std::memcmp(a->h2, b->h2, N) || std::memcmp(&a->stats, &b->stats, sizeof a->stats)) return 0;
-    if (N > 1 && std::memcmp(a->span_counts, b->span_counts, (N - 1) * 8)) return 0;
-    if (ns && (std::memcmp(a->seg_haplotag, b->seg_haplotag, ns) || std::memcmp(a->seg_first_het, b->seg_first_het, ns * 4))) return 0;
-    return 1;
-}

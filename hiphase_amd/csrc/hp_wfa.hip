@@ -446,16 +446,18 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
     return HP_OK;
 }
 
-template <class T> int up(DevBuf& buf, StageVec<T>& v) {
+// (every copy and launch of a pass goes to the calling thread's own stream and the pass waits for THAT stream only: the pass may
+// run beside another stage's persistent kernels - a block stream - and must not wait for them)
+template <class T> int up(DevBuf& buf, StageVec<T>& v, hipStream_t st) {
     int rc = buf.alloc(v.size() * sizeof(T));
     if (rc != HP_OK) return rc;
-    if (v.size()) HP_HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (v.size()) HP_HIP_CHECK(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
     return HP_OK;
 }
-template <class T> int up(DevBuf& buf, const std::vector<T>& v) {
+template <class T> int up(DevBuf& buf, const std::vector<T>& v, hipStream_t st) {
     int rc = buf.alloc(v.size() * sizeof(T));
     if (rc != HP_OK) return rc;
-    if (!v.empty()) HP_HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!v.empty()) HP_HIP_CHECK(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
     return HP_OK;
 }
 
@@ -478,14 +480,19 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pk.jobs[a].read_len > pk.jobs[b].read_len; });
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const double t_pack = now_ms();
+    int cur_dev = 0;
+    HP_HIP_CHECK(hipGetDevice(&cur_dev));
+    hipStream_t stm = thread_stream(cur_dev);
+    if (!stm) { set_error("stream creation failed"); return HP_ERR_HIP; }
+    struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{stm};   // (host vectors below are read by async copies)
     DevBuf d_jobs, d_order, d_nodes, d_edges, d_seq, d_sets, d_score, d_status;
-    if ((rc = up(d_jobs, pk.jobs)) || (rc = up(d_order, order)) || (rc = up(d_nodes, pk.nodes)) || (rc = up(d_edges, pk.edges)) ||
+    if ((rc = up(d_jobs, pk.jobs, stm)) || (rc = up(d_order, order, stm)) || (rc = up(d_nodes, pk.nodes, stm)) || (rc = up(d_edges, pk.edges, stm)) ||
         (rc = d_seq.alloc(pk.seq.size())))
         return rc;
-    if (pk.seq.size()) HP_HIP_CHECK(hipMemcpy(d_seq.p, pk.seq.data(), pk.seq.size(), hipMemcpyHostToDevice));
+    if (pk.seq.size()) HP_HIP_CHECK(hipMemcpyAsync(d_seq.p, pk.seq.data(), pk.seq.size(), hipMemcpyHostToDevice, stm));
     if ((rc = d_sets.alloc(pk.out_set_words * 4 + 16)) || (rc = d_score.alloc(n * 8)) || (rc = d_status.alloc(n * 4))) return rc;
     std::vector<int32_t> st0(n, WFA_ST_PENDING);
-    HP_HIP_CHECK(hipMemcpy(d_status.p, st0.data(), n * 4, hipMemcpyHostToDevice));
+    HP_HIP_CHECK(hipMemcpyAsync(d_status.p, st0.data(), n * 4, hipMemcpyHostToDevice, stm));
     const uint32_t lds_nodes_off = (uint32_t)(((size_t)pk.max_nodes * WFA_NODE_STATE_BYTES + 15) & ~(size_t)15);
     const uint32_t lds_edges_off = lds_nodes_off + pk.max_nodes * 32;
     const size_t lds = big ? 0 : (size_t)lds_edges_off + (size_t)pk.max_edges * sizeof(WfaEdge);   // big graphs: state in HBM, tables read in place
@@ -501,15 +508,13 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     const size_t per_slot = (size_t)stride * 4;
     uint32_t slots = (uint32_t)std::min<size_t>({n, (size_t)n_cu * per_cu, std::max<size_t>(1, (free_b / 2) / std::max<size_t>(per_slot, 1))});
     if (slots == 0) slots = 1;
-    int cur_dev = 0;
-    HP_HIP_CHECK(hipGetDevice(&cur_dev));
     if (g_ctx.device != cur_dev) { g_ctx.scratch.release(); g_ctx.device = cur_dev; g_ctx.dirty = true; }
     if (g_ctx.scratch.bytes < (size_t)slots * per_slot) {
         if ((rc = g_ctx.scratch.alloc((size_t)slots * per_slot)) != HP_OK) return rc;
         g_ctx.dirty = true;
     }
     if (g_ctx.dirty) {
-        HP_HIP_CHECK(hipMemset(g_ctx.scratch.p, 0, g_ctx.scratch.bytes));
+        HP_HIP_CHECK(hipMemsetAsync(g_ctx.scratch.p, 0, g_ctx.scratch.bytes, stm));
         g_ctx.dirty = false;
     }
     const double t_up = now_ms();
@@ -530,12 +535,12 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     hipEvent_t e0, e1;
     HP_HIP_CHECK(hipEventCreate(&e0));
     HP_HIP_CHECK(hipEventCreate(&e1));
-    HP_HIP_CHECK(hipEventRecord(e0, 0));
-    if (big) hipLaunchKernelGGL(hp_wfa_big_kernel, dim3(slots), dim3(64), 0, 0, B);
-    else hipLaunchKernelGGL(hp_wfa_kernel, dim3(slots), dim3(64), lds, 0, B);
+    HP_HIP_CHECK(hipEventRecord(e0, stm));
+    if (big) hipLaunchKernelGGL(hp_wfa_big_kernel, dim3(slots), dim3(64), 0, stm, B);
+    else hipLaunchKernelGGL(hp_wfa_kernel, dim3(slots), dim3(64), lds, stm, B);
     HP_HIP_CHECK(hipGetLastError());
-    HP_HIP_CHECK(hipEventRecord(e1, 0));
-    if (hipDeviceSynchronize() != hipSuccess) { g_ctx.dirty = true; set_error("WFA kernel failed"); return HP_ERR_HIP; }
+    HP_HIP_CHECK(hipEventRecord(e1, stm));
+    if (hipStreamSynchronize(stm) != hipSuccess) { g_ctx.dirty = true; set_error("WFA kernel failed"); return HP_ERR_HIP; }
     float kms = 0.f;
     HP_HIP_CHECK(hipEventElapsedTime(&kms, e0, e1));
     (void)hipEventDestroy(e0);
@@ -546,9 +551,10 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     std::vector<int32_t> st(n);
     std::vector<uint64_t> sc(n);
     std::vector<uint32_t> all_sets(pk.out_set_words + 4);
-    HP_HIP_CHECK(hipMemcpy(st.data(), d_status.p, n * 4, hipMemcpyDeviceToHost));
-    HP_HIP_CHECK(hipMemcpy(sc.data(), d_score.p, n * 8, hipMemcpyDeviceToHost));
-    HP_HIP_CHECK(hipMemcpy(all_sets.data(), d_sets.p, pk.out_set_words * 4, hipMemcpyDeviceToHost));
+    HP_HIP_CHECK(hipMemcpyAsync(st.data(), d_status.p, n * 4, hipMemcpyDeviceToHost, stm));
+    HP_HIP_CHECK(hipMemcpyAsync(sc.data(), d_score.p, n * 8, hipMemcpyDeviceToHost, stm));
+    HP_HIP_CHECK(hipMemcpyAsync(all_sets.data(), d_sets.p, pk.out_set_words * 4, hipMemcpyDeviceToHost, stm));
+    if (hipStreamSynchronize(stm) != hipSuccess) { set_error("WFA result download failed"); return HP_ERR_HIP; }
     for (size_t i = 0; i < n; ++i) {
         status[ids[i]] = st[i];
         score[ids[i]] = sc[i];

@@ -34,7 +34,7 @@ class SynthSet:
         self.info = dict(zip(("blocks", "hets", "records", "read_bases", "qnames", "input_bytes", "max_block_hets"), list(info)))
 
     def outputs(self):
-        return SynthOutputs(self)
+        return Outputs(self.dll, self.inputs, self.n)
 
     def truth(self, b):
         p = self.dll.hp_synth_reads_truth(self.h, b)
@@ -49,18 +49,51 @@ class SynthSet:
         self.close()
 
 
-class SynthOutputs:
-    def __init__(self, sset):
-        self.sset = sset
-        self.h = sset.dll.hp_synth_outputs_create(sset.h)
-        self.arr = sset.dll.hp_synth_outputs_array(self.h)
+class Outputs:
+    """caller-side result buffers for `n` blocks (hp_outputs_*)"""
+
+    def __init__(self, dll, inputs, n):
+        self.dll, self.inputs, self.n = dll, inputs, n
+        self.h = dll.hp_outputs_create(inputs, n)
+        self.arr = dll.hp_outputs_array(self.h)
 
     def equal(self, other, b):
-        return bool(self.sset.dll.hp_block_output_equal(C.byref(self.sset.inputs[b]), C.byref(self.arr[b]), C.byref(other.arr[b])))
+        return bool(self.dll.hp_block_output_equal(C.byref(self.inputs[b]), C.byref(self.arr[b]), C.byref(other.arr[b])))
 
     def close(self):
         if self.h:
-            self.sset.dll.hp_synth_outputs_destroy(self.h)
+            self.dll.hp_outputs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Capture:
+    """A `.hpbr` read-bearing capture loaded back (hp_hpbr_*): `.inputs`, `.n`, `.params`, `.expected` (status INT32_MIN = none)."""
+
+    def __init__(self, path, dll=None):
+        self.dll = dll or _ffi.lib()
+        st = C.c_int(0)
+        self.h = self.dll.hp_hpbr_open(str(path).encode(), C.byref(st))
+        if not self.h:
+            raise _ffi.HpError(st.value, self.dll.hp_hpbr_last_error().decode())
+        n = C.c_size_t(0)
+        self.inputs = self.dll.hp_hpbr_inputs(self.h, C.byref(n))
+        self.n = n.value
+        self.params = self.dll.hp_hpbr_params(self.h)
+        self.expected = self.dll.hp_hpbr_expected(self.h)
+        self.info = {"blocks": self.n, "hets": sum(self.inputs[b].n_hets for b in range(self.n)),
+                     "records": sum(self.inputs[b].n_records for b in range(self.n)),
+                     "read_bases": sum(self.inputs[b].records[r].read_len for b in range(self.n) for r in range(self.inputs[b].n_records)),
+                     "max_block_hets": max([self.inputs[b].n_hets for b in range(self.n)] or [0])}
+
+    def outputs(self):
+        return Outputs(self.dll, self.inputs, self.n)
+
+    def close(self):
+        if self.h:
+            self.dll.hp_hpbr_close(self.h)
             self.h = None
 
     def __del__(self):

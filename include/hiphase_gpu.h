@@ -421,7 +421,6 @@ typedef struct hp_synth_reads_spec {
     uint32_t threads;           /* host threads for the generation; 0 = up to 32 */
 } hp_synth_reads_spec;
 typedef struct hp_synth_set hp_synth_set;
-typedef struct hp_synth_outputs hp_synth_outputs;
 void hp_synth_reads_defaults(hp_synth_reads_spec* s);   /* the bench workload: 60 000 hets, 30x, 15 kb reads, 0.5 % edit noise, BAM 4-bit */
 hp_synth_set* hp_synth_reads_create(const hp_synth_reads_spec* s, int* status);
 const hp_block_input* hp_synth_reads_inputs(const hp_synth_set* s, size_t* n_blocks);
@@ -429,12 +428,29 @@ const hp_block_input* hp_synth_reads_inputs(const hp_synth_set* s, size_t* n_blo
 void hp_synth_reads_info(const hp_synth_set* s, uint64_t out[8]);
 const uint8_t* hp_synth_reads_truth(const hp_synth_set* s, size_t block);   /* [n_hets] the allele haplotype 0 carries */
 void hp_synth_reads_destroy(hp_synth_set* s);
-/* caller-side output buffers for every block of a set, sized from the inputs */
-hp_synth_outputs* hp_synth_outputs_create(const hp_synth_set* s);
-hp_block_output* hp_synth_outputs_array(hp_synth_outputs* o);
-void hp_synth_outputs_destroy(hp_synth_outputs* o);
+
+/* ---- caller-side helpers around the block entries (hp_capture.cpp; host-only) ------------------------------------------------- */
+/* Output buffers for n blocks, every array of hp_block_output allocated and sized from the inputs (seg_cell_cap: per read name
+ * the hull of its records' het ranges). */
+typedef struct hp_outputs hp_outputs;
+hp_outputs* hp_outputs_create(const hp_block_input* in, size_t n);
+hp_block_output* hp_outputs_array(hp_outputs* o);
+void hp_outputs_destroy(hp_outputs* o);
 /* 1 when two outputs of the same block hold the same results in every field hp_solve_blocks fills, else 0 */
 int hp_block_output_equal(const hp_block_input* in, const hp_block_output* a, const hp_block_output* b);
+/* `.hpbr`: READ-BEARING capture of phase blocks - everything hp_solve_blocks reads for a block (reference hull, variant calls,
+ * records with their bases and CIGAR views, parameters) and, when `expected` is given, the results the caller's own solve_block
+ * produced for it. A HiPhase built with the patch of INTEGRATION.md 6 writes the real HG002 blocks this repository cannot
+ * produce (BASELINE.json configs[2-4]); hp_hpbr_open loads a capture back as hp_block_input arrays (valid until hp_hpbr_close)
+ * for hp_solve_blocks / hp_blockstream_submit / `bench.py --replay`. expected[i].status == INT32_MIN: no expected output stored. */
+int hp_hpbr_append(const char* path, const hp_block_input* block, const hp_block_params* p, const hp_block_output* expected);
+typedef struct hp_hpbr hp_hpbr;
+hp_hpbr* hp_hpbr_open(const char* path, int* status);
+const hp_block_input*  hp_hpbr_inputs(const hp_hpbr* h, size_t* n_blocks);
+const hp_block_params* hp_hpbr_params(const hp_hpbr* h);      /* [n_blocks] */
+const hp_block_output* hp_hpbr_expected(const hp_hpbr* h);    /* [n_blocks] */
+void hp_hpbr_close(hp_hpbr* h);
+const char* hp_hpbr_last_error(void);
 
 #ifdef __cplusplus
 }

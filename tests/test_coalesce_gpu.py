@@ -71,6 +71,29 @@ def test_worker_pool_rate_from_cpp():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("queue_devices", ["3", None])
+def test_worker_pool_through_the_block_entry_over_all_devices(queue_devices):
+    """64 std::threads each calling hp_solve_blocks(1, ..., device_id = -1) - what the one-call-site Rust patch does from HiPhase's
+    worker pool - with the dispatcher's queue served by three "devices" (HP_QUEUE_WORKERS=3 on this 1-GPU box) and by the visible
+    ones: every block identical to one hp_solve_blocks call over all blocks (tests/cpp/dispatch_test.cpp); the rates are printed."""
+    import json
+    import os
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    binp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "dispatch_test")
+    env = dict(os.environ)
+    env.pop("HP_QUEUE_WORKERS", None)
+    if queue_devices:
+        env["HP_QUEUE_WORKERS"] = queue_devices
+    r = subprocess.run([binp, "64", "4000"], capture_output=True, text=True, timeout=800, env=env)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["mismatching_blocks"] == 0 and out["failed_calls"] == 0 and out["blocks"] > 64
+
+
 def test_concurrent_solve_blocks_is_merged_and_identical():
     n_thr = 16
     specs = []
