@@ -46,12 +46,19 @@ struct BlockState {         // per block, rebuilt by every solve
     std::vector<uint32_t> read_start, read_end;
     std::vector<uint64_t> row_off;
     std::vector<uint8_t> alleles_2bit, quals, var_flags;
+    // local re-alignment rows of the records that need them (fallbacks; every record in local mode): slot per record, -1 = none
+    std::vector<int64_t> local_slot;
+    std::vector<uint8_t> loc_alleles, loc_quals;
+    std::vector<hp_read_stats> loc_stats;
+    std::vector<uint32_t> loc_need;       // records of the pre-pass (blockset_tail gathers them over all blocks: one device launch)
+    std::vector<hp_local_read> loc_reads;
     Arena arena;
     void reset() {   // keeps every capacity
         segs.clear(); seg_qname.clear(); seg_solver.clear(); solver_rows.clear();
         num_reads = skipped_reads = global_aligned = local_aligned = 0;
         edit_distances.clear(); read_start.clear(); read_end.clear(); row_off.clear();
         alleles_2bit.clear(); quals.clear(); var_flags.clear();
+        local_slot.clear(); loc_alleles.clear(); loc_quals.clear(); loc_stats.clear(); loc_need.clear(); loc_reads.clear();
         arena.reset();
     }
 };

@@ -244,18 +244,57 @@ namespace {
 
 // load_full_read_segments' tail for one block (read_parsing.rs:546-629) once every record's WFA outcome is known:
 // fallback to local re-alignment, the global_disabled switch in BAM order, qualities, ReadSegment::new, collapse, split
+// the records of block b whose local re-alignment is known to be needed before the replay: every record in local mode
+// (read_parsing.rs:47-113), the records whose graph-WFA ran into max_edit_distance otherwise (:564-575). Resets the block's state.
+int local_needs(hp_blockset* bs, size_t b) {
+    const hp_block_input& B = bs->in[b];
+    BlockState& S = bs->st[b];
+    S.reset();
+    const uint32_t R = B.n_records;
+    S.local_slot.assign(R, -1);
+    if (!bs->prm.global_realignment) { S.loc_need.resize(R); for (uint32_t i = 0; i < R; ++i) S.loc_need[i] = i; }
+    else {
+        const std::vector<RecMeta>& meta = bs->meta[b];
+        for (uint32_t i = 0; i < R; ++i) if (meta[i].job >= 0 && bs->wfa_out[(size_t)meta[i].job].status == HP_WFA_MAX_ED) S.loc_need.push_back(i);
+    }
+    if (S.loc_need.empty()) return HP_OK;
+    if (!B.local_hets) { set_error("block %zu: a record needs local re-alignment (read_parsing.rs:121-503) but local_hets is NULL", b); return HP_ERR_ARG; }
+    S.loc_reads.resize(S.loc_need.size());
+    for (size_t k = 0; k < S.loc_need.size(); ++k) {
+        if (!B.records[S.loc_need[k]].local) { set_error("block %zu record %u needs local re-alignment but has no CIGAR view", b, S.loc_need[k]); return HP_ERR_ARG; }
+        S.loc_reads[k] = *B.records[S.loc_need[k]].local;
+    }
+    const size_t N = B.n_hets;
+    S.loc_alleles.resize(S.loc_need.size() * N); S.loc_quals.resize(S.loc_need.size() * N); S.loc_stats.resize(S.loc_need.size());
+    for (size_t k = 0; k < S.loc_need.size(); ++k) S.local_slot[S.loc_need[k]] = (int64_t)k;
+    return HP_OK;
+}
+
+// local re-alignment for the listed blocks' needs: ONE device launch over all of them (a block with a handful of fallbacks used
+// to make a launch of its own - a few hundred small launches per set, each waiting its turn on the device)
+int local_prepass(hp_blockset* bs, const std::vector<size_t>& blocks) {
+    std::vector<LocalGroup> groups;
+    for (size_t b : blocks) {
+        BlockState& S = bs->st[b];
+        if (S.loc_need.empty()) continue;
+        groups.push_back(LocalGroup{S.loc_reads.data(), S.loc_reads.size(), bs->in[b].local_hets, bs->in[b].n_hets, S.loc_alleles.data(), S.loc_quals.data(), S.loc_stats.data()});
+    }
+    return groups.empty() ? HP_OK : local_realign_groups(groups.data(), groups.size(), bs->device);
+}
+
 int assemble_block(hp_blockset* bs, size_t b) {
     const hp_blockset& CH = *bs;
     const hp_block_input& B = bs->in[b];
     const hp_block_params& P = bs->prm;
     BlockState& S = bs->st[b];
-    S.reset();
     const uint32_t N = B.n_hets, R = B.n_records;
     const std::vector<RecMeta>& meta = bs->meta[b];
-    // local re-alignment rows (one batch call per need; a record's local result does not depend on any other record)
-    std::vector<int64_t> local_slot(R, -1);
-    std::vector<uint8_t> loc_alleles, loc_quals;
-    std::vector<hp_read_stats> loc_stats;
+    // local re-alignment rows: the pre-pass (local_needs + local_prepass) has the ones known up front; the `global_disabled`
+    // switch (below) may ask for more (a record's local result does not depend on any other record)
+    std::vector<int64_t>& local_slot = S.local_slot;
+    std::vector<uint8_t>& loc_alleles = S.loc_alleles;
+    std::vector<uint8_t>& loc_quals = S.loc_quals;
+    std::vector<hp_read_stats>& loc_stats = S.loc_stats;
     auto solve_local = [&](const std::vector<uint32_t>& idx) -> int {
         std::vector<uint32_t> need;
         for (uint32_t i : idx) if (local_slot[i] < 0) need.push_back(i);
@@ -277,15 +316,6 @@ int assemble_block(hp_blockset* bs, size_t b) {
         return HP_OK;
     };
     int rc;
-    if (!P.global_realignment) {   // load_read_segments (read_parsing.rs:47-113): every record through local_realignment
-        std::vector<uint32_t> all(R);
-        for (uint32_t i = 0; i < R; ++i) all[i] = i;
-        if ((rc = solve_local(all)) != HP_OK) return rc;
-    } else {
-        std::vector<uint32_t> failed;
-        for (uint32_t i = 0; i < R; ++i) if (meta[i].job >= 0 && CH.wfa_out[(size_t)meta[i].job].status == HP_WFA_MAX_ED) failed.push_back(i);
-        if ((rc = solve_local(failed)) != HP_OK) return rc;
-    }
     // per read name: the segments of its records, in BAM order
     // (a linked list per read name through the records' own segments: almost every read name has one record, and a
     // vector per name would cost an allocation per read)
@@ -492,44 +522,42 @@ int hp::blockset_tail(hp_blockset* bs, hp_block_output* out) {
             }
         }
         const bool dbg = std::getenv("HP_DEBUG") != nullptr;
-        std::vector<double> dbg_sum(std::max(1u, nt), 0.0), dbg_max(std::max(1u, nt), 0.0);
-        std::vector<size_t> dbg_arg(std::max(1u, nt), 0);
-        std::mutex gate_m;
-        bool gate_open = false;
-        std::atomic<size_t> next{0};
-        std::atomic<int> first_rc{HP_OK};
         std::vector<std::string> errs(std::max(1u, nt));
-        auto work = [&](unsigned t) {
-            for (;;) {
-                const size_t k = next.fetch_add(1);
-                if (k >= order.size() || first_rc.load() != HP_OK) return;
-                if (k >= n_free) {
-                    std::lock_guard<std::mutex> lk(gate_m);
-                    if (!gate_open) {
-                        const int r = w2_session_finish(ch.wfa);
-                        gate_open = true;
+        std::atomic<int> first_rc{HP_OK};
+        // one phase = the blocks order[lo, hi): which of their records need local re-alignment (host threads), ONE local
+        // re-alignment launch for all of them, then replay / qualities / collapse / solver rows per block (host threads)
+        auto phase = [&](size_t lo, size_t hi) -> int {
+            if (lo >= hi) return HP_OK;
+            const double ta = blk_now_ms();
+            for (int pass = 0; pass < 2; ++pass) {
+                std::atomic<size_t> next{lo};
+                WorkerPool::get().run(std::max(1u, (unsigned)std::min<size_t>(nt, hi - lo)), [&](unsigned t) {
+                    for (;;) {
+                        const size_t k = next.fetch_add(1);
+                        if (k >= hi || first_rc.load() != HP_OK) return;
+                        const int r = pass == 0 ? local_needs(bs, order[k]) : assemble_block(bs, order[k]);
                         if (r != HP_OK) { int exp = HP_OK; if (first_rc.compare_exchange_strong(exp, r)) errs[t] = hp_last_error(); return; }
                     }
+                });
+                if (first_rc.load() != HP_OK) {
+                    for (auto& e : errs) if (!e.empty()) { set_error("%s", e.c_str()); break; }
+                    return first_rc.load();
                 }
-                const double ta = dbg ? blk_now_ms() : 0.0;
-                const int r = assemble_block(bs, order[k]);
-                if (dbg) { const double d = blk_now_ms() - ta; dbg_sum[t] += d; if (d > dbg_max[t]) { dbg_max[t] = d; dbg_arg[t] = order[k]; } }
-                if (r != HP_OK) { int exp = HP_OK; if (first_rc.compare_exchange_strong(exp, r)) errs[t] = hp_last_error(); return; }
+                if (pass == 0) {
+                    const std::vector<size_t> blocks(order.begin() + (ptrdiff_t)lo, order.begin() + (ptrdiff_t)hi);
+                    const int r = local_prepass(bs, blocks);
+                    if (r != HP_OK) return r;
+                }
             }
+            if (dbg) fprintf(stderr, "[hp] rows: %zu blocks on %u threads in %.2f ms\n", hi - lo, nt, blk_now_ms() - ta);
+            return HP_OK;
         };
-        WorkerPool::get().run(std::max(1u, nt), work);
-        if (first_rc.load() != HP_OK) {
-            for (auto& e : errs) if (!e.empty()) { set_error("%s", e.c_str()); break; }
-            return first_rc.load();
-        }
-        if (has_wfa && (rc = w2_session_finish(ch.wfa)) != HP_OK) return rc;   // (already done unless no block was held)
+        // the blocks that wait for nothing first; then the ones that hold a read the second collection / the dense-band pass
+        // delivers (that pass has had the first phase to finish in)
+        if ((rc = phase(0, n_free)) != HP_OK) return rc;
+        if (has_wfa && (rc = w2_session_finish(ch.wfa)) != HP_OK) return rc;
+        if ((rc = phase(n_free, order.size())) != HP_OK) return rc;
         if (has_wfa) ch.ms[6] = w2_session_span_ms(ch.wfa);
-        if (dbg) {
-            double s = 0.0, m = 0.0; size_t arg = 0;
-            for (unsigned i = 0; i < std::max(1u, nt); ++i) { s += dbg_sum[i]; if (dbg_max[i] > m) { m = dbg_max[i]; arg = dbg_arg[i]; } }
-            fprintf(stderr, "[hp] rows: %zu blocks on %u threads, %.2f ms of assembly in total, the slowest block (%u hets, %u records) %.2f ms, %zu blocks held for leftovers\n",
-                    order.size(), nt, s, bs->in[arg].n_hets, bs->in[arg].n_records, m, order.size() - n_free);
-        }
     }
     const double t2 = blk_now_ms();
     // ---- A* over the chunk's blocks ----

@@ -172,6 +172,15 @@ inline void decode_bam4(const uint8_t* src, uint64_t first_base, uint64_t n, uin
     }
 }
 
+// hp_local.hip: local_realignment (reference src/read_parsing.rs:121-503) for the records of several blocks in one go - every
+// group with its own variant list; alleles / quals: n_reads x n_variants rows; stats may be NULL
+struct LocalGroup {
+    const hp_local_read* reads; size_t n_reads;
+    const hp_local_variant* variants; size_t n_variants;
+    uint8_t* alleles; uint8_t* quals; hp_read_stats* stats;
+};
+int local_realign_groups(LocalGroup* groups, size_t n_groups, int device_id);
+
 // grow-only pinned staging (DMA straight from it; never value-initialised)
 struct PinBuf {
     uint8_t* p = nullptr;

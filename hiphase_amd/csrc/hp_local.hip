@@ -204,101 +204,124 @@ int realign_one(const hp_local_read& rd, uint32_t ri, const hp_local_variant* va
 
 using namespace hp;
 
-extern "C" int hp_local_realign_batch(const hp_local_read* reads_in, size_t n_reads, const hp_local_variant* variants,
-                                      size_t n_variants, uint8_t* alleles, uint8_t* quals, hp_read_stats* stats, int device_id) {
-    if (n_reads == 0) return HP_OK;
-    if (!reads_in || (n_variants && (!variants || !alleles || !quals))) { set_error("null argument"); return HP_ERR_ARG; }
-    // records handed over in the BAM's own 4-bit encoding (HP_SEQ_BAM4) are decoded here, exactly as read.seq().as_bytes() does
-    // (read_parsing.rs:151): local re-alignment sees a few records per block (the fallbacks) or runs in local mode
-    const hp_local_read* reads = reads_in;
-    std::vector<hp_local_read> decoded_reads;
-    std::vector<std::vector<uint8_t>> decoded_seq;
-    for (size_t r = 0; r < n_reads; ++r) {
-        if (reads_in[r].seq_format == HP_SEQ_ASCII) continue;
-        if (reads_in[r].seq_format != HP_SEQ_BAM4) { set_error("record %zu: unknown seq_format %u", r, reads_in[r].seq_format); return HP_ERR_ARG; }
-        if (decoded_reads.empty()) decoded_reads.assign(reads_in, reads_in + n_reads);
-        if (reads_in[r].seq_len && !reads_in[r].seq) { set_error("record %zu: null buffer", r); return HP_ERR_ARG; }
-        decoded_seq.emplace_back((size_t)reads_in[r].seq_len + 1);
-        decode_bam4(reads_in[r].seq, 0, reads_in[r].seq_len, decoded_seq.back().data());
-        decoded_reads[r].seq = decoded_seq.back().data();
-        decoded_reads[r].seq_format = HP_SEQ_ASCII;
-    }
-    if (!decoded_reads.empty()) reads = decoded_reads.data();
-    if (n_reads > 0x7FFFFFFFull || n_variants > 0x7FFFFFFFull) { set_error("batch too large"); return HP_ERR_ARG; }
-    for (size_t i = 0; i < n_variants; ++i) {
-        const hp_local_variant& v = variants[i];
-        if (v.variant_type > VT_UNKNOWN) { set_error("variant %zu: invalid variant_type %u", i, v.variant_type); return HP_ERR_ARG; }
-        if ((uint64_t)v.prefix_len + v.postfix_len > std::min(v.allele0_len, v.allele1_len) || v.position < (int64_t)v.prefix_len ||
-            (v.allele0_len && !v.allele0) || (v.allele1_len && !v.allele1)) {
-            set_error("variant %zu: alleles shorter than prefix + postfix, prefix reaching below coordinate 0, or null allele", i);
-            return HP_ERR_ARG;
-        }
-    }
-    for (size_t r = 0; r < n_reads; ++r) {
-        if ((reads[r].n_cigar && !reads[r].cigar) || (reads[r].seq_len && (!reads[r].seq || !reads[r].qual)) || reads[r].pos < 0) {
-            set_error("record %zu: null buffer or negative position", r);
-            return HP_ERR_ARG;
-        }
-    }
+// local_realignment for the records of SEVERAL blocks at once (hp_block.hip: the fallbacks of a whole block set): the
+// coordinate logic per (group, record) on host threads, then ONE Levenshtein launch for every inexact allele of every group.
+int hp::local_realign_groups(LocalGroup* groups, size_t n_groups, int device_id) {
+    if (n_groups == 0) return HP_OK;
+    if (!groups) { set_error("null argument"); return HP_ERR_ARG; }
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t0 = now_ms();
-    std::vector<uint8_t> flags(n_reads * n_variants);
+    // ---- validation; records handed over in the BAM's own 4-bit encoding (HP_SEQ_BAM4) are decoded here, exactly as
+    // read.seq().as_bytes() does (read_parsing.rs:151): a few records per block (the fallbacks), or everything in local mode ----
+    struct GroupState { std::vector<hp_local_read> reads; std::vector<std::vector<uint8_t>> seqs; const hp_local_read* rd = nullptr; std::vector<uint8_t> flags; size_t first_item = 0; };
+    std::vector<GroupState> gs(n_groups);
+    size_t n_items = 0;
+    for (size_t g = 0; g < n_groups; ++g) {
+        LocalGroup& G = groups[g];
+        GroupState& S = gs[g];
+        S.first_item = n_items;
+        n_items += G.n_reads;
+        if (G.n_reads == 0) continue;
+        if (!G.reads || (G.n_variants && (!G.variants || !G.alleles || !G.quals))) { set_error("null argument"); return HP_ERR_ARG; }
+        if (G.n_reads > 0x7FFFFFFFull || G.n_variants > 0x7FFFFFFFull) { set_error("batch too large"); return HP_ERR_ARG; }
+        S.rd = G.reads;
+        for (size_t r = 0; r < G.n_reads; ++r) {
+            const hp_local_read& R = G.reads[r];
+            if (R.seq_format == HP_SEQ_ASCII) continue;
+            if (R.seq_format != HP_SEQ_BAM4) { set_error("record %zu: unknown seq_format %u", r, R.seq_format); return HP_ERR_ARG; }
+            if (S.reads.empty()) S.reads.assign(G.reads, G.reads + G.n_reads);
+            if (R.seq_len && !R.seq) { set_error("record %zu: null buffer", r); return HP_ERR_ARG; }
+            S.seqs.emplace_back((size_t)R.seq_len + 1);
+            decode_bam4(R.seq, 0, R.seq_len, S.seqs.back().data());
+            S.reads[r].seq = S.seqs.back().data();
+            S.reads[r].seq_format = HP_SEQ_ASCII;
+        }
+        if (!S.reads.empty()) S.rd = S.reads.data();
+        for (size_t i = 0; i < G.n_variants; ++i) {
+            const hp_local_variant& v = G.variants[i];
+            if (v.variant_type > VT_UNKNOWN) { set_error("variant %zu: invalid variant_type %u", i, v.variant_type); return HP_ERR_ARG; }
+            if ((uint64_t)v.prefix_len + v.postfix_len > std::min(v.allele0_len, v.allele1_len) || v.position < (int64_t)v.prefix_len ||
+                (v.allele0_len && !v.allele0) || (v.allele1_len && !v.allele1)) {
+                set_error("variant %zu: alleles shorter than prefix + postfix, prefix reaching below coordinate 0, or null allele", i);
+                return HP_ERR_ARG;
+            }
+        }
+        for (size_t r = 0; r < G.n_reads; ++r) {
+            if ((S.rd[r].n_cigar && !S.rd[r].cigar) || (S.rd[r].seq_len && (!S.rd[r].seq || !S.rd[r].qual)) || S.rd[r].pos < 0) {
+                set_error("record %zu: null buffer or negative position", r);
+                return HP_ERR_ARG;
+            }
+        }
+        S.flags.assign(G.n_reads * G.n_variants, 0);
+    }
+    if (n_items == 0) return HP_OK;
+    // ---- coordinates: host threads over (group, record) ----
     unsigned nt = host_threads(16u);
     if (const char* e = std::getenv("HP_LOCAL_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
-    nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)nt, (size_t)16, n_reads / 32 + 1}));
-    std::vector<Worker> workers(nt);
+    nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)nt, (size_t)16, n_items / 32 + 1}));
+    struct GWorker { Worker w; std::vector<uint32_t> pend_group; };   // group of each pending entry, in order
+    std::vector<GWorker> workers(nt);
     auto body = [&](unsigned t) {
-        Worker& w = workers[t];
-        const size_t lo = n_reads * t / nt, hi = n_reads * (t + 1) / nt;
-        for (size_t r = lo; r < hi && w.rc == HP_OK; ++r)
-            w.rc = realign_one(reads[r], (uint32_t)r, variants, n_variants, alleles + r * n_variants, quals + r * n_variants,
-                               flags.data() + r * n_variants, w);
+        GWorker& W = workers[t];
+        const size_t lo = n_items * t / nt, hi = n_items * (t + 1) / nt;
+        for (size_t it = lo; it < hi && W.w.rc == HP_OK; ++it) {
+            // the group of item `it`: the last one that starts at or before it (empty groups share their start with the next)
+            size_t a = 0, b = n_groups;
+            while (b - a > 1) { const size_t m = (a + b) / 2; if (gs[m].first_item <= it) a = m; else b = m; }
+            const size_t g = a, r = it - gs[g].first_item;
+            const LocalGroup& G = groups[g];
+            W.w.rc = realign_one(gs[g].rd[r], (uint32_t)r, G.variants, G.n_variants, G.alleles + r * G.n_variants, G.quals + r * G.n_variants,
+                                 gs[g].flags.data() + r * G.n_variants, W.w);
+            W.pend_group.resize(W.w.pending.size(), (uint32_t)g);
+        }
     };
     if (nt == 1) body(0);
-    else {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t) th.emplace_back(body, t);
-        for (auto& x : th) x.join();
-    }
+    else WorkerPool::get().run(nt, body);
     const double t1 = now_ms();
     size_t n_pending = 0;
-    for (auto& w : workers) {
-        if (w.rc != HP_OK) { set_error("%s", w.err.c_str()); return w.rc; }
-        n_pending += w.pending.size();
+    for (auto& W : workers) {
+        if (W.w.rc != HP_OK) { set_error("%s", W.w.err.c_str()); return W.w.rc; }
+        n_pending += W.w.pending.size();
     }
-    // every inexact allele of the batch: d0, d1 = edit_distance(obs, allele{0,1}[head .. len - tail]) on the device
+    // ---- every inexact allele of every group: d0, d1 = edit_distance(obs, allele{0,1}[head .. len - tail]) in one launch ----
     if (n_pending) {
         std::vector<hp_ed_pair> pairs;
         pairs.reserve(2 * n_pending);
-        for (auto& w : workers)
-            for (const Pending& p : w.pending) {
-                const hp_local_variant& v = variants[p.var];
-                const uint8_t* obs = reads[p.read].seq + p.ss;
+        for (auto& W : workers)
+            for (size_t k = 0; k < W.w.pending.size(); ++k) {
+                const Pending& p = W.w.pending[k];
+                const uint32_t g = W.pend_group[k];
+                const hp_local_variant& v = groups[g].variants[p.var];
+                const uint8_t* obs = gs[g].rd[p.read].seq + p.ss;
                 pairs.push_back(hp_ed_pair{obs, v.allele0 + p.head, p.se - p.ss, v.allele0_len - p.head - p.tail});
                 pairs.push_back(hp_ed_pair{obs, v.allele1 + p.head, p.se - p.ss, v.allele1_len - p.head - p.tail});
             }
         std::vector<uint64_t> dist(pairs.size());
         const int rc = hp_edit_distance_batch(pairs.data(), pairs.size(), dist.data(), device_id);
         if (rc != HP_OK) return rc;
-        size_t k = 0;
-        for (auto& w : workers)
-            for (const Pending& p : w.pending) {
-                const uint64_t d0 = dist[k], d1 = dist[k + 1];
-                k += 2;
-                alleles[(size_t)p.read * n_variants + p.var] = d0 < d1 ? A_REF : (d0 > d1 ? A_ALT : A_AMBIGUOUS);  // variants.rs:633-640
+        size_t k2 = 0;
+        for (auto& W : workers)
+            for (size_t k = 0; k < W.w.pending.size(); ++k) {
+                const Pending& p = W.w.pending[k];
+                const LocalGroup& G = groups[W.pend_group[k]];
+                const uint64_t d0 = dist[k2], d1 = dist[k2 + 1];
+                k2 += 2;
+                G.alleles[(size_t)p.read * G.n_variants + p.var] = d0 < d1 ? A_REF : (d0 > d1 ? A_ALT : A_AMBIGUOUS);  // variants.rs:633-640
             }
     }
     const double t2 = now_ms();
-    if (stats) {   // read_parsing.rs:460-499
-        auto stat_rows = [&](unsigned t) {
-        for (size_t r = n_reads * t / nt; r < n_reads * (t + 1) / nt; ++r) {
+    // ---- statistics (read_parsing.rs:460-499) ----
+    for (size_t g = 0; g < n_groups; ++g) {
+        const LocalGroup& G = groups[g];
+        if (!G.stats) continue;
+        for (size_t r = 0; r < G.n_reads; ++r) {
             hp_read_stats s{};
             uint64_t overlaps = 0;
-            for (size_t vi = 0; vi < n_variants; ++vi) {
-                const uint8_t f = flags[r * n_variants + vi], a = alleles[r * n_variants + vi];
+            for (size_t vi = 0; vi < G.n_variants; ++vi) {
+                const uint8_t f = gs[g].flags[r * G.n_variants + vi], a = G.alleles[r * G.n_variants + vi];
                 if (!(f & F_OVERLAPS)) continue;
-                const uint32_t t = variants[vi].variant_type;
+                const uint32_t t = G.variants[vi].variant_type;
                 if (a == A_AMBIGUOUS) { s.failed_matches[t] += 1; continue; }
                 if (f & F_EXACT) s.exact_matches[t] += 1; else s.inexact_matches[t] += 1;
                 if (a == A_REF) s.allele0_matches[t] += 1; else s.allele1_matches[t] += 1;
@@ -307,16 +330,16 @@ extern "C" int hp_local_realign_batch(const hp_local_read* reads_in, size_t n_re
             s.num_alleles = overlaps;
             s.skipped_reads = overlaps == 0 ? 1 : 0;
             s.local_aligned = 1 - s.skipped_reads;
-            stats[r] = s;
-        }
-        };
-        if (nt == 1) stat_rows(0);
-        else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; ++t) th.emplace_back(stat_rows, t);
-            for (auto& x : th) x.join();
+            G.stats[r] = s;
         }
     }
-    if (verbose) { fprintf(stderr, "[hp] local re-alignment of %zu records x %zu variants on %u threads: coordinates %.2f ms, %zu inexact alleles on the device %.2f ms, statistics %.2f ms\n", n_reads, n_variants, nt, t1 - t0, n_pending, t2 - t1, now_ms() - t2); fflush(stderr); }
+    if (verbose) { fprintf(stderr, "[hp] local re-alignment of %zu records in %zu groups on %u threads: coordinates %.2f ms, %zu inexact alleles on the device %.2f ms, statistics %.2f ms\n", n_items, n_groups, nt, t1 - t0, n_pending, t2 - t1, now_ms() - t2); fflush(stderr); }
     return HP_OK;
+}
+
+extern "C" int hp_local_realign_batch(const hp_local_read* reads, size_t n_reads, const hp_local_variant* variants,
+                                      size_t n_variants, uint8_t* alleles, uint8_t* quals, hp_read_stats* stats, int device_id) {
+    if (n_reads == 0) return HP_OK;
+    LocalGroup g{reads, n_reads, variants, n_variants, alleles, quals, stats};
+    return local_realign_groups(&g, 1, device_id);
 }

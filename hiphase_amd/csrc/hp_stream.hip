@@ -73,11 +73,14 @@ void hp_blockstream::stage_loop(int k) {
     (void)hipSetDevice(device);
     // The graph-WFA kernels are persistent and fill every compute unit they may use (three wavefronts per SIMD is all their
     // registers allow): a kernel of another stage launched beside them waits until one of their workgroups leaves - the base
-    // expansion of the NEXT set, the A* and post-processing kernels of the PREVIOUS one. So the stages get compute units of
-    // their own (hp_common.h: CU partitions): graph-WFA seven CUs in eight, the other two stages share the eighth - the search
-    // is latency-bound (a block's heuristic chain is sequential) and only has to finish within the period of the WFA stage.
-    static const bool part = [] { const char* e = std::getenv("HP_STREAM_PARTITION"); return !(e && e[0] == '0'); }();
-    if (part) g_cu_partition = k == 1 ? 2 : 1;
+    // expansion of the NEXT set, the A* / Levenshtein / post-processing kernels of the PREVIOUS one. So the graph-WFA stage is
+    // bound to seven compute units in eight (hp_common.h: CU partition 2; a CU-masked stream also has a hardware queue of its
+    // own); the other two stages launch on the whole device and always find the eighth free - the search is latency-bound (a
+    // block's heuristic chain is sequential) and only has to finish within the period of the WFA stage.
+    // HP_STREAM_PARTITION: 0 = no partition, 1 = the other stages confined to the eighth, 2 (default) = as described.
+    static const int part = [] { const char* e = std::getenv("HP_STREAM_PARTITION"); return e ? std::atoi(e) : 2; }();
+    if (part == 1) g_cu_partition = k == 1 ? 2 : 1;
+    else if (part == 2) g_cu_partition = k == 1 ? 2 : 0;
     g_host_share_div = k == 1 ? 4 : 2;   // the three stages' host threads together: about the process's share of the host
     for (;;) {
         Slot* s = nullptr;

@@ -818,8 +818,8 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         pend.posted = true;
         helper->post([self, part]() {
             // (inside a block stream the graph-WFA stage owns partition 2, which the NEXT set's persistent kernels fill: the
-            // dense-band pass of this set's leftovers goes to the other stages' compute units)
-            g_cu_partition = part == 2 ? 1 : part;
+            // dense-band pass of this set's leftovers launches on the whole device and runs where there is room)
+            g_cu_partition = part == 2 ? 0 : part;
             self->pend.rc = self->late();
             if (self->pend.rc != HP_OK) self->pend.err = hp_last_error();
         });
