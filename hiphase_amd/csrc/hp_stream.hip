@@ -71,14 +71,12 @@ struct hp_blockstream {
 void hp_blockstream::stage_loop(int k) {
     WorkerPool::set_thread_pool(pool[k].get());
     (void)hipSetDevice(device);
-    // The graph-WFA kernels are persistent and fill every compute unit they may use (three wavefronts per SIMD is all their
-    // registers allow): a kernel of another stage launched beside them waits until one of their workgroups leaves - the base
-    // expansion of the NEXT set, the A* / Levenshtein / post-processing kernels of the PREVIOUS one. So the graph-WFA stage is
-    // bound to seven compute units in eight (hp_common.h: CU partition 2; a CU-masked stream also has a hardware queue of its
-    // own); the other two stages launch on the whole device and always find the eighth free - the search is latency-bound (a
-    // block's heuristic chain is sequential) and only has to finish within the period of the WFA stage.
-    // HP_STREAM_PARTITION: 0 = no partition, 1 = the other stages confined to the eighth, 2 (default) = as described.
-    static const int part = [] { const char* e = std::getenv("HP_STREAM_PARTITION"); return e ? std::atoi(e) : 2; }();
+    // CU partitions for the stages (hp_common.h) are an experiment switch, off by default. Measured on the bench workload: the
+    // persistent graph-WFA kernels fill every compute unit (three wavefronts per SIMD is all their registers allow), so another
+    // stage's kernels wait for their workgroups to leave - but binding graph-WFA to 7/8 of the CUs (with the other stages confined
+    // to the eighth, HP_STREAM_PARTITION=1, or on the whole device, =2) made the A* kernels 6 x slower (113 vs 18 ms: they start
+    // behind the CU-masked queue's kernels) and the step 165 instead of 73 ms.
+    static const int part = [] { const char* e = std::getenv("HP_STREAM_PARTITION"); return e ? std::atoi(e) : 0; }();
     if (part == 1) g_cu_partition = k == 1 ? 2 : 1;
     else if (part == 2) g_cu_partition = k == 1 ? 2 : 0;
     g_host_share_div = k == 1 ? 4 : 2;   // the three stages' host threads together: about the process's share of the host

@@ -146,6 +146,7 @@ struct W2Session {
     int device_id = -1;
     DevBuf d_qhead;                      // work-queue heads, class counts, hand-over words of the last run
     DevBuf d_packed, d_src_off, d_fmt;   // block mode: the reads as the caller holds them (ASCII or BAM 4-bit), expanded by hp_wfa2_unpack_kernel
+    bool need_unpack = false;            // block mode: the reads are in d_packed and have not been expanded into d_seq yet
     uint64_t h2d_bytes = 0;              // of the last prepare
     double prep_ms[4] = {0, 0, 0, 0};    // of the last prepare: layout, fill + upload, total, -
     std::vector<std::vector<uint8_t>> ascii_scratch;   // block mode: decoded reads of the jobs that leave the compact path
@@ -217,7 +218,7 @@ struct W2Session {
 };
 
 int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
-    jobs = jobs_; n = n_; bl_in = nullptr; bl_jobs = nullptr;
+    jobs = jobs_; n = n_; bl_in = nullptr; bl_jobs = nullptr; need_unpack = false;
     if (n == 0) return HP_OK;
     if (!jobs) { set_error("null argument"); return HP_ERR_ARG; }
     if (n > 0x3FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
@@ -545,7 +546,6 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
     HP_HIP_CHECK(hipMemcpyAsync(d_len_order.p, sb + o_len, n * 4, hipMemcpyHostToDevice, st));
     HP_HIP_CHECK(hipMemcpyAsync(d_src_off.p, sb + o_src, n * 8, hipMemcpyHostToDevice, st));
     HP_HIP_CHECK(hipMemcpyAsync(d_fmt.p, sb + o_fmt, n, hipMemcpyHostToDevice, st));
-    HP_HIP_CHECK(hipMemsetAsync(reinterpret_cast<uint8_t*>(d_seq.p) + seq_bytes - 256, 0, 256, st));
     h2d_bytes = reads_dev + n_vars * sizeof(W2Variant) + n * (sizeof(W2Job) + 13);
     // ---- 3b. the reads, piece by piece: piece k crosses PCIe while the host threads fill piece k + 1 ----------------------------
     {
@@ -576,12 +576,10 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
             h2d_bytes += hi - lo;
             j0 = j1;
         }
-        W2UnpackArgs U{};
-        U.jobs = d_jobs.as<W2Job>(); U.src_off = d_src_off.as<uint64_t>(); U.fmt_nib = d_fmt.as<uint8_t>(); U.n_jobs = (uint32_t)n;
-        U.packed = d_packed.as<uint8_t>(); U.seq = d_seq.as<uint8_t>();
-        hipLaunchKernelGGL(hp_wfa2_unpack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, U);
-        HP_HIP_CHECK(hipGetLastError());
     }
+    // (the base expansion is the first kernel of run(): launched here it would queue behind the persistent alignment kernels of
+    // the set before this one and hold the staging thread up; there it runs when they are gone, at the head of its own set)
+    need_unpack = true;
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("upload failed"); return HP_ERR_HIP; }
     const double t1 = w2_now_ms();
     prep_ms[0] = t_lay - t0; prep_ms[1] = t1 - t_lay; prep_ms[2] = t1 - t0; prep_ms[3] = (double)h2d_bytes;
@@ -629,6 +627,14 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         A.jobs = d_jobs.as<W2Job>(); A.n_jobs = (uint32_t)n; A.vars = d_vars.as<W2Variant>();
         A.nodes = d_nodes.as<W2Node>(); A.edges = d_edges.as<uint16_t>(); A.tags = d_tags.as<uint32_t>();
         A.info = d_info.as<W2Info>();
+        if (need_unpack) {
+            W2UnpackArgs U{};
+            U.jobs = d_jobs.as<W2Job>(); U.src_off = d_src_off.as<uint64_t>(); U.fmt_nib = d_fmt.as<uint8_t>(); U.n_jobs = (uint32_t)n;
+            U.packed = d_packed.as<uint8_t>(); U.seq = d_seq.as<uint8_t>(); U.tail_off = seq_bytes - 256;
+            hipLaunchKernelGGL(hp_wfa2_unpack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, U);
+            HP_HIP_CHECK(hipGetLastError());
+            need_unpack = false;
+        }
         HP_HIP_CHECK(hipEventRecord(e0, st));
         hipLaunchKernelGGL(hp_wfa2_build_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, A);
         HP_HIP_CHECK(hipGetLastError());

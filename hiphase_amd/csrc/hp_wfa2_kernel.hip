@@ -231,8 +231,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
     // current node / item
     uint32_t n = 0, len = 0, child_off = 0, n_child = 0, c01 = 0, n_items = 0, item = 0, npar = 0, pc0 = 0, pc1 = 0;
     const uint8_t* nseq = altp;
-    bool hp0 = false, hp1 = false, use_list = false;
-    int32_t a0 = 0, b0 = 0, o0 = 0, a1 = 0, b1 = 0, o1 = 0;   // previous entries of n: live diagonals [a, b], slot of diagonal d = o + d
+    bool use_list = false;
+    // previous round's live entries of n (NP of them at most: two for the smaller classes, four for the largest, which takes over
+    // the reads whose paths lie far apart after a structural variant): live diagonals [pa, pb], slot of diagonal d = po + d
+    constexpr int NP = C::MAXPREV;
+    uint32_t np = 0;
+    int32_t pa[NP], pb[NP], po[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { pa[k] = 0; pb[k] = 0; po[k] = 0; }
     int32_t lo = 0, hi = 0, base = 0;
     const uint32_t n_class = *B.n_items_dev;   // jobs of this graph-size class
     if (B.esc_role == 1u) (void)atomicAdd(B.esc + 4, lane == 0 ? 1u : 0u);   // a producer workgroup has started
@@ -329,7 +335,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                     // while that class has room: reads with a few per cent of noise fail by the thousand, and a few hundred
                     // groups working through them one after the other (to fail again) took a second; those go straight
                     // to the dense-band pass, as does everything past the budget.
-                    const bool hand = status == W2_ST_NEED_BIG && (why == 1u || why == 2u || why == 3u || why == 7u || why == 8u);
+                    const bool hand = status == W2_ST_NEED_BIG && (why == 1u || why == 2u || why == 3u || why == 6u || why == 7u || why == 8u);
                     if (B.esc_role == 1u && __any(hand)) {
                         // hand the job to the largest class: reserve a list position, store the job there, publish positions in
                         // order. Every lane takes part in every atomic (idle ones on a scratch word): no one-lane branches.
@@ -438,21 +444,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                 }
                 // ---- sources: previous entries of n grown by one diagonal a side, finished parents, the start wave ----
                 lo = INT32_MAX; hi = INT32_MIN;
-                hp0 = false; hp1 = false;
+                np = 0;
                 if (na == n) {
-                    hp0 = true;
-                    a0 = (int32_t)ph.y + (int32_t)(ph.z & 0xFFu); b0 = (int32_t)ph.y + (int32_t)((ph.z >> 8) & 0xFFu); o0 = (int32_t)(ph.x >> 16) - (int32_t)ph.y;
-                    lo = a0 - 1; hi = b0 + 1;
-                    ++pp;
-                    ph = pp < lcnt_prev ? live[p * C::MAXL + pp] : make_uint4(0xFFFFu, 0, 0, 0);
-                    if ((ph.x & 0xFFFFu) == n) {
-                        hp1 = true;
-                        a1 = (int32_t)ph.y + (int32_t)(ph.z & 0xFFu); b1 = (int32_t)ph.y + (int32_t)((ph.z >> 8) & 0xFFu); o1 = (int32_t)(ph.x >> 16) - (int32_t)ph.y;
-                        lo = min(lo, a1 - 1); hi = max(hi, b1 + 1);
-                        ++pp;
-                        ph = pp < lcnt_prev ? live[p * C::MAXL + pp] : make_uint4(0xFFFFu, 0, 0, 0);
-                        if ((ph.x & 0xFFFFu) == n) { status = W2_ST_NEED_BIG, why = 6u; state = S_JOB; continue; }   // three entries of one node
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        if ((ph.x & 0xFFFFu) == n) {   // (entries of one node are consecutive in the live list)
+                            pa[k] = (int32_t)ph.y + (int32_t)(ph.z & 0xFFu); pb[k] = (int32_t)ph.y + (int32_t)((ph.z >> 8) & 0xFFu); po[k] = (int32_t)(ph.x >> 16) - (int32_t)ph.y;
+                            lo = min(lo, pa[k] - 1); hi = max(hi, pb[k] + 1);
+                            np = (uint32_t)k + 1u;
+                            ++pp;
+                            ph = pp < lcnt_prev ? live[p * C::MAXL + pp] : make_uint4(0xFFFFu, 0, 0, 0);
+                        }
                     }
+                    if ((ph.x & 0xFFFFu) == n) { status = W2_ST_NEED_BIG, why = 6u; state = S_JOB; continue; }   // more entries of one node than the class holds
                 }
                 npar = 0; pc0 = 0; pc1 = 0;
                 if (nb == n) {
@@ -472,22 +476,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                     // far-apart sources (a structural variant upstream puts two paths hundreds of diagonals apart): walk
                     // them again, merge what overlaps or touches, every remaining interval is an item of its own
                     uint32_t ni = 0;
-                    const uint32_t ns = (hp0 ? 1u : 0u) + (hp1 ? 1u : 0u) + npar + ((ed == 0 && n == 0) ? 1u : 0u);
+                    const uint32_t ns = np + npar + ((ed == 0 && n == 0) ? 1u : 0u);
                     for (uint32_t i = 0; i < ns; ++i) {
-                        int2 iv;
-                        uint32_t q = i;
-                        if (hp0 && q == 0) iv = make_int2(a0 - 1, b0 + 1);
-                        else {
-                            q -= hp0 ? 1u : 0u;
-                            if (hp1 && q == 0) iv = make_int2(a1 - 1, b1 + 1);
-                            else {
-                                q -= hp1 ? 1u : 0u;
-                                if (q < npar) {
-                                    const uint32_t code = ((q < 4u ? pc0 >> (8u * q) : pc1 >> (8u * (q - 4u))) & 0xFFu);
-                                    const uint4 h = code < 128u ? live[c * C::MAXL + code] : fin[code - 128u];
-                                    iv = make_int2((int32_t)h.y + (int32_t)h.w + (int32_t)((h.z >> 16) & 0xFFu), (int32_t)h.y + (int32_t)h.w + (int32_t)(h.z >> 24));
-                                } else iv = make_int2(0, 0);
-                            }
+                        int2 iv = make_int2(0, 0);
+                        if (i < np) {
+#pragma unroll
+                            for (int k = 0; k < NP; ++k) if (i == (uint32_t)k) iv = make_int2(pa[k] - 1, pb[k] + 1);
+                        } else if (i - np < npar) {
+                            const uint32_t q = i - np;
+                            const uint32_t code = ((q < 4u ? pc0 >> (8u * q) : pc1 >> (8u * (q - 4u))) & 0xFFu);
+                            const uint4 h = code < 128u ? live[c * C::MAXL + code] : fin[code - 128u];
+                            iv = make_int2((int32_t)h.y + (int32_t)h.w + (int32_t)((h.z >> 16) & 0xFFu), (int32_t)h.y + (int32_t)h.w + (int32_t)(h.z >> 24));
                         }
                         uint32_t j = 0;
                         while (j < ni) {
@@ -543,16 +542,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         int32_t oA = -1, oB = -1, oC = -1;
         int32_t sA = -1, sB = -1, sC = -1;   // their slots
         if (act) {
-            if (hp0) {
-                if (d + 1 >= a0 && d + 1 <= b0) sA = o0 + d + 1;
-                if (d >= a0 && d <= b0) sB = o0 + d;
-                if (d - 1 >= a0 && d - 1 <= b0) sC = o0 + d - 1;
-            }
-            if (hp1) {
-                if (d + 1 >= a1 && d + 1 <= b1) sA = o1 + d + 1;
-                if (d >= a1 && d <= b1) sB = o1 + d;
-                if (d - 1 >= a1 && d - 1 <= b1) sC = o1 + d - 1;
-            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+                if ((uint32_t)k < np) {
+                    if (d + 1 >= pa[k] && d + 1 <= pb[k]) sA = po[k] + d + 1;
+                    if (d >= pa[k] && d <= pb[k]) sB = po[k] + d;
+                    if (d - 1 >= pa[k] && d - 1 <= pb[k]) sC = po[k] + d - 1;
+                }
         }
         const uint32_t pbase = p * C::SLOTS, cbase = c * C::SLOTS;
         {
@@ -777,7 +773,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                 } else end_pending = false;
                 // (a node keeps at most two live entries per round - the next round reads at most two: once it has one, the
                 // rest of its diagonals stay one cluster, gaps included)
-                if (chi != INT32_MIN && ((first - chi >= 3 && n_live_node == 0u) || lastd - clo >= (int32_t)C::MAXW)) emit_cluster();
+                if (chi != INT32_MIN && ((first - chi >= 3 && n_live_node == 0u) || lastd - clo >= (int32_t)C::MAXW)) emit_cluster();   // (n_live_node: see MAXPREV)
                 if (bit) {
                     if (chi == INT32_MIN) clo = first;
                     chi = lastd;
@@ -984,6 +980,7 @@ struct W2UnpackArgs {
     uint32_t n_jobs;
     const uint8_t* packed;
     uint8_t* seq;
+    uint64_t tail_off;          // 256 bytes of zeros behind the last read (the 32-byte compares may run past its last base)
 };
 __global__ void __launch_bounds__(256) hp_wfa2_unpack_kernel(W2UnpackArgs A) {
     __shared__ uint16_t lut[256];   // source byte -> two bases (first base = high nibble = low byte of the pair)
@@ -993,6 +990,7 @@ __global__ void __launch_bounds__(256) hp_wfa2_unpack_kernel(W2UnpackArgs A) {
         lut[t] = (uint16_t)((uint32_t)(uint8_t)tab[t >> 4] | ((uint32_t)(uint8_t)tab[t & 15u] << 8));
     }
     __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 64) reinterpret_cast<uint32_t*>(A.seq + A.tail_off)[threadIdx.x] = 0u;
     const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (j >= A.n_jobs) return;
     const W2Job J = A.jobs[j];
