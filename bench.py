@@ -338,7 +338,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
             "stage_ms": {"overlaps_layout_host": st_mean[0], "staging_pcie_expand": st_mean[1], "graph_wfa": st_mean[2], "fallback_rows_collapse_host": st_mean[3],
                          "astar_pack_upload": st_mean[4], "astar_solve": st_mean[5], "postprocess_outputs": st_mean[6], "latency_submit_to_done": st_mean[7],
                          "graph_wfa_kernels": st_mean[8], "astar_kernel": st_mean[9], "waiting_between_stages": st_mean[11],
-                         "stage1_wall": st_mean[12], "stage2_wall": st_mean[13], "stage3_wall": st_mean[14]},
+                         "stage1_wall": st_mean[12], "stage2_wall": st_mean[13], "stage3_wall": st_mean[14], "stage4_wall": st_mean[15]},
             "roofline": {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_gbs", "traffic_frac", "kernel", "kernel_ms", "algorithmic_bytes_per_launch")},
             "kernels": [k_wfa, k_astar],
         }
@@ -403,7 +403,7 @@ def main():
     ap.add_argument("--total-hets", type=int, default=60000, help="path workload: hets per GPU and step")
     ap.add_argument("--max-block-hets", type=int, default=4165, help="largest block HiPhase reports on HG002 (docs/user_guide.md:258)")
     ap.add_argument("--seq-format", choices=["bam4", "ascii"], default="bam4", help="path workload: how the reads are handed over")
-    ap.add_argument("--depth", type=int, default=4, help="path workload: block sets in flight in the stream")
+    ap.add_argument("--depth", type=int, default=5, help="path workload: block sets in flight in the stream")
     ap.add_argument("--distinct-sets", type=int, default=16, help="path workload: generated sets (steps + warm-up if fewer; cycled if more are needed)")
     ap.add_argument("--no-resident", action="store_true", help="path workload: skip the secondary resident (inputs-in-HBM) figure")
     ap.add_argument("--seed", type=int, default=20250928, help="path workload: seed of the synthetic block mix (rank r uses seed + r)")

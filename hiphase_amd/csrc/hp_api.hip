@@ -4,31 +4,30 @@
 #include <atomic>
 #include <cstdlib>
 #include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <algorithm>
 
 namespace hp {
 namespace {
 // see hp_common.h: size classes = next power of two up to 1 MiB, then multiples of 1 MiB (so a re-run of a similar
-// batch finds its blocks again); at most 8 GiB per thread stay cached, single blocks above 2 GiB never do.
+// batch finds its blocks again); at most 24 GiB stay cached, single blocks above 4 GiB never do. The cache is process-wide
+// (one mutex; an entry point takes a couple of dozen blocks per call): a block set travels through the threads of a block
+// stream - laid out by one, aligned by the next, solved by a third - and whoever lets a buffer go must hand it to whoever needs
+// one next, or the first thread would hipMalloc (and synchronise the device) for every set. Never destroyed: threads may still
+// hand blocks back while the process exits.
 struct DevCache {
+    std::mutex m;
     std::multimap<std::pair<int, size_t>, void*> free_;   // (device, bytes) -> block
     size_t cached = 0;
-    static constexpr size_t kMaxCached = 8ull << 30, kMaxBlock = 2ull << 30;
+    static constexpr size_t kMaxCached = 24ull << 30, kMaxBlock = 4ull << 30;
     static size_t round_up(size_t n) {
         if (n <= (1u << 20)) { size_t r = 256; while (r < n) r <<= 1; return r; }
         return (n + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
     }
-    ~DevCache();
 };
-// Thread-local objects of other translation units (the WFA context's scratch DevBuf) may be destroyed AFTER this
-// cache at thread / process exit and hand their block back then: once the cache is gone, get/put talk to
-// hipMalloc/hipFree directly. A plain bool has no destructor, so it stays readable for the rest of the thread's life.
-thread_local bool g_dev_cache_dead = false;
-thread_local DevCache g_dev_cache;
-DevCache::~DevCache() {
-    for (auto& kv : free_) (void)hipFree(kv.second);
-    free_.clear();
-    g_dev_cache_dead = true;
-}
+DevCache& dev_cache() { static DevCache* c = new DevCache(); return *c; }
 }  // namespace
 
 void* dev_cache_get(size_t bytes, size_t* got, int* dev_out) {
@@ -36,29 +35,30 @@ void* dev_cache_get(size_t bytes, size_t* got, int* dev_out) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     *dev_out = dev;
-    if (g_dev_cache_dead) {
-        void* q = nullptr;
-        hipError_t e = hipMalloc(&q, want);
-        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return nullptr; }
-        *got = want;
-        return q;
-    }
-    DevCache& c = g_dev_cache;
-    auto it = c.free_.lower_bound({dev, want});
-    if (it != c.free_.end() && it->first.first == dev && it->first.second <= want + want / 4) {
-        void* p = it->second;
-        *got = it->first.second;
-        c.cached -= it->first.second;
-        c.free_.erase(it);
-        return p;
+    DevCache& c = dev_cache();
+    {
+        std::lock_guard<std::mutex> lk(c.m);
+        auto it = c.free_.lower_bound({dev, want});
+        if (it != c.free_.end() && it->first.first == dev && it->first.second <= want + want / 4) {
+            void* p = it->second;
+            *got = it->first.second;
+            c.cached -= it->first.second;
+            c.free_.erase(it);
+            return p;
+        }
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess && !c.free_.empty()) {   // give the cache back and try once more
-        for (auto& kv : c.free_) (void)hipFree(kv.second);
-        c.free_.clear();
-        c.cached = 0;
-        e = hipMalloc(&p, want);
+    if (e != hipSuccess) {   // give the cache back and try once more
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> lk(c.m);
+            for (auto& kv : c.free_) drop.push_back(kv.second);
+            c.free_.clear();
+            c.cached = 0;
+        }
+        for (void* q : drop) (void)hipFree(q);
+        if (!drop.empty()) e = hipMalloc(&p, want);
     }
     if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return nullptr; }
     *got = want;
@@ -77,6 +77,7 @@ int device_cu_count(int device_id) {
 }
 
 thread_local unsigned g_host_share_div = 0;
+thread_local int g_wfa2_reserve_pct = 0;
 unsigned host_threads(unsigned want) {
     static const unsigned share = [] {
         if (const char* e = std::getenv("HP_HOST_THREADS")) return (unsigned)std::max(1, std::atoi(e));
@@ -133,14 +134,16 @@ hipStream_t thread_stream(int device_id) {
 }
 
 void dev_cache_put(void* p, size_t bytes, int dev) {   // dev: what dev_cache_get reported for this block
-    if (g_dev_cache_dead) { (void)hipFree(p); return; }
-    DevCache& c = g_dev_cache;
-    if (bytes > DevCache::kMaxBlock || c.cached + bytes > DevCache::kMaxCached) {
-        (void)hipFree(p);
-        return;
+    DevCache& c = dev_cache();
+    {
+        std::lock_guard<std::mutex> lk(c.m);
+        if (bytes <= DevCache::kMaxBlock && c.cached + bytes <= DevCache::kMaxCached) {
+            c.free_.insert({{dev, bytes}, p});
+            c.cached += bytes;
+            return;
+        }
     }
-    c.free_.insert({{dev, bytes}, p});
-    c.cached += bytes;
+    (void)hipFree(p);
 }
 
 static std::atomic<int> g_coalesce{-1};   // -1: ask the environment once

@@ -14,6 +14,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 namespace hp {
@@ -273,21 +274,29 @@ struct StreamSet {
         *this = StreamSet{};
     }
 };
-thread_local bool g_stream_pool_dead = false;   // a batch destroyed after the pool (thread exit) destroys its streams itself
+// process-wide (a batch may be created on one thread and solved / destroyed on another: the stages of a block stream); never
+// destroyed
 struct StreamPool {
+    std::mutex m;
     std::vector<StreamSet> free_;
-    ~StreamPool() { for (auto& s : free_) s.destroy(); free_.clear(); g_stream_pool_dead = true; }
     bool get(int dev, StreamSet& out) {
-        for (size_t i = 0; i < free_.size(); ++i)
-            if (free_[i].device == dev && free_[i].partition == g_cu_partition) { out = free_[i]; free_.erase(free_.begin() + i); return true; }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].device == dev && free_[i].partition == g_cu_partition) { out = free_[i]; free_.erase(free_.begin() + i); return true; }
+        }
         return out.create(dev);
     }
     void put(StreamSet& s) {
-        if (!g_stream_pool_dead && free_.size() < 8) free_.push_back(s); else s.destroy();
-        s = StreamSet{};
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (free_.size() < 32) { free_.push_back(s); s = StreamSet{}; return; }
+        }
+        s.destroy();
     }
 };
-thread_local StreamPool g_stream_pool;
+static StreamPool& stream_pool() { static StreamPool* p = new StreamPool(); return *p; }
+#define g_stream_pool (stream_pool())
 
 struct hp_batch {
     int device = 0;

@@ -50,7 +50,7 @@ struct BlockState {         // per block, rebuilt by every solve
     std::vector<int64_t> local_slot;
     std::vector<uint8_t> loc_alleles, loc_quals;
     std::vector<hp_read_stats> loc_stats;
-    std::vector<uint32_t> loc_need;       // records of the pre-pass (blockset_tail gathers them over all blocks: one device launch)
+    std::vector<uint32_t> loc_need;       // records of the pre-pass (blockset_rows gathers them over all blocks: one device launch)
     std::vector<hp_local_read> loc_reads;
     Arena arena;
     void reset() {   // keeps every capacity
@@ -88,7 +88,12 @@ struct hp_blockset {
     double prep[4] = {0, 0, 0, 0};               // of the last init: layout ms, fill + upload ms, total ms, bytes host -> device
     uint64_t work[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // hp_blockset_work of the last solve
     std::vector<hp::BlockState> st;
-    ~hp_blockset() { if (wfa) hp::w2_session_destroy(wfa); }
+    // between blockset_rows and blockset_solve: the A* batch of the set (packed, uploaded), the blocks in it
+    hp_batch* batch = nullptr;
+    std::vector<hp_block_view> views;
+    std::vector<size_t> kept;
+    std::vector<char> unsupported;
+    ~hp_blockset() { if (batch) hp_batch_destroy(batch); if (wfa) hp::w2_session_destroy(wfa); }
 };
 
 namespace hp {
@@ -96,6 +101,8 @@ namespace hp {
 int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id);
 // graph-WFA over every record with overlaps: device graph build, alignment, allele rows (returns after the first collection)
 int blockset_wfa(hp_blockset* bs);
-// fallback / replay / rows / collapse, A*, span counts and haplotags, outputs
-int blockset_tail(hp_blockset* bs, hp_block_output* out);
+// fallback / replay / rows / collapse on host threads, the A* batch packed and uploaded
+int blockset_rows(hp_blockset* bs);
+// A*, span counts and haplotags, outputs
+int blockset_solve(hp_blockset* bs, hp_block_output* out);
 }  // namespace hp

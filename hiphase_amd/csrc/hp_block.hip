@@ -457,7 +457,7 @@ int hp::blockset_wfa(hp_blockset* bs) {
     ch.ms[6] = 0.0;
     if (!ch.jobs.empty()) {
         int rc;
-        // (the few reads the compact kernel hands back are still in the dense-band pass when this returns: blockset_tail)
+        // (the few reads the compact kernel hands back are still in the dense-band pass when this returns: blockset_rows)
         if (ch.wfa_ready) rc = w2_session_run(ch.wfa, bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(), ch.allele_ptrs.data(), 2);
         else {
             // a small set takes the latency path (dense-band kernel, one wavefront per read): the jobs as hp_wfa_assign_batch takes
@@ -487,16 +487,17 @@ int hp::blockset_wfa(hp_blockset* bs) {
         }
         if (rc != HP_OK) return rc;
         // the three class instantiations of hp_wfa2_kernel run concurrently: their span is the kernel time of the stage
-        ch.ms[6] = ch.wfa_ready ? 0.0 : g_last_kernel_ms;   // (resident session: known once its second collection is done, blockset_tail)
+        ch.ms[6] = ch.wfa_ready ? 0.0 : g_last_kernel_ms;   // (resident session: known once its second collection is done, blockset_rows)
     }
     ch.ms[0] = blk_now_ms() - t0;
     return HP_OK;
 }
 
-// everything after the WFA: fallback / replay / rows / collapse (host threads over blocks), A* (one resident batch), span
-// counts and haplotags, outputs. May run on another thread than blockset_wfa did.
-int hp::blockset_tail(hp_blockset* bs, hp_block_output* out) {
+// after the WFA, first half: fallback / replay / rows / collapse (host threads over blocks), then the A* batch of all blocks
+// packed and uploaded. May run on another thread than blockset_wfa did.
+int hp::blockset_rows(hp_blockset* bs) {
     hp_blockset& ch = *bs;
+    if (ch.batch) { hp_batch_destroy(ch.batch); ch.batch = nullptr; }
     const bool has_wfa = ch.wfa_ready;
     const double t1 = blk_now_ms();
     int rc = HP_OK;
@@ -562,7 +563,8 @@ int hp::blockset_tail(hp_blockset* bs, hp_block_output* out) {
     const double t2 = blk_now_ms();
     // ---- A* over the chunk's blocks ----
     const size_t nb = bs->n_blocks;
-    std::vector<hp_block_view> views(nb);
+    std::vector<hp_block_view>& views = ch.views;
+    views.assign(nb, hp_block_view{});
     for (size_t k = 0; k < nb; ++k) {
         const size_t b = k;
         const BlockState& S = bs->st[b];
@@ -579,9 +581,11 @@ int hp::blockset_tail(hp_blockset* bs, hp_block_output* out) {
     // limits must not fail the others - nor the call when it is alone: it is left out of the batch and handed back
     // with the soft status HP_BLOCK_UNSUPPORTED (segments filled; h1 / h2 / stats / spans / tags untouched), whether it came
     // alone, with others, or merged with other callers' blocks
-    std::vector<size_t> kept(nb);
+    std::vector<size_t>& kept = ch.kept;
+    kept.resize(nb);
     for (size_t k = 0; k < nb; ++k) kept[k] = k;
-    std::vector<char> unsupported(nb, 0);
+    std::vector<char>& unsupported = ch.unsupported;
+    unsupported.assign(nb, 0);
     hp_batch* batch = hp_batch_create(nb, views.data(), &ap, bs->device, &st);
     if (!batch && st == HP_ERR_UNSUPPORTED) {
         kept.clear();
@@ -599,7 +603,24 @@ int hp::blockset_tail(hp_blockset* bs, hp_block_output* out) {
             if (!batch) return st != HP_OK ? st : HP_ERR_HIP;
         } else if (!kept.empty()) return HP_ERR_UNSUPPORTED;   // every block packs alone but not together: the batch limits (split the call)
     } else if (!batch) return st != HP_OK ? st : HP_ERR_HIP;
-    struct BatchGuard { hp_batch* b; ~BatchGuard() { if (b) hp_batch_destroy(b); } } guard{batch};
+    ch.batch = batch;
+    const double t3 = blk_now_ms();
+    ch.ms[1] = t2 - t1; ch.ms[2] = t3 - t2;
+    return HP_OK;
+}
+
+// after the WFA, second half: A* over the packed batch, span counts and haplotags on the resident matrix, outputs into the
+// caller's buffers. May run on yet another thread (the fourth stage of a block stream).
+int hp::blockset_solve(hp_blockset* bs, hp_block_output* out) {
+    hp_blockset& ch = *bs;
+    const bool has_wfa = ch.wfa_ready;
+    const size_t nb = bs->n_blocks;
+    std::vector<hp_block_view>& views = ch.views;
+    std::vector<size_t>& kept = ch.kept;
+    std::vector<char>& unsupported = ch.unsupported;
+    hp_batch* batch = ch.batch;
+    struct BatchGuard { hp_blockset* s; ~BatchGuard() { if (s->batch) { hp_batch_destroy(s->batch); s->batch = nullptr; } } } guard{bs};
+    int rc = HP_OK;
     const size_t nk = kept.size();
     const double t3 = blk_now_ms();
     float kms = 0.f;
@@ -706,7 +727,7 @@ int hp::blockset_tail(hp_blockset* bs, hp_block_output* out) {
         if (cap_fail.load() >= 0) { set_error("block %lld: seg_cell_cap too small", (long long)cap_fail.load()); return HP_ERR_ARG; }
     }
     const double t5 = blk_now_ms();
-    ch.ms[1] = t2 - t1; ch.ms[2] = t3 - t2; ch.ms[3] = t4 - t3; ch.ms[4] = t5 - t4; ch.ms[7] = kms;
+    ch.ms[3] = t4 - t3; ch.ms[4] = t5 - t4; ch.ms[7] = kms;
     return HP_OK;
 }
 
@@ -714,7 +735,8 @@ extern "C" int hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* 
     if (!bs || !out) { set_error("null argument"); return HP_ERR_ARG; }
     const double t0 = blk_now_ms();
     int rc = blockset_wfa(bs);
-    if (rc == HP_OK) rc = blockset_tail(bs, out);
+    if (rc == HP_OK) rc = blockset_rows(bs);
+    if (rc == HP_OK) rc = blockset_solve(bs, out);
     if (rc != HP_OK) return rc;
     if (stage_ms) {
         for (int i = 0; i < 8; ++i) stage_ms[i] = bs->ms[i];

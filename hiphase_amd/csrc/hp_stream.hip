@@ -3,15 +3,16 @@
 // HiPhase sees every phase block once (reference src/main.rs:337-408: blocks are generated, queued to the worker pool and
 // written in order; src/phaser.rs:513-543: a block's reads are loaded, then it is solved). A caller that hands over one block
 // set after the other therefore wants set k + 2 to be laid out and cross PCIe while set k + 1 is being aligned and set k is
-// being solved - not the three in a row. Three stages, one thread each, every stage with its own HIP streams, device-buffer
+// being solved - not one after the other. Four stages, one thread each, every stage with its own HIP streams, device-buffer
 // cache, pinned staging and host worker pool (all of them per-thread state of the library), so they overlap on the host and
 // on the device:
 //
 //   stage 1 (hp::blockset_init)   overlaps of every record, layout, reads staged piece by piece as the caller holds them
 //                                 (ASCII or the BAM's own 4-bit codes) while the previous piece crosses PCIe, expanded on the device
 //   stage 2 (hp::blockset_wfa)    device graph build + graph-WFA launch set + allele rows + first collection
-//   stage 3 (hp::blockset_tail)   fallback replay / qualities / collapse on host threads, A* pack + solve, span counts and
-//                                 haplotags, outputs into the caller's buffers
+//   stage 3 (hp::blockset_rows)   fallback replay / qualities / collapse on host threads, the A* batch packed and uploaded
+//   stage 4 (hp::blockset_solve)  A* (a latency-bound kernel: the host thread mostly waits), span counts and haplotags, outputs
+//                                 into the caller's buffers
 //
 // Sets complete in submission order. `depth` slots hold the sets in flight; a slot keeps its host vectors and device buffers
 // from one set to the next (hipMalloc / hipFree synchronise the device). submit() blocks while every slot is taken - the
@@ -49,7 +50,7 @@ struct Slot {
     hp_block_output* out = nullptr;
     int rc = HP_OK;
     std::string err;
-    double t_submit = 0, t_begin[3] = {0, 0, 0}, t_end[3] = {0, 0, 0};
+    double t_submit = 0, t_begin[4] = {0, 0, 0, 0}, t_end[4] = {0, 0, 0, 0};
 };
 
 }  // namespace
@@ -60,11 +61,11 @@ struct hp_blockstream {
     std::vector<std::unique_ptr<Slot>> slots;
     std::mutex m;
     std::condition_variable cv;
-    std::deque<Slot*> q[3];            // waiting for stage 1 / 2 / 3
+    std::deque<Slot*> q[4];            // waiting for stage 1 / 2 / 3 / 4
     uint64_t next_ticket = 1;
     bool quit = false;
-    std::thread th[3];
-    std::unique_ptr<WorkerPool> pool[3];
+    std::thread th[4];
+    std::unique_ptr<WorkerPool> pool[4];
     void stage_loop(int k);
 };
 
@@ -79,7 +80,10 @@ void hp_blockstream::stage_loop(int k) {
     static const int part = [] { const char* e = std::getenv("HP_STREAM_PARTITION"); return e ? std::atoi(e) : 0; }();
     if (part == 1) g_cu_partition = k == 1 ? 2 : 1;
     else if (part == 2) g_cu_partition = k == 1 ? 2 : 0;
-    g_host_share_div = k == 1 ? 4 : 2;   // the three stages' host threads together: about the process's share of the host
+    // ... what works instead: the alignment stage leaves a share of the wavefront slots empty (hp_wfa2.hip)
+    static const int reserve = [] { const char* e = std::getenv("HP_STREAM_RESERVE_PCT"); return e ? std::max(0, std::atoi(e)) : 12; }();
+    if (k == 1) g_wfa2_reserve_pct = reserve;
+    g_host_share_div = (k == 0 || k == 2) ? 2 : 4;   // the stages' host threads together: about the process's share of the host   // the three stages' host threads together: about the process's share of the host
     for (;;) {
         Slot* s = nullptr;
         {
@@ -94,13 +98,14 @@ void hp_blockstream::stage_loop(int k) {
             int rc = HP_OK;
             if (k == 0) rc = blockset_init(&s->bs, s->n_blocks, s->in, &prm, device);
             else if (k == 1) rc = blockset_wfa(&s->bs);
-            else rc = blockset_tail(&s->bs, s->out);
+            else if (k == 2) rc = blockset_rows(&s->bs);
+            else rc = blockset_solve(&s->bs, s->out);
             if (rc != HP_OK) { s->rc = rc; s->err = hp_last_error(); }
         }
         s->t_end[k] = st_now_ms();
         {
             std::unique_lock<std::mutex> lk(m);
-            if (k < 2) q[k + 1].push_back(s); else s->state = Slot::DONE;
+            if (k < 3) q[k + 1].push_back(s); else s->state = Slot::DONE;
             cv.notify_all();
         }
     }
@@ -110,16 +115,16 @@ extern "C" hp_blockstream* hp_blockstream_create(const hp_block_params* p, int d
     auto fail = [&](int rc) -> hp_blockstream* { if (status) *status = rc; return nullptr; };
     if (!p) { set_error("null argument"); return fail(HP_ERR_ARG); }
     if (hp_device_count() <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return fail(HP_ERR_HIP); }
-    if (depth == 0) depth = 4;
+    if (depth == 0) depth = 5;
     if (depth > 16) { set_error("depth %u: at most 16 block sets in flight", depth); return fail(HP_ERR_ARG); }
     auto s = std::unique_ptr<hp_blockstream>(new hp_blockstream());
     s->prm = *p;
     s->device = device_id < 0 ? hp_default_device() : device_id;
     if (hipSetDevice(s->device) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", s->device); return fail(HP_ERR_HIP); }
     for (uint32_t i = 0; i < depth; ++i) s->slots.emplace_back(new Slot());
-    for (int k = 0; k < 3; ++k) s->pool[k].reset(new WorkerPool());
+    for (int k = 0; k < 4; ++k) s->pool[k].reset(new WorkerPool());
     hp_blockstream* raw = s.get();
-    for (int k = 0; k < 3; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_loop(k); });
+    for (int k = 0; k < 4; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_loop(k); });
     if (status) *status = HP_OK;
     return s.release();
 }
@@ -156,12 +161,12 @@ extern "C" int hp_blockstream_wait(hp_blockstream* s, uint64_t ticket, double* s
         const hp_blockset& B = slot->bs;
         stage_ms[0] = B.prep[0]; stage_ms[1] = B.prep[1];
         stage_ms[2] = B.ms[0]; stage_ms[3] = B.ms[1]; stage_ms[4] = B.ms[2]; stage_ms[5] = B.ms[3]; stage_ms[6] = B.ms[4];
-        stage_ms[7] = slot->t_end[2] - slot->t_submit;
+        stage_ms[7] = slot->t_end[3] - slot->t_submit;
         stage_ms[8] = B.ms[6]; stage_ms[9] = B.ms[7];
         stage_ms[10] = B.prep[3];
-        stage_ms[11] = (slot->t_begin[0] - slot->t_submit) + (slot->t_begin[1] - slot->t_end[0]) + (slot->t_begin[2] - slot->t_end[1]);
+        stage_ms[11] = (slot->t_begin[0] - slot->t_submit) + (slot->t_begin[1] - slot->t_end[0]) + (slot->t_begin[2] - slot->t_end[1]) + (slot->t_begin[3] - slot->t_end[2]);
         stage_ms[12] = slot->t_end[0] - slot->t_begin[0]; stage_ms[13] = slot->t_end[1] - slot->t_begin[1]; stage_ms[14] = slot->t_end[2] - slot->t_begin[2];
-        stage_ms[15] = 0.0;
+        stage_ms[15] = slot->t_end[3] - slot->t_begin[3];
     }
     if (work) for (int i = 0; i < 8; ++i) work[i] = slot->bs.work[i];
     slot->state = Slot::FREE;

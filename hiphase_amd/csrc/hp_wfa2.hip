@@ -701,8 +701,23 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     const char* eenv = std::getenv("HP_WFA2_ESCALATE");
     const bool escalate = !(eenv && eenv[0] == '0') && (cls_cnt[0] || cls_cnt[1]);
     uint32_t grid_wg[3] = {0, 0, 0};
-    if (cls_cnt[0]) grid_wg[0] = w2_grid<8, 2>(cls_cnt[0], n_cu, cx.htab_groups);
-    if (cls_cnt[1]) grid_wg[1] = gsel == 16 ? w2_grid<16, 4>(cls_cnt[1], n_cu, cx.htab_groups) : gsel == 32 ? w2_grid<32, 4>(cls_cnt[1], n_cu, cx.htab_groups) : w2_grid<8, 4>(cls_cnt[1], n_cu, cx.htab_groups);
+    // Groups each class may occupy. On its own a launch set fills the chip (each of the two smaller classes is sized for all of
+    // it: the second one's workgroups move in as the first one's leave). As a stage of a block stream it must NOT: the kernels are
+    // persistent - no workgroup leaves before its class has run dry - so the kernels of the other stages (the copy engine's
+    // blits of the next set, the A* / Levenshtein / post-processing kernels of the previous one) would wait tens of
+    // milliseconds for a slot. g_wfa2_reserve_pct leaves that share of the slots empty and splits the rest by job count.
+    uint32_t capg[3] = {cx.htab_groups, cx.htab_groups, cx.htab_groups};
+    if (g_wfa2_reserve_pct > 0 && (cls_cnt[0] || cls_cnt[1])) {
+        const uint64_t total = (uint64_t)n_cu * 96u * (uint64_t)(100 - std::min(90, g_wfa2_reserve_pct)) / 100u;
+        const uint64_t c0 = cls_cnt[0], c1 = cls_cnt[1];
+        uint64_t g0 = total * c0 / (c0 + c1);
+        if (c0) g0 = std::max<uint64_t>(g0, 64);
+        if (c1) g0 = std::min<uint64_t>(g0, total - 64);
+        capg[0] = (uint32_t)std::max<uint64_t>(8, g0 & ~7ull);
+        capg[1] = (uint32_t)std::max<uint64_t>(8, (total - g0) & ~7ull);
+    }
+    if (cls_cnt[0]) grid_wg[0] = w2_grid<8, 2>(cls_cnt[0], n_cu, capg[0]);
+    if (cls_cnt[1]) grid_wg[1] = gsel == 16 ? w2_grid<16, 4>(cls_cnt[1], n_cu, capg[1]) : gsel == 32 ? w2_grid<32, 4>(cls_cnt[1], n_cu, capg[1]) : w2_grid<8, 4>(cls_cnt[1], n_cu, capg[1]);
     // (room for the jobs handed over: about 0.3 % of the two smaller classes on the default bench; HP_WFA2_ESC_DIV to experiment)
     const char* denv = std::getenv("HP_WFA2_ESC_DIV");
     const uint32_t esc_div = denv ? (uint32_t)std::max(1, std::atoi(denv)) : 128u;
@@ -730,10 +745,10 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         B.esc_role = !escalate ? 0u : (k == 2 ? 2u : 1u);
         B.esc_producers = grid_wg[0] + grid_wg[1];
         B.esc_limit = cls_cnt[2] + 2u * (items2 - cls_cnt[2]);   // two jobs for each group reserved for hand-overs
-        if (k == 0) rc = w2_launch<8, 2>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k]);
-        else if (k == 1) rc = gsel == 16 ? w2_launch<16, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k])
-                            : gsel == 32 ? w2_launch<32, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k])
-                                         : w2_launch<8, 4>(B, B.n_items, n_cu, cx.htab_groups, cs, &groups_used[k]);
+        if (k == 0) rc = w2_launch<8, 2>(B, B.n_items, n_cu, capg[0], cs, &groups_used[k]);
+        else if (k == 1) rc = gsel == 16 ? w2_launch<16, 4>(B, B.n_items, n_cu, capg[1], cs, &groups_used[k])
+                            : gsel == 32 ? w2_launch<32, 4>(B, B.n_items, n_cu, capg[1], cs, &groups_used[k])
+                                         : w2_launch<8, 4>(B, B.n_items, n_cu, capg[1], cs, &groups_used[k]);
         else rc = w2_launch<16, 8>(B, items2, n_cu, cx.htab_groups, cs, &groups_used[k]);
         if (rc != HP_OK) return rc;
         if (two_phase && k == 2) { HP_HIP_CHECK(hipEventRecord(e3, cs)); continue; }   // collected later (late())
