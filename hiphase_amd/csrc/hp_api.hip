@@ -2,6 +2,8 @@
 #include "hp_common.h"
 
 #include <atomic>
+#include <cstdio>
+#include <sched.h>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -76,12 +78,35 @@ int device_cu_count(int device_id) {
     return v;
 }
 
+// A block stream keeps a dozen HIP streams busy at once (copies, three class launches, the search's two, the helpers'); the
+// runtime multiplexes streams onto 4 hardware queues by default, and a kernel that lands behind a persistent graph-WFA kernel
+// in a shared queue starts when that one ends. More hardware queues (read by the runtime when it initialises: this runs when
+// the library is loaded, before its first HIP call; an explicit setting of the caller's wins).
+static const int g_hw_queues_set = [] { return setenv("GPU_MAX_HW_QUEUES", "16", 0); }();
 thread_local unsigned g_host_share_div = 0;
 thread_local int g_wfa2_reserve_pct = 0;
 unsigned host_threads(unsigned want) {
     static const unsigned share = [] {
         if (const char* e = std::getenv("HP_HOST_THREADS")) return (unsigned)std::max(1, std::atoi(e));
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        // what this process may really use: the hardware threads, clipped by its affinity mask and by a cgroup CPU quota (a
+        // container on a 256-thread host may be allowed 16 CPUs: 32 workers per stage would only take turns on them)
+        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0) hw = std::min(hw, (unsigned)n); }
+            if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+                char q[32] = {0}; long period = 0;
+                if (std::fscanf(f, "%31s %ld", q, &period) == 2 && q[0] != 'm' && period > 0) { const long quota = std::atol(q); if (quota > 0) hw = std::min(hw, (unsigned)std::max(1l, quota / period)); }
+                std::fclose(f);
+            } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                long quota = -1, period = 0;
+                if (std::fscanf(g, "%ld", &quota) != 1) quota = -1;
+                std::fclose(g);
+                if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(h, "%ld", &period) != 1) period = 0; std::fclose(h); }
+                if (quota > 0 && period > 0) hw = std::min(hw, (unsigned)std::max(1l, quota / period));
+            }
+        }
         unsigned procs = 1;
         if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) procs = (unsigned)std::max(1, std::atoi(e));
         return std::max(2u, hw / procs);
@@ -107,12 +132,12 @@ int partition_cu_count(int device_id) {
     return g_cu_partition == 1 ? std::max(1, s) : std::max(1, n - s);
 }
 
-hipError_t hp_stream_create(hipStream_t* s, int device_id, bool high_priority) {
+hipError_t hp_stream_create(hipStream_t* s, int device_id, int priority) {
     if (g_cu_partition == 0) {
-        if (!high_priority) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-        int prio_lo = 0, prio_hi = 0;
+        if (priority == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        int prio_lo = 0, prio_hi = 0;   // (numerically: the greatest priority is the lowest number)
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_hi);
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority > 0 ? prio_hi : prio_lo);
     }
     const int n = device_cu_count(device_id);
     std::vector<uint32_t> mask((size_t)(n + 31) / 32, 0u);

@@ -260,7 +260,7 @@ struct StreamSet {
         device = dev; partition = g_cu_partition;
         // the segment stream carries the critical path: a high-priority stream also gets a hardware queue of its own
         // (streams of equal priority may share one when the host process has created many, e.g. under PyTorch)
-        return hp_stream_create(&stream, dev) == hipSuccess && hp_stream_create(&stream2, dev, true) == hipSuccess &&
+        return hp_stream_create(&stream, dev, 1) == hipSuccess && hp_stream_create(&stream2, dev, 1) == hipSuccess &&
                hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess &&
                hipEventCreate(&ev_fork) == hipSuccess && hipEventCreate(&ev_join) == hipSuccess;
     }

@@ -556,7 +556,9 @@ int hp::blockset_rows(hp_blockset* bs) {
         // the blocks that wait for nothing first; then the ones that hold a read the second collection / the dense-band pass
         // delivers (that pass has had the first phase to finish in)
         if ((rc = phase(0, n_free)) != HP_OK) return rc;
+        const double tw = blk_now_ms();
         if (has_wfa && (rc = w2_session_finish(ch.wfa)) != HP_OK) return rc;
+        ch.late_wait_ms = blk_now_ms() - tw;
         if ((rc = phase(n_free, order.size())) != HP_OK) return rc;
         if (has_wfa) ch.ms[6] = w2_session_span_ms(ch.wfa);
     }

@@ -52,7 +52,8 @@ int device_cu_count(int device_id);
 // number in every XCD); 2 = the other seven. The setting is per thread: a stream created while it is set is bound to
 // that partition's CUs (and gets a hardware queue of its own), and the persistent kernels size their grids to it.
 extern thread_local int g_cu_partition;
-hipError_t hp_stream_create(hipStream_t* s, int device_id, bool high_priority = false);
+// priority: +1 the latency-critical kernels of the search, 0 normal, -1 the persistent throughput kernels of the alignment stage
+hipError_t hp_stream_create(hipStream_t* s, int device_id, int priority = 0);
 int partition_cu_count(int device_id);   // CUs of the calling thread's current partition
 // The calling thread's own stream on `device` in its current CU partition (created on first use, lives as long as the thread):
 // what the small entry points launch on. Nothing in the library uses the NULL stream or hipDeviceSynchronize - a stage of a block

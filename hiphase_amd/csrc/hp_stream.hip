@@ -63,6 +63,7 @@ struct hp_blockstream {
     std::condition_variable cv;
     std::deque<Slot*> q[4];            // waiting for stage 1 / 2 / 3 / 4
     uint64_t next_ticket = 1;
+    double t_zero = 0.0;
     bool quit = false;
     std::thread th[4];
     std::unique_ptr<WorkerPool> pool[4];
@@ -81,7 +82,7 @@ void hp_blockstream::stage_loop(int k) {
     if (part == 1) g_cu_partition = k == 1 ? 2 : 1;
     else if (part == 2) g_cu_partition = k == 1 ? 2 : 0;
     // ... what works instead: the alignment stage leaves a share of the wavefront slots empty (hp_wfa2.hip)
-    static const int reserve = [] { const char* e = std::getenv("HP_STREAM_RESERVE_PCT"); return e ? std::max(0, std::atoi(e)) : 12; }();
+    static const int reserve = [] { const char* e = std::getenv("HP_STREAM_RESERVE_PCT"); return e ? std::max(0, std::atoi(e)) : 8; }();
     if (k == 1) g_wfa2_reserve_pct = reserve;
     g_host_share_div = (k == 0 || k == 2) ? 2 : 4;   // the stages' host threads together: about the process's share of the host   // the three stages' host threads together: about the process's share of the host
     for (;;) {
@@ -157,6 +158,12 @@ extern "C" int hp_blockstream_wait(hp_blockstream* s, uint64_t ticket, double* s
     s->cv.wait(lk, [&]() { return slot->state == Slot::DONE; });
     const int rc = slot->rc;
     if (rc != HP_OK) set_error("%s", slot->err.c_str());
+    if (std::getenv("HP_STREAM_TRACE")) {   // the set's way through the stages, ms since the stream's first submit
+        if (s->t_zero == 0.0) s->t_zero = slot->t_submit;
+        fprintf(stderr, "[hp] set %llu: submit %.1f | s1 %.1f-%.1f | s2 %.1f-%.1f | s3 %.1f-%.1f (waited %.1f for the late results) | s4 %.1f-%.1f\n", (unsigned long long)ticket,
+                slot->t_submit - s->t_zero, slot->t_begin[0] - s->t_zero, slot->t_end[0] - s->t_zero, slot->t_begin[1] - s->t_zero, slot->t_end[1] - s->t_zero,
+                slot->t_begin[2] - s->t_zero, slot->t_end[2] - s->t_zero, slot->bs.late_wait_ms, slot->t_begin[3] - s->t_zero, slot->t_end[3] - s->t_zero);
+    }
     if (stage_ms) {
         const hp_blockset& B = slot->bs;
         stage_ms[0] = B.prep[0]; stage_ms[1] = B.prep[1];

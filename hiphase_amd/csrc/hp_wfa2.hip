@@ -64,6 +64,7 @@ struct W2Context {
     int streams(int part, Streams** out) {   // created on first use in that partition
         Streams& s = ps[part];
         if (!s.stream) HP_HIP_CHECK(hp_stream_create(&s.stream, device));
+        // (measured: low stream priority for these persistent kernels makes THEM 40 % slower - 48 vs 35 ms - and nothing else faster)
         for (int k = 0; k < 3; ++k) if (!s.cstream[k]) HP_HIP_CHECK(hp_stream_create(&s.cstream[k], device));
         *out = &s;
         return HP_OK;
@@ -710,7 +711,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     if (g_wfa2_reserve_pct > 0 && (cls_cnt[0] || cls_cnt[1])) {
         const uint64_t total = (uint64_t)n_cu * 96u * (uint64_t)(100 - std::min(90, g_wfa2_reserve_pct)) / 100u;
         const uint64_t c0 = cls_cnt[0], c1 = cls_cnt[1];
-        uint64_t g0 = total * c0 / (c0 + c1);
+        uint64_t g0 = total * (10 * c0) / (10 * c0 + 13 * c1);   // (a job of the middle class - a larger graph - takes about 1.3 x as long: measured spans 23 vs 29.5 ms at equal shares)
         if (c0) g0 = std::max<uint64_t>(g0, 64);
         if (c1) g0 = std::min<uint64_t>(g0, total - 64);
         capg[0] = (uint32_t)std::max<uint64_t>(8, g0 & ~7ull);
@@ -718,9 +719,9 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     }
     if (cls_cnt[0]) grid_wg[0] = w2_grid<8, 2>(cls_cnt[0], n_cu, capg[0]);
     if (cls_cnt[1]) grid_wg[1] = gsel == 16 ? w2_grid<16, 4>(cls_cnt[1], n_cu, capg[1]) : gsel == 32 ? w2_grid<32, 4>(cls_cnt[1], n_cu, capg[1]) : w2_grid<8, 4>(cls_cnt[1], n_cu, capg[1]);
-    // (room for the jobs handed over: about 0.3 % of the two smaller classes on the default bench; HP_WFA2_ESC_DIV to experiment)
+    // (room for the jobs handed over: about 2 % of the two smaller classes on the round-3 bench workload - structural variants put a read's paths far apart; HP_WFA2_ESC_DIV to experiment)
     const char* denv = std::getenv("HP_WFA2_ESC_DIV");
-    const uint32_t esc_div = denv ? (uint32_t)std::max(1, std::atoi(denv)) : 128u;
+    const uint32_t esc_div = denv ? (uint32_t)std::max(1, std::atoi(denv)) : 32u;
     const uint32_t items2 = escalate ? cls_cnt[2] + std::max<uint32_t>(4u * 48u, (cls_cnt[0] + cls_cnt[1]) / esc_div) : cls_cnt[2];
     // two phases: the results of everything the two smaller classes finished themselves are collected as soon as THEIR
     // kernels are done; the largest class (its own jobs + what was handed over, the tail of the launch set) is collected
