@@ -239,16 +239,24 @@ def main_path(args, rank, world, local_rank, dist, backend):
     from hiphase_amd.synth_sets import SynthSet, default_spec
     lib = _ffi.lib()
     fmt = _ffi.SEQ_BAM4 if args.seq_format == "bam4" else _ffi.SEQ_ASCII
-    n_sets = max(1, min(args.steps + args.warmup, args.distinct_sets))
+    capture = None
+    if args.replay:   # a .hpbr capture of real blocks: the same blocks every step, still crossing PCIe every step
+        from hiphase_amd.synth_sets import Capture
+        capture = Capture(args.replay)
+        if world > 1:
+            raise SystemExit("--replay of a .hpbr capture runs on one GPU (the multi-GPU replay is hp_solve_blocks(device_id=-1))")
+    n_sets = 1 if capture else max(1, min(args.steps + args.warmup, args.distinct_sets))
     gen_threads = max(2, min(32, host_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     t_gen = time.perf_counter()
-    sets = []
-    for k in range(n_sets):   # rank r, set k: seed + 1000 r + k (disjoint over ranks and steps)
+    sets = [capture] if capture else []
+    for k in range(0 if capture else n_sets):   # rank r, set k: seed + 1000 r + k (disjoint over ranks and steps)
         sets.append(SynthSet(default_spec(lib, seed=args.seed + 1000 * rank + k, total_hets=args.total_hets, max_block_hets=args.max_block_hets,
                                           coverage=float(args.coverage), seq_format=fmt, threads=gen_threads)))
     outs = [s.outputs() for s in sets]
     t_gen = time.perf_counter() - t_gen
     prm = block_params()
+    if capture and capture.n:
+        prm = capture.params[0]   # (the parameters the blocks were captured with)
     st = C.c_int(0)
     stream = lib.hp_blockstream_create(C.byref(prm), local_rank, args.depth, C.byref(st))
     if not stream:
@@ -366,6 +374,12 @@ def main_path(args, rank, world, local_rank, dist, backend):
                 out["resident"] = {"hets_per_s": s0.info["hets"] / dt, "ms_per_step": dt * 1e3, "layout_upload_ms": t_up * 1e3,
                                    "note": "hp_blockset_solve over one resident set (inputs in HBM, no overlap between stages)"}
                 out["streamed_over_resident"] = out["value"] / out["resident"]["hets_per_s"]
+        if capture:
+            out["data"] = "replay of " + os.path.basename(args.replay)
+            out["config"]["workload"] = f"replay of the read-bearing capture {os.path.basename(args.replay)}: {info['blocks']} blocks, {info['hets']} hets, {info['records']} records, streamed again every step"
+            have = [b for b in range(capture.n) if capture.expected[b].status != -2 ** 31]
+            ok = all(bool(lib.hp_block_output_equal(C.byref(capture.inputs[b]), C.byref(outs[0].arr[b]), C.byref(capture.expected[b]))) for b in have)
+            out["parity_vs_capture"] = {"blocks_compared": len(have), "of": capture.n, "bit_identical": bool(ok)}
         if not args.no_cpu and world == 1:
             # CPU leg + parity, on the first timed set: the oracle's whole path (hpo_solve_block) on every host core over ALL its
             # blocks - that is also the parity check of every block - and on one thread over a random sample of them
@@ -415,7 +429,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the WGS-like secondary measurement")
-    ap.add_argument("--replay", default=None, help=".hpbk capture of real phase blocks (strong scaling over ranks)")
+    ap.add_argument("--replay", default=None, help=".hpbr capture of real phase blocks (read-bearing: the whole path) or .hpbk (solver matrices: solver stage, strong scaling over ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -439,8 +453,8 @@ def main():
     if lib.hp_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libhiphase_gpu.so has no CPU fallback")
 
-    if args.replay and args.workload == "path":
-        args.workload = "c2"   # a capture holds solver matrices: replay is a solver-stage run
+    if args.replay and args.workload == "path" and not args.replay.endswith(".hpbr"):
+        args.workload = "c2"   # a .hpbk capture holds solver matrices: replay is a solver-stage run (.hpbr: read-bearing, the whole path)
     if args.workload == "path":
         return main_path(args, rank, world, local_rank, dist, backend)
 

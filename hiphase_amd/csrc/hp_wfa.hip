@@ -572,6 +572,7 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
                         uint8_t* const* alleles, int device_id);   // hp_wfa2.hip
 int wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
                         uint8_t* const* alleles, int device_id);
+extern thread_local const uint32_t* g_wfa_min_ed_hint;   // hp_wfa2_host.h
 }
 using namespace hp;
 
@@ -657,7 +658,8 @@ extern "C" int hp_wfa_assign_batch(const hp_wfa_job* jobs, size_t n, uint64_t pr
 // edit_distance_with_pruning (wfa_graph.rs:350-650) for finished host graphs on the dense-band kernels: status, score and
 // the traversed-node bitsets ((n_nodes + 31) / 32 words per job at set_off[job]).
 static int run_graphs(const std::vector<HostJob>& hj, uint64_t prune_distance, uint64_t max_ed, int device_id,
-                      std::vector<int32_t>& status, std::vector<uint64_t>& score, std::vector<uint32_t>& sets, std::vector<uint64_t>& set_off) {
+                      std::vector<int32_t>& status, std::vector<uint64_t>& score, std::vector<uint32_t>& sets, std::vector<uint64_t>& set_off,
+                      const uint32_t* min_ed_hint = nullptr) {
     const size_t n = hj.size();
     // host-side work is done; from here on a GPU is mandatory (no CPU fallback)
     if (device_id < 0) device_id = hp_default_device();
@@ -677,11 +679,21 @@ static int run_graphs(const std::vector<HostJob>& hj, uint64_t prune_distance, u
         for (size_t i = 0; i < n; ++i) if ((hj[i].nodes.size() > WFA_MAX_NODES) == (big == 1)) ids.push_back((uint32_t)i);
         if (ids.empty()) continue;
         uint32_t band = (uint32_t)std::min<uint64_t>(max_ed, benv ? (uint64_t)std::atoi(benv) : 96);
+        std::vector<uint32_t> wide;   // known to need more than the narrow band (g_wfa_min_ed_hint): they join the second pass
+        if (min_ed_hint && band < max_ed) {
+            std::vector<uint32_t> narrow;
+            for (uint32_t id : ids) (min_ed_hint[id] >= band ? wide : narrow).push_back(id);
+            ids.swap(narrow);
+        }
         for (;;) {
-            int rc = run_pass(hj, ids, band, prune_distance, max_ed, n_cu, status, score, sets, set_off, big == 1);
-            if (rc != HP_OK) return rc;
+            if (!ids.empty()) {
+                int rc = run_pass(hj, ids, band, prune_distance, max_ed, n_cu, status, score, sets, set_off, big == 1);
+                if (rc != HP_OK) return rc;
+            }
             std::vector<uint32_t> again;
             for (uint32_t id : ids) if (status[id] == WFA_ST_NEED_BAND) again.push_back(id);
+            again.insert(again.end(), wide.begin(), wide.end());
+            wide.clear();
             if (again.empty()) break;
             if (band >= max_ed) { set_error("WFA band overflow at full width (internal)"); return HP_ERR_INVARIANT; }
             band = (uint32_t)std::min<uint64_t>(max_ed, (uint64_t)band * 6);
@@ -692,6 +704,8 @@ static int run_graphs(const std::vector<HostJob>& hj, uint64_t prune_distance, u
         if (status[i] != WFA_ST_OK && status[i] != WFA_ST_MAX_ED) { set_error("job %zu: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
     return HP_OK;
 }
+
+thread_local const uint32_t* hp::g_wfa_min_ed_hint = nullptr;
 
 int hp::wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed,
                             hp_wfa_result* out, uint8_t* const* alleles, int device_id) {
@@ -743,7 +757,7 @@ int hp::wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_dis
     std::vector<uint64_t> score, set_off;
     std::vector<uint32_t> sets;
     {
-        const int rc = run_graphs(hj, prune_distance, max_ed, device_id, status, score, sets, set_off);
+        const int rc = run_graphs(hj, prune_distance, max_ed, device_id, status, score, sets, set_off, g_wfa_min_ed_hint);
         if (rc != HP_OK) return rc;
     }
     const double t_map = now_ms();

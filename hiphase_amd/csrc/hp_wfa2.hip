@@ -188,6 +188,7 @@ struct W2Session {
         std::vector<uint32_t> held;     // still with the largest class's kernel when run() collected the others
         std::vector<uint32_t> held_nodes;   // their graphs' node counts (hp_wfa_result::n_nodes)
         std::vector<uint32_t> big;      // for the dense-band pass
+        std::vector<uint32_t> big_ed;   // the edit distance each of them had reached when the compact kernel let go of it
         std::vector<hp_wfa_job> sub;
         std::vector<hp_wfa_result> sub_out;
         std::vector<uint8_t*> sub_al;
@@ -790,8 +791,8 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     pend.stream2 = cs_->cstream[2]; pend.ms_build = ms_build;
     for (size_t i = 0; i < n; ++i) {
         if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %zu", i); return HP_ERR_INVARIANT; }
-        if (status[i] == W2_ST_PENDING) { if (two_phase) { pend.held.push_back((uint32_t)i); pend.held_nodes.push_back(info[i].n_nodes); } else pend.big.push_back((uint32_t)i); }
-        else if (status[i] == W2_ST_NEED_BIG) pend.big.push_back((uint32_t)i);
+        if (status[i] == W2_ST_PENDING) { if (two_phase) { pend.held.push_back((uint32_t)i); pend.held_nodes.push_back(info[i].n_nodes); } else { pend.big.push_back((uint32_t)i); pend.big_ed.push_back(0); } }
+        else if (status[i] == W2_ST_NEED_BIG) { pend.big.push_back((uint32_t)i); pend.big_ed.push_back((uint32_t)(score[i] >> 8)); }
     }
     const size_t n_big = cls_n[3];
 #if W2_STATS
@@ -819,9 +820,9 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         uint32_t hist[3][10] = {};
         for (uint32_t i : pend.big) {
             const uint32_t nn = info[i].n_nodes, ne = info[i].n_edges;
-            if (info[i].status != W2B_OK || score[i] == 0 || score[i] > 9) continue;
+            if (info[i].status != W2B_OK || (score[i] & 0xFF) == 0 || (score[i] & 0xFF) > 9) continue;
             const int k = (nn <= (uint32_t)W2Cfg<2>::MAXN && ne <= (uint32_t)W2Cfg<2>::MAXE) ? 0 : (nn <= (uint32_t)W2Cfg<4>::MAXN && ne <= (uint32_t)W2Cfg<4>::MAXE) ? 1 : 2;
-            hist[k][score[i]]++;
+            hist[k][score[i] & 0xFF]++;
         }
         for (int k = 0; k < 3; ++k) {
             fprintf(stderr, "[hp] wfa2: class %d handed back:", k);
@@ -923,7 +924,7 @@ int W2Session::late() {
         for (size_t hk = 0; hk < h; ++hk) {
             const uint32_t i = pend.held[hk];
             const int32_t sti = rec[hk].status;
-            if (sti == W2_ST_NEED_BIG || sti == W2_ST_PENDING) { pend.big.push_back(i); continue; }   // (PENDING: handed over, never claimed)
+            if (sti == W2_ST_NEED_BIG || sti == W2_ST_PENDING) { pend.big.push_back(i); pend.big_ed.push_back(sti == W2_ST_NEED_BIG ? (uint32_t)(rec[hk].score >> 8) : 0u); continue; }   // (PENDING: handed over, never claimed)
             if (sti != W2_ST_OK && sti != W2_ST_MAX_ED) { set_error("job %u: device status %d", i, sti); return HP_ERR_INVARIANT; }
             s0 += rec[hk].work_updates; s1 += rec[hk].work_bytes; s2w += dj[i].read_len; ++s3;
             pend.dst[i].status = sti == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
@@ -947,11 +948,20 @@ int W2Session::late() {
         work_updates += s0; work_node_bytes += s1; work_read_bytes += s2w; work_jobs += s3;
     }
     if (!pend.big.empty()) {
-        std::sort(pend.big.begin(), pend.big.end());
+        {   // ascending job order (with the hints)
+            std::vector<std::pair<uint32_t, uint32_t>> z(pend.big.size());
+            for (size_t k = 0; k < z.size(); ++k) z[k] = {pend.big[k], k < pend.big_ed.size() ? pend.big_ed[k] : 0u};
+            std::sort(z.begin(), z.end());
+            pend.big_ed.resize(z.size());
+            for (size_t k = 0; k < z.size(); ++k) { pend.big[k] = z[k].first; pend.big_ed[k] = z[k].second; }
+        }
         pend.sub.resize(pend.big.size()); pend.sub_out.resize(pend.big.size()); pend.sub_al.resize(pend.big.size());
         ascii_scratch.clear();
         for (size_t k = 0; k < pend.big.size(); ++k) { pend.sub[k] = materialize(pend.big[k]); pend.sub_al[k] = pend.alleles ? pend.alleles[pend.big[k]] : nullptr; }
+        // a read that was past the narrow band's edit distance when the compact kernel let go of it starts at full width
+        g_wfa_min_ed_hint = pend.big_ed.data();
         const int rc = wfa_assign_batch_v1(pend.sub.data(), pend.sub.size(), pend.prune, pend.max_ed, pend.sub_out.data(), pend.alleles ? pend.sub_al.data() : nullptr, device_id);
+        g_wfa_min_ed_hint = nullptr;
         if (rc != HP_OK) return rc;
         late_kernel_ms += g_last_kernel_ms;
         for (size_t k = 0; k < pend.big.size(); ++k) pend.dst[pend.big[k]] = pend.sub_out[k];

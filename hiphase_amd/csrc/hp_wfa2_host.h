@@ -36,4 +36,8 @@ double w2_session_span_ms(const W2Session* s);
 int wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
                         uint8_t* const* alleles, int device_id);
 
+// optional, per job of the next wfa_assign_batch_v1 call on this thread: an edit distance the job is known to exceed (it starts
+// with a band that wide); nullptr = none
+extern thread_local const uint32_t* g_wfa_min_ed_hint;
+
 }  // namespace hp

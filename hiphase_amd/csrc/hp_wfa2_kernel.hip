@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                         // A position that could not be published leaves the job PENDING: the host's dense-band pass takes it.
                         handed_over = w2_gballot<G>(me, gbase) != 0;
                     }
-                    if (!handed_over && gl == 0) { B.status[job] = status; B.out_score[job] = status == W2_ST_NEED_BIG ? (uint64_t)why : score; B.out_work[(size_t)job * 2] = upd; }
+                    if (!handed_over && gl == 0) { B.status[job] = status; B.out_score[job] = status == W2_ST_NEED_BIG ? (uint64_t)(why | (ed << 8)) /* the limit it ran into, the round it was in */ : score; B.out_work[(size_t)job * 2] = upd; }
                     if (!handed_over && gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
 #if W2_STATS
                     if (W <= 4 && gl == 0) { B.out_sets[(size_t)job * W2_SET_STRIDE + 6] = mx_l | (mx_f << 8) | (mx_top << 16); }

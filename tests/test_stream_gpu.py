@@ -68,3 +68,32 @@ def test_blockstream_on_generated_sets_vs_oracle(monkeypatch):
                 assert [b for b in range(sets[kk].n) if not outs[kk].equal(exps[kk], b)] == []
     finally:
         lib.hp_blockstream_destroy(stream)
+
+
+@pytest.mark.timeout(900)
+def test_hpbr_capture_replays_through_the_product_and_bench(tmp_path):
+    """a `.hpbr` capture written with the oracle's results as expected output (standing in for a patched HiPhase's own
+    solve_block): hp_solve_blocks on the replayed inputs equals the file, and `bench.py --replay` streams it and says so"""
+    import json
+    import os
+    import subprocess
+    import sys
+    lib = _ffi.lib()
+    d = oracle()
+    prm = _params(2, 1000, 3, None, True)
+    s = SynthSet(default_spec(lib, total_hets=500, seed=31, seq_format=_ffi.SEQ_BAM4, **KW))
+    path = tmp_path / "cap.hpbr"
+    exp = oracle_outputs(s, prm)
+    for b in range(s.n):
+        assert lib.hp_hpbr_append(str(path).encode(), C.byref(s.inputs[b]), C.byref(prm), C.byref(exp.arr[b])) == 0
+    from hiphase_amd.synth_sets import Capture
+    cap = Capture(path)
+    got = cap.outputs()
+    _ffi.check(lib.hp_solve_blocks(cap.n, cap.inputs, C.byref(cap.params[0]), got.arr, 0))
+    assert [b for b in range(cap.n) if not lib.hp_block_output_equal(C.byref(cap.inputs[b]), C.byref(got.arr[b]), C.byref(cap.expected[b]))] == []
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--replay", str(path), "--steps", "3", "--warmup", "1", "--no-cpu", "--no-resident"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["parity_vs_capture"] == {"blocks_compared": cap.n, "of": cap.n, "bit_identical": True} and out["value"] > 0
