@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 PMC passes of scripts/prof_path.sh (PMC=1) into profiles/round2-style summaries:
+"""Turns the rocprofv3 PMC passes of scripts/prof_path.sh (PMC=1) into profiles/round3-style summaries:
   <out>/pmc_summary.txt   per-kernel counter totals, the derived ratios DESIGN.md quotes
   <out>/traffic.json      HBM bytes per read (hp_wfa2_kernel, all three class instantiations) and per het (hp_astar_kernel),
                           keyed by the sha256 of the libhiphase_gpu.so they were measured on (bench.py only reports
@@ -60,7 +60,7 @@ for g, unit, n in (("hp_wfa2_kernel", "bytes_per_read", reads), ("hp_astar_kerne
         b = (2.0 * tot[(g, "FETCH_SIZE")] + tot[(g, "WRITE_SIZE")]) * 1024.0 / launches
         traffic[g] = {unit: b / n, "hbm_bytes_per_step": b, "FETCH_SIZE_KB_per_step": tot[(g, "FETCH_SIZE")] / launches,
                       "WRITE_SIZE_KB_per_step": tot[(g, "WRITE_SIZE")] / launches, "so_sha256": sha,
-                      "source": "profiles/round2/path_pmc_summary.txt"}
+                      "source": "profiles/round3/path_pmc_summary.txt"}
         lines.append(f"{g}: HBM traffic (FETCH x 2 + WRITE) = {b / 1e6:.1f} MB per step = {b / n:.0f} {unit.replace('_', ' ')}")
     w, a, wa, wi = (tot.get((g, c)) for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"))
     if w:
