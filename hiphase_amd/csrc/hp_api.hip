@@ -14,7 +14,7 @@
 namespace hp {
 namespace {
 // see hp_common.h: size classes = next power of two up to 1 MiB, then multiples of 1 MiB (so a re-run of a similar
-// batch finds its blocks again); at most 24 GiB stay cached, single blocks above 4 GiB never do. The cache is process-wide
+// batch finds its blocks again); at most 64 GiB stay cached (of 288), single blocks above 8 GiB never do. The cache is process-wide
 // (one mutex; an entry point takes a couple of dozen blocks per call): a block set travels through the threads of a block
 // stream - laid out by one, aligned by the next, solved by a third - and whoever lets a buffer go must hand it to whoever needs
 // one next, or the first thread would hipMalloc (and synchronise the device) for every set. Never destroyed: threads may still
@@ -23,10 +23,14 @@ struct DevCache {
     std::mutex m;
     std::multimap<std::pair<int, size_t>, void*> free_;   // (device, bytes) -> block
     size_t cached = 0;
-    static constexpr size_t kMaxCached = 24ull << 30, kMaxBlock = 4ull << 30;
+    static constexpr size_t kMaxCached = 64ull << 30, kMaxBlock = 8ull << 30;
+    // size classes: powers of two and 1.5 x powers of two. A request takes any cached block up to twice its size: the buffers of a
+    // stage differ a little from set to set (a few hundred leftovers more or less), and a miss is a hipMalloc - which waits for
+    // every kernel on the device, the persistent ones of the neighbouring stage included (measured: stalls of 50-400 ms).
     static size_t round_up(size_t n) {
-        if (n <= (1u << 20)) { size_t r = 256; while (r < n) r <<= 1; return r; }
-        return (n + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+        size_t r = 256;
+        while (r < n) { if (r + r / 2 >= n && r >= 4096) return r + r / 2; r <<= 1; }
+        return r;
     }
 };
 DevCache& dev_cache() { static DevCache* c = new DevCache(); return *c; }
@@ -41,7 +45,7 @@ void* dev_cache_get(size_t bytes, size_t* got, int* dev_out) {
     {
         std::lock_guard<std::mutex> lk(c.m);
         auto it = c.free_.lower_bound({dev, want});
-        if (it != c.free_.end() && it->first.first == dev && it->first.second <= want + want / 4) {
+        if (it != c.free_.end() && it->first.first == dev && it->first.second <= 2 * want) {
             void* p = it->second;
             *got = it->first.second;
             c.cached -= it->first.second;

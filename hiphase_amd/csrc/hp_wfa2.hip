@@ -13,6 +13,7 @@
 #include "hp_wfa2_host.h"
 
 #include <algorithm>
+#include <array>
 #include <memory>
 #include <atomic>
 #include <cstdlib>
@@ -153,6 +154,15 @@ struct W2Session {
     std::vector<std::vector<uint8_t>> ascii_scratch;   // block mode: decoded reads of the jobs that leave the compact path
     // job i as the dense-band path takes it (generic mode: the caller's; block mode: assembled from the block, a BAM 4-bit read
     // decoded on the host - a handful of jobs per batch)
+    hp_wfa_job job_header(size_t i) const {   // job i's window and variant lists (no read)
+        if (jobs) return jobs[i];
+        const W2JobIn& ji = bl_jobs[i];
+        const hp_block_input& B = bl_in[ji.block];
+        hp_wfa_job j{};
+        j.hets = B.hets + ji.het_first; j.n_hets = ji.n_hets;
+        j.homs = ji.n_homs ? B.homs + ji.hom_first : nullptr; j.n_homs = ji.n_homs;
+        return j;
+    }
     hp_wfa_job materialize(size_t i) {
         if (jobs) return jobs[i];
         const W2JobIn& ji = bl_jobs[i];
@@ -189,6 +199,7 @@ struct W2Session {
         std::vector<uint32_t> held_nodes;   // their graphs' node counts (hp_wfa_result::n_nodes)
         std::vector<uint32_t> big;      // for the dense-band pass
         std::vector<uint32_t> big_ed;   // the edit distance each of them had reached when the compact kernel let go of it
+        std::vector<uint32_t> big_nodes; // their graphs' node counts (0: the device builder left the graph to the host)
         std::vector<hp_wfa_job> sub;
         std::vector<hp_wfa_result> sub_out;
         std::vector<uint8_t*> sub_al;
@@ -791,8 +802,8 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     pend.stream2 = cs_->cstream[2]; pend.ms_build = ms_build;
     for (size_t i = 0; i < n; ++i) {
         if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %zu", i); return HP_ERR_INVARIANT; }
-        if (status[i] == W2_ST_PENDING) { if (two_phase) { pend.held.push_back((uint32_t)i); pend.held_nodes.push_back(info[i].n_nodes); } else { pend.big.push_back((uint32_t)i); pend.big_ed.push_back(0); } }
-        else if (status[i] == W2_ST_NEED_BIG) { pend.big.push_back((uint32_t)i); pend.big_ed.push_back((uint32_t)(score[i] >> 8)); }
+        if (status[i] == W2_ST_PENDING) { if (two_phase) { pend.held.push_back((uint32_t)i); pend.held_nodes.push_back(info[i].n_nodes); } else { pend.big.push_back((uint32_t)i); pend.big_ed.push_back(0); pend.big_nodes.push_back(info[i].status == W2B_OK ? info[i].n_nodes : 0u); } }
+        else if (status[i] == W2_ST_NEED_BIG) { pend.big.push_back((uint32_t)i); pend.big_ed.push_back((uint32_t)(score[i] >> 8)); pend.big_nodes.push_back(info[i].status == W2B_OK ? info[i].n_nodes : 0u); }
     }
     const size_t n_big = cls_n[3];
 #if W2_STATS
@@ -924,7 +935,7 @@ int W2Session::late() {
         for (size_t hk = 0; hk < h; ++hk) {
             const uint32_t i = pend.held[hk];
             const int32_t sti = rec[hk].status;
-            if (sti == W2_ST_NEED_BIG || sti == W2_ST_PENDING) { pend.big.push_back(i); pend.big_ed.push_back(sti == W2_ST_NEED_BIG ? (uint32_t)(rec[hk].score >> 8) : 0u); continue; }   // (PENDING: handed over, never claimed)
+            if (sti == W2_ST_NEED_BIG || sti == W2_ST_PENDING) { pend.big.push_back(i); pend.big_ed.push_back(sti == W2_ST_NEED_BIG ? (uint32_t)(rec[hk].score >> 8) : 0u); pend.big_nodes.push_back(pend.held_nodes[hk]); continue; }   // (PENDING: handed over, never claimed)
             if (sti != W2_ST_OK && sti != W2_ST_MAX_ED) { set_error("job %u: device status %d", i, sti); return HP_ERR_INVARIANT; }
             s0 += rec[hk].work_updates; s1 += rec[hk].work_bytes; s2w += dj[i].read_len; ++s3;
             pend.dst[i].status = sti == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
@@ -949,12 +960,65 @@ int W2Session::late() {
     }
     if (!pend.big.empty()) {
         {   // ascending job order (with the hints)
-            std::vector<std::pair<uint32_t, uint32_t>> z(pend.big.size());
-            for (size_t k = 0; k < z.size(); ++k) z[k] = {pend.big[k], k < pend.big_ed.size() ? pend.big_ed[k] : 0u};
+            std::vector<std::array<uint32_t, 3>> z(pend.big.size());
+            for (size_t k = 0; k < z.size(); ++k) z[k] = {pend.big[k], k < pend.big_ed.size() ? pend.big_ed[k] : 0u, k < pend.big_nodes.size() ? pend.big_nodes[k] : 0u};
             std::sort(z.begin(), z.end());
-            pend.big_ed.resize(z.size());
-            for (size_t k = 0; k < z.size(); ++k) { pend.big[k] = z[k].first; pend.big_ed[k] = z[k].second; }
+            pend.big_ed.resize(z.size()); pend.big_nodes.resize(z.size());
+            for (size_t k = 0; k < z.size(); ++k) { pend.big[k] = z[k][0]; pend.big_ed[k] = z[k][1]; pend.big_nodes[k] = z[k][2]; }
         }
+        // ---- the cheap exact verdict first (hp_wfa2_bound_kernel): a read that was deep into its alignment when the compact
+        // kernels let go of it, and whose distance to the reference window alone exceeds max_edit_distance + D, is a
+        // MaxEditDistance - no dense-band pass for it ----
+        {
+            const char* benv = std::getenv("HP_WFA2_BOUND");
+            const uint32_t min_ed = benv ? (uint32_t)std::max(0, std::atoi(benv)) : 48u;   // (HP_WFA2_BOUND=1000000 turns the shortcut off)
+            std::vector<uint32_t> cand, thr, cand_pos;
+            for (size_t k = 0; k < pend.big.size(); ++k) {
+                if (pend.big_ed[k] < min_ed || pend.big_nodes[k] == 0) continue;
+                const hp_wfa_job j = job_header(pend.big[k]);
+                uint64_t D = 0;
+                for (uint32_t v = 0; v < j.n_hets; ++v) D += std::max<uint64_t>({j.hets[v].ref_len, (j.hets[v].flags & 2u) ? j.hets[v].allele0_len : 0u, j.hets[v].allele1_len});
+                for (uint32_t v = 0; v < j.n_homs; ++v) D += std::max<uint64_t>({j.homs[v].ref_len, (j.homs[v].flags & 2u) ? j.homs[v].allele0_len : 0u, j.homs[v].allele1_len});
+                const uint64_t T = pend.max_ed + D;
+                if (T > W2_BOUND_MAX_T) continue;
+                cand.push_back(pend.big[k]); thr.push_back((uint32_t)T); cand_pos.push_back((uint32_t)k);
+            }
+            if (!cand.empty()) {
+                hipStream_t bs = thread_stream(device_id);
+                if (!bs) { set_error("stream creation failed"); return HP_ERR_HIP; }
+                DevBuf d_ids, d_thr, d_exc;
+                int rcb;
+                if ((rcb = d_ids.alloc(cand.size() * 4)) || (rcb = d_thr.alloc(cand.size() * 4)) || (rcb = d_exc.alloc(cand.size() + 16))) return rcb;
+                std::vector<uint8_t> exc(cand.size(), 0);
+                struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{bs};
+                HP_HIP_CHECK(hipMemcpyAsync(d_ids.p, cand.data(), cand.size() * 4, hipMemcpyHostToDevice, bs));
+                HP_HIP_CHECK(hipMemcpyAsync(d_thr.p, thr.data(), thr.size() * 4, hipMemcpyHostToDevice, bs));
+                W2BoundArgs BA{};
+                BA.jobs = d_jobs.as<W2Job>(); BA.ids = d_ids.as<uint32_t>(); BA.thresh = d_thr.as<uint32_t>(); BA.n = (uint32_t)cand.size();
+                BA.seq = d_seq.as<uint8_t>(); BA.exceeds = d_exc.as<uint8_t>();
+                const uint32_t maxT = *std::max_element(thr.begin(), thr.end());
+                hipLaunchKernelGGL(hp_wfa2_bound_kernel, dim3((unsigned)cand.size()), dim3(64), (size_t)(2 * (2 * maxT + 3)) * 4, bs, BA);
+                HP_HIP_CHECK(hipGetLastError());
+                HP_HIP_CHECK(hipMemcpyAsync(exc.data(), d_exc.p, cand.size(), hipMemcpyDeviceToHost, bs));
+                if (hipStreamSynchronize(bs) != hipSuccess) { set_error("WFA bound kernel failed"); return HP_ERR_HIP; }
+                std::vector<uint32_t> keep, keep_ed, keep_nodes;
+                size_t c = 0, settled = 0;
+                for (size_t k = 0; k < pend.big.size(); ++k) {
+                    const bool tested = c < cand_pos.size() && cand_pos[c] == k;
+                    if (tested && exc[c]) {
+                        const uint32_t i = pend.big[k];
+                        pend.dst[i].status = HP_WFA_MAX_ED; pend.dst[i].n_nodes = pend.big_nodes[k]; pend.dst[i].score = pend.max_ed;
+                        if (pend.alleles && pend.alleles[i] && dj[i].n_hets) std::memset(pend.alleles[i], HP_ALLELE_NOOVERLAP, dj[i].n_hets);
+                        ++settled;
+                    } else { keep.push_back(pend.big[k]); keep_ed.push_back(pend.big_ed[k]); keep_nodes.push_back(pend.big_nodes[k]); }
+                    if (tested) ++c;
+                }
+                pend.big.swap(keep); pend.big_ed.swap(keep_ed); pend.big_nodes.swap(keep_nodes);
+                if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa2: %zu of %zu leftovers tested against the reference window alone, %zu settled as MaxEditDistance\n", cand.size(), cand.size() + pend.big.size() - (cand.size() - settled), settled); fflush(stderr); }
+            }
+        }
+    }
+    if (!pend.big.empty()) {
         pend.sub.resize(pend.big.size()); pend.sub_out.resize(pend.big.size()); pend.sub_al.resize(pend.big.size());
         ascii_scratch.clear();
         for (size_t k = 0; k < pend.big.size(); ++k) { pend.sub[k] = materialize(pend.big[k]); pend.sub_al[k] = pend.alleles ? pend.alleles[pend.big[k]] : nullptr; }

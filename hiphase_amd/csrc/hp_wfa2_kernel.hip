@@ -1026,3 +1026,85 @@ __global__ void __launch_bounds__(256) hp_wfa2_unpack_kernel(W2UnpackArgs A) {
 }
 
 }  // namespace hp
+
+namespace hp {
+
+// ---- a cheap exact verdict for hopeless reads ------------------------------------------------------------------------------------
+// A read that leaves the compact kernels deep into its alignment is usually one that will exhaust max_edit_distance (a noisy
+// read, a mis-placed supplementary record): the dense-band pass then walks the whole graph for max_edit_distance rounds only to
+// report Err(MaxEditDistance) (wfa_graph.rs:645-648). This kernel settles most of them first, exactly: plain two-sequence WFA
+// (unit costs, end to end) of the read against the job's REFERENCE window alone, one wavefront per job, up to a threshold
+// T = max_edit_distance + D, D = the sum over the job's variants of max(reference length, allele lengths). Every path P of the
+// job's graph is the reference window with some variants' reference spans replaced by an allele, so ed(window, P) <= D and, by
+// the triangle inequality, ed(read, P) >= ed(read, window) - D: if ed(read, window) > T no path is within max_edit_distance of
+// the read, and the reference's search - pruned or not, it only ever reports the cost of an alignment it found - ends in
+// MaxEditDistance. Nothing is decided when the distance is <= T: those jobs take the dense-band pass as before.
+struct W2BoundArgs {
+    const W2Job* jobs;
+    const uint32_t* ids;       // jobs to test
+    const uint32_t* thresh;    // T per tested job (<= W2_BOUND_MAX_T)
+    uint32_t n;
+    const uint8_t* seq;
+    uint8_t* exceeds;          // out: 1 = ed(read, reference window) > T
+};
+constexpr uint32_t W2_BOUND_MAX_T = 3000;   // two wavefront arrays of 2 T + 3 offsets in LDS
+__global__ void __launch_bounds__(64) hp_wfa2_bound_kernel(W2BoundArgs A) {
+    extern __shared__ int32_t w2b_lds[];
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    if (q >= A.n) return;
+    const W2Job J = A.jobs[A.ids[q]];
+    const int32_t T = (int32_t)A.thresh[q];
+    const int32_t n = (int32_t)J.read_len, m = (int32_t)J.ref_len;
+    const uint8_t* a = A.seq + J.read_off;
+    const uint8_t* b = A.seq + J.ref_off;
+    constexpr int32_t NONE = INT32_MIN / 2;
+    const int32_t W = 2 * T + 3;                 // diagonals -T-1 .. T+1 (the rim stays NONE)
+    int32_t* prev = w2b_lds;
+    int32_t* cur = w2b_lds + W;
+    for (int32_t i = (int32_t)lane; i < 2 * W; i += 64) w2b_lds[i] = NONE;
+    __syncthreads();
+    auto extend = [&](int32_t i, int32_t k) {   // furthest i' >= i with a[i..i') == b[i + k .. i' + k)
+        int32_t j = i + k;
+        while (i < n && j < m) {
+            if (i + 8 <= n && j + 8 <= m) {
+                uint64_t x, y;
+                __builtin_memcpy(&x, a + i, 8); __builtin_memcpy(&y, b + j, 8);
+                const uint64_t d = x ^ y;
+                if (d == 0) { i += 8; j += 8; continue; }
+                const int32_t e = (int32_t)(__builtin_ctzll(d) >> 3);
+                return i + e;
+            }
+            if (a[i] != b[j]) break;
+            ++i; ++j;
+        }
+        return i;
+    };
+    const int32_t kend = m - n;                  // the diagonal of the end cell
+    bool done = false;
+    if (lane == 0) { const int32_t f = extend(0, 0); prev[T + 1] = f; done = (kend == 0 && f == n); }
+    done = __any(done);
+    __syncthreads();
+    int32_t s = 0;
+    while (!done && s < T) {
+        ++s;
+        for (int32_t base = -s; base <= s; base += 64) {
+            const int32_t k = base + (int32_t)lane;
+            if (k <= s) {
+                const int32_t p0 = prev[k + T + 1], p1 = prev[k + 1 + T + 1], pm = prev[k - 1 + T + 1];
+                int32_t f = NONE;
+                if (p0 >= 0 && p0 + 1 <= n && p0 + 1 + k <= m) f = p0 + 1;          // substitution
+                if (p1 >= 0 && p1 + 1 <= n && p1 + 1 > f) f = p1 + 1;               // a read base of its own
+                if (pm >= 0 && pm + k <= m && pm > f) f = pm;                       // a reference base of its own
+                if (f >= 0) f = extend(f, k);
+                cur[k + T + 1] = f;
+                if (k == kend && f == n) done = true;
+            }
+        }
+        done = __any(done);
+        __syncthreads();
+        int32_t* t = prev; prev = cur; cur = t;
+    }
+    if (lane == 0) A.exceeds[q] = done ? 0 : 1;
+}
+
+}  // namespace hp

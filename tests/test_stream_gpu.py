@@ -97,3 +97,24 @@ def test_hpbr_capture_replays_through_the_product_and_bench(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["parity_vs_capture"] == {"blocks_compared": cap.n, "of": cap.n, "bit_identical": True} and out["value"] > 0
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("noise,max_ed", [(0.014, 200), (0.03, 500), (0.006, 80)])
+def test_reads_around_max_edit_distance_vs_oracle(noise, max_ed, monkeypatch):
+    """A third of the reads carry noise that puts their edit distance right around max_edit_distance: some align, some end in
+    Err(MaxEditDistance) and fall back to local re-alignment. The compact kernels hand most of them on; the shortcut that
+    settles hopeless reads against the reference window alone (hp_wfa2_bound_kernel) must never call a read that aligns."""
+    from hiphase_amd.read_parsing import GlobalRealignmentConfig
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0")
+    monkeypatch.setenv("HP_WFA2_BOUND", "8")     # test every leftover that got past 8 edits
+    lib = _ffi.lib()
+    prm = _params(2, 1000, 3, GlobalRealignmentConfig(max_edit_distance=max_ed, wfa_prune_distance=max_ed), True)
+    s = SynthSet(default_spec(lib, total_hets=400, seed=77, seq_format=_ffi.SEQ_BAM4, max_block_hets=120, noisy_fraction=0.35, noisy_noise=noise,
+                              supplementary_fraction=0.03, frac_snv=0.80, frac_indel=0.14, frac_sv=0.03))
+    exp = oracle_outputs(s, prm)
+    got = s.outputs()
+    _ffi.check(lib.hp_solve_blocks(s.n, s.inputs, C.byref(prm), got.arr, 0))
+    assert [b for b in range(s.n) if not got.equal(exp, b)] == []
+    n_local, n_global = sum(got.arr[b].local_aligned for b in range(s.n)), sum(got.arr[b].global_aligned for b in range(s.n))
+    assert n_local > 10 and n_global > 10
