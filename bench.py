@@ -417,7 +417,7 @@ def main():
     ap.add_argument("--total-hets", type=int, default=60000, help="path workload: hets per GPU and step")
     ap.add_argument("--max-block-hets", type=int, default=4165, help="largest block HiPhase reports on HG002 (docs/user_guide.md:258)")
     ap.add_argument("--seq-format", choices=["bam4", "ascii"], default="bam4", help="path workload: how the reads are handed over")
-    ap.add_argument("--depth", type=int, default=5, help="path workload: block sets in flight in the stream")
+    ap.add_argument("--depth", type=int, default=6, help="path workload: block sets in flight in the stream")
     ap.add_argument("--distinct-sets", type=int, default=16, help="path workload: generated sets (steps + warm-up if fewer; cycled if more are needed)")
     ap.add_argument("--no-resident", action="store_true", help="path workload: skip the secondary resident (inputs-in-HBM) figure")
     ap.add_argument("--seed", type=int, default=20250928, help="path workload: seed of the synthetic block mix (rank r uses seed + r)")

@@ -234,6 +234,20 @@ double hp_last_kernel_ms(void) { return hp::g_last_kernel_ms; }
 int hp_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    // Host threads that wait for the device sleep instead of spinning: a block stream has half a dozen threads waiting on
+    // streams at any time, and a process that is allowed 16 CPUs (a cgroup quota) is throttled - every thread of it frozen for
+    // the rest of the scheduler period - when waiters burn the quota that the staging and row-assembly threads need.
+    // Per device, once; refused without harm when the device's context is already active (a host framework got there first).
+    static std::once_flag once;
+    std::call_once(once, [n]() {
+        const char* e = std::getenv("HP_BLOCKING_SYNC");
+        if (e && e[0] == '0') return;
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (int d = 0; d < n; ++d) { if (hipSetDevice(d) == hipSuccess) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); }
+        (void)hipSetDevice(cur);
+        (void)hipGetLastError();
+    });
     return n;
 }
 

@@ -61,17 +61,26 @@ struct hp_blockstream {
     std::vector<std::unique_ptr<Slot>> slots;
     std::mutex m;
     std::condition_variable cv;
-    std::deque<Slot*> q[4];            // waiting for stage 1 / 2 / 3 / 4
+    std::deque<Slot*> q[4];            // waiting for stage 1 / 2 / 3 / 4, in ticket order
     uint64_t next_ticket = 1;
+    uint64_t next_in[4] = {1, 1, 1, 1};   // the ticket each stage takes next
     double t_zero = 0.0;
     bool quit = false;
-    std::thread th[4];
-    std::unique_ptr<WorkerPool> pool[4];
+    // stage 3 has two threads (a set's rows mostly WAIT - for the late results of its alignment stage - so two sets share the
+    // stage; they still reach stage 4 in ticket order), the others one
+    static constexpr int N_THREADS = 5;
+    std::thread th[N_THREADS];
+    std::unique_ptr<WorkerPool> pool[N_THREADS];
+    void stage_thread(int t);
     void stage_loop(int k);
 };
 
+void hp_blockstream::stage_thread(int t) {
+    WorkerPool::set_thread_pool(pool[t].get());
+    stage_loop(t < 3 ? t : t == 3 ? 2 : 3);
+}
+
 void hp_blockstream::stage_loop(int k) {
-    WorkerPool::set_thread_pool(pool[k].get());
     (void)hipSetDevice(device);
     // CU partitions for the stages (hp_common.h) are an experiment switch, off by default. Measured on the bench workload: the
     // persistent graph-WFA kernels fill every compute unit (three wavefronts per SIMD is all their registers allow), so another
@@ -84,15 +93,17 @@ void hp_blockstream::stage_loop(int k) {
     // ... what works instead: the alignment stage leaves a share of the wavefront slots empty (hp_wfa2.hip)
     static const int reserve = [] { const char* e = std::getenv("HP_STREAM_RESERVE_PCT"); return e ? std::max(0, std::atoi(e)) : 8; }();
     if (k == 1) g_wfa2_reserve_pct = reserve;
-    g_host_share_div = (k == 0 || k == 2) ? 2 : 4;   // the stages' host threads together: about the process's share of the host   // the three stages' host threads together: about the process's share of the host
+    g_host_share_div = k == 0 ? 2 : 4;   // the stages' host threads together: about the process's share of the host   // the three stages' host threads together: about the process's share of the host
     for (;;) {
         Slot* s = nullptr;
         {
             std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&]() { return quit || !q[k].empty(); });
-            if (q[k].empty()) return;   // quit, nothing left to do
+            // a stage takes the sets strictly in ticket order (next_in[k]); with two threads in a stage each takes the next one
+            cv.wait(lk, [&]() { return quit || (!q[k].empty() && q[k].front()->ticket == next_in[k]); });
+            if (q[k].empty() || q[k].front()->ticket != next_in[k]) return;   // quit, nothing left to do
             s = q[k].front();
             q[k].pop_front();
+            ++next_in[k];
         }
         s->t_begin[k] = st_now_ms();
         if (s->rc == HP_OK && s->n_blocks) {   // (an empty set, or one that failed an earlier stage, just travels on: tickets complete in order)
@@ -106,7 +117,11 @@ void hp_blockstream::stage_loop(int k) {
         s->t_end[k] = st_now_ms();
         {
             std::unique_lock<std::mutex> lk(m);
-            if (k < 3) q[k + 1].push_back(s); else s->state = Slot::DONE;
+            if (k < 3) {   // (ticket order: the two threads of stage 3 may finish out of turn)
+                auto it = q[k + 1].begin();
+                while (it != q[k + 1].end() && (*it)->ticket < s->ticket) ++it;
+                q[k + 1].insert(it, s);
+            } else s->state = Slot::DONE;
             cv.notify_all();
         }
     }
@@ -116,16 +131,16 @@ extern "C" hp_blockstream* hp_blockstream_create(const hp_block_params* p, int d
     auto fail = [&](int rc) -> hp_blockstream* { if (status) *status = rc; return nullptr; };
     if (!p) { set_error("null argument"); return fail(HP_ERR_ARG); }
     if (hp_device_count() <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return fail(HP_ERR_HIP); }
-    if (depth == 0) depth = 5;
+    if (depth == 0) depth = 6;
     if (depth > 16) { set_error("depth %u: at most 16 block sets in flight", depth); return fail(HP_ERR_ARG); }
     auto s = std::unique_ptr<hp_blockstream>(new hp_blockstream());
     s->prm = *p;
     s->device = device_id < 0 ? hp_default_device() : device_id;
     if (hipSetDevice(s->device) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", s->device); return fail(HP_ERR_HIP); }
     for (uint32_t i = 0; i < depth; ++i) s->slots.emplace_back(new Slot());
-    for (int k = 0; k < 4; ++k) s->pool[k].reset(new WorkerPool());
+    for (int k = 0; k < hp_blockstream::N_THREADS; ++k) s->pool[k].reset(new WorkerPool());
     hp_blockstream* raw = s.get();
-    for (int k = 0; k < 4; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_loop(k); });
+    for (int k = 0; k < hp_blockstream::N_THREADS; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_thread(k); });
     if (status) *status = HP_OK;
     return s.release();
 }

@@ -126,9 +126,10 @@ template <int G, int W> int w2_launch(const W2Batch& B, uint32_t n_items, int n_
     constexpr uint32_t NG = 64 / G;
     const size_t lds = (size_t)C::BYTES * NG;
     const uint32_t grid = w2_grid<G, W>(n_items, n_cu, max_groups);
-    static std::atomic<bool> attr_set{false};
+    static std::atomic<bool> attr_set{false};   // (per instantiation)
     if (lds > 64 * 1024 || !attr_set.load()) {
         HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_kernel<G, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.store(true);
     }
     *groups_used = grid * NG;
     hipLaunchKernelGGL((hp_wfa2_kernel<G, W>), dim3(grid), dim3(64), lds, st, B);
