@@ -314,7 +314,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
                  "kernel_ms": k_wfa_ms, "algorithmic_bytes_per_launch": b_wfa, "achieved": b_wfa / (k_wfa_ms * 1e-3) / 1e9 if k_wfa_ms > 0 else 0.0,
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "reads": work["wfa_reads"], "reads_per_s": work["wfa_reads"] / (k_wfa_ms * 1e-3) if k_wfa_ms > 0 else 0.0,
                  "bytes_per_read": b_wfa / max(1.0, work["wfa_reads"]), "wave_updates_per_read": work["wfa_updates"] / max(1.0, work["wfa_reads"]),
-                 "reads_left_compact_path": info["records"] - work["wfa_reads"]}
+                 "reads_left_compact_path": float(np.mean([sets[k % n_sets].info["records"] for k in range(args.warmup, args.warmup + args.steps)])) - work["wfa_reads"]}
         k_wfa["frac"] = k_wfa["achieved"] / HBM_PEAK_GBS
         k_wfa["traffic"], k_wfa["traffic_source"] = measured_traffic("hp_wfa2_kernel", "bytes_per_read", work["wfa_reads"])
         k_astar = {"kernel": "hp::hp_astar_kernel", "bound": "hbm", "kernel_ms": k_astar_ms, "algorithmic_bytes_per_launch": b_astar,
@@ -417,7 +417,7 @@ def main():
     ap.add_argument("--total-hets", type=int, default=60000, help="path workload: hets per GPU and step")
     ap.add_argument("--max-block-hets", type=int, default=4165, help="largest block HiPhase reports on HG002 (docs/user_guide.md:258)")
     ap.add_argument("--seq-format", choices=["bam4", "ascii"], default="bam4", help="path workload: how the reads are handed over")
-    ap.add_argument("--depth", type=int, default=6, help="path workload: block sets in flight in the stream")
+    ap.add_argument("--depth", type=int, default=5, help="path workload: block sets in flight in the stream")
     ap.add_argument("--distinct-sets", type=int, default=16, help="path workload: generated sets (steps + warm-up if fewer; cycled if more are needed)")
     ap.add_argument("--no-resident", action="store_true", help="path workload: skip the secondary resident (inputs-in-HBM) figure")
     ap.add_argument("--seed", type=int, default=20250928, help="path workload: seed of the synthetic block mix (rank r uses seed + r)")

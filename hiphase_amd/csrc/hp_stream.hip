@@ -77,7 +77,7 @@ struct hp_blockstream {
 
 void hp_blockstream::stage_thread(int t) {
     WorkerPool::set_thread_pool(pool[t].get());
-    stage_loop(t < 3 ? t : t == 3 ? 2 : 3);
+    stage_loop(t < 4 ? t : 2);   // (t == 4: a second thread for stage 3, HP_STREAM_ROWS_THREADS=2)
 }
 
 void hp_blockstream::stage_loop(int k) {
@@ -131,7 +131,7 @@ extern "C" hp_blockstream* hp_blockstream_create(const hp_block_params* p, int d
     auto fail = [&](int rc) -> hp_blockstream* { if (status) *status = rc; return nullptr; };
     if (!p) { set_error("null argument"); return fail(HP_ERR_ARG); }
     if (hp_device_count() <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return fail(HP_ERR_HIP); }
-    if (depth == 0) depth = 6;
+    if (depth == 0) depth = 5;
     if (depth > 16) { set_error("depth %u: at most 16 block sets in flight", depth); return fail(HP_ERR_ARG); }
     auto s = std::unique_ptr<hp_blockstream>(new hp_blockstream());
     s->prm = *p;
@@ -140,7 +140,11 @@ extern "C" hp_blockstream* hp_blockstream_create(const hp_block_params* p, int d
     for (uint32_t i = 0; i < depth; ++i) s->slots.emplace_back(new Slot());
     for (int k = 0; k < hp_blockstream::N_THREADS; ++k) s->pool[k].reset(new WorkerPool());
     hp_blockstream* raw = s.get();
-    for (int k = 0; k < hp_blockstream::N_THREADS; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_thread(k); });
+    // (measured: a second thread in the rows stage makes the step SLOWER, 65 vs 50 ms - the device is the bottleneck and one more
+    // set in flight only adds contention; kept as a switch)
+    const char* rt = std::getenv("HP_STREAM_ROWS_THREADS");
+    const int n_threads = (rt && std::atoi(rt) >= 2) ? hp_blockstream::N_THREADS : 4;
+    for (int k = 0; k < n_threads; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_thread(k); });
     if (status) *status = HP_OK;
     return s.release();
 }

@@ -734,7 +734,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     if (cls_cnt[1]) grid_wg[1] = gsel == 16 ? w2_grid<16, 4>(cls_cnt[1], n_cu, capg[1]) : gsel == 32 ? w2_grid<32, 4>(cls_cnt[1], n_cu, capg[1]) : w2_grid<8, 4>(cls_cnt[1], n_cu, capg[1]);
     // (room for the jobs handed over: about 2 % of the two smaller classes on the round-3 bench workload - structural variants put a read's paths far apart; HP_WFA2_ESC_DIV to experiment)
     const char* denv = std::getenv("HP_WFA2_ESC_DIV");
-    const uint32_t esc_div = denv ? (uint32_t)std::max(1, std::atoi(denv)) : 32u;
+    const uint32_t esc_div = denv ? (uint32_t)std::max(1, std::atoi(denv)) : 64u;
     const uint32_t items2 = escalate ? cls_cnt[2] + std::max<uint32_t>(4u * 48u, (cls_cnt[0] + cls_cnt[1]) / esc_div) : cls_cnt[2];
     // two phases: the results of everything the two smaller classes finished themselves are collected as soon as THEIR
     // kernels are done; the largest class (its own jobs + what was handed over, the tail of the launch set) is collected

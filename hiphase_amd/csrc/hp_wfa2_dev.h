@@ -264,7 +264,7 @@ template <int W> struct W2Cfg {
     static constexpr int MAXPAR = 8;             // finished parent entries of one node in one round
     static constexpr int MAXS = W <= 4 ? 8 : 12; // source intervals of one node (slow path scratch)
     static constexpr int MAXW = 250;             // diagonals per entry (8-bit relative hulls)
-    static constexpr int MAXPREV = W <= 4 ? 2 : 4;   // live entries of ONE node the next round can pull from (kept in registers)
+    static constexpr int MAXPREV = W <= 4 ? 3 : 4;   // live entries of ONE node the next round can pull from (kept in registers)
     static constexpr int a16(int x) { return (x + 15) & ~15; }
     // The node table is read from HBM (L2-resident: one 16-byte descriptor per node visit, with the first two children
     // inline) - with the table sizes above that takes a read's LDS to 1 600 bytes, i.e. 12 workgroups of 8 reads per CU =

@@ -354,7 +354,7 @@ void hp_blockset_destroy(hp_blockset* bs);
  * flight: the back-pressure of the reference's bounded job queue, main.rs:362-383); hp_blockstream_wait returns when that set's
  * results are in its `out` array. Sets complete in submission order; results are identical to hp_solve_blocks on the same set.
  * `in`, everything it points at, and `out` must stay valid until the wait for that ticket returns. Submit and wait may be called
- * from different threads. depth: 0 = 6. stage_ms (16 doubles, may be NULL): [0] overlaps + layout (host), [1] staging copy + PCIe
+ * from different threads. depth: 0 = 5. stage_ms (16 doubles, may be NULL): [0] overlaps + layout (host), [1] staging copy + PCIe
  * + base expansion, [2] graph-WFA stage, [3] fallback / replay / rows (host), [4] A* pack + upload, [5] A* solve, [6] post-processing
  * + outputs, [7] latency submit -> done, [8] graph-WFA kernels (HIP events), [9] A* kernels (HIP events), [10] bytes host -> device,
  * [11] time spent waiting between stages, [12..15] wall time of stage 1 (layout + PCIe) / 2 (graph-WFA) / 3 (rows + A* pack) / 4 (A* + post). work (8 values, may be NULL): as hp_blockset_work. */
