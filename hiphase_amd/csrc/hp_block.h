@@ -50,6 +50,7 @@ struct BlockState {         // per block, rebuilt by every solve
     std::vector<int64_t> local_slot;
     std::vector<uint8_t> loc_alleles, loc_quals;
     std::vector<hp_read_stats> loc_stats;
+    bool wfa_unsupported = false;         // a record's graph-WFA job lies outside the device kernels' limits: the block goes back to the caller
     std::vector<uint32_t> loc_need;       // records of the pre-pass (blockset_rows gathers them over all blocks: one device launch)
     std::vector<hp_local_read> loc_reads;
     Arena arena;
@@ -58,6 +59,7 @@ struct BlockState {         // per block, rebuilt by every solve
         num_reads = skipped_reads = global_aligned = local_aligned = 0;
         edit_distances.clear(); read_start.clear(); read_end.clear(); row_off.clear();
         alleles_2bit.clear(); quals.clear(); var_flags.clear();
+        wfa_unsupported = false;
         local_slot.clear(); loc_alleles.clear(); loc_quals.clear(); loc_stats.clear(); loc_need.clear(); loc_reads.clear();
         arena.reset();
     }

@@ -255,7 +255,13 @@ int local_needs(hp_blockset* bs, size_t b) {
     if (!bs->prm.global_realignment) { S.loc_need.resize(R); for (uint32_t i = 0; i < R; ++i) S.loc_need[i] = i; }
     else {
         const std::vector<RecMeta>& meta = bs->meta[b];
-        for (uint32_t i = 0; i < R; ++i) if (meta[i].job >= 0 && bs->wfa_out[(size_t)meta[i].job].status == HP_WFA_MAX_ED) S.loc_need.push_back(i);
+        for (uint32_t i = 0; i < R; ++i) {
+            if (meta[i].job < 0) continue;
+            const int32_t st = bs->wfa_out[(size_t)meta[i].job].status;
+            if (st == HP_WFA_MAX_ED) S.loc_need.push_back(i);
+            else if (st == HP_WFA_UNSUPPORTED) S.wfa_unsupported = true;   // (the reference has no such limit: the caller solves this block itself)
+        }
+        if (S.wfa_unsupported) { S.loc_need.clear(); return HP_OK; }
     }
     if (S.loc_need.empty()) return HP_OK;
     if (!B.local_hets) { set_error("block %zu: a record needs local re-alignment (read_parsing.rs:121-503) but local_hets is NULL", b); return HP_ERR_ARG; }
@@ -289,6 +295,10 @@ int assemble_block(hp_blockset* bs, size_t b) {
     BlockState& S = bs->st[b];
     const uint32_t N = B.n_hets, R = B.n_records;
     const std::vector<RecMeta>& meta = bs->meta[b];
+    if (S.wfa_unsupported) {   // nothing is assembled: an empty matrix stands in, the block is left out of the A* batch (blockset_rows)
+        S.var_flags.assign(N, 0); S.row_off.assign(1, 0); S.alleles_2bit.assign(1, 0); S.quals.assign(1, 0);
+        return HP_OK;
+    }
     // local re-alignment rows: the pre-pass (local_needs + local_prepass) has the ones known up front; the `global_disabled`
     // switch (below) may ask for more (a record's local result does not depend on any other record)
     std::vector<int64_t>& local_slot = S.local_slot;
@@ -588,10 +598,14 @@ int hp::blockset_rows(hp_blockset* bs) {
     for (size_t k = 0; k < nb; ++k) kept[k] = k;
     std::vector<char>& unsupported = ch.unsupported;
     unsupported.assign(nb, 0);
-    hp_batch* batch = hp_batch_create(nb, views.data(), &ap, bs->device, &st);
+    bool any_wfa_unsupported = false;
+    for (size_t k = 0; k < nb; ++k) if (bs->st[k].wfa_unsupported) { unsupported[k] = 1; any_wfa_unsupported = true; }
+    hp_batch* batch = any_wfa_unsupported ? nullptr : hp_batch_create(nb, views.data(), &ap, bs->device, &st);
+    if (any_wfa_unsupported) st = HP_ERR_UNSUPPORTED;   // (the same road as a block beyond the solver's limits: the others are solved)
     if (!batch && st == HP_ERR_UNSUPPORTED) {
         kept.clear();
         for (size_t k = 0; k < nb; ++k) {   // a create on its own tells which
+            if (unsupported[k]) continue;
             int s1 = HP_OK;
             hp_batch* one = hp_batch_create(1, &views[k], &ap, bs->device, &s1);
             if (one) { hp_batch_destroy(one); kept.push_back(k); continue; }

@@ -686,6 +686,24 @@ static int run_graphs(const std::vector<HostJob>& hj, uint64_t prune_distance, u
             ids.swap(narrow);
         }
         for (;;) {
+            {   // jobs outside what a launch at this band can hold get the soft per-job verdict instead of failing the call
+                std::vector<uint32_t> fit;
+                for (uint32_t id : ids) {
+                    const HostJob& g = hj[id];
+                    const uint64_t set_words = (g.nodes.size() + 31) / 32;
+                    uint64_t entry = 0;
+                    bool ok = true;
+                    for (size_t k = 0; k < g.nodes.size() && ok; ++k) {
+                        const uint32_t np = k == 0 ? 1u : g.nodes[k].n_par;
+                        const int64_t width = (g.nodes[k].emax - g.nodes[k].emin) + 2 * (int64_t)band + 3;
+                        if (np > WFA_MAX_PARENTS || g.nodes[k].n_child > 65535 || width > 65535) ok = false;
+                        entry += (uint64_t)width * (5 + 2 * set_words + np * set_words);
+                        if (entry > 0xFFFFFFF0ull) ok = false;
+                    }
+                    if (ok) fit.push_back(id); else status[id] = WFA_ST_UNSUPPORTED;
+                }
+                ids.swap(fit);
+            }
             if (!ids.empty()) {
                 int rc = run_pass(hj, ids, band, prune_distance, max_ed, n_cu, status, score, sets, set_off, big == 1);
                 if (rc != HP_OK) return rc;
@@ -701,7 +719,7 @@ static int run_graphs(const std::vector<HostJob>& hj, uint64_t prune_distance, u
         }
     }
     for (size_t i = 0; i < n; ++i)
-        if (status[i] != WFA_ST_OK && status[i] != WFA_ST_MAX_ED) { set_error("job %zu: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
+        if (status[i] != WFA_ST_OK && status[i] != WFA_ST_MAX_ED && status[i] != WFA_ST_UNSUPPORTED) { set_error("job %zu: device status %d", i, status[i]); return HP_ERR_INVARIANT; }
     return HP_OK;
 }
 
@@ -712,7 +730,10 @@ int hp::wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_dis
     if (n == 0) return HP_OK;
     if (!jobs || !out) { set_error("null argument"); return HP_ERR_ARG; }
     if (n > 0x7FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
-    if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
+    if (max_ed > 60000) {   // (a band that wide does not fit the kernels' 16-bit diagonal indices: every job of the call, softly)
+        for (size_t i = 0; i < n; ++i) { out[i] = hp_wfa_result{HP_WFA_UNSUPPORTED, 0, 0}; if (alleles && alleles[i]) for (uint32_t k = 0; k < jobs[i].n_hets; ++k) alleles[i][k] = HP_ALLELE_NOOVERLAP; }
+        return HP_OK;
+    }
     std::vector<GraphArena> arenas;
     std::vector<HostJob> hj(n);
     g_last_kernel_ms = 0.0;   // (the caller adds the compact path's time back when this runs its leftovers)
@@ -763,7 +784,7 @@ int hp::wfa_assign_batch_v1(const hp_wfa_job* jobs, size_t n, uint64_t prune_dis
     const double t_map = now_ms();
     auto map_jobs = [&](unsigned t, unsigned nt) {
         for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
-            out[i].status = status[i] == WFA_ST_OK ? HP_OK : HP_WFA_MAX_ED;
+            out[i].status = status[i] == WFA_ST_OK ? HP_OK : status[i] == WFA_ST_UNSUPPORTED ? HP_WFA_UNSUPPORTED : HP_WFA_MAX_ED;
             out[i].n_nodes = (uint32_t)hj[i].nodes.size();
             out[i].score = score[i];
             if (alleles && alleles[i]) {
@@ -803,7 +824,10 @@ extern "C" int hp_wfa_align_graphs(const hp_graph_job* jobs, size_t n, uint64_t 
     if (n == 0) return HP_OK;
     if (!jobs || !out) { set_error("null argument"); return HP_ERR_ARG; }
     if (n > 0x7FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
-    if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
+    if (max_ed > 60000) {
+        for (size_t i = 0; i < n; ++i) { out[i] = hp_graph_result{HP_WFA_UNSUPPORTED, 0, 0}; if (traversed && traversed[i]) for (uint32_t w = 0; w < (jobs[i].n_nodes + 31) / 32; ++w) traversed[i][w] = 0; }
+        return HP_OK;
+    }
     GraphArena arena;
     std::vector<HostJob> hj(n);
     GraphBuild g;
@@ -836,7 +860,7 @@ extern "C" int hp_wfa_align_graphs(const hp_graph_job* jobs, size_t n, uint64_t 
     const int rc = run_graphs(hj, prune_distance, max_ed, device_id, status, score, sets, set_off);
     if (rc != HP_OK) return rc;
     for (size_t i = 0; i < n; ++i) {
-        out[i].status = status[i] == WFA_ST_OK ? HP_OK : HP_WFA_MAX_ED;
+        out[i].status = status[i] == WFA_ST_OK ? HP_OK : status[i] == WFA_ST_UNSUPPORTED ? HP_WFA_UNSUPPORTED : HP_WFA_MAX_ED;
         out[i].score = score[i];
         const uint32_t words = (jobs[i].n_nodes + 31) / 32;
         uint32_t cnt = 0;

@@ -605,7 +605,10 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     if (n == 0) return HP_OK;
     if (pend.on) { const int rcp = finish(); if (rcp != HP_OK) return rcp; }
     if (!out) { set_error("null argument"); return HP_ERR_ARG; }
-    if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
+    if (max_ed > 60000) {   // outside the kernels' diagonal range: every job of the batch, softly (HP_WFA_UNSUPPORTED)
+        for (size_t i = 0; i < n; ++i) { out[i] = hp_wfa_result{HP_WFA_UNSUPPORTED, 0, 0}; if (alleles && alleles[i] && dj[i].n_hets) std::memset(alleles[i], HP_ALLELE_NOOVERLAP, dj[i].n_hets); }
+        return HP_OK;
+    }
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
     const double t0 = w2_now_ms();
     g_last_kernel_ms = 0.0;
@@ -1047,7 +1050,7 @@ int wfa_assign_batch_v2(const hp_wfa_job* jobs, size_t n, uint64_t prune_distanc
                         uint8_t* const* alleles, int device_id) {
     if (n == 0) return HP_OK;
     if (!jobs || !out) { set_error("null argument"); return HP_ERR_ARG; }
-    if (max_ed > 60000) { set_error("max_edit_distance %llu too large", (unsigned long long)max_ed); return HP_ERR_UNSUPPORTED; }
+    if (max_ed > 60000) return wfa_assign_batch_v1(jobs, n, prune_distance, max_ed, out, alleles, device_id);   // (soft HP_WFA_UNSUPPORTED for every job)
     W2Session ses;
     int rc = ses.prepare(jobs, n, device_id);
     if (rc != HP_OK) return rc;

@@ -59,6 +59,7 @@ constexpr int32_t WFA_ST_OK = 0;
 constexpr int32_t WFA_ST_MAX_ED = 1;     // Err(MaxEditDistance) (wfa_graph.rs:645-648)
 constexpr int32_t WFA_ST_NEED_BAND = 2;  // edit distance exceeded this launch's band: host re-runs with a wider one
 constexpr int32_t WFA_ST_PENDING = 7;
+constexpr int32_t WFA_ST_UNSUPPORTED = 9;   // host-side verdict: outside the kernels' limits (soft: HP_WFA_UNSUPPORTED for this job only)
 constexpr int32_t WFA_ST_INTERNAL = -3;
 
 constexpr uint32_t WFA_KIND_NONE = 0;

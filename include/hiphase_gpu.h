@@ -30,6 +30,10 @@ extern "C" {
 /* ---- status codes ------------------------------------------------------------------------- */
 #define HP_OK                 0
 #define HP_WFA_MAX_ED         1   /* per-job: WFAGraphError::MaxEditDistance (wfa_graph.rs:13-17,645-648) */
+#define HP_WFA_UNSUPPORTED    3   /* per-job: the graph-WFA job lies outside what the device kernels hold (max_edit_distance > 60 000, a node
+                                     with more than 64 parents, a diagonal band wider than 65 535, more than 16 GiB of wavefront state for one
+                                     read): nothing is computed for it; the other jobs of the call are. Through hp_solve_blocks a block with such
+                                     a record comes back as HP_BLOCK_UNSUPPORTED */
 #define HP_BLOCK_UNSUPPORTED  2   /* per-block (hp_block_output.status): outside the device solver's packed-key limits;
                                      the other blocks of the call are solved, the caller runs its own solve_block for this one */
 #define HP_ERR_HIP           -1   /* HIP runtime error / no device / kernel image missing */
@@ -172,7 +176,7 @@ typedef struct hp_wfa_job {
 } hp_wfa_job;
 
 typedef struct hp_wfa_result {
-    int32_t  status;       /* HP_OK or HP_WFA_MAX_ED */
+    int32_t  status;       /* HP_OK, HP_WFA_MAX_ED or HP_WFA_UNSUPPORTED */
     uint32_t n_nodes;      /* WFAGraph::get_num_nodes() */
     uint64_t score;        /* WFAResult::score(); max_edit_distance when status == HP_WFA_MAX_ED */
 } hp_wfa_result;
@@ -328,7 +332,8 @@ typedef struct hp_block_output {
     uint64_t        local_aligned;
     uint64_t*       edit_distances;       /* [n_records] wfa_score of every record that was not skipped, in BAM order */
     uint64_t        n_edit_distances;     /* out */
-    int32_t         status;               /* out: HP_OK, or HP_BLOCK_UNSUPPORTED (segments are filled, h1/h2/stats/spans/tags are not) */
+    int32_t         status;               /* out: HP_OK, or HP_BLOCK_UNSUPPORTED (h1/h2/stats/spans/tags are not filled; the segments are,
+                                             unless it was a record's graph-WFA job that fell outside the device limits: then n_segments = 0) */
     uint32_t        reserved;
 } hp_block_output;
 

@@ -314,6 +314,12 @@ def test_unsupported_block_is_soft_alone_together_and_on_the_queue(monkeypatch):
     # parameters the device solver cannot hold are a property of the call: every block is handed back
     allb = solve_blocks(specs[:2], device_id=0, min_queue_size=10 ** 9)
     assert [r.status for r in allb] == [2, 2]
+    monkeypatch.delenv("HP_TEST_UNSUPPORTED_N")
+    # ... and so are graph-WFA parameters beyond the kernels' range (HP_WFA_UNSUPPORTED per record -> the block, without segments)
+    for min_jobs in ("0", "1000000000"):
+        monkeypatch.setenv("HP_WFA2_MIN_JOBS", min_jobs)
+        wide = solve_blocks(specs[:2], device_id=0, config=GlobalRealignmentConfig(max_edit_distance=70000, wfa_prune_distance=500))
+        assert [(r.status, len(r.segments)) for r in wide] == [(2, 0), (2, 0)]
 
 
 def test_block_sets_from_several_host_threads(monkeypatch):

@@ -272,6 +272,23 @@ def test_node_with_more_than_32_parents():
     assert all(g[0] == 0 for g in got) and got[0][2] >= 42
 
 
+def test_job_beyond_the_kernels_limits_is_soft_and_alone():
+    """70 insertion alleles reconnecting on one reference node (71 parents, the kernels hold 64): THAT job comes back with the
+    soft status HP_WFA_UNSUPPORTED, the ordinary jobs of the same call are aligned as ever"""
+    from hiphase_amd.wfa_graph import Variant, WfaJobSpec
+    r = _Rng(4343)
+    ref = r.dna(1500)
+    pos = 600
+    hets = [Variant.new_insertion(0, pos, ref[pos:pos + 1], ref[pos:pos + 1] + r.dna(3 + k % 5) + bytes([b"ACGT"[k % 4]]) * (1 + k // 4), 0, 1) for k in range(70)]
+    wide = WfaJobSpec(reference=ref, ref_start=100, ref_end=1400, hets=hets, homs=[], read=ref[100:1400])
+    plain = WfaJobSpec(reference=ref, ref_start=100, ref_end=1400, hets=hets[:5], homs=[], read=ref[100:pos] + hets[3].allele1 + ref[pos + 1:1400])
+    got = wfa_assign_batch([plain, wide, plain], prune_distance=0, max_edit_distance=100)
+    assert got[1][0] == 3 and (got[1][3] == 3).all()
+    st, score, nn, al = oracle_assign(plain, 0, 100)
+    for g in (got[0], got[2]):
+        assert (g[0], g[1], g[2]) == (st, score, nn) and np.array_equal(g[3], al)
+
+
 @pytest.mark.parametrize("case", G["hand_built"], ids=lambda c: c["name"])
 def test_golden_hand_built_graphs(case):
     """The reference's hand-built topologies (wfa_graph.rs:677-839: single node, two-node splits, basic variant, triple /
