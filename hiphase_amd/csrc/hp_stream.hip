@@ -72,12 +72,13 @@ struct hp_blockstream {
     std::thread th[N_THREADS];
     std::unique_ptr<WorkerPool> pool[N_THREADS];
     void stage_thread(int t);
+    int extra_stage = 1;
     void stage_loop(int k);
 };
 
 void hp_blockstream::stage_thread(int t) {
     WorkerPool::set_thread_pool(pool[t].get());
-    stage_loop(t < 4 ? t : 2);   // (t == 4: a second thread for stage 3, HP_STREAM_ROWS_THREADS=2)
+    stage_loop(t < 4 ? t : extra_stage);   // (t == 4: a second thread for the alignment stage - or, as an experiment, the rows stage)
 }
 
 void hp_blockstream::stage_loop(int k) {
@@ -140,10 +141,15 @@ extern "C" hp_blockstream* hp_blockstream_create(const hp_block_params* p, int d
     for (uint32_t i = 0; i < depth; ++i) s->slots.emplace_back(new Slot());
     for (int k = 0; k < hp_blockstream::N_THREADS; ++k) s->pool[k].reset(new WorkerPool());
     hp_blockstream* raw = s.get();
-    // (measured: a second thread in the rows stage makes the step SLOWER, 65 vs 50 ms - the device is the bottleneck and one more
-    // set in flight only adds contention; kept as a switch)
+    // One thread per stage. Two experiment switches add a fifth thread: HP_STREAM_WFA_THREADS=2 (a second alignment thread with its
+    // own streams and scratch, so that the next set's kernels are queued while this one's drain: measured 53 vs 48 ms per step,
+    // slower) and HP_STREAM_ROWS_THREADS=2 (a second rows thread: 65 vs 50 ms, slower) - the device is the bottleneck, one more set
+    // in flight only adds contention.
+    const char* wt = std::getenv("HP_STREAM_WFA_THREADS");
     const char* rt = std::getenv("HP_STREAM_ROWS_THREADS");
-    const int n_threads = (rt && std::atoi(rt) >= 2) ? hp_blockstream::N_THREADS : 4;
+    int n_threads = hp_blockstream::N_THREADS;
+    if (rt && std::atoi(rt) >= 2) s->extra_stage = 2;
+    else if (!(wt && std::atoi(wt) >= 2)) n_threads = 4;
     for (int k = 0; k < n_threads; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_thread(k); });
     if (status) *status = HP_OK;
     return s.release();

@@ -975,7 +975,10 @@ int W2Session::late() {
         // MaxEditDistance - no dense-band pass for it ----
         {
             const char* benv = std::getenv("HP_WFA2_BOUND");
-            const uint32_t min_ed = benv ? (uint32_t)std::max(0, std::atoi(benv)) : 48u;   // (HP_WFA2_BOUND=1000000 turns the shortcut off)
+            // (every leftover is tested: a read that aligns within the threshold ends the test after about as many rounds as it has
+            // edits, and the noisy ones often leave the compact kernels early, on a full capped set. HP_WFA2_BOUND=n: only reads that
+            // had reached n edits; 1000000 turns the shortcut off)
+            const uint32_t min_ed = benv ? (uint32_t)std::max(0, std::atoi(benv)) : 0u;
             std::vector<uint32_t> cand, thr, cand_pos;
             for (size_t k = 0; k < pend.big.size(); ++k) {
                 if (pend.big_ed[k] < min_ed || pend.big_nodes[k] == 0) continue;
