@@ -888,7 +888,8 @@ private:
             std::vector<BlocksReq*> batch(dev_q_[(size_t)device].begin(), dev_q_[(size_t)device].end());
             dev_q_[(size_t)device].clear();
             // a share of the common queue: what is there, over the service threads that are free to take it
-            size_t take = (any_q_.size() + (size_t)idle_ - 1) / (size_t)std::max(1, idle_);
+            // (... but not in crumbs: a merged set of a dozen blocks costs a device the same 25 ms as one of a hundred)
+            size_t take = std::max<size_t>((any_q_.size() + (size_t)idle_ - 1) / (size_t)std::max(1, idle_), std::min<size_t>(any_q_.size(), 24));
             --idle_;
             for (; take > 0 && !any_q_.empty(); --take) { batch.push_back(any_q_.front()); any_q_.pop_front(); }
             if (batch.empty()) continue;   // (another service thread was quicker)
