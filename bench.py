@@ -250,8 +250,12 @@ def main_path(args, rank, world, local_rank, dist, backend):
     t_gen = time.perf_counter()
     sets = [capture] if capture else []
     for k in range(0 if capture else n_sets):   # rank r, set k: seed + 1000 r + k (disjoint over ranks and steps)
-        sets.append(SynthSet(default_spec(lib, seed=args.seed + 1000 * rank + k, total_hets=args.total_hets, max_block_hets=args.max_block_hets,
-                                          coverage=float(args.coverage), seq_format=fmt, threads=gen_threads)))
+        over = {}
+        for kv in args.spec:   # e.g. --spec edit_noise=0.003 --spec frac_sv=0
+            key, val = kv.split("=", 1)
+            over[key] = float(val)
+        sets.append(SynthSet(default_spec(lib, **dict(dict(seed=args.seed + 1000 * rank + k, total_hets=args.total_hets, max_block_hets=args.max_block_hets,
+                                                           coverage=float(args.coverage), seq_format=fmt, threads=gen_threads), **over))))
     outs = [s.outputs() for s in sets]
     t_gen = time.perf_counter() - t_gen
     prm = block_params()
@@ -342,7 +346,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
                        "distinct_sets": n_sets, "depth": args.depth, "seq_format": args.seq_format,
                        "host_to_device_bytes_per_step": st_mean[10], "host_to_device_gbs": st_mean[10] / (ms_step * 1e-3) / 1e9,
                        "min_queue_size": 1000, "queue_increment": 3, "max_edit_distance": 500, "wfa_prune_distance": 500,
-                       "generate_s": round(t_gen, 2)},
+                       "generate_s": round(t_gen, 2), "spec_overrides": args.spec},
             "stage_ms": {"overlaps_layout_host": st_mean[0], "staging_pcie_expand": st_mean[1], "graph_wfa": st_mean[2], "fallback_rows_collapse_host": st_mean[3],
                          "astar_pack_upload": st_mean[4], "astar_solve": st_mean[5], "postprocess_outputs": st_mean[6], "latency_submit_to_done": st_mean[7],
                          "graph_wfa_kernels": st_mean[8], "astar_kernel": st_mean[9], "waiting_between_stages": st_mean[11],
@@ -419,6 +423,7 @@ def main():
     ap.add_argument("--seq-format", choices=["bam4", "ascii"], default="bam4", help="path workload: how the reads are handed over")
     ap.add_argument("--depth", type=int, default=5, help="path workload: block sets in flight in the stream")
     ap.add_argument("--distinct-sets", type=int, default=16, help="path workload: generated sets (steps + warm-up if fewer; cycled if more are needed)")
+    ap.add_argument("--spec", action="append", default=[], help="path workload: override a field of hp_synth_reads_spec, key=value (repeatable)")
     ap.add_argument("--no-resident", action="store_true", help="path workload: skip the secondary resident (inputs-in-HBM) figure")
     ap.add_argument("--seed", type=int, default=20250928, help="path workload: seed of the synthetic block mix (rank r uses seed + r)")
     ap.add_argument("--blocks", type=int, default=6144, help="blocks per GPU (24 resident single-wave workgroups per CU x 256 CUs)")
