@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -33,8 +34,11 @@ public:
         if (inflight_.fetch_add(1, std::memory_order_acq_rel) == 0) {
             // nobody else is inside the entry point: run on the caller's own thread (its caches are the warm ones for a
             // single-threaded host) - whoever arrives meanwhile queues for the service thread and is merged there
+            // (a lone runner never queues: the service thread must not wait for it, see serve())
+            lone_.fetch_add(1, std::memory_order_acq_rel);
             std::vector<Req*> one(1, r);
-            run_(one);
+            run_guarded(one);
+            lone_.fetch_sub(1, std::memory_order_acq_rel);
             inflight_.fetch_sub(1, std::memory_order_acq_rel);
             return;
         }
@@ -55,16 +59,21 @@ private:
         for (;;) {
             cv_work_.wait(lk, [this]() { return !q_.empty(); });
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us());
-            while ((int)q_.size() < inflight_.load(std::memory_order_acquire))   // someone is still on the way in
+            while ((int)q_.size() < inflight_.load(std::memory_order_acquire) - lone_.load(std::memory_order_acquire))   // someone is still on the way in
                 if (cv_work_.wait_until(lk, deadline) == std::cv_status::timeout) break;
             std::vector<Req*> batch;
             batch.swap(q_);
             lk.unlock();
-            run_(batch);
+            run_guarded(batch);
             lk.lock();
             for (Req* x : batch) x->done = true;
             cv_done_.notify_all();
         }
+    }
+    // a throw out of a batch (std::bad_alloc of a host vector) must not leave its callers asleep for ever
+    void run_guarded(std::vector<Req*>& batch) {
+        try { run_(batch); }
+        catch (...) { for (Req* x : batch) if (x->rc == 0) { x->rc = -2 /* HP_ERR_OOM */; x->err = "host allocation failed in a merged batch"; } }
     }
     static long window_us() {
         static const long w = [] { const char* e = std::getenv("HP_COALESCE_WINDOW_US"); return e ? std::max(0l, std::atol(e)) : 200l; }();
@@ -75,7 +84,7 @@ private:
     std::condition_variable cv_work_, cv_done_;
     std::vector<Req*> q_;
     bool started_ = false;
-    std::atomic<int> inflight_{0};
+    std::atomic<int> inflight_{0}, lone_{0};
 };
 
 }  // namespace hp

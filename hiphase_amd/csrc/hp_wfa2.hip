@@ -1004,7 +1004,16 @@ int W2Session::late() {
                 BA.jobs = d_jobs.as<W2Job>(); BA.ids = d_ids.as<uint32_t>(); BA.thresh = d_thr.as<uint32_t>(); BA.n = (uint32_t)cand.size();
                 BA.seq = d_seq.as<uint8_t>(); BA.exceeds = d_exc.as<uint8_t>();
                 const uint32_t maxT = *std::max_element(thr.begin(), thr.end());
-                hipLaunchKernelGGL(hp_wfa2_bound_kernel, dim3((unsigned)cand.size()), dim3(64), (size_t)(2 * (2 * maxT + 3)) * 4, bs, BA);
+                // LDS: the two wavefront arrays, then room for the longest tested read + its window (most of the CU's 160 KB: these
+                // are a few hundred single-wavefront workgroups, latency is what counts)
+                uint32_t need_seq = 0;
+                for (uint32_t i : cand) need_seq = std::max<uint32_t>(need_seq, ((dj[i].read_len + 31u) & ~15u) + ((dj[i].ref_len + 31u) & ~15u));
+                const size_t lds_wf = (size_t)(2 * (2 * maxT + 3) + 2) * 4 + 16;
+                BA.max_t = maxT;
+                BA.lds_seq = std::min<uint32_t>(need_seq, W2_BOUND_LDS_SEQ);
+                const size_t lds_total = lds_wf + BA.lds_seq;
+                HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_bound_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
+                hipLaunchKernelGGL(hp_wfa2_bound_kernel, dim3((unsigned)cand.size()), dim3(64), lds_total, bs, BA);
                 HP_HIP_CHECK(hipGetLastError());
                 HP_HIP_CHECK(hipMemcpyAsync(exc.data(), d_exc.p, cand.size(), hipMemcpyDeviceToHost, bs));
                 if (hipStreamSynchronize(bs) != hipSuccess) { set_error("WFA bound kernel failed"); return HP_ERR_HIP; }

@@ -251,6 +251,9 @@ constexpr uint32_t W2_LDS_LEN_LIM = 1u << 18;  // node length / 1024 edges / 7 c
 // (relative to y; lo > hi = empty), w = node length. Entries with a live wave go to the round's L list (two rounds
 // deep: the next round pulls from them); entries that only hold FINISHED waves are needed by the node's children in
 // the same round only and go to the F list. A parent entry is named by a code: L index, or 128 + F index.
+#ifndef W2_MAXPREV_SMALL
+#define W2_MAXPREV_SMALL 3
+#endif
 template <int W> struct W2Cfg {
     static constexpr int MAXN = 32 * W;          // nodes
     static constexpr int MAXE = 2 * MAXN + 32;   // edges
@@ -264,7 +267,7 @@ template <int W> struct W2Cfg {
     static constexpr int MAXPAR = 8;             // finished parent entries of one node in one round
     static constexpr int MAXS = W <= 4 ? 8 : 12; // source intervals of one node (slow path scratch)
     static constexpr int MAXW = 250;             // diagonals per entry (8-bit relative hulls)
-    static constexpr int MAXPREV = W <= 4 ? 3 : 4;   // live entries of ONE node the next round can pull from (kept in registers)
+    static constexpr int MAXPREV = W <= 4 ? W2_MAXPREV_SMALL : 4;   // live entries of ONE node the next round can pull from (kept in registers)
     static constexpr int a16(int x) { return (x + 15) & ~15; }
     // The node table is read from HBM (L2-resident: one 16-byte descriptor per node visit, with the first two children
     // inline) - with the table sizes above that takes a read's LDS to 1 600 bytes, i.e. 12 workgroups of 8 reads per CU =

@@ -36,6 +36,9 @@ namespace hp {
 #ifndef W2_QUEUE_ASM
 #define W2_QUEUE_ASM 0
 #endif
+#ifndef W2_MATCH_LANE_BYTES
+#define W2_MATCH_LANE_BYTES 32
+#endif
 #if W2_PROF
 #define W2PT(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); w2pc[i] += t_ - w2tl; w2tl = t_; } while (0)
 #define W2PC(i, v) do { w2pn[i] += (v); } while (0)
@@ -130,6 +133,11 @@ template <int G> W2DEV uint32_t w2_gsel(uint32_t v, uint32_t gl, uint32_t L) { r
 // (the sequences' base addresses are group-uniform). `on`: this group takes part (group-uniform).
 template <int G> W2DEV uint32_t w2_match_rest(const uint8_t* nseq, const uint8_t* readp, uint32_t o, int32_t pos, uint32_t maxlen, uint32_t n, bool done,
                                               bool on, uint32_t gbase, uint32_t gl) {
+    // bytes a lane compares per pass (-DW2_MATCH_LANE_BYTES). A pass is one dependent round trip to memory for the whole wavefront
+    // (every group waits for the slowest), and 88 % of the steps have one: HiFi reads match ~200 bases between two errors, so with
+    // 32 bytes a lane (256 a pass) a quarter of the served extensions need a second pass. 64 bytes a lane would leave 7 % - but
+    // the sixteen more registers spill (18-27 of them at three wavefronts per SIMD) and the launch set gets SLOWER: 43 vs 38 ms.
+    constexpr uint32_t LB = W2_MATCH_LANE_BYTES;
     bool pending = on && !done;
     while (__any(pending)) {
         const uint64_t gb = w2_gballot<G>(pending, gbase);
@@ -138,21 +146,24 @@ template <int G> W2DEV uint32_t w2_match_rest(const uint8_t* nseq, const uint8_t
         const uint32_t so = w2_gsel<G>(o + n, gl, L), sp = w2_gsel<G>((uint32_t)pos + n, gl, L), rem = w2_gsel<G>(maxlen - n, gl, L);
         const uint8_t* pa = nseq + so;
         const uint8_t* pb = readp + sp;
-        const uint32_t off = gl * 32u;
-        uint32_t m = 32u;
+        const uint32_t off = gl * LB;
+        uint32_t m = LB;
         if (active) {
             if (off < rem) {
-                const uint4 a0 = w2_ld16(pa + off), a1 = w2_ld16(pa + off + 16), b0 = w2_ld16(pb + off), b1 = w2_ld16(pb + off + 16);
-                m = w2_pfx16(a0, b0);
-                if (m == 16u) m += w2_pfx16(a1, b1);
+                uint4 a[LB / 16], b[LB / 16];
+#pragma unroll
+                for (uint32_t k = 0; k < LB / 16; ++k) { a[k] = w2_ld16(pa + off + 16 * k); b[k] = w2_ld16(pb + off + 16 * k); }
+                m = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < LB / 16; ++k) if (m == 16u * k) m += w2_pfx16(a[k], b[k]);
                 if (m > rem - off) m = rem - off;
             } else m = 0u;   // beyond the end: acts as a stop
         }
-        const uint64_t stop = w2_gballot<G>(active && m < 32u, gbase);
-        uint32_t got = (uint32_t)G * 32u;
+        const uint64_t stop = w2_gballot<G>(active && m < LB, gbase);
+        uint32_t got = (uint32_t)G * LB;
         if (stop) {
             const uint32_t S = (uint32_t)__builtin_ctzll(stop);
-            got = S * 32u + w2_gsel<G>(m, gl, S);
+            got = S * LB + w2_gsel<G>(m, gl, S);
         }
         if (got > rem) got = rem;
         if (active && gl == L) {
@@ -644,6 +655,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
             };
             const bool xA = quick(pA, nA, oA, pdA), xB = quick(pB, nB, oB, pdB), xC = quick(pC, nC, oC, pdC), xD = quick(pD, nD, 0, pdD);
             tA = tA || xA; tB = tB || xB; tC = tC || xC; tD = tD || xD;
+            W2PC(5, __any(pdA || pdB || pdC || pdD) ? 1 : 0);
             if (__any(pdA || pdB || pdC || pdD)) {   // rare: a long alternative run onto the furthest wave's diagonal
                 auto slow = [&](bool pd, int32_t oX) -> bool {
                     const uint32_t g = pd ? (uint32_t)(omax - oX) : 0u;
@@ -662,6 +674,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         bool capped = in_win && (((rel < 32u ? crec.z : crec.w) >> (rel & 31u)) & 1u);
         bool hfull = false;
         const bool use_hash = has && rec_live && !in_win;          // out of the window: the hash set (rare)
+        W2PC(6, __any(use_hash) ? 1 : 0);
         if (__any(use_hash)) {
             if (use_hash) {
                 const uint64_t key = ((uint64_t)tag << 32) | ((uint64_t)(n & 0x3FFu) << 18) | (uint64_t)((uint32_t)d & 0x3FFFFu);
@@ -696,6 +709,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         // the first such diagonal as its anchor), or - outside its window - in the hash set, one lane at a time so that
         // two of them never take the same empty slot --------------------------------------------------------------------
         bool later = false;
+        W2PC(7, __any(ins) ? 1 : 0);
         if (__any(ins)) {
             const uint64_t im = w2_gballot<G>(ins, gbase);
             if (im) {   // (group-uniform)
@@ -795,9 +809,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
     }
 #if W2_PROF
     if (lane == 0 && (blockIdx.x % 97) == 3)
-        printf("wg %u total %llu | idle->ctl %llu control %llu cand %llu issue %llu ext %llu ties %llu hash %llu write+final %llu cluster %llu | iters %u ctlpasses %u tile-lanes %u has-lanes %u ext2 %u\n",
+        printf("wg %u total %llu | idle->ctl %llu control %llu cand %llu issue %llu ext %llu ties %llu hash %llu write+final %llu cluster %llu | iters %u ctlpasses %u tile-lanes %u has-lanes %u ext2 %u tieslow %u hashprobe %u capins %u\n",
                blockIdx.x, (unsigned long long)(w2tl - w2t0), (unsigned long long)w2pc[0], (unsigned long long)w2pc[1], (unsigned long long)w2pc[2], (unsigned long long)w2pc[3],
-               (unsigned long long)w2pc[4], (unsigned long long)w2pc[5], (unsigned long long)w2pc[6], (unsigned long long)w2pc[7], (unsigned long long)w2pc[8], w2pn[0], w2pn[1], w2pn[2], w2pn[3], w2pn[4]);
+               (unsigned long long)w2pc[4], (unsigned long long)w2pc[5], (unsigned long long)w2pc[6], (unsigned long long)w2pc[7], (unsigned long long)w2pc[8], w2pn[0], w2pn[1], w2pn[2], w2pn[3], w2pn[4], w2pn[5], w2pn[6], w2pn[7]);
 #endif
 }
 
@@ -1046,8 +1060,12 @@ struct W2BoundArgs {
     uint32_t n;
     const uint8_t* seq;
     uint8_t* exceeds;          // out: 1 = ed(read, reference window) > T
+    uint32_t max_t;            // the largest threshold of the launch (sizes the wavefront arrays)
+    uint32_t lds_seq;          // bytes of LDS behind them for a job's read + reference window (0: compare in place)
 };
-constexpr uint32_t W2_BOUND_MAX_T = 3000;   // two wavefront arrays of 2 T + 3 offsets in LDS
+constexpr uint32_t W2_BOUND_MAX_T = 1000;   // the test costs T^2 / 64 tiles: 3 ms of a wavefront at 1 000, 30 at 3 000 (where a structural
+                                            // variant in the window has made D so large that the test rarely settles anything)
+constexpr uint32_t W2_BOUND_LDS_SEQ = 96 * 1024;   // read + reference window are staged in LDS when they fit in this many bytes
 __global__ void __launch_bounds__(64) hp_wfa2_bound_kernel(W2BoundArgs A) {
     extern __shared__ int32_t w2b_lds[];
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
@@ -1057,6 +1075,21 @@ __global__ void __launch_bounds__(64) hp_wfa2_bound_kernel(W2BoundArgs A) {
     const int32_t n = (int32_t)J.read_len, m = (int32_t)J.ref_len;
     const uint8_t* a = A.seq + J.read_off;
     const uint8_t* b = A.seq + J.ref_off;
+    // The extensions are a chain of dependent loads (a noisy read mismatches within a few bases, 5 600 tiles of 64 diagonals for
+    // T = 600): from HBM that is 8 ms a read, from LDS under 1. Both sequences are staged behind the wavefront arrays when they
+    // fit (A.lds_seq = the launch's room for them; reads beyond ~45 kb compare in place).
+    {
+        const uint32_t na = ((uint32_t)n + 16u + 15u) & ~15u, nb = ((uint32_t)m + 16u + 15u) & ~15u;
+        if (na + nb <= A.lds_seq) {
+            uint8_t* la = reinterpret_cast<uint8_t*>(w2b_lds + 2 * (2 * A.max_t + 3) + 2);
+            la = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(la) + 15) & ~(uintptr_t)15);
+            uint8_t* lb = la + na;
+            // (16-byte copies; the sources are 16-byte aligned only for the read - the window starts anywhere in its hull)
+            for (uint32_t o = lane * 16u; o < na; o += 64u * 16u) { uint4 v; __builtin_memcpy(&v, a + o, 16); *reinterpret_cast<uint4*>(la + o) = v; }
+            for (uint32_t o = lane * 16u; o < nb; o += 64u * 16u) { uint4 v; __builtin_memcpy(&v, b + o, 16); *reinterpret_cast<uint4*>(lb + o) = v; }
+            a = la; b = lb;
+        }
+    }
     constexpr int32_t NONE = INT32_MIN / 2;
     const int32_t W = 2 * T + 3;                 // diagonals -T-1 .. T+1 (the rim stays NONE)
     int32_t* prev = w2b_lds;
