@@ -104,8 +104,10 @@ namespace hp {
 int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id);
 // graph-WFA over every record with overlaps: device graph build, alignment, allele rows (returns after the first collection)
 int blockset_wfa(hp_blockset* bs);
-// fallback / replay / rows / collapse on host threads, the A* batch packed and uploaded
+// fallback / replay / rows / collapse on host threads (waits for the alignment stage's late results)
 int blockset_rows(hp_blockset* bs);
+// the A* batch of the set packed (host threads) and uploaded
+int blockset_pack(hp_blockset* bs);
 // A*, span counts and haplotags, outputs
 int blockset_solve(hp_blockset* bs, hp_block_output* out);
 }  // namespace hp

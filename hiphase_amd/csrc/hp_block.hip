@@ -503,11 +503,9 @@ int hp::blockset_wfa(hp_blockset* bs) {
     return HP_OK;
 }
 
-// after the WFA, first half: fallback / replay / rows / collapse (host threads over blocks), then the A* batch of all blocks
-// packed and uploaded. May run on another thread than blockset_wfa did.
+// after the WFA: fallback / replay / rows / collapse (host threads over blocks). May run on another thread than blockset_wfa did.
 int hp::blockset_rows(hp_blockset* bs) {
     hp_blockset& ch = *bs;
-    if (ch.batch) { hp_batch_destroy(ch.batch); ch.batch = nullptr; }
     const bool has_wfa = ch.wfa_ready;
     const double t1 = blk_now_ms();
     int rc = HP_OK;
@@ -572,8 +570,16 @@ int hp::blockset_rows(hp_blockset* bs) {
         if ((rc = phase(n_free, order.size())) != HP_OK) return rc;
         if (has_wfa) ch.ms[6] = w2_session_span_ms(ch.wfa);
     }
+    ch.ms[1] = blk_now_ms() - t1;
+    return HP_OK;
+}
+
+// after the rows: the A* batch of all blocks, packed (host threads) and uploaded
+int hp::blockset_pack(hp_blockset* bs) {
+    hp_blockset& ch = *bs;
+    if (ch.batch) { hp_batch_destroy(ch.batch); ch.batch = nullptr; }
     const double t2 = blk_now_ms();
-    // ---- A* over the chunk's blocks ----
+    // ---- A* over the set's blocks ----
     const size_t nb = bs->n_blocks;
     std::vector<hp_block_view>& views = ch.views;
     views.assign(nb, hp_block_view{});
@@ -621,7 +627,7 @@ int hp::blockset_rows(hp_blockset* bs) {
     } else if (!batch) return st != HP_OK ? st : HP_ERR_HIP;
     ch.batch = batch;
     const double t3 = blk_now_ms();
-    ch.ms[1] = t2 - t1; ch.ms[2] = t3 - t2;
+    ch.ms[2] = t3 - t2;
     return HP_OK;
 }
 
@@ -752,6 +758,7 @@ extern "C" int hp_blockset_solve(hp_blockset* bs, hp_block_output* out, double* 
     const double t0 = blk_now_ms();
     int rc = blockset_wfa(bs);
     if (rc == HP_OK) rc = blockset_rows(bs);
+    if (rc == HP_OK) rc = blockset_pack(bs);
     if (rc == HP_OK) rc = blockset_solve(bs, out);
     if (rc != HP_OK) return rc;
     if (stage_ms) {

@@ -3,15 +3,17 @@
 // HiPhase sees every phase block once (reference src/main.rs:337-408: blocks are generated, queued to the worker pool and
 // written in order; src/phaser.rs:513-543: a block's reads are loaded, then it is solved). A caller that hands over one block
 // set after the other therefore wants set k + 2 to be laid out and cross PCIe while set k + 1 is being aligned and set k is
-// being solved - not one after the other. Four stages, one thread each, every stage with its own HIP streams, device-buffer
+// being solved - not one after the other. Five stages, one thread each, every stage with its own HIP streams, device-buffer
 // cache, pinned staging and host worker pool (all of them per-thread state of the library), so they overlap on the host and
 // on the device:
 //
 //   stage 1 (hp::blockset_init)   overlaps of every record, layout, reads staged piece by piece as the caller holds them
 //                                 (ASCII or the BAM's own 4-bit codes) while the previous piece crosses PCIe, expanded on the device
 //   stage 2 (hp::blockset_wfa)    device graph build + graph-WFA launch set + allele rows + first collection
-//   stage 3 (hp::blockset_rows)   fallback replay / qualities / collapse on host threads, the A* batch packed and uploaded
-//   stage 4 (hp::blockset_solve)  A* (a latency-bound kernel: the host thread mostly waits), span counts and haplotags, outputs
+//   stage 3 (hp::blockset_rows)   fallback replay / qualities / collapse on host threads (mostly a WAIT: for the late results of the
+//                                 set's alignment stage - the largest class's tail, the leftovers)
+//   stage 4 (hp::blockset_pack)   the A* batch packed (host threads) and uploaded
+//   stage 5 (hp::blockset_solve)  A* (a latency-bound kernel: the host thread mostly waits), span counts and haplotags, outputs
 //                                 into the caller's buffers
 //
 // Sets complete in submission order. `depth` slots hold the sets in flight; a slot keeps its host vectors and device buffers
@@ -50,7 +52,7 @@ struct Slot {
     hp_block_output* out = nullptr;
     int rc = HP_OK;
     std::string err;
-    double t_submit = 0, t_begin[4] = {0, 0, 0, 0}, t_end[4] = {0, 0, 0, 0};
+    double t_submit = 0, t_begin[5] = {0, 0, 0, 0, 0}, t_end[5] = {0, 0, 0, 0, 0};
 };
 
 }  // namespace
@@ -61,14 +63,15 @@ struct hp_blockstream {
     std::vector<std::unique_ptr<Slot>> slots;
     std::mutex m;
     std::condition_variable cv;
-    std::deque<Slot*> q[4];            // waiting for stage 1 / 2 / 3 / 4, in ticket order
+    static constexpr int N_STAGES = 5;
+    std::deque<Slot*> q[N_STAGES];     // waiting for stage 1 .. 5, in ticket order
     uint64_t next_ticket = 1;
-    uint64_t next_in[4] = {1, 1, 1, 1};   // the ticket each stage takes next
+    uint64_t next_in[N_STAGES] = {1, 1, 1, 1, 1};   // the ticket each stage takes next
     double t_zero = 0.0;
     bool quit = false;
     // stage 3 has two threads (a set's rows mostly WAIT - for the late results of its alignment stage - so two sets share the
     // stage; they still reach stage 4 in ticket order), the others one
-    static constexpr int N_THREADS = 5;
+    static constexpr int N_THREADS = 6;
     std::thread th[N_THREADS];
     std::unique_ptr<WorkerPool> pool[N_THREADS];
     void stage_thread(int t);
@@ -78,7 +81,7 @@ struct hp_blockstream {
 
 void hp_blockstream::stage_thread(int t) {
     WorkerPool::set_thread_pool(pool[t].get());
-    stage_loop(t < 4 ? t : extra_stage);   // (t == 4: a second thread for the alignment stage - or, as an experiment, the rows stage)
+    stage_loop(t < N_STAGES ? t : extra_stage);   // (the last thread: a second one for the alignment stage - or, as an experiment, the rows stage)
 }
 
 void hp_blockstream::stage_loop(int k) {
@@ -94,7 +97,7 @@ void hp_blockstream::stage_loop(int k) {
     // ... what works instead: the alignment stage leaves a share of the wavefront slots empty (hp_wfa2.hip)
     static const int reserve = [] { const char* e = std::getenv("HP_STREAM_RESERVE_PCT"); return e ? std::max(0, std::atoi(e)) : 8; }();
     if (k == 1) g_wfa2_reserve_pct = reserve;
-    g_host_share_div = k == 0 ? 2 : 4;   // the stages' host threads together: about the process's share of the host   // the three stages' host threads together: about the process's share of the host
+    g_host_share_div = k == 0 ? 2 : 4;   // (stage 1 copies a gigabyte; the others' parallel regions are short)   // the stages' host threads together: about the process's share of the host   // the three stages' host threads together: about the process's share of the host
     for (;;) {
         Slot* s = nullptr;
         {
@@ -112,13 +115,14 @@ void hp_blockstream::stage_loop(int k) {
             if (k == 0) rc = blockset_init(&s->bs, s->n_blocks, s->in, &prm, device);
             else if (k == 1) rc = blockset_wfa(&s->bs);
             else if (k == 2) rc = blockset_rows(&s->bs);
+            else if (k == 3) rc = blockset_pack(&s->bs);
             else rc = blockset_solve(&s->bs, s->out);
             if (rc != HP_OK) { s->rc = rc; s->err = hp_last_error(); }
         }
         s->t_end[k] = st_now_ms();
         {
             std::unique_lock<std::mutex> lk(m);
-            if (k < 3) {   // (ticket order: the two threads of stage 3 may finish out of turn)
+            if (k + 1 < N_STAGES) {   // (ticket order: two threads of one stage may finish out of turn)
                 auto it = q[k + 1].begin();
                 while (it != q[k + 1].end() && (*it)->ticket < s->ticket) ++it;
                 q[k + 1].insert(it, s);
@@ -149,7 +153,7 @@ extern "C" hp_blockstream* hp_blockstream_create(const hp_block_params* p, int d
     const char* rt = std::getenv("HP_STREAM_ROWS_THREADS");
     int n_threads = hp_blockstream::N_THREADS;
     if (rt && std::atoi(rt) >= 2) s->extra_stage = 2;
-    else if (!(wt && std::atoi(wt) >= 2)) n_threads = 4;
+    else if (!(wt && std::atoi(wt) >= 2)) n_threads = hp_blockstream::N_STAGES;
     for (int k = 0; k < n_threads; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_thread(k); });
     if (status) *status = HP_OK;
     return s.release();
@@ -185,20 +189,21 @@ extern "C" int hp_blockstream_wait(hp_blockstream* s, uint64_t ticket, double* s
     if (rc != HP_OK) set_error("%s", slot->err.c_str());
     if (std::getenv("HP_STREAM_TRACE")) {   // the set's way through the stages, ms since the stream's first submit
         if (s->t_zero == 0.0) s->t_zero = slot->t_submit;
-        fprintf(stderr, "[hp] set %llu: submit %.1f | s1 %.1f-%.1f | s2 %.1f-%.1f | s3 %.1f-%.1f (waited %.1f for the late results) | s4 %.1f-%.1f\n", (unsigned long long)ticket,
+        fprintf(stderr, "[hp] set %llu: submit %.1f | s1 %.1f-%.1f | s2 %.1f-%.1f | s3 %.1f-%.1f (waited %.1f for the late results) | s4 %.1f-%.1f | s5 %.1f-%.1f\n", (unsigned long long)ticket,
                 slot->t_submit - s->t_zero, slot->t_begin[0] - s->t_zero, slot->t_end[0] - s->t_zero, slot->t_begin[1] - s->t_zero, slot->t_end[1] - s->t_zero,
-                slot->t_begin[2] - s->t_zero, slot->t_end[2] - s->t_zero, slot->bs.late_wait_ms, slot->t_begin[3] - s->t_zero, slot->t_end[3] - s->t_zero);
+                slot->t_begin[2] - s->t_zero, slot->t_end[2] - s->t_zero, slot->bs.late_wait_ms, slot->t_begin[3] - s->t_zero, slot->t_end[3] - s->t_zero, slot->t_begin[4] - s->t_zero, slot->t_end[4] - s->t_zero);
     }
     if (stage_ms) {
         const hp_blockset& B = slot->bs;
         stage_ms[0] = B.prep[0]; stage_ms[1] = B.prep[1];
         stage_ms[2] = B.ms[0]; stage_ms[3] = B.ms[1]; stage_ms[4] = B.ms[2]; stage_ms[5] = B.ms[3]; stage_ms[6] = B.ms[4];
-        stage_ms[7] = slot->t_end[3] - slot->t_submit;
+        stage_ms[7] = slot->t_end[4] - slot->t_submit;
         stage_ms[8] = B.ms[6]; stage_ms[9] = B.ms[7];
         stage_ms[10] = B.prep[3];
-        stage_ms[11] = (slot->t_begin[0] - slot->t_submit) + (slot->t_begin[1] - slot->t_end[0]) + (slot->t_begin[2] - slot->t_end[1]) + (slot->t_begin[3] - slot->t_end[2]);
+        stage_ms[11] = (slot->t_begin[0] - slot->t_submit) + (slot->t_begin[1] - slot->t_end[0]) + (slot->t_begin[2] - slot->t_end[1]) + (slot->t_begin[3] - slot->t_end[2]) +
+                       (slot->t_begin[4] - slot->t_end[3]);
         stage_ms[12] = slot->t_end[0] - slot->t_begin[0]; stage_ms[13] = slot->t_end[1] - slot->t_begin[1]; stage_ms[14] = slot->t_end[2] - slot->t_begin[2];
-        stage_ms[15] = slot->t_end[3] - slot->t_begin[3];
+        stage_ms[15] = (slot->t_end[3] - slot->t_begin[3]) + (slot->t_end[4] - slot->t_begin[4]);   // (pack + solve)
     }
     if (work) for (int i = 0; i < 8; ++i) work[i] = slot->bs.work[i];
     slot->state = Slot::FREE;

@@ -901,6 +901,10 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
 // The second collection (two phases) and the dense-band pass. Runs on the session's helper thread when run() deferred.
 int W2Session::late() {
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
+    const bool trace = std::getenv("HP_STREAM_TRACE") != nullptr;
+    const double tl0 = w2_now_ms();
+    double tl_tail = tl0, tl_bound = tl0;
+    struct LateTrace { bool on; const double& t0; const double& t1; const double& t2; const W2Session* s; ~LateTrace() { if (on) fprintf(stderr, "[hp] late: largest class done + held results after %.1f ms, reference-window test after %.1f, dense-band pass after %.1f (%zu jobs)\n", t1 - t0, t2 - t0, w2_now_ms() - t0, s->pend.big.size()); } } lt{trace, tl0, tl_tail, tl_bound, this};
     if (pend.two_phase) {
         hipStream_t s2 = pend.stream2;
         // the held jobs' results, gathered on the device: ids + row offsets up, one record + the allele row per job down
@@ -962,6 +966,7 @@ int W2Session::late() {
         std::lock_guard<std::mutex> lk(work_m);
         work_updates += s0; work_node_bytes += s1; work_read_bytes += s2w; work_jobs += s3;
     }
+    tl_tail = tl_bound = w2_now_ms();
     if (!pend.big.empty()) {
         {   // ascending job order (with the hints)
             std::vector<std::array<uint32_t, 3>> z(pend.big.size());
@@ -1034,6 +1039,7 @@ int W2Session::late() {
             }
         }
     }
+    tl_bound = w2_now_ms();
     if (!pend.big.empty()) {
         pend.sub.resize(pend.big.size()); pend.sub_out.resize(pend.big.size()); pend.sub_al.resize(pend.big.size());
         ascii_scratch.clear();

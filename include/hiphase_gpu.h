@@ -362,7 +362,7 @@ void hp_blockset_destroy(hp_blockset* bs);
  * from different threads. depth: 0 = 5. stage_ms (16 doubles, may be NULL): [0] overlaps + layout (host), [1] staging copy + PCIe
  * + base expansion, [2] graph-WFA stage, [3] fallback / replay / rows (host), [4] A* pack + upload, [5] A* solve, [6] post-processing
  * + outputs, [7] latency submit -> done, [8] graph-WFA kernels (HIP events), [9] A* kernels (HIP events), [10] bytes host -> device,
- * [11] time spent waiting between stages, [12..15] wall time of stage 1 (layout + PCIe) / 2 (graph-WFA) / 3 (rows + A* pack) / 4 (A* + post). work (8 values, may be NULL): as hp_blockset_work. */
+ * [11] time spent waiting between stages, [12..15] wall time of stage 1 (layout + PCIe) / 2 (graph-WFA) / 3 (rows) / 4 + 5 (A* pack; A* + post). work (8 values, may be NULL): as hp_blockset_work. */
 typedef struct hp_blockstream hp_blockstream;
 hp_blockstream* hp_blockstream_create(const hp_block_params* p, int device_id, uint32_t depth, int* status);
 int  hp_blockstream_submit(hp_blockstream* s, size_t n_blocks, const hp_block_input* in, hp_block_output* out, uint64_t* ticket);
