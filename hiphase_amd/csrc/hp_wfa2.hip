@@ -41,6 +41,7 @@ inline uint32_t w2_hcap_log2() {   // keys per group's overflow hash set: 2^n x 
     return v;
 }
 #define W2_HCAP_LOG2 (w2_hcap_log2())
+constexpr uint32_t W2_REGIONS = 5;   // scratch regions of a context: one per smaller class, three taking turns for the largest
 constexpr uint32_t W2_GSET_STRIDE = W2Cfg<8>::GROUP_DWORDS;   // dwords per group (node sets + capped records), sized for the largest class
 
 // per-(thread, device) state that survives across calls
@@ -51,7 +52,11 @@ struct W2Context {
     uint32_t htab_groups = 0;
     uint32_t tag_next = 0;   // tags handed out so far (tag 0 = empty)
     // streams per CU partition (hp_common.h): the main stream, and one per graph-size class (the three launches overlap)
-    struct Streams { hipStream_t stream = nullptr; hipStream_t cstream[3] = {nullptr, nullptr, nullptr}; } ps[3];
+    // (the largest class's kernel outlives run() - it is the tail of the launch set, collected by late() - so consecutive runs of a
+    // block stream take turns on three streams, and three scratch regions, for it: the next set's kernel neither queues behind this
+    // one's tail nor is waited for by this one's late())
+    struct Streams { hipStream_t stream = nullptr; hipStream_t cstream[3] = {nullptr, nullptr, nullptr}; hipStream_t c2x[2] = {nullptr, nullptr}; } ps[3];
+    uint32_t run_no = 0;
     hipEvent_t cfork = nullptr, cjoin[3] = {nullptr, nullptr, nullptr};
     PinBuf stage;            // upload staging: seq bytes, then the tables
     PinBuf down;             // download staging
@@ -60,6 +65,7 @@ struct W2Context {
         for (auto& s : ps) {
             if (s.stream) { (void)hipStreamDestroy(s.stream); s.stream = nullptr; }
             for (int k = 0; k < 3; ++k) if (s.cstream[k]) { (void)hipStreamDestroy(s.cstream[k]); s.cstream[k] = nullptr; }
+            for (int k = 0; k < 2; ++k) if (s.c2x[k]) { (void)hipStreamDestroy(s.c2x[k]); s.c2x[k] = nullptr; }
         }
     }
     int streams(int part, Streams** out) {   // created on first use in that partition
@@ -67,6 +73,7 @@ struct W2Context {
         if (!s.stream) HP_HIP_CHECK(hp_stream_create(&s.stream, device));
         // (measured: low stream priority for these persistent kernels makes THEM 40 % slower - 48 vs 35 ms - and nothing else faster)
         for (int k = 0; k < 3; ++k) if (!s.cstream[k]) HP_HIP_CHECK(hp_stream_create(&s.cstream[k], device));
+        for (int k = 0; k < 2; ++k) if (!s.c2x[k]) HP_HIP_CHECK(hp_stream_create(&s.c2x[k], device));
         *out = &s;
         return HP_OK;
     }
@@ -633,7 +640,9 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     const W2Info* info = info_pin;
     const uint32_t* cls_n = reinterpret_cast<const uint32_t*>(cx.down.p + dn_cnt);
     const uint8_t* al = cx.down.p + dn_al;
-    struct StreamDrain { hipStream_t s; W2Context::Streams* c; bool skip2; ~StreamDrain() { for (int k = 0; k < 3; ++k) if (c->cstream[k] && !(skip2 && k == 2)) (void)hipStreamSynchronize(c->cstream[k]); (void)hipStreamSynchronize(s); } } drain{st, cs_, false};
+    const uint32_t turn = cx.run_no++ % 3u;   // whose turn among the largest class's streams / scratch regions
+    hipStream_t cls_stream[3] = {cs_->cstream[0], cs_->cstream[1], turn == 0 ? cs_->cstream[2] : cs_->c2x[turn - 1]};
+    struct StreamDrain { hipStream_t s; hipStream_t* c; bool skip2; ~StreamDrain() { for (int k = 0; k < 3; ++k) if (c[k] && !(skip2 && k == 2)) (void)hipStreamSynchronize(c[k]); (void)hipStreamSynchronize(s); } } drain{st, cls_stream, false};
     const double t_stage = t0;
 
     // ---- 3. graphs on the device ----------------------------------------------------------------------------------------
@@ -661,16 +670,17 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     // capped-diagonal hash sets: one per resident group, kept (and never cleared) across calls
     const uint32_t max_groups = (uint32_t)n_cu * 96u;   // per class: up to 12 resident workgroups of 8 groups per CU
     if (cx.htab_groups < max_groups) {
-        if ((rc = cx.htab.alloc(((size_t)3 * max_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
-        if ((rc = cx.gsets.alloc((size_t)3 * max_groups * W2_GSET_STRIDE * 4)) != HP_OK) return rc;
-        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)3 * max_groups << W2_HCAP_LOG2) * 8, st));
-        HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, (size_t)3 * max_groups * W2_GSET_STRIDE * 4, st));   // (the capped records carry tags too)
+        if ((rc = cx.htab.alloc(((size_t)W2_REGIONS * max_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
+        if ((rc = cx.gsets.alloc((size_t)W2_REGIONS * max_groups * W2_GSET_STRIDE * 4)) != HP_OK) return rc;
+        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)W2_REGIONS * max_groups << W2_HCAP_LOG2) * 8, st));
+        HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, (size_t)W2_REGIONS * max_groups * W2_GSET_STRIDE * 4, st));   // (the capped records carry tags too)
         cx.htab_groups = max_groups; cx.tag_next = 0;
     }
     if ((rc = d_qhead.alloc(512)) != HP_OK) return rc;
     if ((uint64_t)cx.tag_next + n + 2 >= 0xFFFFFFF0ull) {
-        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)3 * cx.htab_groups << W2_HCAP_LOG2) * 8, st));
-        HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, (size_t)3 * cx.htab_groups * W2_GSET_STRIDE * 4, st));
+        (void)hipStreamSynchronize(cs_->cstream[2]); (void)hipStreamSynchronize(cs_->c2x[0]); (void)hipStreamSynchronize(cs_->c2x[1]);   // (an earlier run's tail may still use its region)
+        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)W2_REGIONS * cx.htab_groups << W2_HCAP_LOG2) * 8, st));
+        HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, (size_t)W2_REGIONS * cx.htab_groups * W2_GSET_STRIDE * 4, st));
         cx.tag_next = 0;
     }
     for (int k = 0; k < 3; ++k) {
@@ -749,14 +759,15 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     for (int li = 0; li < 3; ++li) {
         const int k = launch_order[li];
         if (cls_cnt[k] == 0 && !(k == 2 && escalate)) continue;
-        hipStream_t cs = cs_->cstream[k];
+        hipStream_t cs = cls_stream[k];
+        const size_t region = k < 2 ? (size_t)k : 2u + turn;
         HP_HIP_CHECK(hipStreamWaitEvent(cs, cx.cfork, 0));
         B.order = d_order.as<uint32_t>() + (size_t)k * n;
         B.n_items = cls_cnt[k];
         B.n_items_dev = d_counts + k;
         B.next = d_qhead.as<uint32_t>() + 16 * k;
-        B.htab = cx.htab.as<uint64_t>() + (((size_t)k * cx.htab_groups) << W2_HCAP_LOG2);
-        B.gsets = cx.gsets.as<uint32_t>() + (size_t)k * cx.htab_groups * W2_GSET_STRIDE;
+        B.htab = cx.htab.as<uint64_t>() + ((region * cx.htab_groups) << W2_HCAP_LOG2);
+        B.gsets = cx.gsets.as<uint32_t>() + region * cx.htab_groups * W2_GSET_STRIDE;
         B.set_stride = k == 0 ? (uint32_t)W2Cfg<2>::GROUP_DWORDS : k == 1 ? (uint32_t)W2Cfg<4>::GROUP_DWORDS : (uint32_t)W2Cfg<8>::GROUP_DWORDS;
         B.esc = d_esc; B.esc_order = d_order.as<uint32_t>() + (size_t)2 * n; B.handed = d_handed.as<uint8_t>();
         B.esc_role = !escalate ? 0u : (k == 2 ? 2u : 1u);
@@ -803,7 +814,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     // length), or the largest class handed them back, or (one phase) nobody claimed them - the dense-band pass aligns those.
     pend = Pending{};
     pend.two_phase = two_phase; pend.dst = out; pend.alleles = alleles; pend.prune = prune_distance; pend.max_ed = max_ed;
-    pend.stream2 = cs_->cstream[2]; pend.ms_build = ms_build;
+    pend.stream2 = cls_stream[2]; pend.ms_build = ms_build;
     for (size_t i = 0; i < n; ++i) {
         if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %zu", i); return HP_ERR_INVARIANT; }
         if (status[i] == W2_ST_PENDING) { if (two_phase) { pend.held.push_back((uint32_t)i); pend.held_nodes.push_back(info[i].n_nodes); } else { pend.big.push_back((uint32_t)i); pend.big_ed.push_back(0); pend.big_nodes.push_back(info[i].status == W2B_OK ? info[i].n_nodes : 0u); } }

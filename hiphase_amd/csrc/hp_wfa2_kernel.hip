@@ -310,6 +310,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
 #endif
         }
         if (fn)
+#pragma clang loop unroll(disable)
             for (uint32_t j = 0, scan = child_off; j < n_child; ++j)
                 pq_append(j == 0 ? (c01 & 0xFFFFu) : (j == 1 ? (c01 >> 16) : w2_next_child(gedge, n, scan)), code);
         chi = INT32_MIN; cvlo = INT32_MAX; cvhi = INT32_MIN; cflo = INT32_MAX; cfhi = INT32_MIN;
@@ -448,6 +449,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                     continue;
                 }
                 {
+                    // (a copy of the descriptors in LDS, direct-mapped, was measured: the visit no longer waits for L2, the launch set
+                    // is no faster - three wavefronts per SIMD hide that wait already, what the kernel lacks is issue slots - and
+                    // the tables it displaced doubled the hand-overs)
                     const uint4 nd = *reinterpret_cast<const uint4*>(gnode + n);   // seq_off, len | is_ref, children, first two children
                     len = nd.y & ~W2_IS_REF;
                     nseq = ((nd.y & W2_IS_REF) ? refp : altp) + nd.x;
@@ -474,6 +478,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                     const bool mine = pq_node == n;
                     npar = w2_gor<G>(mine ? pq_cnt : 0u); pc0 = w2_gor<G>(mine ? pq_c0 : 0u); pc1 = w2_gor<G>(mine ? pq_c1 : 0u);
                     if (mine) pq_node = 0xFFFFu;
+#pragma clang loop unroll(disable)
                     for (uint32_t i = 0; i < npar; ++i) {
                         const uint32_t code = ((i < 4u ? pc0 >> (8u * i) : pc1 >> (8u * (i - 4u))) & 0xFFu);
                         const uint4 h = code < 128u ? live[c * C::MAXL + code] : fin[code - 128u];
@@ -488,6 +493,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                     // them again, merge what overlaps or touches, every remaining interval is an item of its own
                     uint32_t ni = 0;
                     const uint32_t ns = np + npar + ((ed == 0 && n == 0) ? 1u : 0u);
+#pragma clang loop unroll(disable)
                     for (uint32_t i = 0; i < ns; ++i) {
                         int2 iv = make_int2(0, 0);
                         if (i < np) {
@@ -500,6 +506,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                             iv = make_int2((int32_t)h.y + (int32_t)h.w + (int32_t)((h.z >> 16) & 0xFFu), (int32_t)h.y + (int32_t)h.w + (int32_t)(h.z >> 24));
                         }
                         uint32_t j = 0;
+#pragma clang loop unroll(disable)
                         while (j < ni) {
                             const int2 it = srcs[j];
                             if (it.x <= iv.y + 1 && iv.x <= it.y + 1) {
@@ -577,6 +584,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         bool hinj = false;
         W2Set<W> qD = w2_set0<W>();   // (a second or later finished parent is ORed in at once: rare, and it saves W registers)
         if (run) {
+#pragma clang loop unroll(disable)
             for (uint32_t i = 0; i < npar; ++i) {
                 const uint32_t code = ((i < 4u ? pc0 >> (8u * i) : pc1 >> (8u * (i - 4u))) & 0xFFu);
                 const uint4 h = code < 128u ? live[c * C::MAXL + code] : fin[code - 128u];
@@ -613,8 +621,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
         }
         bool tA = has && oA == omax, tB = has && oB == omax, tC = has && oC == omax;
         bool tD = has && hinj && omax == 0;
-        const bool nA = has && oA >= 0 && oA < omax, nB = has && oB >= 0 && oB < omax, nC = has && oC >= 0 && oC < omax;
-        const bool nD = has && hinj && omax > 0;
+        // A candidate behind the furthest one ties iff it matches the read up to omax. When the furthest is this diagonal's own wave
+        // (B: offset + 1 of a wave that stopped INSIDE node and read, i.e. on a mismatch at offset omax - 1 of this diagonal), every
+        // other candidate would have to match through that very position: none ties, nothing to check.
+        const bool chk = has && !tB;
+        const bool nA = chk && oA >= 0 && oA < omax, nB = chk && oB >= 0 && oB < omax, nC = chk && oC >= 0 && oC < omax;
+        const bool nD = chk && hinj && omax > 0;
         // every global load of the step goes out together: the extension's first 16 bytes, the first 16 bytes of every
         // tie check, and the probe of the capped-diagonal set
         const uint8_t* ra = readp + (has ? pos0 : 0);
@@ -655,6 +667,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
             };
             const bool xA = quick(pA, nA, oA, pdA), xB = quick(pB, nB, oB, pdB), xC = quick(pC, nC, oC, pdC), xD = quick(pD, nD, 0, pdD);
             tA = tA || xA; tB = tB || xB; tC = tC || xC; tD = tD || xD;
+            if (__any(pdA || pdB || pdC || pdD)) {
+                // the long compare only decides whether the candidate's traversed nodes join the slot's set: one whose set adds
+                // nothing to what the tied candidates bring already (the usual case: the same path, a diagonal over) needs none
+                bool addA = false, addB = false, addC = false, addD = false;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    uint32_t dset = qD.w[w];
+                    if ((n >> 5) == (uint32_t)w) dset |= 1u << (n & 31u);
+                    const uint32_t known = (tA ? qA.w[w] : 0u) | (tB ? qB.w[w] : 0u) | (tC ? qC.w[w] : 0u) | (tD ? dset : 0u);
+                    addA = addA || (qA.w[w] & ~known); addB = addB || (qB.w[w] & ~known); addC = addC || (qC.w[w] & ~known); addD = addD || (dset & ~known);
+                }
+                pdA = pdA && addA; pdB = pdB && addB; pdC = pdC && addC; pdD = pdD && addD;
+            }
             W2PC(5, __any(pdA || pdB || pdC || pdD) ? 1 : 0);
             if (__any(pdA || pdB || pdC || pdD)) {   // rare: a long alternative run onto the furthest wave's diagonal
                 auto slow = [&](bool pd, int32_t oX) -> bool {
@@ -680,6 +705,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                 const uint64_t key = ((uint64_t)tag << 32) | ((uint64_t)(n & 0x3FFu) << 18) | (uint64_t)((uint32_t)d & 0x3FFFFu);
                 uint32_t hp = (n * 0x9E3779B1u + (uint32_t)d) & hmask, probes = 0;
                 uint64_t e = htab[hp];
+                // (rolled: unrolled 24 deep, each level of the probe holds a saved exec mask - fifty scalar registers the
+                // rest of the step then spills)
+#pragma clang loop unroll(disable)
                 while (e != key && (uint32_t)(e >> 32) == tag) {
                     if (++probes > 24u) { hfull = true; break; }
                     hp = (hp + 1u) & hmask;
@@ -730,6 +758,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
                     const uint64_t key = ((uint64_t)tag << 32) | ((uint64_t)(n & 0x3FFu) << 18) | (uint64_t)((uint32_t)d & 0x3FFFFu);
                     uint32_t hp = (n * 0x9E3779B1u + (uint32_t)d) & hmask, probes = 0;
                     uint64_t e = htab[hp];
+#pragma clang loop unroll(disable)
                     while (e != key && (uint32_t)(e >> 32) == tag) {
                         if (++probes > 24u) { hfull = true; break; }
                         hp = (hp + 1u) & hmask;
@@ -773,6 +802,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
             uint64_t rem = fm | w2_gballot<G>(kind == W2_KIND_INTERIOR || kind == W2_KIND_INTERIOR_READ || kind == W2_KIND_END_LAST, gbase);
             // one pass per run of diagonals (gaps of at most two inside a run); the item's last tile flushes the open cluster
             bool end_pending = base + (int32_t)G > hi;
+#pragma clang loop unroll(disable)
             while (rem || end_pending) {
                 int32_t first = INT32_MAX / 2, lastd = INT32_MAX / 2;
                 uint64_t rm = 0;
