@@ -42,7 +42,6 @@ inline uint32_t w2_hcap_log2() {   // keys per group's overflow hash set: 2^n x 
 }
 #define W2_HCAP_LOG2 (w2_hcap_log2())
 constexpr uint32_t W2_REGIONS = 5;   // scratch regions of a context: one per smaller class, three taking turns for the largest
-constexpr uint32_t W2_GSET_STRIDE = W2Cfg<8>::GROUP_DWORDS;   // dwords per group (node sets + capped records), sized for the largest class
 
 // per-(thread, device) state that survives across calls
 struct W2Context {
@@ -50,6 +49,11 @@ struct W2Context {
     DevBuf htab;             // capped-diagonal hash sets, [groups][1 << W2_HCAP_LOG2]; zeroed once, then tagged
     DevBuf gsets;            // [groups][W2_SET_STRIDE_MAX] the arena slots' traversed-node sets
     uint32_t htab_groups = 0;
+    // scratch regions: [0], [1] the two smaller classes (htab_groups groups each, their own set strides), [2..4] the largest class
+    // (large_groups groups each; three, taken in turns by consecutive runs)
+    uint32_t large_groups = 0;
+    size_t region_set_off[5] = {0, 0, 0, 0, 0};   // dwords into gsets
+    size_t region_hash_off[5] = {0, 0, 0, 0, 0};  // groups into htab
     uint32_t tag_next = 0;   // tags handed out so far (tag 0 = empty)
     // streams per CU partition (hp_common.h): the main stream, and one per graph-size class (the three launches overlap)
     // (the largest class's kernel outlives run() - it is the tail of the launch set, collected by late() - so consecutive runs of a
@@ -117,8 +121,8 @@ void merge_ranges(std::vector<std::pair<const uint8_t*, uint64_t>>& iv, std::vec
     }
 }
 // one region of `max_groups` groups per class in htab / gsets: the class launches run concurrently
-template <int G, int W> uint32_t w2_grid(uint32_t n_items, int n_cu, uint32_t max_groups) {
-    using C = W2Cfg<W>;
+template <int G, int W, bool WIDE = false> uint32_t w2_grid(uint32_t n_items, int n_cu, uint32_t max_groups) {
+    using C = W2Cfg<W, WIDE>;
     constexpr uint32_t NG = 64 / G;
     const size_t lds = (size_t)C::BYTES * NG;
     const size_t lds_alloc = (lds + 1279) / 1280 * 1280;   // gfx950 allocates LDS in 1280-byte granules
@@ -128,18 +132,18 @@ template <int G, int W> uint32_t w2_grid(uint32_t n_items, int n_cu, uint32_t ma
     grid = std::min<uint32_t>(grid, max_groups / NG);
     return grid == 0 ? 1u : grid;
 }
-template <int G, int W> int w2_launch(const W2Batch& B, uint32_t n_items, int n_cu, uint32_t max_groups, hipStream_t st, uint32_t* groups_used) {
-    using C = W2Cfg<W>;
+template <int G, int W, bool WIDE = false> int w2_launch(const W2Batch& B, uint32_t n_items, int n_cu, uint32_t max_groups, hipStream_t st, uint32_t* groups_used) {
+    using C = W2Cfg<W, WIDE>;
     constexpr uint32_t NG = 64 / G;
     const size_t lds = (size_t)C::BYTES * NG;
-    const uint32_t grid = w2_grid<G, W>(n_items, n_cu, max_groups);
+    const uint32_t grid = w2_grid<G, W, WIDE>(n_items, n_cu, max_groups);
     static std::atomic<bool> attr_set{false};   // (per instantiation)
     if (lds > 64 * 1024 || !attr_set.load()) {
-        HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_kernel<G, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_kernel<G, W, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set.store(true);
     }
     *groups_used = grid * NG;
-    hipLaunchKernelGGL((hp_wfa2_kernel<G, W>), dim3(grid), dim3(64), lds, st, B);
+    hipLaunchKernelGGL((hp_wfa2_kernel<G, W, WIDE>), dim3(grid), dim3(64), lds, st, B);
     HP_HIP_CHECK(hipGetLastError());
     return HP_OK;
 }
@@ -207,7 +211,9 @@ struct W2Session {
         std::vector<uint32_t> held_nodes;   // their graphs' node counts (hp_wfa_result::n_nodes)
         std::vector<uint32_t> big;      // for the dense-band pass
         std::vector<uint32_t> big_ed;   // the edit distance each of them had reached when the compact kernel let go of it
-        std::vector<uint32_t> big_nodes; // their graphs' node counts (0: the device builder left the graph to the host)
+        std::vector<uint32_t> big_nodes; // their graphs' node counts (0: the device builder left the graph to the host) | the limit that ended the compact attempt (hp_wfa2_kernel's `why`) << 24
+        static uint32_t nodes_of(uint32_t x) { return x & 0xFFFFFFu; }
+        static uint32_t why_of(uint32_t x) { return x >> 24; }
         std::vector<hp_wfa_job> sub;
         std::vector<hp_wfa_result> sub_out;
         std::vector<uint8_t*> sub_al;
@@ -215,11 +221,15 @@ struct W2Session {
         uint8_t* const* alleles = nullptr;
         uint64_t prune = 0, max_ed = 0;
         hipStream_t stream2 = nullptr;  // the largest class's stream
+        W2Batch b2{};                   // the largest class's launch of this run (its scratch region; a second tag range)
+        uint32_t large_groups = 0;
+        int n_cu = 0;
         float ms_build = 0.f;
         int rc = HP_OK;
         std::string err;
     } pend;
-    DevBuf d_job_cls, d_handed, d_seen, d_held, d_hoff, d_hrec, d_hrows;
+    DevBuf d_job_cls, d_handed, d_seen, d_held, d_hoff, d_hrec, d_hrows, d_wide, d_wide_sets, d_wide_hash;
+    uint32_t wide_tag_next = 0;
     PinBuf late_down;                      // results of the held jobs
     std::unique_ptr<HelperThread> helper;  // runs late() when run() defers
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build start / end, class launches start / end
@@ -669,18 +679,25 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     // ---- 4. classes by graph size, longest read first: on the device, nothing comes back to the host in between --------------
     // capped-diagonal hash sets: one per resident group, kept (and never cleared) across calls
     const uint32_t max_groups = (uint32_t)n_cu * 96u;   // per class: up to 12 resident workgroups of 8 groups per CU
+    const uint32_t large_groups = (uint32_t)n_cu * 40u;    // the largest class: at most 10 workgroups of 4 groups per CU
+    const size_t set_dwords = (size_t)max_groups * (W2Cfg<2>::GROUP_DWORDS + W2Cfg<4>::GROUP_DWORDS) + (size_t)3 * large_groups * W2Cfg<8>::GROUP_DWORDS;
+    const size_t hash_groups = (size_t)2 * max_groups + (size_t)3 * large_groups;
     if (cx.htab_groups < max_groups) {
-        if ((rc = cx.htab.alloc(((size_t)W2_REGIONS * max_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
-        if ((rc = cx.gsets.alloc((size_t)W2_REGIONS * max_groups * W2_GSET_STRIDE * 4)) != HP_OK) return rc;
-        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)W2_REGIONS * max_groups << W2_HCAP_LOG2) * 8, st));
-        HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, (size_t)W2_REGIONS * max_groups * W2_GSET_STRIDE * 4, st));   // (the capped records carry tags too)
-        cx.htab_groups = max_groups; cx.tag_next = 0;
+        if ((rc = cx.htab.alloc((hash_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
+        if ((rc = cx.gsets.alloc(set_dwords * 4)) != HP_OK) return rc;
+        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, (hash_groups << W2_HCAP_LOG2) * 8, st));
+        HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, set_dwords * 4, st));   // (the capped records carry tags too)
+        cx.htab_groups = max_groups; cx.large_groups = large_groups; cx.tag_next = 0;
+        cx.region_set_off[0] = 0; cx.region_set_off[1] = (size_t)max_groups * W2Cfg<2>::GROUP_DWORDS;
+        cx.region_set_off[2] = cx.region_set_off[1] + (size_t)max_groups * W2Cfg<4>::GROUP_DWORDS;
+        cx.region_hash_off[0] = 0; cx.region_hash_off[1] = max_groups; cx.region_hash_off[2] = (size_t)2 * max_groups;
+        for (int r = 3; r < 5; ++r) { cx.region_set_off[r] = cx.region_set_off[r - 1] + (size_t)large_groups * W2Cfg<8>::GROUP_DWORDS; cx.region_hash_off[r] = cx.region_hash_off[r - 1] + large_groups; }
     }
     if ((rc = d_qhead.alloc(512)) != HP_OK) return rc;
     if ((uint64_t)cx.tag_next + n + 2 >= 0xFFFFFFF0ull) {
         (void)hipStreamSynchronize(cs_->cstream[2]); (void)hipStreamSynchronize(cs_->c2x[0]); (void)hipStreamSynchronize(cs_->c2x[1]);   // (an earlier run's tail may still use its region)
-        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, ((size_t)W2_REGIONS * cx.htab_groups << W2_HCAP_LOG2) * 8, st));
-        HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, (size_t)W2_REGIONS * cx.htab_groups * W2_GSET_STRIDE * 4, st));
+        HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, (hash_groups << W2_HCAP_LOG2) * 8, st));
+        HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, set_dwords * 4, st));
         cx.tag_next = 0;
     }
     for (int k = 0; k < 3; ++k) {
@@ -689,7 +706,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     if (!cx.cfork) HP_HIP_CHECK(hipEventCreateWithFlags(&cx.cfork, hipEventDisableTiming));
     HP_HIP_CHECK(hipMemsetAsync(d_qhead.p, 0, 512, st));   // work-queue heads at dword 16 k, class counts at dwords 64..67
     const uint32_t tag_base = cx.tag_next;
-    cx.tag_next += (uint32_t)n + 1;
+    cx.tag_next += (uint32_t)n + 1u;
     uint32_t* d_counts = d_qhead.as<uint32_t>() + 64;
     uint32_t* d_esc = d_qhead.as<uint32_t>() + 96;   // a cache line of its own
     {
@@ -715,11 +732,14 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     B.jobs = d_jobs.as<W2Job>(); B.info = d_info.as<W2Info>(); B.tag_base = tag_base;
     B.nodes = d_nodes.as<W2Node>(); B.edges = d_edges.as<uint16_t>(); B.seq = d_seq.as<uint8_t>(); B.alt_off = alt_off;
     B.out_sets = d_sets.as<uint32_t>(); B.out_score = d_score.as<uint64_t>(); B.status = d_status.as<int32_t>(); B.out_work = d_work.as<uint32_t>();
-    B.htab = cx.htab.as<uint64_t>(); B.hcap_log2 = W2_HCAP_LOG2; B.gsets = cx.gsets.as<uint32_t>(); B.set_stride = W2_GSET_STRIDE; B.prune_distance = prune_distance; B.max_ed = max_ed;
+    B.htab = cx.htab.as<uint64_t>(); B.hcap_log2 = W2_HCAP_LOG2; B.gsets = cx.gsets.as<uint32_t>(); B.set_stride = 0; B.prune_distance = prune_distance; B.max_ed = max_ed;
     const double t_cls = w2_now_ms();
     HP_HIP_CHECK(hipEventRecord(e2, st));
     HP_HIP_CHECK(hipEventRecord(cx.cfork, st));
     uint32_t groups_used[3] = {0, 0, 0};
+    W2Batch pend_b2 = B;   // what the largest class was launched with (late() may launch it once more)
+    { const size_t region = 2u + turn; pend_b2.htab = cx.htab.as<uint64_t>() + (cx.region_hash_off[region] << W2_HCAP_LOG2); pend_b2.gsets = cx.gsets.as<uint32_t>() + cx.region_set_off[region];
+      pend_b2.set_stride = (uint32_t)W2Cfg<8>::GROUP_DWORDS; pend_b2.esc = d_esc; pend_b2.esc_order = d_order.as<uint32_t>() + (size_t)2 * n; pend_b2.handed = d_handed.as<uint8_t>(); }
     const uint32_t cls_cnt[3] = {cls_n[0], cls_n[1], cls_n[2]};
     const char* genv = std::getenv("HP_WFA2_G");   // experiment: lanes per read for the middle class
     const int gsel = genv ? std::atoi(genv) : 8;
@@ -766,8 +786,8 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         B.n_items = cls_cnt[k];
         B.n_items_dev = d_counts + k;
         B.next = d_qhead.as<uint32_t>() + 16 * k;
-        B.htab = cx.htab.as<uint64_t>() + ((region * cx.htab_groups) << W2_HCAP_LOG2);
-        B.gsets = cx.gsets.as<uint32_t>() + region * cx.htab_groups * W2_GSET_STRIDE;
+        B.htab = cx.htab.as<uint64_t>() + (cx.region_hash_off[region] << W2_HCAP_LOG2);
+        B.gsets = cx.gsets.as<uint32_t>() + cx.region_set_off[region];
         B.set_stride = k == 0 ? (uint32_t)W2Cfg<2>::GROUP_DWORDS : k == 1 ? (uint32_t)W2Cfg<4>::GROUP_DWORDS : (uint32_t)W2Cfg<8>::GROUP_DWORDS;
         B.esc = d_esc; B.esc_order = d_order.as<uint32_t>() + (size_t)2 * n; B.handed = d_handed.as<uint8_t>();
         B.esc_role = !escalate ? 0u : (k == 2 ? 2u : 1u);
@@ -777,7 +797,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         else if (k == 1) rc = gsel == 16 ? w2_launch<16, 4>(B, B.n_items, n_cu, capg[1], cs, &groups_used[k])
                             : gsel == 32 ? w2_launch<32, 4>(B, B.n_items, n_cu, capg[1], cs, &groups_used[k])
                                          : w2_launch<8, 4>(B, B.n_items, n_cu, capg[1], cs, &groups_used[k]);
-        else rc = w2_launch<16, 8>(B, items2, n_cu, cx.htab_groups, cs, &groups_used[k]);
+        else { rc = w2_launch<16, 8>(B, items2, n_cu, cx.large_groups, cs, &groups_used[k]); pend_b2 = B; }
         if (rc != HP_OK) return rc;
         if (two_phase && k == 2) { HP_HIP_CHECK(hipEventRecord(e3, cs)); continue; }   // collected later (late())
         HP_HIP_CHECK(hipEventRecord(cx.cjoin[k], cs));
@@ -815,10 +835,11 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     pend = Pending{};
     pend.two_phase = two_phase; pend.dst = out; pend.alleles = alleles; pend.prune = prune_distance; pend.max_ed = max_ed;
     pend.stream2 = cls_stream[2]; pend.ms_build = ms_build;
+    pend.b2 = pend_b2; pend.large_groups = cx.large_groups; pend.n_cu = n_cu;
     for (size_t i = 0; i < n; ++i) {
         if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %zu", i); return HP_ERR_INVARIANT; }
         if (status[i] == W2_ST_PENDING) { if (two_phase) { pend.held.push_back((uint32_t)i); pend.held_nodes.push_back(info[i].n_nodes); } else { pend.big.push_back((uint32_t)i); pend.big_ed.push_back(0); pend.big_nodes.push_back(info[i].status == W2B_OK ? info[i].n_nodes : 0u); } }
-        else if (status[i] == W2_ST_NEED_BIG) { pend.big.push_back((uint32_t)i); pend.big_ed.push_back((uint32_t)(score[i] >> 8)); pend.big_nodes.push_back(info[i].status == W2B_OK ? info[i].n_nodes : 0u); }
+        else if (status[i] == W2_ST_NEED_BIG) { pend.big.push_back((uint32_t)i); pend.big_ed.push_back((uint32_t)(score[i] >> 8)); pend.big_nodes.push_back(info[i].status == W2B_OK ? (info[i].n_nodes | ((uint32_t)(score[i] & 0xFFu) << 24)) : 0u); }
     }
     const size_t n_big = cls_n[3];
 #if W2_STATS
@@ -916,18 +937,19 @@ int W2Session::late() {
     const double tl0 = w2_now_ms();
     double tl_tail = tl0, tl_bound = tl0;
     struct LateTrace { bool on; const double& t0; const double& t1; const double& t2; const W2Session* s; ~LateTrace() { if (on) fprintf(stderr, "[hp] late: largest class done + held results after %.1f ms, reference-window test after %.1f, dense-band pass after %.1f (%zu jobs)\n", t1 - t0, t2 - t0, w2_now_ms() - t0, s->pend.big.size()); } } lt{trace, tl0, tl_tail, tl_bound, this};
-    if (pend.two_phase) {
-        hipStream_t s2 = pend.stream2;
-        // the held jobs' results, gathered on the device: ids + row offsets up, one record + the allele row per job down
-        const size_t h = pend.held.size();
+    // results of jobs the largest class's kernel wrote after run()'s collection, gathered on the device: ids + row offsets up, one
+    // record + the allele row per job down. What it could not align joins pend.big.
+    hipStream_t s2 = pend.stream2;
+    auto collect = [&](const std::vector<uint32_t>& ids, const std::vector<uint32_t>& id_nodes) -> int {
+        const size_t h = ids.size();
         int rc;
         std::vector<uint32_t> hoff(h + 1, 0);
-        for (size_t k = 0; k < h; ++k) hoff[k + 1] = hoff[k] + dj[pend.held[k]].n_hets;
+        for (size_t k = 0; k < h; ++k) hoff[k + 1] = hoff[k] + dj[ids[k]].n_hets;
         const size_t up_off = (h * 4 + 15) / 16 * 16, dn_rec = (up_off + (h + 1) * 4 + 63) / 64 * 64, dn_rows = dn_rec + h * sizeof(W2HeldRec);
         if ((rc = late_down.reserve(dn_rows + hoff[h] + 64)) != HP_OK) return rc;
         if ((rc = d_held.alloc(h * 4 + 16)) || (rc = d_hoff.alloc((h + 1) * 4 + 16)) || (rc = d_hrec.alloc(h * sizeof(W2HeldRec) + 16)) || (rc = d_hrows.alloc((size_t)hoff[h] + 16))) return rc;
         if (h) {
-            std::memcpy(late_down.p, pend.held.data(), h * 4);
+            std::memcpy(late_down.p, ids.data(), h * 4);
             std::memcpy(late_down.p + up_off, hoff.data(), (h + 1) * 4);
             HP_HIP_CHECK(hipMemcpyAsync(d_held.p, late_down.p, h * 4, hipMemcpyHostToDevice, s2));
             HP_HIP_CHECK(hipMemcpyAsync(d_hoff.p, late_down.p + up_off, (h + 1) * 4, hipMemcpyHostToDevice, s2));
@@ -944,38 +966,85 @@ int W2Session::late() {
             if (hoff[h]) HP_HIP_CHECK(hipMemcpyAsync(late_down.p + dn_rows, d_hrows.p, hoff[h], hipMemcpyDeviceToHost, s2));
         }
         if (hipStreamSynchronize(s2) != hipSuccess) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
-        float ms_wfa = 0.f;
-        (void)hipEventElapsedTime(&ms_wfa, ev[2], ev[3]);
-        last_span_ms = (double)ms_wfa;
-        late_kernel_ms = (double)pend.ms_build + (double)ms_wfa;
         const W2HeldRec* rec = reinterpret_cast<const W2HeldRec*>(late_down.p + dn_rec);
         const uint8_t* rows = late_down.p + dn_rows;
         uint64_t s0 = 0, s1 = 0, s2w = 0, s3 = 0;
         for (size_t hk = 0; hk < h; ++hk) {
-            const uint32_t i = pend.held[hk];
+            const uint32_t i = ids[hk];
             const int32_t sti = rec[hk].status;
-            if (sti == W2_ST_NEED_BIG || sti == W2_ST_PENDING) { pend.big.push_back(i); pend.big_ed.push_back(sti == W2_ST_NEED_BIG ? (uint32_t)(rec[hk].score >> 8) : 0u); pend.big_nodes.push_back(pend.held_nodes[hk]); continue; }   // (PENDING: handed over, never claimed)
+            if (sti == W2_ST_NEED_BIG || sti == W2_ST_PENDING) { pend.big.push_back(i); pend.big_ed.push_back(sti == W2_ST_NEED_BIG ? (uint32_t)(rec[hk].score >> 8) : 0u); pend.big_nodes.push_back(Pending::nodes_of(id_nodes[hk]) | (sti == W2_ST_NEED_BIG ? (uint32_t)(rec[hk].score & 0xFFu) << 24 : 0u)); continue; }   // (PENDING: handed over, never claimed)
             if (sti != W2_ST_OK && sti != W2_ST_MAX_ED) { set_error("job %u: device status %d", i, sti); return HP_ERR_INVARIANT; }
             s0 += rec[hk].work_updates; s1 += rec[hk].work_bytes; s2w += dj[i].read_len; ++s3;
             pend.dst[i].status = sti == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
-            pend.dst[i].n_nodes = pend.held_nodes[hk];
+            pend.dst[i].n_nodes = Pending::nodes_of(id_nodes[hk]);
             pend.dst[i].score = rec[hk].score;
             if (pend.alleles && pend.alleles[i] && dj[i].n_hets) std::memcpy(pend.alleles[i], rows + hoff[hk], dj[i].n_hets);
         }
-#if W2_STATS
-        {   // sizing study: how far into its alignment a job was when it was handed over (round it gave up in / final score)
-            std::vector<uint8_t> hd(n);
-            (void)hipMemcpy(hd.data(), d_handed.p, n, hipMemcpyDeviceToHost);
-            uint32_t hist[11] = {};
-            for (size_t hk = 0; hk < h; ++hk)
-                if (hd[pend.held[hk]] && rec[hk].status == W2_ST_OK && rec[hk].score > 0) hist[std::min<uint64_t>(10, (uint64_t)(hd[pend.held[hk]] - 1) * 2 * 10 / rec[hk].score)]++;
-            fprintf(stderr, "[hp] wfa2 stats handed over at (tenths of the final edit distance):");
-            for (int k = 0; k <= 10; ++k) fprintf(stderr, " %d:%u", k, hist[k]);
-            fprintf(stderr, "\n");
-        }
-#endif
         std::lock_guard<std::mutex> lk(work_m);
         work_updates += s0; work_node_bytes += s1; work_read_bytes += s2w; work_jobs += s3;
+        return HP_OK;
+    };
+    if (pend.two_phase) {
+        const int rc = collect(pend.held, pend.held_nodes);
+        if (rc != HP_OK) return rc;
+        float ms_wfa = 0.f;
+        (void)hipEventElapsedTime(&ms_wfa, ev[2], ev[3]);
+        last_span_ms = (double)ms_wfa;
+        late_kernel_ms = (double)pend.ms_build + (double)ms_wfa;
+    }
+    // Many leftovers (a set of reads with 2 % noise and more: most outgrow the smaller classes' slot tables, and the largest class
+    // only takes over a small share while its kernel runs): a second launch of the largest class's kernel over them, on the whole
+    // device and with wider slot tables (W2Cfg<8, true>), before anything goes to the dense-band pass (HP_WFA2_WIDE_MIN leftovers;
+    // 0 = never). They start again from their first base.
+    {
+        const char* wenv = std::getenv("HP_WFA2_WIDE_MIN");
+        const size_t wide_min = wenv ? (size_t)std::max(0, std::atoi(wenv)) : (size_t)1024;
+        size_t n_cand = 0;
+        for (uint32_t x : pend.big_nodes) n_cand += (Pending::nodes_of(x) != 0 && Pending::nodes_of(x) <= (uint32_t)W2Cfg<8>::MAXN) ? 1 : 0;
+        // (measured at 2 % noise, 108 k leftovers: this launch 147 ms; graphs of up to 128 nodes through an <8,4> launch with the same
+        // tables first - 8 reads per wavefront, but 5 workgroups per CU and three tiles per node instead of two - 174 + 18 ms)
+        if (wide_min && n_cand >= wide_min) {
+            std::vector<uint32_t> ids, id_nodes, keep, keep_ed, keep_nodes;
+            for (size_t k = 0; k < pend.big.size(); ++k) {
+                const uint32_t nn = Pending::nodes_of(pend.big_nodes[k]);
+                if (nn != 0 && nn <= (uint32_t)W2Cfg<8>::MAXN) { ids.push_back(pend.big[k]); id_nodes.push_back(pend.big_nodes[k]); }
+                else { keep.push_back(pend.big[k]); keep_ed.push_back(pend.big_ed[k]); keep_nodes.push_back(pend.big_nodes[k]); }
+            }
+            // longest read first, like the class lists
+            std::vector<uint32_t> ord(ids.size());
+            std::iota(ord.begin(), ord.end(), 0u);
+            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return dj[ids[x]].read_len > dj[ids[y]].read_len; });
+            std::vector<uint32_t> up(ids.size() + 20, 0u);
+            for (size_t k = 0; k < ids.size(); ++k) up[k] = ids[ord[k]];
+            up[ids.size()] = (uint32_t)ids.size();          // n_items_dev
+            int rc;
+            if ((rc = d_wide.alloc(up.size() * 4)) != HP_OK) return rc;
+            HP_HIP_CHECK(hipMemcpyAsync(d_wide.p, up.data(), up.size() * 4, hipMemcpyHostToDevice, s2));   // (pageable: the call returns once it is staged)
+            // scratch of its own (the session's; wider sets than the class regions of the context), its own tags
+            const uint32_t wide_groups = (uint32_t)pend.n_cu * 28u;   // 7 workgroups of 4 groups per CU (LDS)
+            const size_t wset = (size_t)wide_groups * W2Cfg<8, true>::GROUP_DWORDS * 4, whash = ((size_t)wide_groups << W2_HCAP_LOG2) * 8;
+            const bool fresh = !d_wide_sets.p || d_wide_sets.bytes < wset || !d_wide_hash.p || d_wide_hash.bytes < whash;
+            if ((rc = d_wide_sets.alloc(wset)) != HP_OK || (rc = d_wide_hash.alloc(whash)) != HP_OK) return rc;
+            if (fresh || (uint64_t)wide_tag_next + n + 2 >= 0xFFFFFFF0ull) {
+                HP_HIP_CHECK(hipMemsetAsync(d_wide_sets.p, 0, wset, s2));
+                HP_HIP_CHECK(hipMemsetAsync(d_wide_hash.p, 0, whash, s2));
+                wide_tag_next = 0;
+            }
+            W2Batch B = pend.b2;
+            B.gsets = d_wide_sets.as<uint32_t>(); B.htab = d_wide_hash.as<uint64_t>();
+            B.set_stride = (uint32_t)W2Cfg<8, true>::GROUP_DWORDS;
+            B.tag_base = wide_tag_next; wide_tag_next += (uint32_t)n + 1u;
+            B.order = d_wide.as<uint32_t>(); B.n_items = (uint32_t)ids.size(); B.n_items_dev = d_wide.as<uint32_t>() + ids.size();
+            B.next = d_wide.as<uint32_t>() + ids.size() + 4;   // (zero)
+            B.esc_role = 0u; B.esc_producers = 0u; B.esc_limit = 0u;
+            uint32_t used = 0;
+            const double tw0 = w2_now_ms();
+            if ((rc = w2_launch<16, 8, true>(B, B.n_items, pend.n_cu, wide_groups, s2, &used)) != HP_OK) return rc;
+            pend.big.swap(keep); pend.big_ed.swap(keep_ed); pend.big_nodes.swap(keep_nodes);
+            const size_t before = pend.big.size();
+            if ((rc = collect(ids, id_nodes)) != HP_OK) return rc;
+            if (trace || std::getenv("HP_DEBUG")) fprintf(stderr, "[hp] wfa2: launch with the wide slot tables over %zu leftovers, %u groups: %zu aligned, %zu left, %.1f ms\n", ids.size(), used, ids.size() - (pend.big.size() - before), pend.big.size() - before, w2_now_ms() - tw0);
+        }
     }
     tl_tail = tl_bound = w2_now_ms();
     if (!pend.big.empty()) {
@@ -997,7 +1066,7 @@ int W2Session::late() {
             const uint32_t min_ed = benv ? (uint32_t)std::max(0, std::atoi(benv)) : 0u;
             std::vector<uint32_t> cand, thr, cand_pos;
             for (size_t k = 0; k < pend.big.size(); ++k) {
-                if (pend.big_ed[k] < min_ed || pend.big_nodes[k] == 0) continue;
+                if (pend.big_ed[k] < min_ed || Pending::nodes_of(pend.big_nodes[k]) == 0) continue;
                 const hp_wfa_job j = job_header(pend.big[k]);
                 uint64_t D = 0;
                 for (uint32_t v = 0; v < j.n_hets; ++v) D += std::max<uint64_t>({j.hets[v].ref_len, (j.hets[v].flags & 2u) ? j.hets[v].allele0_len : 0u, j.hets[v].allele1_len});
@@ -1039,7 +1108,7 @@ int W2Session::late() {
                     const bool tested = c < cand_pos.size() && cand_pos[c] == k;
                     if (tested && exc[c]) {
                         const uint32_t i = pend.big[k];
-                        pend.dst[i].status = HP_WFA_MAX_ED; pend.dst[i].n_nodes = pend.big_nodes[k]; pend.dst[i].score = pend.max_ed;
+                        pend.dst[i].status = HP_WFA_MAX_ED; pend.dst[i].n_nodes = Pending::nodes_of(pend.big_nodes[k]); pend.dst[i].score = pend.max_ed;
                         if (pend.alleles && pend.alleles[i] && dj[i].n_hets) std::memset(pend.alleles[i], HP_ALLELE_NOOVERLAP, dj[i].n_hets);
                         ++settled;
                     } else { keep.push_back(pend.big[k]); keep_ed.push_back(pend.big_ed[k]); keep_nodes.push_back(pend.big_nodes[k]); }

@@ -251,10 +251,13 @@ constexpr uint32_t W2_LDS_LEN_LIM = 1u << 18;  // node length / 1024 edges / 7 c
 // (relative to y; lo > hi = empty), w = node length. Entries with a live wave go to the round's L list (two rounds
 // deep: the next round pulls from them); entries that only hold FINISHED waves are needed by the node's children in
 // the same round only and go to the F list. A parent entry is named by a code: L index, or 128 + F index.
+#ifndef W2_SLOTS_WIDE
+#define W2_SLOTS_WIDE 384
+#endif
 #ifndef W2_MAXPREV_SMALL
 #define W2_MAXPREV_SMALL 3
 #endif
-template <int W> struct W2Cfg {
+template <int W, bool WIDE = false> struct W2Cfg {
     static constexpr int MAXN = 32 * W;          // nodes
     static constexpr int MAXE = 2 * MAXN + 32;   // edges
     // Table sizes of the two smaller classes follow what jobs actually use (W2_STATS build on the default bench, jobs per
@@ -262,7 +265,12 @@ template <int W> struct W2Cfg {
     // them (about 0.3 %) are handed to the largest class on the device (W2Batch::esc)
     static constexpr int MAXL = W <= 4 ? 16 : 56;     // live entries per round
     static constexpr int MAXF = W <= 4 ? 20 : 32;     // finished-only entries per round
-    static constexpr int SLOTS = W <= 4 ? 86 : 144;   // (node, diagonal) slots per round (86: what is left of 1 600 bytes)
+    // (node, diagonal) slots per round (86: what is left of 1 600 bytes). WIDE: the tables of the second launch (hp_wfa2.hip
+    // late()) over reads that outgrew the slots above: at 2 % edit noise the waves off the best path live ten rounds before the
+    // pruning floor reaches them (500 bases at ~50 a round), a node holds twenty-odd diagonals, and 80 % of the reads of such a
+    // set need more than 86 slots. (Not the largest class's own tables: a read past the edit cap then crawls on to the cap with
+    // hundreds of diagonals instead of leaving early for the reference-window test - the tail of every launch set grew by 10 ms.)
+    static constexpr int SLOTS = WIDE ? W2_SLOTS_WIDE : (W <= 4 ? 86 : 144);
     static constexpr int MAXQ = 8;               // nodes waiting for their turn with waves handed over by parents
     static constexpr int MAXPAR = 8;             // finished parent entries of one node in one round
     static constexpr int MAXS = W <= 4 ? 8 : 12; // source intervals of one node (slow path scratch)

@@ -196,9 +196,9 @@ template <int W> W2DEV void w2_stset(uint32_t* p, const W2Set<W>& s) {
 }
 
 // =====================================================================================================================
-template <int G, int W>
+template <int G, int W, bool WIDE = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W>::WAVES_PER_SIMD, W2Cfg<W>::WAVES_PER_SIMD))) hp_wfa2_kernel(W2Batch B) {
-    using C = W2Cfg<W>;
+    using C = W2Cfg<W, WIDE>;
     static_assert(G >= 8 && G <= 64 && (G & (G - 1)) == 0, "group size");
     static_assert(C::MAXQ <= G, "one lane per pending-queue entry");
     constexpr uint32_t NG = 64 / G;

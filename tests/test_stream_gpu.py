@@ -40,6 +40,23 @@ def test_solve_blocks_on_generated_sets_vs_oracle(fmt, path, monkeypatch):
     assert sum(got.arr[b].local_aligned for b in range(s.n)) > 0
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("wide_min", ["1", "0"])
+def test_noisy_sets_take_the_wide_slot_tables_vs_oracle(wide_min, monkeypatch):
+    """2 % edit noise: most reads outgrow the slot tables of the two smaller graph-size classes. With HP_WFA2_WIDE_MIN=1 every
+    such read is aligned again by the launches with the wide tables (hp_wfa2.hip late()), with 0 by the dense-band kernels:
+    the same rows either way, equal to the oracle's"""
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0")
+    monkeypatch.setenv("HP_WFA2_WIDE_MIN", wide_min)
+    lib = _ffi.lib()
+    prm = _params(2, 1000, 3, None, True)
+    s = SynthSet(default_spec(lib, total_hets=500, seed=23, seq_format=_ffi.SEQ_BAM4, edit_noise=0.02, **KW))
+    exp = oracle_outputs(s, prm)
+    got = s.outputs()
+    _ffi.check(lib.hp_solve_blocks(s.n, s.inputs, C.byref(prm), got.arr, 0))
+    assert [b for b in range(s.n) if not got.equal(exp, b)] == []
+
+
 @pytest.mark.timeout(1200)
 def test_blockstream_on_generated_sets_vs_oracle(monkeypatch):
     """six different sets, three in flight, twice around: every set's results equal the oracle's"""
