@@ -999,15 +999,19 @@ int W2Session::late() {
     {
         const char* wenv = std::getenv("HP_WFA2_WIDE_MIN");
         const size_t wide_min = wenv ? (size_t)std::max(0, std::atoi(wenv)) : (size_t)1024;
-        size_t n_cand = 0;
-        for (uint32_t x : pend.big_nodes) n_cand += (Pending::nodes_of(x) != 0 && Pending::nodes_of(x) <= (uint32_t)W2Cfg<8>::MAXN) ? 1 : 0;
         // (measured at 2 % noise, 108 k leftovers: this launch 147 ms; graphs of up to 128 nodes through an <8,4> launch with the same
         // tables first - 8 reads per wavefront, but 5 workgroups per CU and three tiles per node instead of two - 174 + 18 ms)
-        if (wide_min && n_cand >= wide_min) {
+        // Graphs of 257 .. 512 nodes (no class of the launch set holds their traversed-node sets; a 20-kb read over 85+ calls builds
+        // one) get the same launch with 16-word sets, W2Cfg<16, true>.
+        for (int wide16 = 0; wide16 < 2; ++wide16) {
+            const uint32_t n_lo = wide16 ? (uint32_t)W2Cfg<8>::MAXN : 0u, n_hi = wide16 ? (uint32_t)W2Cfg<16>::MAXN : (uint32_t)W2Cfg<8>::MAXN;
+            size_t n_cand = 0;
+            for (uint32_t x : pend.big_nodes) n_cand += (Pending::nodes_of(x) > n_lo && Pending::nodes_of(x) <= n_hi) ? 1 : 0;
+            if (!wide_min || n_cand < (wide16 ? std::max<size_t>(1, wide_min / 16) : wide_min)) continue;   // (a large graph costs the dense-band kernels far more than a small one)
             std::vector<uint32_t> ids, id_nodes, keep, keep_ed, keep_nodes;
             for (size_t k = 0; k < pend.big.size(); ++k) {
                 const uint32_t nn = Pending::nodes_of(pend.big_nodes[k]);
-                if (nn != 0 && nn <= (uint32_t)W2Cfg<8>::MAXN) { ids.push_back(pend.big[k]); id_nodes.push_back(pend.big_nodes[k]); }
+                if (nn > n_lo && nn <= n_hi) { ids.push_back(pend.big[k]); id_nodes.push_back(pend.big_nodes[k]); }
                 else { keep.push_back(pend.big[k]); keep_ed.push_back(pend.big_ed[k]); keep_nodes.push_back(pend.big_nodes[k]); }
             }
             // longest read first, like the class lists
@@ -1022,7 +1026,8 @@ int W2Session::late() {
             HP_HIP_CHECK(hipMemcpyAsync(d_wide.p, up.data(), up.size() * 4, hipMemcpyHostToDevice, s2));   // (pageable: the call returns once it is staged)
             // scratch of its own (the session's; wider sets than the class regions of the context), its own tags
             const uint32_t wide_groups = (uint32_t)pend.n_cu * 28u;   // 7 workgroups of 4 groups per CU (LDS)
-            const size_t wset = (size_t)wide_groups * W2Cfg<8, true>::GROUP_DWORDS * 4, whash = ((size_t)wide_groups << W2_HCAP_LOG2) * 8;
+            const size_t group_dwords = wide16 ? (size_t)W2Cfg<16, true>::GROUP_DWORDS : (size_t)W2Cfg<8, true>::GROUP_DWORDS;
+            const size_t wset = (size_t)wide_groups * group_dwords * 4, whash = ((size_t)wide_groups << W2_HCAP_LOG2) * 8;
             const bool fresh = !d_wide_sets.p || d_wide_sets.bytes < wset || !d_wide_hash.p || d_wide_hash.bytes < whash;
             if ((rc = d_wide_sets.alloc(wset)) != HP_OK || (rc = d_wide_hash.alloc(whash)) != HP_OK) return rc;
             if (fresh || (uint64_t)wide_tag_next + n + 2 >= 0xFFFFFFF0ull) {
@@ -1032,18 +1037,19 @@ int W2Session::late() {
             }
             W2Batch B = pend.b2;
             B.gsets = d_wide_sets.as<uint32_t>(); B.htab = d_wide_hash.as<uint64_t>();
-            B.set_stride = (uint32_t)W2Cfg<8, true>::GROUP_DWORDS;
+            B.set_stride = (uint32_t)group_dwords;
             B.tag_base = wide_tag_next; wide_tag_next += (uint32_t)n + 1u;
             B.order = d_wide.as<uint32_t>(); B.n_items = (uint32_t)ids.size(); B.n_items_dev = d_wide.as<uint32_t>() + ids.size();
             B.next = d_wide.as<uint32_t>() + ids.size() + 4;   // (zero)
             B.esc_role = 0u; B.esc_producers = 0u; B.esc_limit = 0u;
             uint32_t used = 0;
             const double tw0 = w2_now_ms();
-            if ((rc = w2_launch<16, 8, true>(B, B.n_items, pend.n_cu, wide_groups, s2, &used)) != HP_OK) return rc;
+            rc = wide16 ? w2_launch<16, 16, true>(B, B.n_items, pend.n_cu, wide_groups, s2, &used) : w2_launch<16, 8, true>(B, B.n_items, pend.n_cu, wide_groups, s2, &used);
+            if (rc != HP_OK) return rc;
             pend.big.swap(keep); pend.big_ed.swap(keep_ed); pend.big_nodes.swap(keep_nodes);
             const size_t before = pend.big.size();
             if ((rc = collect(ids, id_nodes)) != HP_OK) return rc;
-            if (trace || std::getenv("HP_DEBUG")) fprintf(stderr, "[hp] wfa2: launch with the wide slot tables over %zu leftovers, %u groups: %zu aligned, %zu left, %.1f ms\n", ids.size(), used, ids.size() - (pend.big.size() - before), pend.big.size() - before, w2_now_ms() - tw0);
+            if (trace || std::getenv("HP_DEBUG")) fprintf(stderr, "[hp] wfa2: launch with the wide slot tables (%d-word sets) over %zu leftovers, %u groups: %zu aligned, %zu left, %.1f ms\n", wide16 ? 16 : 8, ids.size(), used, ids.size() - (pend.big.size() - before), pend.big.size() - before, w2_now_ms() - tw0);
         }
     }
     tl_tail = tl_bound = w2_now_ms();

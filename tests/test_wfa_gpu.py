@@ -256,6 +256,16 @@ def test_graph_beyond_the_lds_budget():
     assert min(g[2] for g in got) > 1024, [g[2] for g in got]
 
 
+def test_graphs_of_257_to_512_nodes_take_the_sixteen_word_sets(monkeypatch):
+    """a read over 90 - 160 calls builds a graph no class of the launch set holds (256 nodes at most); with HP_WFA2_WIDE_MIN
+    reached, those jobs go through hp_wfa2_kernel<16, 16, true> (512 nodes) instead of the dense-band kernels - same results"""
+    monkeypatch.setenv("HP_WFA2_WIDE_MIN", "8")
+    specs = [synth_wfa_job(1300 + s, ref_len=9000, n_vars=95 + 5 * (s % 12), n_homs=10, noise=0.004 + 0.002 * (s % 5), margin=30, multiallelic=0.1)[0] for s in range(24)]
+    got = check_specs(specs)
+    assert sum(1 for g in got if 256 < g[2] <= 512) >= 8, [g[2] for g in got]
+    check_specs(specs, prune=60, max_ed=35)
+
+
 def test_node_with_more_than_32_parents():
     """40 insertion alleles at one position all reconnect on the same reference node (41 parents)."""
     from hiphase_amd.wfa_graph import Variant, WfaJobSpec
