@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <sched.h>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -148,6 +149,86 @@ hipError_t hp_stream_create(hipStream_t* s, int device_id, int priority) {
     for (int i = 0; i < n; ++i)
         if (cu_in_search_partition(i) == (g_cu_partition == 1)) mask[(size_t)i / 32] |= 1u << (i % 32);
     return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
+}
+
+// ---- dev_put / dev_get (hp_common.h) ------------------------------------------------------------------------------------
+// T threads per workgroup: 64 for the small transfers (beside a launch set that holds 92 % of the wavefront slots a CU has one
+// slot free, not four: a job list or a status word must not wait for a hole), 256 from 128 KB on (measured on the A* stage's
+// 1.2 MB of results: 1.2 ms against 6-7 ms with single-wavefront workgroups)
+template <uint32_t T>
+__global__ void __launch_bounds__(T) hp_copy_kernel(uint8_t* dst, const uint8_t* src, size_t n, uint32_t vec) {
+    if (vec) {   // both 16-byte aligned
+        const size_t stride = (size_t)gridDim.x * T * 16u;
+        for (size_t i = ((size_t)blockIdx.x * T + threadIdx.x) * 16u; i + 16u <= n; i += stride) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
+        if (blockIdx.x == 0 && threadIdx.x < (n & 15u)) dst[(n & ~(size_t)15) + threadIdx.x] = src[(n & ~(size_t)15) + threadIdx.x];
+    } else {
+        const size_t stride = (size_t)gridDim.x * T;
+        for (size_t i = (size_t)blockIdx.x * T + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    }
+}
+namespace {
+struct IoArena {
+    PinBuf buf;
+    size_t used = 0;
+    struct Get { void* dst; size_t off, n; };
+    std::vector<Get> gets;
+    // a slice of the arena, or nullptr when it is full while transfers are in flight (the caller then falls back on the runtime's copy)
+    uint8_t* take(size_t n, size_t* off) {
+        if (n > ((size_t)16 << 20)) return nullptr;   // bulk data: the copy engines' job
+        const size_t need = (n + 63) & ~(size_t)63;
+        if (used + need > buf.cap) {
+            if (used != 0) return nullptr;
+            if (buf.reserve(std::max<size_t>(need, (size_t)24 << 20)) != HP_OK) return nullptr;   // (grows only while nothing is in flight)
+        }
+        *off = used; used += need;
+        return buf.p + *off;
+    }
+};
+thread_local IoArena g_io;
+void launch_copy(void* dst, const void* src, size_t n, hipStream_t st) {
+    const uint32_t vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0 ? 1u : 0u;
+    if (n >= ((size_t)128 << 10)) {
+        const size_t per_wg = vec ? 4096 : 256;
+        hipLaunchKernelGGL(hp_copy_kernel<256>, dim3((unsigned)std::min<size_t>(256, (n + per_wg - 1) / per_wg)), dim3(256), 0, st, static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), n, vec);
+    } else {
+        const size_t per_wg = vec ? 1024 : 256;
+        hipLaunchKernelGGL(hp_copy_kernel<64>, dim3((unsigned)std::min<size_t>(512, (n + per_wg - 1) / per_wg)), dim3(64), 0, st, static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), n, vec);
+    }
+}
+}  // namespace
+int dev_copy(void* dst, const void* src, size_t n, hipStream_t st) {
+    if (n == 0) return HP_OK;
+    launch_copy(dst, src, n, st);
+    HP_HIP_CHECK(hipGetLastError());
+    return HP_OK;
+}
+int dev_put(void* d_dst, const void* h_src, size_t n, hipStream_t st) {
+    if (n == 0) return HP_OK;
+    size_t off = 0;
+    uint8_t* a = g_io.take(n, &off);
+    if (!a) { HP_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, st)); return HP_OK; }
+    std::memcpy(a, h_src, n);
+    launch_copy(d_dst, a, n, st);
+    HP_HIP_CHECK(hipGetLastError());
+    return HP_OK;
+}
+int dev_get(void* h_dst, const void* d_src, size_t n, hipStream_t st) {
+    if (n == 0 || !h_dst) return HP_OK;
+    size_t off = 0;
+    uint8_t* a = g_io.take(n, &off);
+    if (!a) { HP_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, st)); return HP_OK; }
+    launch_copy(a, d_src, n, st);
+    HP_HIP_CHECK(hipGetLastError());
+    g_io.gets.push_back({h_dst, off, n});
+    return HP_OK;
+}
+int dev_io_sync(hipStream_t st) {
+    const hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) for (const IoArena::Get& g : g_io.gets) std::memcpy(g.dst, g_io.buf.p + g.off, g.n);
+    g_io.gets.clear();
+    g_io.used = 0;
+    if (e != hipSuccess) { set_error("HIP error %s while waiting for a stream", hipGetErrorString(e)); return HP_ERR_HIP; }
+    return HP_OK;
 }
 
 hipStream_t thread_stream(int device_id) {

@@ -789,6 +789,15 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     return b.release();
 }
 
+// Device -> host for the batch's small result arrays: dev_get (hp_common.h), not hipMemcpy - see there.
+namespace {
+struct Fetch { void* dst; const void* src; size_t n; };
+int fetch_all(hp_batch*, hipStream_t st, std::initializer_list<Fetch> fs) {
+    for (const Fetch& f : fs) { const int rc = dev_get(f.dst, f.src, f.n, st); if (rc != HP_OK) { (void)dev_io_sync(st); return rc; } }
+    return dev_io_sync(st);
+}
+}  // namespace
+
 int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     if (!b) { set_error("null batch"); return HP_ERR_ARG; }
     HP_HIP_CHECK(hipSetDevice(b->device));
@@ -834,7 +843,7 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     HP_HIP_CHECK(hipStreamSynchronize(st));
     float ms_total = 0.f;
     HP_HIP_CHECK(hipEventElapsedTime(&ms_total, b->ev0, b->ev1));
-    HP_HIP_CHECK(hipMemcpy(status.data(), b->d_status.p, status.size() * 4, hipMemcpyDeviceToHost));
+    if ((rc = fetch_all(b, st, {{status.data(), b->d_status.p, status.size() * 4}})) != HP_OK) return rc;
 
     std::vector<uint32_t> retry;
     for (uint32_t i : b->order) if (status[i] == ST_OVERFLOW_MAIN) retry.push_back(i);
@@ -855,7 +864,7 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
         float ms = 0.f;
         HP_HIP_CHECK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
         ms_total += ms;
-        HP_HIP_CHECK(hipMemcpy(status.data(), b->d_status.p, status.size() * 4, hipMemcpyDeviceToHost));
+        if ((rc = fetch_all(b, st, {{status.data(), b->d_status.p, status.size() * 4}})) != HP_OK) return rc;
         std::vector<uint32_t> again;
         for (uint32_t i : retry) if (status[i] == ST_OVERFLOW_MAIN) again.push_back(i);
         retry.swap(again);
@@ -877,12 +886,8 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
 int hp_batch_results(hp_batch* b, uint8_t* h1, uint8_t* h2, hp_phase_stats* stats, hp_work_counters* counters, uint64_t* heuristics) {
     if (!b) { set_error("null batch"); return HP_ERR_ARG; }
     HP_HIP_CHECK(hipSetDevice(b->device));
-    if (h1) HP_HIP_CHECK(hipMemcpy(h1, b->d_h1.p, b->sum_n, hipMemcpyDeviceToHost));
-    if (h2) HP_HIP_CHECK(hipMemcpy(h2, b->d_h2.p, b->sum_n, hipMemcpyDeviceToHost));
-    if (stats) HP_HIP_CHECK(hipMemcpy(stats, b->d_stats.p, b->n_blocks * sizeof(hp_phase_stats), hipMemcpyDeviceToHost));
-    if (counters) HP_HIP_CHECK(hipMemcpy(counters, b->d_counters.p, b->n_blocks * sizeof(hp_work_counters), hipMemcpyDeviceToHost));
-    if (heuristics) HP_HIP_CHECK(hipMemcpy(heuristics, b->d_H.p, b->sum_h * 8, hipMemcpyDeviceToHost));
-    return HP_OK;
+    return fetch_all(b, b->stream, {{h1, b->d_h1.p, b->sum_n}, {h2, b->d_h2.p, b->sum_n}, {stats, b->d_stats.p, b->n_blocks * sizeof(hp_phase_stats)},
+                                    {counters, b->d_counters.p, b->n_blocks * sizeof(hp_work_counters)}, {heuristics, b->d_H.p, b->sum_h * 8}});
 }
 
 int hp_batch_postprocess(hp_batch* b, uint64_t* span_counts, uint8_t* haplotag, uint32_t* first_het) {
@@ -930,14 +935,12 @@ int hp_batch_postprocess(hp_batch* b, uint64_t* span_counts, uint8_t* haplotag, 
     float ms = 0.f;
     HP_HIP_CHECK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
     g_last_kernel_ms = ms;
-    if (span_counts && b->n_junctures) HP_HIP_CHECK(hipMemcpy(span_counts, b->d_span.p, b->n_junctures * 8, hipMemcpyDeviceToHost));
-    if (haplotag || first_het) {
-        std::vector<uint8_t> ht(b->n_rows_packed + 1);
-        std::vector<uint32_t> fh(b->n_rows_packed + 1);
-        if (b->n_rows_packed) {
-            HP_HIP_CHECK(hipMemcpy(ht.data(), b->d_haplotag.p, b->n_rows_packed, hipMemcpyDeviceToHost));
-            HP_HIP_CHECK(hipMemcpy(fh.data(), b->d_first_het.p, b->n_rows_packed * 4, hipMemcpyDeviceToHost));
-        }
+    const bool tags = haplotag || first_het;
+    std::vector<uint8_t> ht(tags ? b->n_rows_packed + 1 : 1);
+    std::vector<uint32_t> fh(tags ? b->n_rows_packed + 1 : 1);
+    if ((rc = fetch_all(b, st, {{span_counts, b->d_span.p, b->n_junctures * 8}, {tags ? ht.data() : nullptr, b->d_haplotag.p, b->n_rows_packed},
+                                {tags ? fh.data() : nullptr, b->d_first_het.p, b->n_rows_packed * 4}})) != HP_OK) return rc;
+    if (tags) {
         // back to the caller's row order; inert rows (start == end) are untagged
         if (haplotag) std::memset(haplotag, 2, b->caller_rows);
         if (first_het) for (uint64_t i = 0; i < b->caller_rows; ++i) first_het[i] = 0xFFFFFFFFu;

@@ -87,6 +87,7 @@ struct hp_blockset {
     hp::W2Session* wfa = nullptr;                // graph-WFA inputs resident on the device (sets of >= HP_WFA2_MIN_JOBS records)
     bool wfa_ready = false;                      // ... laid out and uploaded for the current blocks
     double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // stage times of the last solve
+    double rows_ms[4] = {0, 0, 0, 0};            // of the last blockset_rows: blocks that wait for nothing, blocks that held a late result, of which: their local re-alignment launch; the free blocks' launch
     double late_wait_ms = 0.0;                   // of the last blockset_rows: time spent waiting for the graph-WFA stage's late results
     double prep[4] = {0, 0, 0, 0};               // of the last init: layout ms, fill + upload ms, total ms, bytes host -> device
     uint64_t work[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // hp_blockset_work of the last solve

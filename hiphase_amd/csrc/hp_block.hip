@@ -554,7 +554,9 @@ int hp::blockset_rows(hp_blockset* bs) {
                 }
                 if (pass == 0) {
                     const std::vector<size_t> blocks(order.begin() + (ptrdiff_t)lo, order.begin() + (ptrdiff_t)hi);
+                    const double tl = blk_now_ms();
                     const int r = local_prepass(bs, blocks);
+                    ch.rows_ms[lo == 0 ? 3 : 2] = blk_now_ms() - tl;
                     if (r != HP_OK) return r;
                 }
             }
@@ -563,11 +565,15 @@ int hp::blockset_rows(hp_blockset* bs) {
         };
         // the blocks that wait for nothing first; then the ones that hold a read the second collection / the dense-band pass
         // delivers (that pass has had the first phase to finish in)
+        ch.rows_ms[2] = ch.rows_ms[3] = 0.0;
         if ((rc = phase(0, n_free)) != HP_OK) return rc;
         const double tw = blk_now_ms();
+        ch.rows_ms[0] = tw - t1;
         if (has_wfa && (rc = w2_session_finish(ch.wfa)) != HP_OK) return rc;
         ch.late_wait_ms = blk_now_ms() - tw;
+        const double th = blk_now_ms();
         if ((rc = phase(n_free, order.size())) != HP_OK) return rc;
+        ch.rows_ms[1] = blk_now_ms() - th;
         if (has_wfa) ch.ms[6] = w2_session_span_ms(ch.wfa);
     }
     ch.ms[1] = blk_now_ms() - t1;

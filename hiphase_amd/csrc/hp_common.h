@@ -205,6 +205,20 @@ struct PinBuf {
     }
 };
 
+// Small host <-> device transfers of the side paths (job lists, statuses, result rows: kilobytes to a few megabytes), done by a
+// copy KERNEL on the caller's stream between the device and the calling thread's pinned arena instead of hipMemcpy[Async]:
+// inside a block stream the runtime's copies - its staging of pageable memory, the NULL stream, the copy engines working
+// through the 48 MB pieces of the next set's reads - made a 1 ms step of the A* stage take 25-60 ms every few sets.
+//   dev_put: h_src is copied into the arena at once (the caller may reuse it), the device copy is queued on st
+//   dev_get: queued on st; h_dst is filled by dev_io_sync
+//   dev_io_sync: waits for st, delivers the gets, empties the arena. (Everything a thread queued since its last dev_io_sync
+//   must be on ONE stream.)
+//   dev_copy: the copy kernel alone, between any two device-visible ranges (device memory, pinned host memory)
+int dev_copy(void* dst, const void* src, size_t n, hipStream_t st);
+int dev_put(void* d_dst, const void* h_src, size_t n, hipStream_t st);
+int dev_get(void* h_dst, const void* d_src, size_t n, hipStream_t st);
+int dev_io_sync(hipStream_t st);
+
 // RAII device buffer
 struct DevBuf {
     void* p = nullptr;

@@ -155,9 +155,11 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
     hipStream_t stm = thread_stream(device_id);
     if (!stm) { set_error("stream creation failed"); return HP_ERR_HIP; }
     struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{stm};
-    HP_HIP_CHECK(hipMemcpyAsync(d_pairs.p, dp.data(), n * sizeof(EdPairDev), hipMemcpyHostToDevice, stm));
-    HP_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), n * 4, hipMemcpyHostToDevice, stm));
-    HP_HIP_CHECK(hipMemcpyAsync(d_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice, stm));
+    // (dev_put / dev_get, hp_common.h: not the runtime's copies)
+    struct IoDrain { hipStream_t s; bool armed; ~IoDrain() { if (armed) (void)dev_io_sync(s); } } io{stm, true};
+    if ((rc = dev_put(d_pairs.p, dp.data(), n * sizeof(EdPairDev), stm)) || (rc = dev_put(d_order.p, order.data(), n * 4, stm)) ||
+        (rc = dev_put(d_bytes.p, bytes.data(), bytes.size(), stm)))
+        return rc;
     EdBatchDev B{};
     B.pairs = d_pairs.as<EdPairDev>(); B.order = d_order.as<uint32_t>(); B.n_items = (uint32_t)n;
     B.bytes = d_bytes.as<uint8_t>(); B.out = d_out.as<uint64_t>(); B.scratch = d_scratch.as<uint32_t>();
@@ -169,13 +171,13 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
     hipLaunchKernelGGL(hp_edit_kernel, dim3(slots), dim3(64), (size_t)lds_row_cap * 2 * 4, stm, B);
     HP_HIP_CHECK(hipGetLastError());
     HP_HIP_CHECK(hipEventRecord(e1, stm));
-    HP_HIP_CHECK(hipStreamSynchronize(stm));
+    if ((rc = dev_get(out, d_out.p, n * 8, stm)) != HP_OK) return rc;
+    io.armed = false;
+    if ((rc = dev_io_sync(stm)) != HP_OK) return rc;
     float kms = 0.f;
     HP_HIP_CHECK(hipEventElapsedTime(&kms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     g_last_kernel_ms = kms;
-    HP_HIP_CHECK(hipMemcpyAsync(out, d_out.p, n * 8, hipMemcpyDeviceToHost, stm));
-    HP_HIP_CHECK(hipStreamSynchronize(stm));
     return HP_OK;
 }

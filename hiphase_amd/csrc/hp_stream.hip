@@ -189,9 +189,9 @@ extern "C" int hp_blockstream_wait(hp_blockstream* s, uint64_t ticket, double* s
     if (rc != HP_OK) set_error("%s", slot->err.c_str());
     if (std::getenv("HP_STREAM_TRACE")) {   // the set's way through the stages, ms since the stream's first submit
         if (s->t_zero == 0.0) s->t_zero = slot->t_submit;
-        fprintf(stderr, "[hp] set %llu: submit %.1f | s1 %.1f-%.1f | s2 %.1f-%.1f | s3 %.1f-%.1f (waited %.1f for the late results) | s4 %.1f-%.1f | s5 %.1f-%.1f\n", (unsigned long long)ticket,
+        fprintf(stderr, "[hp] set %llu: submit %.1f | s1 %.1f-%.1f | s2 %.1f-%.1f | s3 %.1f-%.1f (free blocks %.1f [local re-alignment %.1f], waited %.1f for the late results, their blocks %.1f [%.1f]) | s4 %.1f-%.1f | s5 %.1f-%.1f (A* %.1f of which kernels %.1f, post %.1f)\n", (unsigned long long)ticket,
                 slot->t_submit - s->t_zero, slot->t_begin[0] - s->t_zero, slot->t_end[0] - s->t_zero, slot->t_begin[1] - s->t_zero, slot->t_end[1] - s->t_zero,
-                slot->t_begin[2] - s->t_zero, slot->t_end[2] - s->t_zero, slot->bs.late_wait_ms, slot->t_begin[3] - s->t_zero, slot->t_end[3] - s->t_zero, slot->t_begin[4] - s->t_zero, slot->t_end[4] - s->t_zero);
+                slot->t_begin[2] - s->t_zero, slot->t_end[2] - s->t_zero, slot->bs.rows_ms[0], slot->bs.rows_ms[3], slot->bs.late_wait_ms, slot->bs.rows_ms[1], slot->bs.rows_ms[2], slot->t_begin[3] - s->t_zero, slot->t_end[3] - s->t_zero, slot->t_begin[4] - s->t_zero, slot->t_end[4] - s->t_zero, slot->bs.ms[3], slot->bs.ms[7], slot->bs.ms[4]);
     }
     if (stage_ms) {
         const hp_blockset& B = slot->bs;

@@ -451,14 +451,12 @@ int pack_jobs(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, 
 template <class T> int up(DevBuf& buf, StageVec<T>& v, hipStream_t st) {
     int rc = buf.alloc(v.size() * sizeof(T));
     if (rc != HP_OK) return rc;
-    if (v.size()) HP_HIP_CHECK(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
-    return HP_OK;
+    return v.size() ? dev_put(buf.p, v.data(), v.size() * sizeof(T), st) : HP_OK;   // (hp_common.h: small transfers stay off the runtime's copy paths)
 }
 template <class T> int up(DevBuf& buf, const std::vector<T>& v, hipStream_t st) {
     int rc = buf.alloc(v.size() * sizeof(T));
     if (rc != HP_OK) return rc;
-    if (!v.empty()) HP_HIP_CHECK(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
-    return HP_OK;
+    return v.empty() ? HP_OK : dev_put(buf.p, v.data(), v.size() * sizeof(T), st);
 }
 
 // one launch over `ids` with capacity `band`; fills status/score/sets for those jobs
@@ -484,15 +482,15 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     HP_HIP_CHECK(hipGetDevice(&cur_dev));
     hipStream_t stm = thread_stream(cur_dev);
     if (!stm) { set_error("stream creation failed"); return HP_ERR_HIP; }
-    struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{stm};   // (host vectors below are read by async copies)
+    struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)dev_io_sync(s); } } drain{stm};   // (waits for the stream; host vectors below may be read by async copies)
     DevBuf d_jobs, d_order, d_nodes, d_edges, d_seq, d_sets, d_score, d_status;
     if ((rc = up(d_jobs, pk.jobs, stm)) || (rc = up(d_order, order, stm)) || (rc = up(d_nodes, pk.nodes, stm)) || (rc = up(d_edges, pk.edges, stm)) ||
         (rc = d_seq.alloc(pk.seq.size())))
         return rc;
-    if (pk.seq.size()) HP_HIP_CHECK(hipMemcpyAsync(d_seq.p, pk.seq.data(), pk.seq.size(), hipMemcpyHostToDevice, stm));
+    if (pk.seq.size() && (rc = dev_put(d_seq.p, pk.seq.data(), pk.seq.size(), stm)) != HP_OK) return rc;
     if ((rc = d_sets.alloc(pk.out_set_words * 4 + 16)) || (rc = d_score.alloc(n * 8)) || (rc = d_status.alloc(n * 4))) return rc;
     std::vector<int32_t> st0(n, WFA_ST_PENDING);
-    HP_HIP_CHECK(hipMemcpyAsync(d_status.p, st0.data(), n * 4, hipMemcpyHostToDevice, stm));
+    if ((rc = dev_put(d_status.p, st0.data(), n * 4, stm)) != HP_OK) return rc;
     const uint32_t lds_nodes_off = (uint32_t)(((size_t)pk.max_nodes * WFA_NODE_STATE_BYTES + 15) & ~(size_t)15);
     const uint32_t lds_edges_off = lds_nodes_off + pk.max_nodes * 32;
     const size_t lds = big ? 0 : (size_t)lds_edges_off + (size_t)pk.max_edges * sizeof(WfaEdge);   // big graphs: state in HBM, tables read in place
@@ -551,10 +549,8 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     std::vector<int32_t> st(n);
     std::vector<uint64_t> sc(n);
     std::vector<uint32_t> all_sets(pk.out_set_words + 4);
-    HP_HIP_CHECK(hipMemcpyAsync(st.data(), d_status.p, n * 4, hipMemcpyDeviceToHost, stm));
-    HP_HIP_CHECK(hipMemcpyAsync(sc.data(), d_score.p, n * 8, hipMemcpyDeviceToHost, stm));
-    HP_HIP_CHECK(hipMemcpyAsync(all_sets.data(), d_sets.p, pk.out_set_words * 4, hipMemcpyDeviceToHost, stm));
-    if (hipStreamSynchronize(stm) != hipSuccess) { set_error("WFA result download failed"); return HP_ERR_HIP; }
+    if ((rc = dev_get(st.data(), d_status.p, n * 4, stm)) || (rc = dev_get(sc.data(), d_score.p, n * 8, stm)) || (rc = dev_get(all_sets.data(), d_sets.p, pk.out_set_words * 4, stm))) return rc;
+    if (dev_io_sync(stm) != HP_OK) { set_error("WFA result download failed"); return HP_ERR_HIP; }
     for (size_t i = 0; i < n; ++i) {
         status[ids[i]] = st[i];
         score[ids[i]] = sc[i];

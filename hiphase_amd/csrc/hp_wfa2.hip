@@ -121,9 +121,11 @@ void merge_ranges(std::vector<std::pair<const uint8_t*, uint64_t>>& iv, std::vec
     }
 }
 // one region of `max_groups` groups per class in htab / gsets: the class launches run concurrently
-template <int G, int W, bool WIDE = false> uint32_t w2_grid(uint32_t n_items, int n_cu, uint32_t max_groups) {
+// group_jobs > 0: a group leaves after that many jobs, the grid covers the list (at most max_groups groups: the scratch regions)
+template <int G, int W, bool WIDE = false> uint32_t w2_grid(uint32_t n_items, int n_cu, uint32_t max_groups, uint32_t group_jobs = 0) {
     using C = W2Cfg<W, WIDE>;
     constexpr uint32_t NG = 64 / G;
+    if (group_jobs) return std::max<uint32_t>(1u, std::min<uint32_t>((n_items + NG * group_jobs - 1) / (NG * group_jobs), max_groups / NG));
     const size_t lds = (size_t)C::BYTES * NG;
     const size_t lds_alloc = (lds + 1279) / 1280 * 1280;   // gfx950 allocates LDS in 1280-byte granules
     uint32_t per_cu = (uint32_t)std::min<size_t>(32, (160 * 1024) / lds_alloc);
@@ -136,7 +138,7 @@ template <int G, int W, bool WIDE = false> int w2_launch(const W2Batch& B, uint3
     using C = W2Cfg<W, WIDE>;
     constexpr uint32_t NG = 64 / G;
     const size_t lds = (size_t)C::BYTES * NG;
-    const uint32_t grid = w2_grid<G, W, WIDE>(n_items, n_cu, max_groups);
+    const uint32_t grid = w2_grid<G, W, WIDE>(n_items, n_cu, max_groups, B.group_jobs);
     static std::atomic<bool> attr_set{false};   // (per instantiation)
     if (lds > 64 * 1024 || !attr_set.load()) {
         HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_kernel<G, W, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -725,7 +727,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     // the class sizes come back (16 bytes, one short wait): a grid sized for the class fills every workgroup's groups, and
     // an empty class is not launched. Measured: launching each class with the whole batch's grid instead (no wait) cost
     // 3-4 ms of 22 - the W=8 class then spreads its few long jobs one per workgroup and holds LDS for idle groups.
-    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_cnt, d_counts, 16, hipMemcpyDeviceToHost, st));
+    if ((rc = dev_copy(cx.down.p + dn_cnt, d_counts, 16, st)) != HP_OK) return rc;   // (a kernel's store to pinned memory: a copy-engine transfer would queue behind the next set's upload)
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA graph-build kernel failed"); return HP_ERR_HIP; }
     const double t_built = w2_now_ms();
     W2Batch B{};
@@ -763,8 +765,14 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         capg[0] = (uint32_t)std::max<uint64_t>(8, g0 & ~7ull);
         capg[1] = (uint32_t)std::max<uint64_t>(8, (total - g0) & ~7ull);
     }
-    if (cls_cnt[0]) grid_wg[0] = w2_grid<8, 2>(cls_cnt[0], n_cu, capg[0]);
-    if (cls_cnt[1]) grid_wg[1] = gsel == 16 ? w2_grid<16, 4>(cls_cnt[1], n_cu, capg[1]) : gsel == 32 ? w2_grid<32, 4>(cls_cnt[1], n_cu, capg[1]) : w2_grid<8, 4>(cls_cnt[1], n_cu, capg[1]);
+    // HP_WFA2_GROUP_JOBS=k: the two smaller classes' groups leave after k jobs each (more if the list would not fit the scratch
+    // region's groups otherwise) instead of staying until the list is empty
+    const char* gjenv = std::getenv("HP_WFA2_GROUP_JOBS");
+    const uint32_t gj_want = gjenv ? (uint32_t)std::max(0, std::atoi(gjenv)) : 0u;
+    uint32_t gjobs[3] = {0, 0, 0};
+    if (gj_want) for (int k = 0; k < 2; ++k) { gjobs[k] = std::max<uint32_t>(gj_want, (cls_cnt[k] + cx.htab_groups - 1) / cx.htab_groups); capg[k] = cx.htab_groups; }
+    if (cls_cnt[0]) grid_wg[0] = w2_grid<8, 2>(cls_cnt[0], n_cu, capg[0], gjobs[0]);
+    if (cls_cnt[1]) grid_wg[1] = gsel == 16 ? w2_grid<16, 4>(cls_cnt[1], n_cu, capg[1], gjobs[1]) : gsel == 32 ? w2_grid<32, 4>(cls_cnt[1], n_cu, capg[1], gjobs[1]) : w2_grid<8, 4>(cls_cnt[1], n_cu, capg[1], gjobs[1]);
     // (room for the jobs handed over: about 2 % of the two smaller classes on the round-3 bench workload - structural variants put a read's paths far apart; HP_WFA2_ESC_DIV to experiment)
     const char* denv = std::getenv("HP_WFA2_ESC_DIV");
     const uint32_t esc_div = denv ? (uint32_t)std::max(1, std::atoi(denv)) : 64u;
@@ -793,6 +801,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         B.esc_role = !escalate ? 0u : (k == 2 ? 2u : 1u);
         B.esc_producers = grid_wg[0] + grid_wg[1];
         B.esc_limit = cls_cnt[2] + 2u * (items2 - cls_cnt[2]);   // two jobs for each group reserved for hand-overs
+        B.group_jobs = gjobs[k];
         if (k == 0) rc = w2_launch<8, 2>(B, B.n_items, n_cu, capg[0], cs, &groups_used[k]);
         else if (k == 1) rc = gsel == 16 ? w2_launch<16, 4>(B, B.n_items, n_cu, capg[1], cs, &groups_used[k])
                             : gsel == 32 ? w2_launch<32, 4>(B, B.n_items, n_cu, capg[1], cs, &groups_used[k])
@@ -814,12 +823,10 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         HP_HIP_CHECK(hipGetLastError());
     }
     // ---- 5. results --------------------------------------------------------------------------------------------------------
-    HP_HIP_CHECK(hipMemcpyAsync(info_pin, d_info.p, n * sizeof(W2Info), hipMemcpyDeviceToHost, st));
-    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_esc, d_esc, 16, hipMemcpyDeviceToHost, st));
-    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p, d_seen.p, n * 4, hipMemcpyDeviceToHost, st));
-    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_score, d_score.p, n * 8, hipMemcpyDeviceToHost, st));
-    if (allele_tot) HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_al, d_alleles.p, (size_t)allele_tot, hipMemcpyDeviceToHost, st));
-    HP_HIP_CHECK(hipMemcpyAsync(cx.down.p + dn_work, d_work.p, n * 8, hipMemcpyDeviceToHost, st));
+    if ((rc = dev_copy(info_pin, d_info.p, n * sizeof(W2Info), st)) || (rc = dev_copy(cx.down.p + dn_esc, d_esc, 16, st)) || (rc = dev_copy(cx.down.p, d_seen.p, n * 4, st)) ||
+        (rc = dev_copy(cx.down.p + dn_score, d_score.p, n * 8, st)) || (rc = dev_copy(cx.down.p + dn_al, d_alleles.p, (size_t)allele_tot, st)) ||
+        (rc = dev_copy(cx.down.p + dn_work, d_work.p, n * 8, st)))
+        return rc;
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
 #if W2_PROF
     (void)hipDeviceSynchronize();   // flushes the instrumented kernel's printf buffer
@@ -945,14 +952,12 @@ int W2Session::late() {
         int rc;
         std::vector<uint32_t> hoff(h + 1, 0);
         for (size_t k = 0; k < h; ++k) hoff[k + 1] = hoff[k] + dj[ids[k]].n_hets;
-        const size_t up_off = (h * 4 + 15) / 16 * 16, dn_rec = (up_off + (h + 1) * 4 + 63) / 64 * 64, dn_rows = dn_rec + h * sizeof(W2HeldRec);
+        const size_t dn_rec = 0, dn_rows = (h * sizeof(W2HeldRec) + 63) / 64 * 64;
         if ((rc = late_down.reserve(dn_rows + hoff[h] + 64)) != HP_OK) return rc;
         if ((rc = d_held.alloc(h * 4 + 16)) || (rc = d_hoff.alloc((h + 1) * 4 + 16)) || (rc = d_hrec.alloc(h * sizeof(W2HeldRec) + 16)) || (rc = d_hrows.alloc((size_t)hoff[h] + 16))) return rc;
+        struct IoDrain { hipStream_t s; ~IoDrain() { (void)dev_io_sync(s); } } io{s2};   // (dev_put / dev_get, hp_common.h: not the runtime's copies)
         if (h) {
-            std::memcpy(late_down.p, ids.data(), h * 4);
-            std::memcpy(late_down.p + up_off, hoff.data(), (h + 1) * 4);
-            HP_HIP_CHECK(hipMemcpyAsync(d_held.p, late_down.p, h * 4, hipMemcpyHostToDevice, s2));
-            HP_HIP_CHECK(hipMemcpyAsync(d_hoff.p, late_down.p + up_off, (h + 1) * 4, hipMemcpyHostToDevice, s2));
+            if ((rc = dev_put(d_held.p, ids.data(), h * 4, s2)) != HP_OK || (rc = dev_put(d_hoff.p, hoff.data(), (h + 1) * 4, s2)) != HP_OK) return rc;
             W2MapHeldArgs A{};
             W2MapArgs& M = A.M;
             M.jobs = d_jobs.as<W2Job>(); M.info = d_info.as<W2Info>(); M.n_jobs = (uint32_t)n; M.tags = d_tags.as<uint32_t>();
@@ -962,10 +967,10 @@ int W2Session::late() {
             A.rec = d_hrec.as<W2HeldRec>(); A.rows = d_hrows.as<uint8_t>(); A.out_score = d_score.as<uint64_t>();
             hipLaunchKernelGGL(hp_wfa2_map_held_kernel, dim3((unsigned)((h + 63) / 64)), dim3(64), 0, s2, A);
             HP_HIP_CHECK(hipGetLastError());
-            HP_HIP_CHECK(hipMemcpyAsync(late_down.p + dn_rec, d_hrec.p, h * sizeof(W2HeldRec), hipMemcpyDeviceToHost, s2));
-            if (hoff[h]) HP_HIP_CHECK(hipMemcpyAsync(late_down.p + dn_rows, d_hrows.p, hoff[h], hipMemcpyDeviceToHost, s2));
+            if ((rc = dev_get(late_down.p + dn_rec, d_hrec.p, h * sizeof(W2HeldRec), s2)) != HP_OK) return rc;
+            if (hoff[h] && (rc = dev_get(late_down.p + dn_rows, d_hrows.p, hoff[h], s2)) != HP_OK) return rc;
         }
-        if (hipStreamSynchronize(s2) != hipSuccess) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
+        if (dev_io_sync(s2) != HP_OK) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
         const W2HeldRec* rec = reinterpret_cast<const W2HeldRec*>(late_down.p + dn_rec);
         const uint8_t* rows = late_down.p + dn_rows;
         uint64_t s0 = 0, s1 = 0, s2w = 0, s3 = 0;
@@ -1023,7 +1028,7 @@ int W2Session::late() {
             up[ids.size()] = (uint32_t)ids.size();          // n_items_dev
             int rc;
             if ((rc = d_wide.alloc(up.size() * 4)) != HP_OK) return rc;
-            HP_HIP_CHECK(hipMemcpyAsync(d_wide.p, up.data(), up.size() * 4, hipMemcpyHostToDevice, s2));   // (pageable: the call returns once it is staged)
+            if ((rc = dev_put(d_wide.p, up.data(), up.size() * 4, s2)) != HP_OK) return rc;
             // scratch of its own (the session's; wider sets than the class regions of the context), its own tags
             const uint32_t wide_groups = (uint32_t)pend.n_cu * 28u;   // 7 workgroups of 4 groups per CU (LDS)
             const size_t group_dwords = wide16 ? (size_t)W2Cfg<16, true>::GROUP_DWORDS : (size_t)W2Cfg<8, true>::GROUP_DWORDS;
@@ -1089,8 +1094,8 @@ int W2Session::late() {
                 if ((rcb = d_ids.alloc(cand.size() * 4)) || (rcb = d_thr.alloc(cand.size() * 4)) || (rcb = d_exc.alloc(cand.size() + 16))) return rcb;
                 std::vector<uint8_t> exc(cand.size(), 0);
                 struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{bs};
-                HP_HIP_CHECK(hipMemcpyAsync(d_ids.p, cand.data(), cand.size() * 4, hipMemcpyHostToDevice, bs));
-                HP_HIP_CHECK(hipMemcpyAsync(d_thr.p, thr.data(), thr.size() * 4, hipMemcpyHostToDevice, bs));
+                struct IoDrain { hipStream_t s; ~IoDrain() { (void)dev_io_sync(s); } } io{bs};
+                if ((rcb = dev_put(d_ids.p, cand.data(), cand.size() * 4, bs)) != HP_OK || (rcb = dev_put(d_thr.p, thr.data(), thr.size() * 4, bs)) != HP_OK) return rcb;
                 W2BoundArgs BA{};
                 BA.jobs = d_jobs.as<W2Job>(); BA.ids = d_ids.as<uint32_t>(); BA.thresh = d_thr.as<uint32_t>(); BA.n = (uint32_t)cand.size();
                 BA.seq = d_seq.as<uint8_t>(); BA.exceeds = d_exc.as<uint8_t>();
@@ -1106,8 +1111,8 @@ int W2Session::late() {
                 HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_bound_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
                 hipLaunchKernelGGL(hp_wfa2_bound_kernel, dim3((unsigned)cand.size()), dim3(64), lds_total, bs, BA);
                 HP_HIP_CHECK(hipGetLastError());
-                HP_HIP_CHECK(hipMemcpyAsync(exc.data(), d_exc.p, cand.size(), hipMemcpyDeviceToHost, bs));
-                if (hipStreamSynchronize(bs) != hipSuccess) { set_error("WFA bound kernel failed"); return HP_ERR_HIP; }
+                if ((rcb = dev_get(exc.data(), d_exc.p, cand.size(), bs)) != HP_OK) return rcb;
+                if (dev_io_sync(bs) != HP_OK) { set_error("WFA bound kernel failed"); return HP_ERR_HIP; }
                 std::vector<uint32_t> keep, keep_ed, keep_nodes;
                 size_t c = 0, settled = 0;
                 for (size_t k = 0; k < pend.big.size(); ++k) {

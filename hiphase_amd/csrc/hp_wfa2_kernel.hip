@@ -378,6 +378,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W2Cfg<W
 #endif
                     status = W2_ST_PENDING;
                 }
+                if (B.group_jobs != 0u && B.esc_role != 2u && jround >= B.group_jobs) { state = S_DONE; break; }   // this group's share is done
                 // dynamic work queue: the group's first lane pulls the next index. The instruction is written out by hand:
                 // hipcc's atomic optimiser + structuriser turned an atomicAdd under a one-lane branch inside a persistent
                 // loop into a wavefront that never came back (round 1, DESIGN.md bring-up notes)
