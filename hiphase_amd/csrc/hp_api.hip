@@ -87,7 +87,9 @@ int device_cu_count(int device_id) {
 // runtime multiplexes streams onto 4 hardware queues by default, and a kernel that lands behind a persistent graph-WFA kernel
 // in a shared queue starts when that one ends. More hardware queues (read by the runtime when it initialises: this runs when
 // the library is loaded, before its first HIP call; an explicit setting of the caller's wins).
-static const int g_hw_queues_set = [] { return setenv("GPU_MAX_HW_QUEUES", "16", 0); }();
+// (24: a block stream at depth 5 has about twenty streams with work at the same time - six of the alignment stage, one per
+// helper thread of the late results, the A* stream sets, the other stages' own)
+static const int g_hw_queues_set = [] { return setenv("GPU_MAX_HW_QUEUES", "24", 0); }();
 thread_local unsigned g_host_share_div = 0;
 thread_local int g_wfa2_reserve_pct = 0;
 unsigned host_threads(unsigned want) {

@@ -72,12 +72,19 @@ struct W2Context {
             for (int k = 0; k < 2; ++k) if (s.c2x[k]) { (void)hipStreamDestroy(s.c2x[k]); s.c2x[k] = nullptr; }
         }
     }
-    int streams(int part, Streams** out) {   // created on first use in that partition
+    // created on first use in that partition. classes: the five streams of the class launches too - only a thread that runs launch
+    // sets needs them (the layout stage of a block stream does not), and every stream a process creates beyond the runtime's
+    // hardware queues (GPU_MAX_HW_QUEUES) shares a queue with another one: a side path's kernel that lands in a persistent class
+    // kernel's queue waits for that kernel, a class kernel behind a dense-band pass starts late - which streams share depends on
+    // the order the threads got going, and a process where it went wrong ran its launch sets in 42-47 instead of 28 ms
+    int streams(int part, Streams** out, bool classes) {
         Streams& s = ps[part];
         if (!s.stream) HP_HIP_CHECK(hp_stream_create(&s.stream, device));
         // (measured: low stream priority for these persistent kernels makes THEM 40 % slower - 48 vs 35 ms - and nothing else faster)
-        for (int k = 0; k < 3; ++k) if (!s.cstream[k]) HP_HIP_CHECK(hp_stream_create(&s.cstream[k], device));
-        for (int k = 0; k < 2; ++k) if (!s.c2x[k]) HP_HIP_CHECK(hp_stream_create(&s.c2x[k], device));
+        if (classes) {
+            for (int k = 0; k < 3; ++k) if (!s.cstream[k]) HP_HIP_CHECK(hp_stream_create(&s.cstream[k], device));
+            for (int k = 0; k < 2; ++k) if (!s.c2x[k]) HP_HIP_CHECK(hp_stream_create(&s.c2x[k], device));
+        }
         *out = &s;
         return HP_OK;
     }
@@ -356,7 +363,7 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
     W2Context& cx = w2_context(device_id);
     W2Context::Streams* cs_ = nullptr;
-    { const int rc0 = cx.streams(g_cu_partition, &cs_); if (rc0 != HP_OK) return rc0; }
+    { const int rc0 = cx.streams(g_cu_partition, &cs_, false); if (rc0 != HP_OK) return rc0; }
     hipStream_t st = cs_->stream;
     struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{st};
 
@@ -500,7 +507,7 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
     W2Context& cx = w2_context(device_id);
     W2Context::Streams* cs_ = nullptr;
-    { const int rc0 = cx.streams(g_cu_partition, &cs_); if (rc0 != HP_OK) return rc0; }
+    { const int rc0 = cx.streams(g_cu_partition, &cs_, false); if (rc0 != HP_OK) return rc0; }
     hipStream_t st = cs_->stream;
     struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{st};
     int rc;
@@ -637,7 +644,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     const int n_cu = partition_cu_count(device_id);
     W2Context& cx = w2_context(device_id);   // (the calling thread's: need not be the thread that prepared the session)
     W2Context::Streams* cs_ = nullptr;
-    { const int rc0 = cx.streams(g_cu_partition, &cs_); if (rc0 != HP_OK) return rc0; }
+    { const int rc0 = cx.streams(g_cu_partition, &cs_, true); if (rc0 != HP_OK) return rc0; }
     hipStream_t st = cs_->stream;
     int rc = HP_OK;
     // host tables that stream operations read or write; the guard below (destroyed first) drains the stream on every
