@@ -154,18 +154,15 @@ hipError_t hp_stream_create(hipStream_t* s, int device_id, int priority) {
 }
 
 // ---- dev_put / dev_get (hp_common.h) ------------------------------------------------------------------------------------
-// T threads per workgroup: 64 for the small transfers (beside a launch set that holds 92 % of the wavefront slots a CU has one
-// slot free, not four: a job list or a status word must not wait for a hole), 256 from 128 KB on (measured on the A* stage's
-// 1.2 MB of results: 1.2 ms against 6-7 ms with single-wavefront workgroups)
-template <uint32_t T>
-__global__ void __launch_bounds__(T) hp_copy_kernel(uint8_t* dst, const uint8_t* src, size_t n, uint32_t vec) {
+// (single-wavefront workgroups: beside a launch set that holds 92 % of the wavefront slots a CU has one slot free, rarely four)
+__global__ void __launch_bounds__(64) hp_copy_kernel(uint8_t* dst, const uint8_t* src, size_t n, uint32_t vec) {
     if (vec) {   // both 16-byte aligned
-        const size_t stride = (size_t)gridDim.x * T * 16u;
-        for (size_t i = ((size_t)blockIdx.x * T + threadIdx.x) * 16u; i + 16u <= n; i += stride) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
+        const size_t stride = (size_t)gridDim.x * 64u * 16u;
+        for (size_t i = ((size_t)blockIdx.x * 64u + threadIdx.x) * 16u; i + 16u <= n; i += stride) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
         if (blockIdx.x == 0 && threadIdx.x < (n & 15u)) dst[(n & ~(size_t)15) + threadIdx.x] = src[(n & ~(size_t)15) + threadIdx.x];
     } else {
-        const size_t stride = (size_t)gridDim.x * T;
-        for (size_t i = (size_t)blockIdx.x * T + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+        const size_t stride = (size_t)gridDim.x * 64u;
+        for (size_t i = (size_t)blockIdx.x * 64u + threadIdx.x; i < n; i += stride) dst[i] = src[i];
     }
 }
 namespace {
@@ -189,13 +186,8 @@ struct IoArena {
 thread_local IoArena g_io;
 void launch_copy(void* dst, const void* src, size_t n, hipStream_t st) {
     const uint32_t vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0 ? 1u : 0u;
-    if (n >= ((size_t)128 << 10)) {
-        const size_t per_wg = vec ? 4096 : 256;
-        hipLaunchKernelGGL(hp_copy_kernel<256>, dim3((unsigned)std::min<size_t>(256, (n + per_wg - 1) / per_wg)), dim3(256), 0, st, static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), n, vec);
-    } else {
-        const size_t per_wg = vec ? 1024 : 256;
-        hipLaunchKernelGGL(hp_copy_kernel<64>, dim3((unsigned)std::min<size_t>(512, (n + per_wg - 1) / per_wg)), dim3(64), 0, st, static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), n, vec);
-    }
+    const size_t per_wg = vec ? 1024 : 256;   // one 16-byte (or four 1-byte) moves per lane and pass
+    hipLaunchKernelGGL(hp_copy_kernel, dim3((unsigned)std::min<size_t>(2048, (n + per_wg - 1) / per_wg)), dim3(64), 0, st, static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), n, vec);
 }
 }  // namespace
 int dev_copy(void* dst, const void* src, size_t n, hipStream_t st) {

@@ -446,7 +446,7 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     }
     ApplyDev A{};
     A.segs = S.segs; A.seg_offset = T.seg_offset; A.desc = B.desc; A.n_segs = S.n_segs; A.H = B.H;
-    hipLaunchKernelGGL(hp_heur_apply_kernel, dim3(S.n_segs), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(hp_heur_apply_kernel, dim3(S.n_segs), dim3(64), 0, st, A);   // (single-wavefront workgroups, here and below: beside a graph-WFA launch set a CU has one wavefront slot free, rarely four - a 256-thread workgroup of the row kernel waited 18 ms for one)
     HP_HIP_CHECK(hipGetLastError());
     if (std::getenv("HP_DEBUG")) {   // how the seams went (costs a wait: debug only)
         std::vector<int32_t> stt(b->n_blocks);
@@ -761,7 +761,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
         P.rstart = b->d_rstart.as<uint32_t>(); P.rend = b->d_rend.as<uint32_t>(); P.rword = b->d_rword.as<uint32_t>();
         P.rcell = d_rcell.as<uint64_t>(); P.alleles = d_ral.as<uint8_t>(); P.quals = d_rq.as<uint8_t>();
         P.words = b->d_words.as<uint32_t>(); P.n_rows = b->row_block_h.size();
-        hipLaunchKernelGGL(hp_pack_words_kernel, dim3((unsigned)((P.n_rows + 255) / 256)), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(hp_pack_words_kernel, dim3((unsigned)((P.n_rows + 63) / 64)), dim3(64), 0, s, P);
         if (hipGetLastError() != hipSuccess) { set_error("hp_pack_words_kernel launch failed"); return fail(HP_ERR_HIP); }
     }
     // per-position cell tables are derived on the device from the rows just uploaded
@@ -773,7 +773,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
         T.rstart = b->d_rstart.as<uint32_t>(); T.rend = b->d_rend.as<uint32_t>(); T.rword = b->d_rword.as<uint32_t>();
         T.words = b->d_words.as<uint32_t>(); T.ctab = b->d_ctab.as<uint32_t>(); T.n_rows = b->row_block_h.size();
         T.vflags = b->d_vflags.as<uint8_t>();
-        hipLaunchKernelGGL(hp_build_ctab_kernel, dim3((unsigned)((T.n_rows + 3) / 4)), dim3(256), 0, s, T);
+        hipLaunchKernelGGL(hp_build_ctab_kernel, dim3((unsigned)T.n_rows), dim3(64), 0, s, T);
         if (hipGetLastError() != hipSuccess) { set_error("hp_build_ctab_kernel launch failed"); return fail(HP_ERR_HIP); }
     }
     if ((rc = b->d_hapw.alloc(hpk.chunk_total * sizeof(Win) + 16)) != HP_OK) return fail(rc);
@@ -926,9 +926,9 @@ int hp_batch_postprocess(hp_batch* b, uint64_t* span_counts, uint8_t* haplotag, 
     P.junc_block = b->d_junc_block.as<uint32_t>(); P.junc_off = b->d_junc_off.as<uint64_t>(); P.span_counts = b->d_span.as<uint64_t>();
     HP_HIP_CHECK(hipEventRecord(b->ev0, st));
     if (b->n_rows_packed)
-        hipLaunchKernelGGL(hp_post_rows_kernel, dim3((unsigned)((b->n_rows_packed + 255) / 256)), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(hp_post_rows_kernel, dim3((unsigned)((b->n_rows_packed + 63) / 64)), dim3(64), 0, st, P);
     if (b->n_junctures)
-        hipLaunchKernelGGL(hp_post_spans_kernel, dim3((unsigned)((b->n_junctures + 255) / 256)), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(hp_post_spans_kernel, dim3((unsigned)((b->n_junctures + 63) / 64)), dim3(64), 0, st, P);
     HP_HIP_CHECK(hipGetLastError());
     HP_HIP_CHECK(hipEventRecord(b->ev1, st));
     HP_HIP_CHECK(hipStreamSynchronize(st));

@@ -1534,7 +1534,7 @@ struct PackDev {
     uint64_t n_rows;
 };
 __global__ void __launch_bounds__(256) hp_pack_words_kernel(PackDev P) {
-    const uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= P.n_rows) return;
     const uint32_t blk = P.row_block[row];
     const BlockDesc d = P.desc[blk];
@@ -1574,7 +1574,7 @@ struct CtabDev {
     uint64_t n_rows;
 };
 __global__ void __launch_bounds__(256) hp_build_ctab_kernel(CtabDev T) {
-    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t row = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= T.n_rows) return;
     const BlockDesc d = T.desc[T.row_block[row]];
     if (d.cell_off == ~0ull) return;
