@@ -379,7 +379,10 @@ const char* hp_version(void);
  * results are identical either way. 0 turns the merging off (also: HP_COALESCE=0), returns the previous setting. */
 int         hp_set_coalescing(int on);
 /* HIP-event time (ms) of the kernel(s) launched by the last hp_wfa_assign_batch / hp_edit_distance_batch /
- * hp_astar_solve* call made on this thread (diagnostics for bench/roofline reporting). */
+ * hp_astar_solve* call made on this thread (diagnostics for bench/roofline reporting). Only meaningful for calls that ran
+ * on the calling thread: a call merged with other callers' (coalescing on, the default) or handed to the multi-device
+ * dispatcher runs on a service thread and leaves this thread's value as it was - turn coalescing off
+ * (hp_set_coalescing(0)) around a measurement, or use the stage times hp_blockstream_wait / hp_blockset_solve return. */
 double      hp_last_kernel_ms(void);
 /* Appends one block in the .hpbk capture format (hiphase_amd/block_io.py) to `path`: the solver's exact
  * input and - when h1, h2 and stats are given - the output the caller's own astar_solver produced for it. A HiPhase

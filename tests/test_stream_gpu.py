@@ -41,6 +41,21 @@ def test_solve_blocks_on_generated_sets_vs_oracle(fmt, path, monkeypatch):
 
 
 @pytest.mark.timeout(900)
+def test_groups_that_leave_after_a_few_jobs_vs_oracle(monkeypatch):
+    """HP_WFA2_GROUP_JOBS (experiment switch): the two smaller classes' groups take three jobs each and leave, the grid covers
+    the list - workgroups retire all through the launch instead of staying until the queue is empty; same rows"""
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0")
+    monkeypatch.setenv("HP_WFA2_GROUP_JOBS", "3")
+    lib = _ffi.lib()
+    prm = _params(2, 1000, 3, None, True)
+    s = SynthSet(default_spec(lib, total_hets=500, seed=29, seq_format=_ffi.SEQ_BAM4, **KW))
+    exp = oracle_outputs(s, prm)
+    got = s.outputs()
+    _ffi.check(lib.hp_solve_blocks(s.n, s.inputs, C.byref(prm), got.arr, 0))
+    assert [b for b in range(s.n) if not got.equal(exp, b)] == []
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("wide_min", ["1", "0"])
 def test_noisy_sets_take_the_wide_slot_tables_vs_oracle(wide_min, monkeypatch):
     """2 % edit noise: most reads outgrow the slot tables of the two smaller graph-size classes. With HP_WFA2_WIDE_MIN=1 every
