@@ -168,16 +168,17 @@ __global__ void __launch_bounds__(64) hp_copy_kernel(uint8_t* dst, const uint8_t
 namespace {
 struct IoArena {
     PinBuf buf;
-    size_t used = 0;
+    size_t used = 0, wanted = 0;   // wanted: what the transfers since the last sync would have needed (the arena grows after the sync)
     struct Get { void* dst; size_t off, n; };
     std::vector<Get> gets;
     // a slice of the arena, or nullptr when it is full while transfers are in flight (the caller then falls back on the runtime's copy)
     uint8_t* take(size_t n, size_t* off) {
         if (n > ((size_t)16 << 20)) return nullptr;   // bulk data: the copy engines' job
         const size_t need = (n + 63) & ~(size_t)63;
+        wanted += need;
         if (used + need > buf.cap) {
             if (used != 0) return nullptr;
-            if (buf.reserve(std::max<size_t>(need, (size_t)24 << 20)) != HP_OK) return nullptr;   // (grows only while nothing is in flight)
+            if (buf.reserve(std::max<size_t>(need, (size_t)4 << 20)) != HP_OK) return nullptr;   // (grows only while nothing is in flight)
         }
         *off = used; used += need;
         return buf.p + *off;
@@ -221,6 +222,8 @@ int dev_io_sync(hipStream_t st) {
     if (e == hipSuccess) for (const IoArena::Get& g : g_io.gets) std::memcpy(g.dst, g_io.buf.p + g.off, g.n);
     g_io.gets.clear();
     g_io.used = 0;
+    if (g_io.wanted > g_io.buf.cap && g_io.wanted <= ((size_t)64 << 20)) (void)g_io.buf.reserve(g_io.wanted);   // room for the same transfers next time
+    g_io.wanted = 0;
     if (e != hipSuccess) { set_error("HIP error %s while waiting for a stream", hipGetErrorString(e)); return HP_ERR_HIP; }
     return HP_OK;
 }
