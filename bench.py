@@ -229,6 +229,15 @@ def host_cores():
     return max(1, n)
 
 
+def _cgroup_cpu_stat():
+    """cpu.stat of the container's cgroup (v2), {} if there is none: nr_throttled / throttled_usec tell whether a CPU quota froze the process"""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            return {k: int(v) for k, v in (l.split() for l in f if len(l.split()) == 2)}
+    except OSError:
+        return {}
+
+
 def main_path(args, rank, world, local_rank, dist, backend):
     """Whole-path workload, streamed: every timed step submits a DIFFERENT block set to hp_blockstream_submit - its reads,
     references and variants cross PCIe inside the timed region - and `value` = hets of all steps / wall time from the first
@@ -295,10 +304,16 @@ def main_path(args, rank, world, local_rank, dist, backend):
 
     run(0, args.warmup)
     sync_all()
+    cg0, cpu0 = _cgroup_cpu_stat(), time.process_time()
     t0 = time.perf_counter()
     stages, works = run(args.warmup, args.steps)      # every wait returns with that set's results in the caller's buffers
     sync_all()
     elapsed = time.perf_counter() - t0
+    cg1, cpu1 = _cgroup_cpu_stat(), time.process_time()
+    host_cpu = {"process_cpu_s_per_wall_s": (cpu1 - cpu0) / elapsed if elapsed > 0 else None,
+                "cgroup_throttled_periods": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0) if cg0 and cg1 else None,
+                "cgroup_throttled_ms": (cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e3 if cg0 and cg1 else None,
+                "note": "host side of the timed region: CPU seconds the process used per second of wall time, and how often the container's CPU quota froze its threads (cpu.stat)"}
     if dist is not None:
         from hiphase_amd.shard import max_over_ranks
         elapsed = max_over_ranks(dist, elapsed, device="cuda" if backend == "nccl" else "cpu")   # timing only; no block data crosses ranks
@@ -336,7 +351,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
             "value": hets_timed * world / elapsed,
             "unit": "hets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/u64", "data": "synthetic",
+            "dtype": "u8/u64", "data": "synthetic", "host_cpu": host_cpu,
             "config": {"workload": (f"synthetic read-bearing WGS-like block sets, one NEW set per step and GPU through hp_blockstream_* ({args.depth} sets in flight): "
                                     f"{info['blocks']} blocks, {info['hets']} hets (lognormal block sizes, median 15, max {info['max_block_hets']}), "
                                     f"{info['records']} records of {info['read_bases'] / max(1, info['records']):.0f} b mean at {args.coverage}x "
