@@ -139,7 +139,9 @@ int partition_cu_count(int device_id) {
     return g_cu_partition == 1 ? std::max(1, s) : std::max(1, n - s);
 }
 
+std::atomic<int> g_streams_created{0};   // (diagnostics: HP_STREAM_TRACE prints it - streams beyond GPU_MAX_HW_QUEUES share hardware queues)
 hipError_t hp_stream_create(hipStream_t* s, int device_id, int priority) {
+    g_streams_created.fetch_add(1);
     if (g_cu_partition == 0) {
         if (priority == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
         int prio_lo = 0, prio_hi = 0;   // (numerically: the greatest priority is the lowest number)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -54,6 +55,7 @@ int device_cu_count(int device_id);
 extern thread_local int g_cu_partition;
 // priority: +1 the latency-critical kernels of the search, 0 normal, -1 the persistent throughput kernels of the alignment stage
 hipError_t hp_stream_create(hipStream_t* s, int device_id, int priority = 0);
+extern std::atomic<int> g_streams_created;
 int partition_cu_count(int device_id);   // CUs of the calling thread's current partition
 // The calling thread's own stream on `device` in its current CU partition (created on first use, lives as long as the thread):
 // what the small entry points launch on. Nothing in the library uses the NULL stream or hipDeviceSynchronize - a stage of a block
