@@ -22,6 +22,7 @@ namespace hp {
 namespace {
 
 struct HostPack {
+    uint64_t qual_limit = 1ull << 35;  // total quality mass a block may have: the cost field of the packed keys (2^29 with the sub-solver's wide-index keys)
     std::vector<BlockDesc> desc;
     std::vector<uint32_t> vlo, vhi;
     std::vector<uint8_t> vflags;
@@ -176,7 +177,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     // the exact sums are only needed when those coarse bounds do not already clear the limits
     max_row_qual = 255ull * max_row_len;
     total_qual = 255ull * cells;
-    if (max_row_qual * (uint64_t)std::max(max_cov, 1u) >= (1ull << 32) || total_qual >= (1ull << 35)) {
+    if (max_row_qual * (uint64_t)std::max(max_cov, 1u) >= (1ull << 32) || total_qual >= hpk.qual_limit) {
         max_row_qual = 0; total_qual = 0;
         for (uint32_t r : idx) {
             const uint8_t* q = v->quals + v->row_off[r];
@@ -189,7 +190,7 @@ int pack_block(const hp_block_view* v, HostPack& hpk) {
     if (max_row_qual * (uint64_t)std::max(max_cov, 1u) >= (1ull << 32)) {
         set_error("row quality mass x coverage overflows the u32 score accumulators"); return HP_ERR_UNSUPPORTED;
     }
-    if (total_qual >= (1ull << 35)) { set_error("total quality mass of the block exceeds the packed key range (2^35)"); return HP_ERR_UNSUPPORTED; }
+    if (total_qual >= hpk.qual_limit) { set_error("total quality mass of the block exceeds the packed key range (2^%d)", hpk.qual_limit == (1ull << 35) ? 35 : 29); return HP_ERR_UNSUPPORTED; }
     if (idx.size() >= (1u << 28)) { set_error("more than 2^28 rows in one block"); return HP_ERR_UNSUPPORTED; }
     d.max_cov = max_cov;
     d.n_words = (uint32_t)n_words;
@@ -556,6 +557,10 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     if (const char* e = std::getenv("HP_PACK_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
     nt = (unsigned)std::min<size_t>(nt, n_blocks / 8 + 1);
     std::vector<HostPack> parts(nt);
+    // the sub-solver's key: 14 index bits and 36 cost bits, or - for queue sizes whose sub-problems may visit more than 4 095
+    // nodes (--phase-min-queue-size above 39 730 at the default increment) - 20 index bits and 30 cost bits
+    const bool wide_sub_keys = 4ull * ((uint64_t)(p->min_queue_size / 10) + (uint64_t)p->queue_increment * max_seg) + 1ull >= (1ull << 14);
+    if (wide_sub_keys) for (auto& part : parts) part.qual_limit = 1ull << 29;
     // contiguous ranges of blocks with about the same number of cells each (block sizes are heavy-tailed: equal COUNTS left
     // one thread with the 2 000-variant block and its neighbours)
     std::vector<size_t> cut(nt + 1, n_blocks);
@@ -693,7 +698,8 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     prm.cap_chunk_sub = (uint32_t)max_visits + 8;   // at most one ChunkRec per expansion
     prm.sub_heap_in_lds = ((size_t)prm.jcap_sub * 64 * sizeof(uint64_t) <= LDS_SUB_HEAP_MAX_BYTES) ? 1 : 0;
     prm.save_state = (b->tiles == 2) ? 1u : 0u;   // must match the TILES template argument of the launches (see subsolve)
-    if (prm.cap_sub >= (1u << 14)) { set_error("min_queue_size/10 + queue_increment*max_segment_size = %llu visits exceeds the packed sub-key limit (4093)", (unsigned long long)max_visits); return fail(HP_ERR_UNSUPPORTED); }
+    prm.sub_idx_bits = wide_sub_keys ? 20u : 14u;
+    if (4ull * max_visits + 1ull >= (1ull << 20)) { set_error("min_queue_size/10 + queue_increment*max_segment_size = %llu visits exceeds the packed sub-key limit (262 143)", (unsigned long long)max_visits); return fail(HP_ERR_UNSUPPORTED); }
 
     b->order.resize(n_blocks);
     std::iota(b->order.begin(), b->order.end(), 0u);

@@ -108,7 +108,7 @@ struct SolveParams {
     uint32_t sub_heap_in_lds;
     uint32_t max_n_vars;  // largest N among the blocks of this launch (tracker stride)
     uint32_t seg_profile; // 1: launch the s_memtime-instrumented kernel variant (HP_SEG_PROFILE, tuning aid)
-    uint32_t pad1;
+    uint32_t sub_idx_bits; // node-index bits of the sub-solver's packed key: 14, or 20 (wide index: large --phase-min-queue-size)
     uint32_t cap_chunk_sub, cap_chunk_main;  // ChunkRec capacities
     uint32_t save_state;  // 1: the sub-solver pool has room for the per-expansion prefix scores (TILES == 2 launches)
     uint32_t pad3;

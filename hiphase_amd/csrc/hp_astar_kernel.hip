@@ -149,18 +149,21 @@ DEVINL Key wave_min_key(Key k) {  // 128-bit lexicographic minimum (main heap; s
     return Key{bcast64(k.hi), bcast64(k.lo)};
 }
 // Sub-solver key, one u64 (astar_phaser.rs:131-133 restricted to a <= 62-variant sub-problem):
-//   cost:36 | (63 - hets):6 | node_index:14 | depth:6 | rank:2   (host checks cost < 2^36, nodes < 2^14);
+//   cost | (63 - hets):6 | node_index:B | depth:6 | rank:2, B = SolveParams::sub_idx_bits:
+//     B = 14: cost:36 (host checks cost < 2^36, nodes < 2^14) - every --phase-min-queue-size up to 39 730;
+//     B = 20: cost:30 (cost < 2^30, nodes < 2^20) - the wide-index form for larger queues (min_queue_size / 10 +
+//             queue_increment x max_segment_size visits, four nodes each);
 //   rank = creation rank among the siblings; it sits below node_index, which is unique, so it never decides.
-//   key = total << 28 | (63 - hets) << 22 | node_index << 8 | depth << 2 | rank   (built per lane by lane_subkey)
-DEVINL uint64_t subkey_total(uint64_t k) { return k >> 28; }
-DEVINL uint32_t subkey_idx(uint64_t k) { return (uint32_t)(k >> 8) & 0x3FFFu; }
+//   key = total << (B + 14) | (63 - hets) << (B + 8) | node_index << 8 | depth << 2 | rank   (built per lane by lane_subkey)
+DEVINL uint64_t subkey_total(uint64_t k, uint32_t B) { return k >> (B + 14u); }
+DEVINL uint32_t subkey_idx(uint64_t k, uint32_t B) { return (uint32_t)(k >> 8) & ((1u << B) - 1u); }
 DEVINL uint32_t subkey_rank(uint64_t k) { return (uint32_t)k & 3u; }
 DEVINL uint32_t subkey_depth(uint64_t k) { return (uint32_t)(k >> 2) & 63u; }
 // The key of the child in slot `lslot` (a per-lane value) of an expansion, computed entirely on the vector ALU:
 // sumT = the lane's frozen + fluid increment of that slot; slots that do not exist get ~0.
 //   slot 0 = (0,1)  1 = (1,0) [only if the parent's haplotypes differ]  2 = (0,0)  3 = (1,1);  ignored variant: slot 0 only
 DEVINL uint64_t lane_subkey(uint32_t lslot, bool bad, bool has1, uint64_t tbase, uint32_t sumT, uint32_t hets_hom,
-                            uint32_t first_idx, uint32_t depth) {
+                            uint32_t first_idx, uint32_t depth, uint32_t B) {
     // per-slot predicates as arithmetic on the lane's slot number and three uniform words (no per-lane-set masks,
     // which the compiler would hoist out of the loop and then spill)
     const uint32_t valid_set = bad ? 0x1u : (has1 ? 0xFu : 0xDu);      // bit s: slot s exists
@@ -168,8 +171,8 @@ DEVINL uint64_t lane_subkey(uint32_t lslot, bool bad, bool has1, uint64_t tbase,
     const uint32_t lrank = lslot - ((lslot >> 1) & no10);              // creation rank among the siblings
     const uint32_t lhets = hets_hom + ((~lslot >> 1) & real);          // slots 0/1 of a real expansion: one more het
     const uint64_t total = tbase + sumT;
-    const uint32_t low = ((63u - lhets) << 22) | ((first_idx + lrank) << 8) | (depth << 2) | lrank;   // < 2^28
-    const uint64_t k = (total << 28) | low;
+    const uint64_t low = ((uint64_t)(63u - lhets) << (B + 8u)) | ((first_idx + lrank) << 8) | (depth << 2) | lrank;   // < 2^(B + 14)
+    const uint64_t k = (total << (B + 14u)) | low;
     return ((valid_set >> lslot) & 1u) ? k : ~0ull;
 }
 
@@ -833,7 +836,8 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         // the two pipes in this loop (measured: an extra scalar instruction per pop costs four times an extra vector
         // one), and lane l already holds the cost sum of slot s(l) = ((l >> 1) & 1) * 2 + ((l >> 3) & 1).
         const uint32_t lslot = ((lane_id() >> 1) & 1u) * 2u + ((lane_id() >> 3) & 1u);
-        const uint64_t kl = lane_subkey(lslot, kd.bad, kd.has1, kd.tbase, kd.tvec, kd.hets_hom, next_idx, kd.depth);
+        const uint32_t KB = prm.sub_idx_bits;
+        const uint64_t kl = lane_subkey(lslot, kd.bad, kd.has1, kd.tbase, kd.tvec, kd.hets_hom, next_idx, kd.depth, KB);
         const uint64_t kbest = bcast64(lane_min4(kl));
         // the family's next key should kbest leave it: its smallest other child (~0: none)
         const uint64_t ksecond = lane_min4(kl == kbest ? ~0ull : kl);   // stays in vector registers (uniform value)
@@ -848,7 +852,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
             if (__any(ksecond != ~0ull)) heap.deal(ksecond);
             // slots (a1,a2): 0 = (0,1), 1 = (1,0), 2 = (0,0), 3 = (1,1); the kept child's own cell joins the prefix scores
             cur.frozen = kd.pfrozen + (uint32_t)__builtin_amdgcn_readlane((int)kd.gvec, (int)best_lane);   // best_lane is even
-            cur.total = subkey_total(kbest);
+            cur.total = subkey_total(kbest, KB);
             if (best == 0u) { kid_into_cur<0>(kd, next_idx, cur); fast_apply<TILES>(fs, cc, false, true); }
             else if (best == 1u) { kid_into_cur<1>(kd, next_idx, cur); fast_apply<TILES>(fs, cc, true, false); }
             else if (best == 2u) { kid_into_cur<2>(kd, next_idx, cur); fast_apply<TILES>(fs, cc, false, false); }
@@ -858,17 +862,17 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
             // the queue's minimum t is a child of an earlier expansion: rebuild it from its family record, and put
             // that family's next child (the smallest sibling key above t) back in the queue together with kbest
             const uint64_t t = bcast64(heap.top);
-            const uint32_t fbase = subkey_idx(t) - subkey_rank(t);
+            const uint32_t fbase = subkey_idx(t, KB) - subkey_rank(t);
             const FamRec fr = load_fam(pl.fam + fbase);
             const uint64_t hn_t = ringH_get(off + subkey_depth(t));
             const bool fbad = (fr.depth_flags >> 30) & 1u, fhas1 = (fr.depth_flags >> 31) & 1u;
             const uint32_t fdepth = (fr.depth_flags & 0xFFFFFFu) + 1u;
             // the siblings' keys, again one slot per lane group: each lane fetches its slot's cost sum from the record
             const uint32_t ftot = reinterpret_cast<const uint32_t*>(pl.fam + fbase)[16 + lslot];   // FamRec::tot[lslot]
-            const uint64_t sk = lane_subkey(lslot, fbad, fhas1, fr.frozen + hn_t, ftot, fr.hets, fbase, fdepth);
+            const uint64_t sk = lane_subkey(lslot, fbad, fhas1, fr.frozen + hn_t, ftot, fr.hets, fbase, fdepth, KB);
             const uint64_t knext = lane_min4(sk > t ? sk : ~0ull);
             heap.replace_push(kbest, knext);
-            cur = cur_from_fam(fr, subkey_rank(t), subkey_total(t), subkey_idx(t), off);
+            cur = cur_from_fam(fr, subkey_rank(t), subkey_total(t, KB), subkey_idx(t, KB), off);
             // resume the incremental state: the family's saved prefix scores + the popped child's own cell at the
             // parent's variant (unless that variant has colliding rows: then the plane words rebuild it)
             const uint32_t pF = off + fdepth - 1u;

@@ -353,3 +353,12 @@ def test_large_queue_parameters_use_the_hbm_sub_heap():
     the queue in HBM scratch (and TILES = 2) must give the same bits."""
     blocks = [synth_block(n, c, 12, e, 0.02, 8600 + i)[0] for i, (n, c, e) in enumerate([(60, 20, 0.05), (90, 70, 0.1), (40, 10, 0.3)])]
     check_batch(blocks, min_queue_size=35000, queue_increment=3)
+
+
+@pytest.mark.parametrize("minq", [50000, 400000])
+def test_queue_sizes_beyond_39730_take_the_wide_index_keys(minq):
+    """--phase-min-queue-size above 39 730 (min_queue_size / 10 + queue_increment x 40 visits, four nodes each, no longer fit
+    the 14 index bits of the sub-solver's packed key): the key form with 20 index bits and 30 cost bits, same bits out.
+    Noisy blocks: their sub-problems actually fill the larger queue."""
+    blocks = [synth_block(n, c, 12, e, 0.02, 8700 + i)[0] for i, (n, c, e) in enumerate([(60, 20, 0.05), (120, 40, 0.15), (45, 12, 0.3), (200, 30, 0.08)])]
+    check_batch(blocks, min_queue_size=minq, queue_increment=3)
