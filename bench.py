@@ -254,7 +254,11 @@ def main_path(args, rank, world, local_rank, dist, backend):
         capture = Capture(args.replay)
         if world > 1:
             raise SystemExit("--replay of a .hpbr capture runs on one GPU (the multi-GPU replay is hp_solve_blocks(device_id=-1))")
-    n_sets = 1 if capture else max(1, min(args.steps + args.warmup, args.distinct_sets))
+    # (N ranks on one host: 1.3 GB of host memory per generated set and rank - fewer distinct sets each, never fewer than the stream
+    # holds in flight plus one; a set that comes round again still crosses PCIe)
+    n_local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    per_rank_sets = args.distinct_sets if n_local == 1 else max(args.depth + 1, min(args.distinct_sets, 48 // n_local))
+    n_sets = 1 if capture else max(1, min(args.steps + args.warmup, per_rank_sets))
     gen_threads = max(2, min(32, host_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     t_gen = time.perf_counter()
     sets = [capture] if capture else []
