@@ -434,8 +434,8 @@ def main_path(args, rank, world, local_rank, dist, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=6, help="untimed steps first (path workload: at least depth + 1, so that every slot of the stream has sized its buffers)")
     ap.add_argument("--workload", choices=["path", "c2", "wgs"], default="path")
     ap.add_argument("--total-hets", type=int, default=60000, help="path workload: hets per GPU and step")
     ap.add_argument("--max-block-hets", type=int, default=4165, help="largest block HiPhase reports on HG002 (docs/user_guide.md:258)")
