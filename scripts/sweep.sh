@@ -3,8 +3,8 @@
 OUT=$1; KEY=$2; shift 2
 for v in "$@"; do
   for r in 1 2; do
-    if [ "$KEY" = "--depth" ]; then L=$(python bench.py --no-cpu --no-resident --steps 20 --warmup 5 --depth $v 2>/dev/null | tail -1)
-    else L=$(env $KEY=$v python bench.py --no-cpu --no-resident --steps 20 --warmup 5 2>/dev/null | tail -1); fi
+    if [ "$KEY" = "--depth" ]; then L=$(python bench.py --no-cpu --no-resident --steps 20 --warmup 6 --depth $v 2>/dev/null | tail -1)
+    else L=$(env $KEY=$v python bench.py --no-cpu --no-resident --steps 20 --warmup 6 2>/dev/null | tail -1); fi
     echo "$L" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
