@@ -196,7 +196,7 @@ struct PinBuf {
         if (n <= cap) return HP_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
-        const size_t want = n + n / 2 + 4096;   // (growing pinned memory synchronises the device too: leave room)
+        const size_t want = std::max<size_t>(n + n / 2 + 4096, (size_t)1 << 20);   // (growing pinned memory synchronises the device too: leave room)
         if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
             p = nullptr;
             set_error("hipHostMalloc(%zu) failed", want);

@@ -284,7 +284,10 @@ struct StageBuf {
         if (n > cap) {
             if (p) (void)hipHostFree(p);
             p = nullptr; cap = 0;
-            const size_t want = n + n / 4 + 4096;
+            // (pinning and unpinning host memory waits for the whole device - inside a block stream that is the other stages' persistent
+            // kernels: a leftover pass whose tables outgrew its thread's staging by a few per cent stood still for 50-80 ms.
+            // Hence the floor and the headroom: the passes of a stream's late results never grow it after their first.)
+            const size_t want = std::max<size_t>(n + n / 2 + 4096, (size_t)8 << 20);
             if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
                 p = nullptr;
                 set_error("hipHostMalloc(%zu) failed", want);
