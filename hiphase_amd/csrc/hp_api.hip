@@ -55,6 +55,7 @@ void* dev_cache_get(size_t bytes, size_t* got, int* dev_out) {
         }
     }
     void* p = nullptr;
+    g_device_syncing_allocs.fetch_add(1);
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {   // give the cache back and try once more
         std::vector<void*> drop;
@@ -139,6 +140,7 @@ int partition_cu_count(int device_id) {
     return g_cu_partition == 1 ? std::max(1, s) : std::max(1, n - s);
 }
 
+std::atomic<int> g_device_syncing_allocs{0};   // (diagnostics, HP_STREAM_TRACE: hipMalloc / hipHostMalloc calls - each waits for the whole device)
 std::atomic<int> g_streams_created{0};   // (diagnostics: HP_STREAM_TRACE prints it - streams beyond GPU_MAX_HW_QUEUES share hardware queues)
 hipError_t hp_stream_create(hipStream_t* s, int device_id, int priority) {
     g_streams_created.fetch_add(1);

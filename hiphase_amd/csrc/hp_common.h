@@ -56,6 +56,7 @@ extern thread_local int g_cu_partition;
 // priority: +1 the latency-critical kernels of the search, 0 normal, -1 the persistent throughput kernels of the alignment stage
 hipError_t hp_stream_create(hipStream_t* s, int device_id, int priority = 0);
 extern std::atomic<int> g_streams_created;
+extern std::atomic<int> g_device_syncing_allocs;
 int partition_cu_count(int device_id);   // CUs of the calling thread's current partition
 // The calling thread's own stream on `device` in its current CU partition (created on first use, lives as long as the thread):
 // what the small entry points launch on. Nothing in the library uses the NULL stream or hipDeviceSynchronize - a stage of a block
@@ -197,6 +198,7 @@ struct PinBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
         const size_t want = std::max<size_t>(n + n / 2 + 4096, (size_t)1 << 20);   // (growing pinned memory synchronises the device too: leave room)
+        g_device_syncing_allocs.fetch_add(1);
         if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
             p = nullptr;
             set_error("hipHostMalloc(%zu) failed", want);

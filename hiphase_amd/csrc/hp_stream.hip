@@ -223,7 +223,7 @@ extern "C" void hp_blockstream_destroy(hp_blockstream* s) {
         s->quit = true;
         s->cv.notify_all();
     }
-    if (std::getenv("HP_STREAM_TRACE")) fprintf(stderr, "[hp] streams created by the library so far: %d (GPU_MAX_HW_QUEUES=%s)\n", hp::g_streams_created.load(), std::getenv("GPU_MAX_HW_QUEUES") ? std::getenv("GPU_MAX_HW_QUEUES") : "unset");
+    if (std::getenv("HP_STREAM_TRACE")) fprintf(stderr, "[hp] device-wide waits for memory so far (hipMalloc / hipHostMalloc calls): %d\n", hp::g_device_syncing_allocs.load()), fprintf(stderr, "[hp] streams created by the library so far: %d (GPU_MAX_HW_QUEUES=%s)\n", hp::g_streams_created.load(), std::getenv("GPU_MAX_HW_QUEUES") ? std::getenv("GPU_MAX_HW_QUEUES") : "unset");
     for (auto& t : s->th) if (t.joinable()) t.join();
     delete s;
 }

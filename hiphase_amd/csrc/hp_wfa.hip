@@ -288,6 +288,7 @@ struct StageBuf {
             // kernels: a leftover pass whose tables outgrew its thread's staging by a few per cent stood still for 50-80 ms.
             // Hence the floor and the headroom: the passes of a stream's late results never grow it after their first.)
             const size_t want = std::max<size_t>(n + n / 2 + 4096, (size_t)8 << 20);
+            g_device_syncing_allocs.fetch_add(1);
             if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
                 p = nullptr;
                 set_error("hipHostMalloc(%zu) failed", want);
