@@ -3,8 +3,8 @@
 OUT=$1; shift
 for r in 1 2; do
   for v in "$@"; do
-    if [ "$v" = main ]; then L=$(python bench.py --no-cpu --steps 10 --warmup 3 2>/dev/null | tail -1)
-    else L=$(HP_LIB=hiphase_amd/libhiphase_gpu_$v.so python bench.py --no-cpu --steps 10 --warmup 3 2>/dev/null | tail -1); fi
+    if [ "$v" = main ]; then L=$(python bench.py --no-cpu --steps 20 --warmup 6 2>/dev/null | tail -1)
+    else L=$(HP_LIB=hiphase_amd/libhiphase_gpu_$v.so python bench.py --no-cpu --steps 20 --warmup 6 2>/dev/null | tail -1); fi
     echo "$L" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
