@@ -241,8 +241,7 @@ inline double wall_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); retu
 template <class T> int upload(DevBuf& buf, const std::vector<T>& v, hipStream_t s) {
     int rc = buf.alloc(v.size() * sizeof(T));
     if (rc != HP_OK) return rc;
-    if (!v.empty()) HP_HIP_CHECK(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
-    return HP_OK;
+    return v.empty() ? HP_OK : dev_put(buf.p, v.data(), v.size() * sizeof(T), s);   // (hp_common.h: not the copy engines, which are busy with the next set's reads; the caller ends with dev_io_sync on s, or on a stream that waits for s)
 }
 
 }  // namespace
@@ -752,10 +751,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
             put(8, o.rq, q.raw_quals.data(), q.raw_quals.size());
         });
         for (int k = 0; k < 9; ++k)
-            if (sz[k] && hipMemcpyAsync(dst9[k], P + off9[k], sz[k], hipMemcpyHostToDevice, s) != hipSuccess) {
-                set_error("upload failed: %s", hipGetErrorString(hipGetLastError()));
-                return fail(HP_ERR_HIP);
-            }
+            if (sz[k] && dev_copy(dst9[k], P + off9[k], sz[k], s) != HP_OK) return fail(HP_ERR_HIP);   // (P is pinned: the copy kernel reads it in place)
         }
     }
     if ((rc = upload(b->d_row_block, b->row_block_h, s)) != HP_OK) return fail(rc);
@@ -789,7 +785,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     if ((rc = b->d_stats.alloc(n_blocks * sizeof(hp_phase_stats))) != HP_OK) return fail(rc);
     if ((rc = b->d_counters.alloc(n_blocks * sizeof(hp_work_counters))) != HP_OK) return fail(rc);
     if ((rc = b->d_status.alloc(n_blocks * sizeof(int32_t))) != HP_OK) return fail(rc);
-    if (hipStreamSynchronize(s) != hipSuccess) { set_error("upload failed"); return fail(HP_ERR_HIP); }
+    if (dev_io_sync(s) != HP_OK) { set_error("upload failed"); return fail(HP_ERR_HIP); }
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] hp_batch_create total %.1f ms\n", wall_ms() - t_pack0); fflush(stderr); }
     if (status) *status = HP_OK;
     return b.release();
@@ -809,7 +805,7 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     HP_HIP_CHECK(hipSetDevice(b->device));
     hipStream_t st = stream ? (hipStream_t)stream : b->stream;
     std::vector<int32_t> status(b->n_blocks, ST_PENDING);
-    HP_HIP_CHECK(hipMemcpyAsync(b->d_status.p, status.data(), status.size() * 4, hipMemcpyHostToDevice, st));
+    { const int rc0 = dev_put(b->d_status.p, status.data(), status.size() * 4, st); if (rc0 != HP_OK) return rc0; }
     HP_HIP_CHECK(hipEventRecord(b->ev0, st));
 
     // pass 0: every block, scratch sized generously above the clean-data bound (<= 4N+1 nodes); blocks whose
