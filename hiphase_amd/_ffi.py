@@ -254,7 +254,19 @@ class BlockOutput(C.Structure):
         ("n_edit_distances", C.c_uint64),
         ("status", C.c_int32),
         ("reserved", C.c_uint32),
+        # the rest of the loader's ReadStats (writers/phase_stats.rs:12-33), summed over every record before the collapse
+        ("num_alleles", C.c_uint64),
+        ("exact_matches", C.c_uint64 * N_VARIANT_TYPES),
+        ("inexact_matches", C.c_uint64 * N_VARIANT_TYPES),
+        ("failed_matches", C.c_uint64 * N_VARIANT_TYPES),
+        ("allele0_matches", C.c_uint64 * N_VARIANT_TYPES),
+        ("allele1_matches", C.c_uint64 * N_VARIANT_TYPES),
     ]
+
+    def read_stats(self):
+        """(num_alleles, exact, inexact, failed, allele0, allele1) as plain tuples"""
+        return (int(self.num_alleles), tuple(self.exact_matches), tuple(self.inexact_matches), tuple(self.failed_matches),
+                tuple(self.allele0_matches), tuple(self.allele1_matches))
 
 
 class SynthReadsSpec(C.Structure):

@@ -38,6 +38,7 @@ class BlockResult:
     global_aligned: int = 0
     local_aligned: int = 0
     edit_distances: list = field(default_factory=list)
+    read_stats: tuple = ()       # (num_alleles, exact, inexact, failed, allele0, allele1 _matches[11]): the rest of ReadStats
     status: int = 0             # 0, or 2 = HP_BLOCK_UNSUPPORTED (outside the device solver's limits: the caller solves it)
 
 
@@ -172,7 +173,7 @@ class _Outputs:
                     tags[q] = (int(d["fh"][k]), int(d["ht"][k]))
             out.append(BlockResult(d["h1"].copy(), d["h2"].copy(), O.stats.as_tuple(), d["span"][:max(n - 1, 0)].copy(), segs, tags,
                                    int(O.num_reads), int(O.skipped_reads), int(O.global_aligned), int(O.local_aligned),
-                                   d["ed"][:O.n_edit_distances].tolist(), int(O.status)))
+                                   d["ed"][:O.n_edit_distances].tolist(), O.read_stats(), int(O.status)))
         return out
 
 

@@ -41,6 +41,7 @@ struct BlockState {         // per block, rebuilt by every solve
     std::vector<uint8_t> seg_solver;
     std::vector<uint32_t> solver_rows;    // indices into segs
     uint64_t num_reads = 0, skipped_reads = 0, global_aligned = 0, local_aligned = 0;
+    hp_read_stats rs{};                   // joint_stats += read_stats over every record (num_alleles and the five per-type arrays are used)
     std::vector<uint64_t> edit_distances;
     // the solver matrix as the C ABI takes it
     std::vector<uint32_t> read_start, read_end;
@@ -57,6 +58,7 @@ struct BlockState {         // per block, rebuilt by every solve
     void reset() {   // keeps every capacity
         segs.clear(); seg_qname.clear(); seg_solver.clear(); solver_rows.clear();
         num_reads = skipped_reads = global_aligned = local_aligned = 0;
+        rs = hp_read_stats{};
         edit_distances.clear(); read_start.clear(); read_end.clear(); row_off.clear();
         alleles_2bit.clear(); quals.clear(); var_flags.clear();
         wfa_unsupported = false;

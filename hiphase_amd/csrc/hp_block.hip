@@ -93,6 +93,14 @@ bool segment_collapse(Arena& ar, const std::vector<const Segment*>& rs, uint32_t
     out = segment_new(ar, alleles.data(), quals.data(), min_start, (uint32_t)alleles.size(), n_hets);
     return true;
 }
+// joint_stats += read_stats (writers/phase_stats.rs:107-121) for the fields the per-record counts feed
+void add_read_stats(hp_read_stats& acc, const hp_read_stats& r) {
+    acc.num_alleles += r.num_alleles;
+    for (int t = 0; t < HP_N_VARIANT_TYPES; ++t) {
+        acc.exact_matches[t] += r.exact_matches[t]; acc.inexact_matches[t] += r.inexact_matches[t]; acc.failed_matches[t] += r.failed_matches[t];
+        acc.allele0_matches[t] += r.allele0_matches[t]; acc.allele1_matches[t] += r.allele1_matches[t];
+    }
+}
 uint32_t seg_num_set(const Segment& s) {
     uint32_t n = 0;
     for (uint32_t i = 0; i < s.end - s.start; ++i) n += s.alleles[i] < HP_ALLELE_AMBIGUOUS;
@@ -345,6 +353,7 @@ int assemble_block(hp_blockset* bs, size_t b) {
         if (!P.global_realignment) {
             const size_t s = (size_t)local_slot[idx];
             skipped = loc_stats[s].skipped_reads == 1;
+            add_read_stats(S.rs, loc_stats[s]);   // read_parsing.rs:88 (skipped or not)
             if (!skipped) seg = segment_new(S.arena, loc_alleles.data() + s * N, loc_quals.data() + s * N, 0, N, N);
             local_aligned = 1.0;
         } else {
@@ -358,6 +367,7 @@ int assemble_block(hp_blockset* bs, size_t b) {
                 }
                 const size_t s = (size_t)local_slot[idx];
                 skipped = loc_stats[s].skipped_reads == 1;
+                add_read_stats(S.rs, loc_stats[s]);   // read_parsing.rs:607 with local_realignment's stats
                 if (!skipped) seg = segment_new(S.arena, loc_alleles.data() + s * N, loc_quals.data() + s * N, 0, N, N);
                 wfa_score = P.max_edit_distance;   // :559 / :573: the distance carried by the error is max_edit_distance
                 local_aligned = 1.0;
@@ -367,6 +377,17 @@ int assemble_block(hp_blockset* bs, size_t b) {
                 // ReadSegment::new on the window [first, last): clip to the set alleles, then read_parsing.rs:803-835 for the
                 // qualities of what is left (2 x base quality for 0/1 alleles, else 0)
                 uint32_t f0 = n, l0 = n;
+                // the record's ReadStats (read_parsing.rs:805-850): per het of the overlap range - Ambiguous: failed; 0 / 1: inexact
+                // (`exact_allele` is false upstream) + allele0 / allele1 + num_alleles
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t vt = B.het_types[m.first + i];
+                    if (a[i] == HP_ALLELE_AMBIGUOUS) S.rs.failed_matches[vt] += 1;
+                    else if (a[i] < HP_ALLELE_AMBIGUOUS) {
+                        S.rs.inexact_matches[vt] += 1;
+                        if (a[i] == HP_ALLELE_REFERENCE) S.rs.allele0_matches[vt] += 1; else S.rs.allele1_matches[vt] += 1;
+                        S.rs.num_alleles += 1;
+                    }
+                }
                 for (uint32_t i = 0; i < n; ++i) if (a[i] < HP_ALLELE_AMBIGUOUS) { f0 = i; break; }
                 for (uint32_t i = n; i-- > 0;) if (a[i] < HP_ALLELE_AMBIGUOUS) { l0 = i + 1; break; }
                 if (f0 == n) { seg.start = seg.end = N; }
@@ -703,6 +724,11 @@ int hp::blockset_solve(hp_blockset* bs, hp_block_output* out) {
         O.n_segments = (uint32_t)S.segs.size();
         O.n_solver = (uint32_t)S.solver_rows.size();
         O.num_reads = S.num_reads; O.skipped_reads = S.skipped_reads; O.global_aligned = S.global_aligned; O.local_aligned = S.local_aligned;
+        O.num_alleles = S.rs.num_alleles;
+        for (int t = 0; t < HP_N_VARIANT_TYPES; ++t) {
+            O.exact_matches[t] = S.rs.exact_matches[t]; O.inexact_matches[t] = S.rs.inexact_matches[t]; O.failed_matches[t] = S.rs.failed_matches[t];
+            O.allele0_matches[t] = S.rs.allele0_matches[t]; O.allele1_matches[t] = S.rs.allele1_matches[t];
+        }
         O.n_edit_distances = S.edit_distances.size();
         if (O.edit_distances && !S.edit_distances.empty()) std::memcpy(O.edit_distances, S.edit_distances.data(), S.edit_distances.size() * 8);
         uint64_t cells = 0;

@@ -8,7 +8,7 @@
 // block is compared with what the real binary answered.
 //
 // Layout (little endian; one record per block, records concatenated; every array padded with zeros to 8 bytes):
-//   "HPBR0001"
+//   "HPBR0002" ("HPBR0001": the same without the 56 ReadStats words of the expected section; still read)
 //   u64[16]: block_index, n_hets, n_homs, n_records, n_qnames, seq_format, ref_lo (chromosome coordinate of the first
 //            reference byte stored), ref_len, has_local_hets, has_expected, bytes of the variant section, bytes of the record
 //            section, bytes of the expected section, reserved x 3
@@ -23,6 +23,7 @@
 //            if has_local: i64 pos, u32 n_cigar, u32 seq_len, u32 seq_format, u32 0, cigar u32[n_cigar], seq bytes, qual bytes
 //   expected (if has_expected): status i32 + pad, h1, h2 u8[n_hets], hp_phase_stats u64[7], span_counts u64[n_hets - 1],
 //            n_segments, n_solver u32, num_reads, skipped_reads, global_aligned, local_aligned, n_edit_distances u64,
+//            (0002:) num_alleles, exact / inexact / failed / allele0 / allele1 _matches u64[11] each,
 //            edit_distances, seg_qname, seg_start, seg_end u32[n_segments], seg_solver, seg_haplotag u8[n_segments],
 //            seg_first_het u32[n_segments], seg_row_off u64[n_segments + 1], seg_alleles, seg_quals u8[cells]
 // Host-only; compiled into libhiphase_gpu.so and the test oracle alike.
@@ -107,6 +108,9 @@ extern "C" int hp_hpbr_append(const char* path, const hp_block_input* B, const h
         exp.val<uint32_t>(E->n_segments); exp.val<uint32_t>(E->n_solver);
         exp.val<uint64_t>(E->num_reads); exp.val<uint64_t>(E->skipped_reads); exp.val<uint64_t>(E->global_aligned); exp.val<uint64_t>(E->local_aligned);
         exp.val<uint64_t>(E->n_edit_distances);
+        exp.val<uint64_t>(E->num_alleles);
+        exp.raw(E->exact_matches, sizeof E->exact_matches); exp.raw(E->inexact_matches, sizeof E->inexact_matches); exp.raw(E->failed_matches, sizeof E->failed_matches);
+        exp.raw(E->allele0_matches, sizeof E->allele0_matches); exp.raw(E->allele1_matches, sizeof E->allele1_matches);
         exp.arr(E->edit_distances, E->edit_distances ? (size_t)E->n_edit_distances * 8 : 0);
         if (!E->seg_qname || !E->seg_start || !E->seg_end || !E->seg_solver || !E->seg_haplotag || !E->seg_first_het || !E->seg_row_off || !E->seg_alleles || !E->seg_quals ||
             !E->h1 || !E->h2 || !E->span_counts || !E->edit_distances) { g_cap_err = "expected output with a null array"; return HP_ERR_ARG; }
@@ -119,7 +123,7 @@ extern "C" int hp_hpbr_append(const char* path, const hp_block_input* B, const h
     if (!f) { g_cap_err = std::string("cannot open ") + path + " for appending"; return HP_ERR_ARG; }
     const uint64_t hdr[16] = {B->block_index, B->n_hets, B->n_homs, B->n_records, B->n_qnames, B->seq_format, (uint64_t)lo, (uint64_t)(hi - lo),
                               B->local_hets ? 1u : 0u, E ? 1u : 0u, var.buf.size(), rec.buf.size(), exp.buf.size(), 0, 0, 0};
-    bool ok = std::fwrite("HPBR0001", 1, 8, f) == 8 && std::fwrite(hdr, 8, 16, f) == 16 && std::fwrite(P, sizeof *P, 1, f) == 1;
+    bool ok = std::fwrite("HPBR0002", 1, 8, f) == 8 && std::fwrite(hdr, 8, 16, f) == 16 && std::fwrite(P, sizeof *P, 1, f) == 1;
     static const uint8_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const size_t rl = (size_t)(hi - lo);
     if (rl) ok = ok && std::fwrite(B->reference + ((uint64_t)lo - B->ref_base), 1, rl, f) == rl;
@@ -158,7 +162,8 @@ extern "C" hp_hpbr* hp_hpbr_open(const char* path, int* status) {
         const size_t got = std::fread(magic, 1, 8, f);
         if (got == 0) break;
         uint64_t hdr[16];
-        if (got != 8 || std::memcmp(magic, "HPBR0001", 8) || std::fread(hdr, 8, 16, f) != 16) { std::fclose(f); return fail(HP_ERR_ARG, "not an .hpbr capture (bad magic / truncated header)"); }
+        const int version = (got == 8 && !std::memcmp(magic, "HPBR0002", 8)) ? 2 : ((got == 8 && !std::memcmp(magic, "HPBR0001", 8)) ? 1 : 0);
+        if (version == 0 || std::fread(hdr, 8, 16, f) != 16) { std::fclose(f); return fail(HP_ERR_ARG, "not an .hpbr capture (bad magic / truncated header)"); }
         auto blk = std::unique_ptr<hp_hpbr::Block>(new hp_hpbr::Block());
         if (std::fread(&blk->prm, sizeof blk->prm, 1, f) != 1) { std::fclose(f); return fail(HP_ERR_ARG, "truncated capture"); }
         const uint64_t n_hets = hdr[1], n_homs = hdr[2], n_rec = hdr[3], ref_len = hdr[7];
@@ -228,6 +233,15 @@ extern "C" hp_hpbr* hp_hpbr_open(const char* path, int* status) {
             E.span_counts = reinterpret_cast<uint64_t*>(const_cast<uint8_t*>(take(n_hets > 1 ? (size_t)(n_hets - 1) * 8 : 0)));
             q = take(8); E.n_segments = rd32(q); E.n_solver = rd32(q + 4);
             q = take(40); E.num_reads = rd64(q); E.skipped_reads = rd64(q + 8); E.global_aligned = rd64(q + 16); E.local_aligned = rd64(q + 24); E.n_edit_distances = rd64(q + 32);
+            if (version >= 2) {
+                q = take(8 * (1 + 5 * HP_N_VARIANT_TYPES));
+                if (!bad) {
+                    E.num_alleles = rd64(q);
+                    std::memcpy(E.exact_matches, q + 8, sizeof E.exact_matches); std::memcpy(E.inexact_matches, q + 8 + 88, sizeof E.inexact_matches);
+                    std::memcpy(E.failed_matches, q + 8 + 176, sizeof E.failed_matches); std::memcpy(E.allele0_matches, q + 8 + 264, sizeof E.allele0_matches);
+                    std::memcpy(E.allele1_matches, q + 8 + 352, sizeof E.allele1_matches);
+                }
+            }
             E.edit_distances = reinterpret_cast<uint64_t*>(const_cast<uint8_t*>(take((size_t)E.n_edit_distances * 8)));
             const size_t ns = E.n_segments;
             E.seg_qname = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(take(ns * 4))); E.seg_start = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(take(ns * 4)));
@@ -324,6 +338,9 @@ extern "C" int hp_block_output_equal(const hp_block_input* in, const hp_block_ou
     if (a->status != b->status) return 0;
     if (a->n_segments != b->n_segments || a->n_solver != b->n_solver || a->num_reads != b->num_reads || a->skipped_reads != b->skipped_reads ||
         a->global_aligned != b->global_aligned || a->local_aligned != b->local_aligned || a->n_edit_distances != b->n_edit_distances) return 0;
+    if (a->num_alleles != b->num_alleles || std::memcmp(a->exact_matches, b->exact_matches, sizeof a->exact_matches) ||
+        std::memcmp(a->inexact_matches, b->inexact_matches, sizeof a->inexact_matches) || std::memcmp(a->failed_matches, b->failed_matches, sizeof a->failed_matches) ||
+        std::memcmp(a->allele0_matches, b->allele0_matches, sizeof a->allele0_matches) || std::memcmp(a->allele1_matches, b->allele1_matches, sizeof a->allele1_matches)) return 0;
     if (a->n_edit_distances && std::memcmp(a->edit_distances, b->edit_distances, a->n_edit_distances * 8)) return 0;
     const size_t ns = a->n_segments;
     if (ns && (std::memcmp(a->seg_qname, b->seg_qname, ns * 4) || std::memcmp(a->seg_start, b->seg_start, ns * 4) || std::memcmp(a->seg_end, b->seg_end, ns * 4) ||

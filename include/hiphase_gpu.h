@@ -335,6 +335,17 @@ typedef struct hp_block_output {
     int32_t         status;               /* out: HP_OK, or HP_BLOCK_UNSUPPORTED (h1/h2/stats/spans/tags are not filled; the segments are,
                                              unless it was a record's graph-WFA job that fell outside the device limits: then n_segments = 0) */
     uint32_t        reserved;
+    /* The rest of the loader's ReadStats (writers/phase_stats.rs:12-33; returned at phaser.rs:645, written at phase_stats.rs:288):
+     * `joint_stats += read_stats` over EVERY record of the block, skipped or not, BEFORE the collapse (read_parsing.rs:88, :607).
+     * A globally re-aligned record counts per het of its overlap range (read_parsing.rs:803-850): Ambiguous -> failed_matches,
+     * Reference / Alternate -> inexact_matches (`exact_allele` is false upstream) + allele0 / allele1_matches + num_alleles; a
+     * record that fell back (or every record in local mode) brings local_realignment's own counts (read_parsing.rs:121-503). */
+    uint64_t        num_alleles;
+    uint64_t        exact_matches[HP_N_VARIANT_TYPES];
+    uint64_t        inexact_matches[HP_N_VARIANT_TYPES];
+    uint64_t        failed_matches[HP_N_VARIANT_TYPES];
+    uint64_t        allele0_matches[HP_N_VARIANT_TYPES];
+    uint64_t        allele1_matches[HP_N_VARIANT_TYPES];
 } hp_block_output;
 
 int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id);

@@ -19,6 +19,7 @@
 //                      quality assignment, collapse, A*, span counts and haplotags run behind the C ABI
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cstdint>
 #include <map>
 #include <stdexcept>
@@ -318,8 +319,10 @@ struct AlignedRecord {  // what global_realignment needs from one record (read_p
     bool has_local = false;
     LocalRecord local;                            // CIGAR view of the same record (needed when it falls back)
 };
-struct LoadStats {
+struct LoadStats {   // ReadStats (writers/phase_stats.rs:12-33) + the edit distances the loader logs
     uint64_t num_reads = 0, skipped_reads = 0, global_aligned = 0, local_aligned = 0;
+    uint64_t num_alleles = 0;
+    std::array<uint64_t, HP_N_VARIANT_TYPES> exact_matches{}, inexact_matches{}, failed_matches{}, allele0_matches{}, allele1_matches{};
     std::vector<uint64_t> edit_distances;
 };
 struct WfaOutcome {  // Ok(WFAResult) mapped to per-het alleles (read_parsing.rs:790-800) | Err(MaxEditDistance)
@@ -647,6 +650,11 @@ inline PhaseResult solve_block(uint64_t block_index, const std::vector<AlignedRe
         }
     pr.load_stats.num_reads = out.num_reads; pr.load_stats.skipped_reads = out.skipped_reads;
     pr.load_stats.global_aligned = out.global_aligned; pr.load_stats.local_aligned = out.local_aligned;
+    pr.load_stats.num_alleles = out.num_alleles;
+    for (int t = 0; t < HP_N_VARIANT_TYPES; ++t) {
+        pr.load_stats.exact_matches[t] = out.exact_matches[t]; pr.load_stats.inexact_matches[t] = out.inexact_matches[t]; pr.load_stats.failed_matches[t] = out.failed_matches[t];
+        pr.load_stats.allele0_matches[t] = out.allele0_matches[t]; pr.load_stats.allele1_matches[t] = out.allele1_matches[t];
+    }
     pr.load_stats.edit_distances.assign(eds.begin(), eds.begin() + out.n_edit_distances);
     return pr;
 }

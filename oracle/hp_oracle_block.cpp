@@ -54,7 +54,9 @@ std::vector<uint8_t> decode_seq(const uint8_t* p, uint32_t seq_format, uint64_t 
     return out;
 }
 
-struct RecResult { std::vector<uint8_t> alleles, quals; bool skipped = false; uint64_t local_aligned = 0; uint64_t wfa_score = 0; int rc = HP_OK; };
+struct RecResult { std::vector<uint8_t> alleles, quals; bool skipped = false; uint64_t local_aligned = 0; uint64_t wfa_score = 0; int rc = HP_OK;
+                   hp_read_stats st{};   // the record's ReadStats (num_alleles and the five per-type arrays; read_parsing.rs:853-862 / :496-502)
+};
 
 // local_realignment(&read, variant_calls) (read_parsing.rs:121-503) through the pinned piece
 RecResult local_realignment(const hp_block_input* B, uint32_t idx) {
@@ -71,6 +73,7 @@ RecResult local_realignment(const hp_block_input* B, uint32_t idx) {
     if (rc != 0) { r.rc = HP_ERR_INVARIANT; return r; }
     r.skipped = st.skipped_reads != 0;
     r.local_aligned = st.local_aligned;
+    r.st = st;
     return r;
 }
 
@@ -125,7 +128,9 @@ RecResult global_realignment(const hp_block_input* B, const hp_block_params* P, 
     r.quals.assign(num_variants, 0);
     for (size_t i = 0; i < num_variants; ++i) {
         const uint8_t a = r.alleles[i];
-        if (a == NO_OVERLAP || a == AMBIGUOUS) continue;
+        const size_t vt_index = B->het_types[i];
+        if (a == NO_OVERLAP) continue;                                                   // :807-808
+        if (a == AMBIGUOUS) { if (vt_index < HP_N_VARIANT_TYPES) r.st.failed_matches[vt_index] += 1; continue; }   // :809-811
         uint8_t q;
         switch (B->het_types[i]) {
             case SNV: q = SNV_QUAL; break;
@@ -135,6 +140,9 @@ RecResult global_realignment(const hp_block_input* B, const hp_block_params* P, 
             default: r.rc = HP_ERR_INVARIANT; return r;   // panic!("No implementation for matching ...")
         }
         r.quals[i] = (uint8_t)(2 * q);
+        r.st.inexact_matches[vt_index] += 1;                                             // :838-843: `exact_allele` is false
+        if (a == REFERENCE) r.st.allele0_matches[vt_index] += 1; else r.st.allele1_matches[vt_index] += 1;   // :844-848
+        r.st.num_alleles += 1;                                                           // :849
     }
     r.wfa_score = wr.score;
     r.local_aligned = 0;   // ReadStats::new(..., 1, 0): global_aligned 1, local_aligned 0 (:857-862)
@@ -151,6 +159,7 @@ extern "C" int hpo_solve_block(const hp_block_input* B, const hp_block_params* P
     std::vector<uint32_t> order;                     // first-seen read names
     std::vector<uint8_t> seen(B->n_qnames, 0);
     uint64_t num_reads = 0, skipped_reads = 0, global_aligned = 0, local_aligned = 0;
+    hp_read_stats joint{};                            // num_alleles + the per-type arrays of joint_stats
     std::vector<uint64_t> edit_distances;
     bool global_disabled = false;
     double num_global_failures = 0.0, total_parsed = 0.0;
@@ -171,6 +180,11 @@ extern "C" int hpo_solve_block(const hp_block_input* B, const hp_block_params* P
             }
         }
         if (r.rc != HP_OK) return r.rc;
+        joint.num_alleles += r.st.num_alleles;                              // :607 / :88: joint_stats += read_stats, skipped or not
+        for (int t = 0; t < HP_N_VARIANT_TYPES; ++t) {
+            joint.exact_matches[t] += r.st.exact_matches[t]; joint.inexact_matches[t] += r.st.inexact_matches[t]; joint.failed_matches[t] += r.st.failed_matches[t];
+            joint.allele0_matches[t] += r.st.allele0_matches[t]; joint.allele1_matches[t] += r.st.allele1_matches[t];
+        }
         if (!r.skipped) {                                                   // :583-600
             if (!seen[rec.qname_id]) { seen[rec.qname_id] = 1; order.push_back(rec.qname_id); }
             read_groups[rec.qname_id].push_back(row_new(std::move(r.alleles), std::move(r.quals)));
@@ -258,6 +272,11 @@ extern "C" int hpo_solve_block(const hp_block_input* B, const hp_block_params* P
     O->n_segments = (uint32_t)segs.size();
     O->n_solver = view.n_reads;
     O->num_reads = num_reads; O->skipped_reads = skipped_reads; O->global_aligned = global_aligned; O->local_aligned = local_aligned;
+    O->num_alleles = joint.num_alleles;
+    for (int t = 0; t < HP_N_VARIANT_TYPES; ++t) {
+        O->exact_matches[t] = joint.exact_matches[t]; O->inexact_matches[t] = joint.inexact_matches[t]; O->failed_matches[t] = joint.failed_matches[t];
+        O->allele0_matches[t] = joint.allele0_matches[t]; O->allele1_matches[t] = joint.allele1_matches[t];
+    }
     O->n_edit_distances = edit_distances.size();
     if (O->edit_distances && !edit_distances.empty()) std::memcpy(O->edit_distances, edit_distances.data(), edit_distances.size() * 8);
     uint64_t cells = 0;

@@ -14,7 +14,7 @@ from hiphase_amd.read_parsing import GlobalRealignmentConfig, LocalRecord
 from hiphase_amd.read_segments import BlockMatrix
 from hiphase_amd.wfa_graph import VariantType
 from local_util import make_local_block
-from oracle_ffi import oracle, oracle_solve
+from oracle_ffi import oracle, oracle_solve, oracle_solve_blocks
 from test_e2e_gpu import oracle_pipeline
 from test_local_gpu import oracle_segments, reference_order_replay, seg_tuple, to_aligned
 
@@ -91,6 +91,11 @@ def test_block_entry_fallback_replay(max_ed, minimum, ratio, expect_flip, wfa_pa
     osegs, n_local, n_global, flipped = reference_order_replay(oracle(), ref, hets, records, cfg)
     assert flipped == expect_flip
     assert (res.local_aligned, res.global_aligned) == (n_local, n_global)
+    # the rest of ReadStats (num_alleles + exact / inexact / failed / allele0 / allele1 per type, phase_stats.rs:12-33) on a block
+    # with fallbacks: against the count made in Python record by record, and against hpo_solve_block
+    assert res.read_stats == reference_order_replay.joint and res.read_stats[0] > 0
+    ores, = oracle_solve_blocks([BlockSpec(1, ref, hets, [], records)], config=cfg)
+    assert same_result(res, ores)
     check_against_oracle(res, osegs, hets)
 
 
@@ -101,6 +106,7 @@ def test_block_entry_local_mode():
     res, = solve_blocks([BlockSpec(3, ref, variants, [], records)], global_realignment=False)
     osegs, ophas = oracle_segments(oracle(), records, variants)
     check_against_oracle(res, osegs, variants, ophas)
+    assert res.read_stats == oracle_segments.joint and res.read_stats[0] > 0
     assert res.global_aligned == 0 and res.local_aligned > 0
 
 
@@ -199,7 +205,7 @@ def same_result(a, b):
     return (np.array_equal(a.haplotype_1, b.haplotype_1) and np.array_equal(a.haplotype_2, b.haplotype_2) and a.statistics == b.statistics
             and a.segments == b.segments and a.haplotags == b.haplotags and a.span_counts.tolist() == b.span_counts.tolist()
             and a.edit_distances == b.edit_distances and (a.num_reads, a.skipped_reads, a.global_aligned, a.local_aligned) ==
-            (b.num_reads, b.skipped_reads, b.global_aligned, b.local_aligned) and a.status == b.status)
+            (b.num_reads, b.skipped_reads, b.global_aligned, b.local_aligned) and a.read_stats == b.read_stats and a.status == b.status)
 
 
 def test_block_entry_bam4_reads_equal_ascii(wfa_path):

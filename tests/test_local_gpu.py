@@ -77,9 +77,40 @@ def test_local_batch_edge_cases(hp_lib, oracle_lib):
     assert e.value.code == -4
 
 
+
+class JointStats:
+    """joint_stats += read_stats (writers/phase_stats.rs:107-121) for num_alleles and the five per-type arrays, counted here in
+    Python, independently of hp_oracle_block.cpp: -> the tuple hiphase_amd._ffi.BlockOutput.read_stats() returns"""
+
+    def __init__(self):
+        self.num_alleles, self.arr = 0, [[0] * 11 for _ in range(5)]   # exact, inexact, failed, allele0, allele1
+
+    def add_local(self, st):   # hiphase_amd._ffi.ReadStats.as_tuple(): (skipped, num_alleles, exact, inexact, failed, a0, a1, local)
+        self.num_alleles += st[1]
+        for k in range(5):
+            for t in range(11):
+                self.arr[k][t] += st[2 + k][t]
+
+    def add_global(self, alleles, types):   # read_parsing.rs:805-850 over the record's allele row
+        for a, t in zip(alleles, types):
+            if a == 2:
+                self.arr[2][t] += 1
+            elif a < 2:
+                self.arr[1][t] += 1
+                self.arr[3 + a][t] += 1
+                self.num_alleles += 1
+
+    def as_tuple(self):
+        return (self.num_alleles,) + tuple(tuple(x) for x in self.arr)
+
+
 def oracle_segments(oracle_lib, records, variants, min_matched=2):
     oal, oql, ost, rcs = oracle_local(oracle_lib, records, variants)
     groups = {}
+    joint = JointStats()
+    for st in ost:
+        joint.add_local(st)            # read_parsing.rs:88: skipped or not
+    oracle_segments.joint = joint.as_tuple()
     for i, rec in enumerate(records):
         if ost[i][0] == 0:
             groups.setdefault(rec.qname, []).append(ReadSegment(rec.qname, oal[i].tolist(), oql[i].tolist()))
@@ -134,10 +165,13 @@ def reference_order_replay(oracle_lib, ref, hets, records, cfg):
     groups, n = {}, len(hets)
     global_disabled, fails, total = False, 0.0, 0.0
     n_local = n_global = n_skipped = 0
+    joint = JointStats()
+    types = [int(v.variant_type) for v in hets]
     for rec in records:
         def local():
             al, ql, st, rc = oracle_local(d, [rec.local], hets)
             assert rc == [0]
+            joint.add_local(st[0])     # read_parsing.rs:607 with local_realignment's ReadStats
             return al[0].tolist(), ql[0].tolist(), st[0][0] == 1
         if global_disabled:
             alleles, quals, skipped = local()
@@ -162,6 +196,7 @@ def reference_order_replay(oracle_lib, ref, hets, records, cfg):
                     alleles[i] = int(al[k])
                     if alleles[i] < 2:
                         quals[i] = 2 * BASE_QUAL[VariantType(hets[i].variant_type)]
+                joint.add_global(alleles, types)
                 skipped, was_local = False, False
         if skipped:
             n_skipped += 1
@@ -178,6 +213,7 @@ def reference_order_replay(oracle_lib, ref, hets, records, cfg):
         col = ReadSegment.collapse(grp)
         if col.get_num_set() >= 2:
             segs.append(col)
+    reference_order_replay.joint = joint.as_tuple()
     return segs, n_local, n_global, global_disabled
 
 

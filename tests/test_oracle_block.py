@@ -38,6 +38,8 @@ def test_fallback_replay(max_ed, minimum, ratio, expect_flip):
     osegs, n_local, n_global, flipped = reference_order_replay(oracle(), ref, hets, records, cfg)
     assert flipped == expect_flip
     assert (res.local_aligned, res.global_aligned) == (n_local, n_global)
+    assert res.read_stats == reference_order_replay.joint and res.read_stats[0] > 0   # the rest of ReadStats, counted in Python
+    assert res.read_stats[0] == sum(res.read_stats[1]) + sum(res.read_stats[2]) == sum(res.read_stats[4]) + sum(res.read_stats[5])   # phase_stats.rs:62-64
     check_against_oracle(res, osegs, hets)
     packed, = oracle_solve_blocks([BlockSpec(1, ref, hets, [], records)], config=cfg, seq_format=_ffi.SEQ_BAM4)
     assert same_result(res, packed)
@@ -49,4 +51,5 @@ def test_local_mode():
     res, = oracle_solve_blocks([BlockSpec(3, ref, variants, [], records)], global_realignment=False)
     osegs, ophas = oracle_segments(oracle(), records, variants)
     check_against_oracle(res, osegs, variants, ophas)
+    assert res.read_stats == oracle_segments.joint and res.read_stats[0] > 0
     assert res.global_aligned == 0 and res.local_aligned > 0
