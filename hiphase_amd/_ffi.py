@@ -304,6 +304,9 @@ EXPORTS = [
     "hp_blockstream_submit",
     "hp_blockstream_wait",
     "hp_blockstream_destroy",
+    "hp_blockstream_devices",
+    "hp_block_submit",
+    "hp_block_wait",
     "hp_device_count",
     "hp_default_device",
     "hp_last_error",
@@ -430,6 +433,12 @@ def lib():
     dll.hp_blockstream_create.argtypes = [C.POINTER(BlockParams), C.c_int, C.c_uint32, C.POINTER(C.c_int)]
     dll.hp_blockstream_submit.restype = C.c_int
     dll.hp_blockstream_submit.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(BlockInput), C.POINTER(BlockOutput), C.POINTER(C.c_uint64)]
+    dll.hp_blockstream_devices.restype = C.c_int
+    dll.hp_blockstream_devices.argtypes = [C.c_void_p]
+    dll.hp_block_submit.restype = C.c_int
+    dll.hp_block_submit.argtypes = [C.c_size_t, C.POINTER(BlockInput), C.POINTER(BlockParams), C.POINTER(BlockOutput), C.c_int, C.POINTER(C.c_uint64)]
+    dll.hp_block_wait.restype = C.c_int
+    dll.hp_block_wait.argtypes = [C.c_uint64]
     dll.hp_blockstream_wait.restype = C.c_int
     dll.hp_blockstream_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     dll.hp_blockstream_destroy.restype = None

@@ -92,6 +92,7 @@ int device_cu_count(int device_id) {
 // helper thread of the late results, the A* stream sets, the other stages' own)
 static const int g_hw_queues_set = [] { return setenv("GPU_MAX_HW_QUEUES", "24", 0); }();
 thread_local unsigned g_host_share_div = 0;
+std::atomic<int> g_pipelines{0};
 thread_local int g_wfa2_reserve_pct = 0;
 unsigned host_threads(unsigned want) {
     static const unsigned share = [] {
@@ -119,7 +120,9 @@ unsigned host_threads(unsigned want) {
         if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) procs = (unsigned)std::max(1, std::atoi(e));
         return std::max(2u, hw / procs);
     }();
-    const unsigned mine = g_host_share_div ? std::max(2u, share / g_host_share_div) : share;
+    // (a stage thread of a block pipeline takes its stage's part of the process's share; several pipelines in one process - one per
+    // device - split it between them)
+    const unsigned mine = g_host_share_div ? std::max(2u, share / (g_host_share_div * (unsigned)std::max(1, g_pipelines.load(std::memory_order_relaxed)))) : share;
     return std::max(1u, std::min(want, mine));
 }
 

@@ -113,4 +113,15 @@ int blockset_rows(hp_blockset* bs);
 int blockset_pack(hp_blockset* bs);
 // A*, span counts and haplotags, outputs
 int blockset_solve(hp_blockset* bs, hp_block_output* out);
+
+// One device's five-stage pipeline (hp_stream.hip): what hp_blockstream_* and the per-block dispatcher (hp_block.hip) both drive.
+// submit blocks while `depth` sets are in flight; p == nullptr: the parameters the pipeline was created with; sets complete in
+// submission order; wait hands the slot back.
+struct Pipeline;
+Pipeline* pipeline_create(const hp_block_params* p, int device_id, uint32_t depth, int* status);
+int pipeline_submit(Pipeline* s, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, uint64_t* ticket);
+int pipeline_wait(Pipeline* s, uint64_t ticket, double* stage_ms, uint64_t* work);
+uint64_t pipeline_load(Pipeline* s, bool* has_free_slot);   // records in flight
+void pipeline_wait_free(Pipeline* s);                       // returns when a slot is free
+void pipeline_destroy(Pipeline* s);
 }  // namespace hp

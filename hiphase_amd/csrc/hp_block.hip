@@ -139,6 +139,9 @@ int hp::blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in
     const double t0 = blk_now_ms();
     bs->n_blocks = n_blocks; bs->in = in; bs->prm = *p;
     bs->device = device_id < 0 ? hp_default_device() : device_id;
+    // a set that failed between its alignment stage and blockset_rows' join may have left its late pass running: it writes
+    // bs->wfa_out / bs->alleles and reads the previous caller's inputs - join it before any of that is reassigned
+    if (bs->wfa) (void)w2_session_finish(bs->wfa);
     bs->wfa_ready = false;
     bs->prep[0] = bs->prep[1] = bs->prep[2] = bs->prep[3] = 0.0;
     if (bs->meta.size() < n_blocks) bs->meta.resize(n_blocks);
@@ -530,6 +533,10 @@ int hp::blockset_rows(hp_blockset* bs) {
     const bool has_wfa = ch.wfa_ready;
     const double t1 = blk_now_ms();
     int rc = HP_OK;
+    // the deferred late pass of the set's alignment stage (helper thread of the session) writes ch.wfa_out / ch.alleles and reads
+    // the caller's inputs: it is joined on EVERY way out of this function - an error return must not leave it running under a
+    // slot that is recycled, a merged set that is re-run request by request, or inputs the caller frees after the error
+    struct LateJoin { hp_blockset* s; bool on; ~LateJoin() { if (on && s->wfa) (void)w2_session_finish(s->wfa); } } late_join{bs, has_wfa};
     {
         unsigned nt = host_threads(32u);   // measured: 16 -> 32 threads 6.0 -> 4.1 ms, 64 no better
         if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
@@ -820,21 +827,24 @@ static int solve_blocks_on_device(size_t n_blocks, const hp_block_input* in, con
 
 // ---- the node's GPUs behind the unchanged per-block entry -----------------------------------------------------------------------
 // HiPhase calls solve_block once per phase block from its `--threads` pool (reference src/main.rs:326-462: a bounded queue of
-// blocks, T workers, results written in order). With the one-call-site patch of INTEGRATION.md that is T threads sitting in
-// hp_solve_blocks(1, ..., device_id = -1) at once. Requests go into ONE queue; every visible device has service threads pulling
-// from it (two per device: the layout + upload of one merged set overlaps the kernels of the other); a service thread takes its
-// share of what is queued (queued / idle service threads, so that a burst spreads over the devices), merges it into one block
-// set, solves it on its device, hands the results out. A call with many blocks (device_id = -1) is cut into chunks of about
-// total / (8 x devices) records, largest blocks first (LPT: sizes are heavy-tailed), which travel through the same
-// queue. No collective, no device-to-device traffic: a block's 2 N result bytes + statistics go back over PCIe.
-// A request that names its device goes to that device's own queue. The service threads are started by the first call that
-// needs them and live as long as the process (their device-buffer caches, streams and block-set objects stay warm).
+// 40 x threads job slots, T workers, results written in order). With the one-call-site patch of INTEGRATION.md that is T threads
+// sitting in hp_solve_blocks(1, ..., device_id = -1) at once; with the asynchronous entry (hp_block_submit / hp_block_wait) it is
+// the reference's own 40 x T job slots in flight. Either way a request goes into ONE queue. Every visible device has a FEEDER
+// thread and a COMPLETER thread around a five-stage block pipeline (hp_stream.hip, the road bench.py's headline takes): the feeder
+// waits for a free slot of its pipeline - requests pile up meanwhile, which is all the batching there is: no window, no timer -
+// takes its share of what is queued (everything for its own device + queued / devices of the common queue, a few hundred
+// records at least), merges it into one block set and submits it; the completer waits for the sets in order and hands the
+// results out. While set k is aligned, set k + 1 is laid out and crossing PCIe and set k - 1 is solved: the per-block call runs
+// at the stream's rate, not at the serial stages-in-a-row rate of round 3. A call with many blocks (device_id = -1, several
+// devices) is cut into LPT chunks of about total / (8 x devices) records that travel through the same queue (sizes are
+// heavy-tailed). No collective, no device-to-device traffic: a block's 2 N result bytes + statistics go back over
+// PCIe. The threads are started by the first call that needs them and live as long as the process.
 namespace {
 
 struct BlocksReq {
     size_t n; const hp_block_input* in; hp_block_params prm; hp_block_output* out; int device;   // device: -1 = any
-    bool counted = false;   // its caller is counted in BlockDispatcher::entering (a coalescing caller, not a chunk of a large call)
     int rc = HP_OK; std::string err; bool done = false;
+    uint64_t records = 0;
 };
 bool same_params(const hp_block_params& a, const hp_block_params& b) {
     return a.astar.min_queue_size == b.astar.min_queue_size && a.astar.queue_increment == b.astar.queue_increment &&
@@ -843,112 +853,175 @@ bool same_params(const hp_block_params& a, const hp_block_params& b) {
            a.global_failure_minimum == b.global_failure_minimum && a.min_matched_alleles == b.min_matched_alleles &&
            a.global_realignment == b.global_realignment;
 }
-// requests that share their parameters are solved as one set; a merged set that fails is re-run request by request so that
-// every caller gets the status of its own blocks
-void run_requests(std::vector<BlocksReq*>& batch, int device) {
-    std::vector<char> taken(batch.size(), 0);
-    for (size_t i = 0; i < batch.size(); ++i) {
-        if (taken[i]) continue;
-        std::vector<BlocksReq*> grp;
-        for (size_t j = i; j < batch.size(); ++j)
-            if (!taken[j] && same_params(batch[j]->prm, batch[i]->prm)) { taken[j] = 1; grp.push_back(batch[j]); }
-        try {
-            if (grp.size() > 1) {
-                std::vector<hp_block_input> in;
-                std::vector<hp_block_output> out;
-                for (BlocksReq* r : grp) { in.insert(in.end(), r->in, r->in + r->n); out.insert(out.end(), r->out, r->out + r->n); }
-                if (solve_blocks_on_device(in.size(), in.data(), &grp[0]->prm, out.data(), device) == HP_OK) {
-                    size_t o = 0;
-                    for (BlocksReq* r : grp) { std::copy(out.begin() + o, out.begin() + o + r->n, r->out); o += r->n; r->rc = HP_OK; }
-                    continue;
-                }
-            }
-            for (BlocksReq* r : grp) {
-                r->rc = solve_blocks_on_device(r->n, r->in, &r->prm, r->out, device);
-                if (r->rc != HP_OK) r->err = hp_last_error();
-            }
-        } catch (const std::exception& e) {   // (std::bad_alloc of a host vector: nobody may be left waiting)
-            for (BlocksReq* r : grp) if (r->rc == HP_OK) { r->rc = HP_ERR_OOM; r->err = std::string("host allocation failed: ") + e.what(); }
-        }
-    }
-}
+
+// a merged set on its way through a device's pipeline
+struct MergedSet {
+    std::vector<BlocksReq*> reqs;
+    std::vector<hp_block_input> in;
+    std::vector<hp_block_output> out;
+    hp_block_params prm{};
+    uint64_t ticket = 0;
+    int submit_rc = HP_OK;
+    std::string submit_err;
+};
 
 class BlockDispatcher {
 public:
     static BlockDispatcher& get() { static auto* d = new BlockDispatcher(); return *d; }   // never destroyed
     int devices() { std::lock_guard<std::mutex> lk(m_); start_locked(); return n_vdev_; }
-    // queues the requests and waits for all of them; `expected` more single-block callers may be on their way in (call coalescing)
-    void submit(BlocksReq* const* reqs, size_t n) {
+    int real_devices() { std::lock_guard<std::mutex> lk(m_); start_locked(); return real_dev_; }
+    // queues the requests; returns at once (wait() collects them)
+    void post(BlocksReq* const* reqs, size_t n) {
         std::unique_lock<std::mutex> lk(m_);
         start_locked();
         for (size_t i = 0; i < n; ++i) {
             BlocksReq* r = reqs[i];
-            if (r->device >= 0) dev_q_[(size_t)r->device % dev_q_.size()].push_back(r); else any_q_.push_back(r);
-            if (r->counted) ++counted_here_;
+            r->records = 1;
+            for (size_t b = 0; b < r->n; ++b) r->records += r->in[b].n_records;
+            if (r->device >= 0) dev_q_[(size_t)r->device].push_back(r); else any_q_.push_back(r);
         }
         cv_work_.notify_all();
+    }
+    void wait(BlocksReq* const* reqs, size_t n) {
+        std::unique_lock<std::mutex> lk(m_);
         cv_done_.wait(lk, [&]() { for (size_t i = 0; i < n; ++i) if (!reqs[i]->done) return false; return true; });
     }
-    std::atomic<int> entering{0};     // callers inside the coalescing entry that have not queued yet (+ lone runners)
-    std::atomic<int> lone{0};         // callers that took the lone fast path and will never queue
+    std::atomic<int> entering{0};     // callers inside the blocking one-block entry (a lone one runs on its own thread)
 
 private:
+    struct Dev {
+        int device = 0;
+        Pipeline* pipe = nullptr;
+        std::mutex m;
+        std::condition_variable cv;
+        std::deque<std::unique_ptr<MergedSet>> inflight;   // submitted, in ticket order
+    };
     void start_locked() {
         if (started_) return;
         started_ = true;
         real_dev_ = std::max(1, hp_device_count());
-        const char* wenv = std::getenv("HP_QUEUE_WORKERS");   // test hook: n queue "devices" on a box with fewer GPUs (device = worker % real)
-        n_vdev_ = wenv ? std::max(1, std::atoi(wenv)) : real_dev_;
-        dev_q_.resize((size_t)real_dev_);
-        const char* tenv = std::getenv("HP_SERVICE_THREADS");
-        const int per_dev = tenv ? std::max(1, std::atoi(tenv)) : 2;
-        for (int v = 0; v < n_vdev_; ++v)
-            for (int k = 0; k < per_dev; ++k) std::thread([this, v]() { serve(v % real_dev_); }).detach();
+        // test hook: n queue "devices" on a box with fewer GPUs (virtual device v works on GPU v % real); every real device gets
+        // its threads whatever the hook says (a request that names a device must find them)
+        const char* wenv = std::getenv("HP_QUEUE_WORKERS");
+        n_vdev_ = std::max(real_dev_, wenv ? std::max(1, std::atoi(wenv)) : real_dev_);
+        dev_q_.resize((size_t)n_vdev_);
+        devs_.resize((size_t)n_vdev_);
+        for (int v = 0; v < n_vdev_; ++v) {
+            devs_[(size_t)v].reset(new Dev());
+            devs_[(size_t)v]->device = v % real_dev_;
+            std::thread([this, v]() { feed(v); }).detach();
+            std::thread([this, v]() { complete(v); }).detach();
+        }
     }
-    void serve(int device) {
-        (void)hipSetDevice(device);
-        std::unique_lock<std::mutex> lk(m_);
+    static uint64_t max_records() {   // records per merged set (the bench's sets hold ~136 k; a pipeline slot's buffers grow to its largest set)
+        static const uint64_t v = [] { const char* e = std::getenv("HP_DISPATCH_MAX_RECORDS"); return e ? (uint64_t)std::max(1ll, std::atoll(e)) : 160000ull; }();
+        return v;
+    }
+    void feed(int v) {
+        Dev& D = *devs_[(size_t)v];
+        (void)hipSetDevice(D.device);
         for (;;) {
-            ++idle_;
-            cv_work_.wait(lk, [&]() { return !any_q_.empty() || !dev_q_[(size_t)device].empty(); });
-            // callers that are inside the entry point but have not queued yet are about to: a short window collects them
-            // (a lone runner never queues and is not waited for)
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us());
-            // (counted_here_: coalescing callers whose request is queued or being served.) Callers that have just been handed
-            // their results are on their way back with the next block, one by one: the window stays open until as many callers
-            // are here as have ever been inside at once - or it runs out. Without this a pool of 64 threads degenerates into
-            // batches of one or two blocks (measured: 4 k instead of 60 k hets/s).
-            for (;;) {
-                const int inside = entering.load(std::memory_order_acquire) - lone.load(std::memory_order_acquire);
-                peak_ = std::max(peak_, inside);
-                if (counted_here_ >= peak_) break;
-                if (cv_work_.wait_until(lk, deadline) == std::cv_status::timeout) break;
+            {   // something to do?
+                std::unique_lock<std::mutex> lk(m_);
+                cv_work_.wait(lk, [&]() { return !any_q_.empty() || !dev_q_[(size_t)v].empty(); });
             }
-            std::vector<BlocksReq*> batch(dev_q_[(size_t)device].begin(), dev_q_[(size_t)device].end());
-            dev_q_[(size_t)device].clear();
-            // a share of the common queue: what is there, over the service threads that are free to take it
-            // (... but not in crumbs: a merged set of a dozen blocks costs a device the same 25 ms as one of a hundred)
-            size_t take = std::max<size_t>((any_q_.size() + (size_t)idle_ - 1) / (size_t)std::max(1, idle_), std::min<size_t>(any_q_.size(), 24));
-            --idle_;
-            for (; take > 0 && !any_q_.empty(); --take) { batch.push_back(any_q_.front()); any_q_.pop_front(); }
-            if (batch.empty()) continue;   // (another service thread was quicker)
-            lk.unlock();
-            run_requests(batch, device);
-            lk.lock();
-            for (BlocksReq* r : batch) { r->done = true; if (r->counted) --counted_here_; }
+            if (!D.pipe) {   // (first use: the pipeline's threads, streams and pools are this device's from here on)
+                hp_block_params dflt{};
+                int rc = HP_OK;
+                static const uint32_t depth = [] { const char* e = std::getenv("HP_DISPATCH_DEPTH"); return e ? (uint32_t)std::max(1, std::min(16, std::atoi(e))) : 5u; }();
+                D.pipe = pipeline_create(&dflt, D.device, depth, &rc);
+                if (!D.pipe) { fail_queued(v, rc != HP_OK ? rc : HP_ERR_HIP, hp_last_error()); continue; }
+            }
+            // a free slot first: whatever arrives while the pipeline is full joins this set - the batching of a busy device
+            pipeline_wait_free(D.pipe);
+            std::unique_ptr<MergedSet> ms(new MergedSet());
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                std::deque<BlocksReq*>& mine = dev_q_[(size_t)v];
+                if (mine.empty() && any_q_.empty()) continue;   // (another device's feeder was quicker)
+                ms->prm = !mine.empty() ? mine.front()->prm : any_q_.front()->prm;
+                uint64_t rec = 0;
+                auto take_from = [&](std::deque<BlocksReq*>& q, uint64_t cap_records) {
+                    for (auto it = q.begin(); it != q.end() && rec < cap_records;) {
+                        if (!same_params((*it)->prm, ms->prm)) { ++it; continue; }   // (its turn comes with the next set)
+                        rec += (*it)->records;
+                        ms->reqs.push_back(*it);
+                        it = q.erase(it);
+                    }
+                };
+                take_from(mine, max_records());
+                // the common queue: this device's share of what is there - but not in crumbs (a set of a dozen blocks costs a
+                // device the same stages as one of a few hundred)
+                uint64_t queued = 0;
+                for (BlocksReq* r : any_q_) queued += r->records;
+                const uint64_t share = std::max<uint64_t>((queued + (uint64_t)n_vdev_ - 1) / (uint64_t)n_vdev_, std::min<uint64_t>(queued, 4096));
+                if (rec < max_records()) take_from(any_q_, std::min(max_records(), rec + share));
+            }
+            if (ms->reqs.empty()) continue;
+            for (BlocksReq* r : ms->reqs) { ms->in.insert(ms->in.end(), r->in, r->in + r->n); ms->out.insert(ms->out.end(), r->out, r->out + r->n); }
+            ms->submit_rc = pipeline_submit(D.pipe, ms->in.size(), ms->in.data(), &ms->prm, ms->out.data(), &ms->ticket);
+            if (ms->submit_rc != HP_OK) ms->submit_err = hp_last_error();
+            {
+                std::lock_guard<std::mutex> lk(D.m);
+                D.inflight.push_back(std::move(ms));
+            }
+            D.cv.notify_all();
+        }
+    }
+    void complete(int v) {
+        Dev& D = *devs_[(size_t)v];
+        (void)hipSetDevice(D.device);
+        for (;;) {
+            std::unique_ptr<MergedSet> ms;
+            {
+                std::unique_lock<std::mutex> lk(D.m);
+                D.cv.wait(lk, [&]() { return !D.inflight.empty(); });
+                ms = std::move(D.inflight.front());
+                D.inflight.pop_front();
+            }
+            int rc = ms->submit_rc;
+            std::string err = ms->submit_err;
+            if (rc == HP_OK) { rc = pipeline_wait(D.pipe, ms->ticket, nullptr, nullptr); if (rc != HP_OK) err = hp_last_error(); }
+            if (rc == HP_OK) {
+                size_t o = 0;
+                for (BlocksReq* r : ms->reqs) { std::copy(ms->out.begin() + (ptrdiff_t)o, ms->out.begin() + (ptrdiff_t)(o + r->n), r->out); o += r->n; r->rc = HP_OK; }
+            } else if (ms->reqs.size() == 1) { ms->reqs[0]->rc = rc; ms->reqs[0]->err = err; }
+            else {
+                // a merged set that fails is re-run request by request (on this thread, stages in a row) so that every caller gets
+                // the status of its own blocks
+                for (BlocksReq* r : ms->reqs) {
+                    try {
+                        r->rc = solve_blocks_on_device(r->n, r->in, &r->prm, r->out, D.device);
+                        if (r->rc != HP_OK) r->err = hp_last_error();
+                    } catch (const std::exception& e) { r->rc = HP_ERR_OOM; r->err = std::string("host allocation failed: ") + e.what(); }
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                for (BlocksReq* r : ms->reqs) r->done = true;
+            }
             cv_done_.notify_all();
         }
     }
-    static long window_us() {
-        static const long w = [] { const char* e = std::getenv("HP_COALESCE_WINDOW_US"); return e ? std::max(0l, std::atol(e)) : 200l; }();
-        return w;
+    void fail_queued(int v, int rc, const char* why) {
+        std::vector<BlocksReq*> gone;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            gone.assign(dev_q_[(size_t)v].begin(), dev_q_[(size_t)v].end());
+            dev_q_[(size_t)v].clear();
+            if (n_vdev_ == 1) { gone.insert(gone.end(), any_q_.begin(), any_q_.end()); any_q_.clear(); }
+            for (BlocksReq* r : gone) { r->rc = rc; r->err = why; r->done = true; }
+        }
+        cv_done_.notify_all();
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
     }
     std::mutex m_;
     std::condition_variable cv_work_, cv_done_;
     std::deque<BlocksReq*> any_q_;
     std::vector<std::deque<BlocksReq*>> dev_q_;
+    std::vector<std::unique_ptr<Dev>> devs_;
     bool started_ = false;
-    int real_dev_ = 1, n_vdev_ = 1, idle_ = 0, counted_here_ = 0, peak_ = 0;
+    int real_dev_ = 1, n_vdev_ = 1;
 };
 
 // a call with many blocks for the node's GPUs: LPT chunks through the dispatcher's queue
@@ -977,7 +1050,8 @@ int solve_blocks_over_devices(size_t n_blocks, const hp_block_input* in, const h
         c->req = BlocksReq{c->ids.size(), c->ci.data(), *p, c->co.data(), -1};
         reqs.push_back(&c->req);
     }
-    D.submit(reqs.data(), reqs.size());
+    D.post(reqs.data(), reqs.size());
+    D.wait(reqs.data(), reqs.size());
     int rc = HP_OK;
     for (auto& c : chunks) {
         if (c->req.rc != HP_OK) { if (rc == HP_OK) { rc = c->req.rc; set_error("%s", c->req.err.c_str()); } continue; }
@@ -991,7 +1065,9 @@ int solve_blocks_over_devices(size_t n_blocks, const hp_block_input* in, const h
 extern "C" int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id) {
     if (n_blocks == 0) return HP_OK;
     if (!in || !p || !out) { set_error("null argument"); return HP_ERR_ARG; }
-    if (hp_device_count() <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return HP_ERR_HIP; }
+    const int ndev = hp_device_count();
+    if (ndev <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return HP_ERR_HIP; }
+    if (device_id >= ndev) { set_error("device %d: %d visible", device_id, ndev); return HP_ERR_ARG; }
     BlockDispatcher& D = BlockDispatcher::get();
     if (device_id < 0 && n_blocks >= 2) {   // a whole batch for the node's GPUs
         if (D.devices() == 1) return solve_blocks_on_device(n_blocks, in, p, out, hp_default_device());
@@ -1001,18 +1077,49 @@ extern "C" int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const 
     // one block (or a set for a named device) from one of many caller threads: merged with what else is in flight
     if (D.entering.fetch_add(1, std::memory_order_acq_rel) == 0) {
         // nobody else is inside: run on the caller's own thread (its caches are the warm ones for a single-threaded host);
-        // whoever arrives meanwhile queues for the service threads
-        D.lone.fetch_add(1, std::memory_order_acq_rel);
+        // whoever arrives meanwhile queues for the pipelines
         const int rc = solve_blocks_on_device(n_blocks, in, p, out, device_id < 0 ? hp_default_device() : device_id);
-        D.lone.fetch_sub(1, std::memory_order_acq_rel);
         D.entering.fetch_sub(1, std::memory_order_acq_rel);
         return rc;
     }
     BlocksReq r{n_blocks, in, *p, out, device_id};
-    r.counted = true;
     BlocksReq* rp = &r;
-    D.submit(&rp, 1);
+    D.post(&rp, 1);
+    D.wait(&rp, 1);
     D.entering.fetch_sub(1, std::memory_order_acq_rel);
     if (r.rc != HP_OK) set_error("%s", r.err.c_str());
     return r.rc;
+}
+
+// ---- the asynchronous per-block entry --------------------------------------------------------------------------------------------
+// HiPhase keeps `job_slots = 40 x threads` blocks queued but only `threads` calls of solve_block in flight (reference
+// src/main.rs:328,344-383). A worker that SUBMITS its block and goes on to load the next one keeps all 40 x threads of them in
+// flight on the device side: hp_block_submit queues the block(s) for the pipelines and returns a ticket at once, hp_block_wait
+// returns when the results are in `out`. `in`, everything it points at, and `out` must stay valid until the wait returns;
+// any thread may wait. The ticket is consumed by the wait.
+struct hp_block_ticket_rec { BlocksReq req; };
+
+extern "C" int hp_block_submit(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id, uint64_t* ticket) {
+    if (!ticket || !p || (n_blocks && (!in || !out))) { set_error("null argument"); return HP_ERR_ARG; }
+    const int ndev = hp_device_count();
+    if (ndev <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return HP_ERR_HIP; }
+    if (device_id >= ndev) { set_error("device %d: %d visible", device_id, ndev); return HP_ERR_ARG; }
+    auto* t = new (std::nothrow) hp_block_ticket_rec{BlocksReq{n_blocks, in, *p, out, device_id < 0 ? -1 : device_id}};
+    if (!t) { set_error("host allocation failed"); return HP_ERR_OOM; }
+    *ticket = (uint64_t)(uintptr_t)t;
+    if (n_blocks == 0) { t->req.done = true; return HP_OK; }
+    BlocksReq* rp = &t->req;
+    BlockDispatcher::get().post(&rp, 1);
+    return HP_OK;
+}
+
+extern "C" int hp_block_wait(uint64_t ticket) {
+    auto* t = reinterpret_cast<hp_block_ticket_rec*>((uintptr_t)ticket);
+    if (!t) { set_error("null ticket"); return HP_ERR_ARG; }
+    BlocksReq* rp = &t->req;
+    if (rp->n) BlockDispatcher::get().wait(&rp, 1);
+    const int rc = rp->rc;
+    if (rc != HP_OK) set_error("%s", rp->err.c_str());
+    delete t;
+    return rc;
 }

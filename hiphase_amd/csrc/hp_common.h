@@ -41,6 +41,7 @@ void dev_cache_put(void* p, size_t bytes, int dev);
 unsigned host_threads(unsigned want);
 // a pipeline stage (hp_stream.hip) runs beside two others: its parallel regions take this fraction of the share (per thread; 0 = all)
 extern thread_local unsigned g_host_share_div;
+extern std::atomic<int> g_pipelines;   // block pipelines alive in this process (hp_stream.hip): they share the host threads
 // share (per cent) of the chip's wavefront slots the persistent graph-WFA launch set leaves empty for the kernels of other
 // threads (hp_wfa2.hip run(); set by the alignment stage of a block stream, 0 elsewhere)
 extern thread_local int g_wfa2_reserve_pct;

@@ -16,12 +16,19 @@
 //   stage 5 (hp::blockset_solve)  A* (a latency-bound kernel: the host thread mostly waits), span counts and haplotags, outputs
 //                                 into the caller's buffers
 //
-// Sets complete in submission order. `depth` slots hold the sets in flight; a slot keeps its host vectors and device buffers
+// hp::Pipeline is one device's five stages. The public hp_blockstream is one Pipeline per device it was created for
+// (device_id >= 0: that device; -1: every visible device, sets dealt to the least-loaded pipeline - blocks are independent,
+// phaser.rs:406-411, so the node's GPUs need no exchange step; reference fan-out: main.rs:332-408, results re-ordered by
+// block index, writers/ordered_vcf_writer.rs:158-170); the per-block entries (hp_solve_blocks(1, ...), hp_block_submit) feed
+// the same pipelines through the dispatcher of hp_block.hip.
+//
+// Sets of one pipeline complete in submission order. `depth` slots hold the sets in flight; a slot keeps its host vectors and device buffers
 // from one set to the next (hipMalloc / hipFree synchronise the device). submit() blocks while every slot is taken - the
 // back-pressure the reference's bounded job queue applies (main.rs:362-383).
 #include "hp_block.h"
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +54,8 @@ struct Slot {
     hp_blockset bs;
     enum State { FREE, QUEUED, DONE } state = FREE;
     uint64_t ticket = 0;
+    hp_block_params prm{};   // the set's own parameters (the dispatcher merges callers with equal ones)
+    uint64_t load = 0;       // records of the set (what "least loaded" counts)
     size_t n_blocks = 0;
     const hp_block_input* in = nullptr;
     hp_block_output* out = nullptr;
@@ -57,9 +66,10 @@ struct Slot {
 
 }  // namespace
 
-struct hp_blockstream {
+struct hp::Pipeline {
     hp_block_params prm{};
     int device = 0;
+    uint64_t load = 0;   // records in flight (guarded by m)
     std::vector<std::unique_ptr<Slot>> slots;
     std::mutex m;
     std::condition_variable cv;
@@ -79,12 +89,12 @@ struct hp_blockstream {
     void stage_loop(int k);
 };
 
-void hp_blockstream::stage_thread(int t) {
+void hp::Pipeline::stage_thread(int t) {
     WorkerPool::set_thread_pool(pool[t].get());
     stage_loop(t < N_STAGES ? t : extra_stage);   // (the last thread: a second one for the alignment stage - or, as an experiment, the rows stage)
 }
 
-void hp_blockstream::stage_loop(int k) {
+void hp::Pipeline::stage_loop(int k) {
     (void)hipSetDevice(device);
     // CU partitions for the stages (hp_common.h) are an experiment switch, off by default. Measured on the bench workload: the
     // persistent graph-WFA kernels fill every compute unit (three wavefronts per SIMD is all their registers allow), so another
@@ -112,7 +122,7 @@ void hp_blockstream::stage_loop(int k) {
         s->t_begin[k] = st_now_ms();
         if (s->rc == HP_OK && s->n_blocks) {   // (an empty set, or one that failed an earlier stage, just travels on: tickets complete in order)
             int rc = HP_OK;
-            if (k == 0) rc = blockset_init(&s->bs, s->n_blocks, s->in, &prm, device);
+            if (k == 0) rc = blockset_init(&s->bs, s->n_blocks, s->in, &s->prm, device);
             else if (k == 1) rc = blockset_wfa(&s->bs);
             else if (k == 2) rc = blockset_rows(&s->bs);
             else if (k == 3) rc = blockset_pack(&s->bs);
@@ -132,35 +142,39 @@ void hp_blockstream::stage_loop(int k) {
     }
 }
 
-extern "C" hp_blockstream* hp_blockstream_create(const hp_block_params* p, int device_id, uint32_t depth, int* status) {
-    auto fail = [&](int rc) -> hp_blockstream* { if (status) *status = rc; return nullptr; };
+hp::Pipeline* hp::pipeline_create(const hp_block_params* p, int device_id, uint32_t depth, int* status) {
+    auto fail = [&](int rc) -> Pipeline* { if (status) *status = rc; return nullptr; };
     if (!p) { set_error("null argument"); return fail(HP_ERR_ARG); }
     if (hp_device_count() <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return fail(HP_ERR_HIP); }
     if (depth == 0) depth = 5;
     if (depth > 16) { set_error("depth %u: at most 16 block sets in flight", depth); return fail(HP_ERR_ARG); }
-    auto s = std::unique_ptr<hp_blockstream>(new hp_blockstream());
+    auto s = std::unique_ptr<Pipeline>(new Pipeline());
     s->prm = *p;
     s->device = device_id < 0 ? hp_default_device() : device_id;
+    if (s->device >= hp_device_count()) { set_error("device %d: %d visible", s->device, hp_device_count()); return fail(HP_ERR_ARG); }
     if (hipSetDevice(s->device) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", s->device); return fail(HP_ERR_HIP); }
     for (uint32_t i = 0; i < depth; ++i) s->slots.emplace_back(new Slot());
-    for (int k = 0; k < hp_blockstream::N_THREADS; ++k) s->pool[k].reset(new WorkerPool());
-    hp_blockstream* raw = s.get();
+    for (int k = 0; k < Pipeline::N_THREADS; ++k) s->pool[k].reset(new WorkerPool());
+    Pipeline* raw = s.get();
     // One thread per stage. Two experiment switches add a fifth thread: HP_STREAM_WFA_THREADS=2 (a second alignment thread with its
     // own streams and scratch, so that the next set's kernels are queued while this one's drain: measured 53 vs 48 ms per step,
     // slower) and HP_STREAM_ROWS_THREADS=2 (a second rows thread: 65 vs 50 ms, slower) - the device is the bottleneck, one more set
     // in flight only adds contention.
     const char* wt = std::getenv("HP_STREAM_WFA_THREADS");
     const char* rt = std::getenv("HP_STREAM_ROWS_THREADS");
-    int n_threads = hp_blockstream::N_THREADS;
+    int n_threads = Pipeline::N_THREADS;
     if (rt && std::atoi(rt) >= 2) s->extra_stage = 2;
-    else if (!(wt && std::atoi(wt) >= 2)) n_threads = hp_blockstream::N_STAGES;
+    else if (!(wt && std::atoi(wt) >= 2)) n_threads = Pipeline::N_STAGES;
+    g_pipelines.fetch_add(1);
     for (int k = 0; k < n_threads; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_thread(k); });
     if (status) *status = HP_OK;
     return s.release();
 }
 
-extern "C" int hp_blockstream_submit(hp_blockstream* s, size_t n_blocks, const hp_block_input* in, hp_block_output* out, uint64_t* ticket) {
+int hp::pipeline_submit(Pipeline* s, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, uint64_t* ticket) {
     if (!s || !ticket || (n_blocks && (!in || !out))) { set_error("null argument"); return HP_ERR_ARG; }
+    uint64_t load = 1;
+    for (size_t b = 0; b < n_blocks; ++b) load += in[b].n_records;
     std::unique_lock<std::mutex> lk(s->m);
     Slot* slot = nullptr;
     s->cv.wait(lk, [&]() {
@@ -169,6 +183,9 @@ extern "C" int hp_blockstream_submit(hp_blockstream* s, size_t n_blocks, const h
     });
     slot->state = Slot::QUEUED;
     slot->ticket = s->next_ticket++;
+    slot->prm = p ? *p : s->prm;
+    slot->load = load;
+    s->load += load;
     slot->n_blocks = n_blocks; slot->in = in; slot->out = out;
     slot->rc = HP_OK; slot->err.clear();
     slot->t_submit = st_now_ms();
@@ -178,7 +195,18 @@ extern "C" int hp_blockstream_submit(hp_blockstream* s, size_t n_blocks, const h
     return HP_OK;
 }
 
-extern "C" int hp_blockstream_wait(hp_blockstream* s, uint64_t ticket, double* stage_ms, uint64_t* work) {
+uint64_t hp::pipeline_load(Pipeline* s, bool* has_free_slot) {
+    std::unique_lock<std::mutex> lk(s->m);
+    if (has_free_slot) { *has_free_slot = false; for (auto& x : s->slots) if (x->state == Slot::FREE) *has_free_slot = true; }
+    return s->load;
+}
+
+void hp::pipeline_wait_free(Pipeline* s) {
+    std::unique_lock<std::mutex> lk(s->m);
+    s->cv.wait(lk, [&]() { for (auto& x : s->slots) if (x->state == Slot::FREE) return true; return false; });
+}
+
+int hp::pipeline_wait(Pipeline* s, uint64_t ticket, double* stage_ms, uint64_t* work) {
     if (!s) { set_error("null argument"); return HP_ERR_ARG; }
     std::unique_lock<std::mutex> lk(s->m);
     Slot* slot = nullptr;
@@ -206,12 +234,14 @@ extern "C" int hp_blockstream_wait(hp_blockstream* s, uint64_t ticket, double* s
         stage_ms[15] = (slot->t_end[3] - slot->t_begin[3]) + (slot->t_end[4] - slot->t_begin[4]);   // (pack + solve)
     }
     if (work) for (int i = 0; i < 8; ++i) work[i] = slot->bs.work[i];
+    slot->bs.in = nullptr;   // (nothing of the caller's is kept)
+    s->load -= slot->load;
     slot->state = Slot::FREE;
     s->cv.notify_all();
     return rc;
 }
 
-extern "C" void hp_blockstream_destroy(hp_blockstream* s) {
+void hp::pipeline_destroy(Pipeline* s) {
     if (!s) return;
     {
         std::unique_lock<std::mutex> lk(s->m);
@@ -225,5 +255,87 @@ extern "C" void hp_blockstream_destroy(hp_blockstream* s) {
     }
     if (std::getenv("HP_STREAM_TRACE")) fprintf(stderr, "[hp] device-wide waits for memory so far (hipMalloc / hipHostMalloc calls): %d\n", hp::g_device_syncing_allocs.load()), fprintf(stderr, "[hp] streams created by the library so far: %d (GPU_MAX_HW_QUEUES=%s)\n", hp::g_streams_created.load(), std::getenv("GPU_MAX_HW_QUEUES") ? std::getenv("GPU_MAX_HW_QUEUES") : "unset");
     for (auto& t : s->th) if (t.joinable()) t.join();
+    g_pipelines.fetch_sub(1);
+    delete s;
+}
+
+// ---- the public stream: one pipeline per device -------------------------------------------------------------------------------
+// device_id >= 0: that device. device_id == -1: every visible device (HP_STREAM_DEVICES=n: n pipelines, pipeline v on device
+// v % visible - the test hook for a box with fewer GPUs, as HP_QUEUE_WORKERS is for the dispatcher): a set goes to the pipeline
+// with the fewest records in flight among those with a free slot (the first one on ties, so one device behaves as before), and
+// submit blocks only while EVERY pipeline is full. Ticket = the pipeline's own ticket << 8 | pipeline: wait(ticket) finds its
+// set without a table; the sets of one device complete in order, a caller that waits in submission order (bench.py, the
+// INTEGRATION.md patch) gets its results in submission order.
+struct hp_blockstream {
+    std::vector<hp::Pipeline*> pipes;
+    std::mutex m;
+    std::condition_variable cv;   // a wait() freed a slot somewhere
+};
+
+extern "C" hp_blockstream* hp_blockstream_create(const hp_block_params* p, int device_id, uint32_t depth, int* status) {
+    auto fail = [&](int rc) -> hp_blockstream* { if (status) *status = rc; return nullptr; };
+    if (!p) { set_error("null argument"); return fail(HP_ERR_ARG); }
+    const int ndev = hp_device_count();
+    if (ndev <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return fail(HP_ERR_HIP); }
+    if (device_id >= ndev) { set_error("device %d: %d visible", device_id, ndev); return fail(HP_ERR_ARG); }
+    std::vector<int> devs;
+    if (device_id >= 0) devs.push_back(device_id);
+    else {
+        const char* e = std::getenv("HP_STREAM_DEVICES");
+        const int n = e ? std::max(1, std::min(64, std::atoi(e))) : ndev;
+        for (int v = 0; v < n; ++v) devs.push_back(v % ndev);
+    }
+    auto s = std::unique_ptr<hp_blockstream>(new hp_blockstream());
+    for (int d : devs) {
+        int rc = HP_OK;
+        hp::Pipeline* pl = hp::pipeline_create(p, d, depth, &rc);
+        if (!pl) { for (auto* x : s->pipes) hp::pipeline_destroy(x); return fail(rc); }
+        s->pipes.push_back(pl);
+    }
+    if (status) *status = HP_OK;
+    return s.release();
+}
+
+extern "C" int hp_blockstream_devices(const hp_blockstream* s) { return s ? (int)s->pipes.size() : 0; }
+
+extern "C" int hp_blockstream_submit(hp_blockstream* s, size_t n_blocks, const hp_block_input* in, hp_block_output* out, uint64_t* ticket) {
+    if (!s || !ticket || (n_blocks && (!in || !out))) { set_error("null argument"); return HP_ERR_ARG; }
+    size_t pick = 0;
+    if (s->pipes.size() > 1) {
+        std::unique_lock<std::mutex> lk(s->m);   // (one submitter at a time chooses: two must not both take the last free slot's pipeline)
+        for (;;) {
+            uint64_t best = UINT64_MAX;
+            bool any = false;
+            for (size_t k = 0; k < s->pipes.size(); ++k) {
+                bool free_slot = false;
+                const uint64_t l = hp::pipeline_load(s->pipes[k], &free_slot);
+                if (free_slot && l < best) { best = l; pick = k; any = true; }
+            }
+            if (any) break;
+            s->cv.wait_for(lk, std::chrono::milliseconds(2));   // every pipeline is full: the back-pressure of main.rs:362-383
+        }
+        uint64_t t = 0;
+        const int rc = hp::pipeline_submit(s->pipes[pick], n_blocks, in, nullptr, out, &t);   // (has a free slot: does not block)
+        if (rc == HP_OK) *ticket = (t << 8) | (uint64_t)pick;
+        return rc;
+    }
+    uint64_t t = 0;
+    const int rc = hp::pipeline_submit(s->pipes[0], n_blocks, in, nullptr, out, &t);
+    if (rc == HP_OK) *ticket = t << 8;
+    return rc;
+}
+
+extern "C" int hp_blockstream_wait(hp_blockstream* s, uint64_t ticket, double* stage_ms, uint64_t* work) {
+    if (!s) { set_error("null argument"); return HP_ERR_ARG; }
+    const size_t k = (size_t)(ticket & 0xFFu);
+    if (k >= s->pipes.size()) { set_error("hp_blockstream_wait: ticket %llu is not in flight", (unsigned long long)ticket); return HP_ERR_ARG; }
+    const int rc = hp::pipeline_wait(s->pipes[k], ticket >> 8, stage_ms, work);
+    if (s->pipes.size() > 1) { std::lock_guard<std::mutex> lk(s->m); s->cv.notify_all(); }
+    return rc;
+}
+
+extern "C" void hp_blockstream_destroy(hp_blockstream* s) {   // finishes the sets still in flight first
+    if (!s) return;
+    for (auto* p : s->pipes) hp::pipeline_destroy(p);
     delete s;
 }

@@ -258,6 +258,9 @@ struct W2Session {
 };
 
 int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
+    // a deferred late() of the previous run still writes the caller's result arrays and reads the tables laid out below: join it
+    // first, whatever path the caller took out of that run (its status belongs to that run, not to this one)
+    if (pend.on) (void)finish();
     jobs = jobs_; n = n_; bl_in = nullptr; bl_jobs = nullptr; need_unpack = false;
     if (n == 0) return HP_OK;
     if (!jobs) { set_error("null argument"); return HP_ERR_ARG; }
@@ -423,6 +426,7 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
 // once, hets then homs). Everything per job is independent of every other job, so layout, table fill and the staging copy
 // run on host threads; the reads are staged in pieces and each piece's DMA runs while the next one is being filled.
 int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2JobIn* jin, size_t n_, int device) {
+    if (pend.on) (void)finish();   // (as in prepare(): never lay a set out under a late pass that is still running)
     jobs = nullptr; bl_in = in; bl_jobs = jin; n = n_;
     h2d_bytes = 0; prep_ms[0] = prep_ms[1] = prep_ms[2] = prep_ms[3] = 0.0;
     if (n == 0) return HP_OK;

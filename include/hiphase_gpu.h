@@ -373,12 +373,27 @@ void hp_blockset_destroy(hp_blockset* bs);
  * from different threads. depth: 0 = 5. stage_ms (16 doubles, may be NULL): [0] overlaps + layout (host), [1] staging copy + PCIe
  * + base expansion, [2] graph-WFA stage, [3] fallback / replay / rows (host), [4] A* pack + upload, [5] A* solve, [6] post-processing
  * + outputs, [7] latency submit -> done, [8] graph-WFA kernels (HIP events), [9] A* kernels (HIP events), [10] bytes host -> device,
- * [11] time spent waiting between stages, [12..15] wall time of stage 1 (layout + PCIe) / 2 (graph-WFA) / 3 (rows) / 4 + 5 (A* pack; A* + post). work (8 values, may be NULL): as hp_blockset_work. */
+ * [11] time spent waiting between stages, [12..15] wall time of stage 1 (layout + PCIe) / 2 (graph-WFA) / 3 (rows) / 4 + 5 (A* pack; A* + post). work (8 values, may be NULL): as hp_blockset_work.
+ * device_id >= 0: one five-stage pipeline on that device. device_id == -1: one pipeline per visible device behind the same submit /
+ * wait - a set goes to the pipeline with the fewest records in flight, submit blocks only while every pipeline holds `depth` sets,
+ * the sets of one device complete in order (independent blocks: no exchange between devices; the reference's fan-out is
+ * main.rs:332-408, its writers re-order by block index, writers/ordered_vcf_writer.rs:158-170). hp_blockstream_devices: pipelines. */
 typedef struct hp_blockstream hp_blockstream;
 hp_blockstream* hp_blockstream_create(const hp_block_params* p, int device_id, uint32_t depth, int* status);
+int  hp_blockstream_devices(const hp_blockstream* s);
 int  hp_blockstream_submit(hp_blockstream* s, size_t n_blocks, const hp_block_input* in, hp_block_output* out, uint64_t* ticket);
 int  hp_blockstream_wait(hp_blockstream* s, uint64_t ticket, double* stage_ms, uint64_t* work);
 void hp_blockstream_destroy(hp_blockstream* s);   /* finishes the sets still in flight first */
+
+/* Asynchronous per-block entry. HiPhase keeps `job_slots = 40 x threads` phase blocks queued but only `threads` calls of
+ * solve_block in flight (src/main.rs:328,344-383); a worker that SUBMITS its block and goes on to load the next one keeps all of
+ * them in flight on the device side, where they are merged into block sets that travel through the same per-device pipelines as
+ * hp_blockstream_* (INTEGRATION.md 3c has the ~30-line main.rs patch). hp_block_submit queues n_blocks blocks (usually 1) and
+ * returns a ticket at once; hp_block_wait returns when their results are in `out` (same results and statuses as hp_solve_blocks)
+ * and consumes the ticket. `in`, everything it points at, and `out` must stay valid until the wait returns; any thread may wait.
+ * device_id: -1 = any visible device, >= 0 = that one. The blocking call hp_solve_blocks(1, ...) is submit + wait. */
+int hp_block_submit(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id, uint64_t* ticket);
+int hp_block_wait(uint64_t ticket);
 
 /* ---- misc --------------------------------------------------------------------------------- */
 int         hp_device_count(void);

@@ -83,8 +83,9 @@ def test_worker_pool_rate_from_cpp():
 @pytest.mark.parametrize("queue_devices", ["3", None])
 def test_worker_pool_through_the_block_entry_over_all_devices(queue_devices):
     """64 std::threads each calling hp_solve_blocks(1, ..., device_id = -1) - what the one-call-site Rust patch does from HiPhase's
-    worker pool - with the dispatcher's queue served by three "devices" (HP_QUEUE_WORKERS=3 on this 1-GPU box) and by the visible
-    ones: every block identical to one hp_solve_blocks call over all blocks (tests/cpp/dispatch_test.cpp); the rates are printed."""
+    worker pool - and then hp_block_submit / hp_block_wait with 40 tickets pending per thread (the asynchronous patch), with the
+    dispatcher's queue served by three "devices" (HP_QUEUE_WORKERS=3 on this 1-GPU box: three pipelines) and by the visible ones:
+    every block identical to one hp_solve_blocks call over all blocks (tests/cpp/dispatch_test.cpp); the rates are printed."""
     import json
     import os
     import subprocess
@@ -95,11 +96,12 @@ def test_worker_pool_through_the_block_entry_over_all_devices(queue_devices):
     env.pop("HP_QUEUE_WORKERS", None)
     if queue_devices:
         env["HP_QUEUE_WORKERS"] = queue_devices
-    r = subprocess.run([binp, "64", "4000"], capture_output=True, text=True, timeout=800, env=env)
+    r = subprocess.run([binp, "64", "4000", "300", "2"], capture_output=True, text=True, timeout=800, env=env)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["mismatching_blocks"] == 0 and out["failed_calls"] == 0 and out["blocks"] > 64
+    # blocking (T blocks in flight) and asynchronous (40 x T in flight) entries, every pass of both: identical to the one call
+    assert out["mismatching_blocks"] == 0 and out["failed_calls"] == 0 and out["blocks"] > 64 and out["async_hets_per_s"] > 0
 
 
 def test_concurrent_solve_blocks_is_merged_and_identical():

@@ -102,6 +102,97 @@ def test_blockstream_on_generated_sets_vs_oracle(monkeypatch):
         lib.hp_blockstream_destroy(stream)
 
 
+@pytest.mark.timeout(1200)
+def test_blockstream_over_all_devices_vs_oracle(monkeypatch):
+    """hp_blockstream_create(device_id = -1): one five-stage pipeline per device behind one submit / wait - here three of them
+    on this box's GPU (HP_STREAM_DEVICES=3, the hook HP_QUEUE_WORKERS is for the dispatcher). Eight sets, every one handed to the
+    least-loaded pipeline, waited for in submission order: every set's results equal the oracle's; every pipeline got work."""
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "256")
+    monkeypatch.setenv("HP_STREAM_DEVICES", "3")
+    lib = _ffi.lib()
+    prm = _params(2, 1000, 3, None, True)
+    sets = [SynthSet(default_spec(lib, total_hets=250 + 90 * k, seed=300 + k, seq_format=_ffi.SEQ_BAM4 if k % 2 else _ffi.SEQ_ASCII, **KW)) for k in range(8)]
+    exps = [oracle_outputs(s, prm) for s in sets]
+    st = C.c_int(0)
+    stream = lib.hp_blockstream_create(C.byref(prm), -1, 2, C.byref(st))
+    assert stream, lib.hp_last_error()
+    assert lib.hp_blockstream_devices(stream) == 3
+    used = set()
+    try:
+        outs = [s.outputs() for s in sets]
+        pending = []
+        for k, s in enumerate(sets):
+            if len(pending) == 5:
+                kk, t = pending.pop(0)
+                _ffi.check(lib.hp_blockstream_wait(stream, t, None, None))
+                assert [b for b in range(sets[kk].n) if not outs[kk].equal(exps[kk], b)] == []
+            t = C.c_uint64(0)
+            _ffi.check(lib.hp_blockstream_submit(stream, s.n, s.inputs, outs[k].arr, C.byref(t)))
+            used.add(t.value & 0xFF)
+            pending.append((k, t.value))
+        for kk, t in pending:
+            _ffi.check(lib.hp_blockstream_wait(stream, t, None, None))
+            assert [b for b in range(sets[kk].n) if not outs[kk].equal(exps[kk], b)] == []
+    finally:
+        lib.hp_blockstream_destroy(stream)
+    assert used == {0, 1, 2}
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("queue_devices", [None, "2"])
+def test_async_block_entry_vs_oracle(queue_devices, monkeypatch):
+    """hp_block_submit / hp_block_wait: every block of three generated sets submitted on its own (all of them in flight at once,
+    as HiPhase's 40 x threads job slots would be, main.rs:328), merged behind the call into sets that travel through the
+    per-device pipelines; waited for in reverse order. Every block equals the oracle's hpo_solve_block. Run in a subprocess per
+    queue configuration: the dispatcher reads HP_QUEUE_WORKERS once per process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = """
+import ctypes as C, json, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from hiphase_amd import _ffi
+from hiphase_amd.blocks import _params
+from hiphase_amd.synth_sets import SynthSet, default_spec
+from oracle_ffi import oracle
+lib = _ffi.lib()
+prm = _params(2, 1000, 3, None, True)
+KW = %r
+sets = [SynthSet(default_spec(lib, total_hets=400 + 150 * k, seed=500 + k, seq_format=_ffi.SEQ_BAM4, **KW)) for k in range(3)]
+d = oracle()
+bad, tickets, outs = [], [], []
+for s in sets:
+    out = s.outputs(); outs.append(out)
+    for b in range(s.n):
+        t = C.c_uint64(0)
+        _ffi.check(lib.hp_block_submit(1, C.byref(s.inputs[b]), C.byref(prm), C.byref(out.arr[b]), -1, C.byref(t)))
+        tickets.append(t.value)
+for t in reversed(tickets):
+    _ffi.check(lib.hp_block_wait(t))
+n = 0
+for s, out in zip(sets, outs):
+    exp = s.outputs()
+    for b in range(s.n):
+        assert d.hpo_solve_block(C.byref(s.inputs[b]), C.byref(prm), C.byref(exp.arr[b])) == 0
+        n += 1
+        if not out.equal(exp, b): bad.append(b)
+# an invalid device is an argument error, not another GPU's work (ADVICE r3)
+t = C.c_uint64(0)
+rc = lib.hp_block_submit(1, C.byref(sets[0].inputs[0]), C.byref(prm), C.byref(outs[0].arr[0]), 99, C.byref(t))
+print(json.dumps({"blocks": n, "bad": bad, "bad_device_rc": rc}))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), KW)
+    env = dict(os.environ)
+    env.pop("HP_QUEUE_WORKERS", None)
+    env["HP_WFA2_MIN_JOBS"] = "256"
+    if queue_devices:
+        env["HP_QUEUE_WORKERS"] = queue_devices
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1000, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["bad"] == [] and out["blocks"] > 10 and out["bad_device_rc"] == -4   # HP_ERR_ARG
+
+
 @pytest.mark.timeout(900)
 def test_hpbr_capture_replays_through_the_product_and_bench(tmp_path):
     """a `.hpbr` capture written with the oracle's results as expected output (standing in for a patched HiPhase's own
