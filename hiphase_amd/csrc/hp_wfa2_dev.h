@@ -295,6 +295,49 @@ template <int W, bool WIDE = false> struct W2Cfg {
     static constexpr int GROUP_DWORDS = SET_DWORDS + REC_DWORDS;
 };
 
+// ---- third generation (round 4): a round's waves as ONE FLAT SORTED LIST of (node, diagonal) slots --------------------------------
+// hp_wfa3_kernel.hip. A lockstep step of the second generation is one NODE's diagonals per group; a HiFi read's round holds a
+// dozen live slots spread over three or four nodes, so a round costs three or four steps with a third of the lanes busy. Here
+//   * a round's live waves are one list sorted by key = node << 19 | (diagonal + 2^18), 8 bytes a slot (key, offset << 3 | kind);
+//   * the next round's TARGET list is built from it in one pass (every live slot (n, d) emits (n, d - 1), (n, d), (n, d + 1) unless
+//     its predecessor already did): a target's candidates (d + 1: offset + 1, d: offset + 1, d - 1: offset) are the three list
+//     entries from its emitter on;
+//   * a step is a TILE of the next G targets whatever nodes they belong to: node descriptor, sequence pointer, capped-diagonal
+//     record per LANE;
+//   * waves that finish a node THIS round (wfa_graph.rs:527-553) become targets (child, diagonal + length) inserted into the
+//     sorted target list, or merged into the target that is already there. A tile that holds a finishing wave of node q only
+//     COMMITS its slots of nodes < min child(q) (node ids are topological: nothing before q's first child can be reached from q
+//     this round); the others stay targets and are computed again - with what the finished waves hand them - in the next tile.
+// Same results as the second generation by construction (same candidates, same decisions, per (node, diagonal)); tests/cpp/
+// wfa2_model.cpp holds a CPU model of this formulation too (w3m_wfa_assign) and tests/test_wfa2_model.py pins it to the oracle.
+constexpr uint32_t W3_DIAG_BIAS = 1u << 18;
+constexpr uint32_t W3_DIAG_MASK = (1u << 19) - 1u;
+HP_HD uint32_t w3_key(uint32_t node, int32_t diag) { return (node << 19) | (uint32_t)(diag + (int32_t)W3_DIAG_BIAS); }
+HP_HD uint32_t w3_key_node(uint32_t key) { return key >> 19; }
+HP_HD int32_t w3_key_diag(uint32_t key) { return (int32_t)(key & W3_DIAG_MASK) - (int32_t)W3_DIAG_BIAS; }
+// target aux word: back | src0 << 10 | src1 << 20 | start wave << 30. back = index (previous round's live list) of the target's
+// emitter; src = set-arena index of a wave that finished a parent this round and lands on this target; 0x3FF = none
+constexpr uint32_t W3_NONE = 0x3FFu;
+constexpr uint32_t W3_START = 1u << 30;
+HP_HD uint32_t w3_aux(uint32_t back, uint32_t src0, uint32_t src1) { return back | (src0 << 10) | (src1 << 20); }
+
+template <int W, bool WIDE = false> struct W3Cfg {
+    static constexpr int MAXN = 32 * W;
+    static constexpr int MAXE = 2 * MAXN + 32;
+    // slots per round: targets (consumed from the front) and live slots (appended behind them) share one array per round parity;
+    // the sets of waves that finished a node this round take the round's set arena from the top
+    static constexpr int SLOTS = WIDE ? W2_SLOTS_WIDE : (W <= 4 ? 96 : 160);
+    static constexpr int WAVES_PER_SIMD = W <= 4 ? 3 : 2;
+    static constexpr int a16(int x) { return (x + 15) & ~15; }
+    static constexpr int O_A = 0;                                   // uint2[2][SLOTS]
+    static constexpr int O_MISC = a16(O_A + 2 * 8 * SLOTS);          // outset[W]
+    static constexpr int BYTES = a16(O_MISC + 4 * W);
+    static constexpr int SET_DWORDS = 2 * SLOTS * W;                 // per group in HBM: the slots' traversed-node sets
+    static constexpr int REC_DWORDS = 4 * MAXN;                      // + one capped-diagonal record per node
+    static constexpr int GROUP_DWORDS = SET_DWORDS + REC_DWORDS;
+};
+static_assert(W2_SLOTS_WIDE < 0x3FF, "set-arena indices are 10 bits");
+
 struct W2Batch {
     const W2Job* jobs;
     const W2Info* info;

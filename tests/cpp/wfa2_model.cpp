@@ -258,6 +258,187 @@ int model_wfa(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t 
     }
 }
 
+// ---- third generation (hp_wfa3_kernel.hip): flat sorted slot lists, tiles of G targets over any nodes ------------------------------
+// Mirrors the kernel tile by tile: target list built from the previous round's live list, a tile = the next G targets, the commit
+// rule (only slots of nodes below the first child of a node that finished in the tile), finished waves inserted into / merged with
+// the sorted target list, live slots appended in key order, the finished waves' sets from the top of the round's set arena.
+template <int W, int G>
+int model_wfa3(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t prune, uint64_t max_ed, uint64_t* score, uint32_t* out_set) {
+    using C = W3Cfg<W>;
+    const uint32_t nn = b.info.n_nodes;
+    if (nn > (uint32_t)C::MAXN || b.info.n_edges > (uint32_t)C::MAXE || b.job.read_len >= (uint32_t)W2_DIAG_LIM) { g_reason[0]++; return W2_ST_NEED_BIG; }
+    const uint32_t other_len = b.job.read_len, last = nn - 1;
+    struct E2 { uint32_t x, y; };
+    std::vector<E2> A[2];
+    A[0].assign(C::SLOTS, E2{0, 0}); A[1].assign(C::SLOTS, E2{0, 0});
+    std::vector<uint32_t> sets[2];
+    sets[0].assign((size_t)C::SLOTS * W, 0); sets[1].assign((size_t)C::SLOTS * W, 0);
+    std::set<std::pair<uint32_t, int32_t>> capped;
+    for (int w = 0; w < W; ++w) out_set[w] = 0;
+    uint64_t farthest = 0, min_prog = 0;
+    uint32_t nl_prev = 0;
+    for (uint32_t ed = 0;; ++ed) {
+        const uint32_t c = ed & 1u, p = c ^ 1u;
+        uint32_t ip = 0, np = 0, nl = 0, nf = 0;
+        // ---- the round's targets ----
+        if (ed == 0) { A[c][0] = E2{w3_key(0, 0), w3_aux(W3_NONE, W3_NONE, W3_NONE) | W3_START}; np = 1; }
+        else {
+            uint32_t prevkey = 0xFFFFFFFFu;
+            for (uint32_t i = 0; i < nl_prev; ++i) {
+                const uint32_t key = A[p][i].x;
+                const bool same = prevkey != 0xFFFFFFFFu && w3_key_node(prevkey) == w3_key_node(key);
+                const int32_t gap = same ? w3_key_diag(key) - w3_key_diag(prevkey) : 1 << 30;
+                const int cnt = gap == 1 ? 1 : (gap == 2 ? 2 : 3);
+                const uint32_t n = w3_key_node(key);
+                const int32_t d = w3_key_diag(key);
+                for (int t = 2 - cnt; t < 2; ++t) {   // targets d - 1 (cnt 3), d (cnt >= 2), d + 1
+                    const int32_t td = d - 1 + t + (cnt == 3 ? 0 : 0);
+                    (void)td;
+                }
+                for (int j = 0; j < cnt; ++j) {
+                    const int32_t td = d + 1 - (cnt - 1) + j;   // cnt 3: d-1, d, d+1; cnt 2: d, d+1; cnt 1: d+1
+                    if (td <= -W2_DIAG_LIM || td >= W2_DIAG_LIM) { g_reason[3]++; return W2_ST_NEED_BIG; }
+                    if (np >= (uint32_t)C::SLOTS) { g_reason[2]++; return W2_ST_NEED_BIG; }
+                    A[c][np++] = E2{w3_key(n, td), w3_aux(i, W3_NONE, W3_NONE)};
+                }
+                prevkey = key;
+            }
+        }
+        bool final_found = false;
+        uint64_t round_far = 0;
+        uint32_t steps = 0;
+        while (ip < np) {
+            if (++steps > 100000) return W2_ST_INTERNAL;
+            const uint32_t tn = std::min<uint32_t>((uint32_t)G, np - ip);
+            struct Res { uint32_t n; int32_t d; bool has; uint32_t E, kind; bool is_final, ins; uint32_t best[W]; uint64_t pos_end; uint32_t len; };
+            std::vector<Res> R(tn);
+            uint32_t X = 0xFFFFFFFFu;
+            for (uint32_t l = 0; l < tn; ++l) {
+                const E2 tgt = A[c][ip + l];
+                Res& r = R[l];
+                const uint32_t n = w3_key_node(tgt.x);
+                const int32_t d = w3_key_diag(tgt.x);
+                r.n = n; r.d = d;
+                const W2Node nd = b.nodes[n];
+                const uint32_t len = nd.len_ref & ~W2_IS_REF;
+                r.len = len;
+                const uint8_t* nseq = (nd.len_ref & W2_IS_REF) ? ref + nd.seq_off : b.pool.data() + nd.seq_off;
+                int64_t oA = -1, oB = -1, oC = -1;
+                const uint32_t *qA = nullptr, *qB = nullptr, *qC = nullptr;
+                const uint32_t back = tgt.y & 0x3FFu, src0 = (tgt.y >> 10) & 0x3FFu, src1 = (tgt.y >> 20) & 0x3FFu;
+                if (back != W3_NONE)
+                    for (uint32_t k = back; k < back + 3 && k < nl_prev; ++k) {
+                        const E2 e = A[p][k];
+                        if (w3_key_node(e.x) != n) continue;
+                        const int32_t dd = w3_key_diag(e.x);
+                        const uint32_t kd = e.y & 7u;
+                        const uint32_t* q = &sets[p][(size_t)k * W];
+                        if (dd == d + 1) { if (kd & 1u) { oA = (int64_t)(e.y >> 3) + 1; qA = q; } }
+                        else if (dd == d) { if (kd == W2_KIND_INTERIOR_READ) { oB = (int64_t)(e.y >> 3) + 1; qB = q; } }
+                        else if (dd == d - 1) { if (kd == W2_KIND_INTERIOR_READ || kd == W2_KIND_END_LAST) { oC = (int64_t)(e.y >> 3); qC = q; } }
+                    }
+                uint32_t qD[W];
+                for (int w = 0; w < W; ++w) qD[w] = 0;
+                bool hinj = (tgt.y & W3_START) != 0;
+                if (src0 != W3_NONE) { hinj = true; for (int w = 0; w < W; ++w) qD[w] |= sets[c][(size_t)src0 * W + w]; }
+                if (src1 != W3_NONE) { hinj = true; for (int w = 0; w < W; ++w) qD[w] |= sets[c][(size_t)src1 * W + w]; }
+                if (hinj) qD[n >> 5] |= 1u << (n & 31u);
+                r.has = oA >= 0 || oB >= 0 || oC >= 0 || hinj;
+                r.kind = W2_KIND_NONE; r.E = 0; r.is_final = false; r.ins = false; r.pos_end = 0;
+                for (int w = 0; w < W; ++w) r.best[w] = 0;
+                if (!r.has) continue;
+                const int64_t omax = std::max(std::max(oA, oB), std::max(oC, hinj ? (int64_t)0 : (int64_t)-1));
+                auto extend = [&](int64_t o) -> int64_t {
+                    int64_t pos = (int64_t)d + o;
+                    while (o < (int64_t)len && pos >= 0 && pos < (int64_t)other_len && nseq[o] == read[pos]) { ++o; ++pos; }
+                    return o;
+                };
+                const int64_t E = extend(omax);
+                auto ties = [&](int64_t o) -> bool { if (o < 0) return false; if (o == omax) return true; return extend(o) == E; };
+                const bool tA = ties(oA), tB = ties(oB), tC = ties(oC), tD = hinj && ties(0);
+                const int64_t pos_end = (int64_t)d + E;
+                const int64_t cap = std::min<int64_t>((int64_t)len, (int64_t)other_len - (int64_t)d);
+                const bool is_capped = capped.count({n, d}) != 0;
+                for (int w = 0; w < W; ++w) r.best[w] = (tA ? qA[w] : 0u) | (tB ? qB[w] : 0u) | (tC ? qC[w] : 0u) | (tD ? qD[w] : 0u);
+                r.is_final = n == last && E == (int64_t)len && pos_end == (int64_t)other_len;
+                const bool skip = (is_capped && E < cap) || (pos_end < (int64_t)min_prog);
+                if (!skip) {
+                    r.ins = E == cap && !is_capped;
+                    if (E == (int64_t)len) {
+                        if (n == last) { if (pos_end < (int64_t)other_len) r.kind = W2_KIND_END_LAST; }
+                        else r.kind = W2_KIND_FINISHED;
+                    } else r.kind = (pos_end < (int64_t)other_len) ? W2_KIND_INTERIOR_READ : W2_KIND_INTERIOR;
+                    r.pos_end = (uint64_t)pos_end;
+                }
+                r.E = (uint32_t)E;
+                if (r.kind == W2_KIND_FINISHED) X = std::min(X, nd.c01 & 0xFFFFu);   // its first child (ids ascend with creation)
+            }
+            // ---- commit: the slots of nodes below X (a prefix of the tile: targets are sorted) ----
+            uint32_t ncommit = 0;
+            while (ncommit < tn && R[ncommit].n < X) ++ncommit;
+            if (ncommit == 0) return W2_ST_INTERNAL;
+            const uint32_t ip_next = ip + ncommit;
+            for (uint32_t l = 0; l < ncommit; ++l) {
+                const Res& r = R[l];
+                if (!r.has) continue;
+                if (r.is_final) { final_found = true; for (int w = 0; w < W; ++w) out_set[w] |= r.best[w]; }
+                if (r.kind == W2_KIND_NONE) continue;
+                if (r.pos_end > round_far) round_far = r.pos_end;
+                if (r.ins) capped.insert({r.n, r.d});
+                if (r.kind == W2_KIND_FINISHED) {
+                    if (nl + nf + 1 > (uint32_t)C::SLOTS) { g_reason[2]++; return W2_ST_NEED_BIG; }
+                    const uint32_t si = (uint32_t)C::SLOTS - 1u - nf;
+                    ++nf;
+                    for (int w = 0; w < W; ++w) sets[c][(size_t)si * W + w] = r.best[w];
+                    const W2Node nd = b.nodes[r.n];
+                    const uint32_t n_child = nd.child & 0xFFFFu;
+                    uint32_t scan = nd.child >> 16;
+                    for (uint32_t j = 0; j < n_child; ++j) {
+                        const uint32_t cid = j == 0 ? (nd.c01 & 0xFFFFu) : (j == 1 ? (nd.c01 >> 16) : w2_next_child(b.edges.data(), r.n, scan));
+                        const int32_t td = r.d + (int32_t)r.len;
+                        if (td <= -W2_DIAG_LIM || td >= W2_DIAG_LIM) { g_reason[3]++; return W2_ST_NEED_BIG; }
+                        const uint32_t key = w3_key(cid, td);
+                        uint32_t pos = ip_next;
+                        while (pos < np && A[c][pos].x < key) ++pos;
+                        if (pos < np && A[c][pos].x == key) {
+                            uint32_t& y = A[c][pos].y;
+                            if (((y >> 10) & 0x3FFu) == W3_NONE) y = (y & ~(0x3FFu << 10)) | (si << 10);
+                            else if (((y >> 20) & 0x3FFu) == W3_NONE) y = (y & ~(0x3FFu << 20)) | (si << 20);
+                            else {   // a third wave onto one target (rare): its set and the second one's are merged into a fresh arena entry
+                                if (nl + nf + 1 > (uint32_t)C::SLOTS) { g_reason[2]++; return W2_ST_NEED_BIG; }
+                                const uint32_t sm = (uint32_t)C::SLOTS - 1u - nf;
+                                ++nf;
+                                const uint32_t s1 = (y >> 20) & 0x3FFu;
+                                for (int w = 0; w < W; ++w) sets[c][(size_t)sm * W + w] = sets[c][(size_t)s1 * W + w] | sets[c][(size_t)si * W + w];
+                                y = (y & ~(0x3FFu << 20)) | (sm << 20);
+                            }
+                        } else {
+                            if (np >= (uint32_t)C::SLOTS) { g_reason[2]++; return W2_ST_NEED_BIG; }
+                            for (uint32_t k = np; k > pos; --k) A[c][k] = A[c][k - 1];
+                            A[c][pos] = E2{key, w3_aux(W3_NONE, si, W3_NONE)};
+                            ++np;
+                        }
+                    }
+                } else {
+                    if (nl + nf + 1 > (uint32_t)C::SLOTS || nl >= ip_next) { g_reason[2]++; return W2_ST_NEED_BIG; }
+                    for (int w = 0; w < W; ++w) sets[c][(size_t)nl * W + w] = r.best[w];
+                    A[c][nl] = E2{w3_key(r.n, r.d), (r.E << 3) | r.kind};
+                    ++nl;
+                }
+            }
+            ip = ip_next;
+            g_peak[1] = std::max<uint64_t>(g_peak[1], np);
+        }
+        g_peak[3] += steps;
+        if (final_found) { *score = ed; return W2_ST_OK; }
+        if (round_far > farthest) farthest = round_far;
+        if (farthest > prune) min_prog = farthest - prune;
+        if ((uint64_t)ed + 1 > max_ed) { *score = max_ed; return W2_ST_MAX_ED; }
+        if (nl == 0) return W2_ST_INTERNAL;
+        nl_prev = nl;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -280,6 +461,30 @@ int w2m_wfa_assign(const hp_wfa_job* job, uint64_t prune_distance, uint64_t max_
     if (b.info.n_nodes <= 64) st = model_wfa<2>(b, ref, job->read, prune_distance, max_ed, &score, set);
     else if (b.info.n_nodes <= 128) st = model_wfa<4>(b, ref, job->read, prune_distance, max_ed, &score, set);
     else if (b.info.n_nodes <= 256) st = model_wfa<8>(b, ref, job->read, prune_distance, max_ed, &score, set);
+    else { st = W2_ST_NEED_BIG; g_reason[5]++; }
+    if (st == W2_ST_NEED_BIG) { *path = 1; return 0; }
+    if (st != W2_ST_OK && st != W2_ST_MAX_ED) return HP_ERR_INVARIANT;
+    out->status = st == W2_ST_OK ? HP_OK : HP_WFA_MAX_ED;
+    out->n_nodes = b.info.n_nodes;
+    out->score = score;
+    w2_map_alleles(b.tags.data(), b.info.n_tags, set, st == W2_ST_OK, alleles, job->n_hets);
+    return 0;
+}
+
+// the third-generation formulation (flat sorted slot lists), same contract
+int w3m_wfa_assign(const hp_wfa_job* job, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* alleles, int* path) {
+    Built b;
+    build_from_job(job, b);
+    *path = 0;
+    if (b.info.status == W2B_NEED_HOST) { *path = 2; return 0; }
+    if (b.info.status != W2B_OK) return HP_ERR_INVARIANT;
+    const uint8_t* ref = job->reference + (job->ref_start - job->ref_base);
+    uint64_t score = 0;
+    uint32_t set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int st;
+    if (b.info.n_nodes <= 64) st = model_wfa3<2, 8>(b, ref, job->read, prune_distance, max_ed, &score, set);
+    else if (b.info.n_nodes <= 128) st = model_wfa3<4, 8>(b, ref, job->read, prune_distance, max_ed, &score, set);
+    else if (b.info.n_nodes <= 256) st = model_wfa3<8, 16>(b, ref, job->read, prune_distance, max_ed, &score, set);
     else { st = W2_ST_NEED_BIG; g_reason[5]++; }
     if (st == W2_ST_NEED_BIG) { *path = 1; return 0; }
     if (st != W2_ST_OK && st != W2_ST_MAX_ED) return HP_ERR_INVARIANT;

@@ -27,12 +27,17 @@ def model():
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src], check=True)
     d = C.CDLL(so)
     d.w2m_wfa_assign.restype = C.c_int
+    d.w3m_wfa_assign.restype = C.c_int
     return d
 
 
-def compare(specs, prune, max_ed, m=None, d=None):
+GEN = 2   # which formulation compare() holds to the oracle: 2 = per-node hull arenas (hp_wfa2_kernel), 3 = flat sorted slot lists (hp_wfa3_kernel)
+
+
+def compare(specs, prune, max_ed, m=None, d=None, gen=None):
     m = m or model()
     d = d or oracle()
+    assign = m.w3m_wfa_assign if (gen or GEN) == 3 else m.w2m_wfa_assign
     paths = [0, 0, 0]
     for i, spec in enumerate(specs):
         jobs, keep = make_jobs([spec])
@@ -42,7 +47,7 @@ def compare(specs, prune, max_ed, m=None, d=None):
         a2 = np.full(max(1, len(spec.hets)), 3, np.uint8)
         assert d.hpo_wfa_assign(C.byref(jobs[0]), C.c_uint64(pr), C.c_uint64(max_ed), C.byref(o1), C.c_void_p(a1.ctypes.data)) == 0
         path = C.c_int(0)
-        rc = m.w2m_wfa_assign(C.byref(jobs[0]), C.c_uint64(pr), C.c_uint64(max_ed), C.byref(o2), C.c_void_p(a2.ctypes.data), C.byref(path))
+        rc = assign(C.byref(jobs[0]), C.c_uint64(pr), C.c_uint64(max_ed), C.byref(o2), C.c_void_p(a2.ctypes.data), C.byref(path))
         assert rc == 0, (i, rc)
         paths[path.value] += 1
         if path.value != 0:
@@ -52,21 +57,24 @@ def compare(specs, prune, max_ed, m=None, d=None):
     return paths
 
 
+@pytest.mark.parametrize("gen", [2, 3])
 @pytest.mark.parametrize("case", [c for c in G["variant_built"] if c["queries"]], ids=lambda c: c["name"])
-def test_golden_variant_graphs(case):
+def test_golden_variant_graphs(case, gen):
     specs = [spec_from_golden(case, read=bytes(q["seq"])) for q in case["queries"]]
-    paths = compare(specs, 0, 1000)
+    paths = compare(specs, 0, 1000, gen=gen)
     assert paths[0] == len(specs)
 
 
-def test_random_jobs_default_params():
+@pytest.mark.parametrize("gen", [2, 3])
+def test_random_jobs_default_params(gen):
     specs = [synth_wfa_job(seed, ref_len=3000 + 37 * seed, n_vars=6 + seed % 9, noise=0.003 + 0.001 * (seed % 5))[0]
              for seed in range(1, 49)]
-    paths = compare(specs, 500, 500)
+    paths = compare(specs, 500, 500, gen=gen)
     assert paths[0] >= 40, paths
 
 
-def test_random_jobs_wide_parameters():
+@pytest.mark.parametrize("gen", [2, 3])
+def test_random_jobs_wide_parameters(gen):
     r = _Rng(77)
     m, d = model(), oracle()
     tot = [0, 0, 0]
@@ -78,6 +86,6 @@ def test_random_jobs_wide_parameters():
             L = [200, 600, 2000, 6000][r.randint(0, 3)]
             specs.append(synth_wfa_job(r.next(), ref_len=max(L, 800), n_vars=r.randint(0, 24), n_homs=r.randint(0, 6),
                                        noise=[0.0, 0.002, 0.01, 0.03][r.randint(0, 3)], multiallelic=0.3)[0])
-        p = compare(specs, prune, max_ed, m, d)
+        p = compare(specs, prune, max_ed, m, d, gen=gen)
         tot = [a + b for a, b in zip(tot, p)]
     assert tot[0] > 60, tot   # the rest outgrew the compact state (no pruning / heavy noise): dense-band kernel
