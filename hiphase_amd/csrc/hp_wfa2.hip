@@ -10,6 +10,7 @@
 //   5. reads that outgrow the compact state or the device builder's fixed queues (W2_ST_NEED_BIG / W2B_NEED_HOST)
 //      are re-run by the dense-band path of hp_wfa.hip (host graph build + hp_wfa_kernel). Same results either way.
 #include "hp_wfa2_kernel.hip"
+#include "hp_wfa3_kernel.hip"
 #include "hp_wfa2_host.h"
 
 #include <algorithm>
@@ -49,6 +50,7 @@ struct W2Context {
     DevBuf htab;             // capped-diagonal hash sets, [groups][1 << W2_HCAP_LOG2]; zeroed once, then tagged
     DevBuf gsets;            // [groups][W2_SET_STRIDE_MAX] the arena slots' traversed-node sets
     uint32_t htab_groups = 0;
+    int last_gen = 0;        // kernel generation of the last run on this scratch (the generations lay a group's region out differently)
     // scratch regions: [0], [1] the two smaller classes (htab_groups groups each, their own set strides), [2..4] the largest class
     // (large_groups groups each; three, taken in turns by consecutive runs)
     uint32_t large_groups = 0;
@@ -129,11 +131,22 @@ void merge_ranges(std::vector<std::pair<const uint8_t*, uint64_t>>& iv, std::vec
 }
 // one region of `max_groups` groups per class in htab / gsets: the class launches run concurrently
 // group_jobs > 0: a group leaves after that many jobs, the grid covers the list (at most max_groups groups: the scratch regions)
+// which kernel generation aligns the classes: 3 = flat sorted slot lists (hp_wfa3_kernel.hip, round 4), 2 = per-node hull arenas
+// (hp_wfa2_kernel.hip). HP_WFA_GEN=2 keeps the second generation selectable (A/B runs, the parity tests run both).
+int w2_gen() {
+    const char* e = std::getenv("HP_WFA_GEN");   // (read per call: tests switch it inside one process)
+    return (e && e[0] == '2') ? 2 : 3;
+}
+template <int W, bool WIDE = false> constexpr size_t w2_group_dwords() {   // scratch per resident group: what either generation needs
+    return W2Cfg<W, WIDE>::GROUP_DWORDS > W3Cfg<W, WIDE>::GROUP_DWORDS ? (size_t)W2Cfg<W, WIDE>::GROUP_DWORDS : (size_t)W3Cfg<W, WIDE>::GROUP_DWORDS;
+}
+template <int G, int W, bool WIDE = false> size_t w2_lds_bytes(int gen) {
+    return (size_t)(gen == 3 && G <= 16 ? W3Cfg<W, WIDE>::BYTES : W2Cfg<W, WIDE>::BYTES) * (64 / G);
+}
 template <int G, int W, bool WIDE = false> uint32_t w2_grid(uint32_t n_items, int n_cu, uint32_t max_groups, uint32_t group_jobs = 0) {
-    using C = W2Cfg<W, WIDE>;
     constexpr uint32_t NG = 64 / G;
     if (group_jobs) return std::max<uint32_t>(1u, std::min<uint32_t>((n_items + NG * group_jobs - 1) / (NG * group_jobs), max_groups / NG));
-    const size_t lds = (size_t)C::BYTES * NG;
+    const size_t lds = w2_lds_bytes<G, W, WIDE>(w2_gen());
     const size_t lds_alloc = (lds + 1279) / 1280 * 1280;   // gfx950 allocates LDS in 1280-byte granules
     uint32_t per_cu = (uint32_t)std::min<size_t>(32, (160 * 1024) / lds_alloc);
     if (const char* e = std::getenv("HP_WFA2_PER_CU")) per_cu = std::max(1, std::min((int)per_cu, std::atoi(e)));
@@ -142,16 +155,26 @@ template <int G, int W, bool WIDE = false> uint32_t w2_grid(uint32_t n_items, in
     return grid == 0 ? 1u : grid;
 }
 template <int G, int W, bool WIDE = false> int w2_launch(const W2Batch& B, uint32_t n_items, int n_cu, uint32_t max_groups, hipStream_t st, uint32_t* groups_used) {
-    using C = W2Cfg<W, WIDE>;
     constexpr uint32_t NG = 64 / G;
-    const size_t lds = (size_t)C::BYTES * NG;
+    const int gen = G <= 16 ? w2_gen() : 2;
+    const size_t lds = w2_lds_bytes<G, W, WIDE>(gen);
     const uint32_t grid = w2_grid<G, W, WIDE>(n_items, n_cu, max_groups, B.group_jobs);
-    static std::atomic<bool> attr_set{false};   // (per instantiation)
-    if (lds > 64 * 1024 || !attr_set.load()) {
-        HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_kernel<G, W, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set.store(true);
+    static std::atomic<int> attr_set{0};   // (per instantiation; bit g: generation g)
+    if (lds > 64 * 1024 || !(attr_set.load() & (1 << gen))) {
+        if constexpr (G <= 16) {
+            if (gen == 3) HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa3_kernel<G, W, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (gen == 2) HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_kernel<G, W, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.fetch_or(1 << gen);
     }
     *groups_used = grid * NG;
+    if constexpr (G <= 16) {
+        if (gen == 3) {
+            hipLaunchKernelGGL((hp_wfa3_kernel<G, W, WIDE>), dim3(grid), dim3(64), lds, st, B);
+            HP_HIP_CHECK(hipGetLastError());
+            return HP_OK;
+        }
+    }
     hipLaunchKernelGGL((hp_wfa2_kernel<G, W, WIDE>), dim3(grid), dim3(64), lds, st, B);
     HP_HIP_CHECK(hipGetLastError());
     return HP_OK;
@@ -239,6 +262,7 @@ struct W2Session {
     } pend;
     DevBuf d_job_cls, d_handed, d_seen, d_held, d_hoff, d_hrec, d_hrows, d_wide, d_wide_sets, d_wide_hash;
     uint32_t wide_tag_next = 0;
+    int wide_last_gen = 0;
     PinBuf late_down;                      // results of the held jobs
     std::unique_ptr<HelperThread> helper;  // runs late() when run() defers
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build start / end, class launches start / end
@@ -693,7 +717,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     // capped-diagonal hash sets: one per resident group, kept (and never cleared) across calls
     const uint32_t max_groups = (uint32_t)n_cu * 96u;   // per class: up to 12 resident workgroups of 8 groups per CU
     const uint32_t large_groups = (uint32_t)n_cu * 40u;    // the largest class: at most 10 workgroups of 4 groups per CU
-    const size_t set_dwords = (size_t)max_groups * (W2Cfg<2>::GROUP_DWORDS + W2Cfg<4>::GROUP_DWORDS) + (size_t)3 * large_groups * W2Cfg<8>::GROUP_DWORDS;
+    const size_t set_dwords = (size_t)max_groups * (w2_group_dwords<2>() + w2_group_dwords<4>()) + (size_t)3 * large_groups * w2_group_dwords<8>();
     const size_t hash_groups = (size_t)2 * max_groups + (size_t)3 * large_groups;
     if (cx.htab_groups < max_groups) {
         if ((rc = cx.htab.alloc((hash_groups << W2_HCAP_LOG2) * 8)) != HP_OK) return rc;
@@ -701,13 +725,13 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, (hash_groups << W2_HCAP_LOG2) * 8, st));
         HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, set_dwords * 4, st));   // (the capped records carry tags too)
         cx.htab_groups = max_groups; cx.large_groups = large_groups; cx.tag_next = 0;
-        cx.region_set_off[0] = 0; cx.region_set_off[1] = (size_t)max_groups * W2Cfg<2>::GROUP_DWORDS;
-        cx.region_set_off[2] = cx.region_set_off[1] + (size_t)max_groups * W2Cfg<4>::GROUP_DWORDS;
+        cx.region_set_off[0] = 0; cx.region_set_off[1] = (size_t)max_groups * w2_group_dwords<2>();
+        cx.region_set_off[2] = cx.region_set_off[1] + (size_t)max_groups * w2_group_dwords<4>();
         cx.region_hash_off[0] = 0; cx.region_hash_off[1] = max_groups; cx.region_hash_off[2] = (size_t)2 * max_groups;
-        for (int r = 3; r < 5; ++r) { cx.region_set_off[r] = cx.region_set_off[r - 1] + (size_t)large_groups * W2Cfg<8>::GROUP_DWORDS; cx.region_hash_off[r] = cx.region_hash_off[r - 1] + large_groups; }
+        for (int r = 3; r < 5; ++r) { cx.region_set_off[r] = cx.region_set_off[r - 1] + (size_t)large_groups * w2_group_dwords<8>(); cx.region_hash_off[r] = cx.region_hash_off[r - 1] + large_groups; }
     }
     if ((rc = d_qhead.alloc(512)) != HP_OK) return rc;
-    if ((uint64_t)cx.tag_next + n + 2 >= 0xFFFFFFF0ull) {
+    if ((uint64_t)cx.tag_next + n + 2 >= 0xFFFFFFF0ull || (cx.last_gen != 0 && cx.last_gen != w2_gen())) {   // (tags wrap; or the other generation's words could pass for tags)
         (void)hipStreamSynchronize(cs_->cstream[2]); (void)hipStreamSynchronize(cs_->c2x[0]); (void)hipStreamSynchronize(cs_->c2x[1]);   // (an earlier run's tail may still use its region)
         HP_HIP_CHECK(hipMemsetAsync(cx.htab.p, 0, (hash_groups << W2_HCAP_LOG2) * 8, st));
         HP_HIP_CHECK(hipMemsetAsync(cx.gsets.p, 0, set_dwords * 4, st));
@@ -718,6 +742,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     }
     if (!cx.cfork) HP_HIP_CHECK(hipEventCreateWithFlags(&cx.cfork, hipEventDisableTiming));
     HP_HIP_CHECK(hipMemsetAsync(d_qhead.p, 0, 512, st));   // work-queue heads at dword 16 k, class counts at dwords 64..67
+    cx.last_gen = w2_gen();
     const uint32_t tag_base = cx.tag_next;
     cx.tag_next += (uint32_t)n + 1u;
     uint32_t* d_counts = d_qhead.as<uint32_t>() + 64;
@@ -752,7 +777,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     uint32_t groups_used[3] = {0, 0, 0};
     W2Batch pend_b2 = B;   // what the largest class was launched with (late() may launch it once more)
     { const size_t region = 2u + turn; pend_b2.htab = cx.htab.as<uint64_t>() + (cx.region_hash_off[region] << W2_HCAP_LOG2); pend_b2.gsets = cx.gsets.as<uint32_t>() + cx.region_set_off[region];
-      pend_b2.set_stride = (uint32_t)W2Cfg<8>::GROUP_DWORDS; pend_b2.esc = d_esc; pend_b2.esc_order = d_order.as<uint32_t>() + (size_t)2 * n; pend_b2.handed = d_handed.as<uint8_t>(); }
+      pend_b2.set_stride = (uint32_t)w2_group_dwords<8>(); pend_b2.esc = d_esc; pend_b2.esc_order = d_order.as<uint32_t>() + (size_t)2 * n; pend_b2.handed = d_handed.as<uint8_t>(); }
     const uint32_t cls_cnt[3] = {cls_n[0], cls_n[1], cls_n[2]};
     const char* genv = std::getenv("HP_WFA2_G");   // experiment: lanes per read for the middle class
     const int gsel = genv ? std::atoi(genv) : 8;
@@ -807,7 +832,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         B.next = d_qhead.as<uint32_t>() + 16 * k;
         B.htab = cx.htab.as<uint64_t>() + (cx.region_hash_off[region] << W2_HCAP_LOG2);
         B.gsets = cx.gsets.as<uint32_t>() + cx.region_set_off[region];
-        B.set_stride = k == 0 ? (uint32_t)W2Cfg<2>::GROUP_DWORDS : k == 1 ? (uint32_t)W2Cfg<4>::GROUP_DWORDS : (uint32_t)W2Cfg<8>::GROUP_DWORDS;
+        B.set_stride = k == 0 ? (uint32_t)w2_group_dwords<2>() : k == 1 ? (uint32_t)w2_group_dwords<4>() : (uint32_t)w2_group_dwords<8>();
         B.esc = d_esc; B.esc_order = d_order.as<uint32_t>() + (size_t)2 * n; B.handed = d_handed.as<uint8_t>();
         B.esc_role = !escalate ? 0u : (k == 2 ? 2u : 1u);
         B.esc_producers = grid_wg[0] + grid_wg[1];
@@ -1042,11 +1067,12 @@ int W2Session::late() {
             if ((rc = dev_put(d_wide.p, up.data(), up.size() * 4, s2)) != HP_OK) return rc;
             // scratch of its own (the session's; wider sets than the class regions of the context), its own tags
             const uint32_t wide_groups = (uint32_t)pend.n_cu * 28u;   // 7 workgroups of 4 groups per CU (LDS)
-            const size_t group_dwords = wide16 ? (size_t)W2Cfg<16, true>::GROUP_DWORDS : (size_t)W2Cfg<8, true>::GROUP_DWORDS;
+            const size_t group_dwords = wide16 ? w2_group_dwords<16, true>() : w2_group_dwords<8, true>();
             const size_t wset = (size_t)wide_groups * group_dwords * 4, whash = ((size_t)wide_groups << W2_HCAP_LOG2) * 8;
             const bool fresh = !d_wide_sets.p || d_wide_sets.bytes < wset || !d_wide_hash.p || d_wide_hash.bytes < whash;
             if ((rc = d_wide_sets.alloc(wset)) != HP_OK || (rc = d_wide_hash.alloc(whash)) != HP_OK) return rc;
-            if (fresh || (uint64_t)wide_tag_next + n + 2 >= 0xFFFFFFF0ull) {
+            if (fresh || (uint64_t)wide_tag_next + n + 2 >= 0xFFFFFFF0ull || wide_last_gen != w2_gen()) {
+                wide_last_gen = w2_gen();
                 HP_HIP_CHECK(hipMemsetAsync(d_wide_sets.p, 0, wset, s2));
                 HP_HIP_CHECK(hipMemsetAsync(d_wide_hash.p, 0, whash, s2));
                 wide_tag_next = 0;

@@ -1,0 +1,559 @@
+// hp_wfa3_kernel.hip — graph-WFA (unit costs, end-to-end) on gfx950, third generation: A ROUND'S WAVES AS ONE FLAT SORTED LIST.
+//
+// Replaces, bit-identically, reference src/wfa_graph.rs:350-650 `edit_distance_with_pruning`, as hp_wfa2_kernel.hip does; same
+// batch layout, same job lists, same hand-over protocol between the graph-size classes, same capped-diagonal records (W2Batch,
+// hp_wfa2_dev.h) - a drop-in for the class launches of hp_wfa2.hip. What changed is the shape of a lockstep step.
+//
+// Second generation: a step = one NODE's diagonals for each group of G lanes. A HiFi read's round holds a dozen live (node,
+// diagonal) slots spread over three or four nodes: three or four steps a round with a third of the lanes holding a wave, and a
+// state machine per group (entries, clusters, hulls, items, pending queue) that is uniform within a group but differs between the
+// groups of a wavefront - vector code, 290 instructions per group and node visit (profiles/round3/wfa2_phases.txt).
+// Here (W3Cfg, hp_wfa2_dev.h; CPU model: tests/cpp/wfa2_model.cpp `model_wfa3`, pinned to the oracle):
+//   * a round's live waves are ONE list sorted by key = node << 19 | diagonal + 2^18, 8 bytes a slot in LDS (key, offset << 3 | kind),
+//     their traversed-node sets in HBM at the same index;
+//   * the next round's TARGETS are built from it in one pass: slot (n, d) emits (n, d - 1), (n, d), (n, d + 1) unless its
+//     predecessor in the list did; a target's candidates (wfa_graph.rs:555-573 turned into a pull: d + 1 -> offset + 1,
+//     d -> offset + 1, d - 1 -> offset) are among the three list entries from its emitter on;
+//   * a step is a TILE of the next G targets whatever nodes they belong to: the node descriptor, the sequence pointer and the
+//     capped-diagonal record are per LANE (a vector load costs the same whether its lanes read one address or eight);
+//   * a wave that finishes its node (wfa_graph.rs:527-553: the children take it up THIS round at offset 0) becomes a target
+//     (child, diagonal + node length) inserted into the sorted target list, or joins the target that is already there. Nodes must
+//     still be taken in index order within a round: a tile that holds a finishing wave of node q COMMITS only its slots of nodes
+//     below q's first child (ids are topological - nothing before that child can be reached from q this round); the rest stay
+//     targets and are computed again, with what the finished waves hand them, by the next tile. Progress: q itself commits.
+// Nothing else is new: candidates, tie rule, capped diagonals instead of max_wavefronts, pruning, finals are the second
+// generation's, per (node, diagonal) - the results are the same set of slots with the same contents, found in fewer steps.
+// Integer / byte work, no MFMA; bound by instruction issue, hence fewer, fuller steps.
+#include "hp_common.h"
+#include "hp_wfa2_dev.h"
+
+namespace hp {
+
+// Lanes with done == false have matched their first n bytes of their node (at global offset nb + o) against read[pos..] and may match
+// up to maxlen: the group serves them one after the other, G x 32 bytes per pass. The serving lane's node address travels (two
+// dwords), its read offset and what is left. `on`: this group takes part (group-uniform).
+template <int G> W2DEV uint32_t w3_match_rest(const uint8_t* seq, uint64_t nb, const uint8_t* readp, uint32_t o, int32_t pos, uint32_t maxlen, uint32_t n, bool done,
+                                              bool on, uint32_t gbase, uint32_t gl) {
+    constexpr uint32_t LB = W2_MATCH_LANE_BYTES;
+    bool pending = on && !done;
+    while (__any(pending)) {
+        const uint64_t gb = w2_gballot<G>(pending, gbase);
+        const bool active = gb != 0;
+        const uint32_t L = active ? (uint32_t)__builtin_ctzll(gb) : 0u;
+        const uint64_t a = nb + o + n;
+        const uint32_t alo = w2_gsel<G>((uint32_t)a, gl, L), ahi = w2_gsel<G>((uint32_t)(a >> 32), gl, L);
+        const uint32_t sp = w2_gsel<G>((uint32_t)pos + n, gl, L), rem = w2_gsel<G>(maxlen - n, gl, L);
+        const uint8_t* pa = seq + (((uint64_t)ahi << 32) | alo);
+        const uint8_t* pb = readp + sp;
+        const uint32_t off = gl * LB;
+        uint32_t m = LB;
+        if (active) {
+            if (off < rem) {
+                uint4 x[LB / 16], y[LB / 16];
+#pragma unroll
+                for (uint32_t k = 0; k < LB / 16; ++k) { x[k] = w2_ld16(pa + off + 16 * k); y[k] = w2_ld16(pb + off + 16 * k); }
+                m = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < LB / 16; ++k) if (m == 16u * k) m += w2_pfx16(x[k], y[k]);
+                if (m > rem - off) m = rem - off;
+            } else m = 0u;   // beyond the end: acts as a stop
+        }
+        const uint64_t stop = w2_gballot<G>(active && m < LB, gbase);
+        uint32_t got = (uint32_t)G * LB;
+        if (stop) {
+            const uint32_t S = (uint32_t)__builtin_ctzll(stop);
+            got = S * LB + w2_gsel<G>(m, gl, S);
+        }
+        if (got > rem) got = rem;
+        if (active && gl == L) {
+            n += got;
+            if (stop || n >= maxlen) pending = false;
+        }
+    }
+    return n;
+}
+
+// bits of `m` (a group's ballot) below this lane
+W2DEV uint32_t w3_below(uint64_t m, uint32_t gl) { return (uint32_t)__popcll(m & ((1ull << gl) - 1ull)); }
+
+template <int G, int W, bool WIDE = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W>::WAVES_PER_SIMD, W3Cfg<W>::WAVES_PER_SIMD))) hp_wfa3_kernel(W2Batch B) {
+    using C = W3Cfg<W, WIDE>;
+    static_assert(G >= 8 && G <= 16 && (G & (G - 1)) == 0, "group size");
+    static_assert(W <= G, "one lane per set word in the cooperative set merges");
+    constexpr uint32_t NG = 64 / G;
+    constexpr uint32_t SL = (uint32_t)C::SLOTS;
+    const uint32_t lane = w2_lane(), gid = lane / G, gl = lane % G, gbase = gid * G;
+    unsigned char* R = w2_smem + (size_t)gid * C::BYTES;
+    uint2* A = reinterpret_cast<uint2*>(R + C::O_A);                 // [parity * SLOTS + i]: targets (from ip on) and live slots (from 0 on)
+    uint32_t* outset = reinterpret_cast<uint32_t*>(R + C::O_MISC);
+
+    const uint32_t slot = blockIdx.x * NG + gid;
+    uint64_t* htab = B.htab + ((size_t)slot << B.hcap_log2);
+    uint32_t* gs = B.gsets + (size_t)slot * B.set_stride;            // [(parity * SLOTS + s) * W], then the capped records
+    const uint32_t hmask = (1u << B.hcap_log2) - 1u;
+    const uint32_t prune32 = B.prune_distance > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)B.prune_distance;
+    const uint32_t maxed32 = B.max_ed > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (uint32_t)B.max_ed;
+
+    // ---- group-uniform state ---------------------------------------------------------------------------------------------------
+    enum : uint32_t { S_JOB = 0, S_ROUND = 1, S_WAIT = 2, S_TILE = 3, S_DONE = 4 };
+    uint32_t state = S_JOB, jround = 0, job = 0, ticket = 0, idle_polls = 0;
+    bool have_ticket = false;
+    uint32_t poll_div = 0;
+    uint32_t n_nodes = 0, last = 0, other_len = 0, tag = 0;
+    uint64_t ref_off = 0;                                            // of the job's reference window in seq[]
+    const uint8_t* readp = B.seq;
+    const W2Node* gnode = B.nodes; const uint16_t* gedge = B.edges;
+    uint32_t ed = 0, c = 0, p = 1, ip = 0, np = 0, nl = 0, nf = 0, nl_prev = 0;
+    uint32_t farthest = 0, min_prog = 0;
+    bool final_found = false;
+    int32_t status = W2_ST_PENDING;
+    uint32_t score = 0, steps = 0, why = 0;
+    uint32_t lane_far = 0, lane_upd = 0;                             // per lane
+    const uint32_t n_class = *B.n_items_dev;
+    if (B.esc_role == 1u) (void)atomicAdd(B.esc + 4, lane == 0 ? 1u : 0u);   // a producer workgroup has started
+
+    for (;;) {
+        // ============================ 1. control: advance every group to its next tile ===========================================
+        uint32_t spins = 0;
+        if (B.esc_role == 2u && __any(state == S_WAIT) && (!__any(state == S_TILE) || (++poll_div & 15u) == 0u)) {
+            const uint32_t gone = atomicAdd(B.esc + 2, 0u);
+            W2_WAIT_VM();
+            const uint32_t pub = atomicAdd(B.esc + 1, 0u);
+            bool alone = false;
+            if (idle_polls > 750u && gone == 0u) alone = atomicAdd(B.esc + 4, 0u) == 0u;
+            if (state == S_WAIT) {
+                if (pub > ticket) { state = S_JOB; have_ticket = true; }
+                else if (gone >= B.esc_producers || alone) state = S_DONE;
+            }
+        }
+        while (state != S_TILE && state != S_DONE && state != S_WAIT) {
+            if (++spins > (1u << 20)) { state = S_DONE; break; }   // cannot happen; never hang the device
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (state == S_JOB) {
+                if (status != W2_ST_PENDING) {   // results of the job that just ended
+                    const uint32_t upd = w2_gsum<G>(lane_upd);
+                    bool handed_over = false;
+                    // worth handing over: what the largest class's bigger tables fix (the slot lists) - not a full capped set
+                    const bool hand = status == W2_ST_NEED_BIG && why == 8u;
+                    if (B.esc_role == 1u && __any(hand)) {
+                        const uint32_t taken = atomicAdd(B.esc, 0u);
+                        const bool me = hand && gl == 0 && taken < B.esc_limit;
+                        const uint32_t pos = atomicAdd(B.esc, me ? 1u : 0u);
+                        (void)atomicExch(me ? B.esc_order + pos : B.esc + 3, me ? job : 0u);
+                        if (me) B.handed[job] = 1;   // (never written by anyone else: hp_wfa2_map_kernel)
+                        W2_WAIT_VM();
+                        bool pend = me;
+                        for (uint32_t s = 0; s < (1u << 16) && __any(pend); ++s) {
+                            const uint32_t seen = atomicCAS(pend ? B.esc + 1 : B.esc + 3, pend ? pos : 0xFFFFFFFFu, pend ? pos + 1u : 0xFFFFFFFFu);
+                            if (pend && seen == pos) pend = false;
+                        }
+                        handed_over = w2_gballot<G>(me, gbase) != 0;
+                    }
+                    if (!handed_over && gl == 0) { B.status[job] = status; B.out_score[job] = status == W2_ST_NEED_BIG ? (uint64_t)(why | (ed << 8)) : score; B.out_work[(size_t)job * 2] = upd; }
+                    if (!handed_over && gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
+                    status = W2_ST_PENDING;
+                }
+                if (B.group_jobs != 0u && B.esc_role != 2u && jround >= B.group_jobs) { state = S_DONE; break; }
+                const uint32_t mine = atomicAdd(B.next, (gl == 0 && !have_ticket) ? 1u : 0u);   // (every lane takes part: no one-lane branch)
+                const uint32_t k = have_ticket ? ticket : w2_gsel<G>(mine, gl, 0u);
+                jround++;
+                if (B.esc_role == 2u) {
+                    if (!have_ticket && k >= n_class) {
+                        const uint32_t pub = atomicAdd(B.esc + 1, 0u);
+                        if (k >= pub) { ticket = k; state = S_WAIT; break; }
+                    }
+                    have_ticket = false;
+                    job = k < n_class ? B.order[k] : atomicAdd(B.esc_order + k, 0u);
+                } else {
+                    if (k >= n_class) { state = S_DONE; break; }
+                    job = B.order[k];
+                }
+                const W2Job jd = B.jobs[job];
+                const W2Info ji = B.info[job];
+                n_nodes = ji.n_nodes; last = n_nodes - 1u; other_len = jd.read_len;
+                ref_off = jd.ref_off; readp = B.seq + jd.read_off;
+                tag = B.tag_base + job + 1u;
+                if (gl < (uint32_t)W) outset[gl] = 0u;
+                score = 0;
+                if (n_nodes == 0 || n_nodes > (uint32_t)C::MAXN || ji.n_edges > (uint32_t)C::MAXE || other_len >= (uint32_t)W2_DIAG_LIM) {
+                    status = W2_ST_NEED_BIG, why = 4u;
+                    continue;   // stays in S_JOB: the next pass writes this status and fetches the next job
+                }
+                gnode = B.nodes + jd.node_off;
+                gedge = B.edges + jd.edge_off;
+                // the start wave (wfa_graph.rs:366-378): the only target of round 0
+                ed = 0; c = 0; p = 1; ip = 0; np = 1; nl = 0; nf = 0; nl_prev = 0; steps = 0;
+                if (gl == 0) A[0] = make_uint2(w3_key(0u, 0), w3_aux(W3_NONE, W3_NONE, W3_NONE) | W3_START);
+                farthest = 0; min_prog = 0; final_found = false; lane_far = 0; lane_upd = 0;
+                state = S_TILE;
+                continue;
+            }
+            // ---- state == S_ROUND: end of round (wfa_graph.rs:633-648), then the next round's targets ----
+            {
+                const uint32_t far = (uint32_t)w2_gmax<G>((int32_t)lane_far);
+                lane_far = 0;
+                if (final_found) { status = W2_ST_OK; score = ed; state = S_JOB; continue; }
+                if (far > farthest) farthest = far;
+                if (farthest > prune32) min_prog = farthest - prune32;
+                if (ed + 1u > maxed32) { status = W2_ST_MAX_ED; score = maxed32; state = S_JOB; continue; }
+                if (nl == 0u) { status = W2_ST_INTERNAL; state = S_JOB; continue; }
+                ++ed; p = c; c ^= 1u; nl_prev = nl; nl = 0; nf = 0; ip = 0; np = 0;
+                // every live slot (n, d) emits the targets (n, d - 1), (n, d), (n, d + 1) its predecessor has not emitted
+                uint32_t carry = 0xFFFFFFFFu;
+                bool over = false;
+#pragma clang loop unroll(disable)
+                for (uint32_t base = 0; base < nl_prev; base += (uint32_t)G) {
+                    const uint32_t i = base + gl;
+                    const bool valid = i < nl_prev;
+                    const uint32_t key = valid ? A[p * SL + i].x : 0xFFFFFFFFu;
+                    uint32_t prevkey = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)key, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+                    if (gl == 0) prevkey = carry;
+                    const uint32_t nn = w3_key_node(key);
+                    const int32_t d = w3_key_diag(key);
+                    const bool same = prevkey != 0xFFFFFFFFu && w3_key_node(prevkey) == nn;
+                    const int32_t gap = same ? d - w3_key_diag(prevkey) : 3;
+                    const bool c1 = valid && gap >= 2, c2 = valid && gap >= 3;
+                    const uint64_t mv = w2_gballot<G>(valid, gbase), m1 = w2_gballot<G>(c1, gbase), m2 = w2_gballot<G>(c2, gbase);
+                    const uint32_t excl = w3_below(mv, gl) + w3_below(m1, gl) + w3_below(m2, gl);
+                    const uint32_t total = (uint32_t)(__popcll(mv) + __popcll(m1) + __popcll(m2));
+                    if (np + total > SL) { over = true; break; }
+                    if (valid) {
+                        const uint32_t cnt = 1u + (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
+                        const uint32_t at = c * SL + np + excl;
+                        const uint32_t aux = w3_aux(i, W3_NONE, W3_NONE);
+                        // cnt 3: d - 1, d, d + 1; cnt 2: d, d + 1; cnt 1: d + 1
+                        if (c2) A[at] = make_uint2(w3_key(nn, d - 1), aux);
+                        if (c1) A[at + cnt - 2u] = make_uint2(w3_key(nn, d), aux);
+                        A[at + cnt - 1u] = make_uint2(w3_key(nn, d + 1), aux);
+                        if (d - 1 <= -W2_DIAG_LIM || d + 1 >= W2_DIAG_LIM) over = true;
+                    }
+                    np += total;
+                    carry = w2_gsel<G>(key, gl, (uint32_t)G - 1u);   // (0xFFFFFFFF when the chunk is not full: it was the last one)
+                }
+                if (w2_gballot<G>(over, gbase)) { status = W2_ST_NEED_BIG, why = 8u; state = S_JOB; continue; }
+                state = S_TILE;
+            }
+        }
+        if (!__any(state == S_TILE)) {
+            if (!__any(state == S_WAIT)) break;   // every group is done
+            if (++idle_polls > 60000u) break;     // (~1.5 s of nothing to do: never hang the device; unclaimed jobs stay for the host's pass)
+            for (int z = 0; z < 8; ++z) __builtin_amdgcn_s_sleep(127);
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        // ============================ 2. one tile: the next G targets of the round ===============================================
+        const bool run = state == S_TILE;
+        const uint32_t pbase = p * SL, cbase = c * SL;
+        const bool act = run && ip + gl < np;
+        const uint2 tgt = act ? A[cbase + ip + gl] : make_uint2(0u, w3_aux(W3_NONE, W3_NONE, W3_NONE));
+        const uint32_t n = w3_key_node(tgt.x);
+        const int32_t d = act ? w3_key_diag(tgt.x) : 0;
+        const uint32_t back = tgt.y & 0x3FFu, src0 = (tgt.y >> 10) & 0x3FFu, src1 = (tgt.y >> 20) & 0x3FFu;
+        // the node of this lane's target: 16 bytes from HBM (L2-resident)
+        uint4 nd = make_uint4(0, 0, 0, 0);
+        if (act) nd = *reinterpret_cast<const uint4*>(gnode + n);
+        // the node's capped-diagonal record (neighbouring nodes share a line)
+        uint4 crec = make_uint4(0, 0, 0, 0);
+        if (act) crec = *reinterpret_cast<const uint4*>(gs + C::SET_DWORDS + 4u * n);
+        // ---- candidates from the previous round: the three live slots from the emitter on ----
+        int32_t oA = -1, oB = -1, oC = -1;
+        int32_t sA = -1, sB = -1, sC = -1;   // their slots (= set indices)
+        if (act && back != W3_NONE) {
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) {
+                const uint32_t j = back + k;
+                if (j < nl_prev) {
+                    const uint2 e = A[pbase + j];
+                    const int32_t rel = (int32_t)e.x - (int32_t)tgt.x;   // same node: the difference of the diagonals (keys are node << 19 | diagonal + bias)
+                    const uint32_t kd = e.y & 7u;
+                    if (rel == 1) { if (kd & 1u) { oA = (int32_t)(e.y >> 3) + 1; sA = (int32_t)j; } }
+                    else if (rel == 0) { if (kd == W2_KIND_INTERIOR_READ) { oB = (int32_t)(e.y >> 3) + 1; sB = (int32_t)j; } }
+                    else if (rel == -1) { if (kd == W2_KIND_INTERIOR_READ || kd == W2_KIND_END_LAST) { oC = (int32_t)(e.y >> 3); sC = (int32_t)j; } }
+                }
+            }
+        }
+        const W2Set<W> qA = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sA, 0)) * W, sA >= 0);
+        const W2Set<W> qB = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sB, 0)) * W, sB >= 0);
+        const W2Set<W> qC = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sC, 0)) * W, sC >= 0);
+        // ---- waves that finished a parent THIS round (offset 0; wfa_graph.rs:527-553), and the start wave ----
+        const bool hinj = act && ((tgt.y & W3_START) != 0u || src0 != W3_NONE);
+        W2Set<W> qD = w2_ldset<W>(gs + (size_t)(cbase + (src0 != W3_NONE ? src0 : 0u)) * W, act && src0 != W3_NONE);
+        {
+            const W2Set<W> t = w2_ldset<W>(gs + (size_t)(cbase + (src1 != W3_NONE ? src1 : 0u)) * W, act && src1 != W3_NONE);
+#pragma unroll
+            for (int w = 0; w < W; ++w) qD.w[w] |= t.w[w];
+        }
+        const uint32_t len = nd.y & ~W2_IS_REF;
+        const uint64_t nb = ((nd.y & W2_IS_REF) ? ref_off : B.alt_off) + nd.x;   // the node's sequence in seq[]
+        const uint8_t* nseq = B.seq + nb;
+        const bool has = act && (oA >= 0 || oB >= 0 || oC >= 0 || hinj);
+        int32_t omax = max(max(oA, oB), max(oC, hinj ? 0 : -1));
+        if (!has) omax = 0;
+        // ---- extend the furthest candidate; the others tie iff they match the read up to its start -----------------
+        const int32_t pos0 = d + omax;   // >= 0 for real candidates
+        uint32_t room = 0;
+        if (has) {
+            const uint32_t rn = len - (uint32_t)omax;
+            const uint32_t rr = (pos0 >= 0 && (uint32_t)pos0 < other_len) ? other_len - (uint32_t)pos0 : 0u;
+            room = min(rn, rr);
+        }
+        bool tA = has && oA == omax, tB = has && oB == omax, tC = has && oC == omax;
+        bool tD = has && hinj && omax == 0;
+        // (when the furthest is this diagonal's own wave - B: offset + 1 of a wave that stopped on a mismatch at offset omax - 1 of
+        // this very diagonal - every other candidate would have to match through that position: none ties, nothing to check)
+        const bool chk = has && !tB;
+        const bool nA = chk && oA >= 0 && oA < omax, nB = chk && oB >= 0 && oB < omax, nC = chk && oC >= 0 && oC < omax;
+        const bool nD = chk && hinj && omax > 0;
+        const uint8_t* ra = readp + (has ? pos0 : 0);
+        const uint8_t* na_ = nseq + (has ? omax : 0);
+        const W2Pre pm = w2_pre(na_, ra, room > 0);
+        const W2Pre8 pA = w2_pre8(nseq + (nA ? oA : 0), readp + (nA ? d + oA : 0), nA);
+        const W2Pre8 pB = w2_pre8(nseq + (nB ? oB : 0), readp + (nB ? d + oB : 0), nB);
+        const W2Pre8 pC = w2_pre8(nseq + (nC ? oC : 0), readp + (nC ? d + oC : 0), nC);
+        const W2Pre8 pD = w2_pre8(nseq, readp + (nD ? d : 0), nD);
+        uint32_t E;
+        {
+            uint32_t n0 = 0;
+            bool done = (room == 0);
+            if (!done) {
+                uint32_t m = w2_pfx16(pm.a, pm.b);
+                if (m > room) m = room;
+                n0 = m;
+                if (m < 16 || n0 >= room) done = true;
+            }
+            E = (uint32_t)omax + w3_match_rest<G>(B.seq, nb, readp, (uint32_t)omax, pos0, room, n0, done, run, gbase, gl);
+        }
+        {
+            bool pdA = false, pdB = false, pdC = false, pdD = false;
+            auto quick = [&](const W2Pre8& q, bool nX, int32_t oX, bool& pend8) -> bool {
+                if (!nX) return false;
+                const uint32_t g = (uint32_t)(omax - oX), m = w2_pfx8(q.a, q.b);
+                if (g <= 8u) return m >= g;
+                pend8 = (m == 8u);
+                return false;
+            };
+            const bool xA = quick(pA, nA, oA, pdA), xB = quick(pB, nB, oB, pdB), xC = quick(pC, nC, oC, pdC), xD = quick(pD, nD, 0, pdD);
+            tA = tA || xA; tB = tB || xB; tC = tC || xC; tD = tD || xD;
+            if (__any(pdA || pdB || pdC || pdD)) {
+                // the long compare only decides whether the candidate's traversed nodes join the slot's set: one whose set adds
+                // nothing to what the tied candidates bring already (the usual case: the same path, a diagonal over) needs none
+                bool addA = false, addB = false, addC = false, addD = false;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    uint32_t dset = qD.w[w];
+                    if ((n >> 5) == (uint32_t)w) dset |= 1u << (n & 31u);
+                    const uint32_t known = (tA ? qA.w[w] : 0u) | (tB ? qB.w[w] : 0u) | (tC ? qC.w[w] : 0u) | (tD ? dset : 0u);
+                    addA = addA || (qA.w[w] & ~known); addB = addB || (qB.w[w] & ~known); addC = addC || (qC.w[w] & ~known); addD = addD || (dset & ~known);
+                }
+                pdA = pdA && addA; pdB = pdB && addB; pdC = pdC && addC; pdD = pdD && addD;
+            }
+            if (__any(pdA || pdB || pdC || pdD)) {   // rare: a long alternative run onto the furthest wave's diagonal
+                auto slow = [&](bool pd, int32_t oX) -> bool {
+                    const uint32_t g = pd ? (uint32_t)(omax - oX) : 0u;
+                    const uint32_t mr = w3_match_rest<G>(B.seq, nb, readp, (uint32_t)(pd ? oX : 0), pd ? d + oX : 0, g, pd ? 8u : 0u, !pd, run, gbase, gl);
+                    return pd && mr == g;
+                };
+                const bool yA = slow(pdA, oA), yB = slow(pdB, oB), yC = slow(pdC, oC), yD = slow(pdD, 0);
+                tA = tA || yA; tB = tB || yB; tC = tC || yC; tD = tD || yD;
+            }
+        }
+        // ---- capped-diagonal set: is (n, d) recorded? ---------------------------------------------------------------------------
+        const bool rec_live = crec.x == tag;
+        const uint32_t rel = (uint32_t)(d - (int32_t)crec.y + 32);
+        const bool in_win = rec_live && rel < 64u;
+        bool capped = in_win && (((rel < 32u ? crec.z : crec.w) >> (rel & 31u)) & 1u);
+        bool hfull = false;
+        const bool use_hash = has && rec_live && !in_win;
+        if (__any(use_hash)) {
+            if (use_hash) {
+                const uint64_t key = ((uint64_t)tag << 32) | ((uint64_t)(n & 0x3FFu) << 18) | (uint64_t)((uint32_t)d & 0x3FFFFu);
+                uint32_t hp = (n * 0x9E3779B1u + (uint32_t)d) & hmask, probes = 0;
+                uint64_t e = htab[hp];
+#pragma clang loop unroll(disable)
+                while (e != key && (uint32_t)(e >> 32) == tag) {
+                    if (++probes > 24u) { hfull = true; break; }
+                    hp = (hp + 1u) & hmask;
+                    e = htab[hp];
+                }
+                capped = e == key;
+            }
+        }
+        // ---- decide (wfa_graph.rs:463-474) -------------------------------------------------------------------------------------
+        const int32_t pos_end = has ? d + (int32_t)E : 0;
+        const int32_t cap = min((int32_t)len, (int32_t)other_len - d);
+        const bool is_final = has && n == last && E == len && (uint32_t)pos_end == other_len;
+        uint32_t kind = W2_KIND_NONE;
+        bool ins = false, counts_far = false;
+        if (has) {
+            const bool skip = (capped && (int32_t)E < cap) || ((uint32_t)pos_end < min_prog);
+            if (!skip) {
+                counts_far = true;
+                ins = (int32_t)E == cap && !capped && !hfull;
+                if (E == len) {
+                    if (n == last) { if ((uint32_t)pos_end < other_len) kind = W2_KIND_END_LAST; }
+                    else kind = W2_KIND_FINISHED;
+                } else kind = ((uint32_t)pos_end < other_len) ? W2_KIND_INTERIOR_READ : W2_KIND_INTERIOR;
+            }
+        }
+        // ---- commit: the slots of nodes below the first child of every node that finished in this tile (a prefix of the tile) ----
+        const bool fin = kind == W2_KIND_FINISHED;
+        const uint32_t X = (uint32_t)w2_gmin<G>(fin ? (int32_t)(nd.w & 0xFFFFu) : 0x7FFFFFFF);
+        const bool commit = act && n < X;
+        const uint32_t ncommit = (uint32_t)__popcll(w2_gballot<G>(commit, gbase));
+        const bool live_k = commit && kind != W2_KIND_NONE && !fin, fin_k = commit && fin;
+        const uint64_t ml = w2_gballot<G>(live_k, gbase), mf = w2_gballot<G>(fin_k, gbase);
+        const uint32_t lpos = nl + w3_below(ml, gl), fpos = SL - 1u - (nf + w3_below(mf, gl));
+        const uint32_t nlive = (uint32_t)__popcll(ml), nfin = (uint32_t)__popcll(mf);
+        if (run && nl + nlive + nf + nfin > SL) status = W2_ST_NEED_BIG, why = 8u;
+        if (__any(hfull && commit)) { if (w2_gballot<G>(hfull && commit, gbase)) status = W2_ST_NEED_BIG, why = 9u; }
+        const bool ok = status == W2_ST_PENDING;
+        // ---- this round's slots: offset | kind and the union of the tied sets -------------------------------------------------
+        W2Set<W> best;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            uint32_t dset = qD.w[w];
+            if (hinj && (n >> 5) == (uint32_t)w) dset |= 1u << (n & 31u);   // best + the successor (wfa_graph.rs:535-541)
+            best.w[w] = (tA ? qA.w[w] : 0u) | (tB ? qB.w[w] : 0u) | (tC ? qC.w[w] : 0u) | (tD ? dset : 0u);
+        }
+        if (ok && live_k) {
+            A[cbase + lpos] = make_uint2(tgt.x, (E << 3) | kind);
+            w2_stset<W>(gs + (size_t)(cbase + lpos) * W, best);
+        }
+        if (ok && fin_k) w2_stset<W>(gs + (size_t)(cbase + fpos) * W, best);
+        if (commit) {
+            lane_upd += has ? 1u : 0u;
+            if (counts_far && (uint32_t)pos_end > lane_far) lane_far = (uint32_t)pos_end;
+        }
+        // ---- record newly capped diagonals (committed slots only; the lanes of one node share its record) ----------------------
+        bool later = false;
+        {
+            bool pend_ins = commit && ins && ok;
+            while (__any(pend_ins)) {
+                const uint64_t im = w2_gballot<G>(pend_ins, gbase);
+                if (im) {   // (group-uniform)
+                    const uint32_t L = (uint32_t)__builtin_ctzll(im);
+                    const uint32_t nL = w2_gsel<G>(n, gl, L);
+                    const uint32_t liveL = w2_gsel<G>(rec_live ? 1u : 0u, gl, L);
+                    const int32_t anchor = (int32_t)w2_gsel<G>(liveL ? crec.y : (uint32_t)d, gl, L);
+                    const bool mine = pend_ins && n == nL;
+                    const uint32_t r2 = (uint32_t)(d - anchor + 32);
+                    const bool inw = mine && r2 < 64u;
+                    later = later || (mine && !inw);
+                    const uint32_t lo = w2_gor<G>(inw && r2 < 32u ? 1u << r2 : 0u), hi = w2_gor<G>(inw && r2 >= 32u ? 1u << (r2 - 32u) : 0u);
+                    if (gl == L) *reinterpret_cast<uint4*>(gs + C::SET_DWORDS + 4u * n) = make_uint4(tag, (uint32_t)anchor, (rec_live ? crec.z : 0u) | lo, (rec_live ? crec.w : 0u) | hi);
+                    pend_ins = pend_ins && !mine;
+                }
+            }
+        }
+        if (__any(later)) {
+            while (__any(later)) {
+                const uint64_t lm = __ballot(later);
+                const int L = __builtin_ctzll(lm);
+                if ((int)lane == L) {
+                    const uint64_t key = ((uint64_t)tag << 32) | ((uint64_t)(n & 0x3FFu) << 18) | (uint64_t)((uint32_t)d & 0x3FFFFu);
+                    uint32_t hp = (n * 0x9E3779B1u + (uint32_t)d) & hmask, probes = 0;
+                    uint64_t e = htab[hp];
+#pragma clang loop unroll(disable)
+                    while (e != key && (uint32_t)(e >> 32) == tag) {
+                        if (++probes > 24u) { hfull = true; break; }
+                        hp = (hp + 1u) & hmask;
+                        e = htab[hp];
+                    }
+                    if (!hfull) htab[hp] = key;
+                    later = false;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            if (__any(hfull && commit)) { if (w2_gballot<G>(hfull && commit, gbase)) status = W2_ST_NEED_BIG, why = 9u; }
+        }
+        // ---- finals (wfa_graph.rs:576-629): every wave of the last node that consumed node and read ---------------------------
+        if (__any(is_final && commit)) {
+            const bool gf = w2_gballot<G>(is_final && commit, gbase) != 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint32_t o = w2_gor<G>(is_final && commit ? best.w[w] : 0u);
+                if (gf && gl == 0) outset[w] |= o;
+            }
+            if (gf) final_found = true;
+        }
+        // ---- the round's lists move on; finished waves become targets of their node's children --------------------------------
+        if (run) {
+            nl += nlive; nf += nfin; ip += ncommit;
+            uint64_t fm = status == W2_ST_PENDING ? mf : 0ull;
+#pragma clang loop unroll(disable)
+            while (fm) {   // (group-uniform; usually one wave, if any)
+                const uint32_t L = (uint32_t)__builtin_ctzll(fm);
+                fm &= fm - 1ull;
+                const uint32_t qn = w2_gsel<G>(n, gl, L), qz = w2_gsel<G>(nd.z, gl, L), qw = w2_gsel<G>(nd.w, gl, L);
+                const int32_t td = (int32_t)w2_gsel<G>((uint32_t)(d + (int32_t)len), gl, L);
+                const uint32_t si = w2_gsel<G>(fpos, gl, L);
+                const uint32_t n_child = qz & 0xFFFFu;
+                uint32_t scan = qz >> 16;
+                if (td <= -W2_DIAG_LIM || td >= W2_DIAG_LIM) { status = W2_ST_NEED_BIG, why = 8u; break; }
+#pragma clang loop unroll(disable)
+                for (uint32_t j = 0; j < n_child; ++j) {
+                    const uint32_t cid = j == 0 ? (qw & 0xFFFFu) : (j == 1 ? (qw >> 16) : w2_next_child(gedge, qn, scan));
+                    const uint32_t K = w3_key(cid, td);
+                    // where K belongs among the targets still to come: [ip, np) is sorted
+                    uint32_t pos = ip, hit = 0xFFFFFFFFu;
+#pragma clang loop unroll(disable)
+                    for (uint32_t base = ip; base < np; base += (uint32_t)G) {
+                        const uint32_t i = base + gl;
+                        const uint32_t k = i < np ? A[cbase + i].x : 0xFFFFFFFFu;
+                        const uint64_t lt = w2_gballot<G>(k < K, gbase), eq = w2_gballot<G>(k == K, gbase);
+                        const uint32_t nlt = (uint32_t)__popcll(lt);
+                        pos += nlt;
+                        if (eq) { hit = base + (uint32_t)__builtin_ctzll(eq); break; }
+                        if (nlt < (uint32_t)G) break;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (hit != 0xFFFFFFFFu) {
+                        const uint32_t y = A[cbase + hit].y;
+                        uint32_t ny = y;
+                        if (((y >> 10) & 0x3FFu) == W3_NONE) ny = (y & ~(0x3FFu << 10)) | (si << 10);
+                        else if (((y >> 20) & 0x3FFu) == W3_NONE) ny = (y & ~(0x3FFu << 20)) | (si << 20);
+                        else {
+                            // a third wave onto one target (rare): its set and the second one's merge into a fresh entry of the arena
+                            if (nl + nf + 1u > SL) { status = W2_ST_NEED_BIG, why = 8u; break; }
+                            const uint32_t sm = SL - 1u - nf;
+                            ++nf;
+                            const uint32_t s1 = (y >> 20) & 0x3FFu;
+                            if (gl < (uint32_t)W) gs[(size_t)(cbase + sm) * W + gl] = gs[(size_t)(cbase + s1) * W + gl] | gs[(size_t)(cbase + si) * W + gl];
+                            ny = (y & ~(0x3FFu << 20)) | (sm << 20);
+                        }
+                        if (gl == 0) A[cbase + hit].y = ny;
+                    } else {
+                        if (np >= SL) { status = W2_ST_NEED_BIG, why = 8u; break; }
+                        // shift [pos, np) up by one, from the top down, G entries at a time
+#pragma clang loop unroll(disable)
+                        for (uint32_t top = np; top > pos;) {
+                            const uint32_t lo = top - pos > (uint32_t)G ? top - (uint32_t)G : pos;
+                            const uint32_t i = lo + gl;
+                            uint2 v = make_uint2(0, 0);
+                            if (i < top) v = A[cbase + i];
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            if (i < top) A[cbase + i + 1u] = v;
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            top = lo;
+                        }
+                        if (gl == 0) A[cbase + pos] = make_uint2(K, w3_aux(W3_NONE, si, W3_NONE));
+                        ++np;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                if (status != W2_ST_PENDING) break;
+            }
+            if (ip >= np) state = S_ROUND;
+            if (++steps > W2_MAX_STEPS) status = W2_ST_INTERNAL;
+            if (status != W2_ST_PENDING) state = S_JOB;
+        }
+    }
+    if (B.esc_role == 1u) {   // a producer workgroup is gone (everything it hands over has been published)
+        W2_WAIT_VM();
+        (void)atomicAdd(B.esc + 2, lane == 0 ? 1u : 0u);
+    }
+}
+
+}  // namespace hp

@@ -21,9 +21,10 @@ from test_local_gpu import oracle_segments, reference_order_replay, seg_tuple, t
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["compact", "dense-band"])
+@pytest.fixture(params=["compact", "compact-gen2", "dense-band"])
 def wfa_path(request, monkeypatch):
-    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0" if request.param == "compact" else "1000000000")
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0" if request.param.startswith("compact") else "1000000000")
+    monkeypatch.setenv("HP_WFA_GEN", "2" if request.param == "compact-gen2" else "3")   # hp_wfa3_kernel (flat slot lists) / hp_wfa2_kernel (hull arenas)
     return request.param
 
 

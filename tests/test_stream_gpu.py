@@ -26,9 +26,10 @@ def oracle_outputs(sset, prm):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("fmt", [_ffi.SEQ_ASCII, _ffi.SEQ_BAM4])
-@pytest.mark.parametrize("path", ["compact", "dense-band"])
+@pytest.mark.parametrize("path", ["compact", "compact-gen2", "dense-band"])
 def test_solve_blocks_on_generated_sets_vs_oracle(fmt, path, monkeypatch):
-    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0" if path == "compact" else "1000000000")
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0" if path.startswith("compact") else "1000000000")
+    monkeypatch.setenv("HP_WFA_GEN", "2" if path == "compact-gen2" else "3")
     lib = _ffi.lib()
     prm = _params(2, 1000, 3, None, True)
     s = SynthSet(default_spec(lib, total_hets=600, seed=11, seq_format=fmt, **KW))

@@ -18,11 +18,12 @@ pytestmark = pytest.mark.gpu
 G = load_golden("wfa_graph.json")
 
 
-@pytest.fixture(autouse=True, params=["compact", "dense-band"])
+@pytest.fixture(autouse=True, params=["compact", "compact-gen2", "dense-band"])
 def wfa_kernel_path(request, monkeypatch):
     """hp_wfa_assign_batch picks its kernel by batch size (hp_wfa.hip); every test runs through both: the compact
     several-reads-per-wavefront kernel with the device graph builder (hp_wfa2*.hip) and the dense-band one."""
-    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0" if request.param == "compact" else "1000000000")
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0" if request.param.startswith("compact") else "1000000000")
+    monkeypatch.setenv("HP_WFA_GEN", "2" if request.param == "compact-gen2" else "3")   # hp_wfa3_kernel (flat slot lists) / hp_wfa2_kernel (hull arenas)
     return request.param
 
 
