@@ -1025,6 +1025,110 @@ int W2Session::late() {
         work_updates += s0; work_node_bytes += s1; work_read_bytes += s2w; work_jobs += s3;
         return HP_OK;
     };
+    // The leftovers' way out (everything in pend.big): the reference-window test, then the dense-band pass for what it leaves.
+    auto dense_pass = [&]() -> int {
+        if (!pend.big.empty()) {
+            {   // ascending job order (with the hints)
+                std::vector<std::array<uint32_t, 3>> z(pend.big.size());
+                for (size_t k = 0; k < z.size(); ++k) z[k] = {pend.big[k], k < pend.big_ed.size() ? pend.big_ed[k] : 0u, k < pend.big_nodes.size() ? pend.big_nodes[k] : 0u};
+                std::sort(z.begin(), z.end());
+                pend.big_ed.resize(z.size()); pend.big_nodes.resize(z.size());
+                for (size_t k = 0; k < z.size(); ++k) { pend.big[k] = z[k][0]; pend.big_ed[k] = z[k][1]; pend.big_nodes[k] = z[k][2]; }
+            }
+            // ---- the cheap exact verdict first (hp_wfa2_bound_kernel): a read that was deep into its alignment when the compact
+            // kernels let go of it, and whose distance to the reference window alone exceeds max_edit_distance + D, is a
+            // MaxEditDistance - no dense-band pass for it ----
+            {
+                const char* benv = std::getenv("HP_WFA2_BOUND");
+                // (every leftover is tested: a read that aligns within the threshold ends the test after about as many rounds as it has
+                // edits, and the noisy ones often leave the compact kernels early, on a full capped set. HP_WFA2_BOUND=n: only reads that
+                // had reached n edits; 1000000 turns the shortcut off)
+                const uint32_t min_ed = benv ? (uint32_t)std::max(0, std::atoi(benv)) : 0u;
+                std::vector<uint32_t> cand, thr, cand_pos;
+                for (size_t k = 0; k < pend.big.size(); ++k) {
+                    if (pend.big_ed[k] < min_ed || Pending::nodes_of(pend.big_nodes[k]) == 0) continue;
+                    const hp_wfa_job j = job_header(pend.big[k]);
+                    uint64_t D = 0;
+                    for (uint32_t v = 0; v < j.n_hets; ++v) D += std::max<uint64_t>({j.hets[v].ref_len, (j.hets[v].flags & 2u) ? j.hets[v].allele0_len : 0u, j.hets[v].allele1_len});
+                    for (uint32_t v = 0; v < j.n_homs; ++v) D += std::max<uint64_t>({j.homs[v].ref_len, (j.homs[v].flags & 2u) ? j.homs[v].allele0_len : 0u, j.homs[v].allele1_len});
+                    const uint64_t T = pend.max_ed + D;
+                    if (T > W2_BOUND_MAX_T) continue;
+                    cand.push_back(pend.big[k]); thr.push_back((uint32_t)T); cand_pos.push_back((uint32_t)k);
+                }
+                if (!cand.empty()) {
+                    hipStream_t bs = thread_stream(device_id);
+                    if (!bs) { set_error("stream creation failed"); return HP_ERR_HIP; }
+                    DevBuf d_ids, d_thr, d_exc;
+                    int rcb;
+                    if ((rcb = d_ids.alloc(cand.size() * 4)) || (rcb = d_thr.alloc(cand.size() * 4)) || (rcb = d_exc.alloc(cand.size() + 16))) return rcb;
+                    std::vector<uint8_t> exc(cand.size(), 0);
+                    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{bs};
+                    struct IoDrain { hipStream_t s; ~IoDrain() { (void)dev_io_sync(s); } } io{bs};
+                    if ((rcb = dev_put(d_ids.p, cand.data(), cand.size() * 4, bs)) != HP_OK || (rcb = dev_put(d_thr.p, thr.data(), thr.size() * 4, bs)) != HP_OK) return rcb;
+                    W2BoundArgs BA{};
+                    BA.jobs = d_jobs.as<W2Job>(); BA.ids = d_ids.as<uint32_t>(); BA.thresh = d_thr.as<uint32_t>(); BA.n = (uint32_t)cand.size();
+                    BA.seq = d_seq.as<uint8_t>(); BA.exceeds = d_exc.as<uint8_t>();
+                    const uint32_t maxT = *std::max_element(thr.begin(), thr.end());
+                    // LDS: the two wavefront arrays, then room for the longest tested read + its window (most of the CU's 160 KB: these
+                    // are a few hundred single-wavefront workgroups, latency is what counts)
+                    uint32_t need_seq = 0;
+                    for (uint32_t i : cand) need_seq = std::max<uint32_t>(need_seq, ((dj[i].read_len + 31u) & ~15u) + ((dj[i].ref_len + 31u) & ~15u));
+                    const size_t lds_wf = (size_t)(2 * (2 * maxT + 3) + 2) * 4 + 16;
+                    BA.max_t = maxT;
+                    BA.lds_seq = std::min<uint32_t>(need_seq, W2_BOUND_LDS_SEQ);
+                    const size_t lds_total = lds_wf + BA.lds_seq;
+                    HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_bound_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
+                    hipLaunchKernelGGL(hp_wfa2_bound_kernel, dim3((unsigned)cand.size()), dim3(64), lds_total, bs, BA);
+                    HP_HIP_CHECK(hipGetLastError());
+                    if ((rcb = dev_get(exc.data(), d_exc.p, cand.size(), bs)) != HP_OK) return rcb;
+                    if (dev_io_sync(bs) != HP_OK) { set_error("WFA bound kernel failed"); return HP_ERR_HIP; }
+                    std::vector<uint32_t> keep, keep_ed, keep_nodes;
+                    size_t c = 0, settled = 0;
+                    for (size_t k = 0; k < pend.big.size(); ++k) {
+                        const bool tested = c < cand_pos.size() && cand_pos[c] == k;
+                        if (tested && exc[c]) {
+                            const uint32_t i = pend.big[k];
+                            pend.dst[i].status = HP_WFA_MAX_ED; pend.dst[i].n_nodes = Pending::nodes_of(pend.big_nodes[k]); pend.dst[i].score = pend.max_ed;
+                            if (pend.alleles && pend.alleles[i] && dj[i].n_hets) std::memset(pend.alleles[i], HP_ALLELE_NOOVERLAP, dj[i].n_hets);
+                            ++settled;
+                        } else { keep.push_back(pend.big[k]); keep_ed.push_back(pend.big_ed[k]); keep_nodes.push_back(pend.big_nodes[k]); }
+                        if (tested) ++c;
+                    }
+                    pend.big.swap(keep); pend.big_ed.swap(keep_ed); pend.big_nodes.swap(keep_nodes);
+                    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa2: %zu of %zu leftovers tested against the reference window alone, %zu settled as MaxEditDistance\n", cand.size(), cand.size() + pend.big.size() - (cand.size() - settled), settled); fflush(stderr); }
+                }
+            }
+        }
+        tl_bound = w2_now_ms();
+        if (!pend.big.empty()) {
+            pend.sub.resize(pend.big.size()); pend.sub_out.resize(pend.big.size()); pend.sub_al.resize(pend.big.size());
+            ascii_scratch.clear();
+            for (size_t k = 0; k < pend.big.size(); ++k) { pend.sub[k] = materialize(pend.big[k]); pend.sub_al[k] = pend.alleles ? pend.alleles[pend.big[k]] : nullptr; }
+            // a read that was past the narrow band's edit distance when the compact kernel let go of it starts at full width
+            g_wfa_min_ed_hint = pend.big_ed.data();
+            const int rc = wfa_assign_batch_v1(pend.sub.data(), pend.sub.size(), pend.prune, pend.max_ed, pend.sub_out.data(), pend.alleles ? pend.sub_al.data() : nullptr, device_id);
+            g_wfa_min_ed_hint = nullptr;
+            if (rc != HP_OK) return rc;
+            late_kernel_ms += g_last_kernel_ms;
+            for (size_t k = 0; k < pend.big.size(); ++k) pend.dst[pend.big[k]] = pend.sub_out[k];
+        }
+        pend.big.clear(); pend.big_ed.clear(); pend.big_nodes.clear();
+        return HP_OK;
+    };
+    // What the two smaller classes' kernels left unaligned is known since run()'s collection: its way out starts NOW, beside the
+    // largest class's kernel (the tail of the launch set: ~15 ms more on the bench workload), not after it - unless there is so much
+    // of it that the wide-table launch below wants it in one piece.
+    {
+        const char* wenv0 = std::getenv("HP_WFA2_WIDE_MIN");
+        const size_t wide_min0 = wenv0 ? (size_t)std::max(0, std::atoi(wenv0)) : (size_t)1024;
+        const char* eenv = std::getenv("HP_WFA2_EARLY_DENSE");
+        size_t n_large = 0;   // graphs of 257 .. 512 nodes: the 16-word launch takes them when a set has wide_min / 16 of them
+        for (uint32_t x : pend.big_nodes) n_large += Pending::nodes_of(x) > (uint32_t)W2Cfg<8>::MAXN ? 1 : 0;
+        if (pend.two_phase && !pend.big.empty() && !(eenv && eenv[0] == '0') && (wide_min0 == 0 || (pend.big.size() < wide_min0 && n_large < std::max<size_t>(1, wide_min0 / 16)))) {
+            const int rce = dense_pass();
+            if (rce != HP_OK) return rce;
+        }
+    }
     if (pend.two_phase) {
         const int rc = collect(pend.held, pend.held_nodes);
         if (rc != HP_OK) return rc;
@@ -1095,91 +1199,7 @@ int W2Session::late() {
         }
     }
     tl_tail = tl_bound = w2_now_ms();
-    if (!pend.big.empty()) {
-        {   // ascending job order (with the hints)
-            std::vector<std::array<uint32_t, 3>> z(pend.big.size());
-            for (size_t k = 0; k < z.size(); ++k) z[k] = {pend.big[k], k < pend.big_ed.size() ? pend.big_ed[k] : 0u, k < pend.big_nodes.size() ? pend.big_nodes[k] : 0u};
-            std::sort(z.begin(), z.end());
-            pend.big_ed.resize(z.size()); pend.big_nodes.resize(z.size());
-            for (size_t k = 0; k < z.size(); ++k) { pend.big[k] = z[k][0]; pend.big_ed[k] = z[k][1]; pend.big_nodes[k] = z[k][2]; }
-        }
-        // ---- the cheap exact verdict first (hp_wfa2_bound_kernel): a read that was deep into its alignment when the compact
-        // kernels let go of it, and whose distance to the reference window alone exceeds max_edit_distance + D, is a
-        // MaxEditDistance - no dense-band pass for it ----
-        {
-            const char* benv = std::getenv("HP_WFA2_BOUND");
-            // (every leftover is tested: a read that aligns within the threshold ends the test after about as many rounds as it has
-            // edits, and the noisy ones often leave the compact kernels early, on a full capped set. HP_WFA2_BOUND=n: only reads that
-            // had reached n edits; 1000000 turns the shortcut off)
-            const uint32_t min_ed = benv ? (uint32_t)std::max(0, std::atoi(benv)) : 0u;
-            std::vector<uint32_t> cand, thr, cand_pos;
-            for (size_t k = 0; k < pend.big.size(); ++k) {
-                if (pend.big_ed[k] < min_ed || Pending::nodes_of(pend.big_nodes[k]) == 0) continue;
-                const hp_wfa_job j = job_header(pend.big[k]);
-                uint64_t D = 0;
-                for (uint32_t v = 0; v < j.n_hets; ++v) D += std::max<uint64_t>({j.hets[v].ref_len, (j.hets[v].flags & 2u) ? j.hets[v].allele0_len : 0u, j.hets[v].allele1_len});
-                for (uint32_t v = 0; v < j.n_homs; ++v) D += std::max<uint64_t>({j.homs[v].ref_len, (j.homs[v].flags & 2u) ? j.homs[v].allele0_len : 0u, j.homs[v].allele1_len});
-                const uint64_t T = pend.max_ed + D;
-                if (T > W2_BOUND_MAX_T) continue;
-                cand.push_back(pend.big[k]); thr.push_back((uint32_t)T); cand_pos.push_back((uint32_t)k);
-            }
-            if (!cand.empty()) {
-                hipStream_t bs = thread_stream(device_id);
-                if (!bs) { set_error("stream creation failed"); return HP_ERR_HIP; }
-                DevBuf d_ids, d_thr, d_exc;
-                int rcb;
-                if ((rcb = d_ids.alloc(cand.size() * 4)) || (rcb = d_thr.alloc(cand.size() * 4)) || (rcb = d_exc.alloc(cand.size() + 16))) return rcb;
-                std::vector<uint8_t> exc(cand.size(), 0);
-                struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{bs};
-                struct IoDrain { hipStream_t s; ~IoDrain() { (void)dev_io_sync(s); } } io{bs};
-                if ((rcb = dev_put(d_ids.p, cand.data(), cand.size() * 4, bs)) != HP_OK || (rcb = dev_put(d_thr.p, thr.data(), thr.size() * 4, bs)) != HP_OK) return rcb;
-                W2BoundArgs BA{};
-                BA.jobs = d_jobs.as<W2Job>(); BA.ids = d_ids.as<uint32_t>(); BA.thresh = d_thr.as<uint32_t>(); BA.n = (uint32_t)cand.size();
-                BA.seq = d_seq.as<uint8_t>(); BA.exceeds = d_exc.as<uint8_t>();
-                const uint32_t maxT = *std::max_element(thr.begin(), thr.end());
-                // LDS: the two wavefront arrays, then room for the longest tested read + its window (most of the CU's 160 KB: these
-                // are a few hundred single-wavefront workgroups, latency is what counts)
-                uint32_t need_seq = 0;
-                for (uint32_t i : cand) need_seq = std::max<uint32_t>(need_seq, ((dj[i].read_len + 31u) & ~15u) + ((dj[i].ref_len + 31u) & ~15u));
-                const size_t lds_wf = (size_t)(2 * (2 * maxT + 3) + 2) * 4 + 16;
-                BA.max_t = maxT;
-                BA.lds_seq = std::min<uint32_t>(need_seq, W2_BOUND_LDS_SEQ);
-                const size_t lds_total = lds_wf + BA.lds_seq;
-                HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_bound_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
-                hipLaunchKernelGGL(hp_wfa2_bound_kernel, dim3((unsigned)cand.size()), dim3(64), lds_total, bs, BA);
-                HP_HIP_CHECK(hipGetLastError());
-                if ((rcb = dev_get(exc.data(), d_exc.p, cand.size(), bs)) != HP_OK) return rcb;
-                if (dev_io_sync(bs) != HP_OK) { set_error("WFA bound kernel failed"); return HP_ERR_HIP; }
-                std::vector<uint32_t> keep, keep_ed, keep_nodes;
-                size_t c = 0, settled = 0;
-                for (size_t k = 0; k < pend.big.size(); ++k) {
-                    const bool tested = c < cand_pos.size() && cand_pos[c] == k;
-                    if (tested && exc[c]) {
-                        const uint32_t i = pend.big[k];
-                        pend.dst[i].status = HP_WFA_MAX_ED; pend.dst[i].n_nodes = Pending::nodes_of(pend.big_nodes[k]); pend.dst[i].score = pend.max_ed;
-                        if (pend.alleles && pend.alleles[i] && dj[i].n_hets) std::memset(pend.alleles[i], HP_ALLELE_NOOVERLAP, dj[i].n_hets);
-                        ++settled;
-                    } else { keep.push_back(pend.big[k]); keep_ed.push_back(pend.big_ed[k]); keep_nodes.push_back(pend.big_nodes[k]); }
-                    if (tested) ++c;
-                }
-                pend.big.swap(keep); pend.big_ed.swap(keep_ed); pend.big_nodes.swap(keep_nodes);
-                if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa2: %zu of %zu leftovers tested against the reference window alone, %zu settled as MaxEditDistance\n", cand.size(), cand.size() + pend.big.size() - (cand.size() - settled), settled); fflush(stderr); }
-            }
-        }
-    }
-    tl_bound = w2_now_ms();
-    if (!pend.big.empty()) {
-        pend.sub.resize(pend.big.size()); pend.sub_out.resize(pend.big.size()); pend.sub_al.resize(pend.big.size());
-        ascii_scratch.clear();
-        for (size_t k = 0; k < pend.big.size(); ++k) { pend.sub[k] = materialize(pend.big[k]); pend.sub_al[k] = pend.alleles ? pend.alleles[pend.big[k]] : nullptr; }
-        // a read that was past the narrow band's edit distance when the compact kernel let go of it starts at full width
-        g_wfa_min_ed_hint = pend.big_ed.data();
-        const int rc = wfa_assign_batch_v1(pend.sub.data(), pend.sub.size(), pend.prune, pend.max_ed, pend.sub_out.data(), pend.alleles ? pend.sub_al.data() : nullptr, device_id);
-        g_wfa_min_ed_hint = nullptr;
-        if (rc != HP_OK) return rc;
-        late_kernel_ms += g_last_kernel_ms;
-        for (size_t k = 0; k < pend.big.size(); ++k) pend.dst[pend.big[k]] = pend.sub_out[k];
-    }
+    { const int rcd = dense_pass(); if (rcd != HP_OK) return rcd; }
     return HP_OK;
 }
 

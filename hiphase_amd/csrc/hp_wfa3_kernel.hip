@@ -29,6 +29,23 @@
 
 namespace hp {
 
+#ifndef W3_STATS
+#define W3_STATS 0
+#endif
+#if W3_STATS
+#define W3C(i, v) do { w3c[i] += (uint64_t)(v); } while (0)
+#else
+#define W3C(i, v)
+#endif
+#ifndef W3_PROF
+#define W3_PROF 0
+#endif
+#if W3_PROF   // s_memtime between the phases of the lockstep step (a separate build: the timers cost registers)
+#define W3T(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); w3t[i] += t_ - w3tl; w3tl = t_; } while (0)
+#else
+#define W3T(i)
+#endif
+
 // Lanes with done == false have matched their first n bytes of their node (at global offset nb + o) against read[pos..] and may match
 // up to maxlen: the group serves them one after the other, G x 32 bytes per pass. The serving lane's node address travels (two
 // dwords), its read offset and what is left. `on`: this group takes part (group-uniform).
@@ -105,17 +122,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
     const uint8_t* readp = B.seq;
     const W2Node* gnode = B.nodes; const uint16_t* gedge = B.edges;
     uint32_t ed = 0, c = 0, p = 1, ip = 0, np = 0, nl = 0, nf = 0, nl_prev = 0;
+    uint32_t lastkey = 0;                                            // key of the last target of the round's list (np > ip)
     uint32_t farthest = 0, min_prog = 0;
     bool final_found = false;
     int32_t status = W2_ST_PENDING;
     uint32_t score = 0, steps = 0, why = 0;
     uint32_t lane_far = 0, lane_upd = 0;                             // per lane
+#if W3_STATS
+    uint64_t w3c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // wave steps, control passes, group tiles, act lanes, has lanes, committed lanes, jobs, rounds, long extensions (lanes), inserts, tiles with a discard, build chunks
+#endif
     const uint32_t n_class = *B.n_items_dev;
     if (B.esc_role == 1u) (void)atomicAdd(B.esc + 4, lane == 0 ? 1u : 0u);   // a producer workgroup has started
+#if W3_PROF
+    uint64_t w3t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t w3tl = __builtin_amdgcn_s_memtime();
+    const uint64_t w3t0 = w3tl;
+    uint32_t w3steps = 0;
+#endif
 
     for (;;) {
         // ============================ 1. control: advance every group to its next tile ===========================================
         uint32_t spins = 0;
+        W3T(0);
         if (B.esc_role == 2u && __any(state == S_WAIT) && (!__any(state == S_TILE) || (++poll_div & 15u) == 0u)) {
             const uint32_t gone = atomicAdd(B.esc + 2, 0u);
             W2_WAIT_VM();
@@ -128,6 +156,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
             }
         }
         while (state != S_TILE && state != S_DONE && state != S_WAIT) {
+            W3C(1, 1);
             if (++spins > (1u << 20)) { state = S_DONE; break; }   // cannot happen; never hang the device
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (state == S_JOB) {
@@ -135,7 +164,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                     const uint32_t upd = w2_gsum<G>(lane_upd);
                     bool handed_over = false;
                     // worth handing over: what the largest class's bigger tables fix (the slot lists) - not a full capped set
-                    const bool hand = status == W2_ST_NEED_BIG && why == 8u;
+                    // ... and not a read that is heading for Err(MaxEditDistance) anyway (the workload's noisy tail: at 5 % noise a
+                    // read holds fifty diagonals per node and outgrows every class's lists): by the rate it has made so far - edits
+                    // per read base - it would end far beyond the cap. Those skip the largest class (where they would crawl on to
+                    // outgrow its lists too, at the tail of the launch set) and go straight to the exact reference-window verdict of
+                    // the host's pass (hp_wfa2_bound_kernel). Routing only: every road computes the same result.
+                    const bool hopeless = ed >= 16u && (uint64_t)ed * other_len > ((uint64_t)farthest + 1u) * (uint64_t)maxed32 * 2u;
+                    const bool hand = status == W2_ST_NEED_BIG && why == 8u && !hopeless;
                     if (B.esc_role == 1u && __any(hand)) {
                         const uint32_t taken = atomicAdd(B.esc, 0u);
                         const bool me = hand && gl == 0 && taken < B.esc_limit;
@@ -153,6 +188,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                     if (!handed_over && gl == 0) { B.status[job] = status; B.out_score[job] = status == W2_ST_NEED_BIG ? (uint64_t)(why | (ed << 8)) : score; B.out_work[(size_t)job * 2] = upd; }
                     if (!handed_over && gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
                     status = W2_ST_PENDING;
+                    W3C(6, __popcll(__ballot(gl == 0)));
                 }
                 if (B.group_jobs != 0u && B.esc_role != 2u && jround >= B.group_jobs) { state = S_DONE; break; }
                 const uint32_t mine = atomicAdd(B.next, (gl == 0 && !have_ticket) ? 1u : 0u);   // (every lane takes part: no one-lane branch)
@@ -185,6 +221,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 // the start wave (wfa_graph.rs:366-378): the only target of round 0
                 ed = 0; c = 0; p = 1; ip = 0; np = 1; nl = 0; nf = 0; nl_prev = 0; steps = 0;
                 if (gl == 0) A[0] = make_uint2(w3_key(0u, 0), w3_aux(W3_NONE, W3_NONE, W3_NONE) | W3_START);
+                lastkey = w3_key(0u, 0);
                 farthest = 0; min_prog = 0; final_found = false; lane_far = 0; lane_upd = 0;
                 state = S_TILE;
                 continue;
@@ -199,11 +236,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 if (ed + 1u > maxed32) { status = W2_ST_MAX_ED; score = maxed32; state = S_JOB; continue; }
                 if (nl == 0u) { status = W2_ST_INTERNAL; state = S_JOB; continue; }
                 ++ed; p = c; c ^= 1u; nl_prev = nl; nl = 0; nf = 0; ip = 0; np = 0;
+                W3C(7, __popcll(__ballot(gl == 0)));
                 // every live slot (n, d) emits the targets (n, d - 1), (n, d), (n, d + 1) its predecessor has not emitted
                 uint32_t carry = 0xFFFFFFFFu;
                 bool over = false;
 #pragma clang loop unroll(disable)
                 for (uint32_t base = 0; base < nl_prev; base += (uint32_t)G) {
+                    W3C(11, 1);
                     const uint32_t i = base + gl;
                     const bool valid = i < nl_prev;
                     const uint32_t key = valid ? A[p * SL + i].x : 0xFFFFFFFFu;
@@ -229,12 +268,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                         if (d - 1 <= -W2_DIAG_LIM || d + 1 >= W2_DIAG_LIM) over = true;
                     }
                     np += total;
+                    lastkey = (uint32_t)w2_gmax<G>(valid ? (int32_t)w3_key(nn, d + 1) : 0);   // (keys ascend: the chunk's last target)
                     carry = w2_gsel<G>(key, gl, (uint32_t)G - 1u);   // (0xFFFFFFFF when the chunk is not full: it was the last one)
                 }
                 if (w2_gballot<G>(over, gbase)) { status = W2_ST_NEED_BIG, why = 8u; state = S_JOB; continue; }
                 state = S_TILE;
             }
         }
+        W3T(1);
         if (!__any(state == S_TILE)) {
             if (!__any(state == S_WAIT)) break;   // every group is done
             if (++idle_polls > 60000u) break;     // (~1.5 s of nothing to do: never hang the device; unclaimed jobs stay for the host's pass)
@@ -247,6 +288,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
         const bool run = state == S_TILE;
         const uint32_t pbase = p * SL, cbase = c * SL;
         const bool act = run && ip + gl < np;
+        W3C(0, 1); W3C(2, __popcll(__ballot(run && gl == 0))); W3C(3, __popcll(__ballot(act)));
         const uint2 tgt = act ? A[cbase + ip + gl] : make_uint2(0u, w3_aux(W3_NONE, W3_NONE, W3_NONE));
         const uint32_t n = w3_key_node(tgt.x);
         const int32_t d = act ? w3_key_diag(tgt.x) : 0;
@@ -285,6 +327,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
 #pragma unroll
             for (int w = 0; w < W; ++w) qD.w[w] |= t.w[w];
         }
+        W3T(2);
         const uint32_t len = nd.y & ~W2_IS_REF;
         const uint64_t nb = ((nd.y & W2_IS_REF) ? ref_off : B.alt_off) + nd.x;   // the node's sequence in seq[]
         const uint8_t* nseq = B.seq + nb;
@@ -313,6 +356,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
         const W2Pre8 pB = w2_pre8(nseq + (nB ? oB : 0), readp + (nB ? d + oB : 0), nB);
         const W2Pre8 pC = w2_pre8(nseq + (nC ? oC : 0), readp + (nC ? d + oC : 0), nC);
         const W2Pre8 pD = w2_pre8(nseq, readp + (nD ? d : 0), nD);
+        W3T(3);
         uint32_t E;
         {
             uint32_t n0 = 0;
@@ -323,8 +367,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 n0 = m;
                 if (m < 16 || n0 >= room) done = true;
             }
+            W3C(8, __popcll(__ballot(run && !done)));
             E = (uint32_t)omax + w3_match_rest<G>(B.seq, nb, readp, (uint32_t)omax, pos0, room, n0, done, run, gbase, gl);
         }
+        W3T(4);
         {
             bool pdA = false, pdB = false, pdC = false, pdD = false;
             auto quick = [&](const W2Pre8& q, bool nX, int32_t oX, bool& pend8) -> bool {
@@ -359,6 +405,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 tA = tA || yA; tB = tB || yB; tC = tC || yC; tD = tD || yD;
             }
         }
+        W3T(5);
         // ---- capped-diagonal set: is (n, d) recorded? ---------------------------------------------------------------------------
         const bool rec_live = crec.x == tag;
         const uint32_t rel = (uint32_t)(d - (int32_t)crec.y + 32);
@@ -397,10 +444,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 } else kind = ((uint32_t)pos_end < other_len) ? W2_KIND_INTERIOR_READ : W2_KIND_INTERIOR;
             }
         }
+        W3T(6);
         // ---- commit: the slots of nodes below the first child of every node that finished in this tile (a prefix of the tile) ----
         const bool fin = kind == W2_KIND_FINISHED;
         const uint32_t X = (uint32_t)w2_gmin<G>(fin ? (int32_t)(nd.w & 0xFFFFu) : 0x7FFFFFFF);
         const bool commit = act && n < X;
+        W3C(4, __popcll(__ballot(has))); W3C(5, __popcll(__ballot(commit))); W3C(10, __popcll(__ballot(act && !commit)));
         const uint32_t ncommit = (uint32_t)__popcll(w2_gballot<G>(commit, gbase));
         const bool live_k = commit && kind != W2_KIND_NONE && !fin, fin_k = commit && fin;
         const uint64_t ml = w2_gballot<G>(live_k, gbase), mf = w2_gballot<G>(fin_k, gbase);
@@ -426,6 +475,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
             lane_upd += has ? 1u : 0u;
             if (counts_far && (uint32_t)pos_end > lane_far) lane_far = (uint32_t)pos_end;
         }
+        W3T(7);
         // ---- record newly capped diagonals (committed slots only; the lanes of one node share its record) ----------------------
         bool later = false;
         {
@@ -468,6 +518,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
             }
             if (__any(hfull && commit)) { if (w2_gballot<G>(hfull && commit, gbase)) status = W2_ST_NEED_BIG, why = 9u; }
         }
+        W3T(8);
         // ---- finals (wfa_graph.rs:576-629): every wave of the last node that consumed node and read ---------------------------
         if (__any(is_final && commit)) {
             const bool gf = w2_gballot<G>(is_final && commit, gbase) != 0;
@@ -478,12 +529,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
             }
             if (gf) final_found = true;
         }
+        W3T(9);
         // ---- the round's lists move on; finished waves become targets of their node's children --------------------------------
+#if W3_PROF
+        ++w3steps;
+#endif
         if (run) {
             nl += nlive; nf += nfin; ip += ncommit;
             uint64_t fm = status == W2_ST_PENDING ? mf : 0ull;
 #pragma clang loop unroll(disable)
             while (fm) {   // (group-uniform; usually one wave, if any)
+                W3C(15, 1);
                 const uint32_t L = (uint32_t)__builtin_ctzll(fm);
                 fm &= fm - 1ull;
                 const uint32_t qn = w2_gsel<G>(n, gl, L), qz = w2_gsel<G>(nd.z, gl, L), qw = w2_gsel<G>(nd.w, gl, L);
@@ -492,14 +548,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 const uint32_t n_child = qz & 0xFFFFu;
                 uint32_t scan = qz >> 16;
                 if (td <= -W2_DIAG_LIM || td >= W2_DIAG_LIM) { status = W2_ST_NEED_BIG, why = 8u; break; }
-#pragma clang loop unroll(disable)
-                for (uint32_t j = 0; j < n_child; ++j) {
-                    const uint32_t cid = j == 0 ? (qw & 0xFFFFu) : (j == 1 ? (qw >> 16) : w2_next_child(gedge, qn, scan));
-                    const uint32_t K = w3_key(cid, td);
+                // one target per child of the node: key K, the finished wave's set `si` (group-uniform)
+                auto inject = [&](const uint32_t K) {
+                    W3C(9, 1);
+                    // Behind every target still to come (the usual case: the wave that finished was the front of the alignment, nothing
+                    // of the round lies beyond its node): appended, no look at the list. `lastkey` is the list's last key.
+                    if (ip == np || K > lastkey) {
+                        if (np >= SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
+                        if (gl == 0) A[cbase + np] = make_uint2(K, w3_aux(W3_NONE, si, W3_NONE));
+                        ++np;
+                        lastkey = K;
+                        return;
+                    }
                     // where K belongs among the targets still to come: [ip, np) is sorted
+                    W3C(12, 1);
                     uint32_t pos = ip, hit = 0xFFFFFFFFu;
 #pragma clang loop unroll(disable)
                     for (uint32_t base = ip; base < np; base += (uint32_t)G) {
+                        W3C(13, 1);
                         const uint32_t i = base + gl;
                         const uint32_t k = i < np ? A[cbase + i].x : 0xFFFFFFFFu;
                         const uint64_t lt = w2_gballot<G>(k < K, gbase), eq = w2_gballot<G>(k == K, gbase);
@@ -516,7 +582,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                         else if (((y >> 20) & 0x3FFu) == W3_NONE) ny = (y & ~(0x3FFu << 20)) | (si << 20);
                         else {
                             // a third wave onto one target (rare): its set and the second one's merge into a fresh entry of the arena
-                            if (nl + nf + 1u > SL) { status = W2_ST_NEED_BIG, why = 8u; break; }
+                            if (nl + nf + 1u > SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
                             const uint32_t sm = SL - 1u - nf;
                             ++nf;
                             const uint32_t s1 = (y >> 20) & 0x3FFu;
@@ -525,10 +591,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                         }
                         if (gl == 0) A[cbase + hit].y = ny;
                     } else {
-                        if (np >= SL) { status = W2_ST_NEED_BIG, why = 8u; break; }
+                        if (np >= SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
                         // shift [pos, np) up by one, from the top down, G entries at a time
 #pragma clang loop unroll(disable)
                         for (uint32_t top = np; top > pos;) {
+                            W3C(14, 1);
                             const uint32_t lo = top - pos > (uint32_t)G ? top - (uint32_t)G : pos;
                             const uint32_t i = lo + gl;
                             uint2 v = make_uint2(0, 0);
@@ -542,6 +609,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                         ++np;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                };
+                // (the first two children come with the node's descriptor; a third and later one - a node several variants reconnect
+                // at - is read from the overflow list in HBM. Two loops: a load on the way to the common case makes every insert
+                // wait for the step's set stores)
+                if (n_child >= 1u) inject(w3_key(qw & 0xFFFFu, td));
+                if (n_child >= 2u && status == W2_ST_PENDING) inject(w3_key(qw >> 16, td));
+                if (n_child > 2u) {
+#pragma clang loop unroll(disable)
+                    for (uint32_t j = 2; j < n_child && status == W2_ST_PENDING; ++j) inject(w3_key(w2_next_child(gedge, qn, scan), td));
                 }
                 if (status != W2_ST_PENDING) break;
             }
@@ -549,11 +625,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
             if (++steps > W2_MAX_STEPS) status = W2_ST_INTERNAL;
             if (status != W2_ST_PENDING) state = S_JOB;
         }
+        W3T(10);
     }
+#if W3_PROF
+    if (lane == 0 && (blockIdx.x % 61) == 3)
+        printf("w3prof G%d W%d wg %u: total %llu steps %u | between %llu control %llu candidates %llu issue %llu extension %llu ties %llu capped-decide %llu commit-write %llu capins %llu finals %llu inject %llu\n", G, W, blockIdx.x,
+               (unsigned long long)(w3tl - w3t0), w3steps, (unsigned long long)w3t[0], (unsigned long long)w3t[1], (unsigned long long)w3t[2], (unsigned long long)w3t[3], (unsigned long long)w3t[4],
+               (unsigned long long)w3t[5], (unsigned long long)w3t[6], (unsigned long long)w3t[7], (unsigned long long)w3t[8], (unsigned long long)w3t[9], (unsigned long long)w3t[10]);
+#endif
     if (B.esc_role == 1u) {   // a producer workgroup is gone (everything it hands over has been published)
         W2_WAIT_VM();
         (void)atomicAdd(B.esc + 2, lane == 0 ? 1u : 0u);
     }
+#if W3_STATS
+    if (lane == 0 && (blockIdx.x % 61) == 3)
+        printf("w3 G%d W%d wg %u: wave-steps %llu control-passes %llu group-tiles %llu act %llu has %llu committed %llu jobs %llu rounds %llu long-ext-lanes %llu inserts %llu discarded-lanes %llu build-chunks %llu slow-inserts %llu scan-iters %llu shift-iters %llu finished-waves %llu\n", G, W, blockIdx.x,
+               (unsigned long long)w3c[0], (unsigned long long)w3c[1], (unsigned long long)w3c[2], (unsigned long long)w3c[3], (unsigned long long)w3c[4], (unsigned long long)w3c[5],
+               (unsigned long long)w3c[6], (unsigned long long)w3c[7], (unsigned long long)w3c[8], (unsigned long long)w3c[9], (unsigned long long)w3c[10], (unsigned long long)w3c[11],
+               (unsigned long long)w3c[12], (unsigned long long)w3c[13], (unsigned long long)w3c[14], (unsigned long long)w3c[15]);
+#endif
 }
 
 }  // namespace hp

@@ -22,6 +22,8 @@ reads = bench["kernels"][0]["reads"]
 hets = bench["config"]["hets_per_step_per_gpu"]
 
 def group(name):
+    if "hp_wfa3_kernel" in name:
+        return "hp_wfa3_kernel"
     if "hp_wfa2_kernel" in name:
         return "hp_wfa2_kernel"
     if "hp_astar_kernel" in name:
@@ -55,12 +57,12 @@ lines.append("")
 traffic = {"_comment": __doc__.strip().split("\n")[0] + " FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes; per step = total / launches.",
            "workload": bench["config"]["workload"], "launches": launches}
 sha = hashlib.sha256(open(os.path.join(root, "hiphase_amd", "libhiphase_gpu.so"), "rb").read()).hexdigest()
-for g, unit, n in (("hp_wfa2_kernel", "bytes_per_read", reads), ("hp_astar_kernel", "bytes_per_het", hets), ("hp_heur_seg_kernel", "bytes_per_het", hets)):
+for g, unit, n in (("hp_wfa3_kernel", "bytes_per_read", reads), ("hp_wfa2_kernel", "bytes_per_read", reads), ("hp_astar_kernel", "bytes_per_het", hets), ("hp_heur_seg_kernel", "bytes_per_het", hets)):
     if (g, "FETCH_SIZE") in tot and (g, "WRITE_SIZE") in tot:
         b = (2.0 * tot[(g, "FETCH_SIZE")] + tot[(g, "WRITE_SIZE")]) * 1024.0 / launches
         traffic[g] = {unit: b / n, "hbm_bytes_per_step": b, "FETCH_SIZE_KB_per_step": tot[(g, "FETCH_SIZE")] / launches,
                       "WRITE_SIZE_KB_per_step": tot[(g, "WRITE_SIZE")] / launches, "so_sha256": sha,
-                      "source": "profiles/round3/path_pmc_summary.txt"}
+                      "source": "profiles/round4/path_pmc_summary.txt"}
         lines.append(f"{g}: HBM traffic (FETCH x 2 + WRITE) = {b / 1e6:.1f} MB per step = {b / n:.0f} {unit.replace('_', ' ')}")
     w, a, wa, wi = (tot.get((g, c)) for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"))
     if w:
