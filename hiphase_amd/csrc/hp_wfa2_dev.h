@@ -326,11 +326,13 @@ template <int W, bool WIDE = false> struct W3Cfg {
     static constexpr int MAXE = 2 * MAXN + 32;
     // slots per round: targets (consumed from the front) and live slots (appended behind them) share one array per round parity;
     // the sets of waves that finished a node this round take the round's set arena from the top
-    static constexpr int SLOTS = WIDE ? W2_SLOTS_WIDE : (W <= 4 ? 96 : 160);
+    static constexpr int SLOTS = WIDE ? W2_SLOTS_WIDE : (W <= 4 ? 88 : 144);
     static constexpr int WAVES_PER_SIMD = W <= 4 ? 3 : 2;
     static constexpr int a16(int x) { return (x + 15) & ~15; }
     static constexpr int O_A = 0;                                   // uint2[2][SLOTS]
-    static constexpr int O_MISC = a16(O_A + 2 * 8 * SLOTS);          // outset[W]
+    static constexpr int QN = W <= 4 ? 16 : 32;                      // child targets of the waves that finished in one tile (two per lane)
+    static constexpr int O_Q = a16(O_A + 2 * 8 * SLOTS);             // uint2[QN]: key, set-arena index of the finished wave
+    static constexpr int O_MISC = O_Q + 8 * QN;                      // outset[W]
     static constexpr int BYTES = a16(O_MISC + 4 * W);
     static constexpr int SET_DWORDS = 2 * SLOTS * W;                 // per group in HBM: the slots' traversed-node sets
     static constexpr int REC_DWORDS = 4 * MAXN;                      // + one capped-diagonal record per node

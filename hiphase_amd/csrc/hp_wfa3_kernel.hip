@@ -129,12 +129,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
     uint32_t score = 0, steps = 0, why = 0;
     uint32_t lane_far = 0, lane_upd = 0;                             // per lane
 #if W3_STATS
-    uint64_t w3c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // wave steps, control passes, group tiles, act lanes, has lanes, committed lanes, jobs, rounds, long extensions (lanes), inserts, tiles with a discard, build chunks
+    uint64_t w3c[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // wave steps, control passes, group tiles, act lanes, has lanes, committed lanes, jobs, rounds, long extensions (lanes), inserts, tiles with a discard, build chunks
 #endif
     const uint32_t n_class = *B.n_items_dev;
     if (B.esc_role == 1u) (void)atomicAdd(B.esc + 4, lane == 0 ? 1u : 0u);   // a producer workgroup has started
+#ifndef W3_PREFETCH
+#define W3_PREFETCH 0   // measured (round 4): no gain - 24.6-27.2 ms against 24.3-25.2 ms per launch stage over three runs each, and 18 more registers
+#endif
+#if W3_PREFETCH
+    uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;   // see "next round's bases" below
+#endif
 #if W3_PROF
-    uint64_t w3t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t w3t[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t w3tl = __builtin_amdgcn_s_memtime();
     const uint64_t w3t0 = w3tl;
     uint32_t w3steps = 0;
@@ -351,6 +357,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
         const bool nD = chk && hinj && omax > 0;
         const uint8_t* ra = readp + (has ? pos0 : 0);
         const uint8_t* na_ = nseq + (has ? omax : 0);
+#if W3_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" :: "v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));   // (the previous step's look-ahead loads have landed long since: nothing waits here)
+#endif
         const W2Pre pm = w2_pre(na_, ra, room > 0);
         const W2Pre8 pA = w2_pre8(nseq + (nA ? oA : 0), readp + (nA ? d + oA : 0), nA);
         const W2Pre8 pB = w2_pre8(nseq + (nB ? oB : 0), readp + (nB ? d + oB : 0), nB);
@@ -444,6 +453,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 } else kind = ((uint32_t)pos_end < other_len) ? W2_KIND_INTERIOR_READ : W2_KIND_INTERIOR;
             }
         }
+#if W3_PREFETCH
+        // ---- next round's bases: a wave that ran a long stretch and stopped inside node and read is the alignment's front; next round
+        // it goes on right behind the mismatch (on this diagonal, or one beside it: the same lines). Those lines are asked for NOW -
+        // two loads per sequence, 128 bytes apart, into registers nobody reads - so that next round's extension (two dependent trips
+        // to memory: the first 16 bytes, then the cooperative 256) finds them in L2 instead of HBM. ----
+        {
+            const bool ahead = kind == W2_KIND_INTERIOR_READ && E >= (uint32_t)omax + 16u;
+            if (ahead) {
+                const uint8_t* a = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(nseq + E + 1u) & ~(uintptr_t)3);
+                const uint8_t* b = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(readp + pos_end + 1) & ~(uintptr_t)3);
+                pf0 = *reinterpret_cast<const uint32_t*>(a); pf1 = *reinterpret_cast<const uint32_t*>(a + 128);
+                pf2 = *reinterpret_cast<const uint32_t*>(b); pf3 = *reinterpret_cast<const uint32_t*>(b + 128);
+            }
+        }
+#endif
         W3T(6);
         // ---- commit: the slots of nodes below the first child of every node that finished in this tile (a prefix of the tile) ----
         const bool fin = kind == W2_KIND_FINISHED;
@@ -536,90 +560,139 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
 #endif
         if (run) {
             nl += nlive; nf += nfin; ip += ncommit;
-            uint64_t fm = status == W2_ST_PENDING ? mf : 0ull;
-#pragma clang loop unroll(disable)
-            while (fm) {   // (group-uniform; usually one wave, if any)
-                W3C(15, 1);
-                const uint32_t L = (uint32_t)__builtin_ctzll(fm);
-                fm &= fm - 1ull;
-                const uint32_t qn = w2_gsel<G>(n, gl, L), qz = w2_gsel<G>(nd.z, gl, L), qw = w2_gsel<G>(nd.w, gl, L);
-                const int32_t td = (int32_t)w2_gsel<G>((uint32_t)(d + (int32_t)len), gl, L);
-                const uint32_t si = w2_gsel<G>(fpos, gl, L);
-                const uint32_t n_child = qz & 0xFFFFu;
-                uint32_t scan = qz >> 16;
-                if (td <= -W2_DIAG_LIM || td >= W2_DIAG_LIM) { status = W2_ST_NEED_BIG, why = 8u; break; }
-                // one target per child of the node: key K, the finished wave's set `si` (group-uniform)
-                auto inject = [&](const uint32_t K) {
-                    W3C(9, 1);
-                    // Behind every target still to come (the usual case: the wave that finished was the front of the alignment, nothing
-                    // of the round lies beyond its node): appended, no look at the list. `lastkey` is the list's last key.
-                    if (ip == np || K > lastkey) {
+            // ---- finished waves become targets (child, diagonal + node length) of this round, kept sorted ----
+            // one target: key K, the finished wave's set `si` (group-uniform)
+            auto insert = [&](const uint32_t K, const uint32_t si) {
+                W3C(9, 1);
+                // behind every target still to come (the wave was the front of the alignment): appended, no look at the list
+                if (ip == np || K > lastkey) {
+                    if (np >= SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
+                    if (gl == 0) A[cbase + np] = make_uint2(K, w3_aux(W3_NONE, si, W3_NONE));
+                    ++np;
+                    lastkey = K;
+                    return;
+                }
+                W3C(12, 1);
+                const uint32_t rem = np - ip;
+                if (rem <= (uint32_t)G) {
+                    // the whole remainder in one look: a lane per target - read, place, write back one further up behind the new one
+                    const bool in = gl < rem;
+                    const uint32_t i = cbase + ip + gl;
+                    const uint2 v = in ? A[i] : make_uint2(0xFFFFFFFFu, 0u);
+                    const uint64_t lt = w2_gballot<G>(v.x < K, gbase), eq = w2_gballot<G>(v.x == K, gbase);
+                    if (!eq) {
                         if (np >= SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
-                        if (gl == 0) A[cbase + np] = make_uint2(K, w3_aux(W3_NONE, si, W3_NONE));
+                        const uint32_t pos = (uint32_t)__popcll(lt);
+                        if (in && gl >= pos) A[i + 1u] = v;
+                        if (gl == 0) A[cbase + ip + pos] = make_uint2(K, w3_aux(W3_NONE, si, W3_NONE));
                         ++np;
-                        lastkey = K;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         return;
                     }
-                    // where K belongs among the targets still to come: [ip, np) is sorted
-                    W3C(12, 1);
-                    uint32_t pos = ip, hit = 0xFFFFFFFFu;
-#pragma clang loop unroll(disable)
-                    for (uint32_t base = ip; base < np; base += (uint32_t)G) {
-                        W3C(13, 1);
-                        const uint32_t i = base + gl;
-                        const uint32_t k = i < np ? A[cbase + i].x : 0xFFFFFFFFu;
-                        const uint64_t lt = w2_gballot<G>(k < K, gbase), eq = w2_gballot<G>(k == K, gbase);
-                        const uint32_t nlt = (uint32_t)__popcll(lt);
-                        pos += nlt;
-                        if (eq) { hit = base + (uint32_t)__builtin_ctzll(eq); break; }
-                        if (nlt < (uint32_t)G) break;
+                    const bool mine = v.x == K;
+                    const uint32_t free0 = ((v.y >> 10) & 0x3FFu) == W3_NONE ? 1u : 0u, free1 = ((v.y >> 20) & 0x3FFu) == W3_NONE ? 1u : 0u;
+                    const uint32_t room = w2_gor<G>(mine ? (free0 | (free1 << 1)) : 0u);
+                    if (room) {   // the target is there: the wave joins it
+                        if (mine) A[i].y = free0 ? ((v.y & ~(0x3FFu << 10)) | (si << 10)) : ((v.y & ~(0x3FFu << 20)) | (si << 20));
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        return;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    if (hit != 0xFFFFFFFFu) {
-                        const uint32_t y = A[cbase + hit].y;
-                        uint32_t ny = y;
-                        if (((y >> 10) & 0x3FFu) == W3_NONE) ny = (y & ~(0x3FFu << 10)) | (si << 10);
-                        else if (((y >> 20) & 0x3FFu) == W3_NONE) ny = (y & ~(0x3FFu << 20)) | (si << 20);
-                        else {
-                            // a third wave onto one target (rare): its set and the second one's merge into a fresh entry of the arena
-                            if (nl + nf + 1u > SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
-                            const uint32_t sm = SL - 1u - nf;
-                            ++nf;
-                            const uint32_t s1 = (y >> 20) & 0x3FFu;
-                            if (gl < (uint32_t)W) gs[(size_t)(cbase + sm) * W + gl] = gs[(size_t)(cbase + s1) * W + gl] | gs[(size_t)(cbase + si) * W + gl];
-                            ny = (y & ~(0x3FFu << 20)) | (sm << 20);
-                        }
-                        if (gl == 0) A[cbase + hit].y = ny;
-                    } else {
-                        if (np >= SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
-                        // shift [pos, np) up by one, from the top down, G entries at a time
-#pragma clang loop unroll(disable)
-                        for (uint32_t top = np; top > pos;) {
-                            W3C(14, 1);
-                            const uint32_t lo = top - pos > (uint32_t)G ? top - (uint32_t)G : pos;
-                            const uint32_t i = lo + gl;
-                            uint2 v = make_uint2(0, 0);
-                            if (i < top) v = A[cbase + i];
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            if (i < top) A[cbase + i + 1u] = v;
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            top = lo;
-                        }
-                        if (gl == 0) A[cbase + pos] = make_uint2(K, w3_aux(W3_NONE, si, W3_NONE));
-                        ++np;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                };
-                // (the first two children come with the node's descriptor; a third and later one - a node several variants reconnect
-                // at - is read from the overflow list in HBM. Two loops: a load on the way to the common case makes every insert
-                // wait for the step's set stores)
-                if (n_child >= 1u) inject(w3_key(qw & 0xFFFFu, td));
-                if (n_child >= 2u && status == W2_ST_PENDING) inject(w3_key(qw >> 16, td));
-                if (n_child > 2u) {
-#pragma clang loop unroll(disable)
-                    for (uint32_t j = 2; j < n_child && status == W2_ST_PENDING; ++j) inject(w3_key(w2_next_child(gedge, qn, scan), td));
+                    // (a third wave onto one target: the general road below merges two sets)
                 }
-                if (status != W2_ST_PENDING) break;
+                // where K belongs among the targets still to come: [ip, np) is sorted
+                uint32_t pos = ip, hit = 0xFFFFFFFFu;
+#pragma clang loop unroll(disable)
+                for (uint32_t base = ip; base < np; base += (uint32_t)G) {
+                    W3C(13, 1);
+                    const uint32_t i = base + gl;
+                    const uint32_t k = i < np ? A[cbase + i].x : 0xFFFFFFFFu;
+                    const uint64_t lt = w2_gballot<G>(k < K, gbase), eq = w2_gballot<G>(k == K, gbase);
+                    const uint32_t nlt = (uint32_t)__popcll(lt);
+                    pos += nlt;
+                    if (eq) { hit = base + (uint32_t)__builtin_ctzll(eq); break; }
+                    if (nlt < (uint32_t)G) break;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (hit != 0xFFFFFFFFu) {
+                    const uint32_t y = A[cbase + hit].y;
+                    uint32_t ny = y;
+                    if (((y >> 10) & 0x3FFu) == W3_NONE) ny = (y & ~(0x3FFu << 10)) | (si << 10);
+                    else if (((y >> 20) & 0x3FFu) == W3_NONE) ny = (y & ~(0x3FFu << 20)) | (si << 20);
+                    else {
+                        // a third wave onto one target (rare): its set and the second one's merge into a fresh entry of the arena
+                        if (nl + nf + 1u > SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
+                        const uint32_t sm = SL - 1u - nf;
+                        ++nf;
+                        const uint32_t s1 = (y >> 20) & 0x3FFu;
+                        if (gl < (uint32_t)W) gs[(size_t)(cbase + sm) * W + gl] = gs[(size_t)(cbase + s1) * W + gl] | gs[(size_t)(cbase + si) * W + gl];
+                        ny = (y & ~(0x3FFu << 20)) | (sm << 20);
+                    }
+                    if (gl == 0) A[cbase + hit].y = ny;
+                } else {
+                    if (np >= SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
+                    // shift [pos, np) up by one, from the top down, G entries at a time
+#pragma clang loop unroll(disable)
+                    for (uint32_t top = np; top > pos;) {
+                        W3C(14, 1);
+                        const uint32_t lo = top - pos > (uint32_t)G ? top - (uint32_t)G : pos;
+                        const uint32_t i = lo + gl;
+                        uint2 v = make_uint2(0, 0);
+                        if (i < top) v = A[cbase + i];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if (i < top) A[cbase + i + 1u] = v;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        top = lo;
+                    }
+                    if (gl == 0) A[cbase + pos] = make_uint2(K, w3_aux(W3_NONE, si, W3_NONE));
+                    ++np;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            };
+            W3T(11);
+            const uint64_t fm = status == W2_ST_PENDING ? mf : 0ull;
+            if (fm) {   // (group-uniform) a wave finished its node in this tile
+                W3C(15, __popcll(fm));
+                // every finished lane puts the targets of its node's first two children (they come with the node's descriptor) into the
+                // group's scratch itself - no broadcast per lane; then one pass per target
+                const uint32_t nch = nd.z & 0xFFFFu;
+                const bool f2 = fin_k && nch >= 2u;
+                const uint64_t m2 = w2_gballot<G>(f2, gbase);
+                const uint32_t qpos = w3_below(fm, gl) + w3_below(m2, gl);
+                const uint32_t m = (uint32_t)(__popcll(fm) + __popcll(m2));
+                const int32_t tdl = d + (int32_t)len;
+                uint2* qbuf = reinterpret_cast<uint2*>(R + C::O_Q);
+                if (fin_k) {
+                    qbuf[qpos] = make_uint2(w3_key(nd.w & 0xFFFFu, tdl), fpos);
+                    if (f2) qbuf[qpos + 1u] = make_uint2(w3_key(nd.w >> 16, tdl), fpos);
+                }
+                if (w2_gballot<G>(fin_k && (tdl <= -W2_DIAG_LIM || tdl >= W2_DIAG_LIM), gbase)) status = W2_ST_NEED_BIG, why = 8u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // one pass per target. (Measured and left out, round 4: all of a tile's new targets merged into the list's last G entries
+                // at once by rank - a broadcast read and two ballots per key. A third of the tiles fell outside what that handles -
+                // a key before the look, two waves onto one new target - and the one-at-a-time road they then took on top of the
+                // attempt made the class kernels 15 % slower: 29 against 25 ms.)
+#pragma clang loop unroll(disable)
+                for (uint32_t k = 0; k < m && status == W2_ST_PENDING; ++k) {
+                    const uint2 q = qbuf[k];
+                    insert(q.x, q.y);
+                }
+                // a third and later child (a node several variants reconnect at) is read from the overflow list in HBM: per lane, rare.
+                // (Kept apart from the common case: a load on the way to it made every step wait for its own set stores - vmcnt
+                // counts loads and stores in one order.)
+#ifndef W3_NO_OVERFLOW_CHILDREN   // (experiment switch: timing without the rare road's loads)
+                uint64_t m3 = w2_gballot<G>(fin_k && nch > 2u, gbase);
+#pragma clang loop unroll(disable)
+                while (m3 && status == W2_ST_PENDING) {
+                    const uint32_t L = (uint32_t)__builtin_ctzll(m3);
+                    m3 &= m3 - 1ull;
+                    const uint32_t qn = w2_gsel<G>(n, gl, L), qz = w2_gsel<G>(nd.z, gl, L);
+                    const int32_t td = (int32_t)w2_gsel<G>((uint32_t)tdl, gl, L);
+                    const uint32_t si = w2_gsel<G>(fpos, gl, L);
+                    uint32_t scan = qz >> 16;
+#pragma clang loop unroll(disable)
+                    for (uint32_t j = 2; j < (qz & 0xFFFFu) && status == W2_ST_PENDING; ++j) insert(w3_key(w2_next_child(gedge, qn, scan), td), si);
+                }
+#endif
             }
             if (ip >= np) state = S_ROUND;
             if (++steps > W2_MAX_STEPS) status = W2_ST_INTERNAL;
@@ -629,9 +702,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
     }
 #if W3_PROF
     if (lane == 0 && (blockIdx.x % 61) == 3)
-        printf("w3prof G%d W%d wg %u: total %llu steps %u | between %llu control %llu candidates %llu issue %llu extension %llu ties %llu capped-decide %llu commit-write %llu capins %llu finals %llu inject %llu\n", G, W, blockIdx.x,
+        printf("w3prof G%d W%d wg %u: total %llu steps %u | between %llu control %llu candidates %llu issue %llu extension %llu ties %llu capped-decide %llu commit-write %llu capins %llu finals %llu inject %llu pre-inject %llu\n", G, W, blockIdx.x,
                (unsigned long long)(w3tl - w3t0), w3steps, (unsigned long long)w3t[0], (unsigned long long)w3t[1], (unsigned long long)w3t[2], (unsigned long long)w3t[3], (unsigned long long)w3t[4],
-               (unsigned long long)w3t[5], (unsigned long long)w3t[6], (unsigned long long)w3t[7], (unsigned long long)w3t[8], (unsigned long long)w3t[9], (unsigned long long)w3t[10]);
+               (unsigned long long)w3t[5], (unsigned long long)w3t[6], (unsigned long long)w3t[7], (unsigned long long)w3t[8], (unsigned long long)w3t[9], (unsigned long long)w3t[10], (unsigned long long)w3t[11]);
 #endif
     if (B.esc_role == 1u) {   // a producer workgroup is gone (everything it hands over has been published)
         W2_WAIT_VM();

@@ -12,5 +12,5 @@ for l in open(sys.argv[1]):
 for key, d in sorted(tot.items()):
     T = max(1, d['total']); st = max(1, d['steps'])
     print(f"G{key[0]} W{key[1]}: {d['wgs']} workgroups, {st} wave steps, {T / st:.0f} ticks per step")
-    for k in ('between', 'control', 'candidates', 'issue', 'extension', 'ties', 'capped-decide', 'commit-write', 'capins', 'finals', 'inject'):
-        print(f"   {k:14s} {100.0 * d[k] / T:6.2f} %   {d[k] / st:8.0f} ticks/step")
+    for k in ('between', 'control', 'candidates', 'issue', 'extension', 'ties', 'capped-decide', 'commit-write', 'capins', 'finals', 'pre-inject', 'inject'):
+        print(f"   {k:14s} {100.0 * d.get(k, 0) / T:6.2f} %   {d.get(k, 0) / st:8.0f} ticks/step")
