@@ -123,5 +123,6 @@ int pipeline_submit(Pipeline* s, size_t n_blocks, const hp_block_input* in, cons
 int pipeline_wait(Pipeline* s, uint64_t ticket, double* stage_ms, uint64_t* work);
 uint64_t pipeline_load(Pipeline* s, bool* has_free_slot);   // records in flight
 void pipeline_wait_free(Pipeline* s);                       // returns when a slot is free
+uint32_t pipeline_free_slots(Pipeline* s);
 void pipeline_destroy(Pipeline* s);
 }  // namespace hp

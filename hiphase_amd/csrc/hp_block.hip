@@ -148,7 +148,11 @@ int hp::blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in
     if (bs->st.size() < n_blocks) bs->st.resize(n_blocks);
     bs->job_first.assign(n_blocks + 1, 0);
     const char* mj = std::getenv("HP_WFA2_MIN_JOBS");
-    const size_t min_jobs = mj ? (size_t)std::strtoull(mj, nullptr, 10) : 4608;
+    // (sets below this take the latency path - the dense-band kernel, one wavefront per read. 1 024 since round 4: a merged set of
+    // the per-block dispatcher is a few thousand records, its noisy reads cost the dense-band kernel a 500-edit band each, and the
+    // compact road settles them by the reference-window test instead: 64 blocking callers 77 -> 84 k hets/s, 2 560 asynchronous
+    // ones 626 -> 748 k. hp_wfa_assign_batch keeps its own 4 608.)
+    const size_t min_jobs = mj ? (size_t)std::strtoull(mj, nullptr, 10) : 1024;
     // per block (host threads over blocks): validation, and for every record its overlaps (read_parsing.rs:688-730)
     std::vector<uint32_t> njobs(n_blocks, 0);
     {
@@ -917,6 +921,10 @@ private:
         static const uint64_t v = [] { const char* e = std::getenv("HP_DISPATCH_MAX_RECORDS"); return e ? (uint64_t)std::max(1ll, std::atoll(e)) : 160000ull; }();
         return v;
     }
+    static uint64_t min_records() {   // no crumbs: a set of a dozen blocks costs a device the same stage latencies as one of a few hundred
+        static const uint64_t v = [] { const char* e = std::getenv("HP_DISPATCH_MIN_RECORDS"); return e ? (uint64_t)std::max(1ll, std::atoll(e)) : 2048ull; }();
+        return v;
+    }
     void feed(int v) {
         Dev& D = *devs_[(size_t)v];
         (void)hipSetDevice(D.device);
@@ -934,6 +942,7 @@ private:
             }
             // a free slot first: whatever arrives while the pipeline is full joins this set - the batching of a busy device
             pipeline_wait_free(D.pipe);
+            const uint32_t free_slots = std::max(1u, pipeline_free_slots(D.pipe));
             std::unique_ptr<MergedSet> ms(new MergedSet());
             {
                 std::unique_lock<std::mutex> lk(m_);
@@ -954,7 +963,14 @@ private:
                 // device the same stages as one of a few hundred)
                 uint64_t queued = 0;
                 for (BlocksReq* r : any_q_) queued += r->records;
-                const uint64_t share = std::max<uint64_t>((queued + (uint64_t)n_vdev_ - 1) / (uint64_t)n_vdev_, std::min<uint64_t>(queued, 4096));
+                // ... and of that share, what one of this pipeline's FREE slots should carry: callers that block (T calls in flight,
+                // main.rs:385) all sit in the sets that are on their way - one set for all of them is one set's latency per T blocks
+                // (116 ms per 64 blocks, measured); spread over the free slots the stages of consecutive sets overlap. Callers that
+                // submit and go on (40 x T in flight) fill every slot with a full-sized set either way.
+                const uint64_t per_dev = (queued + (uint64_t)n_vdev_ - 1) / (uint64_t)n_vdev_;
+                const uint64_t per_slot = (per_dev + (uint64_t)free_slots - 1) / (uint64_t)free_slots;
+                // (a deep queue means callers that do not wait: full-sized sets)
+                const uint64_t share = queued > 65536 ? max_records() : std::max<uint64_t>(per_slot, std::min<uint64_t>(queued, min_records()));
                 if (rec < max_records()) take_from(any_q_, std::min(max_records(), rec + share));
             }
             if (ms->reqs.empty()) continue;

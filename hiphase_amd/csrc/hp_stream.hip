@@ -201,6 +201,13 @@ uint64_t hp::pipeline_load(Pipeline* s, bool* has_free_slot) {
     return s->load;
 }
 
+uint32_t hp::pipeline_free_slots(Pipeline* s) {
+    std::unique_lock<std::mutex> lk(s->m);
+    uint32_t n = 0;
+    for (auto& x : s->slots) n += x->state == Slot::FREE ? 1u : 0u;
+    return n;
+}
+
 void hp::pipeline_wait_free(Pipeline* s) {
     std::unique_lock<std::mutex> lk(s->m);
     s->cv.wait(lk, [&]() { for (auto& x : s->slots) if (x->state == Slot::FREE) return true; return false; });

@@ -978,8 +978,9 @@ int W2Session::late() {
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
     const bool trace = std::getenv("HP_STREAM_TRACE") != nullptr;
     const double tl0 = w2_now_ms();
-    double tl_tail = tl0, tl_bound = tl0;
-    struct LateTrace { bool on; const double& t0; const double& t1; const double& t2; const W2Session* s; ~LateTrace() { if (on) fprintf(stderr, "[hp] late: largest class done + held results after %.1f ms, reference-window test after %.1f, dense-band pass after %.1f (%zu jobs)\n", t1 - t0, t2 - t0, w2_now_ms() - t0, s->pend.big.size()); } } lt{trace, tl0, tl_tail, tl_bound, this};
+    double tl_early = tl0, tl_tail = tl0, tl_bound = tl0;
+    size_t n_early = 0;
+    struct LateTrace { bool on; const double& t0; const double& te; const double& t1; const double& t2; const size_t& ne; ~LateTrace() { if (on) fprintf(stderr, "[hp] late: the first collection's %zu leftovers settled (reference-window test + dense-band pass) after %.1f ms, largest class done + held results after %.1f, their leftovers' test after %.1f, dense-band pass after %.1f\n", ne, te - t0, t1 - t0, t2 - t0, w2_now_ms() - t0); } } lt{trace, tl0, tl_early, tl_tail, tl_bound, n_early};
     // results of jobs the largest class's kernel wrote after run()'s collection, gathered on the device: ids + row offsets up, one
     // record + the allele row per job down. What it could not align joins pend.big.
     hipStream_t s2 = pend.stream2;
@@ -1077,8 +1078,14 @@ int W2Session::late() {
                     BA.max_t = maxT;
                     BA.lds_seq = std::min<uint32_t>(need_seq, W2_BOUND_LDS_SEQ);
                     const size_t lds_total = lds_wf + BA.lds_seq;
-                    HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_bound_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
-                    hipLaunchKernelGGL(hp_wfa2_bound_kernel, dim3((unsigned)cand.size()), dim3(64), lds_total, bs, BA);
+                    static const int bound_threads = [] { const char* e = std::getenv("HP_BOUND_THREADS"); return (e && std::atoi(e) == 64) ? 64 : 256; }();
+                    if (bound_threads == 64) {
+                        HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_bound_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
+                        hipLaunchKernelGGL(hp_wfa2_bound_kernel<64>, dim3((unsigned)cand.size()), dim3(64), lds_total, bs, BA);
+                    } else {
+                        HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_bound_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
+                        hipLaunchKernelGGL(hp_wfa2_bound_kernel<256>, dim3((unsigned)cand.size()), dim3(256), lds_total, bs, BA);
+                    }
                     HP_HIP_CHECK(hipGetLastError());
                     if ((rcb = dev_get(exc.data(), d_exc.p, cand.size(), bs)) != HP_OK) return rcb;
                     if (dev_io_sync(bs) != HP_OK) { set_error("WFA bound kernel failed"); return HP_ERR_HIP; }
@@ -1125,10 +1132,12 @@ int W2Session::late() {
         size_t n_large = 0;   // graphs of 257 .. 512 nodes: the 16-word launch takes them when a set has wide_min / 16 of them
         for (uint32_t x : pend.big_nodes) n_large += Pending::nodes_of(x) > (uint32_t)W2Cfg<8>::MAXN ? 1 : 0;
         if (pend.two_phase && !pend.big.empty() && !(eenv && eenv[0] == '0') && (wide_min0 == 0 || (pend.big.size() < wide_min0 && n_large < std::max<size_t>(1, wide_min0 / 16)))) {
+            n_early = pend.big.size();
             const int rce = dense_pass();
             if (rce != HP_OK) return rce;
         }
     }
+    tl_early = w2_now_ms();
     if (pend.two_phase) {
         const int rc = collect(pend.held, pend.held_nodes);
         if (rc != HP_OK) return rc;

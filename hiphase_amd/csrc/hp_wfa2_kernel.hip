@@ -1097,9 +1097,14 @@ struct W2BoundArgs {
 constexpr uint32_t W2_BOUND_MAX_T = 1000;   // the test costs T^2 / 64 tiles: 3 ms of a wavefront at 1 000, 30 at 3 000 (where a structural
                                             // variant in the window has made D so large that the test rarely settles anything)
 constexpr uint32_t W2_BOUND_LDS_SEQ = 96 * 1024;   // read + reference window are staged in LDS when they fit in this many bytes
-__global__ void __launch_bounds__(64) hp_wfa2_bound_kernel(W2BoundArgs A) {
+// NT threads per job (64 or 256): a round's diagonals (up to 2 T + 1 of them) are independent, the jobs are a few hundred, and what
+// the rows stage waits for is their latency. Four wavefronts need a free slot on every SIMD of one CU at once, though - beside a
+// resident launch set that may be a long wait (hp_wfa2.hip picks; HP_BOUND_THREADS).
+template <uint32_t W2_BOUND_THREADS>
+__global__ void __launch_bounds__(W2_BOUND_THREADS) hp_wfa2_bound_kernel(W2BoundArgs A) {
     extern __shared__ int32_t w2b_lds[];
-    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    __shared__ int w2b_done;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
     if (q >= A.n) return;
     const W2Job J = A.jobs[A.ids[q]];
     const int32_t T = (int32_t)A.thresh[q];
@@ -1116,8 +1121,8 @@ __global__ void __launch_bounds__(64) hp_wfa2_bound_kernel(W2BoundArgs A) {
             la = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(la) + 15) & ~(uintptr_t)15);
             uint8_t* lb = la + na;
             // (16-byte copies; the sources are 16-byte aligned only for the read - the window starts anywhere in its hull)
-            for (uint32_t o = lane * 16u; o < na; o += 64u * 16u) { uint4 v; __builtin_memcpy(&v, a + o, 16); *reinterpret_cast<uint4*>(la + o) = v; }
-            for (uint32_t o = lane * 16u; o < nb; o += 64u * 16u) { uint4 v; __builtin_memcpy(&v, b + o, 16); *reinterpret_cast<uint4*>(lb + o) = v; }
+            for (uint32_t o = tid * 16u; o < na; o += W2_BOUND_THREADS * 16u) { uint4 v; __builtin_memcpy(&v, a + o, 16); *reinterpret_cast<uint4*>(la + o) = v; }
+            for (uint32_t o = tid * 16u; o < nb; o += W2_BOUND_THREADS * 16u) { uint4 v; __builtin_memcpy(&v, b + o, 16); *reinterpret_cast<uint4*>(lb + o) = v; }
             a = la; b = lb;
         }
     }
@@ -1125,7 +1130,8 @@ __global__ void __launch_bounds__(64) hp_wfa2_bound_kernel(W2BoundArgs A) {
     const int32_t W = 2 * T + 3;                 // diagonals -T-1 .. T+1 (the rim stays NONE)
     int32_t* prev = w2b_lds;
     int32_t* cur = w2b_lds + W;
-    for (int32_t i = (int32_t)lane; i < 2 * W; i += 64) w2b_lds[i] = NONE;
+    for (int32_t i = (int32_t)tid; i < 2 * W; i += (int32_t)W2_BOUND_THREADS) w2b_lds[i] = NONE;
+    if (tid == 0) w2b_done = 0;
     __syncthreads();
     auto extend = [&](int32_t i, int32_t k) {   // furthest i' >= i with a[i..i') == b[i + k .. i' + k)
         int32_t j = i + k;
@@ -1144,15 +1150,15 @@ __global__ void __launch_bounds__(64) hp_wfa2_bound_kernel(W2BoundArgs A) {
         return i;
     };
     const int32_t kend = m - n;                  // the diagonal of the end cell
-    bool done = false;
-    if (lane == 0) { const int32_t f = extend(0, 0); prev[T + 1] = f; done = (kend == 0 && f == n); }
-    done = __any(done);
+    if (tid == 0) { const int32_t f = extend(0, 0); prev[T + 1] = f; if (kend == 0 && f == n) w2b_done = 1; }
     __syncthreads();
+    bool done = w2b_done != 0;
     int32_t s = 0;
     while (!done && s < T) {
         ++s;
-        for (int32_t base = -s; base <= s; base += 64) {
-            const int32_t k = base + (int32_t)lane;
+        bool mine = false;
+        for (int32_t base = -s; base <= s; base += (int32_t)W2_BOUND_THREADS) {
+            const int32_t k = base + (int32_t)tid;
             if (k <= s) {
                 const int32_t p0 = prev[k + T + 1], p1 = prev[k + 1 + T + 1], pm = prev[k - 1 + T + 1];
                 int32_t f = NONE;
@@ -1161,14 +1167,15 @@ __global__ void __launch_bounds__(64) hp_wfa2_bound_kernel(W2BoundArgs A) {
                 if (pm >= 0 && pm + k <= m && pm > f) f = pm;                       // a reference base of its own
                 if (f >= 0) f = extend(f, k);
                 cur[k + T + 1] = f;
-                if (k == kend && f == n) done = true;
+                if (k == kend && f == n) mine = true;
             }
         }
-        done = __any(done);
-        __syncthreads();
+        if (mine) w2b_done = 1;
+        __syncthreads();                         // the round's diagonals are written; everyone sees whether the end cell was reached
+        done = w2b_done != 0;
         int32_t* t = prev; prev = cur; cur = t;
     }
-    if (lane == 0) A.exceeds[q] = done ? 0 : 1;
+    if (tid == 0) A.exceeds[q] = done ? 0 : 1;
 }
 
 }  // namespace hp

@@ -284,7 +284,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
         W3T(1);
         if (!__any(state == S_TILE)) {
             if (!__any(state == S_WAIT)) break;   // every group is done
-            if (++idle_polls > 60000u) break;     // (~1.5 s of nothing to do: never hang the device; unclaimed jobs stay for the host's pass)
+            if (++idle_polls > 60000u) {          // (~1.5 s of nothing to do: never hang the device; unclaimed jobs stay for the host's pass)
+#ifdef W3_DEBUG_TIMEOUT
+                if (lane == 0) printf("w3 timeout: wg %u role %u gone %u producers %u started %u pub %u taken %u ticket %u n_class %u\n", blockIdx.x, B.esc_role, atomicAdd(B.esc + 2, 0u), B.esc_producers, atomicAdd(B.esc + 4, 0u), atomicAdd(B.esc + 1, 0u), atomicAdd(B.esc, 0u), ticket, n_class);
+#endif
+                break;
+            }
             for (int z = 0; z < 8; ++z) __builtin_amdgcn_s_sleep(127);
             continue;
         }
