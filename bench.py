@@ -159,17 +159,23 @@ def so_sha256():
     return hashlib.sha256(open(_ffi.LIB_PATH, "rb").read()).hexdigest()
 
 
-def measured_traffic(kernel, per_unit_key, units):
+def measured_traffic(kernels, per_unit_key, units):
     """HBM bytes per launch from the PMC counters: only a measurement taken on THIS build of the library counts
-    (profiles/round3/traffic.json records the sha256 of the .so it was measured on); otherwise null."""
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "round3", "traffic.json")))
-        e = tj[kernel]
-        if e["so_sha256"] != so_sha256():
-            return None, "stale: measured on another build of libhiphase_gpu.so"
-        return e[per_unit_key] * units, e["source"]
-    except Exception:
-        return None, None
+    (profiles/round4/traffic.json records the sha256 of the .so it was measured on); otherwise null. `kernels`: names to look
+    for, the first one the file holds wins (hp_wfa3_kernel, or hp_wfa2_kernel under HP_WFA_GEN=2)."""
+    for rnd in ("round4", "round3"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
+        except Exception:
+            continue
+        for kernel in ([kernels] if isinstance(kernels, str) else kernels):
+            e = tj.get(kernel)
+            if not e:
+                continue
+            if e["so_sha256"] != so_sha256():
+                return None, "stale: measured on another build of libhiphase_gpu.so"
+            return e[per_unit_key] * units, e["source"]
+    return None, None
 
 
 def block_params(cfg=None):
@@ -217,6 +223,76 @@ def cpu_whole_path(sset, oracle_out, prm, seconds, threads, order):
     return state["hets"], state["records"], state["done"], time.perf_counter() - t0
 
 
+def drop_in_rates(lib, sets, prm, args):
+    """The per-block entries as HiPhase's worker pool would drive them (reference src/main.rs:326-462), same block sets as the
+    headline, every block handed over ON ITS OWN: (a) asynchronous - hp_block_submit / hp_block_wait with 40 x 64 = 2 560 blocks in
+    flight, the reference's own job slots (main.rs:328); (b) blocking - 64 threads each in hp_solve_blocks(1, ...), the one-call-site
+    patch. Behind both the library merges what is in flight into sets for the per-device pipelines. Upload included."""
+    import ctypes as C
+    import threading
+    from hiphase_amd import _ffi
+    n_sets = len(sets)
+    outs = [s.outputs() for s in sets]
+    res = {"threads": 64, "in_flight_async": 2560}
+
+    def blocks_of(passes):
+        for k in range(passes):
+            s, o = sets[k % n_sets], outs[k % n_sets]
+            for b in range(s.n):
+                yield s, o, b
+
+    def run_async(passes):
+        pending, hets = [], 0
+        t0 = time.perf_counter()
+        for s, o, b in blocks_of(passes):
+            if len(pending) >= 2560:
+                _ffi.check(lib.hp_block_wait(pending.pop(0)))
+            t = C.c_uint64(0)
+            _ffi.check(lib.hp_block_submit(1, C.byref(s.inputs[b]), C.byref(prm), C.byref(o.arr[b]), -1, C.byref(t)))
+            pending.append(t.value)
+            hets += s.inputs[b].n_hets
+        for t in pending:
+            _ffi.check(lib.hp_block_wait(t))
+        return hets, time.perf_counter() - t0
+
+    def run_blocking(passes):
+        work = list(blocks_of(passes))
+        lock, state = threading.Lock(), {"next": 0, "err": None}
+
+        def body():
+            while True:
+                with lock:
+                    k = state["next"]
+                    if k >= len(work) or state["err"]:
+                        return
+                    state["next"] = k + 1
+                s, o, b = work[k]
+                rc = lib.hp_solve_blocks(1, C.byref(s.inputs[b]), C.byref(prm), C.byref(o.arr[b]), -1)
+                if rc != 0:
+                    state["err"] = rc
+                    return
+
+        th = [threading.Thread(target=body) for _ in range(64)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if state["err"]:
+            raise RuntimeError(f"hp_solve_blocks failed: {state['err']}")
+        return sum(w[0].inputs[w[2]].n_hets for w in work), time.perf_counter() - t0
+
+    run_async(2)                                  # (starts the dispatcher's pipelines, sizes their buffers)
+    h, dt = run_async(max(6, args.steps // 2))
+    res["async_hets_per_s"] = h / dt
+    run_blocking(1)
+    h, dt = run_blocking(3)
+    res["blocking_hets_per_s"] = h / dt
+    res["note"] = ("every block its own call, merged behind the call into sets for the per-device pipeline; async = hp_block_submit / hp_block_wait "
+                   "(the reference's 40 x threads job slots in flight), blocking = 64 threads in hp_solve_blocks(1, ..., -1)")
+    return res
+
+
 def host_cores():
     """Hardware threads this process may use (affinity mask, clipped by a cgroup CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -258,7 +334,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
     # holds in flight plus one; a set that comes round again still crosses PCIe)
     n_local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     per_rank_sets = args.distinct_sets if n_local == 1 else max(args.depth + 1, min(args.distinct_sets, 48 // n_local))
-    n_sets = 1 if capture else max(1, min(args.steps + args.warmup, per_rank_sets))
+    n_sets = 1 if capture else max(1, min(args.steps + max(args.warmup, args.depth + 1), per_rank_sets))
     gen_threads = max(2, min(32, host_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     t_gen = time.perf_counter()
     sets = [capture] if capture else []
@@ -306,11 +382,14 @@ def main_path(args, rank, world, local_rank, dist, backend):
             wait_oldest()
         return stages, works
 
-    run(0, args.warmup)
+    # (untimed warm-up: at least depth + 1 sets whatever --warmup says - every slot of the stream must have sized its device and
+    # pinned buffers once, hipMalloc / hipHostMalloc wait for the whole device - reported as warmup_run)
+    warm = max(args.warmup, args.depth + 1)
+    run(0, warm)
     sync_all()
     cg0, cpu0 = _cgroup_cpu_stat(), time.process_time()
     t0 = time.perf_counter()
-    stages, works = run(args.warmup, args.steps)      # every wait returns with that set's results in the caller's buffers
+    stages, works = run(warm, args.steps)      # every wait returns with that set's results in the caller's buffers
     sync_all()
     elapsed = time.perf_counter() - t0
     cg1, cpu1 = _cgroup_cpu_stat(), time.process_time()
@@ -321,25 +400,27 @@ def main_path(args, rank, world, local_rank, dist, backend):
     if dist is not None:
         from hiphase_amd.shard import max_over_ranks
         elapsed = max_over_ranks(dist, elapsed, device="cuda" if backend == "nccl" else "cpu")   # timing only; no block data crosses ranks
-    hets_timed = sum(sets[k % n_sets].info["hets"] for k in range(args.warmup, args.warmup + args.steps))
+    hets_timed = sum(sets[k % n_sets].info["hets"] for k in range(warm, warm + args.steps))
     if rank == 0:
         st_mean = np.mean(np.asarray(stages), axis=0)
         work = dict(zip(("wfa_reads", "wfa_read_bytes", "wfa_node_bytes", "wfa_updates", "astar_cells", "astar_evals", "hets", "rows"),
                         np.mean(np.asarray(works, dtype=np.float64), axis=0)))
-        info = sets[args.warmup % n_sets].info
+        info = sets[warm % n_sets].info
         k_wfa_ms, k_astar_ms = st_mean[8], st_mean[9]
         # graph-WFA kernels: algorithmic bytes = read bases + bytes of the traversed graph nodes + 8 B per (node, diagonal) wave update
         # (SURVEY.md 8d), counted on the device for the reads the compact kernels aligned. kernel_ms: the three graph-size
         # instantiations run concurrently on three streams; HIP events around the launch set give their span per set
         b_wfa = work["wfa_read_bytes"] + work["wfa_node_bytes"] + 8 * work["wfa_updates"]
         b_astar = BYTES_PER_CELL * work["astar_cells"]
-        k_wfa = {"kernel": "hp::hp_wfa2_kernel<8,2> + <8,4> + <16,8> (concurrent; span of the launch set, mean over the timed sets)", "bound": "hbm",
+        gen2 = os.environ.get("HP_WFA_GEN", "3").startswith("2")
+        kname = "hp_wfa2_kernel" if gen2 else "hp_wfa3_kernel"
+        k_wfa = {"kernel": f"hp::{kname}<8,2> + <8,4> + <16,8> (concurrent; span of the launch set - the largest class's tail included -, mean over the timed sets)", "bound": "hbm",
                  "kernel_ms": k_wfa_ms, "algorithmic_bytes_per_launch": b_wfa, "achieved": b_wfa / (k_wfa_ms * 1e-3) / 1e9 if k_wfa_ms > 0 else 0.0,
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "reads": work["wfa_reads"], "reads_per_s": work["wfa_reads"] / (k_wfa_ms * 1e-3) if k_wfa_ms > 0 else 0.0,
                  "bytes_per_read": b_wfa / max(1.0, work["wfa_reads"]), "wave_updates_per_read": work["wfa_updates"] / max(1.0, work["wfa_reads"]),
-                 "reads_left_compact_path": float(np.mean([sets[k % n_sets].info["records"] for k in range(args.warmup, args.warmup + args.steps)])) - work["wfa_reads"]}
+                 "reads_left_compact_path": float(np.mean([sets[k % n_sets].info["records"] for k in range(warm, warm + args.steps)])) - work["wfa_reads"]}
         k_wfa["frac"] = k_wfa["achieved"] / HBM_PEAK_GBS
-        k_wfa["traffic"], k_wfa["traffic_source"] = measured_traffic("hp_wfa2_kernel", "bytes_per_read", work["wfa_reads"])
+        k_wfa["traffic"], k_wfa["traffic_source"] = measured_traffic(["hp_wfa2_kernel"] if gen2 else ["hp_wfa3_kernel"], "bytes_per_read", work["wfa_reads"])
         k_astar = {"kernel": "hp::hp_astar_kernel", "bound": "hbm", "kernel_ms": k_astar_ms, "algorithmic_bytes_per_launch": b_astar,
                    "achieved": b_astar / (k_astar_ms * 1e-3) / 1e9 if k_astar_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "cells_per_het": work["astar_cells"] / max(1, info["hets"])}
@@ -353,7 +434,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
         out = {
             "metric": "het variants phased/sec, whole path, streamed (every step a new block set: records over PCIe -> graph-WFA -> rows -> A* -> span counts / haplotags)",
             "value": hets_timed * world / elapsed,
-            "unit": "hets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "hets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_run": warm,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u64", "data": "synthetic", "host_cpu": host_cpu,
             "config": {"workload": (f"synthetic read-bearing WGS-like block sets, one NEW set per step and GPU through hp_blockstream_* ({args.depth} sets in flight): "
@@ -378,7 +459,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
         if world == 1 and not args.no_resident:
             # secondary: the same path over ONE set whose inputs are already in HBM (hp_blockset_solve again and again): what the
             # pipeline would do if PCIe and the host stages were free and nothing overlapped
-            s0 = sets[args.warmup % n_sets]
+            s0 = sets[warm % n_sets]
             stc = C.c_int(0)
             t_up = time.perf_counter()
             bs = lib.hp_blockset_create(s0.n, s0.inputs, C.byref(prm), local_rank, C.byref(stc))
@@ -397,6 +478,8 @@ def main_path(args, rank, world, local_rank, dist, backend):
                 out["resident"] = {"hets_per_s": s0.info["hets"] / dt, "ms_per_step": dt * 1e3, "layout_upload_ms": t_up * 1e3,
                                    "note": "hp_blockset_solve over one resident set (inputs in HBM, no overlap between stages)"}
                 out["streamed_over_resident"] = out["value"] / out["resident"]["hets_per_s"]
+        if world == 1 and not args.no_drop_in:
+            out["drop_in"] = drop_in_rates(lib, sets, prm, args)
         if capture:
             out["data"] = "replay of " + os.path.basename(args.replay)
             out["config"]["workload"] = f"replay of the read-bearing capture {os.path.basename(args.replay)}: {info['blocks']} blocks, {info['hets']} hets, {info['records']} records, streamed again every step"
@@ -406,7 +489,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
         if not args.no_cpu and world == 1:
             # CPU leg + parity, on the first timed set: the oracle's whole path (hpo_solve_block) on every host core over ALL its
             # blocks - that is also the parity check of every block - and on one thread over a random sample of them
-            i0 = args.warmup % n_sets
+            i0 = warm % n_sets
             s0, gpu_out = sets[i0], outs[i0]
             cores = host_cores()
             rng = np.random.default_rng(12345)
@@ -444,6 +527,7 @@ def main():
     ap.add_argument("--distinct-sets", type=int, default=16, help="path workload: generated sets (steps + warm-up if fewer; cycled if more are needed)")
     ap.add_argument("--spec", action="append", default=[], help="path workload: override a field of hp_synth_reads_spec, key=value (repeatable)")
     ap.add_argument("--no-resident", action="store_true", help="path workload: skip the secondary resident (inputs-in-HBM) figure")
+    ap.add_argument("--no-drop-in", action="store_true", help="path workload: skip the secondary per-block (drop-in) rates")
     ap.add_argument("--seed", type=int, default=20250928, help="path workload: seed of the synthetic block mix (rank r uses seed + r)")
     ap.add_argument("--blocks", type=int, default=6144, help="blocks per GPU (24 resident single-wave workgroups per CU x 256 CUs)")
     ap.add_argument("--hets", type=int, default=5000)

@@ -313,6 +313,7 @@ EXPORTS = [
     "hp_version",
     "hp_set_coalescing",
     "hp_last_kernel_ms",
+    "hp_trim_device_cache",
     "hp_abi_layout",
     "hp_hpbk_append",
     "hp_synth_block_size",
@@ -453,6 +454,7 @@ def lib():
     dll.hp_last_error.restype = C.c_char_p
     dll.hp_version.restype = C.c_char_p
     dll.hp_last_kernel_ms.restype = C.c_double
+    dll.hp_trim_device_cache.restype = C.c_size_t
     _lib = dll
     return dll
 

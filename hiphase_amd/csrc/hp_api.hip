@@ -15,7 +15,7 @@
 namespace hp {
 namespace {
 // see hp_common.h: size classes = next power of two up to 1 MiB, then multiples of 1 MiB (so a re-run of a similar
-// batch finds its blocks again); at most 64 GiB stay cached (of 288), single blocks above 8 GiB never do. The cache is process-wide
+// batch finds its blocks again); at most 2/9 of the device's memory stays cached (64 of 288 GiB), single blocks above an eighth of that never do. The cache is process-wide
 // (one mutex; an entry point takes a couple of dozen blocks per call): a block set travels through the threads of a block
 // stream - laid out by one, aligned by the next, solved by a third - and whoever lets a buffer go must hand it to whoever needs
 // one next, or the first thread would hipMalloc (and synchronise the device) for every set. Never destroyed: threads may still
@@ -24,7 +24,19 @@ struct DevCache {
     std::mutex m;
     std::multimap<std::pair<int, size_t>, void*> free_;   // (device, bytes) -> block
     size_t cached = 0;
-    static constexpr size_t kMaxCached = 64ull << 30, kMaxBlock = 8ull << 30;
+    // what may stay cached: a share of the device's memory (2/9 = 64 of an MI355X's 288 GiB; HP_DEV_CACHE_GB overrides), a single
+    // block an eighth of that - a 64 GB part, or a device shared with another allocator, keeps its room. hp_trim_device_cache()
+    // hands everything back.
+    static size_t max_cached() {
+        static const size_t v = [] {
+            if (const char* e = std::getenv("HP_DEV_CACHE_GB")) return (size_t)std::max(0ll, std::atoll(e)) << 30;
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) return (size_t)64 << 30;
+            return tot / 9 * 2;
+        }();
+        return v;
+    }
+    static size_t max_block() { return max_cached() / 8; }
     // size classes: powers of two and 1.5 x powers of two. A request takes any cached block up to twice its size: the buffers of a
     // stage differ a little from set to set (a few hundred leftovers more or less), and a miss is a hipMalloc - which waits for
     // every kernel on the device, the persistent ones of the neighbouring stage included (measured: stalls of 50-400 ms).
@@ -235,6 +247,16 @@ int dev_io_sync(hipStream_t st) {
     return HP_OK;
 }
 
+// the guards' way out (an error return between a dev_get and its dev_io_sync): waits for the stream - queued copies may still read
+// or write the arena and the caller's buffers - and FORGETS the pending gets instead of delivering them: their destinations may
+// be locals that were declared after the guard and are gone by the time it runs
+void dev_io_abort(hipStream_t st) {
+    (void)hipStreamSynchronize(st);
+    g_io.gets.clear();
+    g_io.used = 0;
+    g_io.wanted = 0;
+}
+
 hipStream_t thread_stream(int device_id) {
     struct Slot { int device = -1; hipStream_t s = nullptr; };
     struct Holder { Slot part[3]; ~Holder() { for (auto& x : part) if (x.s) (void)hipStreamDestroy(x.s); } };
@@ -251,13 +273,28 @@ void dev_cache_put(void* p, size_t bytes, int dev) {   // dev: what dev_cache_ge
     DevCache& c = dev_cache();
     {
         std::lock_guard<std::mutex> lk(c.m);
-        if (bytes <= DevCache::kMaxBlock && c.cached + bytes <= DevCache::kMaxCached) {
+        if (bytes <= DevCache::max_block() && c.cached + bytes <= DevCache::max_cached()) {
             c.free_.insert({{dev, bytes}, p});
             c.cached += bytes;
             return;
         }
     }
     (void)hipFree(p);
+}
+
+extern "C" size_t hp_trim_device_cache(void) {   // frees every cached device block (of every device); returns the bytes handed back
+    DevCache& c = dev_cache();
+    std::vector<void*> drop;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(c.m);
+        for (auto& kv : c.free_) drop.push_back(kv.second);
+        bytes = c.cached;
+        c.free_.clear();
+        c.cached = 0;
+    }
+    for (void* q : drop) (void)hipFree(q);
+    return bytes;
 }
 
 static std::atomic<int> g_coalesce{-1};   // -1: ask the environment once

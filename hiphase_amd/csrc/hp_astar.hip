@@ -795,7 +795,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
 namespace {
 struct Fetch { void* dst; const void* src; size_t n; };
 int fetch_all(hp_batch*, hipStream_t st, std::initializer_list<Fetch> fs) {
-    for (const Fetch& f : fs) { const int rc = dev_get(f.dst, f.src, f.n, st); if (rc != HP_OK) { (void)dev_io_sync(st); return rc; } }
+    for (const Fetch& f : fs) { const int rc = dev_get(f.dst, f.src, f.n, st); if (rc != HP_OK) { dev_io_abort(st); return rc; } }
     return dev_io_sync(st);
 }
 }  // namespace

@@ -223,6 +223,9 @@ int dev_copy(void* dst, const void* src, size_t n, hipStream_t st);
 int dev_put(void* d_dst, const void* h_src, size_t n, hipStream_t st);
 int dev_get(void* h_dst, const void* d_src, size_t n, hipStream_t st);
 int dev_io_sync(hipStream_t st);
+//   dev_io_abort: waits for st and drops the pending gets undelivered (scope guards on error paths: after a successful dev_io_sync
+//   there is nothing pending and it only waits)
+void dev_io_abort(hipStream_t st);
 
 // RAII device buffer
 struct DevBuf {

@@ -156,7 +156,7 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
     if (!stm) { set_error("stream creation failed"); return HP_ERR_HIP; }
     struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{stm};
     // (dev_put / dev_get, hp_common.h: not the runtime's copies)
-    struct IoDrain { hipStream_t s; bool armed; ~IoDrain() { if (armed) (void)dev_io_sync(s); } } io{stm, true};
+    struct IoDrain { hipStream_t s; bool armed; ~IoDrain() { if (armed) dev_io_abort(s); } } io{stm, true};
     if ((rc = dev_put(d_pairs.p, dp.data(), n * sizeof(EdPairDev), stm)) || (rc = dev_put(d_order.p, order.data(), n * 4, stm)) ||
         (rc = dev_put(d_bytes.p, bytes.data(), bytes.size(), stm)))
         return rc;

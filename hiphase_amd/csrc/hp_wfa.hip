@@ -486,7 +486,7 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     HP_HIP_CHECK(hipGetDevice(&cur_dev));
     hipStream_t stm = thread_stream(cur_dev);
     if (!stm) { set_error("stream creation failed"); return HP_ERR_HIP; }
-    struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)dev_io_sync(s); } } drain{stm};   // (waits for the stream; host vectors below may be read by async copies)
+    struct StreamDrain { hipStream_t s; ~StreamDrain() { dev_io_abort(s); } } drain{stm};   // (waits for the stream; host vectors below may be read by async copies)
     DevBuf d_jobs, d_order, d_nodes, d_edges, d_seq, d_sets, d_score, d_status;
     if ((rc = up(d_jobs, pk.jobs, stm)) || (rc = up(d_order, order, stm)) || (rc = up(d_nodes, pk.nodes, stm)) || (rc = up(d_edges, pk.edges, stm)) ||
         (rc = d_seq.alloc(pk.seq.size())))

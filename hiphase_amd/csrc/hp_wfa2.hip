@@ -992,7 +992,7 @@ int W2Session::late() {
         const size_t dn_rec = 0, dn_rows = (h * sizeof(W2HeldRec) + 63) / 64 * 64;
         if ((rc = late_down.reserve(dn_rows + hoff[h] + 64)) != HP_OK) return rc;
         if ((rc = d_held.alloc(h * 4 + 16)) || (rc = d_hoff.alloc((h + 1) * 4 + 16)) || (rc = d_hrec.alloc(h * sizeof(W2HeldRec) + 16)) || (rc = d_hrows.alloc((size_t)hoff[h] + 16))) return rc;
-        struct IoDrain { hipStream_t s; ~IoDrain() { (void)dev_io_sync(s); } } io{s2};   // (dev_put / dev_get, hp_common.h: not the runtime's copies)
+        struct IoDrain { hipStream_t s; ~IoDrain() { dev_io_abort(s); } } io{s2};   // (dev_put / dev_get, hp_common.h: not the runtime's copies)
         if (h) {
             if ((rc = dev_put(d_held.p, ids.data(), h * 4, s2)) != HP_OK || (rc = dev_put(d_hoff.p, hoff.data(), (h + 1) * 4, s2)) != HP_OK) return rc;
             W2MapHeldArgs A{};
@@ -1064,7 +1064,7 @@ int W2Session::late() {
                     if ((rcb = d_ids.alloc(cand.size() * 4)) || (rcb = d_thr.alloc(cand.size() * 4)) || (rcb = d_exc.alloc(cand.size() + 16))) return rcb;
                     std::vector<uint8_t> exc(cand.size(), 0);
                     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{bs};
-                    struct IoDrain { hipStream_t s; ~IoDrain() { (void)dev_io_sync(s); } } io{bs};
+                    struct IoDrain { hipStream_t s; ~IoDrain() { dev_io_abort(s); } } io{bs};
                     if ((rcb = dev_put(d_ids.p, cand.data(), cand.size() * 4, bs)) != HP_OK || (rcb = dev_put(d_thr.p, thr.data(), thr.size() * 4, bs)) != HP_OK) return rcb;
                     W2BoundArgs BA{};
                     BA.jobs = d_jobs.as<W2Job>(); BA.ids = d_ids.as<uint32_t>(); BA.thresh = d_thr.as<uint32_t>(); BA.n = (uint32_t)cand.size();

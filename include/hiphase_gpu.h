@@ -410,6 +410,10 @@ int         hp_set_coalescing(int on);
  * dispatcher runs on a service thread and leaves this thread's value as it was - turn coalescing off
  * (hp_set_coalescing(0)) around a measurement, or use the stage times hp_blockstream_wait / hp_blockset_solve return. */
 double      hp_last_kernel_ms(void);
+/* The library keeps device buffers it has let go of in a process-wide cache (hipMalloc / hipFree wait for every kernel on the
+ * device): at most 2/9 of the device's memory (HP_DEV_CACHE_GB overrides). hp_trim_device_cache frees all of it - for a host
+ * application that shares the GPU with another allocator - and returns the bytes handed back. */
+size_t      hp_trim_device_cache(void);
 /* Appends one block in the .hpbk capture format (hiphase_amd/block_io.py) to `path`: the solver's exact
  * input and - when h1, h2 and stats are given - the output the caller's own astar_solver produced for it. A HiPhase
  * built with this call at src/phaser.rs:541-543 writes the real HG002 blocks this repository cannot produce. */
