@@ -92,6 +92,7 @@ struct hp_blockset {
     double rows_ms[4] = {0, 0, 0, 0};            // of the last blockset_rows: blocks that wait for nothing, blocks that held a late result, of which: their local re-alignment launch; the free blocks' launch
     double late_wait_ms = 0.0;                   // of the last blockset_rows: time spent waiting for the graph-WFA stage's late results
     double prep[4] = {0, 0, 0, 0};               // of the last init: layout ms, fill + upload ms, total ms, bytes host -> device
+    size_t upload_min_jobs = 0;                  // (blockset_layout -> blockset_upload: sets below this take the latency path at solve time)
     uint64_t work[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // hp_blockset_work of the last solve
     std::vector<hp::BlockState> st;
     // between blockset_rows and blockset_solve: the A* batch of the set (packed, uploaded), the blocks in it
@@ -103,8 +104,13 @@ struct hp_blockset {
 };
 
 namespace hp {
-// lays the set out and uploads its sequences (host threads + PCIe; no kernel but the expansion of the read bases)
+// lays the set out and uploads its sequences (host threads + PCIe; no kernel but the expansion of the read bases) = the two below
 int blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id);
+// ... in two steps (a pipeline runs them as stages of their own: the next set's overlaps while this one's reads cross PCIe):
+// validation, every record's overlaps, the job list (host threads; nothing touches the device)
+int blockset_layout(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id);
+// staging copy + PCIe of the set's sequences
+int blockset_upload(hp_blockset* bs);
 // graph-WFA over every record with overlaps: device graph build, alignment, allele rows (returns after the first collection)
 int blockset_wfa(hp_blockset* bs);
 // fallback / replay / rows / collapse on host threads (waits for the alignment stage's late results)

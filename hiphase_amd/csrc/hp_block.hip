@@ -134,7 +134,7 @@ bool overlap_range(const hp_wfa_variant* v, uint32_t n, bool sorted, int64_t lo,
 
 }  // namespace
 
-int hp::blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id) {
+int hp::blockset_layout(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id) {
     if (!in || !p) { set_error("null argument"); return HP_ERR_ARG; }
     const double t0 = blk_now_ms();
     bs->n_blocks = n_blocks; bs->in = in; bs->prm = *p;
@@ -241,6 +241,15 @@ int hp::blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in
     for (size_t k = 0; k < n_jobs; ++k) bs->allele_ptrs[k] = bs->alleles.data() + bs->job_alloff[k];
     bs->wfa_out.resize(n_jobs);
     bs->prep[0] = blk_now_ms() - t0;
+    bs->upload_min_jobs = min_jobs;
+    return HP_OK;
+}
+
+// second half of the first stage: the sequences laid out and uploaded (resident) - staging copy + PCIe, then they stay in HBM
+int hp::blockset_upload(hp_blockset* bs) {
+    const double t0 = blk_now_ms();
+    const size_t n_jobs = bs->jobs.size(), min_jobs = bs->upload_min_jobs, n_blocks = bs->n_blocks;
+    const hp_block_input* in = bs->in;
     // large sets: lay the sequences out and upload them now (resident); small ones take the latency path at solve time
     if (n_jobs && n_jobs >= min_jobs) {
         if (!bs->wfa) bs->wfa = w2_session_create();
@@ -251,8 +260,13 @@ int hp::blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in
         w2_session_prepare_stats(bs->wfa, pr);
         bs->prep[0] += pr[0]; bs->prep[1] = pr[1]; bs->prep[3] = pr[3];
     }
-    bs->prep[2] = blk_now_ms() - t0;
+    bs->prep[2] = bs->prep[0] + (blk_now_ms() - t0);
     return HP_OK;
+}
+
+int hp::blockset_init(hp_blockset* bs, size_t n_blocks, const hp_block_input* in, const hp_block_params* p, int device_id) {
+    const int rc = blockset_layout(bs, n_blocks, in, p, device_id);
+    return rc != HP_OK ? rc : blockset_upload(bs);
 }
 
 namespace {

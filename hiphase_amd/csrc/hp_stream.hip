@@ -3,11 +3,13 @@
 // HiPhase sees every phase block once (reference src/main.rs:337-408: blocks are generated, queued to the worker pool and
 // written in order; src/phaser.rs:513-543: a block's reads are loaded, then it is solved). A caller that hands over one block
 // set after the other therefore wants set k + 2 to be laid out and cross PCIe while set k + 1 is being aligned and set k is
-// being solved - not one after the other. Five stages, one thread each, every stage with its own HIP streams, device-buffer
+// being solved - not one after the other. Six stages, one thread each, every stage with its own HIP streams, device-buffer
 // cache, pinned staging and host worker pool (all of them per-thread state of the library), so they overlap on the host and
 // on the device:
 //
-//   stage 1 (hp::blockset_init)   overlaps of every record, layout, reads staged piece by piece as the caller holds them
+//   stage 0 (hp::blockset_layout) validation, overlaps of every record, the job list (host threads only; a stage of its own since round 4:
+//                                 5 ms that used to sit in front of every set's 21-25 ms of PCIe)
+//   stage 1 (hp::blockset_upload) layout of the sequences, reads staged piece by piece as the caller holds them
 //                                 (ASCII or the BAM's own 4-bit codes) while the previous piece crosses PCIe, expanded on the device
 //   stage 2 (hp::blockset_wfa)    device graph build + graph-WFA launch set + allele rows + first collection
 //   stage 3 (hp::blockset_rows)   fallback replay / qualities / collapse on host threads (mostly a WAIT: for the late results of the
@@ -16,7 +18,7 @@
 //   stage 5 (hp::blockset_solve)  A* (a latency-bound kernel: the host thread mostly waits), span counts and haplotags, outputs
 //                                 into the caller's buffers
 //
-// hp::Pipeline is one device's five stages. The public hp_blockstream is one Pipeline per device it was created for
+// hp::Pipeline is one device's stages. The public hp_blockstream is one Pipeline per device it was created for
 // (device_id >= 0: that device; -1: every visible device, sets dealt to the least-loaded pipeline - blocks are independent,
 // phaser.rs:406-411, so the node's GPUs need no exchange step; reference fan-out: main.rs:332-408, results re-ordered by
 // block index, writers/ordered_vcf_writer.rs:158-170); the per-block entries (hp_solve_blocks(1, ...), hp_block_submit) feed
@@ -61,7 +63,7 @@ struct Slot {
     hp_block_output* out = nullptr;
     int rc = HP_OK;
     std::string err;
-    double t_submit = 0, t_begin[5] = {0, 0, 0, 0, 0}, t_end[5] = {0, 0, 0, 0, 0};
+    double t_submit = 0, t_begin[6] = {0, 0, 0, 0, 0, 0}, t_end[6] = {0, 0, 0, 0, 0, 0};
 };
 
 }  // namespace
@@ -73,19 +75,19 @@ struct hp::Pipeline {
     std::vector<std::unique_ptr<Slot>> slots;
     std::mutex m;
     std::condition_variable cv;
-    static constexpr int N_STAGES = 5;
+    static constexpr int N_STAGES = 6;
     std::deque<Slot*> q[N_STAGES];     // waiting for stage 1 .. 5, in ticket order
     uint64_t next_ticket = 1;
-    uint64_t next_in[N_STAGES] = {1, 1, 1, 1, 1};   // the ticket each stage takes next
+    uint64_t next_in[N_STAGES] = {1, 1, 1, 1, 1, 1};   // the ticket each stage takes next
     double t_zero = 0.0;
     bool quit = false;
     // stage 3 has two threads (a set's rows mostly WAIT - for the late results of its alignment stage - so two sets share the
     // stage; they still reach stage 4 in ticket order), the others one
-    static constexpr int N_THREADS = 6;
+    static constexpr int N_THREADS = 7;
     std::thread th[N_THREADS];
     std::unique_ptr<WorkerPool> pool[N_THREADS];
     void stage_thread(int t);
-    int extra_stage = 1;
+    int extra_stage = 2;
     void stage_loop(int k);
 };
 
@@ -102,12 +104,12 @@ void hp::Pipeline::stage_loop(int k) {
     // to the eighth, HP_STREAM_PARTITION=1, or on the whole device, =2) made the A* kernels 6 x slower (113 vs 18 ms: they start
     // behind the CU-masked queue's kernels) and the step 165 instead of 73 ms.
     static const int part = [] { const char* e = std::getenv("HP_STREAM_PARTITION"); return e ? std::atoi(e) : 0; }();
-    if (part == 1) g_cu_partition = k == 1 ? 2 : 1;
-    else if (part == 2) g_cu_partition = k == 1 ? 2 : 0;
+    if (part == 1) g_cu_partition = k == 2 ? 2 : 1;
+    else if (part == 2) g_cu_partition = k == 2 ? 2 : 0;
     // ... what works instead: the alignment stage leaves a share of the wavefront slots empty (hp_wfa2.hip)
     static const int reserve = [] { const char* e = std::getenv("HP_STREAM_RESERVE_PCT"); return e ? std::max(0, std::atoi(e)) : 8; }();
-    if (k == 1) g_wfa2_reserve_pct = reserve;
-    g_host_share_div = k == 0 ? 2 : 4;   // (stage 1 copies a gigabyte; the others' parallel regions are short)   // the stages' host threads together: about the process's share of the host   // the three stages' host threads together: about the process's share of the host
+    if (k == 2) g_wfa2_reserve_pct = reserve;
+    g_host_share_div = k == 1 ? 2 : 4;   // (stage 1 copies a gigabyte; the others' parallel regions are short)   // the stages' host threads together: about the process's share of the host   // the three stages' host threads together: about the process's share of the host
     for (;;) {
         Slot* s = nullptr;
         {
@@ -122,10 +124,11 @@ void hp::Pipeline::stage_loop(int k) {
         s->t_begin[k] = st_now_ms();
         if (s->rc == HP_OK && s->n_blocks) {   // (an empty set, or one that failed an earlier stage, just travels on: tickets complete in order)
             int rc = HP_OK;
-            if (k == 0) rc = blockset_init(&s->bs, s->n_blocks, s->in, &s->prm, device);
-            else if (k == 1) rc = blockset_wfa(&s->bs);
-            else if (k == 2) rc = blockset_rows(&s->bs);
-            else if (k == 3) rc = blockset_pack(&s->bs);
+            if (k == 0) rc = blockset_layout(&s->bs, s->n_blocks, s->in, &s->prm, device);
+            else if (k == 1) rc = blockset_upload(&s->bs);
+            else if (k == 2) rc = blockset_wfa(&s->bs);
+            else if (k == 3) rc = blockset_rows(&s->bs);
+            else if (k == 4) rc = blockset_pack(&s->bs);
             else rc = blockset_solve(&s->bs, s->out);
             if (rc != HP_OK) { s->rc = rc; s->err = hp_last_error(); }
         }
@@ -163,7 +166,7 @@ hp::Pipeline* hp::pipeline_create(const hp_block_params* p, int device_id, uint3
     const char* wt = std::getenv("HP_STREAM_WFA_THREADS");
     const char* rt = std::getenv("HP_STREAM_ROWS_THREADS");
     int n_threads = Pipeline::N_THREADS;
-    if (rt && std::atoi(rt) >= 2) s->extra_stage = 2;
+    if (rt && std::atoi(rt) >= 2) s->extra_stage = 3;
     else if (!(wt && std::atoi(wt) >= 2)) n_threads = Pipeline::N_STAGES;
     g_pipelines.fetch_add(1);
     for (int k = 0; k < n_threads; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_thread(k); });
@@ -224,21 +227,22 @@ int hp::pipeline_wait(Pipeline* s, uint64_t ticket, double* stage_ms, uint64_t* 
     if (rc != HP_OK) set_error("%s", slot->err.c_str());
     if (std::getenv("HP_STREAM_TRACE")) {   // the set's way through the stages, ms since the stream's first submit
         if (s->t_zero == 0.0) s->t_zero = slot->t_submit;
-        fprintf(stderr, "[hp] set %llu: submit %.1f | s1 %.1f-%.1f | s2 %.1f-%.1f | s3 %.1f-%.1f (free blocks %.1f [local re-alignment %.1f], waited %.1f for the late results, their blocks %.1f [%.1f]) | s4 %.1f-%.1f | s5 %.1f-%.1f (A* %.1f of which kernels %.1f, post %.1f)\n", (unsigned long long)ticket,
-                slot->t_submit - s->t_zero, slot->t_begin[0] - s->t_zero, slot->t_end[0] - s->t_zero, slot->t_begin[1] - s->t_zero, slot->t_end[1] - s->t_zero,
-                slot->t_begin[2] - s->t_zero, slot->t_end[2] - s->t_zero, slot->bs.rows_ms[0], slot->bs.rows_ms[3], slot->bs.late_wait_ms, slot->bs.rows_ms[1], slot->bs.rows_ms[2], slot->t_begin[3] - s->t_zero, slot->t_end[3] - s->t_zero, slot->t_begin[4] - s->t_zero, slot->t_end[4] - s->t_zero, slot->bs.ms[3], slot->bs.ms[7], slot->bs.ms[4]);
+        fprintf(stderr, "[hp] set %llu: submit %.1f | layout %.1f-%.1f | s1 %.1f-%.1f | s2 %.1f-%.1f | s3 %.1f-%.1f (free blocks %.1f [local re-alignment %.1f], waited %.1f for the late results, their blocks %.1f [%.1f]) | s4 %.1f-%.1f | s5 %.1f-%.1f (A* %.1f of which kernels %.1f, post %.1f)\n", (unsigned long long)ticket,
+                slot->t_submit - s->t_zero, slot->t_begin[0] - s->t_zero, slot->t_end[0] - s->t_zero, slot->t_begin[1] - s->t_zero, slot->t_end[1] - s->t_zero, slot->t_begin[2] - s->t_zero, slot->t_end[2] - s->t_zero,
+                slot->t_begin[3] - s->t_zero, slot->t_end[3] - s->t_zero, slot->bs.rows_ms[0], slot->bs.rows_ms[3], slot->bs.late_wait_ms, slot->bs.rows_ms[1], slot->bs.rows_ms[2], slot->t_begin[4] - s->t_zero, slot->t_end[4] - s->t_zero, slot->t_begin[5] - s->t_zero, slot->t_end[5] - s->t_zero, slot->bs.ms[3], slot->bs.ms[7], slot->bs.ms[4]);
     }
     if (stage_ms) {
         const hp_blockset& B = slot->bs;
         stage_ms[0] = B.prep[0]; stage_ms[1] = B.prep[1];
         stage_ms[2] = B.ms[0]; stage_ms[3] = B.ms[1]; stage_ms[4] = B.ms[2]; stage_ms[5] = B.ms[3]; stage_ms[6] = B.ms[4];
-        stage_ms[7] = slot->t_end[4] - slot->t_submit;
+        stage_ms[7] = slot->t_end[5] - slot->t_submit;
         stage_ms[8] = B.ms[6]; stage_ms[9] = B.ms[7];
         stage_ms[10] = B.prep[3];
         stage_ms[11] = (slot->t_begin[0] - slot->t_submit) + (slot->t_begin[1] - slot->t_end[0]) + (slot->t_begin[2] - slot->t_end[1]) + (slot->t_begin[3] - slot->t_end[2]) +
-                       (slot->t_begin[4] - slot->t_end[3]);
-        stage_ms[12] = slot->t_end[0] - slot->t_begin[0]; stage_ms[13] = slot->t_end[1] - slot->t_begin[1]; stage_ms[14] = slot->t_end[2] - slot->t_begin[2];
-        stage_ms[15] = (slot->t_end[3] - slot->t_begin[3]) + (slot->t_end[4] - slot->t_begin[4]);   // (pack + solve)
+                       (slot->t_begin[4] - slot->t_end[3]) + (slot->t_begin[5] - slot->t_end[4]);
+        // (stage 1 = the upload stage; the layout stage before it - host only, since round 4 a stage of its own - is stage_ms[0])
+        stage_ms[12] = slot->t_end[1] - slot->t_begin[1]; stage_ms[13] = slot->t_end[2] - slot->t_begin[2]; stage_ms[14] = slot->t_end[3] - slot->t_begin[3];
+        stage_ms[15] = (slot->t_end[4] - slot->t_begin[4]) + (slot->t_end[5] - slot->t_begin[5]);   // (pack + solve)
     }
     if (work) for (int i = 0; i < 8; ++i) work[i] = slot->bs.work[i];
     slot->bs.in = nullptr;   // (nothing of the caller's is kept)
