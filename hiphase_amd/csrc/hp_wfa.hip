@@ -680,6 +680,11 @@ static int run_graphs(const std::vector<HostJob>& hj, uint64_t prune_distance, u
         if (ids.empty()) continue;
         uint32_t band = (uint32_t)std::min<uint64_t>(max_ed, benv ? (uint64_t)std::atoi(benv) : 96);
         std::vector<uint32_t> wide;   // known to need more than the narrow band (g_wfa_min_ed_hint): they join the second pass
+        // The leftovers of a block set's compact kernels (a few dozen reads with hints) take ONE pass at full width: their pass is what
+        // the set's rows wait for, two launches are twice one launch's latency (8 ms each beside a resident launch set), and the
+        // narrow attempt mostly fails for them - they are here because their alignment is not an ordinary one.
+        static const size_t one_pass_max = [] { const char* e = std::getenv("HP_WFA_ONE_PASS_MAX"); return e ? (size_t)std::max(0, std::atoi(e)) : (size_t)512; }();
+        if (min_ed_hint && band < max_ed && ids.size() <= one_pass_max && max_ed <= 2000) band = (uint32_t)max_ed;
         if (min_ed_hint && band < max_ed) {
             std::vector<uint32_t> narrow;
             for (uint32_t id : ids) (min_ed_hint[id] >= band ? wide : narrow).push_back(id);

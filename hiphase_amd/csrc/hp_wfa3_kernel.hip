@@ -175,7 +175,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                     // per read base - it would end far beyond the cap. Those skip the largest class (where they would crawl on to
                     // outgrow its lists too, at the tail of the launch set) and go straight to the exact reference-window verdict of
                     // the host's pass (hp_wfa2_bound_kernel). Routing only: every road computes the same result.
-                    const bool hopeless = ed >= 16u && (uint64_t)ed * other_len > ((uint64_t)farthest + 1u) * (uint64_t)maxed32 * 2u;
+                    // (a dozen rounds in, projected edits 1.25 x the cap: the bench's noisy reads - 5 % noise against a cap of 3.4 % -
+                    // outgrow the lists around their twelfth round. A read that is misjudged only takes the slower road.)
+                    const bool hopeless = ed >= 12u && (uint64_t)ed * other_len * 4u > ((uint64_t)farthest + 1u) * (uint64_t)maxed32 * 5u;
                     const bool hand = status == W2_ST_NEED_BIG && why == 8u && !hopeless;
                     if (B.esc_role == 1u && __any(hand)) {
                         const uint32_t taken = atomicAdd(B.esc, 0u);
