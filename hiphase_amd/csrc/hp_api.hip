@@ -130,7 +130,9 @@ unsigned host_threads(unsigned want) {
         }
         unsigned procs = 1;
         if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) procs = (unsigned)std::max(1, std::atoi(e));
-        return std::max(2u, hw / procs);
+        // (... and at most 8 per process: measured on the streamed bench, 8 threads 1.78 M hets/s at 4.5 CPU-seconds per second, 16
+        // threads 1.73 M at 7.0 - the stages' parallel regions are short, more workers only spin longer; 4: 1.44 M, 2: 1.32 M)
+        return std::max(2u, std::min(8u, hw / procs));
     }();
     // (a stage thread of a block pipeline takes its stage's part of the process's share; several pipelines in one process - one per
     // device - split it between them)
