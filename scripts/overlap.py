@@ -1,6 +1,6 @@
 """Overlap of the stages on the device, from a rocprofv3 kernel + memory-copy trace (scripts/prof_path.sh):
 python scripts/overlap.py gpurun_out/prof_path_<tag>/trace > profiles/roundN/path_overlap.txt
-Classes: wfa = the hp_wfa2_kernel launch sets, dense = dense-band + reference-window kernels of the late results,
+Classes: wfa = the hp_wfa3_kernel (or hp_wfa2_kernel) launch sets, dense = dense-band + reference-window kernels of the late results,
 astar = hp_astar_kernel + hp_heur_*, h2d = host-to-device copies, other = everything else."""
 import csv, glob, sys
 
@@ -9,7 +9,7 @@ iv = {k: [] for k in ("wfa", "dense", "astar", "h2d", "other")}
 for f in glob.glob(d + "/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        k = ("wfa" if "hp_wfa2_kernel<" in n else "dense" if ("hp_wfa_kernel" in n or "hp_wfa_big_kernel" in n or "hp_wfa2_bound_kernel" in n)
+        k = ("wfa" if ("hp_wfa2_kernel<" in n or "hp_wfa3_kernel<" in n) else "dense" if ("hp_wfa_kernel" in n or "hp_wfa_big_kernel" in n or "hp_wfa2_bound_kernel" in n)
              else "astar" if ("hp_astar_kernel" in n or "hp_heur_" in n) else "other")
         iv[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 for f in glob.glob(d + "/*memory_copy_trace.csv"):
