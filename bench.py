@@ -345,6 +345,14 @@ def main_path(args, rank, world, local_rank, dist, backend):
             over[key] = float(val)
         sets.append(SynthSet(default_spec(lib, **dict(dict(seed=args.seed + 1000 * rank + k, total_hets=args.total_hets, max_block_hets=args.max_block_hets,
                                                            coverage=float(args.coverage), seq_format=fmt, threads=gen_threads), **over))))
+    n_pinned = 0
+    if args.host_memory == "pinned" and not capture:   # the records' bases gathered in hp_host_alloc memory: read in place, nothing staged
+        for s_ in sets:
+            try:
+                s_.relocate_pinned()
+                n_pinned += 1
+            except _ffi.HpError:   # (the box would not pin another gigabyte: that set stays where it is and is staged)
+                break
     outs = [s.outputs() for s in sets]
     t_gen = time.perf_counter() - t_gen
     prm = block_params()
@@ -441,9 +449,9 @@ def main_path(args, rank, world, local_rank, dist, backend):
                                     f"{info['blocks']} blocks, {info['hets']} hets (lognormal block sizes, median 15, max {info['max_block_hets']}), "
                                     f"{info['records']} records of {info['read_bases'] / max(1, info['records']):.0f} b mean at {args.coverage}x "
                                     f"(0.5% edit noise: sub / ins / del; 0.3% of the reads at 5%: they exceed max_edit_distance; 2% supplementary), "
-                                    f"het + hom calls SNV .85 / indel .12 / SV .01 / tandem repeat .02, reads handed over as {args.seq_format}"),
+                                    f"het + hom calls SNV .85 / indel .12 / SV .01 / tandem repeat .02, reads handed over as {args.seq_format}" + (", gathered in hp_host_alloc memory" if n_pinned else "")),
                        "blocks": info["blocks"], "hets_per_step_per_gpu": info["hets"], "records": info["records"], "read_bases": info["read_bases"],
-                       "distinct_sets": n_sets, "depth": args.depth, "seq_format": args.seq_format,
+                       "distinct_sets": n_sets, "depth": args.depth, "seq_format": args.seq_format, "host_memory": (f"hp_host_alloc arena ({n_pinned} of {len(sets)} sets)" if n_pinned else "pageable"),
                        "host_to_device_bytes_per_step": st_mean[10], "host_to_device_gbs": st_mean[10] / (ms_step * 1e-3) / 1e9,
                        "min_queue_size": 1000, "queue_increment": 3, "max_edit_distance": 500, "wfa_prune_distance": 500,
                        "generate_s": round(t_gen, 2), "spec_overrides": args.spec},
@@ -525,6 +533,8 @@ def main():
     ap.add_argument("--seq-format", choices=["bam4", "ascii"], default="bam4", help="path workload: how the reads are handed over")
     ap.add_argument("--depth", type=int, default=5, help="path workload: block sets in flight in the stream")
     ap.add_argument("--distinct-sets", type=int, default=16, help="path workload: generated sets (steps + warm-up if fewer; cycled if more are needed)")
+    ap.add_argument("--host-memory", choices=["pageable", "pinned"], default="pinned",
+                    help="path workload: where the records' bases lie on the host - ordinary memory (staged by the library's host threads) or hp_host_alloc memory (read in place by the device)")
     ap.add_argument("--spec", action="append", default=[], help="path workload: override a field of hp_synth_reads_spec, key=value (repeatable)")
     ap.add_argument("--no-resident", action="store_true", help="path workload: skip the secondary resident (inputs-in-HBM) figure")
     ap.add_argument("--no-drop-in", action="store_true", help="path workload: skip the secondary per-block (drop-in) rates")

@@ -314,6 +314,9 @@ EXPORTS = [
     "hp_set_coalescing",
     "hp_last_kernel_ms",
     "hp_trim_device_cache",
+    "hp_host_alloc",
+    "hp_host_free",
+    "hp_host_in_place_bytes",
     "hp_abi_layout",
     "hp_hpbk_append",
     "hp_synth_block_size",
@@ -323,6 +326,7 @@ EXPORTS = [
     "hp_synth_reads_inputs",
     "hp_synth_reads_info",
     "hp_synth_reads_truth",
+    "hp_synth_reads_relocate",
     "hp_synth_reads_destroy",
     "hp_outputs_create",
     "hp_outputs_array",
@@ -354,6 +358,8 @@ def declare_common(dll):
     dll.hp_synth_reads_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     dll.hp_synth_reads_truth.restype = C.POINTER(C.c_uint8)
     dll.hp_synth_reads_truth.argtypes = [C.c_void_p, C.c_size_t]
+    dll.hp_synth_reads_relocate.restype = C.c_int
+    dll.hp_synth_reads_relocate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     dll.hp_synth_reads_destroy.restype = None
     dll.hp_synth_reads_destroy.argtypes = [C.c_void_p]
     dll.hp_outputs_create.restype = C.c_void_p
@@ -455,6 +461,11 @@ def lib():
     dll.hp_version.restype = C.c_char_p
     dll.hp_last_kernel_ms.restype = C.c_double
     dll.hp_trim_device_cache.restype = C.c_size_t
+    dll.hp_host_alloc.restype = C.c_void_p
+    dll.hp_host_alloc.argtypes = [C.c_size_t]
+    dll.hp_host_in_place_bytes.restype = C.c_uint64
+    dll.hp_host_free.restype = None
+    dll.hp_host_free.argtypes = [C.c_void_p]
     _lib = dll
     return dll
 

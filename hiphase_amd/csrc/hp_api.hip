@@ -299,6 +299,41 @@ extern "C" size_t hp_trim_device_cache(void) {   // frees every cached device bl
     return bytes;
 }
 
+// ---- host memory the device reads in place (hp_host_alloc): a registry of the ranges, looked up by the layout stage ----------------
+namespace {
+struct HostRanges { std::mutex m; std::map<uintptr_t, size_t> r; };   // base -> bytes (slack included)
+HostRanges& host_ranges() { static HostRanges* h = new HostRanges(); return *h; }
+}  // namespace
+extern "C" void* hp_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    const size_t n = bytes + 64;
+    g_device_syncing_allocs.fetch_add(1);
+    if (hipHostMalloc(&p, n, hipHostMallocPortable) != hipSuccess || !p) { set_error("hipHostMalloc(%zu) failed", n); return nullptr; }
+    HostRanges& H = host_ranges();
+    std::lock_guard<std::mutex> lk(H.m);
+    H.r[(uintptr_t)p] = n;
+    return p;
+}
+extern "C" void hp_host_free(void* p) {
+    if (!p) return;
+    { HostRanges& H = host_ranges(); std::lock_guard<std::mutex> lk(H.m); H.r.erase((uintptr_t)p); }
+    (void)hipHostFree(p);
+}
+bool host_range_of(const void* p, uintptr_t* lo, uintptr_t* hi) {   // the hp_host_alloc range p lies in
+    HostRanges& H = host_ranges();
+    std::lock_guard<std::mutex> lk(H.m);
+    if (H.r.empty()) return false;
+    auto it = H.r.upper_bound((uintptr_t)p);
+    if (it == H.r.begin()) return false;
+    --it;
+    if ((uintptr_t)p >= it->first + it->second) return false;
+    *lo = it->first; *hi = it->first + it->second;
+    return true;
+}
+std::atomic<uint64_t> g_in_place_bytes{0};
+extern "C" uint64_t hp_host_in_place_bytes(void) { return g_in_place_bytes.load(); }
+bool host_ranges_any() { HostRanges& H = host_ranges(); std::lock_guard<std::mutex> lk(H.m); return !H.r.empty(); }
+
 static std::atomic<int> g_coalesce{-1};   // -1: ask the environment once
 bool coalescing_enabled() {
     int v = g_coalesce.load(std::memory_order_relaxed);

@@ -226,6 +226,10 @@ int dev_io_sync(hipStream_t st);
 //   dev_io_abort: waits for st and drops the pending gets undelivered (scope guards on error paths: after a successful dev_io_sync
 //   there is nothing pending and it only waits)
 void dev_io_abort(hipStream_t st);
+// [p, p + n) lies in memory from hp_host_alloc (pinned, mapped: kernels read it in place); any such memory at all
+bool host_range_of(const void* p, uintptr_t* lo, uintptr_t* hi);   // the hp_host_alloc range (slack included) that holds p
+bool host_ranges_any();
+extern std::atomic<uint64_t> g_in_place_bytes;
 
 // RAII device buffer
 struct DevBuf {

@@ -308,6 +308,9 @@ struct hp_synth_set {
     std::vector<hp_block_input> inputs;
     std::vector<uint8_t> qual;   // one quality string shared by every record (a pattern of Q20..Q50)
     uint64_t hets = 0, records = 0, read_bases = 0, qnames = 0, input_bytes = 0;
+    uint8_t* arena = nullptr;    // hp_synth_reads_relocate: every block's read bases, back to back
+    void (*arena_free)(void*) = nullptr;
+    ~hp_synth_set() { if (arena && arena_free) arena_free(arena); }
 };
 
 extern "C" void hp_synth_reads_defaults(hp_synth_reads_spec* s) {
@@ -399,4 +402,24 @@ extern "C" const uint8_t* hp_synth_reads_truth(const hp_synth_set* s, size_t blo
 }
 
 extern "C" void hp_synth_reads_destroy(hp_synth_set* s) { delete s; }
+
+extern "C" int hp_synth_reads_relocate(hp_synth_set* s, void* (*alloc)(size_t), void (*dealloc)(void*)) {
+    if (!s || !alloc || !dealloc || s->arena) return HP_ERR_ARG;
+    size_t total = 0;
+    for (auto& b : s->blocks) total += (b->reads.size() + 63) & ~(size_t)63;
+    uint8_t* a = static_cast<uint8_t*>(alloc(total + 64));
+    if (!a) return HP_ERR_OOM;
+    size_t off = 0;
+    for (auto& bp : s->blocks) {
+        BlockData& B = *bp;
+        const uint8_t* old = B.reads.data();
+        std::memcpy(a + off, old, B.reads.size());
+        for (auto& R : B.records) R.read_align = a + off + (R.read_align - old);
+        for (auto& L : B.locals) L.seq = a + off + (L.seq - old);
+        off += (B.reads.size() + 63) & ~(size_t)63;
+        std::vector<uint8_t>().swap(B.reads);   // (the bases live in the arena from here on)
+    }
+    s->arena = a; s->arena_free = dealloc;
+    return HP_OK;
+}
 

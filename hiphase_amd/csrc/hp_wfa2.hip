@@ -517,6 +517,60 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
         d.allele_off = (uint32_t)allele_tot; allele_tot += ji.n_hets;
     }
     src_off[n] = packed;
+    // Do the records' bases all lie in host memory the copy engines read in place (hp_host_alloc)? Then nothing of them is staged:
+    // the blocks' address hulls, merged where they touch, cross PCIe as they are - one DMA per run of blocks - and a record's source
+    // offset is its place in that image. (Blocks gathered one after the other into an arena give a handful of runs; records
+    // scattered so that the hulls hold much more than the records do take the staged way.)
+    struct Run { uintptr_t lo, hi; uint64_t dev; };
+    std::vector<Run> runs;
+    bool in_place = host_ranges_any() && !std::getenv("HP_NO_IN_PLACE");
+    uint64_t in_place_bytes = 0;
+    if (in_place) {
+        uintptr_t r_lo = 0, r_hi = 0;   // the hp_host_alloc range the last record lay in
+        uint64_t payload = 0;
+        std::vector<Run> hull;          // per block
+        size_t cur_block = (size_t)-1;
+        for (size_t i = 0; i < n && in_place; ++i) {
+            const hp_block_input& B = in[jin[i].block];
+            const hp_block_record& rec = B.records[jin[i].rec];
+            if (!rec.read_len) continue;
+            const uint8_t* p = B.seq_format == HP_SEQ_BAM4 ? rec.read_align + (rec.read_offset >> 1) : rec.read_align + rec.read_offset;
+            const uint64_t pb = B.seq_format == HP_SEQ_BAM4 ? ((uint64_t)(rec.read_offset & 1u) + rec.read_len + 1) / 2 : rec.read_len;
+            const uintptr_t a = (uintptr_t)p, e = a + pb + 24;   // (the expansion reads 16 bytes at a time, the odd-nibble shift 8 further)
+            if (!(a >= r_lo && e <= r_hi) && !(host_range_of(p, &r_lo, &r_hi) && e <= r_hi)) { in_place = false; break; }
+            if (jin[i].block == cur_block && a + (1u << 20) >= hull.back().lo && e <= hull.back().hi + (1u << 20)) {
+                hull.back().lo = std::min(hull.back().lo, a); hull.back().hi = std::max(hull.back().hi, e);
+            } else {   // (a record far from its block's others opens a hull of its own)
+                hull.push_back(Run{a, e, 0});
+                cur_block = jin[i].block;
+            }
+            payload += pb;
+        }
+        if (in_place) {
+            std::sort(hull.begin(), hull.end(), [](const Run& x, const Run& y) { return x.lo < y.lo; });
+            for (const Run& h : hull) {
+                if (!runs.empty() && h.lo <= runs.back().hi + 4096) runs.back().hi = std::max(runs.back().hi, h.hi);
+                else runs.push_back(h);
+            }
+            uint64_t image = 0;
+            for (Run& r : runs) { r.dev = image; image += ((r.hi - r.lo) + 15) & ~(uint64_t)15; }
+            if (runs.size() > 4096 || image > payload + payload / 4 + (1u << 20)) in_place = false;   // too scattered: stage
+            else {
+                for (size_t i = 0; i < n; ++i) {
+                    const hp_block_input& B = in[jin[i].block];
+                    const hp_block_record& rec = B.records[jin[i].rec];
+                    if (!rec.read_len) { src_off[i] = 0; continue; }
+                    const uintptr_t a = (uintptr_t)(B.seq_format == HP_SEQ_BAM4 ? rec.read_align + (rec.read_offset >> 1) : rec.read_align + rec.read_offset);
+                    auto it = std::upper_bound(runs.begin(), runs.end(), a, [](uintptr_t v, const Run& r) { return v < r.lo; });
+                    --it;
+                    src_off[i] = it->dev + (a - it->lo);
+                }
+                packed = image; src_off[n] = packed;
+                in_place_bytes = image;
+            }
+        }
+        if (!in_place) runs.clear();
+    }
     seq_bytes = reads_dev + dev_reads + 256;
     // longest read first (stable counting sort; reads beyond 64 k bases share the first bucket - the order only steers the work queues)
     len_order.resize(n);
@@ -543,7 +597,7 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
     auto a64 = [](uint64_t x) { return (x + 63) & ~63ull; };
     const uint64_t o_vars = a64(reads_dev), o_jobs = a64(o_vars + n_vars * sizeof(W2Variant)), o_len = a64(o_jobs + n * sizeof(W2Job)),
                    o_src = a64(o_len + n * 4), o_fmt = a64(o_src + n * 8), o_packed = a64(o_fmt + n);
-    if ((rc = cx.stage.reserve(o_packed + packed + 64)) != HP_OK) return rc;
+    if ((rc = cx.stage.reserve(o_packed + (in_place ? 0 : packed) + 64)) != HP_OK) return rc;
     if ((rc = d_seq.alloc(seq_bytes)) || (rc = d_packed.alloc(packed + 64)) || (rc = d_src_off.alloc(n * 8)) || (rc = d_fmt.alloc(n + 16)) ||
         (rc = d_vars.alloc(std::max<size_t>(1, (size_t)n_vars) * sizeof(W2Variant))) || (rc = d_jobs.alloc(n * sizeof(W2Job))) ||
         (rc = d_nodes.alloc((size_t)node_tot * sizeof(W2Node))) || (rc = d_edges.alloc((size_t)edge_tot * 2)) || (rc = d_tags.alloc((size_t)tag_tot * 4)) ||
@@ -615,8 +669,15 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
     HP_HIP_CHECK(hipMemcpyAsync(d_src_off.p, sb + o_src, n * 8, hipMemcpyHostToDevice, st));
     HP_HIP_CHECK(hipMemcpyAsync(d_fmt.p, sb + o_fmt, n, hipMemcpyHostToDevice, st));
     h2d_bytes = reads_dev + n_vars * sizeof(W2Variant) + n * (sizeof(W2Job) + 13);
-    // ---- 3b. the reads, piece by piece: piece k crosses PCIe while the host threads fill piece k + 1 ----------------------------
-    {
+    // ---- 3b. the reads: in place, run by run (no host thread touches them) ... ---------------------------------------------------
+    if (in_place) {
+        for (const Run& r : runs)
+            HP_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(d_packed.p) + r.dev, reinterpret_cast<const void*>(r.lo), r.hi - r.lo, hipMemcpyHostToDevice, st));
+        h2d_bytes += in_place_bytes;
+        g_in_place_bytes.fetch_add(in_place_bytes);
+    }
+    // ---- ... or staged piece by piece: piece k crosses PCIe while the host threads fill piece k + 1 -----------------------------
+    if (!in_place) {
         const char* penv = std::getenv("HP_STAGE_PIECE_MB");
         const uint64_t piece = (uint64_t)std::max(1, penv ? std::atoi(penv) : 48) << 20;
         size_t j0 = 0;

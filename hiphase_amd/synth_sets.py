@@ -36,6 +36,16 @@ class SynthSet:
     def outputs(self):
         return Outputs(self.dll, self.inputs, self.n)
 
+    def relocate_pinned(self):
+        """Moves the records' bases into memory from hp_host_alloc (pinned, device-readable: the library then reads them in
+        place instead of staging them - what a loader that decodes BAM records into such an arena gets). The allocator always
+        comes from the PRODUCT library, whichever library generated the set."""
+        prod = _ffi.lib()
+        rc = self.dll.hp_synth_reads_relocate(self.h, C.cast(prod.hp_host_alloc, C.c_void_p), C.cast(prod.hp_host_free, C.c_void_p))
+        if rc != 0:
+            raise _ffi.HpError(rc, "hp_synth_reads_relocate")
+        return self
+
     def truth(self, b):
         p = self.dll.hp_synth_reads_truth(self.h, b)
         return [p[i] for i in range(self.inputs[b].n_hets)]

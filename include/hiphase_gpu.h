@@ -414,6 +414,18 @@ double      hp_last_kernel_ms(void);
  * device): at most 2/9 of the device's memory (HP_DEV_CACHE_GB overrides). hp_trim_device_cache frees all of it - for a host
  * application that shares the GPU with another allocator - and returns the bytes handed back. */
 size_t      hp_trim_device_cache(void);
+/* Host memory the device reads IN PLACE. A block set whose records' bases (hp_block_record.read_align) all lie in memory from
+ * hp_host_alloc is not staged: no copy into the library's pinned staging on host threads (1 GB per 60 000 hets at 30x - most of
+ * the library's host CPU time); the copy engines take the blocks' address ranges as they are, one DMA per run of neighbouring
+ * blocks. The natural caller-side arena: decode / gather a block's records into it one after the other, hand the block over,
+ * reuse it once the call (or the wait) has returned. Records scattered so that the blocks' address hulls hold over 1.25 x the
+ * bytes the records do are staged as ever. 64 bytes of slack behind the request (the device reads 16 bytes at a time). NULL
+ * when the allocation fails; hp_host_free(NULL) is a no-op. */
+void*       hp_host_alloc(size_t bytes);
+void        hp_host_free(void* p);
+/* Bytes of such memory the copy engines have read in place since the library was loaded (0 = every set so far was staged: a
+ * loader's check that its arena is the one the library sees). */
+uint64_t    hp_host_in_place_bytes(void);
 /* Appends one block in the .hpbk capture format (hiphase_amd/block_io.py) to `path`: the solver's exact
  * input and - when h1, h2 and stats are given - the output the caller's own astar_solver produced for it. A HiPhase
  * built with this call at src/phaser.rs:541-543 writes the real HG002 blocks this repository cannot produce. */
@@ -466,6 +478,9 @@ const hp_block_input* hp_synth_reads_inputs(const hp_synth_set* s, size_t* n_blo
 void hp_synth_reads_info(const hp_synth_set* s, uint64_t out[8]);
 const uint8_t* hp_synth_reads_truth(const hp_synth_set* s, size_t block);   /* [n_hets] the allele haplotype 0 carries */
 void hp_synth_reads_destroy(hp_synth_set* s);
+/* Moves every record's bases of the set into ONE buffer from `alloc` (and frees it with `dealloc` when the set is destroyed) - with
+ * hp_host_alloc / hp_host_free: the set as a caller holds it that keeps its records in memory the device reads in place. */
+int hp_synth_reads_relocate(hp_synth_set* s, void* (*alloc)(size_t), void (*dealloc)(void*));
 
 /* ---- caller-side helpers around the block entries (hp_capture.cpp; host-only) ------------------------------------------------- */
 /* Output buffers for n blocks, every array of hp_block_output allocated and sized from the inputs (seg_cell_cap: per read name

@@ -42,6 +42,62 @@ def test_solve_blocks_on_generated_sets_vs_oracle(fmt, path, monkeypatch):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("fmt", [_ffi.SEQ_ASCII, _ffi.SEQ_BAM4])
+def test_reads_in_device_readable_host_memory_vs_oracle(fmt, monkeypatch):
+    """hp_host_alloc: a set whose records' bases all lie in it is read in place by the copy engines (hp_host_in_place_bytes counts them),
+    through the one-call entry and through a block stream; a set with ONE block's bases elsewhere is staged as ever. Same results."""
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0")
+    lib = _ffi.lib()
+    prm = _params(2, 1000, 3, None, True)
+    s = SynthSet(default_spec(lib, total_hets=700, seed=37, seq_format=fmt, **KW))
+    exp = oracle_outputs(s, prm)   # (the oracle reads the same host bytes: before or after the move makes no difference)
+    s.relocate_pinned()
+    before = lib.hp_host_in_place_bytes()
+    got = s.outputs()
+    _ffi.check(lib.hp_solve_blocks(s.n, s.inputs, C.byref(prm), got.arr, 0))
+    assert [b for b in range(s.n) if not got.equal(exp, b)] == []
+    moved = lib.hp_host_in_place_bytes() - before
+    bases = s.info["read_bases"]
+    want = bases // 2 if fmt == _ffi.SEQ_BAM4 else bases   # (records that cover no het of their block are not aligned at all)
+    assert 0.9 * want <= moved <= 1.25 * want + (1 << 20)
+    st = C.c_int(0)
+    stream = lib.hp_blockstream_create(C.byref(prm), 0, 3, C.byref(st))
+    assert stream
+    try:
+        outs = [s.outputs() for _ in range(4)]
+        tickets = []
+        for o in outs:   # (three sets in flight: a fourth submit would wait for a slot only hp_blockstream_wait frees)
+            if len(tickets) == 3:
+                _ffi.check(lib.hp_blockstream_wait(stream, tickets.pop(0), None, None))
+            t = C.c_uint64(0)
+            _ffi.check(lib.hp_blockstream_submit(stream, s.n, s.inputs, o.arr, C.byref(t)))
+            tickets.append(t.value)
+        for t in tickets:
+            _ffi.check(lib.hp_blockstream_wait(stream, t, None, None))
+        for o in outs:
+            assert [b for b in range(s.n) if not o.equal(exp, b)] == []
+        assert lib.hp_host_in_place_bytes() - before == 5 * moved
+    finally:
+        lib.hp_blockstream_destroy(stream)
+    # one block's records somewhere else: the whole set takes the staged way
+    other = SynthSet(default_spec(lib, total_hets=700, seed=37, seq_format=fmt, **KW))
+    mixed = (_ffi.BlockInput * s.n)(*[s.inputs[b] for b in range(s.n)])
+    mixed[s.n // 2] = other.inputs[s.n // 2]
+    before = lib.hp_host_in_place_bytes()
+    got2 = s.outputs()
+    _ffi.check(lib.hp_solve_blocks(s.n, mixed, C.byref(prm), got2.arr, 0))
+    assert [b for b in range(s.n) if not got2.equal(exp, b)] == []
+    assert lib.hp_host_in_place_bytes() == before
+    # that block's bases in a second arena: in place again, as three runs (the first arena's blocks before it, after it, the other arena's)
+    other.relocate_pinned()
+    mixed[s.n // 2] = other.inputs[s.n // 2]
+    got3 = s.outputs()
+    _ffi.check(lib.hp_solve_blocks(s.n, mixed, C.byref(prm), got3.arr, 0))
+    assert [b for b in range(s.n) if not got3.equal(exp, b)] == []
+    assert 0.9 * want <= lib.hp_host_in_place_bytes() - before <= 1.25 * want + (1 << 20)
+
+
+@pytest.mark.timeout(900)
 def test_groups_that_leave_after_a_few_jobs_vs_oracle(monkeypatch):
     """HP_WFA2_GROUP_JOBS (experiment switch): the two smaller classes' groups take three jobs each and leave, the grid covers
     the list - workgroups retire all through the launch instead of staying until the queue is empty; same rows"""
