@@ -305,6 +305,26 @@ def host_cores():
     return max(1, n)
 
 
+def _thread_cpu():
+    """tid -> (thread name, CPU seconds so far) of this process's threads (/proc/self/task/*/stat: utime + stime)"""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                raw = open(f"/proc/self/task/{tid}/stat").read()
+            except OSError:
+                continue
+            name = raw[raw.index("(") + 1:raw.rindex(")")]
+            f = raw[raw.rindex(")") + 2:].split()
+            if not name.startswith("hp-"):   # not one of the library's: the caller's own thread, or one the HIP runtime started
+                name = "caller (main thread)" if tid == str(os.getpid()) else "unnamed (HIP runtime / interpreter threads)"
+            out[tid] = (name, (int(f[11]) + int(f[12])) / tick)
+    except OSError:
+        pass
+    return out
+
+
 def _cgroup_cpu_stat():
     """cpu.stat of the container's cgroup (v2), {} if there is none: nr_throttled / throttled_usec tell whether a CPU quota froze the process"""
     try:
@@ -395,13 +415,19 @@ def main_path(args, rank, world, local_rank, dist, backend):
     warm = max(args.warmup, args.depth + 1)
     run(0, warm)
     sync_all()
-    cg0, cpu0 = _cgroup_cpu_stat(), time.process_time()
+    cg0, cpu0, th0 = _cgroup_cpu_stat(), time.process_time(), _thread_cpu()
     t0 = time.perf_counter()
     stages, works = run(warm, args.steps)      # every wait returns with that set's results in the caller's buffers
     sync_all()
     elapsed = time.perf_counter() - t0
-    cg1, cpu1 = _cgroup_cpu_stat(), time.process_time()
+    cg1, cpu1, th1 = _cgroup_cpu_stat(), time.process_time(), _thread_cpu()
+    by_thread = {}
+    for tid, (name, sec) in th1.items():   # the library names its threads: hp-s<stage>, their pool workers ...w, helpers ...h
+        d = sec - th0.get(tid, (name, 0.0))[1]
+        if d > 0:
+            by_thread[name] = by_thread.get(name, 0.0) + d
     host_cpu = {"process_cpu_s_per_wall_s": (cpu1 - cpu0) / elapsed if elapsed > 0 else None,
+                "by_thread_name_cpu_s_per_wall_s": {k: round(v / elapsed, 3) for k, v in sorted(by_thread.items(), key=lambda kv: -kv[1]) if v / elapsed >= 0.005},
                 "cgroup_throttled_periods": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0) if cg0 and cg1 else None,
                 "cgroup_throttled_ms": (cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e3 if cg0 and cg1 else None,
                 "note": "host side of the timed region: CPU seconds the process used per second of wall time, and how often the container's CPU quota froze its threads (cpu.stat)"}

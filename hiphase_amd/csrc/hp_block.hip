@@ -927,8 +927,8 @@ private:
         for (int v = 0; v < n_vdev_; ++v) {
             devs_[(size_t)v].reset(new Dev());
             devs_[(size_t)v]->device = v % real_dev_;
-            std::thread([this, v]() { feed(v); }).detach();
-            std::thread([this, v]() { complete(v); }).detach();
+            std::thread([this, v]() { name_thread("hp-feed"); feed(v); }).detach();
+            std::thread([this, v]() { name_thread("hp-done"); complete(v); }).detach();
         }
     }
     static uint64_t max_records() {   // records per merged set (the bench's sets hold ~136 k; a pipeline slot's buffers grow to its largest set)

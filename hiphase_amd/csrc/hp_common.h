@@ -9,6 +9,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -64,6 +65,14 @@ int partition_cu_count(int device_id);   // CUs of the calling thread's current 
 // stream must never wait for another stage's kernels.
 hipStream_t thread_stream(int device_id);
 
+// Library threads carry names (`hp-...`, /proc/<pid>/task/*/comm): bench.py attributes the process's CPU time to them.
+inline void name_thread(const char* name) { (void)pthread_setname_np(pthread_self(), name); }
+inline void name_thread_after_creator(const char* creator, char suffix) {   // "<creator's name><suffix>"
+    char b[16];
+    std::snprintf(b, sizeof b, "%.13s%c", creator, suffix);
+    name_thread(b);
+}
+
 // A helper thread that lives as long as its owner: its thread-local device-buffer cache (below) then survives from one
 // task to the next (a fresh thread would hipMalloc every buffer again and hipFree it at exit, synchronising the device).
 struct HelperThread {
@@ -73,7 +82,11 @@ struct HelperThread {
     std::function<void()> task;
     bool has_task = false, busy = false, quit = false;
     void start() {
-        th = std::thread([this]() {
+        char who[16] = "hp";
+        (void)pthread_getname_np(pthread_self(), who, sizeof who);
+        const std::string creator = who;
+        th = std::thread([this, creator]() {
+            name_thread_after_creator(creator.c_str(), 'h');
             std::unique_lock<std::mutex> lk(m);
             for (;;) {
                 cv.wait(lk, [this]() { return has_task || quit; });
@@ -155,7 +168,12 @@ public:
             return;
         }
         busy = true;
-        while (th.size() + 1 < nt) th.emplace_back([this]() { loop(); });
+        if (th.size() + 1 < nt) {
+            char who[16] = "hp";
+            (void)pthread_getname_np(pthread_self(), who, sizeof who);
+            const std::string creator = who;
+            while (th.size() + 1 < nt) th.emplace_back([this, creator]() { name_thread_after_creator(creator.c_str(), 'w'); loop(); });
+        }
         job = [&f](unsigned t) { f(t); };
         want = nt - 1; started = 0; done = 0;
         cv.notify_all();

@@ -92,6 +92,7 @@ struct hp::Pipeline {
 };
 
 void hp::Pipeline::stage_thread(int t) {
+    { char b[16]; std::snprintf(b, sizeof b, "hp-s%d", t < N_STAGES ? t : extra_stage); name_thread(b); }
     WorkerPool::set_thread_pool(pool[t].get());
     stage_loop(t < N_STAGES ? t : extra_stage);   // (the last thread: a second one for the alignment stage - or, as an experiment, the rows stage)
 }

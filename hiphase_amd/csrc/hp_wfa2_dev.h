@@ -326,8 +326,11 @@ template <int W, bool WIDE = false> struct W3Cfg {
     static constexpr int MAXE = 2 * MAXN + 32;
     // slots per round: targets (consumed from the front) and live slots (appended behind them) share one array per round parity;
     // the sets of waves that finished a node this round take the round's set arena from the top
-    static constexpr int SLOTS = WIDE ? W2_SLOTS_WIDE : (W <= 4 ? 88 : 144);
-    static constexpr int WAVES_PER_SIMD = W <= 4 ? 3 : 2;
+#ifndef W3_OCC
+#define W3_OCC 3   // wavefronts per SIMD the two smaller classes are built for (experiment: 4 = 70 slots, 128 registers)
+#endif
+    static constexpr int SLOTS = WIDE ? W2_SLOTS_WIDE : (W <= 4 ? (W3_OCC >= 4 ? 70 : 88) : 144);
+    static constexpr int WAVES_PER_SIMD = W <= 4 ? W3_OCC : 2;
     static constexpr int a16(int x) { return (x + 15) & ~15; }
     static constexpr int O_A = 0;                                   // uint2[2][SLOTS]
     static constexpr int QN = W <= 4 ? 16 : 32;                      // child targets of the waves that finished in one tile (two per lane)
