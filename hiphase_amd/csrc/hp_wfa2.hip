@@ -605,6 +605,12 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
         (rc = d_score.alloc(n * 8)) || (rc = d_work.alloc(n * 8 + 16)) || (rc = d_status.alloc(n * 4)) || (rc = d_alleles.alloc(std::max<uint64_t>(allele_tot, 16))))
         return rc;
     uint8_t* sb = cx.stage.p;
+    // ---- the reads in place: run by run, no host thread touches them - and they cross while the tables below are filled ----------
+    if (in_place) {
+        for (const Run& r : runs)
+            HP_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(d_packed.p) + r.dev, reinterpret_cast<const void*>(r.lo), r.hi - r.lo, hipMemcpyHostToDevice, st));
+        g_in_place_bytes.fetch_add(in_place_bytes);
+    }
     const unsigned nt = [&] {
         const char* tenv = std::getenv("HP_WFA_HOST_THREADS");
         const unsigned want = tenv ? (unsigned)std::max(1, std::atoi(tenv)) : host_threads(16u);
@@ -668,15 +674,9 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
     HP_HIP_CHECK(hipMemcpyAsync(d_len_order.p, sb + o_len, n * 4, hipMemcpyHostToDevice, st));
     HP_HIP_CHECK(hipMemcpyAsync(d_src_off.p, sb + o_src, n * 8, hipMemcpyHostToDevice, st));
     HP_HIP_CHECK(hipMemcpyAsync(d_fmt.p, sb + o_fmt, n, hipMemcpyHostToDevice, st));
-    h2d_bytes = reads_dev + n_vars * sizeof(W2Variant) + n * (sizeof(W2Job) + 13);
-    // ---- 3b. the reads: in place, run by run (no host thread touches them) ... ---------------------------------------------------
-    if (in_place) {
-        for (const Run& r : runs)
-            HP_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(d_packed.p) + r.dev, reinterpret_cast<const void*>(r.lo), r.hi - r.lo, hipMemcpyHostToDevice, st));
-        h2d_bytes += in_place_bytes;
-        g_in_place_bytes.fetch_add(in_place_bytes);
-    }
-    // ---- ... or staged piece by piece: piece k crosses PCIe while the host threads fill piece k + 1 -----------------------------
+    h2d_bytes = reads_dev + n_vars * sizeof(W2Variant) + n * (sizeof(W2Job) + 13) + in_place_bytes;
+    // ---- 3b. the reads (unless they are crossing in place since before 3a), staged piece by piece: piece k crosses PCIe while the host
+    // threads fill piece k + 1 ----
     if (!in_place) {
         const char* penv = std::getenv("HP_STAGE_PIECE_MB");
         const uint64_t piece = (uint64_t)std::max(1, penv ? std::atoi(penv) : 48) << 20;
@@ -1178,6 +1178,15 @@ int W2Session::late() {
             g_wfa_min_ed_hint = nullptr;
             if (rc != HP_OK) return rc;
             late_kernel_ms += g_last_kernel_ms;
+            if (const char* dbg = std::getenv("HP_DEBUG")) if (std::atoi(dbg) >= 2)   // what the dense-band pass was given, and what came of it
+                for (size_t k = 0; k < pend.big.size(); ++k) {
+                    const hp_wfa_job j = job_header(pend.big[k]);
+                    uint64_t D = 0, Dmax = 0;
+                    for (uint32_t v = 0; v < j.n_hets; ++v) { const uint64_t x = std::max<uint64_t>({j.hets[v].ref_len, (j.hets[v].flags & 2u) ? j.hets[v].allele0_len : 0u, j.hets[v].allele1_len}); D += x; Dmax = std::max(Dmax, x); }
+                    for (uint32_t v = 0; v < j.n_homs; ++v) { const uint64_t x = std::max<uint64_t>({j.homs[v].ref_len, (j.homs[v].flags & 2u) ? j.homs[v].allele0_len : 0u, j.homs[v].allele1_len}); D += x; Dmax = std::max(Dmax, x); }
+                    fprintf(stderr, "[hp] dense job: read %u b, window %u b, %u + %u variants, D %llu (largest %llu), let go at %u edits, %u nodes -> status %d score %llu\n", dj[pend.big[k]].read_len, dj[pend.big[k]].ref_len,
+                            j.n_hets, j.n_homs, (unsigned long long)D, (unsigned long long)Dmax, pend.big_ed[k], Pending::nodes_of(pend.big_nodes[k]), pend.sub_out[k].status, (unsigned long long)pend.sub_out[k].score);
+                }
             for (size_t k = 0; k < pend.big.size(); ++k) pend.dst[pend.big[k]] = pend.sub_out[k];
         }
         pend.big.clear(); pend.big_ed.clear(); pend.big_nodes.clear();
