@@ -856,7 +856,10 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     if (g_wfa2_reserve_pct > 0 && (cls_cnt[0] || cls_cnt[1])) {
         const uint64_t total = (uint64_t)n_cu * 96u * (uint64_t)(100 - std::min(90, g_wfa2_reserve_pct)) / 100u;
         const uint64_t c0 = cls_cnt[0], c1 = cls_cnt[1];
-        uint64_t g0 = total * (10 * c0) / (10 * c0 + 13 * c1);   // (a job of the middle class - a larger graph - takes about 1.3 x as long: measured spans 23 vs 29.5 ms at equal shares)
+        // (a job of the middle class - a larger graph - takes longer: 1.3 x in the second generation (spans 23 vs 29.5 ms at equal shares),
+        // about 1.1 x in the third (21.9 vs 18.2 ms at 10 : 13). HP_WFA2_SPLIT = its weight in hundredths.)
+        static const uint64_t w1 = [] { const char* e = std::getenv("HP_WFA2_SPLIT"); return (uint64_t)(e ? std::max(50, std::min(400, std::atoi(e))) : (w2_gen() == 3 ? 110 : 130)); }();
+        uint64_t g0 = total * (100 * c0) / (100 * c0 + w1 * c1);
         if (c0) g0 = std::max<uint64_t>(g0, 64);
         if (c1) g0 = std::min<uint64_t>(g0, total - 64);
         capg[0] = (uint32_t)std::max<uint64_t>(8, g0 & ~7ull);

@@ -20,8 +20,15 @@ fi
 T=$1
 PMC=1 timeout 1500 bash scripts/prof_path.sh $T --steps 5 --warmup 2 > gpurun_out/${T}_prof.log 2>&1
 cp gpurun_out/prof_path_$T/traffic.json profiles/round4/traffic.json
-python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
 HP_LIB=hiphase_amd/libhiphase_gpu_prof.so timeout 300 python bench.py --no-cpu --no-resident --no-drop-in --steps 1 --warmup 1 --depth 1 > gpurun_out/${T}_phases.txt 2>&1
 HP_LIB=hiphase_amd/libhiphase_gpu_stats.so timeout 300 python bench.py --no-cpu --no-resident --no-drop-in --steps 1 --warmup 1 --depth 1 > gpurun_out/${T}_stats.txt 2>&1
-HP_STREAM_TRACE=1 python bench.py --no-cpu --no-resident --no-drop-in --steps 12 > /dev/null 2> gpurun_out/${T}_stream_trace.txt
-tests/cpp/dispatch_test 64 60000 4165 8 > gpurun_out/${T}_dispatch.json 2>/dev/null
+HP_STREAM_TRACE=1 timeout 300 python bench.py --no-cpu --no-resident --no-drop-in --steps 12 > /dev/null 2> gpurun_out/${T}_stream_trace.txt
+timeout 300 tests/cpp/dispatch_test 64 60000 4165 8 > gpurun_out/${T}_dispatch.json 2>/dev/null
+# side figures for DESIGN.md 4: reads staged by the library, two host threads, more edit noise, ASCII hand-over
+timeout 240 python bench.py --no-cpu --no-resident --no-drop-in --steps 20 --host-memory pageable 2>/dev/null | tail -1 > gpurun_out/${T}_pageable.json
+HP_HOST_THREADS=2 timeout 240 python bench.py --no-cpu --no-resident --no-drop-in --steps 20 2>/dev/null | tail -1 > gpurun_out/${T}_ht2.json
+timeout 240 python bench.py --no-cpu --no-resident --no-drop-in --steps 10 --spec edit_noise=0.01 2>/dev/null | tail -1 > gpurun_out/${T}_noise1.json
+timeout 400 python bench.py --no-cpu --no-resident --no-drop-in --steps 8 --spec edit_noise=0.02 2>/dev/null | tail -1 > gpurun_out/${T}_noise2.json
+timeout 300 python bench.py --no-cpu --no-resident --no-drop-in --steps 12 --seq-format ascii 2>/dev/null | tail -1 > gpurun_out/${T}_ascii.json
+timeout 240 python bench.py --no-cpu --no-resident --no-drop-in --steps 20 --depth 5 2>/dev/null | tail -1 > gpurun_out/${T}_depth5.json
