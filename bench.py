@@ -557,7 +557,7 @@ def main():
     ap.add_argument("--total-hets", type=int, default=60000, help="path workload: hets per GPU and step")
     ap.add_argument("--max-block-hets", type=int, default=4165, help="largest block HiPhase reports on HG002 (docs/user_guide.md:258)")
     ap.add_argument("--seq-format", choices=["bam4", "ascii"], default="bam4", help="path workload: how the reads are handed over")
-    ap.add_argument("--depth", type=int, default=7, help="path workload: block sets in flight in the stream (measured: 5 -> 33.1, 6 -> 31.9, 7 -> 30.5-31.5, 8 -> 30.8 ms per step; latency 157 -> 200 ms)")
+    ap.add_argument("--depth", type=int, default=6, help="path workload: block sets in flight in the stream (measured: 5 -> 31, 6 -> 28.3-29.4, 7 -> 29.2-30.2, 8 -> 29.3-29.6 ms per step; 160 / 190 / 215 ms from submit to done at 6 / 7 / 8)")
     ap.add_argument("--distinct-sets", type=int, default=16, help="path workload: generated sets (steps + warm-up if fewer; cycled if more are needed)")
     ap.add_argument("--host-memory", choices=["pageable", "pinned"], default="pinned",
                     help="path workload: where the records' bases lie on the host - ordinary memory (staged by the library's host threads) or hp_host_alloc memory (read in place by the device)")

@@ -902,6 +902,8 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         B.esc_producers = grid_wg[0] + grid_wg[1];
         B.esc_limit = cls_cnt[2] + 2u * (items2 - cls_cnt[2]);   // two jobs for each group reserved for hand-overs
         B.group_jobs = gjobs[k];
+        static const uint32_t hopeless_pct = [] { const char* e = std::getenv("HP_WFA2_HOPELESS"); return (uint32_t)(e ? std::max(10, std::min(100000, std::atoi(e))) : 50); }();
+        B.hopeless_pct = hopeless_pct;
         if (k == 0) rc = w2_launch<8, 2>(B, B.n_items, n_cu, capg[0], cs, &groups_used[k]);
         else if (k == 1) rc = gsel == 16 ? w2_launch<16, 4>(B, B.n_items, n_cu, capg[1], cs, &groups_used[k])
                             : gsel == 32 ? w2_launch<32, 4>(B, B.n_items, n_cu, capg[1], cs, &groups_used[k])
@@ -1043,8 +1045,8 @@ int W2Session::late() {
     const bool trace = std::getenv("HP_STREAM_TRACE") != nullptr;
     const double tl0 = w2_now_ms();
     double tl_early = tl0, tl_tail = tl0, tl_bound = tl0;
-    size_t n_early = 0;
-    struct LateTrace { bool on; const double& t0; const double& te; const double& t1; const double& t2; const size_t& ne; ~LateTrace() { if (on) fprintf(stderr, "[hp] late: the first collection's %zu leftovers settled (reference-window test + dense-band pass) after %.1f ms, largest class done + held results after %.1f, their leftovers' test after %.1f, dense-band pass after %.1f\n", ne, te - t0, t1 - t0, t2 - t0, w2_now_ms() - t0); } } lt{trace, tl0, tl_early, tl_tail, tl_bound, n_early};
+    size_t n_early = 0, n_late = 0;
+    struct LateTrace { bool on; const double& t0; const double& te; const double& t1; const double& t2; const size_t& ne; const size_t& nl; ~LateTrace() { if (on) fprintf(stderr, "[hp] late: the first collection's %zu leftovers settled (reference-window test + dense-band pass) after %.1f ms, largest class done + held results after %.1f, their %zu leftovers' test after %.1f, dense-band pass after %.1f\n", ne, te - t0, t1 - t0, nl, t2 - t0, w2_now_ms() - t0); } } lt{trace, tl0, tl_early, tl_tail, tl_bound, n_early, n_late};
     // results of jobs the largest class's kernel wrote after run()'s collection, gathered on the device: ids + row offsets up, one
     // record + the allele row per job down. What it could not align joins pend.big.
     hipStream_t s2 = pend.stream2;
@@ -1281,6 +1283,7 @@ int W2Session::late() {
         }
     }
     tl_tail = tl_bound = w2_now_ms();
+    n_late = pend.big.size();
     { const int rcd = dense_pass(); if (rcd != HP_OK) return rcd; }
     return HP_OK;
 }

@@ -376,6 +376,7 @@ struct W2Batch {
     uint32_t esc_producers;    // consumer: producer workgroups to wait for
     uint32_t esc_limit;        // producer: no hand-over once this many list positions are taken (the class's own jobs + a budget)
     uint8_t* handed;           // [n_jobs]: set by the producer that hands a job over (zeroed before the launch)
+    uint32_t hopeless_pct;     // third generation: a job that outgrows its lists is NOT handed over when its projected edit distance exceeds this share of max_ed (it goes to the host's pass)
     uint32_t group_jobs;       // > 0: a group leaves after this many jobs (the grid then has a workgroup for every NG x group_jobs jobs:
                                // workgroups retire all through the launch and other streams' kernels get their slots); 0: persistent
 };

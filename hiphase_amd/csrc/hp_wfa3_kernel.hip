@@ -170,14 +170,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                     const uint32_t upd = w2_gsum<G>(lane_upd);
                     bool handed_over = false;
                     // worth handing over: what the largest class's bigger tables fix (the slot lists) - not a full capped set
-                    // ... and not a read that is heading for Err(MaxEditDistance) anyway (the workload's noisy tail: at 5 % noise a
-                    // read holds fifty diagonals per node and outgrows every class's lists): by the rate it has made so far - edits
-                    // per read base - it would end far beyond the cap. Those skip the largest class (where they would crawl on to
-                    // outgrow its lists too, at the tail of the launch set) and go straight to the exact reference-window verdict of
-                    // the host's pass (hp_wfa2_bound_kernel). Routing only: every road computes the same result.
-                    // (a dozen rounds in, projected edits 1.25 x the cap: the bench's noisy reads - 5 % noise against a cap of 3.4 % -
-                    // outgrow the lists around their twelfth round. A read that is misjudged only takes the slower road.)
-                    const bool hopeless = ed >= 12u && (uint64_t)ed * other_len * 4u > ((uint64_t)farthest + 1u) * (uint64_t)maxed32 * 5u;
+                    // ... and not a read that is heading for the neighbourhood of max_edit_distance anyway (the workload's noisy tail: at
+                    // 5 % noise a read holds fifty diagonals per node and outgrows every class's lists): by the rate it has made so far -
+                    // edits per read base - it would end beyond hopeless_pct (50) per cent of the cap. Those skip the largest class - where
+                    // they would crawl on to outgrow its lists too, as the tail of the launch set: at 125 per cent a hundred reads a set
+                    // still did, and the class ended 12-15 ms after the other two - and go straight to the host's pass (the exact
+                    // reference-window verdict of hp_wfa2_bound_kernel, then the dense band). Routing only: every road computes the same
+                    // result. (A dozen rounds in: the bench's noisy reads outgrow the lists around their twelfth round; an ordinary HiFi
+                    // read over a structural variant projects to 20-30 per cent of the cap and is handed over as before.)
+                    const bool hopeless = ed >= 12u && (uint64_t)ed * other_len * 100u > ((uint64_t)farthest + 1u) * (uint64_t)maxed32 * B.hopeless_pct;
                     const bool hand = status == W2_ST_NEED_BIG && why == 8u && !hopeless;
                     if (B.esc_role == 1u && __any(hand)) {
                         const uint32_t taken = atomicAdd(B.esc, 0u);
