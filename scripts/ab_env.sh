@@ -1,9 +1,10 @@
 #!/bin/bash
-# A/B of environment switches on the default bench: ab_env.sh <steps> "VAR=a" "VAR=b VAR2=c" ... ("-" = nothing set)
+# A/B of environment switches on the default bench: ab_env.sh <steps> "VAR=a" "VAR=b VAR2=c" ... ("-" = nothing set;
+# BENCH_ARGS=--depth=7 adds bench.py arguments, no spaces inside)
 STEPS=$1; shift
 for e in "$@"; do
   if [ "$e" = "-" ]; then E=""; else E="$e"; fi
-  env $E timeout 240 python bench.py --no-cpu --no-resident --no-drop-in --steps $STEPS 2>/dev/null | tail -1 | python -c "
+  env $E STEPS=$STEPS bash -c 'timeout 240 python bench.py --no-cpu --no-resident --no-drop-in --steps $STEPS $BENCH_ARGS 2>/dev/null' | tail -1 | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
 s = d['stage_ms']
