@@ -88,8 +88,9 @@ struct hp_blockset {
     std::vector<hp_wfa_result> wfa_out;
     hp::W2Session* wfa = nullptr;                // graph-WFA inputs resident on the device (sets of >= HP_WFA2_MIN_JOBS records)
     bool wfa_ready = false;                      // ... laid out and uploaded for the current blocks
+    bool wfa_laid = false;                       // ... its host-only layout half done (blockset_layout), the upload still to come
     double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // stage times of the last solve
-    double rows_ms[4] = {0, 0, 0, 0};            // of the last blockset_rows: blocks that wait for nothing, blocks that held a late result, of which: their local re-alignment launch; the free blocks' launch
+    double rows_ms[5] = {0, 0, 0, 0, 0};          // of the last blockset_rows: blocks that wait for nothing, blocks that held a late result, of which: their local re-alignment launch; the free blocks' launch; the wait for the first collection + its scatter
     double late_wait_ms = 0.0;                   // of the last blockset_rows: time spent waiting for the graph-WFA stage's late results
     double prep[4] = {0, 0, 0, 0};               // of the last init: layout ms, fill + upload ms, total ms, bytes host -> device
     size_t upload_min_jobs = 0;                  // (blockset_layout -> blockset_upload: sets below this take the latency path at solve time)

@@ -240,8 +240,17 @@ int hp::blockset_layout(hp_blockset* bs, size_t n_blocks, const hp_block_input* 
     bs->allele_ptrs.resize(n_jobs);
     for (size_t k = 0; k < n_jobs; ++k) bs->allele_ptrs[k] = bs->alleles.data() + bs->job_alloff[k];
     bs->wfa_out.resize(n_jobs);
-    bs->prep[0] = blk_now_ms() - t0;
     bs->upload_min_jobs = min_jobs;
+    // large sets (the compact road): the host-only half of the sequence layout - offsets, the runs the copy engines read in place,
+    // the length order - belongs to this stage too: in front of the upload it was 4-5 ms of every set's turn on the PCIe link
+    bs->wfa_laid = false;
+    if (n_jobs && n_jobs >= min_jobs) {
+        if (!bs->wfa) bs->wfa = w2_session_create();
+        const int rc = w2_session_layout_blocks(bs->wfa, in, n_blocks, bs->jobs.data(), n_jobs);
+        if (rc != HP_OK) return rc;
+        bs->wfa_laid = true;
+    }
+    bs->prep[0] = blk_now_ms() - t0;
     return HP_OK;
 }
 
@@ -252,13 +261,18 @@ int hp::blockset_upload(hp_blockset* bs) {
     const hp_block_input* in = bs->in;
     // large sets: lay the sequences out and upload them now (resident); small ones take the latency path at solve time
     if (n_jobs && n_jobs >= min_jobs) {
-        if (!bs->wfa) bs->wfa = w2_session_create();
-        const int rc = w2_session_prepare_blocks(bs->wfa, in, n_blocks, bs->jobs.data(), n_jobs, bs->device);
+        int rc;
+        if (bs->wfa_laid) rc = w2_session_upload_blocks(bs->wfa, bs->device);
+        else {
+            if (!bs->wfa) bs->wfa = w2_session_create();
+            rc = w2_session_prepare_blocks(bs->wfa, in, n_blocks, bs->jobs.data(), n_jobs, bs->device);
+        }
+        bs->wfa_laid = false;
         if (rc != HP_OK) return rc;
         bs->wfa_ready = true;
         double pr[4];
         w2_session_prepare_stats(bs->wfa, pr);
-        bs->prep[0] += pr[0]; bs->prep[1] = pr[1]; bs->prep[3] = pr[3];
+        bs->prep[1] = pr[1]; bs->prep[3] = pr[3];   // (the layout half's time is in prep[0] already: blockset_layout)
     }
     bs->prep[2] = bs->prep[0] + (blk_now_ms() - t0);
     return HP_OK;
@@ -565,6 +579,9 @@ int hp::blockset_rows(hp_blockset* bs) {
         // blocks that hold a read whose alignment is still in the dense-band pass go last; whoever reaches the first of
         // them waits for that pass (it has had the other blocks' assembly to finish in)
         size_t n_free = order.size();
+        // the set's alignment stage did not wait for its own results (w2_session_run, defer = 2): they are handed over here
+        if (has_wfa && (rc = w2_session_collected(ch.wfa)) != HP_OK) return rc;
+        ch.rows_ms[4] = blk_now_ms() - t1;
         if (has_wfa) {
             const uint32_t* ids = nullptr; size_t n_ids = 0;
             w2_session_pending(ch.wfa, &ids, &n_ids);

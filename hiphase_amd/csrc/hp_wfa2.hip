@@ -264,27 +264,72 @@ struct W2Session {
     uint32_t wide_tag_next = 0;
     int wide_last_gen = 0;
     PinBuf late_down;                      // results of the held jobs
+    PinBuf down;                           // results of a run's first collection (the session's own: the calling thread may have queued the next set's run before they are read)
     std::unique_ptr<HelperThread> helper;  // runs late() when run() defers
+    // what a run's first collection needs once its results are on the host (collect_host, scatter): kept here because with
+    // defer = 2 the thread that launched the set does not wait for them (see run())
+    struct RunState {
+        size_t dn_score = 0, dn_work = 0, dn_info = 0, dn_cnt = 0, dn_al = 0;
+        hp_wfa_result* out = nullptr;
+        uint8_t* const* alleles = nullptr;
+        bool two_phase = false, verbose = false;
+        uint64_t prune = 0, max_ed = 0;
+        hipStream_t stream2 = nullptr;
+        W2Batch b2{};
+        uint32_t large_groups = 0, groups_used[3] = {0, 0, 0};
+        int n_cu = 0, defer = 0;
+        double t0 = 0, t_built = 0, t_cls = 0, t_done = 0;
+    } rs;
+    hipEvent_t ev_c = nullptr;             // the first collection's copies are done
+    bool async_inflight = false;           // run() returned before its first collection: the helper thread collects, then runs late()
+    std::mutex cm;
+    std::condition_variable ccv;
+    bool collected = false, scattered = false;
+    int collect_rc = HP_OK;
+    std::string collect_err;
+    int collect_host();                    // the first collection's results sorted out on the host: what is still held, what goes to the dense band
+    int scatter();                         // ... and handed to the caller's arrays
+    int wait_collected();                  // defer = 2: waits for collect_host (helper thread), then scatters on the calling thread
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build start / end, class launches start / end
     int late();                            // second collection + dense-band pass; on the helper thread when deferred
     double late_kernel_ms = 0.0;
     std::mutex work_m;
     int prepare(const hp_wfa_job* jobs_, size_t n_, int device);
-    int prepare_blocks(const hp_block_input* in, size_t n_in, const W2JobIn* jin, size_t n_, int device);
+    // block mode in two halves: layout_blocks is host only (offsets, the in-place runs, the length order: a block stream runs it in its
+    // layout stage, ahead of the set's turn on the PCIe link), upload_blocks fills the tables and sends everything; prepare_blocks = both
+    struct BlockLay { int64_t lo = INT64_MAX, hi = INT64_MIN; uint64_t ref_dev = 0, pool_off = 0; uint32_t var_base = 0; };
+    struct Run { uintptr_t lo, hi; uint64_t dev; };
+    struct Lay {
+        bool valid = false, in_place = false;
+        size_t n_in = 0;
+        std::vector<BlockLay> bl;
+        std::vector<uint64_t> src_off;
+        std::vector<uint8_t> fmt;
+        std::vector<Run> runs;
+        uint64_t n_vars = 0, pool_bytes = 0, ref_bytes = 0, reads_dev = 0, dev_reads = 0, packed = 0, in_place_bytes = 0;
+        double t0 = 0.0, t_lay = 0.0;
+    } lay;
+    int layout_blocks(const hp_block_input* in, size_t n_in, const W2JobIn* jin, size_t n_);
+    int upload_blocks(int device);
+    int prepare_blocks(const hp_block_input* in, size_t n_in, const W2JobIn* jin, size_t n_, int device) {
+        const int rc = layout_blocks(in, n_in, jin, n_);
+        return rc != HP_OK ? rc : upload_blocks(device);
+    }
     // defer: 0 = everything is in `out` on return; 1 = the dense-band pass of the leftovers may still run (finish() waits);
     // 2 = also the largest class's kernel (two phases) - the caller must not start another run on this thread before finish()
     int run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer = 0);
     int finish();
     ~W2Session() {
-        if (pend.on && pend.posted && helper) helper->wait();
+        if ((async_inflight || (pend.on && pend.posted)) && helper) helper->wait();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (ev_c) (void)hipEventDestroy(ev_c);
     }
 };
 
 int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     // a deferred late() of the previous run still writes the caller's result arrays and reads the tables laid out below: join it
     // first, whatever path the caller took out of that run (its status belongs to that run, not to this one)
-    if (pend.on) (void)finish();
+    if (pend.on || async_inflight) (void)finish();
     jobs = jobs_; n = n_; bl_in = nullptr; bl_jobs = nullptr; need_unpack = false;
     if (n == 0) return HP_OK;
     if (!jobs) { set_error("null argument"); return HP_ERR_ARG; }
@@ -449,18 +494,19 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
 // read windows of ONE reference buffer (their hull is uploaded once) and slices of the block's two variant vectors (uploaded
 // once, hets then homs). Everything per job is independent of every other job, so layout, table fill and the staging copy
 // run on host threads; the reads are staged in pieces and each piece's DMA runs while the next one is being filled.
-int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2JobIn* jin, size_t n_, int device) {
-    if (pend.on) (void)finish();   // (as in prepare(): never lay a set out under a late pass that is still running)
+int W2Session::layout_blocks(const hp_block_input* in, size_t n_in, const W2JobIn* jin, size_t n_) {
+    if (pend.on || async_inflight) (void)finish();   // (as in prepare(): never lay a set out under a late pass that is still running)
     jobs = nullptr; bl_in = in; bl_jobs = jin; n = n_;
     h2d_bytes = 0; prep_ms[0] = prep_ms[1] = prep_ms[2] = prep_ms[3] = 0.0;
-    if (n == 0) return HP_OK;
+    lay.valid = false; lay.n_in = n_in;
+    if (n == 0) { lay.valid = true; return HP_OK; }
     if (!in || !jin) { set_error("null argument"); return HP_ERR_ARG; }
     if (n > 0x3FFFFFFFull) { set_error("too many jobs"); return HP_ERR_ARG; }
     const double t0 = w2_now_ms();
     seq_bytes = 0; node_tot = edge_tot = tag_tot = allele_tot = 0;
     // ---- 1. per block: hull of its jobs' windows, variant base, allele pool -------------------------------------------------
-    struct BlockLay { int64_t lo = INT64_MAX, hi = INT64_MIN; uint64_t ref_dev = 0, pool_off = 0; uint32_t var_base = 0; };
-    std::vector<BlockLay> bl(n_in);
+    std::vector<BlockLay>& bl = lay.bl;
+    bl.assign(n_in, BlockLay{});
     for (size_t i = 0; i < n; ++i) {
         const W2JobIn& ji = jin[i];
         if (ji.block >= n_in || ji.rec >= in[ji.block].n_records) { set_error("job %zu: bad block / record index", i); return HP_ERR_ARG; }
@@ -494,8 +540,9 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
     const uint64_t reads_dev = ref_bytes + ((pool_bytes + 15) & ~15ull);   // device: [reference hulls][allele pool][one byte per base][pad]
     // ---- 2. per job: offsets (serial prefix sums, a few bytes per job) ------------------------------------------------------------
     dj.assign(n, W2Job{});
-    std::vector<uint64_t> src_off(n + 1);
-    std::vector<uint8_t> fmt(n);
+    std::vector<uint64_t>& src_off = lay.src_off;
+    std::vector<uint8_t>& fmt = lay.fmt;
+    src_off.assign(n + 1, 0); fmt.assign(n, 0);
     uint64_t dev_reads = 0, packed = 0;
     for (size_t i = 0; i < n; ++i) {
         const W2JobIn& ji = jin[i];
@@ -521,8 +568,8 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
     // the blocks' address hulls, merged where they touch, cross PCIe as they are - one DMA per run of blocks - and a record's source
     // offset is its place in that image. (Blocks gathered one after the other into an arena give a handful of runs; records
     // scattered so that the hulls hold much more than the records do take the staged way.)
-    struct Run { uintptr_t lo, hi; uint64_t dev; };
-    std::vector<Run> runs;
+    std::vector<Run>& runs = lay.runs;
+    runs.clear();
     bool in_place = host_ranges_any() && !std::getenv("HP_NO_IN_PLACE");
     uint64_t in_place_bytes = 0;
     if (in_place) {
@@ -581,7 +628,28 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
         for (size_t i = 0; i < n; ++i) len_order[cnt[65535u - std::min<uint32_t>(dj[i].read_len, 65535u)]++] = (uint32_t)i;
     }
     vars.clear();
-    const double t_lay = w2_now_ms();
+    lay.in_place = in_place; lay.n_vars = n_vars; lay.pool_bytes = pool_bytes; lay.ref_bytes = ref_bytes; lay.reads_dev = reads_dev;
+    lay.dev_reads = dev_reads; lay.packed = packed; lay.in_place_bytes = in_place_bytes;
+    lay.t0 = t0; lay.t_lay = w2_now_ms();
+    prep_ms[0] = lay.t_lay - t0;
+    lay.valid = true;
+    return HP_OK;
+}
+
+int W2Session::upload_blocks(int device) {
+    if (!lay.valid) { set_error("upload_blocks without layout_blocks"); return HP_ERR_ARG; }
+    lay.valid = false;
+    if (n == 0) return HP_OK;
+    const hp_block_input* in = bl_in;
+    const W2JobIn* jin = bl_jobs;
+    const size_t n_in = lay.n_in;
+    const std::vector<BlockLay>& bl = lay.bl;
+    const std::vector<uint64_t>& src_off = lay.src_off;
+    const std::vector<uint8_t>& fmt = lay.fmt;
+    const std::vector<Run>& runs = lay.runs;
+    const bool in_place = lay.in_place;
+    const uint64_t n_vars = lay.n_vars, ref_bytes = lay.ref_bytes, reads_dev = lay.reads_dev, packed = lay.packed, in_place_bytes = lay.in_place_bytes;
+    const double t_up0 = w2_now_ms();
 
     // ---- from here on a GPU is mandatory (no CPU fallback) -------------------------------------------------------------
     if (device < 0) device = hp_default_device();
@@ -711,14 +779,14 @@ int W2Session::prepare_blocks(const hp_block_input* in, size_t n_in, const W2Job
     need_unpack = true;
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("upload failed"); return HP_ERR_HIP; }
     const double t1 = w2_now_ms();
-    prep_ms[0] = t_lay - t0; prep_ms[1] = t1 - t_lay; prep_ms[2] = t1 - t0; prep_ms[3] = (double)h2d_bytes;
-    last_prepare_ms = t1 - t0;
+    prep_ms[1] = t1 - t_up0; prep_ms[2] = prep_ms[0] + prep_ms[1]; prep_ms[3] = (double)h2d_bytes;
+    last_prepare_ms = prep_ms[2];
     return HP_OK;
 }
 
 int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer) {
     if (n == 0) return HP_OK;
-    if (pend.on) { const int rcp = finish(); if (rcp != HP_OK) return rcp; }
+    if (pend.on || async_inflight) { const int rcp = finish(); if (rcp != HP_OK) return rcp; }
     if (!out) { set_error("null argument"); return HP_ERR_ARG; }
     if (max_ed > 60000) {   // outside the kernels' diagonal range: every job of the batch, softly (HP_WFA_UNSUPPORTED)
         for (size_t i = 0; i < n; ++i) { out[i] = hp_wfa_result{HP_WFA_UNSUPPORTED, 0, 0}; if (alleles && alleles[i] && dj[i].n_hets) std::memset(alleles[i], HP_ALLELE_NOOVERLAP, dj[i].n_hets); }
@@ -740,17 +808,12 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     // exit path, so none of them goes out of scope with a copy in flight
     // results come back into pinned staging (a pageable destination costs a bounce through the runtime's own buffers)
     const size_t dn_score = (n * 4 + 15) / 16 * 16, dn_work = dn_score + n * 8, dn_info = dn_work + n * 8, dn_cnt = dn_info + n * sizeof(W2Info), dn_esc = dn_cnt + 16, dn_al = dn_esc + 16;
-    if ((rc = cx.down.reserve(dn_al + (size_t)allele_tot + 16)) != HP_OK) return rc;
-    const int32_t* status = reinterpret_cast<const int32_t*>(cx.down.p);
-    const uint64_t* score = reinterpret_cast<const uint64_t*>(cx.down.p + dn_score);
-    const uint32_t* work = reinterpret_cast<const uint32_t*>(cx.down.p + dn_work);
-    W2Info* info_pin = reinterpret_cast<W2Info*>(cx.down.p + dn_info);
-    const W2Info* info = info_pin;
-    const uint32_t* cls_n = reinterpret_cast<const uint32_t*>(cx.down.p + dn_cnt);
-    const uint8_t* al = cx.down.p + dn_al;
+    if ((rc = down.reserve(dn_al + (size_t)allele_tot + 16)) != HP_OK) return rc;
+    W2Info* info_pin = reinterpret_cast<W2Info*>(down.p + dn_info);
+    const uint32_t* cls_n = reinterpret_cast<const uint32_t*>(down.p + dn_cnt);
     const uint32_t turn = cx.run_no++ % 3u;   // whose turn among the largest class's streams / scratch regions
     hipStream_t cls_stream[3] = {cs_->cstream[0], cs_->cstream[1], turn == 0 ? cs_->cstream[2] : cs_->c2x[turn - 1]};
-    struct StreamDrain { hipStream_t s; hipStream_t* c; bool skip2; ~StreamDrain() { for (int k = 0; k < 3; ++k) if (c[k] && !(skip2 && k == 2)) (void)hipStreamSynchronize(c[k]); (void)hipStreamSynchronize(s); } } drain{st, cls_stream, false};
+    struct StreamDrain { hipStream_t s; hipStream_t* c; bool skip2; bool off; ~StreamDrain() { if (off) return; for (int k = 0; k < 3; ++k) if (c[k] && !(skip2 && k == 2)) (void)hipStreamSynchronize(c[k]); (void)hipStreamSynchronize(s); } } drain{st, cls_stream, false, false};
     const double t_stage = t0;
 
     // ---- 3. graphs on the device ----------------------------------------------------------------------------------------
@@ -824,7 +887,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     // the class sizes come back (16 bytes, one short wait): a grid sized for the class fills every workgroup's groups, and
     // an empty class is not launched. Measured: launching each class with the whole batch's grid instead (no wait) cost
     // 3-4 ms of 22 - the W=8 class then spreads its few long jobs one per workgroup and holds LDS for idle groups.
-    if ((rc = dev_copy(cx.down.p + dn_cnt, d_counts, 16, st)) != HP_OK) return rc;   // (a kernel's store to pinned memory: a copy-engine transfer would queue behind the next set's upload)
+    if ((rc = dev_copy(down.p + dn_cnt, d_counts, 16, st)) != HP_OK) return rc;   // (a kernel's store to pinned memory: a copy-engine transfer would queue behind the next set's upload)
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA graph-build kernel failed"); return HP_ERR_HIP; }
     const double t_built = w2_now_ms();
     W2Batch B{};
@@ -925,54 +988,104 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         HP_HIP_CHECK(hipGetLastError());
     }
     // ---- 5. results --------------------------------------------------------------------------------------------------------
-    if ((rc = dev_copy(info_pin, d_info.p, n * sizeof(W2Info), st)) || (rc = dev_copy(cx.down.p + dn_esc, d_esc, 16, st)) || (rc = dev_copy(cx.down.p, d_seen.p, n * 4, st)) ||
-        (rc = dev_copy(cx.down.p + dn_score, d_score.p, n * 8, st)) || (rc = dev_copy(cx.down.p + dn_al, d_alleles.p, (size_t)allele_tot, st)) ||
-        (rc = dev_copy(cx.down.p + dn_work, d_work.p, n * 8, st)))
+    if ((rc = dev_copy(info_pin, d_info.p, n * sizeof(W2Info), st)) || (rc = dev_copy(down.p + dn_esc, d_esc, 16, st)) || (rc = dev_copy(down.p, d_seen.p, n * 4, st)) ||
+        (rc = dev_copy(down.p + dn_score, d_score.p, n * 8, st)) || (rc = dev_copy(down.p + dn_al, d_alleles.p, (size_t)allele_tot, st)) ||
+        (rc = dev_copy(down.p + dn_work, d_work.p, n * 8, st)))
         return rc;
+    rs = RunState{};
+    rs.dn_score = dn_score; rs.dn_work = dn_work; rs.dn_info = dn_info; rs.dn_cnt = dn_cnt; rs.dn_al = dn_al;
+    rs.out = out; rs.alleles = alleles; rs.two_phase = two_phase; rs.verbose = verbose; rs.prune = prune_distance; rs.max_ed = max_ed;
+    rs.stream2 = cls_stream[2]; rs.b2 = pend_b2; rs.large_groups = cx.large_groups; rs.n_cu = n_cu; rs.defer = defer;
+    for (int k = 0; k < 3; ++k) rs.groups_used[k] = groups_used[k];
+    rs.t0 = t0; rs.t_built = t_built; rs.t_cls = t_cls;
+    // Inside a block stream (defer = 2) the launching thread does not wait for the set: the class kernels take ~20 ms, and whatever this
+    // thread did after them - the wait for the copies above, sorting out what is held and what is left over, handing the results to
+    // the block layer's arrays: 2.5-3 ms a set - stood between this set's kernels and the next set's. The session's helper thread
+    // waits for the copies, sorts the results out (collect_host) and goes on with late(); the block layer's row stage scatters
+    // (wait_collected) before it reads anything. The next run() of the calling thread queues behind this one on the same streams.
+    static const bool async_ok = [] { const char* e = std::getenv("HP_WFA2_ASYNC"); return !(e && e[0] == '0'); }();
+    if (two_phase && defer >= 2 && async_ok) {
+        if (!ev_c) HP_HIP_CHECK(hipEventCreateWithFlags(&ev_c, hipEventDisableTiming));
+        HP_HIP_CHECK(hipEventRecord(ev_c, st));
+        if (!helper) { helper.reset(new HelperThread()); helper->start(); }
+        { std::lock_guard<std::mutex> lk(cm); collected = false; scattered = false; collect_rc = HP_OK; collect_err.clear(); }
+        async_inflight = true;
+        drain.off = true;   // (nothing of this frame is read or written by what is still queued: the results land in the session's `down`)
+        const int part = g_cu_partition;
+        W2Session* self = this;
+        helper->post([self, part]() {
+            // (inside a block stream the graph-WFA stage owns partition 2, which the NEXT set's persistent kernels fill: the
+            // dense-band pass of this set's leftovers launches on the whole device and runs where there is room)
+            g_cu_partition = part == 2 ? 0 : part;
+            int rcc = HP_OK;
+            if (hipSetDevice(self->device_id) != hipSuccess || hipEventSynchronize(self->ev_c) != hipSuccess) { set_error("WFA kernel failed"); rcc = HP_ERR_HIP; }
+            if (rcc == HP_OK) rcc = self->collect_host();
+            if (rcc == HP_OK && self->pend.on) self->pend.posted = true;
+            {
+                std::lock_guard<std::mutex> lk(self->cm);
+                self->collect_rc = rcc;
+                if (rcc != HP_OK) self->collect_err = hp_last_error();
+                self->collected = true;
+            }
+            self->ccv.notify_all();
+            self->pend.rc = rcc;
+            if (rcc != HP_OK) { self->pend.err = hp_last_error(); return; }
+            if (!self->pend.on) return;
+            self->pend.rc = self->late();
+            if (self->pend.rc != HP_OK) self->pend.err = hp_last_error();
+        });
+        return HP_OK;
+    }
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
 #if W2_PROF
     (void)hipDeviceSynchronize();   // flushes the instrumented kernel's printf buffer
 #endif
+    if ((rc = collect_host()) != HP_OK) return rc;
+    // ---- 6. what is not here yet (late()): on the session's helper thread when the caller defers, else right below ----
+    if (pend.on && defer) {
+        if (!helper) { helper.reset(new HelperThread()); helper->start(); }
+        const int part = g_cu_partition;
+        W2Session* self = this;
+        pend.posted = true;
+        helper->post([self, part]() {
+            g_cu_partition = part == 2 ? 0 : part;
+            self->pend.rc = self->late();
+            if (self->pend.rc != HP_OK) self->pend.err = hp_last_error();
+        });
+        drain.skip2 = true;
+    }
+    struct Joiner { W2Session* s; bool armed; ~Joiner() { if (armed && s->pend.on && s->pend.posted) { s->helper->wait(); s->pend.on = false; } } } joiner{this, true};
+    if ((rc = scatter()) != HP_OK) return rc;
+    joiner.armed = false;
+    if (defer) return HP_OK;
+    return finish();
+}
+
+// The first collection sorted out on the host, once its copies have landed in `down`: which jobs are still with the largest class
+// (held), which no class could align (big: the dense-band pass). Fills `pend`. On the helper thread when run() did not wait.
+int W2Session::collect_host() {
+    const int32_t* status = reinterpret_cast<const int32_t*>(down.p);
+    const uint64_t* score = reinterpret_cast<const uint64_t*>(down.p + rs.dn_score);
+    const W2Info* info = reinterpret_cast<const W2Info*>(down.p + rs.dn_info);
+    const bool two_phase = rs.two_phase;
     float ms_build = 0.f, ms_wfa = 0.f;
-    (void)hipEventElapsedTime(&ms_build, e0, e1);
-    if (!two_phase) (void)hipEventElapsedTime(&ms_wfa, e2, e3);
+    (void)hipEventElapsedTime(&ms_build, ev[0], ev[1]);
+    if (!two_phase) (void)hipEventElapsedTime(&ms_wfa, ev[2], ev[3]);
     g_last_kernel_ms = (double)ms_build + (double)ms_wfa;
     last_span_ms = (double)ms_wfa;
-    const double t_done = w2_now_ms();
+    rs.t_done = w2_now_ms();
     // held: still with the largest class's kernel (two phases). big: no class took them (builder limits, graph size, read
     // length), or the largest class handed them back, or (one phase) nobody claimed them - the dense-band pass aligns those.
     pend = Pending{};
-    pend.two_phase = two_phase; pend.dst = out; pend.alleles = alleles; pend.prune = prune_distance; pend.max_ed = max_ed;
-    pend.stream2 = cls_stream[2]; pend.ms_build = ms_build;
-    pend.b2 = pend_b2; pend.large_groups = cx.large_groups; pend.n_cu = n_cu;
+    pend.two_phase = two_phase; pend.dst = rs.out; pend.alleles = rs.alleles; pend.prune = rs.prune; pend.max_ed = rs.max_ed;
+    pend.stream2 = rs.stream2; pend.ms_build = ms_build;
+    pend.b2 = rs.b2; pend.large_groups = rs.large_groups; pend.n_cu = rs.n_cu;
     for (size_t i = 0; i < n; ++i) {
         if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %zu", i); return HP_ERR_INVARIANT; }
         if (status[i] == W2_ST_PENDING) { if (two_phase) { pend.held.push_back((uint32_t)i); pend.held_nodes.push_back(info[i].n_nodes); } else { pend.big.push_back((uint32_t)i); pend.big_ed.push_back(0); pend.big_nodes.push_back(info[i].status == W2B_OK ? info[i].n_nodes : 0u); } }
         else if (status[i] == W2_ST_NEED_BIG) { pend.big.push_back((uint32_t)i); pend.big_ed.push_back((uint32_t)(score[i] >> 8)); pend.big_nodes.push_back(info[i].status == W2B_OK ? (info[i].n_nodes | ((uint32_t)(score[i] & 0xFFu) << 24)) : 0u); }
     }
-    const size_t n_big = cls_n[3];
-#if W2_STATS
-    {   // sizing study: how far the jobs of the two smaller classes fill their tables
-        std::vector<uint32_t> sets(n * W2_SET_STRIDE);
-        (void)hipMemcpy(sets.data(), d_sets.p, n * W2_SET_STRIDE * 4, hipMemcpyDeviceToHost);
-        std::vector<uint32_t> hl(64, 0), hf(64, 0), ht(40, 0);
-        size_t cnt = 0;
-        for (size_t i = 0; i < n; ++i) {
-            if (status[i] != W2_ST_OK || info[i].n_nodes > (uint32_t)W2Cfg<4>::MAXN) continue;
-            const uint32_t v = sets[i * W2_SET_STRIDE + 6];
-            hl[std::min<uint32_t>(63, v & 0xFF)]++; hf[std::min<uint32_t>(63, (v >> 8) & 0xFF)]++; ht[std::min<uint32_t>(39, (v >> 16) / 8)]++;
-            ++cnt;
-        }
-        auto tail = [&](const std::vector<uint32_t>& h, const char* name, int scale) {
-            fprintf(stderr, "[hp] wfa2 stats %s (jobs above the value, per 10000):", name);
-            size_t above = cnt;
-            for (size_t k = 0; k < h.size(); ++k) { above -= h[k]; if (k % 2 == 1 || scale > 1) fprintf(stderr, " >%zu:%zu", k * scale + (scale - 1), above * 10000 / std::max<size_t>(cnt, 1)); }
-            fprintf(stderr, "\n");
-        };
-        tail(hl, "live entries", 1); tail(hf, "finished-only entries", 1); tail(ht, "arena slots", 8);
-    }
-#endif
-    if (verbose && !pend.big.empty()) {   // which class handed jobs back, and which of its limits (hp_wfa2_kernel's `why`)
+    if (rs.verbose && !pend.big.empty()) {   // which class handed jobs back, and which of its limits (hp_wfa2_kernel's `why`)
         uint32_t hist[3][10] = {};
         for (uint32_t i : pend.big) {
             const uint32_t nn = info[i].n_nodes, ne = info[i].n_edges;
@@ -986,25 +1099,22 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
             fprintf(stderr, "\n");
         }
     }
-    // ---- 6. what is not here yet (late()): on the session's helper thread when the caller defers, else right below ----
     pend.ids = pend.held;
     pend.ids.insert(pend.ids.end(), pend.big.begin(), pend.big.end());
     pend.on = !pend.ids.empty() || two_phase;
-    if (pend.on && defer) {
-        if (!helper) { helper.reset(new HelperThread()); helper->start(); }
-        const int part = g_cu_partition;
-        W2Session* self = this;
-        pend.posted = true;
-        helper->post([self, part]() {
-            // (inside a block stream the graph-WFA stage owns partition 2, which the NEXT set's persistent kernels fill: the
-            // dense-band pass of this set's leftovers launches on the whole device and runs where there is room)
-            g_cu_partition = part == 2 ? 0 : part;
-            self->pend.rc = self->late();
-            if (self->pend.rc != HP_OK) self->pend.err = hp_last_error();
-        });
-        drain.skip2 = true;
-    }
-    struct Joiner { W2Session* s; bool armed; ~Joiner() { if (armed && s->pend.on && s->pend.posted) { s->helper->wait(); s->pend.on = false; } } } joiner{this, true};
+    return HP_OK;
+}
+
+// The first collection's results into the caller's arrays (host threads of the calling thread's pool).
+int W2Session::scatter() {
+    const int32_t* status = reinterpret_cast<const int32_t*>(down.p);
+    const uint64_t* score = reinterpret_cast<const uint64_t*>(down.p + rs.dn_score);
+    const uint32_t* work = reinterpret_cast<const uint32_t*>(down.p + rs.dn_work);
+    const W2Info* info = reinterpret_cast<const W2Info*>(down.p + rs.dn_info);
+    const uint32_t* cls_n = reinterpret_cast<const uint32_t*>(down.p + rs.dn_cnt);
+    const uint8_t* al = down.p + rs.dn_al;
+    hp_wfa_result* out = rs.out;
+    uint8_t* const* alleles = rs.alleles;
     std::atomic<int64_t> bad{-1};
     {
         const unsigned nt = w2_host_threads(n, 8192);
@@ -1029,14 +1139,25 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         work_updates += s0; work_node_bytes += s1; work_read_bytes += s2; work_jobs += s3;
     }
     if (bad.load() >= 0) { set_error("job %lld: device status %d", (long long)bad.load(), status[bad.load()]); return HP_ERR_INVARIANT; }
-    if (verbose) {
-        fprintf(stderr, "[hp] wfa2: %zu jobs (classes %zu/%zu/%zu, groups %u/%u/%u, %zu for the dense-band path of which %zu by size/builder, %zu collected later with the largest class): layout+stage %.2f ms, upload+build %.2f ms (build kernel %.3f), queueing the classes %.2f ms, class kernels %.3f ms%s, first results on the host after %.2f ms, scattered after %.2f ms\n",
-                n, (size_t)cls_n[0], (size_t)cls_n[1], (size_t)cls_n[2], groups_used[0], groups_used[1], groups_used[2], pend.big.size(), n_big, pend.held.size(), t_stage - t0, t_built - t_stage, ms_build, t_cls - t_built, ms_wfa, two_phase ? " (span known after the second collection)" : "", t_done - t0, w2_now_ms() - t0);
+    if (rs.verbose) {
+        fprintf(stderr, "[hp] wfa2: %zu jobs (classes %zu/%zu/%zu, groups %u/%u/%u, %zu for the dense-band path of which %zu by size/builder, %zu collected later with the largest class): upload+build %.2f ms, queueing the classes %.2f ms%s, first results on the host after %.2f ms, scattered after %.2f ms\n",
+                n, (size_t)cls_n[0], (size_t)cls_n[1], (size_t)cls_n[2], rs.groups_used[0], rs.groups_used[1], rs.groups_used[2], pend.ids.size() - pend.held.size(), (size_t)cls_n[3], pend.held.size(), rs.t_built - rs.t0, rs.t_cls - rs.t_built,
+                rs.two_phase ? " (span known after the second collection)" : "", rs.t_done - rs.t0, w2_now_ms() - rs.t0);
         fflush(stderr);
     }
-    joiner.armed = false;
-    if (defer) return HP_OK;
-    return finish();
+    return HP_OK;
+}
+
+int W2Session::wait_collected() {
+    if (!async_inflight) return HP_OK;   // (run() waited itself: everything of the first collection is with the caller already)
+    {
+        std::unique_lock<std::mutex> lk(cm);
+        ccv.wait(lk, [this]() { return collected; });
+        if (collect_rc != HP_OK) { set_error("%s", collect_err.c_str()); return collect_rc; }
+        if (scattered) return HP_OK;
+        scattered = true;
+    }
+    return scatter();
 }
 
 // The second collection (two phases) and the dense-band pass. Runs on the session's helper thread when run() deferred.
@@ -1289,6 +1410,14 @@ int W2Session::late() {
 }
 
 int W2Session::finish() {
+    if (async_inflight) {   // run() did not wait: the helper thread collects and runs late() in one task
+        helper->wait();
+        async_inflight = false;
+        pend.on = false;
+        if (pend.rc != HP_OK) { set_error("%s", pend.err.c_str()); return pend.rc; }
+        g_last_kernel_ms = late_kernel_ms;
+        return HP_OK;
+    }
     if (!pend.on) return HP_OK;
     if (pend.posted) helper->wait(); else pend.rc = late();
     pend.on = false;
@@ -1314,11 +1443,14 @@ W2Session* w2_session_create() { return new W2Session(); }
 void w2_session_destroy(W2Session* s) { delete s; }
 int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int device_id) { return s->prepare(jobs, n, device_id); }
 int w2_session_prepare_blocks(W2Session* s, const hp_block_input* in, size_t n_in, const W2JobIn* jobs, size_t n, int device_id) { return s->prepare_blocks(in, n_in, jobs, n, device_id); }
+int w2_session_layout_blocks(W2Session* s, const hp_block_input* in, size_t n_in, const W2JobIn* jobs, size_t n) { return s->layout_blocks(in, n_in, jobs, n); }
+int w2_session_upload_blocks(W2Session* s, int device_id) { return s->upload_blocks(device_id); }
 void w2_session_prepare_stats(const W2Session* s, double prep[4]) { for (int i = 0; i < 4; ++i) prep[i] = s->prep_ms[i]; }
 int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer) { return s->run(prune_distance, max_ed, out, alleles, defer); }
 int w2_session_finish(W2Session* s) { return s->finish(); }
+int w2_session_collected(W2Session* s) { return s->wait_collected(); }
 // jobs whose results finish() delivers (valid until the next run)
-void w2_session_pending(const W2Session* s, const uint32_t** ids, size_t* n) { *ids = s->pend.on ? s->pend.ids.data() : nullptr; *n = s->pend.on ? s->pend.ids.size() : 0; }
+void w2_session_pending(const W2Session* s, const uint32_t** ids, size_t* n) { *ids = s->pend.on ? s->pend.ids.data() : nullptr; *n = s->pend.on ? s->pend.ids.size() : 0; }   // (after w2_session_collected)
 double w2_session_span_ms(const W2Session* s) { return s->last_span_ms; }
 void w2_session_work(const W2Session* s, uint64_t out[4]) { out[0] = s->work_jobs; out[1] = s->work_read_bytes; out[2] = s->work_node_bytes; out[3] = s->work_updates; }
 

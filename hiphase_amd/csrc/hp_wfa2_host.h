@@ -25,10 +25,16 @@ int w2_session_prepare(W2Session* s, const hp_wfa_job* jobs, size_t n, int devic
 // records of blocks: per-block layout (one reference hull, the block's variant vectors once), reads staged as the caller holds
 // them (HP_SEQ_ASCII / HP_SEQ_BAM4) piece by piece while the previous piece crosses PCIe, expanded on the device
 int w2_session_prepare_blocks(W2Session* s, const hp_block_input* in, size_t n_in, const W2JobIn* jobs, size_t n, int device_id);
+// ... in two halves: the host-only layout (offsets, in-place runs, length order - no device call) and the fill + upload
+int w2_session_layout_blocks(W2Session* s, const hp_block_input* in, size_t n_in, const W2JobIn* jobs, size_t n);
+int w2_session_upload_blocks(W2Session* s, int device_id);
 // prep[0] layout ms, [1] fill + upload ms, [2] total ms, [3] bytes host -> device
 void w2_session_prepare_stats(const W2Session* s, double prep[4]);
 int w2_session_run(W2Session* s, uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer);
 int w2_session_finish(W2Session* s);
+// after a run with defer = 2: waits until the first collection's results are on the host and hands them to the caller's arrays
+// (on the calling thread's pool). Before it returns neither `out` nor w2_session_pending may be read. A no-op otherwise.
+int w2_session_collected(W2Session* s);
 void w2_session_pending(const W2Session* s, const uint32_t** ids, size_t* n);
 void w2_session_work(const W2Session* s, uint64_t out[4]);
 double w2_session_span_ms(const W2Session* s);
