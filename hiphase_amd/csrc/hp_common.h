@@ -191,11 +191,14 @@ public:
 // re-alignment); the bulk of the reads is expanded on the device (hp_wfa2_unpack_kernel).
 inline void decode_bam4(const uint8_t* src, uint64_t first_base, uint64_t n, uint8_t* dst) {
     static const char tab[17] = "=ACMGRSVTWYHKDBN";
-    for (uint64_t k = 0; k < n; ++k) {
-        const uint64_t b = first_base + k;
-        const uint8_t byte = src[b >> 1];
-        dst[k] = (uint8_t)tab[(b & 1u) ? (byte & 15u) : (byte >> 4)];
-    }
+    // two bases per source byte through a 256-entry table (the high nibble is the first base = the low byte of the pair): the
+    // fallbacks of a block set are a few hundred 15-kb reads, base by base that was 5 ms of a host thread
+    static const struct Pairs { uint16_t v[256]; Pairs() { for (int b = 0; b < 256; ++b) v[b] = (uint16_t)((uint8_t)tab[b >> 4] | ((uint16_t)(uint8_t)tab[b & 15] << 8)); } } pairs;
+    uint64_t k = 0;
+    if ((first_base & 1u) && n) { dst[0] = (uint8_t)tab[src[first_base >> 1] & 15u]; k = 1; }
+    const uint8_t* s = src + ((first_base + k) >> 1);
+    for (; k + 2 <= n; k += 2, ++s) { const uint16_t v = pairs.v[*s]; __builtin_memcpy(dst + k, &v, 2); }
+    if (k < n) dst[k] = (uint8_t)tab[*s >> 4];
 }
 
 // hp_local.hip: local_realignment (reference src/read_parsing.rs:121-503) for the records of several blocks in one go - every

@@ -142,7 +142,10 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
         for (uint32_t b = 0; b < NB; ++b) start[b + 1] += start[b];
         for (size_t i = 0; i < n; ++i) order[start[bucket(i)]++] = (uint32_t)i;
     }
-    const uint32_t lds_row_cap = 2048;  // 2 rows x 2048 cells x 4 B = 16 KiB of LDS per wave
+    // rows in LDS up to 2 048 cells (2 rows x 2 048 x 4 B = 16 KiB per wavefront) - but no more than the batch's longest row needs:
+    // beside a resident graph-WFA launch set a compute unit has ~19 KB of LDS left, and the fallbacks of a block set (alleles of a
+    // few hundred bases at most) then run four or more workgroups per compute unit instead of one
+    const uint32_t lds_row_cap = std::min<uint32_t>(2048u, std::max<uint32_t>(64u, (max_short + 1u + 63u) & ~63u));
     const uint64_t row_stride = ((uint64_t)max_short + 1 + 63) & ~63ull;
     const uint32_t slots = (uint32_t)std::min<size_t>(n, (size_t)n_cu * 8);
     DevBuf d_pairs, d_order, d_bytes, d_out, d_scratch;

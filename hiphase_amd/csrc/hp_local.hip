@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -214,7 +215,8 @@ int hp::local_realign_groups(LocalGroup* groups, size_t n_groups, int device_id)
     const double t0 = now_ms();
     // ---- validation; records handed over in the BAM's own 4-bit encoding (HP_SEQ_BAM4) are decoded here, exactly as
     // read.seq().as_bytes() does (read_parsing.rs:151): a few records per block (the fallbacks), or everything in local mode ----
-    struct GroupState { std::vector<hp_local_read> reads; std::vector<std::vector<uint8_t>> seqs; const hp_local_read* rd = nullptr; std::vector<uint8_t> flags; size_t first_item = 0; };
+    // (the decode itself happens per record on the host threads below: a few hundred 15-kb reads per block set were 3 ms of one thread)
+    struct GroupState { std::vector<hp_local_read> reads; std::vector<std::unique_ptr<uint8_t[]>> seqs; const hp_local_read* rd = nullptr; std::vector<uint8_t> flags; size_t first_item = 0; };
     std::vector<GroupState> gs(n_groups);
     size_t n_items = 0;
     for (size_t g = 0; g < n_groups; ++g) {
@@ -230,12 +232,9 @@ int hp::local_realign_groups(LocalGroup* groups, size_t n_groups, int device_id)
             const hp_local_read& R = G.reads[r];
             if (R.seq_format == HP_SEQ_ASCII) continue;
             if (R.seq_format != HP_SEQ_BAM4) { set_error("record %zu: unknown seq_format %u", r, R.seq_format); return HP_ERR_ARG; }
-            if (S.reads.empty()) S.reads.assign(G.reads, G.reads + G.n_reads);
+            if (S.reads.empty()) { S.reads.assign(G.reads, G.reads + G.n_reads); S.seqs.resize(G.n_reads); }
             if (R.seq_len && !R.seq) { set_error("record %zu: null buffer", r); return HP_ERR_ARG; }
-            S.seqs.emplace_back((size_t)R.seq_len + 1);
-            decode_bam4(R.seq, 0, R.seq_len, S.seqs.back().data());
-            S.reads[r].seq = S.seqs.back().data();
-            S.reads[r].seq_format = HP_SEQ_ASCII;
+            S.seqs[r].reset(new uint8_t[(size_t)R.seq_len + 1]);   // (filled by the thread that takes the record)
         }
         if (!S.reads.empty()) S.rd = S.reads.data();
         for (size_t i = 0; i < G.n_variants; ++i) {
@@ -271,6 +270,12 @@ int hp::local_realign_groups(LocalGroup* groups, size_t n_groups, int device_id)
             while (b - a > 1) { const size_t m = (a + b) / 2; if (gs[m].first_item <= it) a = m; else b = m; }
             const size_t g = a, r = it - gs[g].first_item;
             const LocalGroup& G = groups[g];
+            if (!gs[g].seqs.empty() && gs[g].seqs[r]) {   // a record in the BAM's 4-bit codes: decoded here, by the thread that needs it
+                hp_local_read& R = gs[g].reads[r];
+                decode_bam4(R.seq, 0, R.seq_len, gs[g].seqs[r].get());
+                R.seq = gs[g].seqs[r].get();
+                R.seq_format = HP_SEQ_ASCII;
+            }
             W.w.rc = realign_one(gs[g].rd[r], (uint32_t)r, G.variants, G.n_variants, G.alleles + r * G.n_variants, G.quals + r * G.n_variants,
                                  gs[g].flags.data() + r * G.n_variants, W.w);
             W.pend_group.resize(W.w.pending.size(), (uint32_t)g);

@@ -7,13 +7,17 @@
 // cache, pinned staging and host worker pool (all of them per-thread state of the library), so they overlap on the host and
 // on the device:
 //
-//   stage 0 (hp::blockset_layout) validation, overlaps of every record, the job list (host threads only; a stage of its own since round 4:
-//                                 5 ms that used to sit in front of every set's 21-25 ms of PCIe)
-//   stage 1 (hp::blockset_upload) layout of the sequences, reads staged piece by piece as the caller holds them
-//                                 (ASCII or the BAM's own 4-bit codes) while the previous piece crosses PCIe, expanded on the device
-//   stage 2 (hp::blockset_wfa)    device graph build + graph-WFA launch set + allele rows + first collection
-//   stage 3 (hp::blockset_rows)   fallback replay / qualities / collapse on host threads (mostly a WAIT: for the late results of the
-//                                 set's alignment stage - the largest class's tail, the leftovers)
+//   stage 0 (hp::blockset_layout) validation, overlaps of every record, the job list, and the host-only half of the sequence layout
+//                                 (offsets, the runs the copy engines read in place, the length order): host threads only, 10 ms a set,
+//                                 nothing of it in front of the set's turn on the PCIe link
+//   stage 1 (hp::blockset_upload) the tables filled and everything sent: reads in place from hp_host_alloc memory, or staged piece by
+//                                 piece as the caller holds them (ASCII or the BAM's own 4-bit codes) while the previous piece crosses
+//   stage 2 (hp::blockset_wfa)    base expansion + device graph build + the graph-WFA launch set + allele rows, all QUEUED: the stage
+//                                 does not wait for its own results (the session's helper thread collects them and goes on with the
+//                                 late pass), so the next set's launch set follows this one's on the device
+//   stage 3 (hp::blockset_rows)   the first collection handed over (w2_session_collected), fallback replay / qualities / collapse on host
+//                                 threads (mostly a WAIT: for the class kernels, then for the late results of the set's alignment
+//                                 stage - the largest class's tail, the leftovers)
 //   stage 4 (hp::blockset_pack)   the A* batch packed (host threads) and uploaded
 //   stage 5 (hp::blockset_solve)  A* (a latency-bound kernel: the host thread mostly waits), span counts and haplotags, outputs
 //                                 into the caller's buffers
@@ -110,7 +114,7 @@ void hp::Pipeline::stage_loop(int k) {
     // ... what works instead: the alignment stage leaves a share of the wavefront slots empty (hp_wfa2.hip)
     static const int reserve = [] { const char* e = std::getenv("HP_STREAM_RESERVE_PCT"); return e ? std::max(0, std::atoi(e)) : 8; }();
     if (k == 2) g_wfa2_reserve_pct = reserve;
-    g_host_share_div = k == 1 ? 2 : 4;   // (stage 1 copies a gigabyte; the others' parallel regions are short)   // the stages' host threads together: about the process's share of the host   // the three stages' host threads together: about the process's share of the host
+    g_host_share_div = (k == 1 || k == 3) ? 2 : 4;   // (the upload stage fills the tables of a gigabyte of reads, the row stage is the one whose host work sets the period; the others' parallel regions are short)
     for (;;) {
         Slot* s = nullptr;
         {
@@ -228,9 +232,9 @@ int hp::pipeline_wait(Pipeline* s, uint64_t ticket, double* stage_ms, uint64_t* 
     if (rc != HP_OK) set_error("%s", slot->err.c_str());
     if (std::getenv("HP_STREAM_TRACE")) {   // the set's way through the stages, ms since the stream's first submit
         if (s->t_zero == 0.0) s->t_zero = slot->t_submit;
-        fprintf(stderr, "[hp] set %llu: submit %.1f | layout %.1f-%.1f | s1 %.1f-%.1f | s2 %.1f-%.1f | s3 %.1f-%.1f (free blocks %.1f [local re-alignment %.1f], waited %.1f for the late results, their blocks %.1f [%.1f]) | s4 %.1f-%.1f | s5 %.1f-%.1f (A* %.1f of which kernels %.1f, post %.1f)\n", (unsigned long long)ticket,
+        fprintf(stderr, "[hp] set %llu: submit %.1f | layout %.1f-%.1f | s1 %.1f-%.1f | s2 %.1f-%.1f | s3 %.1f-%.1f (first collection in hand after %.1f, free blocks %.1f [local re-alignment %.1f], waited %.1f for the late results, their blocks %.1f [%.1f]) | s4 %.1f-%.1f | s5 %.1f-%.1f (A* %.1f of which kernels %.1f, post %.1f)\n", (unsigned long long)ticket,
                 slot->t_submit - s->t_zero, slot->t_begin[0] - s->t_zero, slot->t_end[0] - s->t_zero, slot->t_begin[1] - s->t_zero, slot->t_end[1] - s->t_zero, slot->t_begin[2] - s->t_zero, slot->t_end[2] - s->t_zero,
-                slot->t_begin[3] - s->t_zero, slot->t_end[3] - s->t_zero, slot->bs.rows_ms[0], slot->bs.rows_ms[3], slot->bs.late_wait_ms, slot->bs.rows_ms[1], slot->bs.rows_ms[2], slot->t_begin[4] - s->t_zero, slot->t_end[4] - s->t_zero, slot->t_begin[5] - s->t_zero, slot->t_end[5] - s->t_zero, slot->bs.ms[3], slot->bs.ms[7], slot->bs.ms[4]);
+                slot->t_begin[3] - s->t_zero, slot->t_end[3] - s->t_zero, slot->bs.rows_ms[4], slot->bs.rows_ms[0] - slot->bs.rows_ms[4], slot->bs.rows_ms[3], slot->bs.late_wait_ms, slot->bs.rows_ms[1], slot->bs.rows_ms[2], slot->t_begin[4] - s->t_zero, slot->t_end[4] - s->t_zero, slot->t_begin[5] - s->t_zero, slot->t_end[5] - s->t_zero, slot->bs.ms[3], slot->bs.ms[7], slot->bs.ms[4]);
     }
     if (stage_ms) {
         const hp_blockset& B = slot->bs;
