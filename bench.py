@@ -484,7 +484,8 @@ def main_path(args, rank, world, local_rank, dist, backend):
             "stage_ms": {"overlaps_layout_host": st_mean[0], "staging_pcie_expand": st_mean[1], "graph_wfa": st_mean[2], "fallback_rows_collapse_host": st_mean[3],
                          "astar_pack_upload": st_mean[4], "astar_solve": st_mean[5], "postprocess_outputs": st_mean[6], "latency_submit_to_done": st_mean[7],
                          "graph_wfa_kernels": st_mean[8], "astar_kernel": st_mean[9], "waiting_between_stages": st_mean[11],
-                         "stage1_wall": st_mean[12], "stage2_wall": st_mean[13], "stage3_wall": st_mean[14], "stage4_wall": st_mean[15]},
+                         "stage1_wall": st_mean[12], "stage2_wall": st_mean[13], "stage3_wall": st_mean[14], "stage4_wall": st_mean[15],
+                         "note": "means over the timed sets, ms. graph_wfa / stage2_wall = the alignment stage's THREAD time: it queues a set's kernels and moves on (what it waits for is the previous set's class kernels); graph_wfa_kernels = the launch set's span on the device (HIP events). fallback_rows_collapse_host / stage3_wall include the wait for the set's first collection and for its late results. overlaps_layout_host = the layout stage incl. the host-only half of the sequence layout; staging_pcie_expand / stage1_wall = tables + DMA"},
             "roofline": {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_gbs", "traffic_frac", "kernel", "kernel_ms", "algorithmic_bytes_per_launch")},
             "kernels": [k_wfa, k_astar],
         }
