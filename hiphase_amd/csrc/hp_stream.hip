@@ -85,8 +85,8 @@ struct hp::Pipeline {
     uint64_t next_in[N_STAGES] = {1, 1, 1, 1, 1, 1};   // the ticket each stage takes next
     double t_zero = 0.0;
     bool quit = false;
-    // stage 3 has two threads (a set's rows mostly WAIT - for the late results of its alignment stage - so two sets share the
-    // stage; they still reach stage 4 in ticket order), the others one
+    // one thread per stage; a seventh only behind the experiment switches HP_STREAM_ROWS_THREADS=2 / HP_STREAM_WFA_THREADS=2 (a second
+    // rows or alignment thread: two sets share the stage and still reach the next one in ticket order - measured equal / slower)
     static constexpr int N_THREADS = 7;
     std::thread th[N_THREADS];
     std::unique_ptr<WorkerPool> pool[N_THREADS];
