@@ -121,7 +121,7 @@ int blockset_pack(hp_blockset* bs);
 // A*, span counts and haplotags, outputs
 int blockset_solve(hp_blockset* bs, hp_block_output* out);
 
-// One device's five-stage pipeline (hp_stream.hip): what hp_blockstream_* and the per-block dispatcher (hp_block.hip) both drive.
+// One device's six-stage pipeline (hp_stream.hip): what hp_blockstream_* and the per-block dispatcher (hp_block.hip) both drive.
 // submit blocks while `depth` sets are in flight; p == nullptr: the parameters the pipeline was created with; sets complete in
 // submission order; wait hands the slot back.
 struct Pipeline;

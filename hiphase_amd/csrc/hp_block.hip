@@ -865,7 +865,7 @@ static int solve_blocks_on_device(size_t n_blocks, const hp_block_input* in, con
 // 40 x threads job slots, T workers, results written in order). With the one-call-site patch of INTEGRATION.md that is T threads
 // sitting in hp_solve_blocks(1, ..., device_id = -1) at once; with the asynchronous entry (hp_block_submit / hp_block_wait) it is
 // the reference's own 40 x T job slots in flight. Either way a request goes into ONE queue. Every visible device has a FEEDER
-// thread and a COMPLETER thread around a five-stage block pipeline (hp_stream.hip, the road bench.py's headline takes): the feeder
+// thread and a COMPLETER thread around a six-stage block pipeline (hp_stream.hip, the road bench.py's headline takes): the feeder
 // waits for a free slot of its pipeline - requests pile up meanwhile, which is all the batching there is: no window, no timer -
 // takes its share of what is queued (everything for its own device + queued / devices of the common queue, a few hundred
 // records at least), merges it into one block set and submits it; the completer waits for the sets in order and hands the

@@ -374,7 +374,7 @@ void hp_blockset_destroy(hp_blockset* bs);
  * + base expansion, [2] graph-WFA stage, [3] fallback / replay / rows (host), [4] A* pack + upload, [5] A* solve, [6] post-processing
  * + outputs, [7] latency submit -> done, [8] graph-WFA kernels (HIP events), [9] A* kernels (HIP events), [10] bytes host -> device,
  * [11] time spent waiting between stages, [12..15] wall time of stage 1 (layout + PCIe) / 2 (graph-WFA) / 3 (rows) / 4 + 5 (A* pack; A* + post). work (8 values, may be NULL): as hp_blockset_work.
- * device_id >= 0: one five-stage pipeline on that device. device_id == -1: one pipeline per visible device behind the same submit /
+ * device_id >= 0: one six-stage pipeline on that device. device_id == -1: one pipeline per visible device behind the same submit /
  * wait - a set goes to the pipeline with the fewest records in flight, submit blocks only while every pipeline holds `depth` sets,
  * the sets of one device complete in order (independent blocks: no exchange between devices; the reference's fan-out is
  * main.rs:332-408, its writers re-order by block index, writers/ordered_vcf_writer.rs:158-170). hp_blockstream_devices: pipelines. */
