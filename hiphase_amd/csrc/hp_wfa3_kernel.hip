@@ -46,6 +46,17 @@ namespace hp {
 #define W3T(i)
 #endif
 
+// A group's ballot as a 32-bit word (G <= 16): the group's bits of the wavefront's ballot - one select and one bit-field extract, and
+// everything computed from it (counts, first set bit, tests) stays 32-bit vector code (the 64-bit shift / and / count it replaces
+// were two passes each).
+template <int G> W2DEV uint32_t w3_gb(bool pred, uint32_t gbase) {
+    const uint64_t b = __ballot(pred);
+    const uint32_t half = (gbase & 32u) ? (uint32_t)(b >> 32) : (uint32_t)b;
+    return __builtin_amdgcn_ubfe(half, gbase & 31u, (uint32_t)G);
+}
+// bits of `m` (a group's ballot) below this lane; lmask = (1 << gl) - 1
+W2DEV uint32_t w3_below(uint32_t m, uint32_t lmask) { return (uint32_t)__popc(m & lmask); }
+
 // Lanes with done == false have matched their first n bytes of their node (at global offset nb + o) against read[pos..] and may match
 // up to maxlen: the group serves them one after the other, G x 32 bytes per pass. The serving lane's node address travels (two
 // dwords), its read offset and what is left. `on`: this group takes part (group-uniform).
@@ -54,9 +65,9 @@ template <int G> W2DEV uint32_t w3_match_rest(const uint8_t* seq, uint64_t nb, c
     constexpr uint32_t LB = W2_MATCH_LANE_BYTES;
     bool pending = on && !done;
     while (__any(pending)) {
-        const uint64_t gb = w2_gballot<G>(pending, gbase);
+        const uint32_t gb = w3_gb<G>(pending, gbase);
         const bool active = gb != 0;
-        const uint32_t L = active ? (uint32_t)__builtin_ctzll(gb) : 0u;
+        const uint32_t L = active ? (uint32_t)__builtin_ctz(gb) : 0u;
         const uint64_t a = nb + o + n;
         const uint32_t alo = w2_gsel<G>((uint32_t)a, gl, L), ahi = w2_gsel<G>((uint32_t)(a >> 32), gl, L);
         const uint32_t sp = w2_gsel<G>((uint32_t)pos + n, gl, L), rem = w2_gsel<G>(maxlen - n, gl, L);
@@ -75,10 +86,10 @@ template <int G> W2DEV uint32_t w3_match_rest(const uint8_t* seq, uint64_t nb, c
                 if (m > rem - off) m = rem - off;
             } else m = 0u;   // beyond the end: acts as a stop
         }
-        const uint64_t stop = w2_gballot<G>(active && m < LB, gbase);
+        const uint32_t stop = w3_gb<G>(active && m < LB, gbase);
         uint32_t got = (uint32_t)G * LB;
         if (stop) {
-            const uint32_t S = (uint32_t)__builtin_ctzll(stop);
+            const uint32_t S = (uint32_t)__builtin_ctz(stop);
             got = S * LB + w2_gsel<G>(m, gl, S);
         }
         if (got > rem) got = rem;
@@ -90,9 +101,6 @@ template <int G> W2DEV uint32_t w3_match_rest(const uint8_t* seq, uint64_t nb, c
     return n;
 }
 
-// bits of `m` (a group's ballot) below this lane
-W2DEV uint32_t w3_below(uint64_t m, uint32_t gl) { return (uint32_t)__popcll(m & ((1ull << gl) - 1ull)); }
-
 template <int G, int W, bool WIDE = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W>::WAVES_PER_SIMD, W3Cfg<W>::WAVES_PER_SIMD))) hp_wfa3_kernel(W2Batch B) {
     using C = W3Cfg<W, WIDE>;
@@ -101,6 +109,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
     constexpr uint32_t NG = 64 / G;
     constexpr uint32_t SL = (uint32_t)C::SLOTS;
     const uint32_t lane = w2_lane(), gid = lane / G, gl = lane % G, gbase = gid * G;
+    const uint32_t lmask = (1u << gl) - 1u;
     unsigned char* R = w2_smem + (size_t)gid * C::BYTES;
     uint2* A = reinterpret_cast<uint2*>(R + C::O_A);                 // [parity * SLOTS + i]: targets (from ip on) and live slots (from 0 on)
     uint32_t* outset = reinterpret_cast<uint32_t*>(R + C::O_MISC);
@@ -192,7 +201,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                             const uint32_t seen = atomicCAS(pend ? B.esc + 1 : B.esc + 3, pend ? pos : 0xFFFFFFFFu, pend ? pos + 1u : 0xFFFFFFFFu);
                             if (pend && seen == pos) pend = false;
                         }
-                        handed_over = w2_gballot<G>(me, gbase) != 0;
+                        handed_over = w3_gb<G>(me, gbase) != 0;
                     }
                     if (!handed_over && gl == 0) { B.status[job] = status; B.out_score[job] = status == W2_ST_NEED_BIG ? (uint64_t)(why | (ed << 8)) : score; B.out_work[(size_t)job * 2] = upd; }
                     if (!handed_over && gl < (uint32_t)W) B.out_sets[(size_t)job * W2_SET_STRIDE + gl] = outset[gl];
@@ -262,9 +271,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                     const bool same = prevkey != 0xFFFFFFFFu && w3_key_node(prevkey) == nn;
                     const int32_t gap = same ? d - w3_key_diag(prevkey) : 3;
                     const bool c1 = valid && gap >= 2, c2 = valid && gap >= 3;
-                    const uint64_t mv = w2_gballot<G>(valid, gbase), m1 = w2_gballot<G>(c1, gbase), m2 = w2_gballot<G>(c2, gbase);
-                    const uint32_t excl = w3_below(mv, gl) + w3_below(m1, gl) + w3_below(m2, gl);
-                    const uint32_t total = (uint32_t)(__popcll(mv) + __popcll(m1) + __popcll(m2));
+                    const uint32_t mv = w3_gb<G>(valid, gbase), m1 = w3_gb<G>(c1, gbase), m2 = w3_gb<G>(c2, gbase);
+                    const uint32_t excl = w3_below(mv, lmask) + w3_below(m1, lmask) + w3_below(m2, lmask);
+                    const uint32_t total = (uint32_t)(__popc(mv) + __popc(m1) + __popc(m2));
                     if (np + total > SL) { over = true; break; }
                     if (valid) {
                         const uint32_t cnt = 1u + (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
@@ -280,7 +289,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                     lastkey = (uint32_t)w2_gmax<G>(valid ? (int32_t)w3_key(nn, d + 1) : 0);   // (keys ascend: the chunk's last target)
                     carry = w2_gsel<G>(key, gl, (uint32_t)G - 1u);   // (0xFFFFFFFF when the chunk is not full: it was the last one)
                 }
-                if (w2_gballot<G>(over, gbase)) { status = W2_ST_NEED_BIG, why = 8u; state = S_JOB; continue; }
+                if (w3_gb<G>(over, gbase)) { status = W2_ST_NEED_BIG, why = 8u; state = S_JOB; continue; }
                 state = S_TILE;
             }
         }
@@ -478,17 +487,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
 #endif
         W3T(6);
         // ---- commit: the slots of nodes below the first child of every node that finished in this tile (a prefix of the tile) ----
+        // (round 5: by KEY, not by node - everything below the smallest target a wave that finished in this tile hands to a child is
+        // final: what could still reach a slot comes from a parent's slot with a smaller key, and those are all in this prefix or
+        // before it, their own children's targets at or beyond that smallest key. 2.7 % fewer tiles than the cut at the child's node.)
         const bool fin = kind == W2_KIND_FINISHED;
-        const uint32_t X = (uint32_t)w2_gmin<G>(fin ? (int32_t)(nd.w & 0xFFFFu) : 0x7FFFFFFF);
-        const bool commit = act && n < X;
+        const int32_t tdl = d + (int32_t)len;   // the diagonal a wave that finished its node hands to the node's children
+        if (w3_gb<G>(fin && (tdl <= -W2_DIAG_LIM || tdl >= W2_DIAG_LIM), gbase)) status = W2_ST_NEED_BIG, why = 8u;
+        const uint32_t X = (uint32_t)w2_gmin<G>(fin ? (int32_t)w3_key(nd.w & 0xFFFFu, tdl) : 0x7FFFFFFF);
+        const bool commit = act && tgt.x < X;
         W3C(4, __popcll(__ballot(has))); W3C(5, __popcll(__ballot(commit))); W3C(10, __popcll(__ballot(act && !commit)));
-        const uint32_t ncommit = (uint32_t)__popcll(w2_gballot<G>(commit, gbase));
+        const uint32_t ncommit = (uint32_t)__popc(w3_gb<G>(commit, gbase));
         const bool live_k = commit && kind != W2_KIND_NONE && !fin, fin_k = commit && fin;
-        const uint64_t ml = w2_gballot<G>(live_k, gbase), mf = w2_gballot<G>(fin_k, gbase);
-        const uint32_t lpos = nl + w3_below(ml, gl), fpos = SL - 1u - (nf + w3_below(mf, gl));
-        const uint32_t nlive = (uint32_t)__popcll(ml), nfin = (uint32_t)__popcll(mf);
+        const uint32_t ml = w3_gb<G>(live_k, gbase), mf = w3_gb<G>(fin_k, gbase);
+        const uint32_t lpos = nl + w3_below(ml, lmask), fpos = SL - 1u - (nf + w3_below(mf, lmask));
+        const uint32_t nlive = (uint32_t)__popc(ml), nfin = (uint32_t)__popc(mf);
         if (run && nl + nlive + nf + nfin > SL) status = W2_ST_NEED_BIG, why = 8u;
-        if (__any(hfull && commit)) { if (w2_gballot<G>(hfull && commit, gbase)) status = W2_ST_NEED_BIG, why = 9u; }
+        if (__any(hfull && commit)) { if (w3_gb<G>(hfull && commit, gbase)) status = W2_ST_NEED_BIG, why = 9u; }
         const bool ok = status == W2_ST_PENDING;
         // ---- this round's slots: offset | kind and the union of the tied sets -------------------------------------------------
         W2Set<W> best;
@@ -513,9 +527,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
         {
             bool pend_ins = commit && ins && ok;
             while (__any(pend_ins)) {
-                const uint64_t im = w2_gballot<G>(pend_ins, gbase);
+                const uint32_t im = w3_gb<G>(pend_ins, gbase);
                 if (im) {   // (group-uniform)
-                    const uint32_t L = (uint32_t)__builtin_ctzll(im);
+                    const uint32_t L = (uint32_t)__builtin_ctz(im);
                     const uint32_t nL = w2_gsel<G>(n, gl, L);
                     const uint32_t liveL = w2_gsel<G>(rec_live ? 1u : 0u, gl, L);
                     const int32_t anchor = (int32_t)w2_gsel<G>(liveL ? crec.y : (uint32_t)d, gl, L);
@@ -548,12 +562,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
-            if (__any(hfull && commit)) { if (w2_gballot<G>(hfull && commit, gbase)) status = W2_ST_NEED_BIG, why = 9u; }
+            if (__any(hfull && commit)) { if (w3_gb<G>(hfull && commit, gbase)) status = W2_ST_NEED_BIG, why = 9u; }
         }
         W3T(8);
         // ---- finals (wfa_graph.rs:576-629): every wave of the last node that consumed node and read ---------------------------
         if (__any(is_final && commit)) {
-            const bool gf = w2_gballot<G>(is_final && commit, gbase) != 0;
+            const bool gf = w3_gb<G>(is_final && commit, gbase) != 0;
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 const uint32_t o = w2_gor<G>(is_final && commit ? best.w[w] : 0u);
@@ -570,43 +584,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
             nl += nlive; nf += nfin; ip += ncommit;
             // ---- finished waves become targets (child, diagonal + node length) of this round, kept sorted ----
             // one target: key K, the finished wave's set `si` (group-uniform)
-            auto insert = [&](const uint32_t K, const uint32_t si) {
-                W3C(9, 1);
-                // behind every target still to come (the wave was the front of the alignment): appended, no look at the list
-                if (ip == np || K > lastkey) {
-                    if (np >= SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
-                    if (gl == 0) A[cbase + np] = make_uint2(K, w3_aux(W3_NONE, si, W3_NONE));
-                    ++np;
-                    lastkey = K;
-                    return;
-                }
+            auto insert_slow = [&](const uint32_t K, const uint32_t si) {
                 W3C(12, 1);
-                const uint32_t rem = np - ip;
-                if (rem <= (uint32_t)G) {
-                    // the whole remainder in one look: a lane per target - read, place, write back one further up behind the new one
-                    const bool in = gl < rem;
-                    const uint32_t i = cbase + ip + gl;
-                    const uint2 v = in ? A[i] : make_uint2(0xFFFFFFFFu, 0u);
-                    const uint64_t lt = w2_gballot<G>(v.x < K, gbase), eq = w2_gballot<G>(v.x == K, gbase);
-                    if (!eq) {
-                        if (np >= SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
-                        const uint32_t pos = (uint32_t)__popcll(lt);
-                        if (in && gl >= pos) A[i + 1u] = v;
-                        if (gl == 0) A[cbase + ip + pos] = make_uint2(K, w3_aux(W3_NONE, si, W3_NONE));
-                        ++np;
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        return;
-                    }
-                    const bool mine = v.x == K;
-                    const uint32_t free0 = ((v.y >> 10) & 0x3FFu) == W3_NONE ? 1u : 0u, free1 = ((v.y >> 20) & 0x3FFu) == W3_NONE ? 1u : 0u;
-                    const uint32_t room = w2_gor<G>(mine ? (free0 | (free1 << 1)) : 0u);
-                    if (room) {   // the target is there: the wave joins it
-                        if (mine) A[i].y = free0 ? ((v.y & ~(0x3FFu << 10)) | (si << 10)) : ((v.y & ~(0x3FFu << 20)) | (si << 20));
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        return;
-                    }
-                    // (a third wave onto one target: the general road below merges two sets)
-                }
+                // (the general road: any list length, a third wave onto one target, no space below the targets)
                 // where K belongs among the targets still to come: [ip, np) is sorted
                 uint32_t pos = ip, hit = 0xFFFFFFFFu;
 #pragma clang loop unroll(disable)
@@ -614,10 +594,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                     W3C(13, 1);
                     const uint32_t i = base + gl;
                     const uint32_t k = i < np ? A[cbase + i].x : 0xFFFFFFFFu;
-                    const uint64_t lt = w2_gballot<G>(k < K, gbase), eq = w2_gballot<G>(k == K, gbase);
-                    const uint32_t nlt = (uint32_t)__popcll(lt);
+                    const uint32_t lt = w3_gb<G>(k < K, gbase), eq = w3_gb<G>(k == K, gbase);
+                    const uint32_t nlt = (uint32_t)__popc(lt);
                     pos += nlt;
-                    if (eq) { hit = base + (uint32_t)__builtin_ctzll(eq); break; }
+                    if (eq) { hit = base + (uint32_t)__builtin_ctz(eq); break; }
                     if (nlt < (uint32_t)G) break;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -656,24 +636,56 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             };
+            // One target K with the finished wave's set `si` (group-uniform), ONE code shape for the three things that happen to it
+            // (round 5; the one-at-a-time roads above cost a quarter of a step because the eight groups of a wavefront took
+            // different ones): the next G targets still to come are looked at once, a lane each;
+            //   * K is there: the wave joins that target (second source);
+            //   * K lies beyond everything listed (the front of the alignment): appended;
+            //   * K belongs among those G: the targets BELOW it move one slot DOWN into the space the consumed targets left
+            //     (ip - 1 >= nl: the live list grows from 0 by at most one entry per consumed target) - a child's target lands
+            //     right behind the tile that finished its parent, so this moves one or two entries where shifting the list's
+            //     tail up moved all of it;
+            // anything else - the key further up a long list, a third wave onto one target, no space below - takes the general road.
+            auto insert = [&](const uint32_t K, const uint32_t si) {
+                W3C(9, 1);
+                const uint32_t rem = np - ip;
+                const bool in = gl < rem;
+                const uint32_t i = cbase + ip + gl;
+                const uint2 v = in ? A[i] : make_uint2(0xFFFFFFFFu, 0u);
+                const bool mine = v.x == K;
+                const uint32_t free0 = ((v.y >> 10) & 0x3FFu) == W3_NONE ? 1u : 0u, free1 = ((v.y >> 20) & 0x3FFu) == W3_NONE ? 1u : 0u;
+                const uint32_t lt = w3_gb<G>(v.x < K, gbase), eq = w3_gb<G>(mine, gbase), jn = w3_gb<G>(mine && (free0 | free1) != 0u, gbase);
+                const uint32_t pos = (uint32_t)__popc(lt);
+                const bool app = rem == 0u || K > lastkey;
+                const bool join = jn != 0u;
+                const bool front = !eq && !app && pos < (uint32_t)G && ip > nl;
+                const bool full = !eq && app && np >= SL;
+                const bool slow = (eq && !join) || (!eq && !app && !front);
+                if (join && mine) A[i].y = free0 ? ((v.y & ~(0x3FFu << 10)) | (si << 10)) : ((v.y & ~(0x3FFu << 20)) | (si << 20));
+                if (front && gl < pos) A[i - 1u] = v;
+                if ((front || (app && !eq && !full)) && gl == 0) A[front ? cbase + ip + pos - 1u : cbase + np] = make_uint2(K, w3_aux(W3_NONE, si, W3_NONE));
+                if (front) --ip;
+                if (app && !eq && !full) { ++np; lastkey = K; }
+                if (full) status = W2_ST_NEED_BIG, why = 8u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (slow) insert_slow(K, si);
+            };
             W3T(11);
-            const uint64_t fm = status == W2_ST_PENDING ? mf : 0ull;
+            const uint32_t fm = status == W2_ST_PENDING ? mf : 0u;
             if (fm) {   // (group-uniform) a wave finished its node in this tile
-                W3C(15, __popcll(fm));
+                W3C(15, __popc(fm));
                 // every finished lane puts the targets of its node's first two children (they come with the node's descriptor) into the
                 // group's scratch itself - no broadcast per lane; then one pass per target
                 const uint32_t nch = nd.z & 0xFFFFu;
                 const bool f2 = fin_k && nch >= 2u;
-                const uint64_t m2 = w2_gballot<G>(f2, gbase);
-                const uint32_t qpos = w3_below(fm, gl) + w3_below(m2, gl);
-                const uint32_t m = (uint32_t)(__popcll(fm) + __popcll(m2));
-                const int32_t tdl = d + (int32_t)len;
+                const uint32_t m2 = w3_gb<G>(f2, gbase);
+                const uint32_t qpos = w3_below(fm, lmask) + w3_below(m2, lmask);
+                const uint32_t m = (uint32_t)(__popc(fm) + __popc(m2));
                 uint2* qbuf = reinterpret_cast<uint2*>(R + C::O_Q);
                 if (fin_k) {
                     qbuf[qpos] = make_uint2(w3_key(nd.w & 0xFFFFu, tdl), fpos);
                     if (f2) qbuf[qpos + 1u] = make_uint2(w3_key(nd.w >> 16, tdl), fpos);
                 }
-                if (w2_gballot<G>(fin_k && (tdl <= -W2_DIAG_LIM || tdl >= W2_DIAG_LIM), gbase)) status = W2_ST_NEED_BIG, why = 8u;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // one pass per target. (Measured and left out, round 4: all of a tile's new targets merged into the list's last G entries
                 // at once by rank - a broadcast read and two ballots per key. A third of the tiles fell outside what that handles -
@@ -688,11 +700,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 // (Kept apart from the common case: a load on the way to it made every step wait for its own set stores - vmcnt
                 // counts loads and stores in one order.)
 #ifndef W3_NO_OVERFLOW_CHILDREN   // (experiment switch: timing without the rare road's loads)
-                uint64_t m3 = w2_gballot<G>(fin_k && nch > 2u, gbase);
+                uint32_t m3 = w3_gb<G>(fin_k && nch > 2u, gbase);
 #pragma clang loop unroll(disable)
                 while (m3 && status == W2_ST_PENDING) {
-                    const uint32_t L = (uint32_t)__builtin_ctzll(m3);
-                    m3 &= m3 - 1ull;
+                    const uint32_t L = (uint32_t)__builtin_ctz(m3);
+                    m3 &= m3 - 1u;
                     const uint32_t qn = w2_gsel<G>(n, gl, L), qz = w2_gsel<G>(nd.z, gl, L);
                     const int32_t td = (int32_t)w2_gsel<G>((uint32_t)tdl, gl, L);
                     const uint32_t si = w2_gsel<G>(fpos, gl, L);

@@ -96,6 +96,9 @@ size_t     hpo_graph_node_edges(const hpo_graph* g, uint64_t node, uint64_t* out
 int        hpo_graph_edit_distance(const hpo_graph* g, const uint8_t* other, size_t other_len,
                                    uint64_t prune_distance, uint64_t shuffle_seed,
                                    uint64_t* score, uint64_t* traversed, size_t* n_traversed);
+/* Independent check of the above (hp_oracle_brute.cpp): every root -> last-node path spelled out, plain Levenshtein against each.
+ * out[0] min distance, [1] paths, [2] optimal paths, [3] union of their nodes (bit per node), [4] some optimal path lies inside wfa_mask. */
+int        hpo_graph_bruteforce(const hpo_graph* g, const uint8_t* other, size_t other_len, uint64_t wfa_mask, uint64_t out[5]);
 /* Full per-job path: graph build + WFA + allele mapping of read_parsing.rs:790-800. */
 int        hpo_wfa_assign(const hp_wfa_job* job, uint64_t prune_distance, uint64_t max_ed,
                           hp_wfa_result* out, uint8_t* alleles);

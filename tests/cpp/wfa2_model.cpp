@@ -22,6 +22,9 @@
 
 using namespace hp;
 
+uint64_t g_x[64];
+int g_opt = 1;   // bit 0: commit by KEY below the smallest target a finished wave hands on (round 5, as the kernel does); 0: by node (round 4)   // step / lane / insert counters of the third-generation model (scripts/w3_explore.cpp prints them)
+
 namespace {
 
 uint64_t g_reason[8];   // which limit sent a job to NEED_BIG (diagnostics)
@@ -307,10 +310,12 @@ int model_wfa3(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t
         bool final_found = false;
         uint64_t round_far = 0;
         uint32_t steps = 0;
+        g_x[0]++; g_x[13] += np;
         while (ip < np) {
             if (++steps > 100000) return W2_ST_INTERNAL;
             const uint32_t tn = std::min<uint32_t>((uint32_t)G, np - ip);
-            struct Res { uint32_t n; int32_t d; bool has; uint32_t E, kind; bool is_final, ins; uint32_t best[W]; uint64_t pos_end; uint32_t len; };
+            g_x[1]++; g_x[2] += tn; if (steps == 1) g_x[12]++;
+            struct Res { uint32_t n; int32_t d; bool has; uint32_t E, kind; bool is_final, ins; uint32_t best[W]; uint64_t pos_end; uint32_t len; int64_t omax; bool inj; };
             std::vector<Res> R(tn);
             uint32_t X = 0xFFFFFFFFu;
             for (uint32_t l = 0; l < tn; ++l) {
@@ -354,6 +359,7 @@ int model_wfa3(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t
                     return o;
                 };
                 const int64_t E = extend(omax);
+                r.omax = omax; r.inj = hinj;
                 auto ties = [&](int64_t o) -> bool { if (o < 0) return false; if (o == omax) return true; return extend(o) == E; };
                 const bool tA = ties(oA), tB = ties(oB), tC = ties(oC), tD = hinj && ties(0);
                 const int64_t pos_end = (int64_t)d + E;
@@ -371,13 +377,15 @@ int model_wfa3(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t
                     r.pos_end = (uint64_t)pos_end;
                 }
                 r.E = (uint32_t)E;
-                if (r.kind == W2_KIND_FINISHED) X = std::min(X, nd.c01 & 0xFFFFu);   // its first child (ids ascend with creation)
+                if (r.kind == W2_KIND_FINISHED) X = std::min(X, (g_opt & 1) ? w3_key(nd.c01 & 0xFFFFu, d + (int32_t)len) : ((nd.c01 & 0xFFFFu) << 19));   // its first child (ids ascend with creation)
             }
             // ---- commit: the slots of nodes below X (a prefix of the tile: targets are sorted) ----
             uint32_t ncommit = 0;
-            while (ncommit < tn && R[ncommit].n < X) ++ncommit;
+            while (ncommit < tn && w3_key(R[ncommit].n, R[ncommit].d) < X) ++ncommit;
             if (ncommit == 0) return W2_ST_INTERNAL;
             const uint32_t ip_next = ip + ncommit;
+            g_x[4] += ncommit; g_x[14] += tn - ncommit; if (X != 0xFFFFFFFFu) g_x[11]++;
+            for (uint32_t l = 0; l < tn; ++l) g_x[3] += R[l].has ? 1 : 0;
             for (uint32_t l = 0; l < ncommit; ++l) {
                 const Res& r = R[l];
                 if (!r.has) continue;
@@ -389,6 +397,7 @@ int model_wfa3(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t
                     if (nl + nf + 1 > (uint32_t)C::SLOTS) { g_reason[2]++; return W2_ST_NEED_BIG; }
                     const uint32_t si = (uint32_t)C::SLOTS - 1u - nf;
                     ++nf;
+                    g_x[5]++; if (r.omax == (int64_t)r.len) g_x[16]++; else if (r.E - r.omax <= 2) g_x[17]++; if (r.len <= 2) g_x[18]++; if (r.inj && r.omax == 0) g_x[19]++;
                     for (int w = 0; w < W; ++w) sets[c][(size_t)si * W + w] = r.best[w];
                     const W2Node nd = b.nodes[r.n];
                     const uint32_t n_child = nd.child & 0xFFFFu;
@@ -400,11 +409,17 @@ int model_wfa3(const Built& b, const uint8_t* ref, const uint8_t* read, uint64_t
                         const uint32_t key = w3_key(cid, td);
                         uint32_t pos = ip_next;
                         while (pos < np && A[c][pos].x < key) ++pos;
+                        g_x[6]++;
+                        if (pos == np) g_x[7]++; else if (A[c][pos].x == key) g_x[8]++; else if (np - ip_next <= (uint32_t)G) g_x[9]++; else g_x[10]++;
+                        if (r.omax == (int64_t)r.len) { if (pos == np) g_x[20]++; else if (A[c][pos].x == key) g_x[21]++; else g_x[22]++; }
+                        if (pos != np && pos - ip_next >= (uint32_t)G) g_x[23]++;   // neither appended nor within the first G targets still to come
+                        if (pos != np && pos - ip_next < (uint32_t)G && A[c][pos].x != key && ip_next - nl < 1) g_x[24]++;
                         if (pos < np && A[c][pos].x == key) {
                             uint32_t& y = A[c][pos].y;
                             if (((y >> 10) & 0x3FFu) == W3_NONE) y = (y & ~(0x3FFu << 10)) | (si << 10);
                             else if (((y >> 20) & 0x3FFu) == W3_NONE) y = (y & ~(0x3FFu << 20)) | (si << 20);
                             else {   // a third wave onto one target (rare): its set and the second one's are merged into a fresh arena entry
+                                g_x[15]++;
                                 if (nl + nf + 1 > (uint32_t)C::SLOTS) { g_reason[2]++; return W2_ST_NEED_BIG; }
                                 const uint32_t sm = (uint32_t)C::SLOTS - 1u - nf;
                                 ++nf;

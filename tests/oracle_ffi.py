@@ -82,6 +82,8 @@ def oracle():
     d.hpo_graph_edit_distance.restype = C.c_int
     d.hpo_graph_edit_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, u64p,
                                           C.c_void_p, C.POINTER(C.c_size_t)]
+    d.hpo_graph_bruteforce.restype = C.c_int
+    d.hpo_graph_bruteforce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
     d.hpo_wfa_assign.restype = C.c_int
     d.hpo_wfa_assign.argtypes = [C.POINTER(_ffi.WfaJob), C.c_uint64, C.c_uint64, C.POINTER(_ffi.WfaResult), C.c_void_p]
     d.hpo_solve_block.restype = C.c_int
@@ -181,6 +183,18 @@ class OracleGraph:
         st = self.d.hpo_graph_edit_distance(self.h, o.ctypes.data if o.size else None, o.size, prune_distance,
                                             shuffle_seed, C.byref(score), trav.ctypes.data, C.byref(n))
         return st, int(score.value), [int(x) for x in trav[:n.value]]
+
+    def bruteforce(self, other, wfa_nodes=()):
+        """(min Levenshtein over every root -> last-node path, paths, optimal paths, union of the optimal paths' nodes, whether
+        some optimal path lies inside wfa_nodes) - hp_oracle_brute.cpp, nothing shared with the wavefront code"""
+        o = np.asarray(list(other), dtype=np.uint8)
+        out = np.zeros(5, np.uint64)
+        mask = 0
+        for n in wfa_nodes:
+            mask |= 1 << n
+        rc = self.d.hpo_graph_bruteforce(self.h, o.ctypes.data if o.size else None, o.size, mask, out.ctypes.data)
+        assert rc == 0, rc
+        return int(out[0]), int(out[1]), int(out[2]), [k for k in range(64) if (int(out[3]) >> k) & 1], bool(out[4])
 
     def __del__(self):
         try:

@@ -105,3 +105,61 @@ def test_synthetic_recovers_haplotype(seed):
         if al[i] in (0, 1) and al[i] != pick:
             wrong += 1
     assert wrong <= 1, (al[:len(chosen)].tolist(), [p for _, p in chosen])
+
+
+def _random_graph(r, max_nodes=12):
+    """A random DAG in creation order the way add_node takes it (wfa_graph.rs:298-331): node 0 has no parents, every later node one
+    to three earlier ones; sequences of 0-5 bases over a 2- or 4-letter alphabet (small alphabets make ties and repeats)."""
+    g = OracleGraph(max_edit_distance=10 ** 6)
+    n = r.randint(2, max_nodes)
+    alpha = b"AC" if r.u01() < 0.4 else b"ACGT"
+    seqs = []
+    for i in range(n):
+        ln = r.randint(0, 5) if r.u01() < 0.8 else r.randint(0, 12)
+        s = bytes(alpha[r.randint(0, len(alpha) - 1)] for _ in range(ln))
+        if i == 0:
+            parents = []
+        else:
+            k = min(i, r.randint(1, 3))
+            parents = sorted({r.randint(max(0, i - 4), i - 1) for _ in range(k)})
+            if r.u01() < 0.7 and (i - 1) not in parents and r.u01() < 0.5:
+                parents.append(i - 1)
+        assert g.add_node(s, parents) == i
+        seqs.append(s)
+    return g, seqs, alpha
+
+
+@pytest.mark.parametrize("chunk", range(10))
+def test_score_equals_path_enumeration(chunk):
+    """Independent of the wavefront code: the score of edit_distance_with_pruning (pruning off) is the minimum, over every path from
+    node 0 to the last node, of the plain Levenshtein distance between the path's spelling and the query (hp_oracle_brute.cpp;
+    reference src/wfa_graph.rs:350-650). The traversed set lies inside the union of the optimal paths' nodes and holds one of them
+    whole. 10 x 1 100 random graphs of up to 12 nodes (the A* side has hpo_bruteforce_mec for the same purpose)."""
+    from wfa_util import _Rng
+    r = _Rng(9000 + chunk)
+    n_cases = ties = 0
+    for _ in range(1100):
+        g, seqs, alpha = _random_graph(r)
+        # the query: a walk through the graph with a few edits, or plain random
+        if r.u01() < 0.7:
+            node, q = 0, bytearray()
+            while True:
+                q += seqs[node]
+                ch = g.node_edges(node)
+                if not ch:
+                    break
+                node = ch[r.randint(0, len(ch) - 1)]
+            q = bytearray(b for b in q if r.u01() > 0.08)
+            for _k in range(r.randint(0, 3)):
+                q.insert(r.randint(0, len(q)), alpha[r.randint(0, len(alpha) - 1)])
+        else:
+            q = bytearray(alpha[r.randint(0, len(alpha) - 1)] for _ in range(r.randint(0, 30)))
+        st, score, nodes = g.edit_distance(bytes(q), shuffle_seed=r.randint(0, 3))
+        assert st == 0
+        best, n_paths, n_opt, union, inside = g.bruteforce(bytes(q), nodes)
+        assert score == best, (chunk, seqs, bytes(q), score, best)
+        assert set(nodes) <= set(union), (chunk, seqs, bytes(q), nodes, union)
+        assert inside, (chunk, seqs, bytes(q), nodes)
+        n_cases += 1
+        ties += n_opt > 1
+    assert n_cases == 1100 and ties > 50
