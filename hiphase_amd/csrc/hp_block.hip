@@ -32,6 +32,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace hp {
@@ -877,9 +878,17 @@ static int solve_blocks_on_device(size_t n_blocks, const hp_block_input* in, con
 namespace {
 
 struct BlocksReq {
+    BlocksReq(size_t n_, const hp_block_input* in_, const hp_block_params& prm_, hp_block_output* out_, int device_) : n(n_), in(in_), prm(prm_), out(out_), device(device_) {}
+    BlocksReq(const BlocksReq&) = delete;
+    BlocksReq& operator=(const BlocksReq&) = delete;
     size_t n; const hp_block_input* in; hp_block_params prm; hp_block_output* out; int device;   // device: -1 = any
-    int rc = HP_OK; std::string err; bool done = false;
+    int rc = HP_OK; std::string err;
     uint64_t records = 0;
+    // completion is signalled per request (round 5): with one condition variable for the dispatcher, every finished set woke every
+    // waiter - 40 x T tickets + T blocking callers - to re-check its flag under the dispatcher's mutex
+    std::mutex m; std::condition_variable cv; bool done = false;
+    void finish() { std::lock_guard<std::mutex> lk(m); done = true; cv.notify_all(); }   // (notified under the lock: the waiter may free the request as soon as it holds it)
+    void wait_done() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&]() { return done; }); }
 };
 bool same_params(const hp_block_params& a, const hp_block_params& b) {
     return a.astar.min_queue_size == b.astar.min_queue_size && a.astar.queue_increment == b.astar.queue_increment &&
@@ -917,10 +926,7 @@ public:
         }
         cv_work_.notify_all();
     }
-    void wait(BlocksReq* const* reqs, size_t n) {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_done_.wait(lk, [&]() { for (size_t i = 0; i < n; ++i) if (!reqs[i]->done) return false; return true; });
-    }
+    void wait(BlocksReq* const* reqs, size_t n) { for (size_t i = 0; i < n; ++i) reqs[i]->wait_done(); }
     std::atomic<int> entering{0};     // callers inside the blocking one-block entry (a lone one runs on its own thread)
 
 private:
@@ -940,6 +946,7 @@ private:
         const char* wenv = std::getenv("HP_QUEUE_WORKERS");
         n_vdev_ = std::max(real_dev_, wenv ? std::max(1, std::atoi(wenv)) : real_dev_);
         dev_q_.resize((size_t)n_vdev_);
+        dev_failed_.assign((size_t)n_vdev_, 0);
         devs_.resize((size_t)n_vdev_);
         for (int v = 0; v < n_vdev_; ++v) {
             devs_[(size_t)v].reset(new Dev());
@@ -970,6 +977,7 @@ private:
                 static const uint32_t depth = [] { const char* e = std::getenv("HP_DISPATCH_DEPTH"); return e ? (uint32_t)std::max(1, std::min(16, std::atoi(e))) : 5u; }();
                 D.pipe = pipeline_create(&dflt, D.device, depth, &rc);
                 if (!D.pipe) { fail_queued(v, rc != HP_OK ? rc : HP_ERR_HIP, hp_last_error()); continue; }
+                { std::lock_guard<std::mutex> lk(m_); dev_failed_[(size_t)v] = 0; }
             }
             // a free slot first: whatever arrives while the pipeline is full joins this set - the batching of a busy device
             pipeline_wait_free(D.pipe);
@@ -1005,12 +1013,15 @@ private:
                 if (rec < max_records()) take_from(any_q_, std::min(max_records(), rec + share));
             }
             if (ms->reqs.empty()) continue;
-            for (BlocksReq* r : ms->reqs) { ms->in.insert(ms->in.end(), r->in, r->in + r->n); ms->out.insert(ms->out.end(), r->out, r->out + r->n); }
-            ms->submit_rc = pipeline_submit(D.pipe, ms->in.size(), ms->in.data(), &ms->prm, ms->out.data(), &ms->ticket);
-            if (ms->submit_rc != HP_OK) ms->submit_err = hp_last_error();
-            {
+            try {   // (the feeder must never take the host process down: a failed host allocation is these callers' status)
+                for (BlocksReq* r : ms->reqs) { ms->in.insert(ms->in.end(), r->in, r->in + r->n); ms->out.insert(ms->out.end(), r->out, r->out + r->n); }
+                ms->submit_rc = pipeline_submit(D.pipe, ms->in.size(), ms->in.data(), &ms->prm, ms->out.data(), &ms->ticket);
+                if (ms->submit_rc != HP_OK) ms->submit_err = hp_last_error();
                 std::lock_guard<std::mutex> lk(D.m);
                 D.inflight.push_back(std::move(ms));
+            } catch (const std::exception& e) {
+                if (ms) for (BlocksReq* r : ms->reqs) { r->rc = HP_ERR_OOM; r->err = std::string("host allocation failed while merging a block set: ") + e.what(); r->finish(); }
+                continue;
             }
             D.cv.notify_all();
         }
@@ -1043,27 +1054,28 @@ private:
                     } catch (const std::exception& e) { r->rc = HP_ERR_OOM; r->err = std::string("host allocation failed: ") + e.what(); }
                 }
             }
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                for (BlocksReq* r : ms->reqs) r->done = true;
-            }
-            cv_done_.notify_all();
+            for (BlocksReq* r : ms->reqs) r->finish();
         }
     }
+    // device v has no pipeline: its own requests fail; the common queue's fail too once NO device has one (with several devices and
+    // every pipeline_create failing, nobody would ever take them and hp_solve_blocks / hp_block_wait would hang)
     void fail_queued(int v, int rc, const char* why) {
         std::vector<BlocksReq*> gone;
         {
             std::lock_guard<std::mutex> lk(m_);
+            dev_failed_[(size_t)v] = 1;
             gone.assign(dev_q_[(size_t)v].begin(), dev_q_[(size_t)v].end());
             dev_q_[(size_t)v].clear();
-            if (n_vdev_ == 1) { gone.insert(gone.end(), any_q_.begin(), any_q_.end()); any_q_.clear(); }
-            for (BlocksReq* r : gone) { r->rc = rc; r->err = why; r->done = true; }
+            bool any_usable = false;
+            for (int w = 0; w < n_vdev_; ++w) any_usable = any_usable || dev_failed_[(size_t)w] == 0;
+            if (!any_usable) { gone.insert(gone.end(), any_q_.begin(), any_q_.end()); any_q_.clear(); }
         }
-        cv_done_.notify_all();
+        for (BlocksReq* r : gone) { r->rc = rc; r->err = why ? why : "no pipeline"; r->finish(); }
         std::this_thread::sleep_for(std::chrono::milliseconds(5));
     }
     std::mutex m_;
-    std::condition_variable cv_work_, cv_done_;
+    std::condition_variable cv_work_;
+    std::vector<char> dev_failed_;   // 1: the device's last pipeline_create failed (it is tried again with the next request); devices that have not tried yet count as usable
     std::deque<BlocksReq*> any_q_;
     std::vector<std::deque<BlocksReq*>> dev_q_;
     std::vector<std::unique_ptr<Dev>> devs_;
@@ -1081,7 +1093,7 @@ int solve_blocks_over_devices(size_t n_blocks, const hp_block_input* in, const h
     uint64_t total = 0;
     for (size_t i = 0; i < n_blocks; ++i) total += in[i].n_records + 1;
     const uint64_t target = std::max<uint64_t>(1, total / ((uint64_t)ndev * 8));
-    struct Chunk { std::vector<uint32_t> ids; std::vector<hp_block_input> ci; std::vector<hp_block_output> co; BlocksReq req; };
+    struct Chunk { std::vector<uint32_t> ids; std::vector<hp_block_input> ci; std::vector<hp_block_output> co; std::unique_ptr<BlocksReq> req; };
     std::vector<std::unique_ptr<Chunk>> chunks;
     {
         uint64_t acc = 0;
@@ -1094,14 +1106,14 @@ int solve_blocks_over_devices(size_t n_blocks, const hp_block_input* in, const h
     std::vector<BlocksReq*> reqs;
     for (auto& c : chunks) {
         for (uint32_t b : c->ids) { c->ci.push_back(in[b]); c->co.push_back(out[b]); }
-        c->req = BlocksReq{c->ids.size(), c->ci.data(), *p, c->co.data(), -1};
-        reqs.push_back(&c->req);
+        c->req.reset(new BlocksReq(c->ids.size(), c->ci.data(), *p, c->co.data(), -1));
+        reqs.push_back(c->req.get());
     }
     D.post(reqs.data(), reqs.size());
     D.wait(reqs.data(), reqs.size());
     int rc = HP_OK;
     for (auto& c : chunks) {
-        if (c->req.rc != HP_OK) { if (rc == HP_OK) { rc = c->req.rc; set_error("%s", c->req.err.c_str()); } continue; }
+        if (c->req->rc != HP_OK) { if (rc == HP_OK) { rc = c->req->rc; set_error("%s", c->req->err.c_str()); } continue; }
         for (size_t k = 0; k < c->ids.size(); ++k) out[c->ids[k]] = c->co[k];
     }
     return rc;
@@ -1129,7 +1141,7 @@ extern "C" int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const 
         D.entering.fetch_sub(1, std::memory_order_acq_rel);
         return rc;
     }
-    BlocksReq r{n_blocks, in, *p, out, device_id};
+    BlocksReq r(n_blocks, in, *p, out, device_id);
     BlocksReq* rp = &r;
     D.post(&rp, 1);
     D.wait(&rp, 1);
@@ -1144,29 +1156,48 @@ extern "C" int hp_solve_blocks(size_t n_blocks, const hp_block_input* in, const 
 // flight on the device side: hp_block_submit queues the block(s) for the pipelines and returns a ticket at once, hp_block_wait
 // returns when the results are in `out`. `in`, everything it points at, and `out` must stay valid until the wait returns;
 // any thread may wait. The ticket is consumed by the wait.
-struct hp_block_ticket_rec { BlocksReq req; };
+// Tickets are ids out of a table, never pointers (round 5): a ticket that was never issued, was waited for already or is waited for
+// twice at once is an HP_ERR_ARG, as with hp_blockstream_wait - not a use-after-free in the caller's process.
+namespace {
+struct TicketTable {
+    std::mutex m;
+    std::unordered_map<uint64_t, std::unique_ptr<BlocksReq>> live;
+    uint64_t next = 1;
+    static TicketTable& get() { static auto* t = new TicketTable(); return *t; }   // never destroyed
+};
+}  // namespace
 
 extern "C" int hp_block_submit(size_t n_blocks, const hp_block_input* in, const hp_block_params* p, hp_block_output* out, int device_id, uint64_t* ticket) {
     if (!ticket || !p || (n_blocks && (!in || !out))) { set_error("null argument"); return HP_ERR_ARG; }
     const int ndev = hp_device_count();
     if (ndev <= 0) { set_error("no HIP device visible; there is no CPU fallback"); return HP_ERR_HIP; }
     if (device_id >= ndev) { set_error("device %d: %d visible", device_id, ndev); return HP_ERR_ARG; }
-    auto* t = new (std::nothrow) hp_block_ticket_rec{BlocksReq{n_blocks, in, *p, out, device_id < 0 ? -1 : device_id}};
-    if (!t) { set_error("host allocation failed"); return HP_ERR_OOM; }
-    *ticket = (uint64_t)(uintptr_t)t;
-    if (n_blocks == 0) { t->req.done = true; return HP_OK; }
-    BlocksReq* rp = &t->req;
-    BlockDispatcher::get().post(&rp, 1);
+    BlocksReq* rp = nullptr;
+    try {
+        std::unique_ptr<BlocksReq> r(new BlocksReq(n_blocks, in, *p, out, device_id < 0 ? -1 : device_id));
+        rp = r.get();
+        if (n_blocks == 0) rp->done = true;
+        TicketTable& T = TicketTable::get();
+        std::lock_guard<std::mutex> lk(T.m);
+        *ticket = T.next++;
+        T.live.emplace(*ticket, std::move(r));
+    } catch (const std::exception&) { set_error("host allocation failed"); return HP_ERR_OOM; }
+    if (n_blocks) BlockDispatcher::get().post(&rp, 1);
     return HP_OK;
 }
 
 extern "C" int hp_block_wait(uint64_t ticket) {
-    auto* t = reinterpret_cast<hp_block_ticket_rec*>((uintptr_t)ticket);
-    if (!t) { set_error("null ticket"); return HP_ERR_ARG; }
-    BlocksReq* rp = &t->req;
-    if (rp->n) BlockDispatcher::get().wait(&rp, 1);
-    const int rc = rp->rc;
-    if (rc != HP_OK) set_error("%s", rp->err.c_str());
-    delete t;
+    std::unique_ptr<BlocksReq> r;
+    {
+        TicketTable& T = TicketTable::get();
+        std::lock_guard<std::mutex> lk(T.m);
+        auto it = T.live.find(ticket);
+        if (it == T.live.end()) { set_error("hp_block_wait: ticket %llu was never issued or has been waited for already", (unsigned long long)ticket); return HP_ERR_ARG; }
+        r = std::move(it->second);   // (the ticket is consumed here: a second wait on it - even one racing this one - finds nothing)
+        T.live.erase(it);
+    }
+    r->wait_done();
+    const int rc = r->rc;
+    if (rc != HP_OK) set_error("%s", r->err.c_str());
     return rc;
 }

@@ -129,13 +129,15 @@ void hp::Pipeline::stage_loop(int k) {
         s->t_begin[k] = st_now_ms();
         if (s->rc == HP_OK && s->n_blocks) {   // (an empty set, or one that failed an earlier stage, just travels on: tickets complete in order)
             int rc = HP_OK;
-            if (k == 0) rc = blockset_layout(&s->bs, s->n_blocks, s->in, &s->prm, device);
-            else if (k == 1) rc = blockset_upload(&s->bs);
-            else if (k == 2) rc = blockset_wfa(&s->bs);
-            else if (k == 3) rc = blockset_rows(&s->bs);
-            else if (k == 4) rc = blockset_pack(&s->bs);
-            else rc = blockset_solve(&s->bs, s->out);
-            if (rc != HP_OK) { s->rc = rc; s->err = hp_last_error(); }
+            try {   // (a stage thread must never take the host process down: a failed host allocation is the set's status, and the set travels on)
+                if (k == 0) rc = blockset_layout(&s->bs, s->n_blocks, s->in, &s->prm, device);
+                else if (k == 1) rc = blockset_upload(&s->bs);
+                else if (k == 2) rc = blockset_wfa(&s->bs);
+                else if (k == 3) rc = blockset_rows(&s->bs);
+                else if (k == 4) rc = blockset_pack(&s->bs);
+                else rc = blockset_solve(&s->bs, s->out);
+                if (rc != HP_OK) { s->rc = rc; s->err = hp_last_error(); }
+            } catch (const std::exception& e) { s->rc = HP_ERR_OOM; s->err = std::string("host allocation failed in a pipeline stage: ") + e.what(); }
         }
         s->t_end[k] = st_now_ms();
         {

@@ -298,7 +298,7 @@ struct W2Session {
     // block mode in two halves: layout_blocks is host only (offsets, the in-place runs, the length order: a block stream runs it in its
     // layout stage, ahead of the set's turn on the PCIe link), upload_blocks fills the tables and sends everything; prepare_blocks = both
     struct BlockLay { int64_t lo = INT64_MAX, hi = INT64_MIN; uint64_t ref_dev = 0, pool_off = 0; uint32_t var_base = 0; };
-    struct Run { uintptr_t lo, hi; uint64_t dev; };
+    struct Run { uintptr_t lo, hi; uint64_t dev; uintptr_t range; };   // range: start of the hp_host_alloc range that owns [lo, hi) - a hull / run never leaves it
     struct Lay {
         bool valid = false, in_place = false;
         size_t n_in = 0;
@@ -585,10 +585,12 @@ int W2Session::layout_blocks(const hp_block_input* in, size_t n_in, const W2JobI
             const uint64_t pb = B.seq_format == HP_SEQ_BAM4 ? ((uint64_t)(rec.read_offset & 1u) + rec.read_len + 1) / 2 : rec.read_len;
             const uintptr_t a = (uintptr_t)p, e = a + pb + 24;   // (the expansion reads 16 bytes at a time, the odd-nibble shift 8 further)
             if (!(a >= r_lo && e <= r_hi) && !(host_range_of(p, &r_lo, &r_hi) && e <= r_hi)) { in_place = false; break; }
-            if (jin[i].block == cur_block && a + (1u << 20) >= hull.back().lo && e <= hull.back().hi + (1u << 20)) {
+            // (several arenas - one per worker thread, and the dispatcher merges blocks of many callers into one set: a hull only grows
+            // inside the pinned range its records lie in, so the DMA below never reads the gap between two allocations)
+            if (jin[i].block == cur_block && hull.back().range == r_lo && a + (1u << 20) >= hull.back().lo && e <= hull.back().hi + (1u << 20)) {
                 hull.back().lo = std::min(hull.back().lo, a); hull.back().hi = std::max(hull.back().hi, e);
-            } else {   // (a record far from its block's others opens a hull of its own)
-                hull.push_back(Run{a, e, 0});
+            } else {   // (a record far from its block's others, or in another arena, opens a hull of its own)
+                hull.push_back(Run{a, e, 0, r_lo});
                 cur_block = jin[i].block;
             }
             payload += pb;
@@ -596,7 +598,7 @@ int W2Session::layout_blocks(const hp_block_input* in, size_t n_in, const W2JobI
         if (in_place) {
             std::sort(hull.begin(), hull.end(), [](const Run& x, const Run& y) { return x.lo < y.lo; });
             for (const Run& h : hull) {
-                if (!runs.empty() && h.lo <= runs.back().hi + 4096) runs.back().hi = std::max(runs.back().hi, h.hi);
+                if (!runs.empty() && h.range == runs.back().range && h.lo <= runs.back().hi + 4096) runs.back().hi = std::max(runs.back().hi, h.hi);
                 else runs.push_back(h);
             }
             uint64_t image = 0;

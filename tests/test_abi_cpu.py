@@ -150,3 +150,12 @@ def test_abi_layout_matches_the_ctypes_bindings(hp_lib):
         assert list(fields) == [f for f, _ in cls._fields_], name
         for f, _ in cls._fields_:
             assert fields[f] == getattr(cls, f).offset, (name, f)
+
+
+def test_block_tickets_are_checked_on_host(hp_lib):
+    """hp_block_wait looks its ticket up in a table before anything else (round 5): a ticket that was never issued is HP_ERR_ARG
+    with a message, whatever its value - the round-4 entry cast it to a pointer and freed it. No GPU needed for that."""
+    import ctypes as C
+    for t in (0, 1, 7, 0xDEADBEEF, 2 ** 64 - 1):
+        assert hp_lib.hp_block_wait(C.c_uint64(t)) == -4
+        assert b"ticket" in hp_lib.hp_last_error()
