@@ -163,7 +163,7 @@ def measured_traffic(kernels, per_unit_key, units):
     """HBM bytes per launch from the PMC counters: only a measurement taken on THIS build of the library counts
     (profiles/round4/traffic.json records the sha256 of the .so it was measured on); otherwise null. `kernels`: names to look
     for, the first one the file holds wins (hp_wfa3_kernel, or hp_wfa2_kernel under HP_WFA_GEN=2)."""
-    for rnd in ("round4", "round3"):
+    for rnd in ("round5", "round4", "round3"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
         except Exception:
@@ -293,6 +293,89 @@ def drop_in_rates(lib, sets, prm, args):
     return res
 
 
+def drop_in_rates_cpp(args):
+    """The per-block entries measured from C++ threads (tests/cpp/dispatch_test, built by __graft_entry__.build()): 64 std::threads,
+    the headline's block-size mix, every block its own call - blocking hp_solve_blocks(1, ..., -1) and hp_block_submit / hp_block_wait
+    with 40 tickets per thread - checked against one hp_solve_blocks call over all blocks. A subprocess after the timed region: the
+    Python loop this replaces submitted 428 ctypes calls per set from ONE interpreter thread and measured the interpreter."""
+    import subprocess
+    binp = os.path.join(ROOT, "tests", "cpp", "dispatch_test")
+    if not os.path.exists(binp):
+        return None
+    try:
+        r = subprocess.run([binp, "64", str(args.total_hets), str(args.max_block_hets), str(max(4, args.steps // 3))], capture_output=True, text=True, timeout=600)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001
+        return {"error": repr(e)}
+    return {"threads": d["threads"], "in_flight_async": 40 * d["threads"], "async_hets_per_s": d["async_hets_per_s"], "blocking_hets_per_s": d["pool_hets_per_s"],
+            "one_call_hets_per_s": d["one_call_hets_per_s"], "blocks": d["blocks"], "passes": d["passes"], "mismatching_blocks": d["mismatching_blocks"], "failed_calls": d["failed_calls"],
+            "measured_by": "tests/cpp/dispatch_test (C++ threads, its own process)",
+            "note": "every block its own call, merged behind the call into sets for the per-device pipeline; async = hp_block_submit / hp_block_wait (the reference's 40 x threads job slots in flight, main.rs:328), blocking = 64 threads in hp_solve_blocks(1, ..., -1); every block compared with one hp_solve_blocks call over all of them"}
+
+
+def pinned_h2d_gbs():
+    """This box's pinned host -> device copy rate, GB/s (scripts/pcie_probe h2d: 1 GiB, best of three), or None"""
+    import subprocess
+    binp = os.path.join(ROOT, "scripts", "pcie_probe")
+    if not os.path.exists(binp):
+        return None
+    try:
+        r = subprocess.run([binp, "h2d"], capture_output=True, text=True, timeout=120)
+        vals = [float(l.split(":")[1].split()[0]) for l in r.stdout.splitlines() if l.startswith("H2D 1 GiB pinned")]
+        return max(vals) if vals else None
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def hifi_mix(lib, args, prm, local_rank, fmt, gen_threads, run, period_of):
+    """Secondary line: the same block mix with HiFi-shaped errors (hp_synth_reads_hifi: per-read rate lognormal around 0.2 %, a tail
+    to 1-2 %, half of the errors homopolymer indels; docs/performance.md:59-82 quotes HG002 HiFi data) - which regime a real run
+    lands in. Its own stream, its own sets, parity of a sample of one set's blocks against the oracle."""
+    import ctypes as C
+    import numpy as np
+    from hiphase_amd import _ffi
+    from hiphase_amd.synth_sets import SynthSet, default_spec
+    n_sets = args.depth + 2
+    sets = [SynthSet(default_spec(lib, hifi=True, seed=args.seed + 500000 + k, total_hets=args.total_hets, max_block_hets=args.max_block_hets,
+                                  coverage=float(args.coverage), seq_format=fmt, threads=gen_threads)) for k in range(n_sets)]
+    if args.host_memory == "pinned":
+        for s_ in sets:
+            try:
+                s_.relocate_pinned()
+            except _ffi.HpError:
+                break
+    outs = [s.outputs() for s in sets]
+    st = C.c_int(0)
+    stream = lib.hp_blockstream_create(C.byref(prm), local_rank, args.depth, C.byref(st))
+    if not stream:
+        return {"error": f"hp_blockstream_create: {st.value}"}
+    try:
+        warm, steps = args.depth + 1, max(8, args.steps // 2)
+        run(0, warm, stream=stream, sets=sets, outs=outs)
+        done_at = []
+        t0 = time.perf_counter()
+        stages, works = run(warm, steps, stream=stream, sets=sets, outs=outs, done_at=done_at)
+        dt = time.perf_counter() - t0
+    finally:
+        lib.hp_blockstream_destroy(stream)
+    hets = sum(sets[k % n_sets].info["hets"] for k in range(warm, warm + steps))
+    stm = np.mean(np.asarray(stages), axis=0)
+    wk = np.mean(np.asarray(works, dtype=np.float64), axis=0)
+    res = {"value": hets / dt, "unit": "hets/s", "steps": steps, "ms_per_step": dt / steps * 1e3, "period_ms": period_of(done_at),
+           "graph_wfa_kernels_ms": stm[8], "astar_kernel_ms": stm[9], "wave_updates_per_read": wk[3] / max(1.0, wk[0]),
+           "records": sets[0].info["records"], "hets_per_step": sets[0].info["hets"],
+           "workload": "the headline's block mix with HiFi-shaped errors: per-read error rate lognormal (median 0.2 %, sigma 0.8, clamp 4 %), half of the errors homopolymer-run indels, no separate noisy class"}
+    if not args.no_cpu:
+        i0 = warm % n_sets
+        s0, gpu_out = sets[i0], outs[i0]
+        oo = s0.outputs()
+        rng = np.random.default_rng(777)
+        h, r, done, cdt = cpu_whole_path(s0, oo, prm, 2.0 * args.cpu_seconds, host_cores(), [int(b) for b in rng.permutation(s0.n)])
+        res["parity"] = {"blocks_compared": len(done), "of": s0.n, "hets_compared": h, "bit_identical": bool(all(gpu_out.equal(oo, b) for b in done))}
+        res["cpu_all_cores_hets_per_s"] = h / cdt
+    return res
+
+
 def host_cores():
     """Hardware threads this process may use (affinity mask, clipped by a cgroup CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -363,7 +446,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
         for kv in args.spec:   # e.g. --spec edit_noise=0.003 --spec frac_sv=0
             key, val = kv.split("=", 1)
             over[key] = float(val)
-        sets.append(SynthSet(default_spec(lib, **dict(dict(seed=args.seed + 1000 * rank + k, total_hets=args.total_hets, max_block_hets=args.max_block_hets,
+        sets.append(SynthSet(default_spec(lib, hifi=args.hifi, **dict(dict(seed=args.seed + 1000 * rank + k, total_hets=args.total_hets, max_block_hets=args.max_block_hets,
                                                            coverage=float(args.coverage), seq_format=fmt, threads=gen_threads), **over))))
     n_pinned = 0
     if args.host_memory == "pinned" and not capture:   # the records' bases gathered in hp_host_alloc memory: read in place, nothing staged
@@ -379,7 +462,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
     if capture and capture.n:
         prm = capture.params[0]   # (the parameters the blocks were captured with)
     st = C.c_int(0)
-    stream = lib.hp_blockstream_create(C.byref(prm), local_rank, args.depth, C.byref(st))
+    stream = stream0 = lib.hp_blockstream_create(C.byref(prm), local_rank, args.depth, C.byref(st))
     if not stream:
         raise SystemExit(f"hp_blockstream_create failed: {st.value} {lib.hp_last_error().decode()}")
 
@@ -389,26 +472,36 @@ def main_path(args, rank, world, local_rank, dist, backend):
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run(first, count):
-        """submits sets first .. first + count - 1 (cycling over the generated ones), at most `depth` in flight; -> per-set stage_ms, work"""
+    def run(first, count, stream=None, sets=sets, outs=outs, done_at=None):
+        """submits sets first .. first + count - 1 (cycling over the generated ones), at most `depth` in flight; -> per-set stage_ms, work.
+        done_at: list that receives the time each set's wait returned (the stream's period = the median interval between them)"""
+        stream = stream or stream0
         pending, stages, works = [], [], []
         ms, work = (C.c_double * 16)(), (C.c_uint64 * 8)()
 
         def wait_oldest():
             _ffi.check(lib.hp_blockstream_wait(stream, pending.pop(0), ms, work))
+            if done_at is not None:
+                done_at.append(time.perf_counter())
             stages.append(list(ms))
             works.append(list(work))
 
         for k in range(first, first + count):
             if len(pending) >= args.depth:
                 wait_oldest()
-            i = k % n_sets
+            i = k % len(sets)
             t = C.c_uint64(0)
             _ffi.check(lib.hp_blockstream_submit(stream, sets[i].n, sets[i].inputs, outs[i].arr, C.byref(t)))
             pending.append(t.value)
         while pending:
             wait_oldest()
         return stages, works
+
+    def period_of(done_at):
+        """median interval between consecutive completions, ms: the stream's steady-state period (ms_per_step = wall / steps also holds
+        the fill and drain of the stages, a fifth of a 20-step run)"""
+        gaps = sorted(b - a for a, b in zip(done_at, done_at[1:]))
+        return 1e3 * gaps[len(gaps) // 2] if gaps else None
 
     # (untimed warm-up: at least depth + 1 sets whatever --warmup says - every slot of the stream must have sized its device and
     # pinned buffers once, hipMalloc / hipHostMalloc wait for the whole device - reported as warmup_run)
@@ -417,7 +510,8 @@ def main_path(args, rank, world, local_rank, dist, backend):
     sync_all()
     cg0, cpu0, th0 = _cgroup_cpu_stat(), time.process_time(), _thread_cpu()
     t0 = time.perf_counter()
-    stages, works = run(warm, args.steps)      # every wait returns with that set's results in the caller's buffers
+    done_at = []
+    stages, works = run(warm, args.steps, done_at=done_at)      # every wait returns with that set's results in the caller's buffers
     sync_all()
     elapsed = time.perf_counter() - t0
     cg1, cpu1, th1 = _cgroup_cpu_stat(), time.process_time(), _thread_cpu()
@@ -459,18 +553,31 @@ def main_path(args, rank, world, local_rank, dist, backend):
                    "achieved": b_astar / (k_astar_ms * 1e-3) / 1e9 if k_astar_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "cells_per_het": work["astar_cells"] / max(1, info["hets"])}
         k_astar["frac"] = k_astar["achieved"] / HBM_PEAK_GBS
+        # (kernel_ms above covers hp_astar_kernel AND the segment-parallel heuristic hp_heur_seg_kernel: so does the traffic - 0.5 + 13.6 KB per het in round 4)
         k_astar["traffic"], k_astar["traffic_source"] = measured_traffic("hp_astar_kernel", "bytes_per_het", info["hets"])
+        t_seg, _src = measured_traffic("hp_heur_seg_kernel", "bytes_per_het", info["hets"])
+        if k_astar["traffic"] is not None and t_seg is not None:
+            k_astar["traffic"] += t_seg
+            k_astar["kernel"] = "hp::hp_astar_kernel + hp::hp_heur_seg_kernel (kernel_ms and traffic: both)"
         for k in (k_wfa, k_astar):   # what actually crossed the HBM interface, next to the algorithmic figure
             k["traffic_gbs"] = k["traffic"] / (k["kernel_ms"] * 1e-3) / 1e9 if k["traffic"] and k["kernel_ms"] > 0 else None
             k["traffic_frac"] = k["traffic_gbs"] / HBM_PEAK_GBS if k["traffic_gbs"] else None
         dom = k_wfa if k_wfa_ms >= k_astar_ms else k_astar
         ms_step = elapsed / args.steps * 1e3
+        period_ms = period_of(done_at)
+        h2d = pinned_h2d_gbs() if (world == 1 and not args.no_pcie_probe) else None   # (a subprocess, after the timed region)
+        pcie = None
+        if h2d and period_ms:
+            need_ms = st_mean[10] / (h2d * 1e9) * 1e3
+            pcie = {"bound": "pcie", "bytes_per_step": st_mean[10], "peak": h2d, "unit": "GB/s", "achieved": st_mean[10] / (period_ms * 1e-3) / 1e9,
+                    "frac": need_ms / period_ms, "floor_ms_per_step": need_ms, "hets_per_s_at_the_floor": info["hets"] / (need_ms * 1e-3),
+                    "note": "what bounds the PATH: a set's bytes over the box's own pinned host-to-device rate (scripts/pcie_probe, measured after the timed region) against the stream's period; `roofline` is the dominant kernel against HBM"}
         out = {
             "metric": "het variants phased/sec, whole path, streamed (every step a new block set: records over PCIe -> graph-WFA -> rows -> A* -> span counts / haplotags)",
             "value": hets_timed * world / elapsed,
             "unit": "hets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_run": warm,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/u64", "data": "synthetic", "host_cpu": host_cpu,
+            "ms_per_step": ms_step, "period_ms": period_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u64", "data": "synthetic", "host_cpu": host_cpu, "roofline_pcie": pcie,
             "config": {"workload": (f"synthetic read-bearing WGS-like block sets, one NEW set per step and GPU through hp_blockstream_* ({args.depth} sets in flight): "
                                     f"{info['blocks']} blocks, {info['hets']} hets (lognormal block sizes, median 15, max {info['max_block_hets']}), "
                                     f"{info['records']} records of {info['read_bases'] / max(1, info['records']):.0f} b mean at {args.coverage}x "
@@ -514,7 +621,9 @@ def main_path(args, rank, world, local_rank, dist, backend):
                                    "note": "hp_blockset_solve over one resident set (inputs in HBM, no overlap between stages)"}
                 out["streamed_over_resident"] = out["value"] / out["resident"]["hets_per_s"]
         if world == 1 and not args.no_drop_in:
-            out["drop_in"] = drop_in_rates(lib, sets, prm, args)
+            out["drop_in"] = drop_in_rates_cpp(args) or drop_in_rates(lib, sets, prm, args)
+        if world == 1 and not args.no_hifi and not capture:
+            out["hifi_mix"] = hifi_mix(lib, args, prm, local_rank, fmt, gen_threads, run, period_of)
         if capture:
             out["data"] = "replay of " + os.path.basename(args.replay)
             out["config"]["workload"] = f"replay of the read-bearing capture {os.path.basename(args.replay)}: {info['blocks']} blocks, {info['hets']} hets, {info['records']} records, streamed again every step"
@@ -565,6 +674,9 @@ def main():
     ap.add_argument("--spec", action="append", default=[], help="path workload: override a field of hp_synth_reads_spec, key=value (repeatable)")
     ap.add_argument("--no-resident", action="store_true", help="path workload: skip the secondary resident (inputs-in-HBM) figure")
     ap.add_argument("--no-drop-in", action="store_true", help="path workload: skip the secondary per-block (drop-in) rates")
+    ap.add_argument("--no-hifi", action="store_true", help="path workload: skip the secondary line on HiFi-shaped errors")
+    ap.add_argument("--no-pcie-probe", action="store_true", help="path workload: skip the pinned host-to-device rate probe (roofline_pcie)")
+    ap.add_argument("--hifi", action="store_true", help="path workload: the HEADLINE run on the HiFi-shaped error model instead of uniform 0.5 %% (for profiling it)")
     ap.add_argument("--seed", type=int, default=20250928, help="path workload: seed of the synthetic block mix (rank r uses seed + r)")
     ap.add_argument("--blocks", type=int, default=6144, help="blocks per GPU (24 resident single-wave workgroups per CU x 256 CUs)")
     ap.add_argument("--hets", type=int, default=5000)

@@ -279,6 +279,7 @@ class SynthReadsSpec(C.Structure):
         ("edit_noise", C.c_double), ("noisy_fraction", C.c_double), ("noisy_noise", C.c_double), ("supplementary_fraction", C.c_double),
         ("seq_format", C.c_uint32),
         ("threads", C.c_uint32),
+        ("hifi_sigma", C.c_double), ("homopolymer_share", C.c_double),
     ]
 
 
@@ -305,6 +306,7 @@ EXPORTS = [
     "hp_blockstream_wait",
     "hp_blockstream_destroy",
     "hp_blockstream_devices",
+    "hp_synth_reads_hifi",
     "hp_block_submit",
     "hp_block_wait",
     "hp_device_count",
@@ -350,6 +352,8 @@ def declare_common(dll):
     dll.hp_synth_block.argtypes = [C.POINTER(SynthSpec)] + [C.c_void_p] * 7
     dll.hp_synth_reads_defaults.restype = None
     dll.hp_synth_reads_defaults.argtypes = [C.POINTER(SynthReadsSpec)]
+    dll.hp_synth_reads_hifi.argtypes = [C.POINTER(SynthReadsSpec)]
+    dll.hp_synth_reads_hifi.restype = None
     dll.hp_synth_reads_create.restype = C.c_void_p
     dll.hp_synth_reads_create.argtypes = [C.POINTER(SynthReadsSpec), C.POINTER(C.c_int)]
     dll.hp_synth_reads_inputs.restype = C.POINTER(BlockInput)

@@ -91,17 +91,33 @@ void cigar_push(std::vector<uint32_t>& c, uint32_t op, uint32_t n) {
 }
 
 // one record: the bases of haplotype `hap` over reference [a, b] with edit noise, and its CIGAR against the reference
-void make_record(const BlockData& B, const std::vector<uint8_t>& carries_alt /* per var, this haplotype */, int64_t a, int64_t b, double noise, Rng& r, RecTmp& out) {
+void make_record(const BlockData& B, const std::vector<uint8_t>& carries_alt /* per var, this haplotype */, int64_t a, int64_t b, double noise, double hp_share, Rng& r, RecTmp& out) {
     out.a = a; out.b = b;
     out.seq.clear(); out.cigar.clear();
     enum { M = 0, I = 1, D = 2 };
     const uint8_t* ref = B.reference.data();
     bool first = true;
+    // HiFi-shaped errors (hp_share > 0): that share of the errors sits on bases that CONTINUE a homopolymer run (a quarter of a random
+    // template's bases) as an insertion / deletion of the run's base; the other bases take the rest, uniform sub / ins / del
+    const double f_run = 0.25, p_run = hp_share > 0 ? noise * hp_share / f_run : noise, p_other = hp_share > 0 ? noise * (1.0 - hp_share) / (1.0 - f_run) : noise;
+    uint8_t prev_base = 0;
     // emits one template base: kind M (consumes a reference base) or I (read only); `last` = the record's final base
     auto emit = [&](uint8_t base, int kind, bool last) {
         const bool clean = first || last;   // a record begins and ends on an aligned base (min / max position, read_parsing.rs:672-685)
         first = false;
-        if (!clean && r.u01() < noise) {
+        const bool in_run = hp_share > 0 && base == prev_base;
+        prev_base = base;
+        if (in_run) {
+            if (!clean && r.u01() < p_run) {
+                if (r.below(2) == 0) { out.seq.push_back(base); cigar_push(out.cigar, kind == M ? M : I, 1); out.seq.push_back(base); cigar_push(out.cigar, I, 1); }   // the run one longer
+                else { if (kind == M) cigar_push(out.cigar, D, 1); }                                                                                                    // ... or one shorter
+                return;
+            }
+            out.seq.push_back(base);
+            cigar_push(out.cigar, kind == M ? M : I, 1);
+            return;
+        }
+        if (!clean && r.u01() < p_other) {
             const uint32_t k = r.below(3);
             if (k == 0) { out.seq.push_back(other_base(base, r)); cigar_push(out.cigar, kind == M ? M : I, 1); }     // substitution
             else if (k == 1) { out.seq.push_back(base); cigar_push(out.cigar, kind == M ? M : I, 1);                      // insertion after it
@@ -215,22 +231,24 @@ void build_block(const hp_synth_reads_spec& S, uint64_t block_index, uint32_t n_
         const int64_t start = (int64_t)(r.u01() * (double)(region_len - len));
         const int64_t a = plain(start), b = std::max(plain(std::min(start + len - 1, region_len - 1)), a);
         const uint32_t hap = r.below(2);
-        const double noise = r.u01() < S.noisy_fraction ? S.noisy_noise : S.edit_noise;
+        double noise = r.u01() < S.noisy_fraction ? S.noisy_noise : S.edit_noise;
+        if (S.hifi_sigma > 0 && noise == S.edit_noise)   // per-read rate: lognormal around the median (one normal draw per read)
+            noise = std::min(0.04, std::max(S.edit_noise / 20.0, S.edit_noise * std::exp(S.hifi_sigma * r.normal())));
         const bool split = r.u01() < S.supplementary_fraction && b - a > 4000;
         if (split) {
             const int64_t mid = plain((a + b) / 2);
             if (mid > a + 10 && mid < b - 10) {
-                recs.emplace_back(); make_record(B, carries[hap], a, mid, noise, r, recs.back()); recs.back().qname = qn;
+                recs.emplace_back(); make_record(B, carries[hap], a, mid, noise, S.homopolymer_share, r, recs.back()); recs.back().qname = qn;
                 // (the second record starts on the next plain base: mid + 1 may sit on a variant's first base)
                 int64_t a2 = mid + 1;
                 while (plain(a2) != a2 || [&] { auto it = std::lower_bound(B.vars.begin(), B.vars.end(), a2, [](const Var& v, int64_t p) { return v.pos < p; }); return it != B.vars.end() && it->pos == a2; }()) ++a2;
-                if (a2 < b) { recs.emplace_back(); make_record(B, carries[hap], a2, b, noise, r, recs.back()); recs.back().qname = qn; }
+                if (a2 < b) { recs.emplace_back(); make_record(B, carries[hap], a2, b, noise, S.homopolymer_share, r, recs.back()); recs.back().qname = qn; }
                 ++qn;
                 continue;
             }
         }
         recs.emplace_back();
-        make_record(B, carries[hap], a, b, noise, r, recs.back());
+        make_record(B, carries[hap], a, b, noise, S.homopolymer_share, r, recs.back());
         recs.back().qname = qn++;
     }
     std::stable_sort(recs.begin(), recs.end(), [](const RecTmp& x, const RecTmp& y) { return x.a < y.a; });   // BAM order
@@ -321,12 +339,24 @@ extern "C" void hp_synth_reads_defaults(hp_synth_reads_spec* s) {
     s->frac_snv = 0.85; s->frac_indel = 0.12; s->frac_sv = 0.01; s->frac_multiallelic = 0.25;   // the rest (.02): tandem repeats
     s->edit_noise = 0.005; s->noisy_fraction = 0.003; s->noisy_noise = 0.05; s->supplementary_fraction = 0.02;
     s->seq_format = HP_SEQ_BAM4; s->threads = 0;
+    s->hifi_sigma = 0.0; s->homopolymer_share = 0.0;
+}
+
+// The same workload with errors shaped like a HiFi run's (docs/performance.md:59-82 quotes HG002 HiFi data): per-read rate lognormal
+// around 0.2 % (sigma 0.8: 2 % of the reads beyond 1 %, 0.2 % beyond 2 %, clamp 4 %), half of the errors homopolymer-run indels;
+// the separate 5 % "noisy" class is switched off - the lognormal's own tail is the noisy tail.
+extern "C" void hp_synth_reads_hifi(hp_synth_reads_spec* s) {
+    if (!s) return;
+    hp_synth_reads_defaults(s);
+    s->edit_noise = 0.002; s->hifi_sigma = 0.8; s->homopolymer_share = 0.5;
+    s->noisy_fraction = 0.0;
 }
 
 extern "C" hp_synth_set* hp_synth_reads_create(const hp_synth_reads_spec* spec, int* status) {
     auto fail = [&](int rc) -> hp_synth_set* { if (status) *status = rc; return nullptr; };
     if (!spec || spec->total_hets < 2 || spec->max_block_hets < 2 || !(spec->coverage > 0) || !(spec->read_mean >= 3000) || !(spec->het_spacing > 0) ||
-        spec->frac_snv + spec->frac_indel + spec->frac_sv > 1.0 + 1e-9 || (spec->seq_format != HP_SEQ_ASCII && spec->seq_format != HP_SEQ_BAM4))
+        spec->frac_snv + spec->frac_indel + spec->frac_sv > 1.0 + 1e-9 || (spec->seq_format != HP_SEQ_ASCII && spec->seq_format != HP_SEQ_BAM4) ||
+        !(spec->hifi_sigma >= 0) || !(spec->homopolymer_share >= 0 && spec->homopolymer_share <= 1.0))
         return fail(HP_ERR_ARG);
     auto set = std::unique_ptr<hp_synth_set>(new hp_synth_set());
     set->spec = *spec;

@@ -6,10 +6,12 @@ import ctypes as C
 from . import _ffi
 
 
-def default_spec(dll=None, **kw):
+def default_spec(dll=None, hifi=False, **kw):
+    """The bench workload's spec (uniform 0.5 % edit noise); hifi=True: HiFi-shaped errors (hp_synth_reads_hifi: per-read rate
+    lognormal around 0.2 %, half of the errors homopolymer indels)."""
     dll = dll or _ffi.lib()
     s = _ffi.SynthReadsSpec()
-    dll.hp_synth_reads_defaults(C.byref(s))
+    (dll.hp_synth_reads_hifi if hifi else dll.hp_synth_reads_defaults)(C.byref(s))
     for k, v in kw.items():
         if not hasattr(s, k):
             raise AttributeError(k)

@@ -469,9 +469,16 @@ typedef struct hp_synth_reads_spec {
     double   edit_noise, noisy_fraction, noisy_noise, supplementary_fraction;
     uint32_t seq_format;        /* HP_SEQ_* of the records' bases */
     uint32_t threads;           /* host threads for the generation; 0 = up to 32 */
+    /* HiFi-shaped errors (round 5). hifi_sigma > 0: a record's error rate is drawn per READ from a lognormal with median
+     * `edit_noise` and this sigma (clamped to [edit_noise / 20, 0.04]): median 0.2 %, sigma 0.8 puts 2 % of the reads beyond 1 %
+     * and 0.2 % beyond 2 % - the shape of a HiFi run's per-read accuracy (median Q27-30, a tail at Q20). homopolymer_share > 0:
+     * that share of the errors are insertions / deletions of the run's base inside homopolymer runs (the dominant HiFi error),
+     * the rest uniform substitutions / insertions / deletions as before. Both 0 (hp_synth_reads_defaults): the uniform model. */
+    double   hifi_sigma, homopolymer_share;
 } hp_synth_reads_spec;
 typedef struct hp_synth_set hp_synth_set;
 void hp_synth_reads_defaults(hp_synth_reads_spec* s);   /* the bench workload: 60 000 hets, 30x, 15 kb reads, 0.5 % edit noise, BAM 4-bit */
+void hp_synth_reads_hifi(hp_synth_reads_spec* s);       /* the same with HiFi-shaped errors: per-read rate lognormal (median 0.2 %, sigma 0.8), half of the errors homopolymer indels, no separate noisy class */
 hp_synth_set* hp_synth_reads_create(const hp_synth_reads_spec* s, int* status);
 const hp_block_input* hp_synth_reads_inputs(const hp_synth_set* s, size_t* n_blocks);
 /* out[0] blocks, [1] hets, [2] records, [3] read bases, [4] read names, [5] bytes of reads + references as handed over, [6] largest block (hets) */

@@ -5,7 +5,8 @@
 #include <cstring>
 #include <thread>
 #include <vector>
-int main() {
+int main(int argc, char** argv) {
+    const bool only_h2d = argc > 1 && !strcmp(argv[1], "h2d");   // bench.py: just the pinned host -> device rate
     const size_t n = 1ull << 30;
     void *h = nullptr, *d = nullptr;
     hipHostMalloc(&h, n, hipHostMallocDefault); hipMalloc(&d, n);
@@ -17,6 +18,7 @@ int main() {
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         printf("H2D 1 GiB pinned: %.1f GB/s\n", n / dt / 1e9);
     }
+    if (only_h2d) return 0;
     for (size_t piece : {1ull << 22, 1ull << 24, 48ull << 20}) {
         auto t0 = std::chrono::steady_clock::now();
         for (size_t o = 0; o + piece <= n; o += piece) hipMemcpyAsync((char*)d + o, (char*)h + o, piece, hipMemcpyHostToDevice, s);

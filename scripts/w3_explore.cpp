@@ -29,12 +29,14 @@ int w4m_wfa_assign(const hp_wfa_job* job, uint64_t prune_distance, uint64_t max_
 int main(int argc, char** argv) {
     hp_synth_reads_spec s;
     hp_synth_reads_defaults(&s);
+    const uint32_t th_ = argc > 1 ? (uint32_t)atoi(argv[1]) : 2000;
     s.total_hets = argc > 1 ? (uint32_t)atoi(argv[1]) : 2000;
-    if (argc > 2) s.edit_noise = atof(argv[2]);
+    if (argc > 2 && atof(argv[2]) < 0) hp_synth_reads_hifi(&s);   // negative noise: the HiFi-shaped model
+    else if (argc > 2) s.edit_noise = atof(argv[2]);
     const int which = argc > 3 ? atoi(argv[3]) : 3;
     if (argc > 4) g_opt = atoi(argv[4]);
     if (argc > 5) g_spec_len = atoi(argv[5]);
-    s.max_block_hets = 600;
+    s.total_hets = th_; s.max_block_hets = 600;
     int st = 0;
     hp_synth_set* set = hp_synth_reads_create(&s, &st);
     if (!set) { printf("create failed %d\n", st); return 1; }

@@ -32,29 +32,3 @@ def load_golden(name):
     import json
     with open(os.path.join(ROOT, "tests", "golden", name)) as f:
         return json.load(f)
-
-
-# ---- the worker-pool RATE measurement runs before this process touches the GPU -----------------------------------------------------
-# tests/test_coalesce_gpu.py::test_worker_pool_rate_from_cpp asserts a speed-up (64 std::threads through hp_astar_solve, merged vs one
-# launch per call). Measured from inside a pytest process that has initialised HIP, the binary shares the GPU with that process's
-# idle queues and context (4.4 x instead of 8-10 x, round 3 - when the bar was lowered to 3 x). So the binary runs HERE, once the
-# collection is known and before any test has run: nothing of this process is on the device yet. The test only reads the result.
-WORKER_POOL_RATE = {}
-
-
-def pytest_collection_finish(session):
-    if not any(item.name.startswith("test_worker_pool_rate_from_cpp") for item in session.items):
-        return
-    import subprocess
-    try:
-        import __graft_entry__ as g
-        g.build()
-        binp = os.path.join(ROOT, "tests", "cpp", "coalesce_test")
-        # bit-identity is asserted by every run; the rate is a property of the machine's moment too: best of up to three runs at 6 x
-        for attempt in range(3):
-            r = subprocess.run([binp, "64", "12", "6"], capture_output=True, text=True, timeout=600)
-            WORKER_POOL_RATE.update(returncode=r.returncode, stdout=r.stdout, stderr=r.stderr, attempts=attempt + 1)
-            if r.returncode in (0, 3):   # (3: no GPU - the test is skipped by its marker on such a box anyway)
-                break
-    except Exception as e:   # noqa: BLE001 - the test reports it
-        WORKER_POOL_RATE.update(returncode=-1, stdout="", stderr=repr(e), attempts=0)
