@@ -301,3 +301,38 @@ def test_reads_around_max_edit_distance_vs_oracle(noise, max_ed, monkeypatch):
     assert [b for b in range(s.n) if not got.equal(exp, b)] == []
     n_local, n_global = sum(got.arr[b].local_aligned for b in range(s.n)), sum(got.arr[b].global_aligned for b in range(s.n))
     assert n_local > 10 and n_global > 10
+
+
+@pytest.mark.timeout(1200)
+def test_hifi_shaped_sets_vs_oracle():
+    """Block sets with HiFi-shaped errors (hp_synth_reads_hifi: per-read rate lognormal around 0.2 %, a tail of reads at 1-4 %, half of
+    the errors homopolymer-run indels - round 5) through the stream, in the records' BAM 4-bit codes: every field
+    of every block identical to the oracle's hpo_solve_block (reference src/read_parsing.rs:520-867, src/astar_phaser.rs). The long
+    homopolymer indels are where a read's alignment has equally good placements on neighbouring diagonals - the tie rules of
+    src/wfa_graph.rs:476-510 at work."""
+    lib = _ffi.lib()
+    prm = _params(2, 1000, 3, None, True)
+    sets = [SynthSet(default_spec(lib, hifi=True, total_hets=2500 + 400 * k, max_block_hets=700, seed=900 + k, seq_format=_ffi.SEQ_BAM4)) for k in range(3)]
+    sets.append(SynthSet(default_spec(lib, hifi=True, total_hets=1500, max_block_hets=300, seed=950, seq_format=_ffi.SEQ_ASCII, hifi_sigma=1.2, edit_noise=0.004)))   # a fatter tail
+    st = C.c_int(0)
+    stream = lib.hp_blockstream_create(C.byref(prm), 0, 2, C.byref(st))
+    assert stream
+    try:
+        outs, tickets = [s.outputs() for s in sets], []
+        for s, o in zip(sets, outs):
+            if len(tickets) == 2:
+                _ffi.check(lib.hp_blockstream_wait(stream, tickets.pop(0), None, None))
+            t = C.c_uint64(0)
+            _ffi.check(lib.hp_blockstream_submit(stream, s.n, s.inputs, o.arr, C.byref(t)))
+            tickets.append(t.value)
+        for t in tickets:
+            _ffi.check(lib.hp_blockstream_wait(stream, t, None, None))
+    finally:
+        lib.hp_blockstream_destroy(stream)
+    n_blocks = fell_back = 0
+    for s, o in zip(sets, outs):
+        exp = oracle_outputs(s, prm)
+        assert [b for b in range(s.n) if not o.equal(exp, b)] == []
+        n_blocks += s.n
+        fell_back += sum(o.arr[b].local_aligned for b in range(s.n))
+    assert n_blocks > 40

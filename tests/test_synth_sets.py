@@ -75,3 +75,57 @@ def test_workload_exercises_the_path_and_recovers_the_planted_phase():
                 total += sel.sum()
             start = cut
     assert total > 200 and wrong <= 0.02 * total
+
+
+def _edits_per_base(sset):
+    """per record: (I + D + X-free estimate) - insertions and deletions of the record's CIGAR per read base, and the rate of all records"""
+    rates = []
+    for b in range(sset.n):
+        B = sset.inputs[b]
+        for r in range(B.n_records):
+            rec = B.records[r]
+            cg = np.ctypeslib.as_array(rec.local.contents.cigar, (rec.local.contents.n_cigar,))
+            ops = cg & 15
+            rates.append(float(((ops == 1) | (ops == 2)).sum()) / max(1, rec.read_len))
+    return np.asarray(rates)
+
+
+def test_hifi_shaped_error_model():
+    """hp_synth_reads_hifi (round 5): deterministic, the uniform model untouched by the new fields, the per-read
+    rates spread like a HiFi run's (most reads cleaner than the uniform 0.5 %, a tail beyond 1 %), indels concentrated in
+    homopolymer runs, and the whole path still recovers the planted phase on the oracle."""
+    d = oracle()
+    kw = dict(total_hets=300, max_block_hets=80, seed=11)
+    uni = SynthSet(default_spec(d, **kw), d)
+    uni2 = SynthSet(default_spec(d, hifi_sigma=0.0, homopolymer_share=0.0, **kw), d)
+    assert uni.info == uni2.info
+    h1 = SynthSet(default_spec(d, hifi=True, **kw), d)
+    h2 = SynthSet(default_spec(d, hifi=True, threads=1, **kw), d)
+    assert h1.info == h2.info and abs(h1.info["records"] - uni.info["records"]) < 0.05 * uni.info["records"]
+    ru, rh = _edits_per_base(uni), _edits_per_base(h1)
+    # uniform 0.5 %: two thirds of the events are indel runs of the CIGAR -> ~0.3 % per base, narrow; HiFi: median well below, wide
+    assert 0.002 < np.median(ru) < 0.0045
+    assert np.median(rh) < 0.6 * np.median(ru)
+    assert np.quantile(rh, 0.99) > 3.0 * np.median(rh)
+    # homopolymer indels: an inserted base repeats its neighbour far more often than a uniform insertion does (1 in 4)
+    def same_as_neighbour(sset):
+        same = tot = 0
+        for b in range(min(sset.n, 6)):
+            B = sset.inputs[b]
+            for r in range(0, B.n_records, 3):
+                rec = B.records[r]
+                packed = np.ctypeslib.as_array(rec.read_align, ((rec.read_offset + rec.read_len + 1) // 2,))
+                codes = np.stack([packed >> 4, packed & 15], axis=1).reshape(-1)[rec.read_offset:rec.read_offset + rec.read_len]
+                cg = np.ctypeslib.as_array(rec.local.contents.cigar, (rec.local.contents.n_cigar,))
+                pos = 0
+                for op, ln in zip(cg & 15, cg >> 4):
+                    if op == 1 and ln == 1 and 0 < pos < rec.read_len:
+                        same += int(codes[pos] == codes[pos - 1]); tot += 1
+                    if op in (0, 1):
+                        pos += int(ln)
+        return same / max(1, tot), tot
+    fu, nu = same_as_neighbour(uni)
+    fh, nh = same_as_neighbour(h1)
+    assert nu > 50 and nh > 30 and fh > fu + 0.2, (fu, nu, fh, nh)
+    out = solve_all(d, h1)
+    assert sum(out.arr[b].global_aligned for b in range(h1.n)) > 0.9 * h1.info["records"] * 0.9
