@@ -172,8 +172,12 @@ hp::Pipeline* hp::pipeline_create(const hp_block_params* p, int device_id, uint3
     // in flight only adds contention.
     const char* wt = std::getenv("HP_STREAM_WFA_THREADS");
     const char* rt = std::getenv("HP_STREAM_ROWS_THREADS");
+    // HP_STREAM_SOLVE_THREADS=2 (round 5): a second thread for the last stage - A* is a latency chain, not issue (3e8 busy cycles per set
+    // against the alignment kernels' 2.3e9), so set k + 1's chain can run beside set k's
+    const char* sv = std::getenv("HP_STREAM_SOLVE_THREADS");
     int n_threads = Pipeline::N_THREADS;
-    if (rt && std::atoi(rt) >= 2) s->extra_stage = 3;
+    if (sv && std::atoi(sv) >= 2) s->extra_stage = 5;
+    else if (rt && std::atoi(rt) >= 2) s->extra_stage = 3;
     else if (!(wt && std::atoi(wt) >= 2)) n_threads = Pipeline::N_STAGES;
     g_pipelines.fetch_add(1);
     for (int k = 0; k < n_threads; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_thread(k); });

@@ -316,39 +316,47 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
         const uint32_t n = w3_key_node(tgt.x);
         const int32_t d = act ? w3_key_diag(tgt.x) : 0;
         const uint32_t back = tgt.y & 0x3FFu, src0 = (tgt.y >> 10) & 0x3FFu, src1 = (tgt.y >> 20) & 0x3FFu;
-        // the node of this lane's target: 16 bytes from HBM (L2-resident)
-        uint4 nd = make_uint4(0, 0, 0, 0);
-        if (act) nd = *reinterpret_cast<const uint4*>(gnode + n);
-        // the node's capped-diagonal record (neighbouring nodes share a line)
-        uint4 crec = make_uint4(0, 0, 0, 0);
-        if (act) crec = *reinterpret_cast<const uint4*>(gs + C::SET_DWORDS + 4u * n);
+        // The node of this lane's target (16 bytes from HBM, L2-resident), its capped-diagonal record (neighbouring nodes share a line),
+        // the three candidate slots and the candidates' sets: every load is issued UNCONDITIONALLY on an address that is valid whatever
+        // the lane holds (node 0, slot 0 for a lane without a target) and the results are masked - round 5: as `if (act) load` chains the
+        // compiler built nested exec-mask regions with a wait after each of the three list reads (three serialised trips to the LDS
+        // and a dozen branches per tile).
+        const uint4 nd = *reinterpret_cast<const uint4*>(gnode + n);
+        const uint4 crec = *reinterpret_cast<const uint4*>(gs + C::SET_DWORDS + 4u * n);
         // ---- candidates from the previous round: the three live slots from the emitter on ----
         int32_t oA = -1, oB = -1, oC = -1;
         int32_t sA = -1, sB = -1, sC = -1;   // their slots (= set indices)
-        if (act && back != W3_NONE) {
+        {
+            const bool cand = act && back != W3_NONE;
+            uint2 e[3];
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) e[k] = A[pbase + ((cand && back + k < nl_prev) ? back + k : 0u)];
 #pragma unroll
             for (uint32_t k = 0; k < 3; ++k) {
                 const uint32_t j = back + k;
-                if (j < nl_prev) {
-                    const uint2 e = A[pbase + j];
-                    const int32_t rel = (int32_t)e.x - (int32_t)tgt.x;   // same node: the difference of the diagonals (keys are node << 19 | diagonal + bias)
-                    const uint32_t kd = e.y & 7u;
-                    if (rel == 1) { if (kd & 1u) { oA = (int32_t)(e.y >> 3) + 1; sA = (int32_t)j; } }
-                    else if (rel == 0) { if (kd == W2_KIND_INTERIOR_READ) { oB = (int32_t)(e.y >> 3) + 1; sB = (int32_t)j; } }
-                    else if (rel == -1) { if (kd == W2_KIND_INTERIOR_READ || kd == W2_KIND_END_LAST) { oC = (int32_t)(e.y >> 3); sC = (int32_t)j; } }
-                }
+                const bool ok = cand && j < nl_prev;
+                const int32_t rel = (int32_t)e[k].x - (int32_t)tgt.x;   // same node: the difference of the diagonals (keys are node << 19 | diagonal + bias)
+                const uint32_t kd = e[k].y & 7u;
+                const int32_t off = (int32_t)(e[k].y >> 3);
+                const bool a = ok && rel == 1 && (kd & 1u) != 0u;
+                const bool b = ok && rel == 0 && kd == W2_KIND_INTERIOR_READ;
+                const bool c_ = ok && rel == -1 && (kd == W2_KIND_INTERIOR_READ || kd == W2_KIND_END_LAST);
+                oA = a ? off + 1 : oA; sA = a ? (int32_t)j : sA;
+                oB = b ? off + 1 : oB; sB = b ? (int32_t)j : sB;
+                oC = c_ ? off : oC; sC = c_ ? (int32_t)j : sC;
             }
         }
-        const W2Set<W> qA = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sA, 0)) * W, sA >= 0);
-        const W2Set<W> qB = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sB, 0)) * W, sB >= 0);
-        const W2Set<W> qC = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sC, 0)) * W, sC >= 0);
+        const W2Set<W> qA = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sA, 0)) * W, true);
+        const W2Set<W> qB = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sB, 0)) * W, true);
+        const W2Set<W> qC = w2_ldset<W>(gs + (size_t)(pbase + (uint32_t)max(sC, 0)) * W, true);
         // ---- waves that finished a parent THIS round (offset 0; wfa_graph.rs:527-553), and the start wave ----
         const bool hinj = act && ((tgt.y & W3_START) != 0u || src0 != W3_NONE);
-        W2Set<W> qD = w2_ldset<W>(gs + (size_t)(cbase + (src0 != W3_NONE ? src0 : 0u)) * W, act && src0 != W3_NONE);
+        W2Set<W> qD = w2_ldset<W>(gs + (size_t)(cbase + (src0 != W3_NONE ? src0 : 0u)) * W, true);
         {
-            const W2Set<W> t = w2_ldset<W>(gs + (size_t)(cbase + (src1 != W3_NONE ? src1 : 0u)) * W, act && src1 != W3_NONE);
+            const W2Set<W> t = w2_ldset<W>(gs + (size_t)(cbase + (src1 != W3_NONE ? src1 : 0u)) * W, true);
+            const bool h0 = act && src0 != W3_NONE, h1 = act && src1 != W3_NONE;
 #pragma unroll
-            for (int w = 0; w < W; ++w) qD.w[w] |= t.w[w];
+            for (int w = 0; w < W; ++w) qD.w[w] = (h0 ? qD.w[w] : 0u) | (h1 ? t.w[w] : 0u);
         }
         W3T(2);
         const uint32_t len = nd.y & ~W2_IS_REF;
@@ -377,11 +385,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
 #if W3_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" :: "v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));   // (the previous step's look-ahead loads have landed long since: nothing waits here)
 #endif
-        const W2Pre pm = w2_pre(na_, ra, room > 0);
-        const W2Pre8 pA = w2_pre8(nseq + (nA ? oA : 0), readp + (nA ? d + oA : 0), nA);
-        const W2Pre8 pB = w2_pre8(nseq + (nB ? oB : 0), readp + (nB ? d + oB : 0), nB);
-        const W2Pre8 pC = w2_pre8(nseq + (nC ? oC : 0), readp + (nC ? d + oC : 0), nC);
-        const W2Pre8 pD = w2_pre8(nseq, readp + (nD ? d : 0), nD);
+        // (unconditional loads on addresses that are valid for every lane - the start of the node / of the read for a lane that needs
+        // none; seq[] ends in 256 bytes of padding - and results that are only looked at under the lane's own flag: no exec-mask region each)
+        const W2Pre pm = w2_pre(na_, ra, true);
+        const W2Pre8 pA = w2_pre8(nseq + (nA ? oA : 0), readp + (nA ? d + oA : 0), true);
+        const W2Pre8 pB = w2_pre8(nseq + (nB ? oB : 0), readp + (nB ? d + oB : 0), true);
+        const W2Pre8 pC = w2_pre8(nseq + (nC ? oC : 0), readp + (nC ? d + oC : 0), true);
+        const W2Pre8 pD = w2_pre8(nseq, readp + (nD ? d : 0), true);
         W3T(3);
         uint32_t E;
         {
