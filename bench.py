@@ -296,7 +296,7 @@ def drop_in_rates(lib, sets, prm, args):
 def drop_in_rates_cpp(args):
     """The per-block entries measured from C++ threads (tests/cpp/dispatch_test, built by __graft_entry__.build()): 64 std::threads,
     the headline's block-size mix, every block its own call - blocking hp_solve_blocks(1, ..., -1) and hp_block_submit / hp_block_wait
-    with 40 tickets per thread - checked against one hp_solve_blocks call over all blocks. A subprocess after the timed region: the
+    with 40 tickets per thread - checked against one hp_solve_blocks call over all blocks. A subprocess BEFORE this process touches the GPU: the
     Python loop this replaces submitted 428 ctypes calls per set from ONE interpreter thread and measured the interpreter."""
     import subprocess
     binp = os.path.join(ROOT, "tests", "cpp", "dispatch_test")
@@ -427,6 +427,12 @@ def main_path(args, rank, world, local_rank, dist, backend):
     from hiphase_amd.synth_sets import SynthSet, default_spec
     lib = _ffi.lib()
     fmt = _ffi.SEQ_BAM4 if args.seq_format == "bam4" else _ffi.SEQ_ASCII
+    # Two measurements by other PROCESSES, taken before this one creates its HIP context and queues (a second process on a GPU whose
+    # hardware queues this one already holds is time-sliced against them: the same dispatch_test read 17 k instead of 700 k hets/s
+    # when it ran after the timed region) - outside the timed region either way: the box's pinned host-to-device rate for
+    # `roofline_pcie`, and the per-block entries driven by 64 C++ threads for `drop_in`.
+    pre_h2d = pinned_h2d_gbs() if (rank == 0 and world == 1 and not args.no_pcie_probe) else None
+    pre_drop_in = drop_in_rates_cpp(args) if (rank == 0 and world == 1 and not args.no_drop_in) else None
     capture = None
     if args.replay:   # a .hpbr capture of real blocks: the same blocks every step, still crossing PCIe every step
         from hiphase_amd.synth_sets import Capture
@@ -565,18 +571,20 @@ def main_path(args, rank, world, local_rank, dist, backend):
         dom = k_wfa if k_wfa_ms >= k_astar_ms else k_astar
         ms_step = elapsed / args.steps * 1e3
         period_ms = period_of(done_at)
-        h2d = pinned_h2d_gbs() if (world == 1 and not args.no_pcie_probe) else None   # (a subprocess, after the timed region)
+        h2d = pre_h2d   # (measured by a subprocess before this process touched the GPU)
         pcie = None
         if h2d and period_ms:
             need_ms = st_mean[10] / (h2d * 1e9) * 1e3
             pcie = {"bound": "pcie", "bytes_per_step": st_mean[10], "peak": h2d, "unit": "GB/s", "achieved": st_mean[10] / (period_ms * 1e-3) / 1e9,
                     "frac": need_ms / period_ms, "floor_ms_per_step": need_ms, "hets_per_s_at_the_floor": info["hets"] / (need_ms * 1e-3),
-                    "note": "what bounds the PATH: a set's bytes over the box's own pinned host-to-device rate (scripts/pcie_probe, measured after the timed region) against the stream's period; `roofline` is the dominant kernel against HBM"}
+                    "note": "what bounds the PATH: a set's bytes over the box's own pinned host-to-device rate (scripts/pcie_probe, its own process, before the timed region) against the stream's period; `roofline` is the dominant kernel against HBM"}
         out = {
             "metric": "het variants phased/sec, whole path, streamed (every step a new block set: records over PCIe -> graph-WFA -> rows -> A* -> span counts / haplotags)",
             "value": hets_timed * world / elapsed,
             "unit": "hets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_run": warm,
-            "ms_per_step": ms_step, "period_ms": period_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "period_ms": period_ms, "first_completion_ms": (done_at[0] - t0) * 1e3 if done_at else None,
+            "completion_intervals_ms": [round((b - a) * 1e3, 1) for a, b in zip(done_at, done_at[1:])],
+            "first_sets_stage_ms": [[round(x, 1) for x in st_] for st_ in stages[:3]], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u64", "data": "synthetic", "host_cpu": host_cpu, "roofline_pcie": pcie,
             "config": {"workload": (f"synthetic read-bearing WGS-like block sets, one NEW set per step and GPU through hp_blockstream_* ({args.depth} sets in flight): "
                                     f"{info['blocks']} blocks, {info['hets']} hets (lognormal block sizes, median 15, max {info['max_block_hets']}), "
@@ -621,9 +629,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
                                    "note": "hp_blockset_solve over one resident set (inputs in HBM, no overlap between stages)"}
                 out["streamed_over_resident"] = out["value"] / out["resident"]["hets_per_s"]
         if world == 1 and not args.no_drop_in:
-            out["drop_in"] = drop_in_rates_cpp(args) or drop_in_rates(lib, sets, prm, args)
-        if world == 1 and not args.no_hifi and not capture:
-            out["hifi_mix"] = hifi_mix(lib, args, prm, local_rank, fmt, gen_threads, run, period_of)
+            out["drop_in"] = pre_drop_in or drop_in_rates(lib, sets, prm, args)
         if capture:
             out["data"] = "replay of " + os.path.basename(args.replay)
             out["config"]["workload"] = f"replay of the read-bearing capture {os.path.basename(args.replay)}: {info['blocks']} blocks, {info['hets']} hets, {info['records']} records, streamed again every step"
@@ -651,6 +657,12 @@ def main_path(args, rank, world, local_rank, dist, backend):
             out["cpu_baseline"] = {"value": h1 / dt1, "unit": "hets/s", "cores": 1, "kind": "port",
                                    "sample": f"{len(done1)} blocks drawn at random from the first timed set ({h1} hets, {r1} records) through the whole path on the C++ restatement, single thread, {dt1:.1f}s"}
             out["fallbacks"] = {"local_aligned": int(sum(gpu_out.arr[b].local_aligned for b in range(s0.n))), "global_aligned": int(sum(gpu_out.arr[b].global_aligned for b in range(s0.n)))}
+        if world == 1 and not args.no_hifi and not capture:
+            # (last, with the headline's sets given back first: beside their 17 GB of pinned host memory the same run read 0.9-1.5 M
+            # hets/s where it reads 2.4 M on its own - `bench.py --hifi`)
+            for x in outs + sets:
+                x.close()
+            out["hifi_mix"] = hifi_mix(lib, args, prm, local_rank, fmt, gen_threads, run, period_of)
         print(json.dumps(out), flush=True)
     if stream:
         lib.hp_blockstream_destroy(stream)
@@ -667,7 +679,7 @@ def main():
     ap.add_argument("--total-hets", type=int, default=60000, help="path workload: hets per GPU and step")
     ap.add_argument("--max-block-hets", type=int, default=4165, help="largest block HiPhase reports on HG002 (docs/user_guide.md:258)")
     ap.add_argument("--seq-format", choices=["bam4", "ascii"], default="bam4", help="path workload: how the reads are handed over")
-    ap.add_argument("--depth", type=int, default=6, help="path workload: block sets in flight in the stream (measured: 5 -> 31, 6 -> 28.3-29.4, 7 -> 29.2-30.2, 8 -> 29.3-29.6 ms per step; 160 / 190 / 215 ms from submit to done at 6 / 7 / 8)")
+    ap.add_argument("--depth", type=int, default=7, help="path workload: block sets in flight in the stream (measured: 5 -> 31, 6 -> 28.3-29.4, 7 -> 29.2-30.2, 8 -> 29.3-29.6 ms per step; 160 / 190 / 215 ms from submit to done at 6 / 7 / 8)")
     ap.add_argument("--distinct-sets", type=int, default=16, help="path workload: generated sets (steps + warm-up if fewer; cycled if more are needed)")
     ap.add_argument("--host-memory", choices=["pageable", "pinned"], default="pinned",
                     help="path workload: where the records' bases lie on the host - ordinary memory (staged by the library's host threads) or hp_host_alloc memory (read in place by the device)")

@@ -266,7 +266,12 @@ hipStream_t thread_stream(int device_id) {
     Slot& x = h.part[g_cu_partition];
     if (x.s && x.device == device_id) return x.s;
     if (x.s) { (void)hipStreamDestroy(x.s); x.s = nullptr; }
-    if (hp_stream_create(&x.s, device_id) != hipSuccess) { x.s = nullptr; return nullptr; }
+    // The kernels on a thread's own stream are the latency chains behind a launch set - the reference-window test, the dense-band
+    // pass over a set's leftovers, the Levenshtein batch of the fallbacks - a few hundred workgroups that the rows stage of a block
+    // stream WAITS for, beside the next sets' persistent alignment kernels that fill every compute unit: high priority, so that the
+    // wavefront slots those kernels' retiring workgroups free go to the chain first (HP_CHAIN_PRIORITY=1; measured round 5: no effect on the first set's latency, 146-153 ms either way - off by default).
+    static const int prio = [] { const char* e = std::getenv("HP_CHAIN_PRIORITY"); return e ? std::atoi(e) : 0; }();
+    if (hp_stream_create(&x.s, device_id, prio) != hipSuccess) { x.s = nullptr; return nullptr; }
     x.device = device_id;
     return x.s;
 }

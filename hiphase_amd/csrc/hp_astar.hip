@@ -371,13 +371,13 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     // single-wave workgroups per SIMD run at the speed of one (profiles/round2/issue_ceiling.txt), so the shorter chain is free
     uint64_t target = tenv ? (uint64_t)std::atoll(tenv) : std::max<uint64_t>(32, total / max_slots);
     target = std::max<uint64_t>(32, (target + 31) / 32 * 32);
-    // Two rounds: a short warm-up first (64 variants close every seam of the synthetic mixes; the chain forgets its start
+    // Two rounds: a short warm-up first (48 variants; 64 closed every seam of the synthetic mixes; the chain forgets its start
     // after a few dozen variants), then only the segments below a seam that stayed open are solved again with the long
     // one (160: scripts/spec_converge.py found 120 sufficient at 1 % and 15 % error). The seam check decides, so both
     // lengths only matter for speed. HP_SEG_WARM / HP_SEG_WARM2 override them; WARM >= WARM2 means one round.
     const char* wenv = std::getenv("HP_SEG_WARM");
     const char* wenv2 = std::getenv("HP_SEG_WARM2");
-    const uint32_t warm = wenv ? (uint32_t)std::atoi(wenv) : 64;
+    const uint32_t warm = wenv ? (uint32_t)std::atoi(wenv) : 48;   // (round 5: 48 closes nearly every seam of the bench's mix - A* kernels 17.3 against 19.0 ms per set in the stream with 64; at 40 and 32 so many segments are solved again with the long warm-up that they take 30)
     const uint32_t warm2 = wenv2 ? (uint32_t)std::atoi(wenv2) : 160;
     const bool two_rounds = warm < warm2;
     std::vector<SegDesc>& segs = b->h_segs;

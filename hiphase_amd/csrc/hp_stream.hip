@@ -174,11 +174,14 @@ hp::Pipeline* hp::pipeline_create(const hp_block_params* p, int device_id, uint3
     const char* rt = std::getenv("HP_STREAM_ROWS_THREADS");
     // HP_STREAM_SOLVE_THREADS=2 (round 5): a second thread for the last stage - A* is a latency chain, not issue (3e8 busy cycles per set
     // against the alignment kernels' 2.3e9), so set k + 1's chain can run beside set k's
+    // Measured (round 5, default bench, three runs a side): 2.15 -> 2.19 M hets/s at depth 6, 2.29 M at depth 7 (one more set in flight
+    // feeds the second chain), 2.34 M with the 48-variant warm-up of hp_astar.hip on top. On by default; =1 switches it off.
     const char* sv = std::getenv("HP_STREAM_SOLVE_THREADS");
     int n_threads = Pipeline::N_THREADS;
-    if (sv && std::atoi(sv) >= 2) s->extra_stage = 5;
-    else if (rt && std::atoi(rt) >= 2) s->extra_stage = 3;
-    else if (!(wt && std::atoi(wt) >= 2)) n_threads = Pipeline::N_STAGES;
+    if (rt && std::atoi(rt) >= 2) s->extra_stage = 3;
+    else if (wt && std::atoi(wt) >= 2) s->extra_stage = 2;
+    else if (!sv || std::atoi(sv) >= 2) s->extra_stage = 5;
+    else n_threads = Pipeline::N_STAGES;
     g_pipelines.fetch_add(1);
     for (int k = 0; k < n_threads; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_thread(k); });
     if (status) *status = HP_OK;
