@@ -468,9 +468,13 @@ def main_path(args, rank, world, local_rank, dist, backend):
     if capture and capture.n:
         prm = capture.params[0]   # (the parameters the blocks were captured with)
     st = C.c_int(0)
-    stream = stream0 = lib.hp_blockstream_create(C.byref(prm), local_rank, args.depth, C.byref(st))
+    # --inproc: ONE process, one pipeline per visible device behind one stream (device_id = -1) - the form a single HiPhase process
+    # on a multi-GPU node uses; HP_STREAM_DEVICES=n stands n pipelines on a box with fewer GPUs
+    stream = stream0 = lib.hp_blockstream_create(C.byref(prm), -1 if args.inproc else local_rank, args.depth, C.byref(st))
     if not stream:
         raise SystemExit(f"hp_blockstream_create failed: {st.value} {lib.hp_last_error().decode()}")
+    n_pipes = lib.hp_blockstream_devices(stream)
+    in_flight_cap = args.depth * n_pipes
 
     def sync_all():
         if dist is not None:
@@ -493,7 +497,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
             works.append(list(work))
 
         for k in range(first, first + count):
-            if len(pending) >= args.depth:
+            if len(pending) >= in_flight_cap:
                 wait_oldest()
             i = k % len(sets)
             t = C.c_uint64(0)
@@ -511,7 +515,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
 
     # (untimed warm-up: at least depth + 1 sets whatever --warmup says - every slot of the stream must have sized its device and
     # pinned buffers once, hipMalloc / hipHostMalloc wait for the whole device - reported as warmup_run)
-    warm = max(args.warmup, args.depth + 1)
+    warm = max(args.warmup, in_flight_cap + 1)
     run(0, warm)
     sync_all()
     cg0, cpu0, th0 = _cgroup_cpu_stat(), time.process_time(), _thread_cpu()
@@ -581,7 +585,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
         out = {
             "metric": "het variants phased/sec, whole path, streamed (every step a new block set: records over PCIe -> graph-WFA -> rows -> A* -> span counts / haplotags)",
             "value": hets_timed * world / elapsed,
-            "unit": "hets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_run": warm,
+            "unit": "hets/s", "n_gpus": world if not args.inproc else n_pipes, "pipelines": n_pipes, "inproc": bool(args.inproc), "steps": args.steps, "warmup": args.warmup, "warmup_run": warm,
             "ms_per_step": ms_step, "period_ms": period_ms, "first_completion_ms": (done_at[0] - t0) * 1e3 if done_at else None,
             "completion_intervals_ms": [round((b - a) * 1e3, 1) for a, b in zip(done_at, done_at[1:])],
             "first_sets_stage_ms": [[round(x, 1) for x in st_] for st_ in stages[:3]], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -686,6 +690,7 @@ def main():
     ap.add_argument("--spec", action="append", default=[], help="path workload: override a field of hp_synth_reads_spec, key=value (repeatable)")
     ap.add_argument("--no-resident", action="store_true", help="path workload: skip the secondary resident (inputs-in-HBM) figure")
     ap.add_argument("--no-drop-in", action="store_true", help="path workload: skip the secondary per-block (drop-in) rates")
+    ap.add_argument("--inproc", action="store_true", help="path workload: one process drives every visible device through ONE stream (hp_blockstream_create(device_id = -1)); steps = sets over all devices")
     ap.add_argument("--no-hifi", action="store_true", help="path workload: skip the secondary line on HiFi-shaped errors")
     ap.add_argument("--no-pcie-probe", action="store_true", help="path workload: skip the pinned host-to-device rate probe (roofline_pcie)")
     ap.add_argument("--hifi", action="store_true", help="path workload: the HEADLINE run on the HiFi-shaped error model instead of uniform 0.5 %% (for profiling it)")

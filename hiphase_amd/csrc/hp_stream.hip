@@ -92,11 +92,14 @@ struct hp::Pipeline {
     std::unique_ptr<WorkerPool> pool[N_THREADS];
     void stage_thread(int t);
     int extra_stage = 2;
+    int index = 0;   // among the pipelines alive when it was created (thread names)
     void stage_loop(int k);
 };
 
 void hp::Pipeline::stage_thread(int t) {
-    { char b[16]; std::snprintf(b, sizeof b, "hp-s%d", t < N_STAGES ? t : extra_stage); name_thread(b); }
+    // (the first pipeline of a process keeps the plain names bench.py's host_cpu table has always shown; further ones - several devices
+    // behind one stream, the dispatcher's per-device pipelines - carry their index: hp-p3s5 = pipeline 3, stage 5)
+    { char b[16]; if (index == 0) std::snprintf(b, sizeof b, "hp-s%d", t < N_STAGES ? t : extra_stage); else std::snprintf(b, sizeof b, "hp-p%ds%d", index % 100, t < N_STAGES ? t : extra_stage); name_thread(b); }
     WorkerPool::set_thread_pool(pool[t].get());
     stage_loop(t < N_STAGES ? t : extra_stage);   // (the last thread: a second one for the alignment stage - or, as an experiment, the rows stage)
 }
@@ -182,7 +185,7 @@ hp::Pipeline* hp::pipeline_create(const hp_block_params* p, int device_id, uint3
     else if (wt && std::atoi(wt) >= 2) s->extra_stage = 2;
     else if (!sv || std::atoi(sv) >= 2) s->extra_stage = 5;
     else n_threads = Pipeline::N_STAGES;
-    g_pipelines.fetch_add(1);
+    s->index = g_pipelines.fetch_add(1);
     for (int k = 0; k < n_threads; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_thread(k); });
     if (status) *status = HP_OK;
     return s.release();

@@ -336,3 +336,74 @@ def test_hifi_shaped_sets_vs_oracle():
         n_blocks += s.n
         fell_back += sum(o.arr[b].local_aligned for b in range(s.n))
     assert n_blocks > 40
+
+
+def oracle_outputs_mt(sset, prm, threads=16):
+    """hpo_solve_block over every block on `threads` host threads (ctypes releases the GIL for each call), largest blocks first"""
+    import threading
+    d = oracle()
+    out = sset.outputs()
+    order = sorted(range(sset.n), key=lambda b: -sset.inputs[b].n_records)
+    lock, state = threading.Lock(), {"next": 0, "bad": []}
+
+    def work():
+        while True:
+            with lock:
+                k = state["next"]
+                if k >= len(order):
+                    return
+                state["next"] = k + 1
+            b = order[k]
+            if d.hpo_solve_block(C.byref(sset.inputs[b]), C.byref(prm), C.byref(out.arr[b])) != 0:
+                state["bad"].append(b)
+
+    th = [threading.Thread(target=work) for _ in range(threads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert state["bad"] == []
+    return out
+
+
+@pytest.mark.timeout(1500)
+def test_eight_pipelines_with_bench_sized_sets_vs_oracle(monkeypatch):
+    """What an 8-GPU node's single HiPhase process would run, exercised on ONE GPU: hp_blockstream_create(device_id
+    = -1) with HP_STREAM_DEVICES=8 - eight six-stage pipelines (8 x 7 stage threads and their worker pools, 8 x the copy engines'
+    descriptors) - depth 2, bench-sized sets (60 000 hets, ~136 k records, ~1.07 GB across PCIe each), 20 of them in submission
+    order with 16 in flight: no deadlock, every pipeline gets work, every block of every set equals the oracle's hpo_solve_block
+    (reference src/phaser.rs:406-630 per block; no collective)."""
+    monkeypatch.setenv("HP_STREAM_DEVICES", "8")
+    lib = _ffi.lib()
+    prm = _params(2, 1000, 3, None, True)
+    sets = [SynthSet(default_spec(lib, seed=7100 + k)) for k in range(3)]
+    for s in sets[:2]:
+        s.relocate_pinned()          # two sets read in place by the copy engines, the third staged by the library
+    exps = [oracle_outputs_mt(s, prm) for s in sets]
+    st = C.c_int(0)
+    stream = lib.hp_blockstream_create(C.byref(prm), -1, 2, C.byref(st))
+    assert stream, lib.hp_last_error()
+    assert lib.hp_blockstream_devices(stream) == 8
+    used, n_sets, checked = set(), 20, 0
+    try:
+        outs = [sets[k % 3].outputs() for k in range(n_sets)]
+        pending = []
+
+        def finish(kk, t):
+            _ffi.check(lib.hp_blockstream_wait(stream, t, None, None))
+            s = sets[kk % 3]
+            assert [b for b in range(s.n) if not outs[kk].equal(exps[kk % 3], b)] == [], f"set {kk}"
+            return s.n
+
+        for k in range(n_sets):
+            if len(pending) == 16:
+                checked += finish(*pending.pop(0))
+            t = C.c_uint64(0)
+            _ffi.check(lib.hp_blockstream_submit(stream, sets[k % 3].n, sets[k % 3].inputs, outs[k].arr, C.byref(t)))
+            used.add(t.value & 0xFF)
+            pending.append((k, t.value))
+        for kk, t in pending:
+            checked += finish(kk, t)
+    finally:
+        lib.hp_blockstream_destroy(stream)
+    assert used == set(range(8)) and checked > 20 * 200
