@@ -327,53 +327,28 @@ def pinned_h2d_gbs():
         return None
 
 
-def hifi_mix(lib, args, prm, local_rank, fmt, gen_threads, run, period_of):
-    """Secondary line: the same block mix with HiFi-shaped errors (hp_synth_reads_hifi: per-read rate lognormal around 0.2 %, a tail
-    to 1-2 %, half of the errors homopolymer indels; docs/performance.md:59-82 quotes HG002 HiFi data) - which regime a real run
-    lands in. Its own stream, its own sets, parity of a sample of one set's blocks against the oracle."""
-    import ctypes as C
-    import numpy as np
-    from hiphase_amd import _ffi
-    from hiphase_amd.synth_sets import SynthSet, default_spec
-    n_sets = args.depth + 2
-    sets = [SynthSet(default_spec(lib, hifi=True, seed=args.seed + 500000 + k, total_hets=args.total_hets, max_block_hets=args.max_block_hets,
-                                  coverage=float(args.coverage), seq_format=fmt, threads=gen_threads)) for k in range(n_sets)]
-    if args.host_memory == "pinned":
-        for s_ in sets:
-            try:
-                s_.relocate_pinned()
-            except _ffi.HpError:
-                break
-    outs = [s.outputs() for s in sets]
-    st = C.c_int(0)
-    stream = lib.hp_blockstream_create(C.byref(prm), local_rank, args.depth, C.byref(st))
-    if not stream:
-        return {"error": f"hp_blockstream_create: {st.value}"}
+def hifi_mix_own_process(args):
+    """Secondary line `hifi_mix`: this very bench with `--hifi` (HiFi-shaped errors: per-read rate lognormal around 0.2 %, a tail to
+    1-4 %, half of the errors homopolymer indels) in a process of its own, before this one touches the GPU - as a second stream
+    inside the headline's process it read 0.9-1.7 M hets/s (a new stream's buffers grow beside the old one's 17 GB of pinned sets)
+    where the same run on its own reads 2.4 M. Its own parity count: every block of its first timed set against the oracle."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--hifi", "--no-resident", "--no-drop-in", "--no-hifi", "--no-pcie-probe",
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", str(min(args.cpu_seconds, 3.0)), "--total-hets", str(args.total_hets),
+           "--max-block-hets", str(args.max_block_hets), "--seq-format", args.seq_format, "--depth", str(args.depth), "--host-memory", args.host_memory]
+    if args.no_cpu:
+        cmd.append("--no-cpu")
     try:
-        warm, steps = args.depth + 1, max(8, args.steps // 2)
-        run(0, warm, stream=stream, sets=sets, outs=outs)
-        done_at = []
-        t0 = time.perf_counter()
-        stages, works = run(warm, steps, stream=stream, sets=sets, outs=outs, done_at=done_at)
-        dt = time.perf_counter() - t0
-    finally:
-        lib.hp_blockstream_destroy(stream)
-    hets = sum(sets[k % n_sets].info["hets"] for k in range(warm, warm + steps))
-    stm = np.mean(np.asarray(stages), axis=0)
-    wk = np.mean(np.asarray(works, dtype=np.float64), axis=0)
-    res = {"value": hets / dt, "unit": "hets/s", "steps": steps, "ms_per_step": dt / steps * 1e3, "period_ms": period_of(done_at),
-           "graph_wfa_kernels_ms": stm[8], "astar_kernel_ms": stm[9], "wave_updates_per_read": wk[3] / max(1.0, wk[0]),
-           "records": sets[0].info["records"], "hets_per_step": sets[0].info["hets"],
-           "workload": "the headline's block mix with HiFi-shaped errors: per-read error rate lognormal (median 0.2 %, sigma 0.8, clamp 4 %), half of the errors homopolymer-run indels, no separate noisy class"}
-    if not args.no_cpu:
-        i0 = warm % n_sets
-        s0, gpu_out = sets[i0], outs[i0]
-        oo = s0.outputs()
-        rng = np.random.default_rng(777)
-        h, r, done, cdt = cpu_whole_path(s0, oo, prm, 2.0 * args.cpu_seconds, host_cores(), [int(b) for b in rng.permutation(s0.n)])
-        res["parity"] = {"blocks_compared": len(done), "of": s0.n, "hets_compared": h, "bit_identical": bool(all(gpu_out.equal(oo, b) for b in done))}
-        res["cpu_all_cores_hets_per_s"] = h / cdt
-    return res
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001
+        return {"error": repr(e)}
+    return {"value": d["value"], "unit": "hets/s", "steps": d["steps"], "ms_per_step": d["ms_per_step"], "period_ms": d.get("period_ms"), "first_completion_ms": d.get("first_completion_ms"),
+            "graph_wfa_kernels_ms": d["kernels"][0]["kernel_ms"], "astar_kernel_ms": d["kernels"][1]["kernel_ms"], "wave_updates_per_read": d["kernels"][0]["wave_updates_per_read"],
+            "reads_left_compact_path": d["kernels"][0]["reads_left_compact_path"], "records": d["config"]["records"], "hets_per_step": d["config"]["hets_per_step_per_gpu"],
+            "parity": d.get("parity"), "cpu_all_cores_hets_per_s": (d.get("cpu_baseline_all_cores") or {}).get("value"), "fallbacks": d.get("fallbacks"),
+            "measured_by": "python bench.py --hifi (its own process, before the headline's)",
+            "workload": "the headline's block mix with HiFi-shaped errors: per-read error rate lognormal (median 0.2 %, sigma 0.8, clamp 4 %), half of the errors homopolymer-run indels, no separate noisy class"}
 
 
 def host_cores():
@@ -433,6 +408,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
     # `roofline_pcie`, and the per-block entries driven by 64 C++ threads for `drop_in`.
     pre_h2d = pinned_h2d_gbs() if (rank == 0 and world == 1 and not args.no_pcie_probe) else None
     pre_drop_in = drop_in_rates_cpp(args) if (rank == 0 and world == 1 and not args.no_drop_in) else None
+    pre_hifi = hifi_mix_own_process(args) if (rank == 0 and world == 1 and not args.no_hifi and not args.hifi and not args.replay and not args.inproc) else None
     capture = None
     if args.replay:   # a .hpbr capture of real blocks: the same blocks every step, still crossing PCIe every step
         from hiphase_amd.synth_sets import Capture
@@ -661,12 +637,8 @@ def main_path(args, rank, world, local_rank, dist, backend):
             out["cpu_baseline"] = {"value": h1 / dt1, "unit": "hets/s", "cores": 1, "kind": "port",
                                    "sample": f"{len(done1)} blocks drawn at random from the first timed set ({h1} hets, {r1} records) through the whole path on the C++ restatement, single thread, {dt1:.1f}s"}
             out["fallbacks"] = {"local_aligned": int(sum(gpu_out.arr[b].local_aligned for b in range(s0.n))), "global_aligned": int(sum(gpu_out.arr[b].global_aligned for b in range(s0.n)))}
-        if world == 1 and not args.no_hifi and not capture:
-            # (last, with the headline's sets given back first: beside their 17 GB of pinned host memory the same run read 0.9-1.5 M
-            # hets/s where it reads 2.4 M on its own - `bench.py --hifi`)
-            for x in outs + sets:
-                x.close()
-            out["hifi_mix"] = hifi_mix(lib, args, prm, local_rank, fmt, gen_threads, run, period_of)
+        if pre_hifi is not None:
+            out["hifi_mix"] = pre_hifi
         print(json.dumps(out), flush=True)
     if stream:
         lib.hp_blockstream_destroy(stream)

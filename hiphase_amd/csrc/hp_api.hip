@@ -40,8 +40,10 @@ struct DevCache {
     // size classes: powers of two and 1.5 x powers of two. A request takes any cached block up to twice its size: the buffers of a
     // stage differ a little from set to set (a few hundred leftovers more or less), and a miss is a hipMalloc - which waits for
     // every kernel on the device, the persistent ones of the neighbouring stage included (measured: stalls of 50-400 ms).
+    // (round 5: nothing below 1 MB - the few dozen small tables of a side path then all come out of one class, whatever a set's
+    // leftovers number, and a miss there is rare after a stream's first sets)
     static size_t round_up(size_t n) {
-        size_t r = 256;
+        size_t r = (size_t)1 << 20;
         while (r < n) { if (r + r / 2 >= n && r >= 4096) return r + r / 2; r <<= 1; }
         return r;
     }

@@ -219,7 +219,7 @@ struct PinBuf {
         if (n <= cap) return HP_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
-        const size_t want = std::max<size_t>(n + n / 2 + 4096, (size_t)1 << 20);   // (growing pinned memory synchronises the device too: leave room)
+        const size_t want = std::max<size_t>(2 * n + 4096, (size_t)4 << 20);   // (growing pinned memory synchronises the device too: leave room - twice the need, 4 MB at least)
         g_device_syncing_allocs.fetch_add(1);
         if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
             p = nullptr;

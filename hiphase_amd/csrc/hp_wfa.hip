@@ -287,7 +287,7 @@ struct StageBuf {
             // (pinning and unpinning host memory waits for the whole device - inside a block stream that is the other stages' persistent
             // kernels: a leftover pass whose tables outgrew its thread's staging by a few per cent stood still for 50-80 ms.
             // Hence the floor and the headroom: the passes of a stream's late results never grow it after their first.)
-            const size_t want = std::max<size_t>(n + n / 2 + 4096, (size_t)8 << 20);
+            const size_t want = std::max<size_t>(2 * n + 4096, (size_t)64 << 20);   // (round 5: 64 MB, twice the need - a HiFi-shaped set leaves five hundred reads to this pass where the uniform workload leaves seventy-five, and how many varies from set to set: at 8 MB + half, a stream's tables grew three or four times, 100-370 ms of standing still each, some of them inside a timed region)
             g_device_syncing_allocs.fetch_add(1);
             if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
                 p = nullptr;
