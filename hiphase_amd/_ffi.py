@@ -319,6 +319,7 @@ EXPORTS = [
     "hp_host_alloc",
     "hp_host_free",
     "hp_host_in_place_bytes",
+    "hp_wfa_routed_records",
     "hp_abi_layout",
     "hp_hpbk_append",
     "hp_synth_block_size",
@@ -468,6 +469,7 @@ def lib():
     dll.hp_host_alloc.restype = C.c_void_p
     dll.hp_host_alloc.argtypes = [C.c_size_t]
     dll.hp_host_in_place_bytes.restype = C.c_uint64
+    dll.hp_wfa_routed_records.restype = C.c_uint64
     dll.hp_host_free.restype = None
     dll.hp_host_free.argtypes = [C.c_void_p]
     _lib = dll

@@ -261,6 +261,7 @@ void dev_io_abort(hipStream_t st) {
     g_io.wanted = 0;
 }
 
+thread_local bool g_thread_stream_high = false;
 hipStream_t thread_stream(int device_id) {
     struct Slot { int device = -1; hipStream_t s = nullptr; };
     struct Holder { Slot part[3]; ~Holder() { for (auto& x : part) if (x.s) (void)hipStreamDestroy(x.s); } };
@@ -273,7 +274,11 @@ hipStream_t thread_stream(int device_id) {
     // stream WAITS for, beside the next sets' persistent alignment kernels that fill every compute unit: high priority, so that the
     // wavefront slots those kernels' retiring workgroups free go to the chain first (HP_CHAIN_PRIORITY=1; measured round 5: no effect on the first set's latency, 146-153 ms either way - off by default).
     static const int prio = [] { const char* e = std::getenv("HP_CHAIN_PRIORITY"); return e ? std::atoi(e) : 0; }();
-    if (hp_stream_create(&x.s, device_id, prio) != hipSuccess) { x.s = nullptr; return nullptr; }
+    // (g_thread_stream_high: the device's early worker - hp_wfa2.hip - asks for a high-priority stream for the hardware QUEUE it comes
+    // with: a process streaming seven sets deep holds more streams than the runtime has queues (36 against GPU_MAX_HW_QUEUES = 24),
+    // streams of one priority share them, and a chain's kernels behind a persistent class kernel in one queue wait for it to end -
+    // measured: the reference-window test 50-60 instead of 7-10 ms, and the class kernels behind a dense-band pass 23-27 instead of 19)
+    if (hp_stream_create(&x.s, device_id, g_thread_stream_high ? 1 : prio) != hipSuccess) { x.s = nullptr; return nullptr; }
     x.device = device_id;
     return x.s;
 }
@@ -339,6 +344,8 @@ bool host_range_of(const void* p, uintptr_t* lo, uintptr_t* hi) {   // the hp_ho
 }
 std::atomic<uint64_t> g_in_place_bytes{0};
 extern "C" uint64_t hp_host_in_place_bytes(void) { return g_in_place_bytes.load(); }
+std::atomic<uint64_t> g_routed_records{0};
+extern "C" uint64_t hp_wfa_routed_records(void) { return g_routed_records.load(); }
 bool host_ranges_any() { HostRanges& H = host_ranges(); std::lock_guard<std::mutex> lk(H.m); return !H.r.empty(); }
 
 static std::atomic<int> g_coalesce{-1};   // -1: ask the environment once

@@ -64,6 +64,7 @@ int partition_cu_count(int device_id);   // CUs of the calling thread's current 
 // what the small entry points launch on. Nothing in the library uses the NULL stream or hipDeviceSynchronize - a stage of a block
 // stream must never wait for another stage's kernels.
 hipStream_t thread_stream(int device_id);
+extern thread_local bool g_thread_stream_high;   // set before the thread's first thread_stream(): a high-priority stream (a hardware queue of its own)
 
 // Library threads carry names (`hp-...`, /proc/<pid>/task/*/comm): bench.py attributes the process's CPU time to them.
 inline void name_thread(const char* name) { (void)pthread_setname_np(pthread_self(), name); }
@@ -251,6 +252,7 @@ void dev_io_abort(hipStream_t st);
 bool host_range_of(const void* p, uintptr_t* lo, uintptr_t* hi);   // the hp_host_alloc range (slack included) that holds p
 bool host_ranges_any();
 extern std::atomic<uint64_t> g_in_place_bytes;
+extern std::atomic<uint64_t> g_routed_records;   // hp_wfa_routed_records()
 
 // RAII device buffer
 struct DevBuf {

@@ -18,8 +18,14 @@
 #include <memory>
 #include <atomic>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <ctime>
+#include <deque>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <pthread.h>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -118,6 +124,55 @@ template <class F> void w2_parallel(unsigned nt, F&& f) {
     WorkerPool::get().run(std::max(1u, nt), [&f, nt](unsigned t) { f(t, std::max(1u, nt)); });
 }
 
+// A few threads per device that run the block sets' EARLY passes, each one after the other (W2Session::early_pass: the records a set's layout
+// routed past the compact kernels take their way out - reference-window test, dense band - while the set's launch set runs). One
+// thread, hence one stream and one dense-band scratch per device however many sets are in flight: every stream a process creates
+// beyond the runtime's hardware queues shares a queue with another one (W2Context::streams). Never destroyed: a set may still be
+// in its hands when the static destructors run.
+struct EarlyWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    void post(std::function<void()> f) {
+        std::unique_lock<std::mutex> lk(m);
+        if (!th.joinable()) {
+            th = std::thread([this]() {
+                (void)pthread_setname_np(pthread_self(), "hp-early");
+                g_thread_stream_high = true;   // (a hardware queue that no persistent class kernel sits in: hp_api.hip, thread_stream)
+                std::unique_lock<std::mutex> l2(m);
+                for (;;) {
+                    cv.wait(l2, [this]() { return !q.empty(); });
+                    std::function<void()> t = std::move(q.front());
+                    q.pop_front();
+                    l2.unlock();
+                    t();
+                    l2.lock();
+                }
+            });
+            th.detach();
+        }
+        q.push_back(std::move(f));
+        cv.notify_all();
+    }
+};
+// launch sets of a device between their launch and their first collection (W2Session::run, HP_WFA2_ROUTE)
+std::atomic<int>& sets_aligning(int device) {
+    static std::atomic<int> c[64];
+    return c[(unsigned)device % 64u];
+}
+// (two per device, taken in turns: a pass is 20-25 ms of latency chain - the test, then up to max_edit_distance rounds of the dense
+// band - and a stream's sets arrive every 18-20 ms; HP_EARLY_WORKERS)
+EarlyWorker& early_worker(int device) {
+    static std::mutex gm;
+    static std::map<int, std::pair<std::vector<EarlyWorker*>, size_t>>* ws = new std::map<int, std::pair<std::vector<EarlyWorker*>, size_t>>();
+    static const size_t per_device = [] { const char* e = std::getenv("HP_EARLY_WORKERS"); return (size_t)(e ? std::max(1, std::min(8, std::atoi(e))) : 2); }();
+    std::lock_guard<std::mutex> lk(gm);
+    auto& d = (*ws)[device];
+    if (d.first.empty()) for (size_t k = 0; k < per_device; ++k) d.first.push_back(new EarlyWorker());
+    return *d.first[d.second++ % d.first.size()];
+}
+
 // union of address ranges [p, p + len): sorted, merged where they overlap or touch
 struct Range { const uint8_t* lo; const uint8_t* hi; uint64_t dev; };
 void merge_ranges(std::vector<std::pair<const uint8_t*, uint64_t>>& iv, std::vector<Range>& out, uint64_t elem) {
@@ -195,7 +250,6 @@ struct W2Session {
     bool need_unpack = false;            // block mode: the reads are in d_packed and have not been expanded into d_seq yet
     uint64_t h2d_bytes = 0;              // of the last prepare
     double prep_ms[4] = {0, 0, 0, 0};    // of the last prepare: layout, fill + upload, total, -
-    std::vector<std::vector<uint8_t>> ascii_scratch;   // block mode: decoded reads of the jobs that leave the compact path
     // job i as the dense-band path takes it (generic mode: the caller's; block mode: assembled from the block, a BAM 4-bit read
     // decoded on the host - a handful of jobs per batch)
     hp_wfa_job job_header(size_t i) const {   // job i's window and variant lists (no read)
@@ -207,7 +261,7 @@ struct W2Session {
         j.homs = ji.n_homs ? B.homs + ji.hom_first : nullptr; j.n_homs = ji.n_homs;
         return j;
     }
-    hp_wfa_job materialize(size_t i) {
+    hp_wfa_job materialize(size_t i, std::vector<std::vector<uint8_t>>& ascii_scratch) {
         if (jobs) return jobs[i];
         const W2JobIn& ji = bl_jobs[i];
         const hp_block_input& B = bl_in[ji.block];
@@ -246,9 +300,6 @@ struct W2Session {
         std::vector<uint32_t> big_nodes; // their graphs' node counts (0: the device builder left the graph to the host) | the limit that ended the compact attempt (hp_wfa2_kernel's `why`) << 24
         static uint32_t nodes_of(uint32_t x) { return x & 0xFFFFFFu; }
         static uint32_t why_of(uint32_t x) { return x >> 24; }
-        std::vector<hp_wfa_job> sub;
-        std::vector<hp_wfa_result> sub_out;
-        std::vector<uint8_t*> sub_al;
         hp_wfa_result* dst = nullptr;
         uint8_t* const* alleles = nullptr;
         uint64_t prune = 0, max_ed = 0;
@@ -260,6 +311,50 @@ struct W2Session {
         int rc = HP_OK;
         std::string err;
     } pend;
+    // what a dense-band pass over leftovers needs of its own (the late pass and the early pass of one set may run side by side)
+    struct SubWork {
+        std::vector<hp_wfa_job> sub;
+        std::vector<hp_wfa_result> sub_out;
+        std::vector<uint8_t*> sub_al;
+        std::vector<std::vector<uint8_t>> ascii;   // block mode: decoded reads of the jobs that take the dense-band pass
+    } late_sw;
+    // The leftovers' way out (everything in `big`): the reference-window test (hp_wfa2_bound_kernel), then the dense-band pass for what
+    // it leaves; results straight into dst / alleles. beside_launch_set: the test runs one wavefront per job and compares in place - a
+    // workgroup that fits the slot a compute unit has free beside a resident launch set.
+    int leftovers_out(std::vector<uint32_t>& big, std::vector<uint32_t>& big_ed, std::vector<uint32_t>& big_nodes, SubWork& sw, hp_wfa_result* dst,
+                      uint8_t* const* alleles, uint64_t prune, uint64_t max_ed, bool beside_launch_set, double* t_bound, size_t* n_settled, double* kernel_ms);
+    // Records the layout routed past the compact kernels (layout_blocks: by their CIGARs they are heading for the neighbourhood of
+    // max_edit_distance - the noisy tail that outgrows every class's lists a dozen rounds in and was, until round 5, only sent on
+    // its way out AFTER the class kernels: a chain of 20-40 ms behind the first collection that the set's rows waited for). Their
+    // way out starts when the launch set does, on the device's early worker (early_pass); finish() joins it.
+    struct Early {
+        bool on = false, done = true;
+        int rc = HP_OK;
+        std::string err;
+        std::vector<uint32_t> ids;         // ascending
+        std::vector<uint8_t> mask;         // [n] 1 = routed
+        std::vector<uint32_t> big, big_ed, big_nodes;
+        SubWork sw;
+        hp_wfa_result* dst = nullptr;
+        uint8_t* const* alleles = nullptr;
+        uint64_t prune = 0, max_ed = 0;
+        double t_post = 0, t_start = 0, t_bound = 0, t_done = 0;
+        size_t n_settled = 0;
+    } early;
+    std::mutex em;
+    std::condition_variable ecv;
+    std::atomic<bool> aligning{false};   // counted in sets_aligning(device_id)
+    void aligning_done() { if (aligning.exchange(false)) sets_aligning(device_id).fetch_sub(1); }
+    void early_pass();
+    int wait_early() {
+        std::unique_lock<std::mutex> lk(em);
+        ecv.wait(lk, [this]() { return early.done; });
+        const bool was_on = early.on;
+        early.on = false;
+        if (was_on && early.rc != HP_OK) { set_error("%s", early.err.c_str()); return early.rc; }
+        return HP_OK;
+    }
+    int finish_late();
     DevBuf d_job_cls, d_handed, d_seen, d_held, d_hoff, d_hrec, d_hrows, d_wide, d_wide_sets, d_wide_hash;
     uint32_t wide_tag_next = 0;
     int wide_last_gen = 0;
@@ -306,6 +401,7 @@ struct W2Session {
         std::vector<uint64_t> src_off;
         std::vector<uint8_t> fmt;
         std::vector<Run> runs;
+        std::vector<uint32_t> suspects;   // jobs routed past the compact kernels (ascending ids; fmt bit W2_FMT_SUSPECT)
         uint64_t n_vars = 0, pool_bytes = 0, ref_bytes = 0, reads_dev = 0, dev_reads = 0, packed = 0, in_place_bytes = 0;
         double t0 = 0.0, t_lay = 0.0;
     } lay;
@@ -321,6 +417,8 @@ struct W2Session {
     int finish();
     ~W2Session() {
         if ((async_inflight || (pend.on && pend.posted)) && helper) helper->wait();
+        { std::unique_lock<std::mutex> lk(em); ecv.wait(lk, [this]() { return early.done; }); }
+        aligning_done();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (ev_c) (void)hipEventDestroy(ev_c);
     }
@@ -329,7 +427,7 @@ struct W2Session {
 int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     // a deferred late() of the previous run still writes the caller's result arrays and reads the tables laid out below: join it
     // first, whatever path the caller took out of that run (its status belongs to that run, not to this one)
-    if (pend.on || async_inflight) (void)finish();
+    if (pend.on || async_inflight || early.on) (void)finish();
     jobs = jobs_; n = n_; bl_in = nullptr; bl_jobs = nullptr; need_unpack = false;
     if (n == 0) return HP_OK;
     if (!jobs) { set_error("null argument"); return HP_ERR_ARG; }
@@ -495,7 +593,7 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
 // once, hets then homs). Everything per job is independent of every other job, so layout, table fill and the staging copy
 // run on host threads; the reads are staged in pieces and each piece's DMA runs while the next one is being filled.
 int W2Session::layout_blocks(const hp_block_input* in, size_t n_in, const W2JobIn* jin, size_t n_) {
-    if (pend.on || async_inflight) (void)finish();   // (as in prepare(): never lay a set out under a late pass that is still running)
+    if (pend.on || async_inflight || early.on) (void)finish();   // (as in prepare(): never lay a set out under a late pass that is still running)
     jobs = nullptr; bl_in = in; bl_jobs = jin; n = n_;
     h2d_bytes = 0; prep_ms[0] = prep_ms[1] = prep_ms[2] = prep_ms[3] = 0.0;
     lay.valid = false; lay.n_in = n_in;
@@ -544,10 +642,23 @@ int W2Session::layout_blocks(const hp_block_input* in, size_t n_in, const W2JobI
     std::vector<uint8_t>& fmt = lay.fmt;
     src_off.assign(n + 1, 0); fmt.assign(n, 0);
     uint64_t dev_reads = 0, packed = 0;
+    // Which records are heading for the neighbourhood of max_edit_distance? The record's own CIGAR says (the view local re-alignment
+    // reads, when the caller handed one over): an alignment operation begins every 1 / (2 x indel rate) bases - one op in 150 at HiFi
+    // error rates, one in 15 on a read with 5 % noise (with = / X CIGARs the substitutions count too). Such a read holds fifty
+    // diagonals per node, outgrows every class's lists a dozen rounds in and ends in the reference-window test and the dense band
+    // anyway (hp_wfa3_kernel's `hopeless`): routed there NOW, its way out runs beside the set's launch set instead of behind it
+    // (W2Session::Early). Routing only - every road computes the same result. HP_WFA2_SUSPECT_OPS: ops per 1 000 bases from which a
+    // record is routed (50; 0 = never); more than HP_WFA2_SUSPECT_MAX of them in a set (1 024: a noisy SET is the wide-table
+    // launch's business, late()) and nobody is.
+    const uint32_t sus_ops = [] { const char* e = std::getenv("HP_WFA2_SUSPECT_OPS"); return (uint32_t)(e ? std::max(0, std::atoi(e)) : 50); }();   // (read per set: a dozen nanoseconds, and a test can switch it)
+    const size_t sus_max = [] { const char* e = std::getenv("HP_WFA2_SUSPECT_MAX"); return (size_t)(e ? std::max(0, std::atoi(e)) : 1024); }();
+    std::vector<uint32_t>& suspects = lay.suspects;
+    suspects.clear();
     for (size_t i = 0; i < n; ++i) {
         const W2JobIn& ji = jin[i];
         const hp_block_input& B = in[ji.block];
         const hp_block_record& rec = B.records[ji.rec];
+        if (sus_ops && rec.local && rec.local->n_cigar >= 100u && (uint64_t)rec.local->n_cigar * 1000u >= (uint64_t)sus_ops * rec.read_len) suspects.push_back((uint32_t)i);
         W2Job& d = dj[i];
         d.read_off = reads_dev + dev_reads; d.read_len = rec.read_len;
         dev_reads += ((uint64_t)rec.read_len + 15) & ~15ull;
@@ -564,6 +675,8 @@ int W2Session::layout_blocks(const hp_block_input* in, size_t n_in, const W2JobI
         d.allele_off = (uint32_t)allele_tot; allele_tot += ji.n_hets;
     }
     src_off[n] = packed;
+    if (suspects.size() > sus_max) suspects.clear();
+    for (uint32_t i : suspects) fmt[i] |= (uint8_t)W2_FMT_SUSPECT;
     // Do the records' bases all lie in host memory the copy engines read in place (hp_host_alloc)? Then nothing of them is staged:
     // the blocks' address hulls, merged where they touch, cross PCIe as they are - one DMA per run of blocks - and a record's source
     // offset is its place in that image. (Blocks gathered one after the other into an arena give a handful of runs; records
@@ -788,7 +901,7 @@ int W2Session::upload_blocks(int device) {
 
 int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out, uint8_t* const* alleles, int defer) {
     if (n == 0) return HP_OK;
-    if (pend.on || async_inflight) { const int rcp = finish(); if (rcp != HP_OK) return rcp; }
+    if (pend.on || async_inflight || early.on) { const int rcp = finish(); if (rcp != HP_OK) return rcp; }
     if (!out) { set_error("null argument"); return HP_ERR_ARG; }
     if (max_ed > 60000) {   // outside the kernels' diagonal range: every job of the batch, softly (HP_WFA_UNSUPPORTED)
         for (size_t i = 0; i < n; ++i) { out[i] = hp_wfa_result{HP_WFA_UNSUPPORTED, 0, 0}; if (alleles && alleles[i] && dj[i].n_hets) std::memset(alleles[i], HP_ALLELE_NOOVERLAP, dj[i].n_hets); }
@@ -856,6 +969,22 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         cx.region_hash_off[0] = 0; cx.region_hash_off[1] = max_groups; cx.region_hash_off[2] = (size_t)2 * max_groups;
         for (int r = 3; r < 5; ++r) { cx.region_set_off[r] = cx.region_set_off[r - 1] + (size_t)large_groups * w2_group_dwords<8>(); cx.region_hash_off[r] = cx.region_hash_off[r - 1] + large_groups; }
     }
+    // The records the layout marked (layout_blocks: by their CIGARs they are heading for the neighbourhood of max_edit_distance) CAN be
+    // routed past the compact kernels, their way out starting beside this launch set on the device's early worker instead of behind
+    // it. HP_WFA2_ROUTE = 0 (default) never, 1 only while no other launch set of this device is between its launch and its first
+    // collection, 2 always. OFF by default because it loses (round 5, MI355X, three runs a side, profiles/DIARY.md): a resident launch
+    // set holds every wavefront slot its three wavefronts per SIMD and the largest class's waiting consumers can take, and the early
+    // pass's kernels get in only where a workgroup retires - the reference-window test (one wavefront per job, in place) takes 13-17 ms
+    // there against 3-4 in the gap a draining launch set opens (the late pass's moment), the dense band 12-19 with a long wait in
+    // front: a set's routed records were out after 25-200 ms where the late pass delivers them 40-45 ms after the launch. Default bench
+    // 1.73-1.92 M hets/s against 2.33-2.39 M (a set 190-240 ms from submit to done against 160-165), `idle only` the same (launch
+    // sets follow each other so closely that the device counts as idle every other set), one call over a whole set 505 k against
+    // 704 k hets/s, 64 blocking callers 62 k against 97 k. Kept as a switch with its parity test: what would make it pay is a
+    // dense-band kernel that fits beside three class wavefronts per SIMD (<= 40 registers), not a different moment.
+    const int route_mode = [] { const char* e = std::getenv("HP_WFA2_ROUTE"); return e ? std::atoi(e) : 0; }();
+    const bool route = bl_in && !lay.suspects.empty() && route_mode > 0 && (route_mode >= 2 || sets_aligning(device_id).load() == 0);
+    aligning_done();
+    aligning.store(true); sets_aligning(device_id).fetch_add(1);
     if ((rc = d_qhead.alloc(512)) != HP_OK) return rc;
     if ((uint64_t)cx.tag_next + n + 2 >= 0xFFFFFFF0ull || (cx.last_gen != 0 && cx.last_gen != w2_gen())) {   // (tags wrap; or the other generation's words could pass for tags)
         (void)hipStreamSynchronize(cs_->cstream[2]); (void)hipStreamSynchronize(cs_->c2x[0]); (void)hipStreamSynchronize(cs_->c2x[1]);   // (an earlier run's tail may still use its region)
@@ -882,6 +1011,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         CA.cls = d_cls.as<uint8_t>(); CA.blockcnt = d_blockcnt.as<uint32_t>(); CA.esc = d_esc; CA.job_cls = d_job_cls.as<uint8_t>();
         HP_HIP_CHECK(hipMemsetAsync(d_handed.p, 0, n, st));
         { const char* e = std::getenv("HP_WFA2_USE_W2"); CA.use_w2 = (e && e[0] == '0') ? 0u : 1u; }
+        CA.fmt = route ? d_fmt.as<uint8_t>() : nullptr;
         hipLaunchKernelGGL(hp_wfa2_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CA);
         hipLaunchKernelGGL(hp_wfa2_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CA);
         HP_HIP_CHECK(hipGetLastError());
@@ -890,6 +1020,8 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     // an empty class is not launched. Measured: launching each class with the whole batch's grid instead (no wait) cost
     // 3-4 ms of 22 - the W=8 class then spreads its few long jobs one per workgroup and holds LDS for idle groups.
     if ((rc = dev_copy(down.p + dn_cnt, d_counts, 16, st)) != HP_OK) return rc;   // (a kernel's store to pinned memory: a copy-engine transfer would queue behind the next set's upload)
+    const bool has_early = route;
+    if (has_early && (rc = dev_copy(info_pin, d_info.p, n * sizeof(W2Info), st)) != HP_OK) return rc;   // (the routed records' node counts: their results carry them)
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA graph-build kernel failed"); return HP_ERR_HIP; }
     const double t_built = w2_now_ms();
     W2Batch B{};
@@ -980,6 +1112,23 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         HP_HIP_CHECK(hipStreamWaitEvent(st, cx.cjoin[k], 0));
     }
     if (!two_phase) HP_HIP_CHECK(hipEventRecord(e3, st));
+    if (has_early) {   // the routed records' way out starts now (the expanded bases, the job table and the builder's verdicts are on the device)
+        early.ids = lay.suspects;
+        early.mask.assign(n, 0);
+        early.big = early.ids; early.big_ed.assign(early.ids.size(), (uint32_t)std::min<uint64_t>(max_ed, 0xFFFFFFu)); early.big_nodes.resize(early.ids.size());
+        for (size_t k = 0; k < early.ids.size(); ++k) {
+            const uint32_t i = early.ids[k];
+            early.mask[i] = 1;
+            early.big_nodes[k] = info_pin[i].status == W2B_OK ? info_pin[i].n_nodes : 0u;
+        }
+        early.dst = out; early.alleles = alleles; early.prune = prune_distance; early.max_ed = max_ed;
+        early.rc = HP_OK; early.err.clear(); early.n_settled = 0;
+        early.t_post = w2_now_ms();
+        g_routed_records.fetch_add(early.ids.size());
+        { std::lock_guard<std::mutex> lk(em); early.on = true; early.done = false; }
+        W2Session* self = this;
+        early_worker(device_id).post([self]() { self->early_pass(); });
+    }
     {
         W2MapArgs M{};
         M.jobs = d_jobs.as<W2Job>(); M.info = d_info.as<W2Info>(); M.n_jobs = (uint32_t)n; M.tags = d_tags.as<uint32_t>();
@@ -1021,6 +1170,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
             g_cu_partition = part == 2 ? 0 : part;
             int rcc = HP_OK;
             if (hipSetDevice(self->device_id) != hipSuccess || hipEventSynchronize(self->ev_c) != hipSuccess) { set_error("WFA kernel failed"); rcc = HP_ERR_HIP; }
+            self->aligning_done();
             if (rcc == HP_OK) rcc = self->collect_host();
             if (rcc == HP_OK && self->pend.on) self->pend.posted = true;
             {
@@ -1038,7 +1188,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
         });
         return HP_OK;
     }
-    if (hipStreamSynchronize(st) != hipSuccess) { set_error("WFA kernel failed"); return HP_ERR_HIP; }
+    { const bool okk = hipStreamSynchronize(st) == hipSuccess; aligning_done(); if (!okk) { set_error("WFA kernel failed"); return HP_ERR_HIP; } }
 #if W2_PROF
     (void)hipDeviceSynchronize();   // flushes the instrumented kernel's printf buffer
 #endif
@@ -1081,9 +1231,13 @@ int W2Session::collect_host() {
     pend = Pending{};
     pend.two_phase = two_phase; pend.dst = rs.out; pend.alleles = rs.alleles; pend.prune = rs.prune; pend.max_ed = rs.max_ed;
     pend.stream2 = rs.stream2; pend.ms_build = ms_build;
+    bool early_on;
+    { std::lock_guard<std::mutex> lk(em); early_on = early.on; }
+    const uint8_t* routed = early_on ? early.mask.data() : nullptr;
     pend.b2 = rs.b2; pend.large_groups = rs.large_groups; pend.n_cu = rs.n_cu;
     for (size_t i = 0; i < n; ++i) {
         if (info[i].status == W2B_INVARIANT) { set_error("graph construction assert (wfa_graph.rs:170,257,276,281) on job %zu", i); return HP_ERR_INVARIANT; }
+        if (routed && routed[i]) continue;   // (with the early pass since the launch set started; finish() delivers it: pend.ids below)
         if (status[i] == W2_ST_PENDING) { if (two_phase) { pend.held.push_back((uint32_t)i); pend.held_nodes.push_back(info[i].n_nodes); } else { pend.big.push_back((uint32_t)i); pend.big_ed.push_back(0); pend.big_nodes.push_back(info[i].status == W2B_OK ? info[i].n_nodes : 0u); } }
         else if (status[i] == W2_ST_NEED_BIG) { pend.big.push_back((uint32_t)i); pend.big_ed.push_back((uint32_t)(score[i] >> 8)); pend.big_nodes.push_back(info[i].status == W2B_OK ? (info[i].n_nodes | ((uint32_t)(score[i] & 0xFFu) << 24)) : 0u); }
     }
@@ -1103,6 +1257,7 @@ int W2Session::collect_host() {
     }
     pend.ids = pend.held;
     pend.ids.insert(pend.ids.end(), pend.big.begin(), pend.big.end());
+    if (routed) pend.ids.insert(pend.ids.end(), early.ids.begin(), early.ids.end());
     pend.on = !pend.ids.empty() || two_phase;
     return HP_OK;
 }
@@ -1162,6 +1317,126 @@ int W2Session::wait_collected() {
     return scatter();
 }
 
+// The leftovers' way out (everything in `big`): the reference-window test, then the dense-band pass for what it leaves. Runs on the
+// session's helper thread (late()) and, for the records the layout routed past the compact kernels, on the device's early worker.
+int W2Session::leftovers_out(std::vector<uint32_t>& big, std::vector<uint32_t>& big_ed, std::vector<uint32_t>& big_nodes, SubWork& sw, hp_wfa_result* dst,
+                             uint8_t* const* alleles, uint64_t prune, uint64_t max_ed, bool beside_launch_set, double* t_bound, size_t* n_settled, double* kernel_ms) {
+    if (!big.empty()) {
+        {   // ascending job order (with the hints)
+            std::vector<std::array<uint32_t, 3>> z(big.size());
+            for (size_t k = 0; k < z.size(); ++k) z[k] = {big[k], k < big_ed.size() ? big_ed[k] : 0u, k < big_nodes.size() ? big_nodes[k] : 0u};
+            std::sort(z.begin(), z.end());
+            big_ed.resize(z.size()); big_nodes.resize(z.size());
+            for (size_t k = 0; k < z.size(); ++k) { big[k] = z[k][0]; big_ed[k] = z[k][1]; big_nodes[k] = z[k][2]; }
+        }
+        // ---- the cheap exact verdict first (hp_wfa2_bound_kernel): a read that was deep into its alignment when the compact
+        // kernels let go of it, and whose distance to the reference window alone exceeds max_edit_distance + D, is a
+        // MaxEditDistance - no dense-band pass for it ----
+        {
+            const char* benv = std::getenv("HP_WFA2_BOUND");
+            // (every leftover is tested: a read that aligns within the threshold ends the test after about as many rounds as it has
+            // edits, and the noisy ones often leave the compact kernels early, on a full capped set. HP_WFA2_BOUND=n: only reads that
+            // had reached n edits; 1000000 turns the shortcut off)
+            const uint32_t min_ed = benv ? (uint32_t)std::max(0, std::atoi(benv)) : 0u;
+            std::vector<uint32_t> cand, thr, cand_pos;
+            for (size_t k = 0; k < big.size(); ++k) {
+                if (big_ed[k] < min_ed || Pending::nodes_of(big_nodes[k]) == 0) continue;
+                const hp_wfa_job j = job_header(big[k]);
+                uint64_t D = 0;
+                for (uint32_t v = 0; v < j.n_hets; ++v) D += std::max<uint64_t>({j.hets[v].ref_len, (j.hets[v].flags & 2u) ? j.hets[v].allele0_len : 0u, j.hets[v].allele1_len});
+                for (uint32_t v = 0; v < j.n_homs; ++v) D += std::max<uint64_t>({j.homs[v].ref_len, (j.homs[v].flags & 2u) ? j.homs[v].allele0_len : 0u, j.homs[v].allele1_len});
+                const uint64_t T = max_ed + D;
+                if (T > W2_BOUND_MAX_T) continue;
+                cand.push_back(big[k]); thr.push_back((uint32_t)T); cand_pos.push_back((uint32_t)k);
+            }
+            if (!cand.empty()) {
+                hipStream_t bs = thread_stream(device_id);
+                if (!bs) { set_error("stream creation failed"); return HP_ERR_HIP; }
+                DevBuf d_ids, d_thr, d_exc;
+                int rcb;
+                if ((rcb = d_ids.alloc(cand.size() * 4)) || (rcb = d_thr.alloc(cand.size() * 4)) || (rcb = d_exc.alloc(cand.size() + 16))) return rcb;
+                std::vector<uint8_t> exc(cand.size(), 0);
+                struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{bs};
+                struct IoDrain { hipStream_t s; ~IoDrain() { dev_io_abort(s); } } io{bs};
+                if ((rcb = dev_put(d_ids.p, cand.data(), cand.size() * 4, bs)) != HP_OK || (rcb = dev_put(d_thr.p, thr.data(), thr.size() * 4, bs)) != HP_OK) return rcb;
+                W2BoundArgs BA{};
+                BA.jobs = d_jobs.as<W2Job>(); BA.ids = d_ids.as<uint32_t>(); BA.thresh = d_thr.as<uint32_t>(); BA.n = (uint32_t)cand.size();
+                BA.seq = d_seq.as<uint8_t>(); BA.exceeds = d_exc.as<uint8_t>();
+                const uint32_t maxT = *std::max_element(thr.begin(), thr.end());
+                // LDS: the two wavefront arrays, then room for the longest tested read + its window (most of the CU's 160 KB: these
+                // are a few hundred single-wavefront workgroups, latency is what counts)
+                uint32_t need_seq = 0;
+                for (uint32_t i : cand) need_seq = std::max<uint32_t>(need_seq, ((dj[i].read_len + 31u) & ~15u) + ((dj[i].ref_len + 31u) & ~15u));
+                const size_t lds_wf = (size_t)(2 * (2 * maxT + 3) + 2) * 4 + 16;
+                BA.max_t = maxT;
+                // (beside a resident launch set - the early pass - a compute unit has one wavefront slot and 11-23 KB of LDS to spare: one
+                // wavefront per job, the sequences compared where they lie (L2), only the two wavefront arrays in LDS - 10 KB at T = 600.
+                // A workgroup of four wavefronts with 46 KB waited for a launch set to drain, i.e. for the moment the late pass starts at.)
+                BA.lds_seq = beside_launch_set ? 0u : std::min<uint32_t>(need_seq, W2_BOUND_LDS_SEQ);
+                const size_t lds_total = lds_wf + BA.lds_seq;
+                static const int bound_threads = [] { const char* e = std::getenv("HP_BOUND_THREADS"); return (e && std::atoi(e) == 64) ? 64 : 256; }();
+                {   // (once per device, and for the most any launch asks for: launches of several threads must not lower it under each other)
+                    static std::mutex attr_m;
+                    static std::map<int, hipError_t> attr_done;
+                    std::lock_guard<std::mutex> lk(attr_m);
+                    auto it = attr_done.find(device_id);
+                    if (it == attr_done.end()) {
+                        const int most = (int)((size_t)(2 * (2 * W2_BOUND_MAX_T + 3) + 2) * 4 + 16 + W2_BOUND_LDS_SEQ);
+                        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_bound_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+                        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_bound_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+                        it = attr_done.emplace(device_id, e).first;
+                    }
+                    HP_HIP_CHECK(it->second);
+                }
+                if (bound_threads == 64 || beside_launch_set) hipLaunchKernelGGL(hp_wfa2_bound_kernel<64>, dim3((unsigned)cand.size()), dim3(64), lds_total, bs, BA);
+                else hipLaunchKernelGGL(hp_wfa2_bound_kernel<256>, dim3((unsigned)cand.size()), dim3(256), lds_total, bs, BA);
+                HP_HIP_CHECK(hipGetLastError());
+                if ((rcb = dev_get(exc.data(), d_exc.p, cand.size(), bs)) != HP_OK) return rcb;
+                if (dev_io_sync(bs) != HP_OK) { set_error("WFA bound kernel failed"); return HP_ERR_HIP; }
+                std::vector<uint32_t> keep, keep_ed, keep_nodes;
+                size_t c = 0, settled = 0;
+                for (size_t k = 0; k < big.size(); ++k) {
+                    const bool tested = c < cand_pos.size() && cand_pos[c] == k;
+                    if (tested && exc[c]) {
+                        const uint32_t i = big[k];
+                        dst[i].status = HP_WFA_MAX_ED; dst[i].n_nodes = Pending::nodes_of(big_nodes[k]); dst[i].score = max_ed;
+                        if (alleles && alleles[i] && dj[i].n_hets) std::memset(alleles[i], HP_ALLELE_NOOVERLAP, dj[i].n_hets);
+                        ++settled;
+                        if (n_settled) ++*n_settled;
+                    } else { keep.push_back(big[k]); keep_ed.push_back(big_ed[k]); keep_nodes.push_back(big_nodes[k]); }
+                    if (tested) ++c;
+                }
+                big.swap(keep); big_ed.swap(keep_ed); big_nodes.swap(keep_nodes);
+                if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa2: %zu of %zu leftovers tested against the reference window alone, %zu settled as MaxEditDistance\n", cand.size(), cand.size() + big.size() - (cand.size() - settled), settled); fflush(stderr); }
+            }
+        }
+    }
+    if (t_bound) *t_bound = w2_now_ms();
+    if (!big.empty()) {
+        sw.sub.resize(big.size()); sw.sub_out.resize(big.size()); sw.sub_al.resize(big.size());
+        sw.ascii.clear();
+        for (size_t k = 0; k < big.size(); ++k) { sw.sub[k] = materialize(big[k], sw.ascii); sw.sub_al[k] = alleles ? alleles[big[k]] : nullptr; }
+        // a read that was past the narrow band's edit distance when the compact kernel let go of it starts at full width
+        g_wfa_min_ed_hint = big_ed.data();
+        const int rc = wfa_assign_batch_v1(sw.sub.data(), sw.sub.size(), prune, max_ed, sw.sub_out.data(), alleles ? sw.sub_al.data() : nullptr, device_id);
+        g_wfa_min_ed_hint = nullptr;
+        if (rc != HP_OK) return rc;
+        if (kernel_ms) *kernel_ms += g_last_kernel_ms;
+        if (const char* dbg = std::getenv("HP_DEBUG")) if (std::atoi(dbg) >= 2)   // what the dense-band pass was given, and what came of it
+            for (size_t k = 0; k < big.size(); ++k) {
+                const hp_wfa_job j = job_header(big[k]);
+                uint64_t D = 0, Dmax = 0;
+                for (uint32_t v = 0; v < j.n_hets; ++v) { const uint64_t x = std::max<uint64_t>({j.hets[v].ref_len, (j.hets[v].flags & 2u) ? j.hets[v].allele0_len : 0u, j.hets[v].allele1_len}); D += x; Dmax = std::max(Dmax, x); }
+                for (uint32_t v = 0; v < j.n_homs; ++v) { const uint64_t x = std::max<uint64_t>({j.homs[v].ref_len, (j.homs[v].flags & 2u) ? j.homs[v].allele0_len : 0u, j.homs[v].allele1_len}); D += x; Dmax = std::max(Dmax, x); }
+                fprintf(stderr, "[hp] dense job: read %u b, window %u b, %u + %u variants, D %llu (largest %llu), let go at %u edits, %u nodes -> status %d score %llu\n", dj[big[k]].read_len, dj[big[k]].ref_len,
+                        j.n_hets, j.n_homs, (unsigned long long)D, (unsigned long long)Dmax, big_ed[k], Pending::nodes_of(big_nodes[k]), sw.sub_out[k].status, (unsigned long long)sw.sub_out[k].score);
+            }
+        for (size_t k = 0; k < big.size(); ++k) dst[big[k]] = sw.sub_out[k];
+    }
+    big.clear(); big_ed.clear(); big_nodes.clear();
+    return HP_OK;
+}
+
 // The second collection (two phases) and the dense-band pass. Runs on the session's helper thread when run() deferred.
 int W2Session::late() {
     if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
@@ -1215,110 +1490,8 @@ int W2Session::late() {
         work_updates += s0; work_node_bytes += s1; work_read_bytes += s2w; work_jobs += s3;
         return HP_OK;
     };
-    // The leftovers' way out (everything in pend.big): the reference-window test, then the dense-band pass for what it leaves.
     auto dense_pass = [&]() -> int {
-        if (!pend.big.empty()) {
-            {   // ascending job order (with the hints)
-                std::vector<std::array<uint32_t, 3>> z(pend.big.size());
-                for (size_t k = 0; k < z.size(); ++k) z[k] = {pend.big[k], k < pend.big_ed.size() ? pend.big_ed[k] : 0u, k < pend.big_nodes.size() ? pend.big_nodes[k] : 0u};
-                std::sort(z.begin(), z.end());
-                pend.big_ed.resize(z.size()); pend.big_nodes.resize(z.size());
-                for (size_t k = 0; k < z.size(); ++k) { pend.big[k] = z[k][0]; pend.big_ed[k] = z[k][1]; pend.big_nodes[k] = z[k][2]; }
-            }
-            // ---- the cheap exact verdict first (hp_wfa2_bound_kernel): a read that was deep into its alignment when the compact
-            // kernels let go of it, and whose distance to the reference window alone exceeds max_edit_distance + D, is a
-            // MaxEditDistance - no dense-band pass for it ----
-            {
-                const char* benv = std::getenv("HP_WFA2_BOUND");
-                // (every leftover is tested: a read that aligns within the threshold ends the test after about as many rounds as it has
-                // edits, and the noisy ones often leave the compact kernels early, on a full capped set. HP_WFA2_BOUND=n: only reads that
-                // had reached n edits; 1000000 turns the shortcut off)
-                const uint32_t min_ed = benv ? (uint32_t)std::max(0, std::atoi(benv)) : 0u;
-                std::vector<uint32_t> cand, thr, cand_pos;
-                for (size_t k = 0; k < pend.big.size(); ++k) {
-                    if (pend.big_ed[k] < min_ed || Pending::nodes_of(pend.big_nodes[k]) == 0) continue;
-                    const hp_wfa_job j = job_header(pend.big[k]);
-                    uint64_t D = 0;
-                    for (uint32_t v = 0; v < j.n_hets; ++v) D += std::max<uint64_t>({j.hets[v].ref_len, (j.hets[v].flags & 2u) ? j.hets[v].allele0_len : 0u, j.hets[v].allele1_len});
-                    for (uint32_t v = 0; v < j.n_homs; ++v) D += std::max<uint64_t>({j.homs[v].ref_len, (j.homs[v].flags & 2u) ? j.homs[v].allele0_len : 0u, j.homs[v].allele1_len});
-                    const uint64_t T = pend.max_ed + D;
-                    if (T > W2_BOUND_MAX_T) continue;
-                    cand.push_back(pend.big[k]); thr.push_back((uint32_t)T); cand_pos.push_back((uint32_t)k);
-                }
-                if (!cand.empty()) {
-                    hipStream_t bs = thread_stream(device_id);
-                    if (!bs) { set_error("stream creation failed"); return HP_ERR_HIP; }
-                    DevBuf d_ids, d_thr, d_exc;
-                    int rcb;
-                    if ((rcb = d_ids.alloc(cand.size() * 4)) || (rcb = d_thr.alloc(cand.size() * 4)) || (rcb = d_exc.alloc(cand.size() + 16))) return rcb;
-                    std::vector<uint8_t> exc(cand.size(), 0);
-                    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{bs};
-                    struct IoDrain { hipStream_t s; ~IoDrain() { dev_io_abort(s); } } io{bs};
-                    if ((rcb = dev_put(d_ids.p, cand.data(), cand.size() * 4, bs)) != HP_OK || (rcb = dev_put(d_thr.p, thr.data(), thr.size() * 4, bs)) != HP_OK) return rcb;
-                    W2BoundArgs BA{};
-                    BA.jobs = d_jobs.as<W2Job>(); BA.ids = d_ids.as<uint32_t>(); BA.thresh = d_thr.as<uint32_t>(); BA.n = (uint32_t)cand.size();
-                    BA.seq = d_seq.as<uint8_t>(); BA.exceeds = d_exc.as<uint8_t>();
-                    const uint32_t maxT = *std::max_element(thr.begin(), thr.end());
-                    // LDS: the two wavefront arrays, then room for the longest tested read + its window (most of the CU's 160 KB: these
-                    // are a few hundred single-wavefront workgroups, latency is what counts)
-                    uint32_t need_seq = 0;
-                    for (uint32_t i : cand) need_seq = std::max<uint32_t>(need_seq, ((dj[i].read_len + 31u) & ~15u) + ((dj[i].ref_len + 31u) & ~15u));
-                    const size_t lds_wf = (size_t)(2 * (2 * maxT + 3) + 2) * 4 + 16;
-                    BA.max_t = maxT;
-                    BA.lds_seq = std::min<uint32_t>(need_seq, W2_BOUND_LDS_SEQ);
-                    const size_t lds_total = lds_wf + BA.lds_seq;
-                    static const int bound_threads = [] { const char* e = std::getenv("HP_BOUND_THREADS"); return (e && std::atoi(e) == 64) ? 64 : 256; }();
-                    if (bound_threads == 64) {
-                        HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_bound_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
-                        hipLaunchKernelGGL(hp_wfa2_bound_kernel<64>, dim3((unsigned)cand.size()), dim3(64), lds_total, bs, BA);
-                    } else {
-                        HP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_wfa2_bound_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
-                        hipLaunchKernelGGL(hp_wfa2_bound_kernel<256>, dim3((unsigned)cand.size()), dim3(256), lds_total, bs, BA);
-                    }
-                    HP_HIP_CHECK(hipGetLastError());
-                    if ((rcb = dev_get(exc.data(), d_exc.p, cand.size(), bs)) != HP_OK) return rcb;
-                    if (dev_io_sync(bs) != HP_OK) { set_error("WFA bound kernel failed"); return HP_ERR_HIP; }
-                    std::vector<uint32_t> keep, keep_ed, keep_nodes;
-                    size_t c = 0, settled = 0;
-                    for (size_t k = 0; k < pend.big.size(); ++k) {
-                        const bool tested = c < cand_pos.size() && cand_pos[c] == k;
-                        if (tested && exc[c]) {
-                            const uint32_t i = pend.big[k];
-                            pend.dst[i].status = HP_WFA_MAX_ED; pend.dst[i].n_nodes = Pending::nodes_of(pend.big_nodes[k]); pend.dst[i].score = pend.max_ed;
-                            if (pend.alleles && pend.alleles[i] && dj[i].n_hets) std::memset(pend.alleles[i], HP_ALLELE_NOOVERLAP, dj[i].n_hets);
-                            ++settled;
-                        } else { keep.push_back(pend.big[k]); keep_ed.push_back(pend.big_ed[k]); keep_nodes.push_back(pend.big_nodes[k]); }
-                        if (tested) ++c;
-                    }
-                    pend.big.swap(keep); pend.big_ed.swap(keep_ed); pend.big_nodes.swap(keep_nodes);
-                    if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] wfa2: %zu of %zu leftovers tested against the reference window alone, %zu settled as MaxEditDistance\n", cand.size(), cand.size() + pend.big.size() - (cand.size() - settled), settled); fflush(stderr); }
-                }
-            }
-        }
-        tl_bound = w2_now_ms();
-        if (!pend.big.empty()) {
-            pend.sub.resize(pend.big.size()); pend.sub_out.resize(pend.big.size()); pend.sub_al.resize(pend.big.size());
-            ascii_scratch.clear();
-            for (size_t k = 0; k < pend.big.size(); ++k) { pend.sub[k] = materialize(pend.big[k]); pend.sub_al[k] = pend.alleles ? pend.alleles[pend.big[k]] : nullptr; }
-            // a read that was past the narrow band's edit distance when the compact kernel let go of it starts at full width
-            g_wfa_min_ed_hint = pend.big_ed.data();
-            const int rc = wfa_assign_batch_v1(pend.sub.data(), pend.sub.size(), pend.prune, pend.max_ed, pend.sub_out.data(), pend.alleles ? pend.sub_al.data() : nullptr, device_id);
-            g_wfa_min_ed_hint = nullptr;
-            if (rc != HP_OK) return rc;
-            late_kernel_ms += g_last_kernel_ms;
-            if (const char* dbg = std::getenv("HP_DEBUG")) if (std::atoi(dbg) >= 2)   // what the dense-band pass was given, and what came of it
-                for (size_t k = 0; k < pend.big.size(); ++k) {
-                    const hp_wfa_job j = job_header(pend.big[k]);
-                    uint64_t D = 0, Dmax = 0;
-                    for (uint32_t v = 0; v < j.n_hets; ++v) { const uint64_t x = std::max<uint64_t>({j.hets[v].ref_len, (j.hets[v].flags & 2u) ? j.hets[v].allele0_len : 0u, j.hets[v].allele1_len}); D += x; Dmax = std::max(Dmax, x); }
-                    for (uint32_t v = 0; v < j.n_homs; ++v) { const uint64_t x = std::max<uint64_t>({j.homs[v].ref_len, (j.homs[v].flags & 2u) ? j.homs[v].allele0_len : 0u, j.homs[v].allele1_len}); D += x; Dmax = std::max(Dmax, x); }
-                    fprintf(stderr, "[hp] dense job: read %u b, window %u b, %u + %u variants, D %llu (largest %llu), let go at %u edits, %u nodes -> status %d score %llu\n", dj[pend.big[k]].read_len, dj[pend.big[k]].ref_len,
-                            j.n_hets, j.n_homs, (unsigned long long)D, (unsigned long long)Dmax, pend.big_ed[k], Pending::nodes_of(pend.big_nodes[k]), pend.sub_out[k].status, (unsigned long long)pend.sub_out[k].score);
-                }
-            for (size_t k = 0; k < pend.big.size(); ++k) pend.dst[pend.big[k]] = pend.sub_out[k];
-        }
-        pend.big.clear(); pend.big_ed.clear(); pend.big_nodes.clear();
-        return HP_OK;
+        return leftovers_out(pend.big, pend.big_ed, pend.big_nodes, late_sw, pend.dst, pend.alleles, pend.prune, pend.max_ed, false, &tl_bound, nullptr, &late_kernel_ms);
     };
     // What the two smaller classes' kernels left unaligned is known since run()'s collection: its way out starts NOW, beside the
     // largest class's kernel (the tail of the launch set: ~15 ms more on the bench workload), not after it - unless there is so much
@@ -1411,7 +1584,40 @@ int W2Session::late() {
     return HP_OK;
 }
 
+// The records the layout routed past the compact kernels: reference-window test (one wavefront per job, in place: it has to fit
+// beside the launch set that has just been queued), then the dense-band pass. On the device's early worker thread.
+void W2Session::early_pass() {
+    const bool trace = std::getenv("HP_STREAM_TRACE") != nullptr;
+    early.t_start = w2_now_ms();
+    early.t_bound = early.t_start;
+    const size_t n0 = early.big.size();
+    int rc = HP_OK;
+    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); rc = HP_ERR_HIP; }
+    if (rc == HP_OK) rc = leftovers_out(early.big, early.big_ed, early.big_nodes, early.sw, early.dst, early.alleles, early.prune, early.max_ed, true, &early.t_bound, &early.n_settled, nullptr);
+    early.t_done = w2_now_ms();
+    if (trace)
+        fprintf(stderr, "[hp] early: %zu records routed past the compact kernels; their pass started %.1f ms after the launch set was queued, the reference-window test had settled %zu after %.1f, the dense-band pass of the other %zu was done after %.1f (rc %d)\n",
+                n0, early.t_start - early.t_post, early.n_settled, early.t_bound - early.t_post, n0 - early.n_settled, early.t_done - early.t_post, rc);
+    {
+        std::lock_guard<std::mutex> lk(em);
+        early.rc = rc;
+        if (rc != HP_OK) early.err = hp_last_error();
+        early.done = true;
+    }
+    ecv.notify_all();
+}
+
 int W2Session::finish() {
+    const int rc = finish_late();
+    aligning_done();   // (every way out of a run ends here)
+    std::string err_late;
+    if (rc != HP_OK) err_late = hp_last_error();
+    const int rce = wait_early();   // (always joined: it writes the caller's result arrays)
+    if (rc != HP_OK) { set_error("%s", err_late.c_str()); return rc; }
+    return rce;
+}
+
+int W2Session::finish_late() {
     if (async_inflight) {   // run() did not wait: the helper thread collects and runs late() in one task
         helper->wait();
         async_inflight = false;

@@ -242,6 +242,7 @@ constexpr uint32_t W2_KIND_INTERIOR_READ = 3;  // ... and the read has bases lef
 constexpr uint32_t W2_KIND_END_LAST = 4;       // end of the LAST node with read left: only the +1 diagonal
 
 constexpr uint32_t W2_MAX_STEPS = 1u << 24;    // watchdog on the tiles of one job
+constexpr uint32_t W2_FMT_SUSPECT = 0x80u;       // bit of a job's format byte (block mode): routed past the compact kernels by the host (hp_wfa2.hip, layout_blocks)
 constexpr int W2_SET_STRIDE = 16;              // out_sets: 16 words per job (graphs of up to 512 nodes: W2Cfg<16, true>)
 constexpr int32_t W2_DIAG_LIM = 1 << 17;       // |diagonal| representable in a capped-set key
 constexpr uint32_t W2_LDS_LEN_LIM = 1u << 18;  // node length / 1024 edges / 7 children: what the packed LDS node descriptor holds

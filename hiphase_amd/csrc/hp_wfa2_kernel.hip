@@ -864,6 +864,8 @@ struct W2ClassArgs {
     uint32_t* esc;        // W2Batch::esc: [0] = [1] = jobs of the largest class, [2] = [3] = 0
     uint32_t use_w2;      // 0: graphs of at most 64 nodes join the middle class (one queue, one tail)
     uint8_t* job_cls;     // [n_jobs] by job id: 0..2, 3 = no class
+    const uint8_t* fmt;   // block mode (else null): bit 7 = the host routed this record past the compact kernels (W2_FMT_SUSPECT):
+                          // its way out - reference-window test, dense band - started when the set's launch set did
 };
 __global__ void __launch_bounds__(256) hp_wfa2_classify_kernel(W2ClassArgs A) {
     __shared__ uint32_t wcnt[4][4];
@@ -873,7 +875,8 @@ __global__ void __launch_bounds__(256) hp_wfa2_classify_kernel(W2ClassArgs A) {
     if (on) {
         const uint32_t i = A.len_order[t];
         const W2Info in = A.info[i];
-        if (in.status == W2B_OK && A.jobs[i].read_len < (uint32_t)W2_DIAG_LIM) {
+        const bool routed = A.fmt != nullptr && (A.fmt[i] & W2_FMT_SUSPECT) != 0u;
+        if (in.status == W2B_OK && A.jobs[i].read_len < (uint32_t)W2_DIAG_LIM && !routed) {
             if (A.use_w2 && in.n_nodes <= (uint32_t)W2Cfg<2>::MAXN && in.n_edges <= (uint32_t)W2Cfg<2>::MAXE) k = 0;
             else if (in.n_nodes <= (uint32_t)W2Cfg<4>::MAXN && in.n_edges <= (uint32_t)W2Cfg<4>::MAXE) k = 1;
             else if (in.n_nodes <= (uint32_t)W2Cfg<8>::MAXN && in.n_edges <= (uint32_t)W2Cfg<8>::MAXE) k = 2;
@@ -1049,7 +1052,7 @@ __global__ void __launch_bounds__(256) hp_wfa2_unpack_kernel(W2UnpackArgs A) {
         }
         return;
     }
-    const uint32_t odd = fm >> 4;
+    const uint32_t odd = (fm >> 4) & 1u;   // (bit 7: routed past the compact kernels, W2_FMT_SUSPECT - not this kernel's business)
     for (uint32_t o = lane * 16u; o < len; o += 64u * 16u) {
         uint64_t lo, hi;
         __builtin_memcpy(&lo, src + (o >> 1), 8);
@@ -1157,9 +1160,16 @@ __global__ void __launch_bounds__(W2_BOUND_THREADS) hp_wfa2_bound_kernel(W2Bound
     while (!done && s < T) {
         ++s;
         bool mine = false;
-        for (int32_t base = -s; base <= s; base += (int32_t)W2_BOUND_THREADS) {
+        // Only diagonals that can still reach the end cell's within the T - s edits that are left take part: |kend - k| <= T - s (every
+        // edit moves a path by at most one diagonal). Exact - a cell outside feeds only cells outside (its successors lie on k - 1, k,
+        // k + 1 one round later, where the allowance is one smaller), so every cell inside sees the predecessors it would have seen -
+        // and half the work: the triangle |k| <= s becomes the diamond between the start and the end cell. The cells a round reads
+        // just outside its range are last round's (computed: the range shrinks by one a side) or the rim (never written: NONE).
+        const int32_t left = T - s;
+        const int32_t klo = kend - left > -s ? kend - left : -s, khi = kend + left < s ? kend + left : s;
+        for (int32_t base = klo; base <= khi; base += (int32_t)W2_BOUND_THREADS) {
             const int32_t k = base + (int32_t)tid;
-            if (k <= s) {
+            if (k <= khi) {
                 const int32_t p0 = prev[k + T + 1], p1 = prev[k + 1 + T + 1], pm = prev[k - 1 + T + 1];
                 int32_t f = NONE;
                 if (p0 >= 0 && p0 + 1 <= n && p0 + 1 + k <= m) f = p0 + 1;          // substitution

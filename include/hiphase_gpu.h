@@ -426,6 +426,13 @@ void        hp_host_free(void* p);
 /* Bytes of such memory the copy engines have read in place since the library was loaded (0 = every set so far was staged: a
  * loader's check that its arena is the one the library sees). */
 uint64_t    hp_host_in_place_bytes(void);
+/* Records of block sets that took their way out of the alignment stage EARLY since the library was loaded (an experiment switch,
+ * HP_WFA2_ROUTE=1|2; 0 = never, the default: it measured slower): a record whose CIGAR (hp_block_record.local) begins
+ * an operation every 20 bases or less is heading for the neighbourhood of max_edit_distance (read_parsing.rs:564-575:
+ * Err(MaxEditDistance) -> local re-alignment, or an alignment of several hundred edits) and can be routed past the
+ * several-reads-per-wavefront kernels to the reference-window test and the one-read-per-wavefront kernel, beside the set's launch
+ * set instead of behind it. Routing only: the results are the same on every road. */
+uint64_t    hp_wfa_routed_records(void);
 /* Appends one block in the .hpbk capture format (hiphase_amd/block_io.py) to `path`: the solver's exact
  * input and - when h1, h2 and stats are given - the output the caller's own astar_solver produced for it. A HiPhase
  * built with this call at src/phaser.rs:541-543 writes the real HG002 blocks this repository cannot produce. */

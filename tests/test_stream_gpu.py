@@ -407,3 +407,64 @@ def test_eight_pipelines_with_bench_sized_sets_vs_oracle(monkeypatch):
     finally:
         lib.hp_blockstream_destroy(stream)
     assert used == set(range(8)) and checked > 20 * 200
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("case", ["routed", "into-an-idle-device", "over-the-cap", "off", "routed-reads-align"])
+def test_records_routed_past_the_compact_kernels_vs_oracle(case, monkeypatch):
+    """Round 5: a record whose CIGAR begins an operation every 20 bases or less (hp_block_record.local) is routed past the
+    several-reads-per-wavefront kernels when its set is laid out; its way out (reference-window test, dense band) runs on the
+    device's early worker beside the set's launch set, and finish() joins it (hp_wfa2.hip: W2Session::Early). Routing only - through
+    the one-call entry and through a stream two deep every field of every block equals the oracle's hpo_solve_block (reference
+    src/read_parsing.rs:520-637: Err(MaxEditDistance) -> local re-alignment), whether the records are routed, too many to be routed
+    (a noisy SET is the wide-table launch's), not routed at all, routed only into an idle device, or routed and then
+    ALIGNED by the dense band at a few hundred edits."""
+    from hiphase_amd.read_parsing import GlobalRealignmentConfig
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0")
+    # (HP_WFA2_ROUTE: 0 = never - the default, it measured slower on the bench: DESIGN.md 3.7 -, 1 = only while no other launch set of the
+    # device is being aligned, 2 = always)
+    monkeypatch.setenv("HP_WFA2_ROUTE", "1" if case == "into-an-idle-device" else "2")
+    if case == "over-the-cap":
+        monkeypatch.setenv("HP_WFA2_SUSPECT_MAX", "3")
+    if case == "off":
+        monkeypatch.setenv("HP_WFA2_SUSPECT_OPS", "0")
+    lib = _ffi.lib()
+    grc = GlobalRealignmentConfig(max_edit_distance=1500, wfa_prune_distance=1500) if case == "routed-reads-align" else None
+    prm = _params(2, 1000, 3, grc, True)
+    kw = dict(KW, noisy_fraction=0.04)
+    sets = [SynthSet(default_spec(lib, total_hets=700 + 150 * k, seed=1200 + k, seq_format=_ffi.SEQ_BAM4 if k != 1 else _ffi.SEQ_ASCII, **kw)) for k in range(3)]
+    exps = [oracle_outputs(s, prm) for s in sets]
+    before = lib.hp_wfa_routed_records()
+    got = sets[0].outputs()
+    _ffi.check(lib.hp_solve_blocks(sets[0].n, sets[0].inputs, C.byref(prm), got.arr, 0))
+    assert [b for b in range(sets[0].n) if not got.equal(exps[0], b)] == []
+    routed_one_call = lib.hp_wfa_routed_records() - before
+    st = C.c_int(0)
+    stream = lib.hp_blockstream_create(C.byref(prm), 0, 2, C.byref(st))
+    assert stream
+    try:
+        outs, tickets = [s.outputs() for s in sets], []
+        for s, o in zip(sets, outs):
+            if len(tickets) == 2:
+                _ffi.check(lib.hp_blockstream_wait(stream, tickets.pop(0), None, None))
+            t = C.c_uint64(0)
+            _ffi.check(lib.hp_blockstream_submit(stream, s.n, s.inputs, o.arr, C.byref(t)))
+            tickets.append(t.value)
+        for t in tickets:
+            _ffi.check(lib.hp_blockstream_wait(stream, t, None, None))
+    finally:
+        lib.hp_blockstream_destroy(stream)
+    for s, o, e in zip(sets, outs, exps):
+        assert [b for b in range(s.n) if not o.equal(e, b)] == []
+    routed = lib.hp_wfa_routed_records() - before
+    n_local = sum(outs[k].arr[b].local_aligned for k in range(3) for b in range(sets[k].n))
+    if case in ("routed", "routed-reads-align"):
+        assert routed_one_call > 10 and routed > 4 * 10
+    elif case == "into-an-idle-device":
+        assert routed_one_call > 10 and routed >= 2 * routed_one_call    # the one call and the stream's first set found the device idle
+    else:
+        assert routed == 0
+    if case == "routed-reads-align":
+        assert n_local < routed // 4      # most of the routed reads align within 1 500 edits: the dense band delivered their rows
+    else:
+        assert n_local > 30
