@@ -1070,9 +1070,15 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     if (gj_want) for (int k = 0; k < 2; ++k) { gjobs[k] = std::max<uint32_t>(gj_want, (cls_cnt[k] + cx.htab_groups - 1) / cx.htab_groups); capg[k] = cx.htab_groups; }
     if (cls_cnt[0]) grid_wg[0] = w2_grid<8, 2>(cls_cnt[0], n_cu, capg[0], gjobs[0]);
     if (cls_cnt[1]) grid_wg[1] = gsel == 16 ? w2_grid<16, 4>(cls_cnt[1], n_cu, capg[1], gjobs[1]) : gsel == 32 ? w2_grid<32, 4>(cls_cnt[1], n_cu, capg[1], gjobs[1]) : w2_grid<8, 4>(cls_cnt[1], n_cu, capg[1], gjobs[1]);
-    // (room for the jobs handed over: about 2 % of the two smaller classes on the round-3 bench workload - structural variants put a read's paths far apart; HP_WFA2_ESC_DIV to experiment)
+    // (room for the jobs handed over. Round 3 sized it for 2 % of the two smaller classes (1 200 hand-overs a set then); the third
+    // generation hands over 160-200 a set, and 2 100 groups of consumers - 575 workgroups that mostly sleep on their tickets - sat in
+    // exactly the wavefront slots the stream's reserve (HP_STREAM_RESERVE_PCT) is meant to leave to the neighbouring stages' kernels:
+    // the launch set asked for 3 427 of the device's 3 072 slots. Round 5, three runs a side: 1 / 64 of the smaller classes' jobs
+    // 2.36-2.39 M hets/s (class kernels' span 18.9-19.5 ms), 1 / 256: 2.43-2.45 M (17.9), 1 / 1 024: 2.44-2.50 M (18.0-18.2) - with
+    // the reserve really free its size no longer matters between 4 and 12 %. 1 / 512 (>= 192 groups): room for 530 hand-overs a set;
+    // what does not fit stays a leftover for the late pass, as ever. HP_WFA2_ESC_DIV to experiment.)
     const char* denv = std::getenv("HP_WFA2_ESC_DIV");
-    const uint32_t esc_div = denv ? (uint32_t)std::max(1, std::atoi(denv)) : 64u;
+    const uint32_t esc_div = denv ? (uint32_t)std::max(1, std::atoi(denv)) : 512u;
     const uint32_t items2 = escalate ? cls_cnt[2] + std::max<uint32_t>(4u * 48u, (cls_cnt[0] + cls_cnt[1]) / esc_div) : cls_cnt[2];
     // two phases: the results of everything the two smaller classes finished themselves are collected as soon as THEIR
     // kernels are done; the largest class (its own jobs + what was handed over, the tail of the launch set) is collected
