@@ -506,6 +506,19 @@ def main_path(args, rank, world, local_rank, dist, backend):
         d = sec - th0.get(tid, (name, 0.0))[1]
         if d > 0:
             by_thread[name] = by_thread.get(name, 0.0) + d
+    if os.environ.get("HP_BENCH_THREAD_DUMP"):   # which threads are the unnamed ones? (tid, CPU share, what the kernel says they wait in)
+        rows = []
+        for tid, (name, sec) in th1.items():
+            d = sec - th0.get(tid, (name, 0.0))[1]
+            if d / max(elapsed, 1e-9) >= 0.01:
+                def rd(f):
+                    try:
+                        return open(f"/proc/self/task/{tid}/{f}").read().strip().replace("\n", " | ")[:400]
+                    except OSError as e:
+                        return f"({e.strerror})"
+                rows.append((d / elapsed, tid, name, rd("comm"), rd("wchan"), rd("stack")))
+        for r in sorted(rows, reverse=True):
+            print("[bench] thread %s %-44s comm %-16s cpu %.3f wchan %s stack %s" % (r[1], r[2], r[3], r[0], r[4], r[5]), file=sys.stderr)
     host_cpu = {"process_cpu_s_per_wall_s": (cpu1 - cpu0) / elapsed if elapsed > 0 else None,
                 "by_thread_name_cpu_s_per_wall_s": {k: round(v / elapsed, 3) for k, v in sorted(by_thread.items(), key=lambda kv: -kv[1]) if v / elapsed >= 0.005},
                 "cgroup_throttled_periods": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0) if cg0 and cg1 else None,

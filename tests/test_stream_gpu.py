@@ -468,3 +468,4 @@ def test_records_routed_past_the_compact_kernels_vs_oracle(case, monkeypatch):
         assert n_local < routed // 4      # most of the routed reads align within 1 500 edits: the dense band delivered their rows
     else:
         assert n_local > 30
+
