@@ -19,6 +19,7 @@
 #include <thread>
 #include <vector>
 
+namespace hp { extern thread_local const uint32_t* g_wfa_min_ed_hint; }   // hp_wfa2_host.h: set while a block set's leftovers take their dense-band pass
 namespace hp {
 namespace {
 
@@ -512,8 +513,21 @@ int run_pass(const std::vector<HostJob>& hj, const std::vector<uint32_t>& ids, u
     if (slots == 0) slots = 1;
     if (g_ctx.device != cur_dev) { g_ctx.scratch.release(); g_ctx.device = cur_dev; g_ctx.dirty = true; }
     if (g_ctx.scratch.bytes < (size_t)slots * per_slot) {
-        if ((rc = g_ctx.scratch.alloc((size_t)slots * per_slot)) != HP_OK) return rc;
-        g_ctx.dirty = true;
+        // The band scratch does not grow for ONE pass's sake when it is a block set's leftovers that ask (g_wfa_min_ed_hint: the late pass
+        // of a stream): a pass's need is jobs x the widest band of any of them - 350 reads at 2-4 % noise x 10-35 MB on a HiFi-shaped
+        // set, different from set to set - and a hipMalloc inside a stream waits for the resident launch sets (round 5, HiFi-shaped
+        // bench: 8 of 28 late passes took 140-260 ms instead of 17-25, 1.3-1.6 M hets/s instead of 2 M+). The pass is served with the
+        // slots the scratch HOLDS - its workgroups take the jobs in turns, the kernel was written that way - as long as that is a
+        // reasonable number; the first such pass of a thread asks for HP_WFA_SCRATCH_FLOOR_MB (4 096) at once.
+        const size_t have = g_ctx.scratch.bytes / std::max<size_t>(per_slot, 1);
+        static const size_t floor_b = [] { const char* e = std::getenv("HP_WFA_SCRATCH_FLOOR_MB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 4096) << 20; }();
+        if (g_wfa_min_ed_hint && have >= std::min<size_t>(slots, 48)) slots = (uint32_t)std::min<size_t>(slots, have);
+        else {
+            size_t want = (size_t)slots * per_slot;
+            if (g_wfa_min_ed_hint && want < floor_b && floor_b <= free_b / 4) want = floor_b;
+            if ((rc = g_ctx.scratch.alloc(want)) != HP_OK) return rc;
+            g_ctx.dirty = true;
+        }
     }
     if (g_ctx.dirty) {
         HP_HIP_CHECK(hipMemsetAsync(g_ctx.scratch.p, 0, g_ctx.scratch.bytes, stm));

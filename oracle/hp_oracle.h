@@ -100,6 +100,7 @@ int        hpo_graph_edit_distance(const hpo_graph* g, const uint8_t* other, siz
  * out[0] min distance, [1] paths, [2] optimal paths, [3] union of their nodes (bit per node), [4] some optimal path lies inside wfa_mask. */
 int        hpo_graph_bruteforce(const hpo_graph* g, const uint8_t* other, size_t other_len, uint64_t wfa_mask, uint64_t out[5]);
 /* Full per-job path: graph build + WFA + allele mapping of read_parsing.rs:790-800. */
+void       hpo_wfa_hull_stats(uint64_t out[8], int reset);   /* measurement aid: hulls of live diagonals per (round, node) visit, hp_oracle_wfa.cpp */
 int        hpo_wfa_assign(const hp_wfa_job* job, uint64_t prune_distance, uint64_t max_ed,
                           hp_wfa_result* out, uint8_t* alleles);
 

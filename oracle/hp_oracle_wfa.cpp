@@ -179,6 +179,12 @@ struct SetTable {
     }
 };
 
+// What a dense-band kernel with lanes = a node's diagonals would execute (measurement aid, DESIGN.md 7: does a read's alignment have
+// more than one wavefront's worth of diagonals per node?): per (round, node) visit the hull of the diagonals that kept a wave.
+// [0] node visits, [1] sum of hull widths, [2] widest hull, [3] visits x ceil(width / 64), [4] visits x ceil(width / 256), [5] rounds,
+// [6] most nodes visited in one round, [7] visits with a hull wider than 64
+thread_local uint64_t g_hull_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 // wfa_graph.rs:350-650
 int edit_distance_with_pruning(const hpo_graph& g, const uint8_t* other, size_t other_len, uint64_t prune_distance,
                                uint64_t shuffle_seed, uint64_t* score_out, std::vector<size_t>* traversed_out) {
@@ -196,9 +202,11 @@ int edit_distance_with_pruning(const hpo_graph& g, const uint8_t* other, size_t 
     size_t edit_distance = 0, farthest_progression = 0, min_progression = 0;
 
     for (;;) {
+        uint64_t visits_this_round = 0;
         for (size_t node_index = 0; node_index < n_nodes; ++node_index) {
             auto act = active_wavefronts.find(node_index);
             if (act == active_wavefronts.end()) continue;
+            int64_t hull_lo = INT64_MAX, hull_hi = INT64_MIN;
             const std::vector<uint8_t>& node_sequence = g.nodes[node_index].sequence;
             const size_t node_length = node_sequence.size();
             DiagMap wavefront = std::move(act->second);
@@ -224,6 +232,7 @@ int edit_distance_with_pruning(const hpo_graph& g, const uint8_t* other, size_t 
                 size_t& maxfront_record = maxfront.emplace(other_start, 0).first->second;
                 if (max_offset < maxfront_record || (other_start + (int64_t)max_offset) < (int64_t)min_progression) continue;
                 maxfront_record = max_offset;
+                hull_lo = std::min(hull_lo, other_start); hull_hi = std::max(hull_hi, other_start);
                 farthest_progression = std::max(farthest_progression, (size_t)(other_start + (int64_t)max_offset));
 
                 std::vector<size_t> best_sets;
@@ -254,6 +263,12 @@ int edit_distance_with_pruning(const hpo_graph& g, const uint8_t* other, size_t 
                 }
             }
 
+            if (hull_lo <= hull_hi) {
+                const uint64_t w = (uint64_t)(hull_hi - hull_lo) + 1;
+                g_hull_stats[0] += 1; g_hull_stats[1] += w; g_hull_stats[2] = std::max(g_hull_stats[2], w);
+                g_hull_stats[3] += (w + 63) / 64; g_hull_stats[4] += (w + 255) / 256; g_hull_stats[7] += w > 64 ? 1 : 0;
+                ++visits_this_round;
+            }
             if (node_index == n_nodes - 1) {
                 std::vector<size_t> final_hashsets;
                 for (auto& kv : wavefront)
@@ -271,6 +286,7 @@ int edit_distance_with_pruning(const hpo_graph& g, const uint8_t* other, size_t 
                 }
             }
         }
+        g_hull_stats[5] += 1; g_hull_stats[6] = std::max(g_hull_stats[6], visits_this_round);
         edit_distance += 1;
         active_wavefronts = std::move(next_wavefronts);
         next_wavefronts.clear();
@@ -285,6 +301,11 @@ int edit_distance_with_pruning(const hpo_graph& g, const uint8_t* other, size_t 
 }  // namespace
 
 extern "C" {
+
+// the hull statistics above since the last call with reset != 0 (per thread: the calling thread's own alignments)
+void hpo_wfa_hull_stats(uint64_t out[8], int reset) {
+    for (int i = 0; i < 8; ++i) { out[i] = g_hull_stats[i]; if (reset) g_hull_stats[i] = 0; }
+}
 
 // sequence_alignment.rs:7-38
 uint64_t hpo_edit_distance(const uint8_t* v1, size_t l1, const uint8_t* v2, size_t l2) {
