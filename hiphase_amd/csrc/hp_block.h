@@ -101,7 +101,27 @@ struct hp_blockset {
     std::vector<hp_block_view> views;
     std::vector<size_t> kept;
     std::vector<char> unsupported;
-    ~hp_blockset() { if (batch) hp_batch_destroy(batch); if (wfa) hp::w2_session_destroy(wfa); }
+    // A SMALL set (the latency path: one wavefront per read, a pass or two of the dense-band kernel, 10-25 ms of waiting) inside a
+    // pipeline: its alignment runs on the slot's helper thread and is joined by the rows stage (small_join), so that the alignment
+    // stage - one thread - goes on with the next set: the passes of the sets in flight run side by side. Round 5: the blocking
+    // per-block callers' merged sets are all of this kind, and their stage 2 was busy all of the time.
+    bool small_async = false;                    // set by the pipeline that owns the slot
+    std::unique_ptr<hp::HelperThread> small_helper;
+    bool small_inflight = false;
+    int small_rc = 0;
+    std::string small_err;
+    double small_kernel_ms = 0.0;
+    std::vector<hp_wfa_job> small_jobs;
+    std::vector<std::vector<uint8_t>> small_ascii;
+    int small_join() {                           // waits for the helper's pass; its status
+        if (!small_inflight) return 0;
+        small_helper->wait();
+        small_inflight = false;
+        ms[6] = small_kernel_ms;
+        if (small_rc != 0) hp::set_error("%s", small_err.c_str());
+        return small_rc;
+    }
+    ~hp_blockset() { if (small_inflight && small_helper) small_helper->wait(); if (batch) hp_batch_destroy(batch); if (wfa) hp::w2_session_destroy(wfa); }
 };
 
 namespace hp {

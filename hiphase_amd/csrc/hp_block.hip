@@ -143,6 +143,7 @@ int hp::blockset_layout(hp_blockset* bs, size_t n_blocks, const hp_block_input* 
     // a set that failed between its alignment stage and blockset_rows' join may have left its late pass running: it writes
     // bs->wfa_out / bs->alleles and reads the previous caller's inputs - join it before any of that is reassigned
     if (bs->wfa) (void)w2_session_finish(bs->wfa);
+    if (bs->small_inflight && bs->small_helper) { bs->small_helper->wait(); bs->small_inflight = false; }   // (likewise a small set's pass on the slot's helper thread)
     bs->wfa_ready = false;
     bs->prep[0] = bs->prep[1] = bs->prep[2] = bs->prep[3] = 0.0;
     if (bs->meta.size() < n_blocks) bs->meta.resize(n_blocks);
@@ -529,14 +530,15 @@ int hp::blockset_wfa(hp_blockset* bs) {
         else {
             // a small set takes the latency path (dense-band kernel, one wavefront per read): the jobs as hp_wfa_assign_batch takes
             // them, BAM 4-bit reads decoded on the host (a few thousand reads at most)
-            std::vector<hp_wfa_job> jobs(ch.jobs.size());
-            std::vector<std::vector<uint8_t>> ascii;
+            std::vector<hp_wfa_job>& jobs = ch.small_jobs;
+            std::vector<std::vector<uint8_t>>& ascii = ch.small_ascii;
+            jobs.assign(ch.jobs.size(), hp_wfa_job{});
+            ascii.clear();
             for (size_t k = 0; k < ch.jobs.size(); ++k) {
                 const W2JobIn& ji = ch.jobs[k];
                 const hp_block_input& B = bs->in[ji.block];
                 const hp_block_record& rec = B.records[ji.rec];
                 hp_wfa_job& j = jobs[k];
-                j = hp_wfa_job{};
                 j.reference = B.reference; j.ref_base = B.ref_base;
                 j.ref_start = (uint64_t)rec.min_position; j.ref_end = (uint64_t)rec.max_position + 1;   // read_parsing.rs:772-773
                 j.hets = B.hets + ji.het_first; j.n_hets = ji.n_hets;
@@ -548,9 +550,24 @@ int hp::blockset_wfa(hp_blockset* bs) {
                     j.read = ascii.back().data();
                 } else j.read = rec.read_align + rec.read_offset;
             }
-            // (straight to the dense-band implementation, on this thread: the public entry would queue behind the call combiner)
-            rc = wfa_assign_batch_v1(jobs.data(), jobs.size(), bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(),
-                                     ch.allele_ptrs.data(), bs->device);
+            // (straight to the dense-band implementation: the public entry would queue behind the call combiner)
+            if (ch.small_async) {   // inside a pipeline: on the slot's helper thread, joined by the rows stage (hp_block.h)
+                if (!ch.small_helper) { ch.small_helper.reset(new HelperThread()); ch.small_helper->start(); }
+                ch.small_rc = HP_OK; ch.small_err.clear(); ch.small_kernel_ms = 0.0;
+                ch.small_inflight = true;
+                hp_blockset* self = bs;
+                const int part = g_cu_partition;
+                ch.small_helper->post([self, part]() {
+                    g_cu_partition = part == 2 ? 0 : part;
+                    self->small_rc = wfa_assign_batch_v1(self->small_jobs.data(), self->small_jobs.size(), self->prm.wfa_prune_distance, self->prm.max_edit_distance,
+                                                         self->wfa_out.data(), self->allele_ptrs.data(), self->device);
+                    if (self->small_rc != HP_OK) self->small_err = hp_last_error();
+                    self->small_kernel_ms = g_last_kernel_ms;
+                });
+                rc = HP_OK;
+            } else
+                rc = wfa_assign_batch_v1(jobs.data(), jobs.size(), bs->prm.wfa_prune_distance, bs->prm.max_edit_distance, ch.wfa_out.data(),
+                                         ch.allele_ptrs.data(), bs->device);
         }
         if (rc != HP_OK) return rc;
         // the three class instantiations of hp_wfa2_kernel run concurrently: their span is the kernel time of the stage
@@ -570,6 +587,7 @@ int hp::blockset_rows(hp_blockset* bs) {
     // the caller's inputs: it is joined on EVERY way out of this function - an error return must not leave it running under a
     // slot that is recycled, a merged set that is re-run request by request, or inputs the caller frees after the error
     struct LateJoin { hp_blockset* s; bool on; ~LateJoin() { if (on && s->wfa) (void)w2_session_finish(s->wfa); } } late_join{bs, has_wfa};
+    if ((rc = ch.small_join()) != HP_OK) return rc;   // (a small set's alignment ran on the slot's helper thread: blockset_wfa)
     {
         unsigned nt = host_threads(32u);   // measured: 16 -> 32 threads 6.0 -> 4.1 ms, 64 no better
         if (const char* e = std::getenv("HP_BLOCK_HOST_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));

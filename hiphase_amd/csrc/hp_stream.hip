@@ -166,7 +166,7 @@ hp::Pipeline* hp::pipeline_create(const hp_block_params* p, int device_id, uint3
     s->device = device_id < 0 ? hp_default_device() : device_id;
     if (s->device >= hp_device_count()) { set_error("device %d: %d visible", s->device, hp_device_count()); return fail(HP_ERR_ARG); }
     if (hipSetDevice(s->device) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", s->device); return fail(HP_ERR_HIP); }
-    for (uint32_t i = 0; i < depth; ++i) s->slots.emplace_back(new Slot());
+    for (uint32_t i = 0; i < depth; ++i) { s->slots.emplace_back(new Slot()); s->slots.back()->bs.small_async = !(std::getenv("HP_STREAM_SMALL_ASYNC") && std::getenv("HP_STREAM_SMALL_ASYNC")[0] == '0'); }   // (hp_block.h: small sets' alignment off the stage thread)
     for (int k = 0; k < Pipeline::N_THREADS; ++k) s->pool[k].reset(new WorkerPool());
     Pipeline* raw = s.get();
     // One thread per stage. Two experiment switches add a fifth thread: HP_STREAM_WFA_THREADS=2 (a second alignment thread with its
