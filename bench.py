@@ -161,7 +161,7 @@ def so_sha256():
 
 def measured_traffic(kernels, per_unit_key, units):
     """HBM bytes per launch from the PMC counters: only a measurement taken on THIS build of the library counts
-    (profiles/round4/traffic.json records the sha256 of the .so it was measured on); otherwise null. `kernels`: names to look
+    (profiles/round5/traffic.json records the sha256 of the .so it was measured on); otherwise null. `kernels`: names to look
     for, the first one the file holds wins (hp_wfa3_kernel, or hp_wfa2_kernel under HP_WFA_GEN=2)."""
     for rnd in ("round5", "round4", "round3"):
         try:
@@ -484,8 +484,13 @@ def main_path(args, rank, world, local_rank, dist, backend):
         return stages, works
 
     def period_of(done_at):
-        """median interval between consecutive completions, ms: the stream's steady-state period (ms_per_step = wall / steps also holds
-        the fill and drain of the stages, a fifth of a 20-step run)"""
+        """MEAN interval between consecutive completions, ms = (last completion - first completion) / (sets - 1): the stream's steady-state
+        period (ms_per_step = wall / steps also holds the first set's way through an empty stream, a fifth of a 20-step run). The mean, not
+        the median: with two threads in the last stage the completions come in bursts (a 4 ms interval, then a 36 ms one), and the median
+        of 19 such intervals read 17.6 ms - below what the set's bytes need on the PCIe link (round 5: roofline_pcie.frac 1.06)."""
+        return 1e3 * (done_at[-1] - done_at[0]) / (len(done_at) - 1) if len(done_at) > 1 else None
+
+    def period_median_of(done_at):
         gaps = sorted(b - a for a, b in zip(done_at, done_at[1:]))
         return 1e3 * gaps[len(gaps) // 2] if gaps else None
 
@@ -561,7 +566,11 @@ def main_path(args, rank, world, local_rank, dist, backend):
         for k in (k_wfa, k_astar):   # what actually crossed the HBM interface, next to the algorithmic figure
             k["traffic_gbs"] = k["traffic"] / (k["kernel_ms"] * 1e-3) / 1e9 if k["traffic"] and k["kernel_ms"] > 0 else None
             k["traffic_frac"] = k["traffic_gbs"] / HBM_PEAK_GBS if k["traffic_gbs"] else None
-        dom = k_wfa if k_wfa_ms >= k_astar_ms else k_astar
+        # the dominant kernel = the one that holds the device: the graph-WFA launch set (53.6 % of all kernel time in
+        # profiles/round5/path_kernel_stats.csv, 2.0e9 busy cycles a set, 92 % of the wavefront slots while it runs) - not the A* figure
+        # beside it, which is the LENGTH of a latency chain of a few hundred wavefronts on two streams (18.7 % of the kernel time, 5.5e8
+        # busy cycles) and can read longer than the launch set's span (round 5: 19.7 against 18.4 ms). Both are in `kernels`.
+        dom = k_wfa
         ms_step = elapsed / args.steps * 1e3
         period_ms = period_of(done_at)
         h2d = pre_h2d   # (measured by a subprocess before this process touched the GPU)
@@ -575,7 +584,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
             "metric": "het variants phased/sec, whole path, streamed (every step a new block set: records over PCIe -> graph-WFA -> rows -> A* -> span counts / haplotags)",
             "value": hets_timed * world / elapsed,
             "unit": "hets/s", "n_gpus": world if not args.inproc else n_pipes, "pipelines": n_pipes, "inproc": bool(args.inproc), "steps": args.steps, "warmup": args.warmup, "warmup_run": warm,
-            "ms_per_step": ms_step, "period_ms": period_ms, "first_completion_ms": (done_at[0] - t0) * 1e3 if done_at else None,
+            "ms_per_step": ms_step, "period_ms": period_ms, "period_median_ms": period_median_of(done_at), "first_completion_ms": (done_at[0] - t0) * 1e3 if done_at else None,
             "completion_intervals_ms": [round((b - a) * 1e3, 1) for a, b in zip(done_at, done_at[1:])],
             "first_sets_stage_ms": [[round(x, 1) for x in st_] for st_ in stages[:3]], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u64", "data": "synthetic", "host_cpu": host_cpu, "roofline_pcie": pcie,
