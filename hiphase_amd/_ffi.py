@@ -469,7 +469,8 @@ def lib():
     dll.hp_host_alloc.restype = C.c_void_p
     dll.hp_host_alloc.argtypes = [C.c_size_t]
     dll.hp_host_in_place_bytes.restype = C.c_uint64
-    dll.hp_wfa_routed_records.restype = C.c_uint64
+    if hasattr(dll, "hp_wfa_routed_records"):   # (HP_LIB may name an older build of the library)
+        dll.hp_wfa_routed_records.restype = C.c_uint64
     dll.hp_host_free.restype = None
     dll.hp_host_free.argtypes = [C.c_void_p]
     _lib = dll
