@@ -159,9 +159,32 @@ def so_sha256():
     return hashlib.sha256(open(_ffi.LIB_PATH, "rb").read()).hexdigest()
 
 
+def fatbin_sha256(path=None):
+    """sha256 of the library's DEVICE code (the ELF section .hip_fatbin): what a kernel's HBM traffic is a property of. A build that
+    differs from the profiled one on the host side only (round 5: a mutex around the teardown calls) runs the same kernels."""
+    import hashlib
+    import struct
+    from hiphase_amd import _ffi
+    try:
+        b = open(path or _ffi.LIB_PATH, "rb").read()
+        if b[:4] != b"\x7fELF" or b[4] != 2:
+            return None
+        shoff = struct.unpack_from("<Q", b, 0x28)[0]
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+        sh = lambda i: struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize)
+        stroff = sh(shstrndx)[4]
+        for i in range(shnum):
+            name_off, _, _, _, off, size = sh(i)[:6]
+            if b[stroff + name_off: b.index(b"\0", stroff + name_off)] == b".hip_fatbin":
+                return hashlib.sha256(b[off:off + size]).hexdigest()
+    except Exception:
+        pass
+    return None
+
+
 def measured_traffic(kernels, per_unit_key, units):
     """HBM bytes per launch from the PMC counters: only a measurement taken on THIS build of the library counts
-    (profiles/round5/traffic.json records the sha256 of the .so it was measured on); otherwise null. `kernels`: names to look
+    (profiles/round5/traffic.json records the sha256 of the .so it was measured on, and of its device code - .hip_fatbin -, which is what must match); otherwise null. `kernels`: names to look
     for, the first one the file holds wins (hp_wfa3_kernel, or hp_wfa2_kernel under HP_WFA_GEN=2)."""
     for rnd in ("round5", "round4", "round3"):
         try:
@@ -172,8 +195,8 @@ def measured_traffic(kernels, per_unit_key, units):
             e = tj.get(kernel)
             if not e:
                 continue
-            if e["so_sha256"] != so_sha256():
-                return None, "stale: measured on another build of libhiphase_gpu.so"
+            if e["so_sha256"] != so_sha256() and not (e.get("fatbin_sha256") and e["fatbin_sha256"] == fatbin_sha256()):
+                return None, "stale: measured on another build of libhiphase_gpu.so"   # (neither the library nor its device code match)
             return e[per_unit_key] * units, e["source"]
     return None, None
 

@@ -57,11 +57,24 @@ lines.append("")
 traffic = {"_comment": __doc__.strip().split("\n")[0] + " FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes; per step = total / launches.",
            "workload": bench["config"]["workload"], "launches": launches}
 sha = hashlib.sha256(open(os.path.join(root, "hiphase_amd", "libhiphase_gpu.so"), "rb").read()).hexdigest()
+def _fatbin_sha(path):   # the library's device code (.hip_fatbin): what the traffic is a property of (bench.py matches on either hash)
+    import struct
+    b = open(path, "rb").read()
+    shoff = struct.unpack_from("<Q", b, 0x28)[0]
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+    sh = lambda i: struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize)
+    stroff = sh(shstrndx)[4]
+    for i in range(shnum):
+        name_off, _, _, _, off, size = sh(i)[:6]
+        if b[stroff + name_off: b.index(b"\0", stroff + name_off)] == b".hip_fatbin":
+            return hashlib.sha256(b[off:off + size]).hexdigest()
+    return None
+fat = _fatbin_sha(os.path.join(root, "hiphase_amd", "libhiphase_gpu.so"))
 for g, unit, n in (("hp_wfa3_kernel", "bytes_per_read", reads), ("hp_wfa2_kernel", "bytes_per_read", reads), ("hp_astar_kernel", "bytes_per_het", hets), ("hp_heur_seg_kernel", "bytes_per_het", hets)):
     if (g, "FETCH_SIZE") in tot and (g, "WRITE_SIZE") in tot:
         b = (2.0 * tot[(g, "FETCH_SIZE")] + tot[(g, "WRITE_SIZE")]) * 1024.0 / launches
         traffic[g] = {unit: b / n, "hbm_bytes_per_step": b, "FETCH_SIZE_KB_per_step": tot[(g, "FETCH_SIZE")] / launches,
-                      "WRITE_SIZE_KB_per_step": tot[(g, "WRITE_SIZE")] / launches, "so_sha256": sha,
+                      "WRITE_SIZE_KB_per_step": tot[(g, "WRITE_SIZE")] / launches, "so_sha256": sha, "fatbin_sha256": fat,
                       "source": "profiles/round5/path_pmc_summary.txt"}
         lines.append(f"{g}: HBM traffic (FETCH x 2 + WRITE) = {b / 1e6:.1f} MB per step = {b / n:.0f} {unit.replace('_', ' ')}")
     w, a, wa, wi = (tot.get((g, c)) for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"))
