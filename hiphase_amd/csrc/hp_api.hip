@@ -275,7 +275,7 @@ hipStream_t thread_stream(int device_id) {
     // wavefront slots those kernels' retiring workgroups free go to the chain first (HP_CHAIN_PRIORITY=1; measured round 5: no effect on the first set's latency, 146-153 ms either way - off by default).
     static const int prio = [] { const char* e = std::getenv("HP_CHAIN_PRIORITY"); return e ? std::atoi(e) : 0; }();
     // (g_thread_stream_high: the device's early worker - hp_wfa2.hip - asks for a high-priority stream for the hardware QUEUE it comes
-    // with: a process streaming seven sets deep holds more streams than the runtime has queues (36 against GPU_MAX_HW_QUEUES = 24),
+    // with: a process may hold more streams than the runtime has queues (a stream seven sets deep: 23 of GPU_MAX_HW_QUEUES = 24; more with other entries in use),
     // streams of one priority share them, and a chain's kernels behind a persistent class kernel in one queue wait for it to end -
     // measured: the reference-window test 50-60 instead of 7-10 ms, and the class kernels behind a dense-band pass 23-27 instead of 19)
     if (hp_stream_create(&x.s, device_id, g_thread_stream_high ? 1 : prio) != hipSuccess) { x.s = nullptr; return nullptr; }
