@@ -163,3 +163,46 @@ def test_score_equals_path_enumeration(chunk):
         n_cases += 1
         ties += n_opt > 1
     assert n_cases == 1100 and ties > 50
+
+
+def test_hull_statistics_count_what_the_alignment_visits():
+    """hpo_wfa_hull_stats (oracle/hp_oracle_wfa.cpp): a measurement aid - per (round, node) visit the hull of the diagonals that kept a
+    wave (how wide a one-read-per-wavefront kernel's steps are). It must count and must not change a result: a read equal
+    to its reference visits one diagonal per node in round 0; a noisier read takes more rounds and wider hulls; the scores are the
+    plain edit distances either way (reference src/wfa_graph.rs:350-650)."""
+    import ctypes as C
+    from oracle_ffi import oracle
+    d = oracle()
+    d.hpo_wfa_hull_stats.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    d.hpo_wfa_hull_stats.restype = None
+    d.hpo_graph_new.restype = C.c_void_p
+    d.hpo_graph_new.argtypes = [C.c_uint64]
+    d.hpo_graph_add_node.restype = C.c_int64
+    d.hpo_graph_add_node.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t]
+    d.hpo_graph_free.argtypes = [C.c_void_p]
+    d.hpo_graph_edit_distance.restype = C.c_int
+    g = d.hpo_graph_new(1000)
+    try:
+        assert d.hpo_graph_add_node(g, b"ACGTACGTAC", 10, None, 0) == 0
+        par = (C.c_uint64 * 1)(0)
+        assert d.hpo_graph_add_node(g, b"GGTTAACCGG", 10, par, 1) == 1
+        st = (C.c_uint64 * 8)()
+        score = C.c_uint64(0)
+        trav = (C.c_uint64 * 4)()
+        ntrav = C.c_size_t(0)
+
+        def run(read):
+            d.hpo_wfa_hull_stats(st, 1)
+            d.hpo_graph_edit_distance.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
+            ntrav.value = 4
+            rc = d.hpo_graph_edit_distance(g, read, len(read), 2 ** 64 - 1, 0, C.byref(score), trav, C.byref(ntrav))
+            d.hpo_wfa_hull_stats(st, 0)
+            return rc, score.value, [int(x) for x in st]
+        rc, sc, a = run(b"ACGTACGTACGGTTAACCGG")
+        assert rc == 0 and sc == 0
+        assert a[0] == 2 and a[1] == 2 and a[2] == 1 and a[7] == 0                  # two node visits, one diagonal each
+        rc, sc, b = run(b"ACGTTCGTACGGTAACCGGA")
+        assert rc == 0 and sc == 3                                                  # one substitution, one deletion, one insertion
+        assert b[0] > a[0] and b[2] >= 2 and b[3] >= b[0] and b[4] <= b[3]          # more visits, wider hulls; chunk counts consistent
+    finally:
+        d.hpo_graph_free(g)
