@@ -315,6 +315,7 @@ EXPORTS = [
     "hp_version",
     "hp_set_coalescing",
     "hp_last_kernel_ms",
+    "hp_runtime_wait_mode",
     "hp_trim_device_cache",
     "hp_host_alloc",
     "hp_host_free",
@@ -465,6 +466,7 @@ def lib():
     dll.hp_last_error.restype = C.c_char_p
     dll.hp_version.restype = C.c_char_p
     dll.hp_last_kernel_ms.restype = C.c_double
+    dll.hp_runtime_wait_mode.restype = C.c_int
     dll.hp_trim_device_cache.restype = C.c_size_t
     dll.hp_host_alloc.restype = C.c_void_p
     dll.hp_host_alloc.argtypes = [C.c_size_t]

@@ -339,7 +339,7 @@ struct hp_batch {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     ~hp_batch() {
-        (void)hipSetDevice(device);
+        (void)hp_set_device(device);
         // the device buffers go back to the per-thread cache (hp_common.h), not to hipFree: nothing may still use them
         if (stream2) (void)hipStreamSynchronize(stream2);
         if (stream) (void)hipStreamSynchronize(stream);
@@ -656,7 +656,7 @@ hp_batch* hp_batch_create(size_t n_blocks, const hp_block_view* blks, const hp_a
     if (tot_words > 0xFFFFFFFFFFull) { set_error("batch too large"); return fail(HP_ERR_UNSUPPORTED); }
     // host-side validation/packing is done; from here on a GPU is mandatory
     if (device_id < 0) device_id = hp_default_device();
-    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return fail(HP_ERR_HIP); }
+    if (hp_set_device(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return fail(HP_ERR_HIP); }
     device_touched = true;
     std::unique_ptr<hp_batch> b(new hp_batch());
     b->device = device_id;
@@ -802,7 +802,7 @@ int fetch_all(hp_batch*, hipStream_t st, std::initializer_list<Fetch> fs) {
 
 int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     if (!b) { set_error("null batch"); return HP_ERR_ARG; }
-    HP_HIP_CHECK(hipSetDevice(b->device));
+    HP_HIP_CHECK(hp_set_device(b->device));
     hipStream_t st = stream ? (hipStream_t)stream : b->stream;
     std::vector<int32_t> status(b->n_blocks, ST_PENDING);
     { const int rc0 = dev_put(b->d_status.p, status.data(), status.size() * 4, st); if (rc0 != HP_OK) return rc0; }
@@ -887,7 +887,7 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
 
 int hp_batch_results(hp_batch* b, uint8_t* h1, uint8_t* h2, hp_phase_stats* stats, hp_work_counters* counters, uint64_t* heuristics) {
     if (!b) { set_error("null batch"); return HP_ERR_ARG; }
-    HP_HIP_CHECK(hipSetDevice(b->device));
+    HP_HIP_CHECK(hp_set_device(b->device));
     return fetch_all(b, b->stream, {{h1, b->d_h1.p, b->sum_n}, {h2, b->d_h2.p, b->sum_n}, {stats, b->d_stats.p, b->n_blocks * sizeof(hp_phase_stats)},
                                     {counters, b->d_counters.p, b->n_blocks * sizeof(hp_work_counters)}, {heuristics, b->d_H.p, b->sum_h * 8}});
 }
@@ -895,7 +895,7 @@ int hp_batch_results(hp_batch* b, uint8_t* h1, uint8_t* h2, hp_phase_stats* stat
 int hp_batch_postprocess(hp_batch* b, uint64_t* span_counts, uint8_t* haplotag, uint32_t* first_het) {
     if (!b) { set_error("null batch"); return HP_ERR_ARG; }
     if (!b->solved) { set_error("hp_batch_postprocess needs a successful hp_batch_solve first"); return HP_ERR_ARG; }
-    HP_HIP_CHECK(hipSetDevice(b->device));
+    HP_HIP_CHECK(hp_set_device(b->device));
     hipStream_t st = b->stream;
     int rc;
     if (!b->d_js.p) {

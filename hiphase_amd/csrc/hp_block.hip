@@ -983,7 +983,7 @@ private:
     }
     void feed(int v) {
         Dev& D = *devs_[(size_t)v];
-        (void)hipSetDevice(D.device);
+        (void)hp_set_device(D.device);
         for (;;) {
             {   // something to do?
                 std::unique_lock<std::mutex> lk(m_);
@@ -1046,7 +1046,7 @@ private:
     }
     void complete(int v) {
         Dev& D = *devs_[(size_t)v];
-        (void)hipSetDevice(D.device);
+        (void)hp_set_device(D.device);
         for (;;) {
             std::unique_ptr<MergedSet> ms;
             {

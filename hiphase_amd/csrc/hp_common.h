@@ -47,6 +47,18 @@ extern std::atomic<int> g_pipelines;   // block pipelines alive in this process 
 // threads (hp_wfa2.hip run(); set by the alignment stage of a block stream, 0 elsewhere)
 extern thread_local int g_wfa2_reserve_pct;
 
+// The library's one-time runtime setup (hp_api.hip), before its first stream / allocation / hipSetDevice in the process:
+// hipDeviceScheduleBlockingSync for every device whose primary context is NOT active yet. Every hipSetDevice of the library goes
+// through hp_set_device. (Round 6: the flag used to be set by hp_device_count() only - i.e. whenever an entry point that asks for
+// the device count was first called. Set on a device that already has streams, ROCm 7.2 does not refuse it (older runtimes
+// returned hipErrorSetOnActiveProcess): the device switches from spinning on completion signals to waiting for their
+// interrupt handlers, the signals of the streams that exist were created without interrupts,
+// hsa_amd_signal_async_handler() fails on them ("failed to set the handler!", AMD_LOG_LEVEL=1) and whoever waits for such a
+// command's completion through the handler path - hipHostFree / hipFree synchronising every stream - waits for ever. That was
+// the "kernel that never ends" of rounds 4-5: no kernel at all)
+void ensure_runtime_flags();
+hipError_t hp_set_device(int device_id);
+
 // number of compute units of a device, queried once (hipGetDeviceProperties costs milliseconds per call)
 int device_cu_count(int device_id);
 
@@ -221,6 +233,7 @@ struct PinBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
         const size_t want = std::max<size_t>(2 * n + 4096, (size_t)4 << 20);   // (growing pinned memory synchronises the device too: leave room - twice the need, 4 MB at least)
+        ensure_runtime_flags();
         g_device_syncing_allocs.fetch_add(1);
         if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
             p = nullptr;

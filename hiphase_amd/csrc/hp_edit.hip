@@ -127,7 +127,7 @@ extern "C" int hp_edit_distance_batch(const hp_ed_pair* pairs, size_t n, uint64_
     }
     bytes.resize(bytes.size() + 16, 0);
     if (device_id < 0) device_id = hp_default_device();
-    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
+    if (hp_set_device(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
     const int n_cu = partition_cu_count(device_id);
     // largest tables first (LPT). The order only balances the work list, so a counting sort over 65536 size classes
     // (O(n)) does as well as an exact sort

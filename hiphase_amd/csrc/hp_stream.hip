@@ -105,7 +105,7 @@ void hp::Pipeline::stage_thread(int t) {
 }
 
 void hp::Pipeline::stage_loop(int k) {
-    (void)hipSetDevice(device);
+    (void)hp_set_device(device);
     // CU partitions for the stages (hp_common.h) are an experiment switch, off by default. Measured on the bench workload: the
     // persistent graph-WFA kernels fill every compute unit (three wavefronts per SIMD is all their registers allow), so another
     // stage's kernels wait for their workgroups to leave - but binding graph-WFA to 7/8 of the CUs (with the other stages confined
@@ -165,7 +165,7 @@ hp::Pipeline* hp::pipeline_create(const hp_block_params* p, int device_id, uint3
     s->prm = *p;
     s->device = device_id < 0 ? hp_default_device() : device_id;
     if (s->device >= hp_device_count()) { set_error("device %d: %d visible", s->device, hp_device_count()); return fail(HP_ERR_ARG); }
-    if (hipSetDevice(s->device) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", s->device); return fail(HP_ERR_HIP); }
+    if (hp_set_device(s->device) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", s->device); return fail(HP_ERR_HIP); }
     for (uint32_t i = 0; i < depth; ++i) { s->slots.emplace_back(new Slot()); s->slots.back()->bs.small_async = !(std::getenv("HP_STREAM_SMALL_ASYNC") && std::getenv("HP_STREAM_SMALL_ASYNC")[0] == '0'); }   // (hp_block.h: small sets' alignment off the stage thread)
     for (int k = 0; k < Pipeline::N_THREADS; ++k) s->pool[k].reset(new WorkerPool());
     Pipeline* raw = s.get();

@@ -677,7 +677,7 @@ static int run_graphs(const std::vector<HostJob>& hj, uint64_t prune_distance, u
     const size_t n = hj.size();
     // host-side work is done; from here on a GPU is mandatory (no CPU fallback)
     if (device_id < 0) device_id = hp_default_device();
-    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
+    if (hp_set_device(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
     const int n_cu = device_cu_count(device_id);
     status.assign(n, WFA_ST_PENDING);
     score.assign(n, 0);

@@ -530,7 +530,7 @@ int W2Session::prepare(const hp_wfa_job* jobs_, size_t n_, int device) {
     // ---- from here on a GPU is mandatory (no CPU fallback) -------------------------------------------------------------
     if (device < 0) device = hp_default_device();
     device_id = device;
-    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
+    if (hp_set_device(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
     W2Context& cx = w2_context(device_id);
     W2Context::Streams* cs_ = nullptr;
     { const int rc0 = cx.streams(g_cu_partition, &cs_, false); if (rc0 != HP_OK) return rc0; }
@@ -769,7 +769,7 @@ int W2Session::upload_blocks(int device) {
     // ---- from here on a GPU is mandatory (no CPU fallback) -------------------------------------------------------------
     if (device < 0) device = hp_default_device();
     device_id = device;
-    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
+    if (hp_set_device(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed - no usable GPU; there is no CPU fallback", device_id); return HP_ERR_HIP; }
     W2Context& cx = w2_context(device_id);
     W2Context::Streams* cs_ = nullptr;
     { const int rc0 = cx.streams(g_cu_partition, &cs_, false); if (rc0 != HP_OK) return rc0; }
@@ -912,7 +912,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
     g_last_kernel_ms = 0.0;
     work_updates = work_node_bytes = work_read_bytes = work_jobs = 0;
     late_kernel_ms = 0.0;
-    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
+    if (hp_set_device(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
     const int n_cu = partition_cu_count(device_id);
     W2Context& cx = w2_context(device_id);   // (the calling thread's: need not be the thread that prepared the session)
     W2Context::Streams* cs_ = nullptr;
@@ -1175,7 +1175,7 @@ int W2Session::run(uint64_t prune_distance, uint64_t max_ed, hp_wfa_result* out,
             // dense-band pass of this set's leftovers launches on the whole device and runs where there is room)
             g_cu_partition = part == 2 ? 0 : part;
             int rcc = HP_OK;
-            if (hipSetDevice(self->device_id) != hipSuccess || hipEventSynchronize(self->ev_c) != hipSuccess) { set_error("WFA kernel failed"); rcc = HP_ERR_HIP; }
+            if (hp_set_device(self->device_id) != hipSuccess || hipEventSynchronize(self->ev_c) != hipSuccess) { set_error("WFA kernel failed"); rcc = HP_ERR_HIP; }
             self->aligning_done();
             if (rcc == HP_OK) rcc = self->collect_host();
             if (rcc == HP_OK && self->pend.on) self->pend.posted = true;
@@ -1445,7 +1445,7 @@ int W2Session::leftovers_out(std::vector<uint32_t>& big, std::vector<uint32_t>& 
 
 // The second collection (two phases) and the dense-band pass. Runs on the session's helper thread when run() deferred.
 int W2Session::late() {
-    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
+    if (hp_set_device(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); return HP_ERR_HIP; }
     const bool trace = std::getenv("HP_STREAM_TRACE") != nullptr;
     const double tl0 = w2_now_ms();
     double tl_early = tl0, tl_tail = tl0, tl_bound = tl0;
@@ -1598,7 +1598,7 @@ void W2Session::early_pass() {
     early.t_bound = early.t_start;
     const size_t n0 = early.big.size();
     int rc = HP_OK;
-    if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); rc = HP_ERR_HIP; }
+    if (hp_set_device(device_id) != hipSuccess) { set_error("hipSetDevice(%d) failed", device_id); rc = HP_ERR_HIP; }
     if (rc == HP_OK) rc = leftovers_out(early.big, early.big_ed, early.big_nodes, early.sw, early.dst, early.alleles, early.prune, early.max_ed, true, &early.t_bound, &early.n_settled, nullptr);
     early.t_done = w2_now_ms();
     if (trace)

@@ -410,6 +410,10 @@ int         hp_set_coalescing(int on);
  * dispatcher runs on a service thread and leaves this thread's value as it was - turn coalescing off
  * (hp_set_coalescing(0)) around a measurement, or use the stage times hp_blockstream_wait / hp_blockset_solve return. */
 double      hp_last_kernel_ms(void);
+/* How the library's host threads wait for the device: -1 not decided yet (no entry point has touched a device), 1 blocking
+ * (hipDeviceScheduleBlockingSync on every device - the library got to them before anything else in the process), 2 on some
+ * of them, 0 on none (the process had initialised the devices already: they keep their mode; or HP_BLOCKING_SYNC=0). */
+int         hp_runtime_wait_mode(void);
 /* The library keeps device buffers it has let go of in a process-wide cache (hipMalloc / hipFree wait for every kernel on the
  * device): at most 2/9 of the device's memory (HP_DEV_CACHE_GB overrides). hp_trim_device_cache frees all of it - for a host
  * application that shares the GPU with another allocator - and returns the bytes handed back. */

@@ -2,6 +2,7 @@
 (hpo_solve_block) on the same inputs: hp_solve_blocks and hp_blockstream_*, reads as ASCII and as BAM 4-bit, through the
 compact graph-WFA kernels and the dense-band ones. The sets carry everything the bench workload does: SV / tandem-repeat /
 multi-allelic calls, edit noise, reads that exceed max_edit_distance (local re-alignment fallback), supplementary records."""
+import os
 import ctypes as C
 
 import pytest
@@ -468,44 +469,3 @@ def test_records_routed_past_the_compact_kernels_vs_oracle(case, monkeypatch):
         assert n_local < routed // 4      # most of the routed reads align within 1 500 edits: the dense band delivered their rows
     else:
         assert n_local > 30
-
-
-
-@pytest.mark.skip(reason="KNOWN OPEN ISSUE (predates round 5, profiles/DIARY.md): hangs in hp_blockstream_destroy - a kernel of the asynchronous two-phase flow never "
-                         "ends once a generic-mode compact session has run on another thread earlier in the process; HP_WFA2_ASYNC=0 / HP_WFA2_TWO_PHASE=0 / "
-                         "HP_WFA2_ESCALATE=0 each cure it. Un-skip to reproduce (hangs within seconds); the suite's own order does not produce the sequence.")
-@pytest.mark.timeout(120)
-def test_stream_after_generic_compact_sessions_on_other_threads(monkeypatch):
-    """The sequence that hangs: hp_wfa_assign_batch through the compact kernels from worker threads (HiPhase's per-record form,
-    reference src/read_parsing.rs:769-780), then a block stream created, used and destroyed in the same process."""
-    import threading
-    from wfa_util import synth_wfa_job, wfa_assign_batch
-    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0")
-    specs = [synth_wfa_job(7100 + s, ref_len=1500 + 40 * s, n_vars=10, n_homs=3, noise=0.01)[0] for s in range(24)]
-    ts = [threading.Thread(target=lambda t=t: wfa_assign_batch(specs[t::4], prune_distance=500, max_edit_distance=500)) for t in range(4)]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    lib = _ffi.lib()
-    prm = _params(2, 1000, 3, None, True)
-    s = SynthSet(default_spec(lib, total_hets=700, seed=37, seq_format=_ffi.SEQ_ASCII, **KW))
-    exp = oracle_outputs(s, prm)
-    st = C.c_int(0)
-    stream = lib.hp_blockstream_create(C.byref(prm), 0, 3, C.byref(st))
-    assert stream
-    try:
-        outs = [s.outputs() for _ in range(4)]
-        tickets = []
-        for o in outs:
-            if len(tickets) == 3:
-                _ffi.check(lib.hp_blockstream_wait(stream, tickets.pop(0), None, None))
-            t = C.c_uint64(0)
-            _ffi.check(lib.hp_blockstream_submit(stream, s.n, s.inputs, o.arr, C.byref(t)))
-            tickets.append(t.value)
-        for t in tickets:
-            _ffi.check(lib.hp_blockstream_wait(stream, t, None, None))
-        for o in outs:
-            assert [b for b in range(s.n) if not o.equal(exp, b)] == []
-    finally:
-        lib.hp_blockstream_destroy(stream)
