@@ -610,7 +610,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
             "ms_per_step": ms_step, "period_ms": period_ms, "period_median_ms": period_median_of(done_at), "first_completion_ms": (done_at[0] - t0) * 1e3 if done_at else None,
             "completion_intervals_ms": [round((b - a) * 1e3, 1) for a, b in zip(done_at, done_at[1:])],
             "first_sets_stage_ms": [[round(x, 1) for x in st_] for st_ in stages[:3]], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/u64", "data": "synthetic", "host_cpu": host_cpu, "roofline_pcie": pcie,
+            "dtype": "u8/u64", "data": "synthetic", "host_cpu": host_cpu, "wait_mode": int(lib.hp_runtime_wait_mode()), "roofline_pcie": pcie,
             "config": {"workload": (f"synthetic read-bearing WGS-like block sets, one NEW set per step and GPU through hp_blockstream_* ({args.depth} sets in flight): "
                                     f"{info['blocks']} blocks, {info['hets']} hets (lognormal block sizes, median 15, max {info['max_block_hets']}), "
                                     f"{info['records']} records of {info['read_bases'] / max(1, info['records']):.0f} b mean at {args.coverage}x "
@@ -691,6 +691,25 @@ def main_path(args, rank, world, local_rank, dist, backend):
         dist.destroy_process_group()
 
 
+def _blocking_sync_through_torchs_runtime(device):
+    """hipSetDeviceFlags(hipDeviceScheduleBlockingSync) on the rank's device (None: every device) through the HIP runtime torch
+    loaded, before anything in the process has initialised a device. Best effort: a refusal leaves the runtime's default (spinning)."""
+    import ctypes as _C
+    import torch
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    try:
+        hip = _C.CDLL(path if os.path.exists(path) else "libamdhip64.so")
+        n = _C.c_int(0)
+        if hip.hipGetDeviceCount(_C.byref(n)) != 0:
+            return
+        for d in ([device] if device is not None else range(n.value)):
+            if 0 <= d < n.value and hip.hipSetDevice(d) == 0:
+                hip.hipSetDeviceFlags(4)   # hipDeviceScheduleBlockingSync
+        hip.hipSetDevice(device if device is not None and device < n.value else 0)
+    except OSError:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -728,9 +747,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     backend = os.environ.get("HP_BENCH_BACKEND", "nccl")   # "gloo": control-flow test of the N>1 path on a box with fewer GPUs
+    # N = 1: the library is the first (and only) user of the HIP runtime in this process and decides how host threads wait for the device
+    # (hipDeviceScheduleBlockingSync, hp_runtime_wait_mode). N > 1: torch comes first - its wheel bundles its own libamdhip64 under the
+    # same soname, and the library must bind to THAT copy (two HIP runtimes in one process: the second one finds no GPU) - so the
+    # wait mode is set through torch's runtime before torch initialises the device; the library then finds it set.
     if world > 1:
         import torch
         import torch.distributed as dist
+        _blocking_sync_through_torchs_runtime(local_rank if backend == "nccl" else None)
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -322,6 +322,8 @@ EXPORTS = [
     "hp_host_in_place_bytes",
     "hp_wfa_routed_records",
     "hp_abi_layout",
+    "hp_abi_sizeof",
+    "hp_abi_offsetof",
     "hp_hpbk_append",
     "hp_synth_block_size",
     "hp_synth_block",
@@ -335,6 +337,7 @@ EXPORTS = [
     "hp_outputs_create",
     "hp_outputs_array",
     "hp_outputs_destroy",
+    "hp_outputs_poison",
     "hp_block_output_equal",
     "hp_hpbr_append",
     "hp_hpbr_open",
@@ -374,6 +377,8 @@ def declare_common(dll):
     dll.hp_outputs_array.argtypes = [C.c_void_p]
     dll.hp_outputs_destroy.restype = None
     dll.hp_outputs_destroy.argtypes = [C.c_void_p]
+    dll.hp_outputs_poison.restype = None
+    dll.hp_outputs_poison.argtypes = [C.c_void_p, C.c_uint8]
     dll.hp_hpbr_append.restype = C.c_int
     dll.hp_hpbr_append.argtypes = [C.c_char_p, C.POINTER(BlockInput), C.POINTER(BlockParams), C.POINTER(BlockOutput)]
     dll.hp_hpbr_open.restype = C.c_void_p

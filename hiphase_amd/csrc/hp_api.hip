@@ -182,7 +182,11 @@ static void ensure_runtime_flags_impl(bool from_device_count) {
         for (int d = 0; d < n; ++d) {
             unsigned int flags = 0;
             int active = 1;
-            if (hipDevicePrimaryCtxGetState(d, &flags, &active) != hipSuccess || (active && !late_wait_mode())) continue;
+            if (hipDevicePrimaryCtxGetState(d, &flags, &active) != hipSuccess) continue;
+            if (active && !late_wait_mode()) {   // whoever initialised the device decided; it may well have decided the same
+                if ((flags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync) ++set;
+                continue;
+            }
             if (hipSetDevice(d) == hipSuccess) { moved = true; if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) == hipSuccess) ++set; }
         }
         g_wait_mode.store(n > 0 && set == n ? 1 : set > 0 ? 2 : 0);
@@ -430,28 +434,6 @@ extern "C" {
 
 const char* hp_last_error(void) { return hp::g_err.c_str(); }
 const char* hp_version(void) { return "hiphase_gpu 0.2.0 (gfx950)"; }
-// Capture side of the .hpbk format (hiphase_amd/block_io.py): a patched HiPhase calls this at
-// reference src/phaser.rs:541-543 with the solver's exact input and, after astar_solver returns, its output.
-int hp_hpbk_append(const char* path, const hp_block_view* blk, const hp_astar_params* p, const uint8_t* h1, const uint8_t* h2,
-                   const hp_phase_stats* stats) {
-    if (!path || !blk || !p) { hp::set_error("null argument"); return HP_ERR_ARG; }
-    FILE* f = std::fopen(path, "ab");
-    if (!f) { hp::set_error("cannot open %s for appending", path); return HP_ERR_ARG; }
-    const uint64_t N = blk->n_variants, R = blk->n_reads, cells = R ? blk->row_off[R] : 0;
-    const bool has_exp = h1 && h2 && stats;
-    static const unsigned char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool ok = true;
-    auto put = [&](const void* d, size_t n) { if (n) ok = ok && std::fwrite(d, 1, n, f) == n; const size_t pad = (8 - n % 8) % 8; if (pad) ok = ok && std::fwrite(zeros, 1, pad, f) == pad; };
-    const uint64_t hdr[10] = {p->block_index, N, R, cells, p->min_queue_size, p->queue_increment, has_exp ? 1u : 0u, 0, 0, 0};
-    ok = ok && std::fwrite("HPBK0001", 1, 8, f) == 8;
-    ok = ok && std::fwrite(hdr, 8, 10, f) == 10;
-    put(blk->read_start, R * 4); put(blk->read_end, R * 4); put(blk->row_off, (R + 1) * 8);
-    put(blk->alleles_2bit, (cells + 3) / 4); put(blk->quals, cells); put(blk->var_flags, N);
-    if (has_exp) { put(h1, N); put(h2, N); ok = ok && std::fwrite(stats, 8, 7, f) == 7; }
-    ok = (std::fclose(f) == 0) && ok;
-    if (!ok) { hp::set_error("short write to %s", path); return HP_ERR_ARG; }
-    return HP_OK;
-}
 int hp_set_coalescing(int on) {
     const int prev = hp::coalescing_enabled() ? 1 : 0;
     hp::g_coalesce.store(on ? 1 : 0, std::memory_order_relaxed);

@@ -57,6 +57,31 @@ thread_local std::string g_cap_err;
 
 extern "C" const char* hp_hpbr_last_error(void) { return g_cap_err.c_str(); }
 
+// (host-only like the rest of this file, so that libhiphase_capture.so - `make capture`, g++ alone - carries it: a capture
+// machine needs neither ROCm nor a GPU; errors of both writers are read with hp_hpbr_last_error)
+// Capture side of the .hpbk format (hiphase_amd/block_io.py): a patched HiPhase calls this at
+// reference src/phaser.rs:541-543 with the solver's exact input and, after astar_solver returns, its output.
+extern "C" int hp_hpbk_append(const char* path, const hp_block_view* blk, const hp_astar_params* p, const uint8_t* h1, const uint8_t* h2,
+                   const hp_phase_stats* stats) {
+    if (!path || !blk || !p) { g_cap_err = "null argument"; return HP_ERR_ARG; }
+    FILE* f = std::fopen(path, "ab");
+    if (!f) { g_cap_err = std::string("cannot open ") + path + " for appending"; return HP_ERR_ARG; }
+    const uint64_t N = blk->n_variants, R = blk->n_reads, cells = R ? blk->row_off[R] : 0;
+    const bool has_exp = h1 && h2 && stats;
+    static const unsigned char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool ok = true;
+    auto put = [&](const void* d, size_t n) { if (n) ok = ok && std::fwrite(d, 1, n, f) == n; const size_t pad = (8 - n % 8) % 8; if (pad) ok = ok && std::fwrite(zeros, 1, pad, f) == pad; };
+    const uint64_t hdr[10] = {p->block_index, N, R, cells, p->min_queue_size, p->queue_increment, has_exp ? 1u : 0u, 0, 0, 0};
+    ok = ok && std::fwrite("HPBK0001", 1, 8, f) == 8;
+    ok = ok && std::fwrite(hdr, 8, 10, f) == 10;
+    put(blk->read_start, R * 4); put(blk->read_end, R * 4); put(blk->row_off, (R + 1) * 8);
+    put(blk->alleles_2bit, (cells + 3) / 4); put(blk->quals, cells); put(blk->var_flags, N);
+    if (has_exp) { put(h1, N); put(h2, N); ok = ok && std::fwrite(stats, 8, 7, f) == 7; }
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) { g_cap_err = std::string("short write to ") + path; return HP_ERR_ARG; }
+    return HP_OK;
+}
+
 extern "C" int hp_hpbr_append(const char* path, const hp_block_input* B, const hp_block_params* P, const hp_block_output* E) {
     if (!path || !B || !P) { g_cap_err = "null argument"; return HP_ERR_ARG; }
     if (B->seq_format != HP_SEQ_ASCII && B->seq_format != HP_SEQ_BAM4) { g_cap_err = "unknown seq_format"; return HP_ERR_ARG; }
@@ -329,6 +354,24 @@ extern "C" hp_outputs* hp_outputs_create(const hp_block_input* in, size_t n) {
     return o.release();
 }
 extern "C" hp_block_output* hp_outputs_array(hp_outputs* o) { return o ? o->out.data() : nullptr; }
+// Fills everything a solve may write - every array to its capacity and every scalar result - with the byte `fill`, keeping the pointers
+// and the capacities: two output sets poisoned with DIFFERENT bytes can only compare equal in fields that were really written.
+extern "C" void hp_outputs_poison(hp_outputs* o, uint8_t fill) {
+    if (!o) return;
+    for (size_t b = 0; b < o->out.size(); ++b) {
+        auto& st = o->store[b];
+        auto fillv = [&](auto& v) { if (!v.empty()) std::memset(v.data(), fill, v.size() * sizeof v[0]); };
+        fillv(st.h1); fillv(st.h2); fillv(st.span_counts); fillv(st.seg_qname); fillv(st.seg_start); fillv(st.seg_end); fillv(st.seg_solver);
+        fillv(st.seg_haplotag); fillv(st.seg_first_het); fillv(st.seg_row_off); fillv(st.seg_alleles); fillv(st.seg_quals); fillv(st.edit_distances);
+        hp_block_output& O = o->out[b];
+        const hp_block_output keep = O;
+        std::memset(&O, fill, sizeof O);
+        O.h1 = keep.h1; O.h2 = keep.h2; O.span_counts = keep.span_counts; O.seg_qname = keep.seg_qname; O.seg_start = keep.seg_start; O.seg_end = keep.seg_end;
+        O.seg_solver = keep.seg_solver; O.seg_haplotag = keep.seg_haplotag; O.seg_first_het = keep.seg_first_het; O.seg_row_off = keep.seg_row_off;
+        O.seg_alleles = keep.seg_alleles; O.seg_quals = keep.seg_quals; O.seg_cell_cap = keep.seg_cell_cap; O.edit_distances = keep.edit_distances;
+        O.reserved = 0;
+    }
+}
 extern "C" void hp_outputs_destroy(hp_outputs* o) { delete o; }
 
 // every field hp_solve_blocks fills, block `b` of two output sets over the same inputs: 1 = identical

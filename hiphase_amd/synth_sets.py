@@ -72,6 +72,12 @@ class Outputs:
     def equal(self, other, b):
         return bool(self.dll.hp_block_output_equal(C.byref(self.inputs[b]), C.byref(self.arr[b]), C.byref(other.arr[b])))
 
+    def poison(self, fill):
+        """every array and scalar result filled with the byte `fill` (pointers and capacities kept): two sets poisoned with
+        different bytes can only compare equal in fields a solve really wrote"""
+        self.dll.hp_outputs_poison(self.h, fill)
+        return self
+
     def close(self):
         if self.h:
             self.dll.hp_outputs_destroy(self.h)

@@ -411,8 +411,9 @@ int         hp_set_coalescing(int on);
  * (hp_set_coalescing(0)) around a measurement, or use the stage times hp_blockstream_wait / hp_blockset_solve return. */
 double      hp_last_kernel_ms(void);
 /* How the library's host threads wait for the device: -1 not decided yet (no entry point has touched a device), 1 blocking
- * (hipDeviceScheduleBlockingSync on every device - the library got to them before anything else in the process), 2 on some
- * of them, 0 on none (the process had initialised the devices already: they keep their mode; or HP_BLOCKING_SYNC=0). */
+ * (hipDeviceScheduleBlockingSync on every device: set by the library on the devices nothing in the process had used, or found set on
+ * the ones the host had initialised), 2 on some of them, 0 on none (the host initialised the devices in another mode - they keep it:
+ * switching a device that has streams loses completions, DESIGN.md 5 - or HP_BLOCKING_SYNC=0). */
 int         hp_runtime_wait_mode(void);
 /* The library keeps device buffers it has let go of in a process-wide cache (hipMalloc / hipFree wait for every kernel on the
  * device): at most 2/9 of the device's memory (HP_DEV_CACHE_GB overrides). hp_trim_device_cache frees all of it - for a host
@@ -445,6 +446,10 @@ int         hp_hpbk_append(const char* path, const hp_block_view* blk, const hp_
 /* JSON: sizeof / alignof / offsetof of every struct in this header as the library was compiled (generated by
  * scripts/gen_abi_layout.py) - diff the #[repr(C)] side of a binding against it once at start-up. */
 const char* hp_abi_layout(void);
+/* The same numbers one at a time, for a binding without a JSON parser (patches/0001: the Rust side checks every #[repr(C)] struct it
+ * declares once at start-up): (size_t)-1 for a name the library does not know. */
+size_t      hp_abi_sizeof(const char* struct_name);
+size_t      hp_abi_offsetof(const char* struct_name, const char* field_name);
 
 /* Deterministic synthetic block generator of SURVEY.md §8(d) (splitmix64). Fills caller-provided
  * buffers sized via hp_synth_block_size(). Used by tests and bench.py on both legs. */
@@ -507,6 +512,9 @@ typedef struct hp_outputs hp_outputs;
 hp_outputs* hp_outputs_create(const hp_block_input* in, size_t n);
 hp_block_output* hp_outputs_array(hp_outputs* o);
 void hp_outputs_destroy(hp_outputs* o);
+/* every array (to its capacity) and every scalar result of every block filled with `fill`; pointers and capacities kept. Two sets
+ * poisoned with different bytes compare equal only in what a solve really wrote (tests). */
+void hp_outputs_poison(hp_outputs* o, uint8_t fill);
 /* 1 when two outputs of the same block hold the same results in every field hp_solve_blocks fills, else 0 */
 int hp_block_output_equal(const hp_block_input* in, const hp_block_output* a, const hp_block_output* b);
 /* `.hpbr`: READ-BEARING capture of phase blocks - everything hp_solve_blocks reads for a block (reference hull, variant calls,

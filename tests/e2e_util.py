@@ -74,3 +74,58 @@ def make_block(seed, ref_len=40000, n_hets=50, n_homs=10, n_reads=120, read_len=
         else:
             records.append(AlignedRecord(f"read{k}", a, b, bytes(noisy)))
     return bytes(ref), hets, homs, records, truth
+
+
+# ---- a second, independent comparator of two hp_block_output structs (pure Python, field by field) ------------------------------
+# Every whole-path parity claim of the suite and of bench.py goes through the product's hp_block_output_equal (compiled into the
+# library under test). This one shares nothing with it: it names the FIRST field that differs, compares every scalar, and every
+# array over the extent the outputs themselves declare. tests/test_comparator_cpu.py holds the two to each other, field class by
+# field class.
+def _arr(ptr, n):
+    return [ptr[i] for i in range(n)]
+
+
+def output_diff(inp, a, b):
+    """-> None when every field hp_solve_blocks fills is identical in a and b (two hp_block_output of the same hp_block_input),
+    else the name of the first differing field"""
+    N = inp.n_hets
+    scalars = ("status", "n_segments", "n_solver", "num_reads", "skipped_reads", "global_aligned", "local_aligned", "n_edit_distances", "num_alleles")
+    for f in scalars:
+        if getattr(a, f) != getattr(b, f):
+            return f
+    for f in ("exact_matches", "inexact_matches", "failed_matches", "allele0_matches", "allele1_matches"):
+        if tuple(getattr(a, f)) != tuple(getattr(b, f)):
+            return f
+    ne = a.n_edit_distances
+    if ne and _arr(a.edit_distances, ne) != _arr(b.edit_distances, ne):
+        return "edit_distances"
+    ns = a.n_segments
+    for f in ("seg_qname", "seg_start", "seg_end", "seg_solver"):
+        if ns and _arr(getattr(a, f), ns) != _arr(getattr(b, f), ns):
+            return f
+    if ns and _arr(a.seg_row_off, ns + 1) != _arr(b.seg_row_off, ns + 1):
+        return "seg_row_off"
+    cells = a.seg_row_off[ns] if ns else 0
+    if cells:
+        import ctypes as C
+        for f in ("seg_alleles", "seg_quals"):
+            if C.string_at(getattr(a, f), cells) != C.string_at(getattr(b, f), cells):
+                return f
+    if a.status != 0:
+        return None   # (an unsupported block carries its segments only)
+    for f in ("h1", "h2"):
+        if _arr(getattr(a, f), N) != _arr(getattr(b, f), N):
+            return f
+    if a.stats.as_tuple() != b.stats.as_tuple():
+        return "stats"
+    if N > 1 and _arr(a.span_counts, N - 1) != _arr(b.span_counts, N - 1):
+        return "span_counts"
+    for f in ("seg_haplotag", "seg_first_het"):
+        if ns and _arr(getattr(a, f), ns) != _arr(getattr(b, f), ns):
+            return f
+    return None
+
+
+def outputs_diff(sset, got, exp):
+    """[(block, first differing field)] over every block of a set"""
+    return [(b, f) for b in range(sset.n) for f in [output_diff(sset.inputs[b], got.arr[b], exp.arr[b])] if f is not None]
