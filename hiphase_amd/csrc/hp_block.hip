@@ -1031,13 +1031,18 @@ private:
                 if (rec < max_records()) take_from(any_q_, std::min(max_records(), rec + share));
             }
             if (ms->reqs.empty()) continue;
+            bool submitted = false;
             try {   // (the feeder must never take the host process down: a failed host allocation is these callers' status)
                 for (BlocksReq* r : ms->reqs) { ms->in.insert(ms->in.end(), r->in, r->in + r->n); ms->out.insert(ms->out.end(), r->out, r->out + r->n); }
                 ms->submit_rc = pipeline_submit(D.pipe, ms->in.size(), ms->in.data(), &ms->prm, ms->out.data(), &ms->ticket);
+                submitted = ms->submit_rc == HP_OK;
                 if (ms->submit_rc != HP_OK) ms->submit_err = hp_last_error();
                 std::lock_guard<std::mutex> lk(D.m);
                 D.inflight.push_back(std::move(ms));
             } catch (const std::exception& e) {
+                // (a set that IS in the pipeline - the hand-over to the completer is what failed - keeps reading ms->in and writing ms->out
+                // and the callers' buffers: it is waited for before anybody is told anything, and its slot is given back)
+                if (ms && submitted) (void)pipeline_wait(D.pipe, ms->ticket, nullptr, nullptr);
                 if (ms) for (BlocksReq* r : ms->reqs) { r->rc = HP_ERR_OOM; r->err = std::string("host allocation failed while merging a block set: ") + e.what(); r->finish(); }
                 continue;
             }

@@ -141,6 +141,9 @@ void hp::Pipeline::stage_loop(int k) {
                 else rc = blockset_solve(&s->bs, s->out);
                 if (rc != HP_OK) { s->rc = rc; s->err = hp_last_error(); }
             } catch (const std::exception& e) { s->rc = HP_ERR_OOM; s->err = std::string("host allocation failed in a pipeline stage: ") + e.what(); }
+            // (a set that fails travels on without its remaining stages - the rows stage, which joins a small set's alignment pass on the
+            // slot's helper thread, among them: joined here, before the caller is told and frees the inputs that pass reads)
+            if (s->rc != HP_OK) { const std::string keep = s->err; (void)s->bs.small_join(); s->err = keep; }
         }
         s->t_end[k] = st_now_ms();
         {

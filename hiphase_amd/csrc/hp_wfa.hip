@@ -288,7 +288,10 @@ struct StageBuf {
             // (pinning and unpinning host memory waits for the whole device - inside a block stream that is the other stages' persistent
             // kernels: a leftover pass whose tables outgrew its thread's staging by a few per cent stood still for 50-80 ms.
             // Hence the floor and the headroom: the passes of a stream's late results never grow it after their first.)
-            const size_t want = std::max<size_t>(2 * n + 4096, (size_t)64 << 20);   // (round 5: 64 MB, twice the need - a HiFi-shaped set leaves five hundred reads to this pass where the uniform workload leaves seventy-five, and how many varies from set to set: at 8 MB + half, a stream's tables grew three or four times, 100-370 ms of standing still each, some of them inside a timed region)
+            // (the 64 MB floor only on a thread that runs a block set's leftovers - g_wfa_min_ed_hint: the late / early pass; every other
+            // thread that comes here - a small set's helper per pipeline slot, a generic caller - keeps 8 MB: three such buffers per thread,
+            // and a depth-7 stream on eight pipelines pinned 2.7 GB of host memory for nothing)
+            const size_t want = std::max<size_t>(2 * n + 4096, (size_t)(g_wfa_min_ed_hint ? 64 : 8) << 20);   // (round 5: 64 MB, twice the need - a HiFi-shaped set leaves five hundred reads to this pass where the uniform workload leaves seventy-five, and how many varies from set to set: at 8 MB + half, a stream's tables grew three or four times, 100-370 ms of standing still each, some of them inside a timed region)
             g_device_syncing_allocs.fetch_add(1);
             if (hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault) != hipSuccess) {
                 p = nullptr;

@@ -134,9 +134,11 @@ struct EarlyWorker {
     std::mutex m;
     std::condition_variable cv;
     std::deque<std::function<void()>> q;
+    bool started = false;   // (not th.joinable(): the thread is detached, and a detached thread is never joinable - every post() started another one)
     void post(std::function<void()> f) {
         std::unique_lock<std::mutex> lk(m);
-        if (!th.joinable()) {
+        if (!started) {
+            started = true;
             th = std::thread([this]() {
                 (void)pthread_setname_np(pthread_self(), "hp-early");
                 g_thread_stream_high = true;   // (a hardware queue that no persistent class kernel sits in: hp_api.hip, thread_stream)
@@ -1609,8 +1611,8 @@ void W2Session::early_pass() {
         early.rc = rc;
         if (rc != HP_OK) early.err = hp_last_error();
         early.done = true;
+        ecv.notify_all();   // (under the lock: ~W2Session / wait_early may destroy the condition variable as soon as they see done)
     }
-    ecv.notify_all();
 }
 
 int W2Session::finish() {
