@@ -350,28 +350,41 @@ def pinned_h2d_gbs():
         return None
 
 
-def hifi_mix_own_process(args):
-    """Secondary line `hifi_mix`: this very bench with `--hifi` (HiFi-shaped errors: per-read rate lognormal around 0.2 %, a tail to
-    1-4 %, half of the errors homopolymer indels) in a process of its own, before this one touches the GPU - as a second stream
-    inside the headline's process it read 0.9-1.7 M hets/s (a new stream's buffers grow beside the old one's 17 GB of pinned sets)
-    where the same run on its own reads 2.4 M. Its own parity count: every block of its first timed set against the oracle."""
+def secondary_own_process(args, which):
+    """Secondary lines `hifi_mix` / `deep60`: this very bench with `--hifi` (HiFi-shaped errors: per-read rate lognormal around 0.2 %, a
+    tail to 1-4 %, half of the errors homopolymer indels) or `--deep60` (BASELINE.json configs[4]'s shape for the whole path: 60x, 15 % of the
+    cells carrying the other haplotype's allele so that the A* frontier prunes, every tandem-repeat het multi-allelic, 20 000 hets a set)
+    in a process of its own, before this one touches the GPU - as a second stream inside the headline's process a run read 0.9-1.7 M
+    hets/s (a new stream's buffers grow beside the old one's 17 GB of pinned sets) where the same run on its own reads 2.4 M. Its own
+    parity count: every block of its first timed set against the oracle."""
     import subprocess
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--hifi", "--no-resident", "--no-drop-in", "--no-hifi", "--no-pcie-probe",
-           "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", str(min(args.cpu_seconds, 3.0)), "--total-hets", str(args.total_hets),
+    hets = args.total_hets if which == "hifi" else max(2000, args.total_hets // 3)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--" + which, "--no-resident", "--no-drop-in", "--no-hifi", "--no-deep60", "--no-pcie-probe",
+           "--steps", str(args.steps if which == "hifi" else max(4, args.steps // 2)), "--warmup", str(args.warmup), "--cpu-seconds", str(min(args.cpu_seconds, 3.0)), "--total-hets", str(hets),
            "--max-block-hets", str(args.max_block_hets), "--seq-format", args.seq_format, "--depth", str(args.depth), "--host-memory", args.host_memory]
+    if which == "deep60":
+        cmd += ["--coverage", "60"]
     if args.no_cpu:
         cmd.append("--no-cpu")
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
         d = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:   # noqa: BLE001
         return {"error": repr(e)}
-    return {"value": d["value"], "unit": "hets/s", "steps": d["steps"], "ms_per_step": d["ms_per_step"], "period_ms": d.get("period_ms"), "first_completion_ms": d.get("first_completion_ms"),
-            "graph_wfa_kernels_ms": d["kernels"][0]["kernel_ms"], "astar_kernel_ms": d["kernels"][1]["kernel_ms"], "wave_updates_per_read": d["kernels"][0]["wave_updates_per_read"],
-            "reads_left_compact_path": d["kernels"][0]["reads_left_compact_path"], "records": d["config"]["records"], "hets_per_step": d["config"]["hets_per_step_per_gpu"],
-            "parity": d.get("parity"), "cpu_all_cores_hets_per_s": (d.get("cpu_baseline_all_cores") or {}).get("value"), "fallbacks": d.get("fallbacks"),
-            "measured_by": "python bench.py --hifi (its own process, before the headline's)",
-            "workload": "the headline's block mix with HiFi-shaped errors: per-read error rate lognormal (median 0.2 %, sigma 0.8, clamp 4 %), half of the errors homopolymer-run indels, no separate noisy class"}
+    out = {"value": d["value"], "unit": "hets/s", "steps": d["steps"], "ms_per_step": d["ms_per_step"], "period_ms": d.get("period_ms"), "first_completion_ms": d.get("first_completion_ms"),
+           "graph_wfa_kernels_ms": d["kernels"][0]["kernel_ms"], "astar_kernel_ms": d["kernels"][1]["kernel_ms"], "wave_updates_per_read": d["kernels"][0]["wave_updates_per_read"],
+           "reads_left_compact_path": d["kernels"][0]["reads_left_compact_path"], "records": d["config"]["records"], "hets_per_step": d["config"]["hets_per_step_per_gpu"],
+           "parity": d.get("parity"), "cpu_all_cores_hets_per_s": (d.get("cpu_baseline_all_cores") or {}).get("value"), "fallbacks": d.get("fallbacks"),
+           "stage_ms": d.get("stage_ms"), "roofline_pcie_frac": (d.get("roofline_pcie") or {}).get("frac"),
+           "measured_by": f"python bench.py --{which} (its own process, before the headline's)"}
+    if which == "hifi":
+        out["workload"] = "the headline's block mix with HiFi-shaped errors: per-read error rate lognormal (median 0.2 %, sigma 0.8, clamp 4 %), half of the errors homopolymer-run indels, no separate noisy class"
+    else:
+        out["pruned_solutions"] = d.get("pruned_solutions")
+        out["astar_cells_per_het"] = d["kernels"][1].get("cells_per_het")
+        out["workload"] = ("BASELINE.json configs[4]'s shape for the whole path (hp_synth_reads_deep60): 60x coverage, 15 % of the cells carry the other haplotype's allele (the A* frontier prunes: "
+                           "pruned_solutions > 0), every tandem-repeat het multi-allelic (allele0 itself an ALT: 22 % of the hets), 1 % of the reads past max_edit_distance, blocks up to the 4 165-het cap")
+    return out
 
 
 def host_cores():
@@ -431,7 +444,9 @@ def main_path(args, rank, world, local_rank, dist, backend):
     # `roofline_pcie`, and the per-block entries driven by 64 C++ threads for `drop_in`.
     pre_h2d = pinned_h2d_gbs() if (rank == 0 and world == 1 and not args.no_pcie_probe) else None
     pre_drop_in = drop_in_rates_cpp(args) if (rank == 0 and world == 1 and not args.no_drop_in) else None
-    pre_hifi = hifi_mix_own_process(args) if (rank == 0 and world == 1 and not args.no_hifi and not args.hifi and not args.replay and not args.inproc) else None
+    secondary_ok = rank == 0 and world == 1 and not args.hifi and not args.deep60 and not args.replay and not args.inproc
+    pre_hifi = secondary_own_process(args, "hifi") if (secondary_ok and not args.no_hifi) else None
+    pre_deep60 = secondary_own_process(args, "deep60") if (secondary_ok and not args.no_deep60) else None
     capture = None
     if args.replay:   # a .hpbr capture of real blocks: the same blocks every step, still crossing PCIe every step
         from hiphase_amd.synth_sets import Capture
@@ -451,7 +466,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
         for kv in args.spec:   # e.g. --spec edit_noise=0.003 --spec frac_sv=0
             key, val = kv.split("=", 1)
             over[key] = float(val)
-        sets.append(SynthSet(default_spec(lib, hifi=args.hifi, **dict(dict(seed=args.seed + 1000 * rank + k, total_hets=args.total_hets, max_block_hets=args.max_block_hets,
+        sets.append(SynthSet(default_spec(lib, hifi=args.hifi, deep60=args.deep60, **dict(dict(seed=args.seed + 1000 * rank + k, total_hets=args.total_hets, max_block_hets=args.max_block_hets,
                                                            coverage=float(args.coverage), seq_format=fmt, threads=gen_threads), **over))))
     n_pinned = 0
     if args.host_memory == "pinned" and not capture:   # the records' bases gathered in hp_host_alloc memory: read in place, nothing staged
@@ -682,8 +697,11 @@ def main_path(args, rank, world, local_rank, dist, backend):
             out["cpu_baseline"] = {"value": h1 / dt1, "unit": "hets/s", "cores": 1, "kind": "port",
                                    "sample": f"{len(done1)} blocks drawn at random from the first timed set ({h1} hets, {r1} records) through the whole path on the C++ restatement, single thread, {dt1:.1f}s"}
             out["fallbacks"] = {"local_aligned": int(sum(gpu_out.arr[b].local_aligned for b in range(s0.n))), "global_aligned": int(sum(gpu_out.arr[b].global_aligned for b in range(s0.n)))}
+            out["pruned_solutions"] = int(sum(gpu_out.arr[b].stats.pruned_solutions for b in range(s0.n) if gpu_out.arr[b].status == 0))   # (PhaseStats of the first timed set: > 0 = the A* frontier pruned, astar_phaser.rs:564-585)
         if pre_hifi is not None:
             out["hifi_mix"] = pre_hifi
+        if pre_deep60 is not None:
+            out["deep60"] = pre_deep60
         print(json.dumps(out), flush=True)
     if stream:
         lib.hp_blockstream_destroy(stream)
@@ -729,6 +747,8 @@ def main():
     ap.add_argument("--inproc", action="store_true", help="path workload: one process drives every visible device through ONE stream (hp_blockstream_create(device_id = -1)); steps = sets over all devices")
     ap.add_argument("--no-hifi", action="store_true", help="path workload: skip the secondary line on HiFi-shaped errors")
     ap.add_argument("--no-pcie-probe", action="store_true", help="path workload: skip the pinned host-to-device rate probe (roofline_pcie)")
+    ap.add_argument("--no-deep60", action="store_true", help="path workload: skip the secondary line on the 60x / conflicting-rows / multi-allelic set (BASELINE.json configs[4]'s shape)")
+    ap.add_argument("--deep60", action="store_true", help="path workload: the HEADLINE run on hp_synth_reads_deep60 (use with --coverage 60 --total-hets 20000)")
     ap.add_argument("--hifi", action="store_true", help="path workload: the HEADLINE run on the HiFi-shaped error model instead of uniform 0.5 %% (for profiling it)")
     ap.add_argument("--seed", type=int, default=20250928, help="path workload: seed of the synthetic block mix (rank r uses seed + r)")
     ap.add_argument("--blocks", type=int, default=6144, help="blocks per GPU (24 resident single-wave workgroups per CU x 256 CUs)")

@@ -280,6 +280,7 @@ class SynthReadsSpec(C.Structure):
         ("seq_format", C.c_uint32),
         ("threads", C.c_uint32),
         ("hifi_sigma", C.c_double), ("homopolymer_share", C.c_double),
+        ("allele_switch", C.c_double),
     ]
 
 
@@ -307,6 +308,7 @@ EXPORTS = [
     "hp_blockstream_destroy",
     "hp_blockstream_devices",
     "hp_synth_reads_hifi",
+    "hp_synth_reads_deep60",
     "hp_block_submit",
     "hp_block_wait",
     "hp_device_count",
@@ -359,6 +361,8 @@ def declare_common(dll):
     dll.hp_synth_reads_defaults.argtypes = [C.POINTER(SynthReadsSpec)]
     dll.hp_synth_reads_hifi.argtypes = [C.POINTER(SynthReadsSpec)]
     dll.hp_synth_reads_hifi.restype = None
+    dll.hp_synth_reads_deep60.argtypes = [C.POINTER(SynthReadsSpec)]
+    dll.hp_synth_reads_deep60.restype = None
     dll.hp_synth_reads_create.restype = C.c_void_p
     dll.hp_synth_reads_create.argtypes = [C.POINTER(SynthReadsSpec), C.POINTER(C.c_int)]
     dll.hp_synth_reads_inputs.restype = C.POINTER(BlockInput)

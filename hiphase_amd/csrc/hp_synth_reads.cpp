@@ -234,21 +234,29 @@ void build_block(const hp_synth_reads_spec& S, uint64_t block_index, uint32_t n_
         double noise = r.u01() < S.noisy_fraction ? S.noisy_noise : S.edit_noise;
         if (S.hifi_sigma > 0 && noise == S.edit_noise)   // per-read rate: lognormal around the median (one normal draw per read)
             noise = std::min(0.04, std::max(S.edit_noise / 20.0, S.edit_noise * std::exp(S.hifi_sigma * r.normal())));
+        // wrong-haplotype cells (allele_switch > 0; no draw otherwise: older sets stay byte-for-byte): the hets this read spans, flipped one by one
+        std::vector<uint8_t> switched;
+        if (S.allele_switch > 0) {
+            switched = carries[hap];
+            size_t vi = (size_t)(std::lower_bound(B.vars.begin(), B.vars.end(), a, [](const Var& v, int64_t p) { return v.pos < p; }) - B.vars.begin());
+            for (; vi < B.vars.size() && B.vars[vi].pos <= b; ++vi) if (B.vars[vi].het && r.u01() < S.allele_switch) switched[vi] ^= 1u;
+        }
+        const std::vector<uint8_t>& carried = S.allele_switch > 0 ? switched : carries[hap];
         const bool split = r.u01() < S.supplementary_fraction && b - a > 4000;
         if (split) {
             const int64_t mid = plain((a + b) / 2);
             if (mid > a + 10 && mid < b - 10) {
-                recs.emplace_back(); make_record(B, carries[hap], a, mid, noise, S.homopolymer_share, r, recs.back()); recs.back().qname = qn;
+                recs.emplace_back(); make_record(B, carried, a, mid, noise, S.homopolymer_share, r, recs.back()); recs.back().qname = qn;
                 // (the second record starts on the next plain base: mid + 1 may sit on a variant's first base)
                 int64_t a2 = mid + 1;
                 while (plain(a2) != a2 || [&] { auto it = std::lower_bound(B.vars.begin(), B.vars.end(), a2, [](const Var& v, int64_t p) { return v.pos < p; }); return it != B.vars.end() && it->pos == a2; }()) ++a2;
-                if (a2 < b) { recs.emplace_back(); make_record(B, carries[hap], a2, b, noise, S.homopolymer_share, r, recs.back()); recs.back().qname = qn; }
+                if (a2 < b) { recs.emplace_back(); make_record(B, carried, a2, b, noise, S.homopolymer_share, r, recs.back()); recs.back().qname = qn; }
                 ++qn;
                 continue;
             }
         }
         recs.emplace_back();
-        make_record(B, carries[hap], a, b, noise, S.homopolymer_share, r, recs.back());
+        make_record(B, carried, a, b, noise, S.homopolymer_share, r, recs.back());
         recs.back().qname = qn++;
     }
     std::stable_sort(recs.begin(), recs.end(), [](const RecTmp& x, const RecTmp& y) { return x.a < y.a; });   // BAM order
@@ -339,7 +347,7 @@ extern "C" void hp_synth_reads_defaults(hp_synth_reads_spec* s) {
     s->frac_snv = 0.85; s->frac_indel = 0.12; s->frac_sv = 0.01; s->frac_multiallelic = 0.25;   // the rest (.02): tandem repeats
     s->edit_noise = 0.005; s->noisy_fraction = 0.003; s->noisy_noise = 0.05; s->supplementary_fraction = 0.02;
     s->seq_format = HP_SEQ_BAM4; s->threads = 0;
-    s->hifi_sigma = 0.0; s->homopolymer_share = 0.0;
+    s->hifi_sigma = 0.0; s->homopolymer_share = 0.0; s->allele_switch = 0.0;
 }
 
 // The same workload with errors shaped like a HiFi run's (docs/performance.md:59-82 quotes HG002 HiFi data): per-read rate lognormal
@@ -352,11 +360,25 @@ extern "C" void hp_synth_reads_hifi(hp_synth_reads_spec* s) {
     s->noisy_fraction = 0.0;
 }
 
+// BASELINE.json configs[4]'s shape (60x HiFi, no down-sampling, multi-allelic sites, the A* frontier under stress) for the WHOLE path:
+// twice the rows per het, 15 % of the cells carrying the other haplotype's allele (conflicting rows: every large block prunes,
+// astar_phaser.rs:564-585), every tandem-repeat het a 1|2 genotype whose allele0 is itself an ALT (wfa_graph.rs:216-231: an
+// allele0 node per site; 22 % of the hets), 1 % of the reads past max_edit_distance. A third of the default set's hets: the
+// rows per het double and the search is several times the default's per het.
+extern "C" void hp_synth_reads_deep60(hp_synth_reads_spec* s) {
+    if (!s) return;
+    hp_synth_reads_defaults(s);
+    s->total_hets = 20000; s->coverage = 60.0;
+    s->frac_snv = 0.62; s->frac_indel = 0.14; s->frac_sv = 0.02; s->frac_multiallelic = 1.0;   // the rest (.22): tandem repeats, all multi-allelic
+    s->noisy_fraction = 0.01;
+    s->allele_switch = 0.15;
+}
+
 extern "C" hp_synth_set* hp_synth_reads_create(const hp_synth_reads_spec* spec, int* status) {
     auto fail = [&](int rc) -> hp_synth_set* { if (status) *status = rc; return nullptr; };
     if (!spec || spec->total_hets < 2 || spec->max_block_hets < 2 || !(spec->coverage > 0) || !(spec->read_mean >= 3000) || !(spec->het_spacing > 0) ||
         spec->frac_snv + spec->frac_indel + spec->frac_sv > 1.0 + 1e-9 || (spec->seq_format != HP_SEQ_ASCII && spec->seq_format != HP_SEQ_BAM4) ||
-        !(spec->hifi_sigma >= 0) || !(spec->homopolymer_share >= 0 && spec->homopolymer_share <= 1.0))
+        !(spec->hifi_sigma >= 0) || !(spec->homopolymer_share >= 0 && spec->homopolymer_share <= 1.0) || !(spec->allele_switch >= 0 && spec->allele_switch <= 0.5))
         return fail(HP_ERR_ARG);
     auto set = std::unique_ptr<hp_synth_set>(new hp_synth_set());
     set->spec = *spec;

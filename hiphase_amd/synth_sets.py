@@ -6,12 +6,13 @@ import ctypes as C
 from . import _ffi
 
 
-def default_spec(dll=None, hifi=False, **kw):
+def default_spec(dll=None, hifi=False, deep60=False, **kw):
     """The bench workload's spec (uniform 0.5 % edit noise); hifi=True: HiFi-shaped errors (hp_synth_reads_hifi: per-read rate
-    lognormal around 0.2 %, half of the errors homopolymer indels)."""
+    lognormal around 0.2 %, half of the errors homopolymer indels); deep60=True: BASELINE.json configs[4]'s shape (hp_synth_reads_deep60:
+    60x, 15 % wrong-haplotype cells, every tandem-repeat het multi-allelic)."""
     dll = dll or _ffi.lib()
     s = _ffi.SynthReadsSpec()
-    (dll.hp_synth_reads_hifi if hifi else dll.hp_synth_reads_defaults)(C.byref(s))
+    (dll.hp_synth_reads_deep60 if deep60 else dll.hp_synth_reads_hifi if hifi else dll.hp_synth_reads_defaults)(C.byref(s))
     for k, v in kw.items():
         if not hasattr(s, k):
             raise AttributeError(k)

@@ -491,9 +491,15 @@ typedef struct hp_synth_reads_spec {
      * that share of the errors are insertions / deletions of the run's base inside homopolymer runs (the dominant HiFi error),
      * the rest uniform substitutions / insertions / deletions as before. Both 0 (hp_synth_reads_defaults): the uniform model. */
     double   hifi_sigma, homopolymer_share;
+    /* Wrong-haplotype alleles (round 6: the deep-coverage frontier stress of BASELINE.json configs[4]). allele_switch > 0: at every
+     * het a record spans it carries the OTHER haplotype's allele with this probability (a miscalled / chimeric cell): the allele
+     * matrix then holds conflicting rows, the A* frontier grows and its pruning (astar_phaser.rs:564-585) gets to work - at 0.15 and
+     * 60x every large block prunes. 0 (the defaults): reads follow their haplotype, sets are byte-for-byte what they were. */
+    double   allele_switch;
 } hp_synth_reads_spec;
 typedef struct hp_synth_set hp_synth_set;
 void hp_synth_reads_defaults(hp_synth_reads_spec* s);   /* the bench workload: 60 000 hets, 30x, 15 kb reads, 0.5 % edit noise, BAM 4-bit */
+void hp_synth_reads_deep60(hp_synth_reads_spec* s);     /* configs[4]'s shape: 60x, 15 % wrong-haplotype cells, every tandem-repeat het multi-allelic (22 % of the hets), blocks up to the 4 165-het cap, 20 000 hets */
 void hp_synth_reads_hifi(hp_synth_reads_spec* s);       /* the same with HiFi-shaped errors: per-read rate lognormal (median 0.2 %, sigma 0.8), half of the errors homopolymer indels, no separate noisy class */
 hp_synth_set* hp_synth_reads_create(const hp_synth_reads_spec* s, int* status);
 const hp_block_input* hp_synth_reads_inputs(const hp_synth_set* s, size_t* n_blocks);

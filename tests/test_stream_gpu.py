@@ -471,3 +471,43 @@ def test_records_routed_past_the_compact_kernels_vs_oracle(case, monkeypatch):
         assert n_local < routed // 4      # most of the routed reads align within 1 500 edits: the dense band delivered their rows
     else:
         assert n_local > 30
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("gen", ["3", "2"])
+def test_deep60_sets_vs_oracle(gen, monkeypatch):
+    """BASELINE.json configs[4]'s shape through the WHOLE path (hp_synth_reads_deep60: 60x coverage, 15 % of the cells carrying the other
+    haplotype's allele - conflicting rows, so the A* frontier prunes, reference src/astar_phaser.rs:564-585 - every tandem-repeat het
+    multi-allelic, index_allele0 != 0, src/wfa_graph.rs:216-231, 1 % of the reads past max_edit_distance): the one-call entry and a block
+    stream three deep, both kernel generations, every field of every block against hpo_solve_block - with pruned_solutions > 0 in it."""
+    monkeypatch.setenv("HP_WFA2_MIN_JOBS", "0")
+    monkeypatch.setenv("HP_WFA_GEN", gen)
+    lib = _ffi.lib()
+    prm = _params(2, 1000, 3, None, True)
+    sets = [SynthSet(default_spec(lib, deep60=True, total_hets=1400, max_block_hets=500, seed=71 + k, seq_format=fmt))
+            for k, fmt in enumerate((_ffi.SEQ_BAM4, _ffi.SEQ_ASCII))]
+    exps = [oracle_outputs(s, prm) for s in sets]
+    assert sum(e.arr[b].stats.pruned_solutions for s, e in zip(sets, exps) for b in range(s.n)) > 100
+    assert sum(1 for s in sets for b in range(s.n) for v in range(s.inputs[b].n_hets) if s.inputs[b].hets[v].flags & 2) > 300
+    got = sets[0].outputs().poison(0x77)
+    _ffi.check(lib.hp_solve_blocks(sets[0].n, sets[0].inputs, C.byref(prm), got.arr, 0))
+    assert outputs_diff(sets[0], got, exps[0]) == [] and all(got.equal(exps[0], b) for b in range(sets[0].n))
+    st = C.c_int(0)
+    stream = lib.hp_blockstream_create(C.byref(prm), 0, 3, C.byref(st))
+    assert stream
+    try:
+        order = [0, 1, 0, 1]
+        outs, tickets = [sets[k].outputs().poison(0x33) for k in order], []
+        for k, o in zip(order, outs):
+            if len(tickets) == 3:
+                _ffi.check(lib.hp_blockstream_wait(stream, tickets.pop(0), None, None))
+            t = C.c_uint64(0)
+            _ffi.check(lib.hp_blockstream_submit(stream, sets[k].n, sets[k].inputs, o.arr, C.byref(t)))
+            tickets.append(t.value)
+        for t in tickets:
+            _ffi.check(lib.hp_blockstream_wait(stream, t, None, None))
+    finally:
+        lib.hp_blockstream_destroy(stream)
+    for k, o in zip(order, outs):
+        assert outputs_diff(sets[k], o, exps[k]) == []
+        assert [b for b in range(sets[k].n) if not o.equal(exps[k], b)] == []

@@ -129,3 +129,36 @@ def test_hifi_shaped_error_model():
     assert nu > 50 and nh > 30 and fh > fu + 0.2, (fu, nu, fh, nh)
     out = solve_all(d, h1)
     assert sum(out.arr[b].global_aligned for b in range(h1.n)) > 0.9 * h1.info["records"] * 0.9
+
+
+def test_deep60_shape_on_the_oracle():
+    """hp_synth_reads_deep60 (BASELINE.json configs[4]'s shape for the whole path): allele_switch = 0 leaves a set byte-for-byte what it
+    was; with it the matrix holds conflicting rows and the oracle's A* prunes (astar_phaser.rs:564-585) in the whole path; every
+    tandem-repeat het is multi-allelic (allele0 itself an ALT: wfa_graph.rs:216-231); deterministic."""
+    d = oracle()
+    kw = dict(total_hets=400, max_block_hets=200, seed=3, seq_format=_ffi.SEQ_ASCII)
+    base = SynthSet(default_spec(d, **kw), d)
+    same = SynthSet(default_spec(d, allele_switch=0.0, **kw), d)
+    assert base.info == same.info
+    for b in range(base.n):
+        for r in range(0, base.inputs[b].n_records, 5):
+            x, y = base.inputs[b].records[r], same.inputs[b].records[r]
+            assert x.read_len == y.read_len and C.string_at(x.read_align, x.read_len) == C.string_at(y.read_align, y.read_len)
+    a = SynthSet(default_spec(d, deep60=True, total_hets=700, max_block_hets=350, seed=5, seq_format=_ffi.SEQ_BAM4), d)
+    a2 = SynthSet(default_spec(d, deep60=True, total_hets=700, max_block_hets=350, seed=5, seq_format=_ffi.SEQ_BAM4, threads=1), d)
+    half = SynthSet(default_spec(d, deep60=True, total_hets=700, max_block_hets=350, seed=5, seq_format=_ffi.SEQ_BAM4, coverage=30.0), d)
+    assert a.info == a2.info and a.info["records"] > 1.8 * half.info["records"]    # twice the default's rows per het
+    multi = sum(1 for b in range(a.n) for v in range(a.inputs[b].n_hets) if a.inputs[b].hets[v].flags & 2)
+    tr = sum(1 for b in range(a.n) for v in range(a.inputs[b].n_hets) if a.inputs[b].het_types[v] == 9)
+    assert multi == tr and 0.12 * 700 < multi < 0.32 * 700
+    out = solve_all(d, a)
+    out2 = solve_all(d, a2)
+    assert all(out.equal(out2, b) for b in range(a.n))
+    assert sum(out.arr[b].stats.pruned_solutions for b in range(a.n)) > 0
+    assert sum(out.arr[b].local_aligned for b in range(a.n)) > 0
+    # the planted phase still comes back for most hets of the large blocks (15 % wrong cells at 60x)
+    big = max(range(a.n), key=lambda b: a.inputs[b].n_hets)
+    truth, h1 = a.truth(big), [out.arr[big].h1[i] for i in range(a.inputs[big].n_hets)]
+    agree = sum(1 for t, h in zip(truth, h1) if h < 2 and t == h)
+    n = sum(1 for h in h1 if h < 2)
+    assert n > 0.5 * len(h1) and max(agree, n - agree) > 0.8 * n
