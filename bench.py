@@ -567,10 +567,16 @@ def main_path(args, rank, world, local_rank, dist, backend):
                 "cgroup_throttled_periods": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0) if cg0 and cg1 else None,
                 "cgroup_throttled_ms": (cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e3 if cg0 and cg1 else None,
                 "note": "host side of the timed region: CPU seconds the process used per second of wall time, and how often the container's CPU quota froze its threads (cpu.stat)"}
-    if dist is not None:
-        from hiphase_amd.shard import max_over_ranks
-        elapsed = max_over_ranks(dist, elapsed, device="cuda" if backend == "nccl" else "cpu")   # timing only; no block data crosses ranks
     hets_timed = sum(sets[k % n_sets].info["hets"] for k in range(warm, warm + args.steps))
+    per_rank = None
+    if dist is not None:
+        from hiphase_amd.shard import gather_per_rank, max_over_ranks
+        dev_ = "cuda" if backend == "nccl" else "cpu"
+        # every rank's own clock, hets and host share, so that a scaling run explains itself: a rank that ran slower than the others
+        # (host contention: N generators and N x 3.4 CPU-seconds per second on one host) shows here, not only in the maximum
+        rows_ = gather_per_rank(dist, [elapsed, hets_timed, host_cpu["process_cpu_s_per_wall_s"] or 0.0, float(lib.hp_runtime_wait_mode())], device=dev_)
+        per_rank = [{"rank": r_, "elapsed_s": e_, "hets_per_s": h_ / e_ if e_ > 0 else None, "host_cpu_s_per_wall_s": c_, "wait_mode": int(w_)} for r_, (e_, h_, c_, w_) in enumerate(rows_)]
+        elapsed = max_over_ranks(dist, elapsed, device=dev_)   # timing only; no block data crosses ranks
     if rank == 0:
         st_mean = np.mean(np.asarray(stages), axis=0)
         work = dict(zip(("wfa_reads", "wfa_read_bytes", "wfa_node_bytes", "wfa_updates", "astar_cells", "astar_evals", "hets", "rows"),
@@ -625,7 +631,7 @@ def main_path(args, rank, world, local_rank, dist, backend):
             "ms_per_step": ms_step, "period_ms": period_ms, "period_median_ms": period_median_of(done_at), "first_completion_ms": (done_at[0] - t0) * 1e3 if done_at else None,
             "completion_intervals_ms": [round((b - a) * 1e3, 1) for a, b in zip(done_at, done_at[1:])],
             "first_sets_stage_ms": [[round(x, 1) for x in st_] for st_ in stages[:3]], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/u64", "data": "synthetic", "host_cpu": host_cpu, "wait_mode": int(lib.hp_runtime_wait_mode()), "roofline_pcie": pcie,
+            "dtype": "u8/u64", "data": "synthetic", "host_cpu": host_cpu, "wait_mode": int(lib.hp_runtime_wait_mode()), "per_rank": per_rank, "roofline_pcie": pcie,
             "config": {"workload": (f"synthetic read-bearing WGS-like block sets, one NEW set per step and GPU through hp_blockstream_* ({args.depth} sets in flight): "
                                     f"{info['blocks']} blocks, {info['hets']} hets (lognormal block sizes, median 15, max {info['max_block_hets']}), "
                                     f"{info['records']} records of {info['read_bases'] / max(1, info['records']):.0f} b mean at {args.coverage}x "

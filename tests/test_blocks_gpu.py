@@ -178,6 +178,7 @@ def test_bench_path_two_ranks_gloo():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["hets_per_step_per_gpu"] == 2500
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and all(r["hets_per_s"] > 0 and r["elapsed_s"] <= out["ms_per_step"] * out["steps"] / 1e3 + 1e-6 for r in out["per_rank"])
 
 
 @pytest.mark.timeout(900)
