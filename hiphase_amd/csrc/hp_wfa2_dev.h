@@ -338,11 +338,19 @@ template <int W, bool WIDE = false> struct W3Cfg {
     static constexpr int O_Q = a16(O_A + 2 * 8 * SLOTS);             // uint2[QN]: key, set-arena index of the finished wave
     static constexpr int O_MISC = O_Q + 8 * QN;                      // outset[W]
     static constexpr int BYTES = a16(O_MISC + 4 * W);
-    static constexpr int SET_DWORDS = 2 * SLOTS * W;                 // per group in HBM: the slots' traversed-node sets
+#ifndef W3_SETIDS
+#define W3_SETIDS 0   // hp_wfa3_kernel.hip: 1 = slots carry the index of an immutable set entry instead of a copy of the set (round 6: built,
+                      // bit-identical, HBM traffic 12.2 -> 7.6 GB a set - and 3 % slower, 4 % at 1 % noise: measured, left off; profiles/DIARY.md)
+#endif
+#ifndef W3_ARENA
+#define W3_ARENA 1023   // entries of a job's set arena (W3_SETIDS; indices are 10 bits, 0x3FF = none)
+#endif
+    static constexpr int SET_ENTRIES = W3_SETIDS ? W3_ARENA : 2 * SLOTS;
+    static constexpr int SET_DWORDS = (SET_ENTRIES * W + 3) & ~3;    // per group in HBM: the traversed-node sets
     static constexpr int REC_DWORDS = 4 * MAXN;                      // + one capped-diagonal record per node
     static constexpr int GROUP_DWORDS = SET_DWORDS + REC_DWORDS;
 };
-static_assert(W2_SLOTS_WIDE < 0x3FF, "set-arena indices are 10 bits");
+static_assert(W2_SLOTS_WIDE < 0x3FF && W3_ARENA <= 0x3FF, "set-arena indices are 10 bits");
 
 struct W2Batch {
     const W2Job* jobs;

@@ -40,6 +40,16 @@ namespace hp {
 #ifndef W3_PROF
 #define W3_PROF 0
 #endif
+// Round 6: a slot carries the RING INDEX of its traversed-node set instead of owning a copy of it. Until round 5 every committed slot
+// wrote its set (W words) to HBM every round and every tile loaded up to five of them - 24 KB written per read, all of it copies:
+// a wave that only advances keeps its set. Now the group's set arena is a list of IMMUTABLE entries; a slot's word carries the entry's index (10 bits beside offset and kind), a tile forwards the index of its
+// tied candidate, and an entry is written only where a set really changes: a wave taken up by a child node (parents' sets + the
+// node, wfa_graph.rs:535-541) and a tie between waves whose sets differ (:476-510) - a few hundred times per read instead of
+// eight thousand. The reference hash-conses its sets for the same reason (wfa_graph.rs:363-370). Entries may duplicate each other
+// (no look-up for an equal set): a tie between two copies writes a third - harmless. A job's arena holds W3_ARENA (1 023) entries,
+// written once each in order; a job that needs more is handed on like one that outgrows its slot lists (why = 8).
+// -DW3_SETIDS=0: the round-5 kernel.
+// (W3_SETIDS / W3_ARENA: hp_wfa2_dev.h - the host sizes the groups' scratch from them)
 #if W3_PROF   // s_memtime between the phases of the lockstep step (a separate build: the timers cost registers)
 #define W3T(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); w3t[i] += t_ - w3tl; w3tl = t_; } while (0)
 #else
@@ -132,6 +142,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
     const W2Node* gnode = B.nodes; const uint16_t* gedge = B.edges;
     uint32_t ed = 0, c = 0, p = 1, ip = 0, np = 0, nl = 0, nf = 0, nl_prev = 0;
     uint32_t lastkey = 0;                                            // key of the last target of the round's list (np > ip)
+#if W3_SETIDS
+    constexpr uint32_t CAP = (uint32_t)C::SET_ENTRIES;               // entries of a job's set arena: written once each, in order
+    uint32_t ring_next = 0;                                          // where the next entry goes
+#endif
     uint32_t farthest = 0, min_prog = 0;
     bool final_found = false;
     int32_t status = W2_ST_PENDING;
@@ -238,6 +252,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 gedge = B.edges + jd.edge_off;
                 // the start wave (wfa_graph.rs:366-378): the only target of round 0
                 ed = 0; c = 0; p = 1; ip = 0; np = 1; nl = 0; nf = 0; nl_prev = 0; steps = 0;
+#if W3_SETIDS
+                ring_next = 0;
+#endif
                 if (gl == 0) A[0] = make_uint2(w3_key(0u, 0), w3_aux(W3_NONE, W3_NONE, W3_NONE) | W3_START);
                 lastkey = w3_key(0u, 0);
                 farthest = 0; min_prog = 0; final_found = false; lane_far = 0; lane_upd = 0;
@@ -258,6 +275,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 // every live slot (n, d) emits the targets (n, d - 1), (n, d), (n, d + 1) its predecessor has not emitted
                 uint32_t carry = 0xFFFFFFFFu;
                 bool over = false;
+
 #pragma clang loop unroll(disable)
                 for (uint32_t base = 0; base < nl_prev; base += (uint32_t)G) {
                     W3C(11, 1);
@@ -329,6 +347,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
         // ---- candidates from the previous round: the three live slots from the emitter on ----
         int32_t oA = -1, oB = -1, oC = -1;
         int32_t sA = -1, sB = -1, sC = -1;   // their slots (= set indices)
+#if W3_SETIDS
+        uint32_t idA = 0, idB = 0, idC = 0;  // ring indices of their sets
+#endif
         {
             const bool cand = act && back != W3_NONE;
             uint2 e[3];
@@ -340,15 +361,39 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 const bool ok = cand && j < nl_prev;
                 const int32_t rel = (int32_t)e[k].x - (int32_t)tgt.x;   // same node: the difference of the diagonals (keys are node << 19 | diagonal + bias)
                 const uint32_t kd = e[k].y & 7u;
+#if W3_SETIDS
+                const int32_t off = (int32_t)((e[k].y >> 3) & 0x3FFFFu);
+                const uint32_t eid = e[k].y >> 21;
+#else
                 const int32_t off = (int32_t)(e[k].y >> 3);
+#endif
                 const bool a = ok && rel == 1 && (kd & 1u) != 0u;
                 const bool b = ok && rel == 0 && kd == W2_KIND_INTERIOR_READ;
                 const bool c_ = ok && rel == -1 && (kd == W2_KIND_INTERIOR_READ || kd == W2_KIND_END_LAST);
                 oA = a ? off + 1 : oA; sA = a ? (int32_t)j : sA;
                 oB = b ? off + 1 : oB; sB = b ? (int32_t)j : sB;
                 oC = c_ ? off : oC; sC = c_ ? (int32_t)j : sC;
+#if W3_SETIDS
+                idA = a ? eid : idA; idB = b ? eid : idB; idC = c_ ? eid : idC;
+#endif
             }
         }
+#if W3_SETIDS
+        // ---- waves that finished a parent THIS round (offset 0; wfa_graph.rs:527-553), and the start wave: src0 / src1 are the ring
+        // indices of the parents' sets ----
+        const bool hinj = act && ((tgt.y & W3_START) != 0u || src0 != W3_NONE);
+        const bool h0 = act && src0 != W3_NONE, h1 = act && src1 != W3_NONE;
+        // (the parents' sets are asked for NOW, with the tile's other loads, on addresses that are valid whatever the lane holds - entry 0
+        // of the device's first group for a lane without a parent: the one place a new entry is made in nearly every tile must not
+        // cost a trip to memory of its own in the middle of it. Measured: with these loads where the entry is put together the class
+        // kernels were 4 % SLOWER than round 5's - 18.0 against 17.3 ms a set - for all the stores they no longer make.)
+        W2Set<W> qD = w2_ldset<W>(h0 ? gs + (size_t)src0 * W : B.gsets, true);
+        {
+            const W2Set<W> t = w2_ldset<W>(h1 ? gs + (size_t)src1 * W : B.gsets, true);
+#pragma unroll
+            for (int w = 0; w < W; ++w) qD.w[w] = (h0 ? qD.w[w] : 0u) | (h1 ? t.w[w] : 0u);
+        }
+#else
         const W2Set<W> qA = w2_ldset<W>(sA >= 0 ? gs + (size_t)(pbase + (uint32_t)sA) * W : B.gsets, true);
         const W2Set<W> qB = w2_ldset<W>(sB >= 0 ? gs + (size_t)(pbase + (uint32_t)sB) * W : B.gsets, true);
         const W2Set<W> qC = w2_ldset<W>(sC >= 0 ? gs + (size_t)(pbase + (uint32_t)sC) * W : B.gsets, true);
@@ -361,6 +406,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
 #pragma unroll
             for (int w = 0; w < W; ++w) qD.w[w] = (h0 ? qD.w[w] : 0u) | (h1 ? t.w[w] : 0u);
         }
+#endif
         W3T(2);
         const uint32_t len = nd.y & ~W2_IS_REF;
         const uint64_t nb = ((nd.y & W2_IS_REF) ? ref_off : B.alt_off) + nd.x;   // the node's sequence in seq[]
@@ -427,6 +473,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
             if (__any(pdA || pdB || pdC || pdD)) {
                 // the long compare only decides whether the candidate's traversed nodes join the slot's set: one whose set adds
                 // nothing to what the tied candidates bring already (the usual case: the same path, a diagonal over) needs none
+#if W3_SETIDS
+                // (by index: a candidate that names the entry a tied one names brings nothing new; different indices may still hold equal
+                // sets - then the long compare runs for nothing, the result is the same)
+                const bool addA = !((tB && idB == idA) || (tC && idC == idA));
+                const bool addB = !((tA && idA == idB) || (tC && idC == idB));
+                const bool addC = !((tA && idA == idC) || (tB && idB == idC));
+                const bool addD = true;
+#else
                 bool addA = false, addB = false, addC = false, addD = false;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
@@ -435,6 +489,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                     const uint32_t known = (tA ? qA.w[w] : 0u) | (tB ? qB.w[w] : 0u) | (tC ? qC.w[w] : 0u) | (tD ? dset : 0u);
                     addA = addA || (qA.w[w] & ~known); addB = addB || (qB.w[w] & ~known); addC = addC || (qC.w[w] & ~known); addD = addD || (dset & ~known);
                 }
+#endif
                 pdA = pdA && addA; pdB = pdB && addB; pdC = pdC && addC; pdD = pdD && addD;
             }
             if (__any(pdA || pdB || pdC || pdD)) {   // rare: a long alternative run onto the furthest wave's diagonal
@@ -517,9 +572,58 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
         const uint32_t ml = w3_gb<G>(live_k, gbase), mf = w3_gb<G>(fin_k, gbase);
         const uint32_t lpos = nl + w3_below(ml, lmask), fpos = SL - 1u - (nf + w3_below(mf, lmask));
         const uint32_t nlive = (uint32_t)__popc(ml), nfin = (uint32_t)__popc(mf);
+#if W3_SETIDS
+        if (run && nl + nlive > SL) status = W2_ST_NEED_BIG, why = 8u;
+#else
         if (run && nl + nlive + nf + nfin > SL) status = W2_ST_NEED_BIG, why = 8u;
+#endif
         if (__any(hfull && commit)) { if (w3_gb<G>(hfull && commit, gbase)) status = W2_ST_NEED_BIG, why = 9u; }
         const bool ok = status == W2_ST_PENDING;
+#if W3_SETIDS
+        // ---- this round's slots: offset | kind | the ring index of the union of the tied sets. One tied candidate (or several that name
+        // one entry): its index travels on. A wave taken up from a parent, or tied candidates with different entries: a new entry. ----
+        uint32_t bid = tA ? idA : tB ? idB : idC;
+        W2Set<W> made = w2_set0<W>();
+        bool words = false;   // this lane holds the words of its wave's set in `made`
+        {
+            // (bid is the first tied candidate's entry: the others differ from IT or from nothing)
+            const bool differ = (tB && idB != bid) || (tC && idC != bid);
+            // (a wave that ends the alignment keeps no slot - its set only goes into the job's result - but it may be one that was taken up
+            // from a parent in this very tile: it needs the words, not an entry)
+            const bool kept = kind != W2_KIND_NONE;   // (commit && kept = live_k || fin_k)
+            words = ok && commit && (kept || is_final) && (tD || differ);
+            const bool need = words && kept;
+            // the usual new entry - a wave taken up from its parents and tied with nothing else: the parents' sets are in hand
+            const bool slow = words && (differ || (tD && (tA || tB || tC)));   // (a wave taken up at offset 0 ties with a further one when it matches the read up to there)
+            if (words && !slow) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) made.w[w] = qD.w[w] | ((n >> 5) == (uint32_t)w ? 1u << (n & 31u) : 0u);   // + the node itself (wfa_graph.rs:535-541)
+            }
+            if (__any(slow)) {   // rare: tied waves whose sets differ - their words are fetched here
+                if (slow) {
+                    auto add = [&](uint32_t idx) { const W2Set<W> t = w2_ldset<W>(gs + (size_t)idx * W, true);
+#pragma unroll
+                                                   for (int w = 0; w < W; ++w) made.w[w] |= t.w[w]; };
+                    if (tA) add(idA);
+                    if (tB && !(tA && idB == idA)) add(idB);
+                    if (tC && !(tA && idC == idA) && !(tB && idC == idB)) add(idC);
+                    if (tD) {
+#pragma unroll
+                        for (int w = 0; w < W; ++w) made.w[w] |= qD.w[w] | ((n >> 5) == (uint32_t)w ? 1u << (n & 31u) : 0u);
+                    }
+                }
+            }
+            {
+                const uint32_t nm = w3_gb<G>(need, gbase);
+                const uint32_t at = ring_next + w3_below(nm, lmask);
+                ring_next += (uint32_t)__popc(nm);
+                if (ring_next > CAP) status = W2_ST_NEED_BIG, why = 8u;   // (group-uniform: the job has used up its arena - it is handed on like one that outgrows its slot lists)
+                if (need && ring_next <= CAP) { w2_stset<W>(gs + (size_t)at * W, made); bid = at; }
+            }
+        }
+        const bool ok2 = status == W2_ST_PENDING;
+        if (ok2 && live_k) A[cbase + lpos] = make_uint2(tgt.x, (E << 3) | kind | (bid << 21));
+#else
         // ---- this round's slots: offset | kind and the union of the tied sets -------------------------------------------------
         W2Set<W> best;
 #pragma unroll
@@ -533,6 +637,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
             w2_stset<W>(gs + (size_t)(cbase + lpos) * W, best);
         }
         if (ok && fin_k) w2_stset<W>(gs + (size_t)(cbase + fpos) * W, best);
+#endif
         if (commit) {
             lane_upd += has ? 1u : 0u;
             if (counts_far && (uint32_t)pos_end > lane_far) lane_far = (uint32_t)pos_end;
@@ -582,6 +687,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
         }
         W3T(8);
         // ---- finals (wfa_graph.rs:576-629): every wave of the last node that consumed node and read ---------------------------
+#if W3_SETIDS
+        if (__any(is_final && commit)) {
+            const bool gf = w3_gb<G>(is_final && commit, gbase) != 0;
+            W2Set<W> fs = made;   // (a lane that has just put its set together holds the words)
+            if (is_final && commit && !words) fs = w2_ldset<W>(gs + (size_t)bid * W, true);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint32_t o = w2_gor<G>(is_final && commit ? fs.w[w] : 0u);
+                if (gf && gl == 0) outset[w] |= o;
+            }
+            if (gf) final_found = true;
+        }
+#else
         if (__any(is_final && commit)) {
             const bool gf = w3_gb<G>(is_final && commit, gbase) != 0;
 #pragma unroll
@@ -591,13 +709,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
             }
             if (gf) final_found = true;
         }
+#endif
         W3T(9);
         // ---- the round's lists move on; finished waves become targets of their node's children --------------------------------
 #if W3_PROF
         ++w3steps;
 #endif
         if (run) {
+#if W3_SETIDS
+            nl += nlive; ip += ncommit;   // (finished waves hold no slot: their children's targets carry the index of their set)
+#else
             nl += nlive; nf += nfin; ip += ncommit;
+#endif
             // ---- finished waves become targets (child, diagonal + node length) of this round, kept sorted ----
             // one target: key K, the finished wave's set `si` (group-uniform)
             auto insert_slow = [&](const uint32_t K, const uint32_t si) {
@@ -624,11 +747,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                     else if (((y >> 20) & 0x3FFu) == W3_NONE) ny = (y & ~(0x3FFu << 20)) | (si << 20);
                     else {
                         // a third wave onto one target (rare): its set and the second one's merge into a fresh entry of the arena
+#if W3_SETIDS
+                        if (ring_next >= CAP) { status = W2_ST_NEED_BIG, why = 8u; return; }
+                        const uint32_t sm = ring_next++;
+#else
                         if (nl + nf + 1u > SL) { status = W2_ST_NEED_BIG, why = 8u; return; }
                         const uint32_t sm = SL - 1u - nf;
                         ++nf;
+#endif
                         const uint32_t s1 = (y >> 20) & 0x3FFu;
+#if W3_SETIDS
+                        if (gl < (uint32_t)W) gs[(size_t)sm * W + gl] = gs[(size_t)s1 * W + gl] | gs[(size_t)si * W + gl];
+#else
                         if (gl < (uint32_t)W) gs[(size_t)(cbase + sm) * W + gl] = gs[(size_t)(cbase + s1) * W + gl] | gs[(size_t)(cbase + si) * W + gl];
+#endif
                         ny = (y & ~(0x3FFu << 20)) | (sm << 20);
                     }
                     if (gl == 0) A[cbase + hit].y = ny;
@@ -698,9 +830,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                 const uint32_t qpos = w3_below(fm, lmask) + w3_below(m2, lmask);
                 const uint32_t m = (uint32_t)(__popc(fm) + __popc(m2));
                 uint2* qbuf = reinterpret_cast<uint2*>(R + C::O_Q);
+#if W3_SETIDS
+                const uint32_t fset = bid;    // the finished wave's set: what its children's targets name
+#else
+                const uint32_t fset = fpos;
+#endif
                 if (fin_k) {
-                    qbuf[qpos] = make_uint2(w3_key(nd.w & 0xFFFFu, tdl), fpos);
-                    if (f2) qbuf[qpos + 1u] = make_uint2(w3_key(nd.w >> 16, tdl), fpos);
+                    qbuf[qpos] = make_uint2(w3_key(nd.w & 0xFFFFu, tdl), fset);
+                    if (f2) qbuf[qpos + 1u] = make_uint2(w3_key(nd.w >> 16, tdl), fset);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // one pass per target. (Measured and left out, round 4: all of a tile's new targets merged into the list's last G entries
@@ -723,7 +860,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W3Cfg<W
                     m3 &= m3 - 1u;
                     const uint32_t qn = w2_gsel<G>(n, gl, L), qz = w2_gsel<G>(nd.z, gl, L);
                     const int32_t td = (int32_t)w2_gsel<G>((uint32_t)tdl, gl, L);
+#if W3_SETIDS
+                    const uint32_t si = w2_gsel<G>(bid, gl, L);
+#else
                     const uint32_t si = w2_gsel<G>(fpos, gl, L);
+#endif
                     uint32_t scan = qz >> 16;
 #pragma clang loop unroll(disable)
                     for (uint32_t j = 2; j < (qz & 0xFFFFu) && status == W2_ST_PENDING; ++j) insert(w3_key(w2_next_child(gedge, qn, scan), td), si);

@@ -3,7 +3,7 @@
 STEPS=$1; shift
 for v in "$@"; do
   if [ $v = base ]; then unset HP_LIB; else export HP_LIB=hiphase_amd/libhiphase_gpu_$v.so; fi
-  timeout 240 python bench.py --no-cpu --no-resident --no-drop-in --no-hifi --no-pcie-probe --steps $STEPS $AB_ARGS 2>/dev/null | tail -1 | python -c "
+  timeout 240 python bench.py --no-cpu --no-resident --no-drop-in --no-hifi --no-deep60 --no-pcie-probe --steps $STEPS $AB_ARGS 2>/dev/null | tail -1 | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
 s = d['stage_ms']
