@@ -123,8 +123,8 @@ def check(text):
 
 
 if __name__ == "__main__":
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "patches", "0001-hiphase-gpu.patch")
-    text = gpu_ffi_from_patch(src) if src.endswith(".patch") else open(src).read()
+    srcs = sys.argv[1:] or [os.path.join(ROOT, "patches", n) for n in sorted(os.listdir(os.path.join(ROOT, "patches"))) if n.endswith(".patch")]
+    text = "\n".join(gpu_ffi_from_patch(src) if src.endswith(".patch") else open(src).read() for src in srcs)
     problems, names = check(text)
     for p in problems:
         print("MISMATCH:", p)

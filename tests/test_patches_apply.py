@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 REFERENCE = "/root/reference"
-PATCHES = ["0001-hiphase-gpu.patch", "0002-hiphase-capture.patch"]
+PATCHES = ["0001-hiphase-gpu.patch", "0002-hiphase-capture.patch", "0003-hiphase-gpu-async.patch"]
 
 
 def _capture_lib():
@@ -42,13 +42,19 @@ def test_patches_apply_in_order_to_the_reference_tree(tmp_path):
         assert r.returncode == 0, f"{name}: {r.stderr}"
     ffi = (tree / "src" / "gpu_ffi.rs").read_text()
     phaser = (tree / "src" / "phaser.rs").read_text()
-    for text in (ffi, phaser, (tree / "src" / "read_parsing.rs").read_text(), (tree / "build.rs").read_text()):
+    main_rs = (tree / "src" / "main.rs").read_text()
+    for text in (ffi, phaser, main_rs, (tree / "src" / "read_parsing.rs").read_text(), (tree / "build.rs").read_text()):
         code = re.sub(r'"(?:[^"\\]|\\.)*"', '""', re.sub(r"//[^\n]*", "", text))   # (no string / comment contents)
         code = re.sub(r"'(?:[^'\\]|\\.)'", "' '", code)
         assert code.count("{") == code.count("}") and code.count("(") == code.count(")") and code.count("[") == code.count("]")
     # the call sites the patches name
     assert "read_parsing::gather_block_records(" in phaser and "crate::gpu_ffi::solve_block_gpu(&marshal)?" in phaser
     assert "crate::gpu_ffi::capture_block(" in phaser and "fn finish_block(" in phaser
+    # the asynchronous form (0003): solve_block split into submit / finish, one finisher thread beside the pool (main.rs:326-462)
+    assert "pub fn submit_block(" in phaser and "pub fn finish_block_gpu(" in phaser and "fn load_block_variants(" in phaser
+    assert "hiphase::phaser::submit_block(" in main_rs and "hiphase::phaser::finish_block_gpu(submitted)" in main_rs
+    assert main_rs.count('#[cfg(feature = "gpu")]') == 3 and main_rs.count('#[cfg(not(feature = "gpu"))]') == 1
+    assert "pub struct PendingBlock" in ffi and "hp_block_submit(1, &p.marshal.input" in ffi and "hp_block_wait(self.ticket)" in ffi
     assert 'pub mod gpu_ffi;' in (tree / "src" / "lib.rs").read_text()
     cargo = (tree / "Cargo.toml").read_text()
     assert "gpu = []" in cargo and "capture = []" in cargo
@@ -91,7 +97,7 @@ def test_rust_externs_match_the_header():
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hiphase_gpu.h")).read(), flags=re.S)
     dll = C.CDLL(_capture_lib())
     externs = re.findall(r"pub fn (hp_\w+)\(([^)]*)\)", text)
-    assert {n for n, _ in externs} >= {"hp_solve_blocks", "hp_last_error", "hp_abi_sizeof", "hp_abi_offsetof", "hp_hpbr_append", "hp_hpbk_append", "hp_hpbr_last_error"}
+    assert {n for n, _ in externs} >= {"hp_solve_blocks", "hp_block_submit", "hp_block_wait", "hp_last_error", "hp_abi_sizeof", "hp_abi_offsetof", "hp_hpbr_append", "hp_hpbk_append", "hp_hpbr_last_error"}
     host_only = {"hp_abi_sizeof", "hp_abi_offsetof", "hp_hpbr_append", "hp_hpbk_append", "hp_hpbr_last_error"}
     for name, args in externs:
         m = re.search(r"\b" + name + r"\s*\(([^)]*)\)\s*;", hdr)
