@@ -360,7 +360,16 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     b->last_n_segs = 0;
     seg_blocks.clear();
     if (std::getenv("HP_NO_SEGMENTS") || !b->prm.sub_heap_in_lds || b->prm.max_seg > SEG_STATE) return HP_OK;
-    const size_t lds_bytes = LDS_HEAP_OFF + (size_t)b->prm.jcap_sub * 64 * sizeof(uint64_t);
+    // HP_SEG_CRING=1: the sub-solver's window of the cell table staged in LDS (hp_astar_kernel.hip, CR) instead of read where it lies
+    // (launches whose blocks need two tiles per variant - coverage 45 and up - never stage: their ring would be 32 KB). Read per call:
+    // the parity tests switch it inside one process. OFF by default, measured (round 6, MI355X, three runs a side): one C2 block 505.2
+    // against 506.5 ms - the rows it replaces were L1 / L2 hits, the chain is bound by its instructions - and inside a block stream the
+    // A* kernels' chain 20.0-21.3 against 17.6-19.4 ms per set: a resident graph-WFA launch set holds 154 of a compute unit's 160 KB of
+    // LDS, a 19 KB segment workgroup waits for one of its workgroups to retire where a 2.8 KB one moves in beside them.
+    const bool cring_env = [] { const char* e = std::getenv("HP_SEG_CRING"); return e && e[0] == '1'; }();
+    const bool cring = cring_env && b->tiles != 2 && b->d_ctab.p != nullptr;
+    const size_t heap_bytes = LDS_HEAP_OFF + (size_t)b->prm.jcap_sub * 64 * sizeof(uint64_t);
+    const size_t lds_bytes = heap_bytes + (cring ? (size_t)64 * 64 * 4 : 0);
     const int occ = 6;
     const uint32_t per_cu = (uint32_t)std::min<size_t>(4 * occ, (160 * 1024) / lds_bytes);
     const uint64_t max_slots = (uint64_t)b->n_cu * std::max(per_cu, 1u);
@@ -429,7 +438,7 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     B.prm = prm;
     S.segs = b->d_segs.as<SegDesc>(); S.seg_order = b->d_seg_order.as<uint32_t>(); S.n_segs = (uint32_t)segs.size();
     S.out = b->d_seg_out.as<SegOut>();
-    S.run_flag = nullptr; S.warm = 0;
+    S.run_flag = nullptr; S.warm = 0; S.cring_off = (uint32_t)heap_bytes;
     if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] segment-parallel heuristic: %zu segments of ~%llu hets (+%u warm-up, open seams again with +%u) over %zu blocks, slots=%u\n", segs.size(), (unsigned long long)target, warm, two_rounds ? warm2 : warm, sb_id.size(), slots); fflush(stderr); }
     StitchDev T{};
     T.desc = B.desc; T.segs = S.segs; T.out = S.out;
@@ -440,8 +449,9 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     for (int round = 0; round < (two_rounds ? 2 : 1); ++round) {
         if (round == 1) { S.run_flag = T.retry; S.warm = warm2; }
         T.final_round = (round == 1 || !two_rounds) ? 1u : 0u;
-        if (b->tiles == 2) hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 2>), dim3(slots), dim3(64), lds_bytes, st, S);
-        else hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 1>), dim3(slots), dim3(64), lds_bytes, st, S);
+        if (b->tiles == 2) hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 2, false>), dim3(slots), dim3(64), lds_bytes, st, S);
+        else if (cring) hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 1, true>), dim3(slots), dim3(64), lds_bytes, st, S);
+        else hipLaunchKernelGGL((hp_heur_seg_kernel<true, 6, 1, false>), dim3(slots), dim3(64), lds_bytes, st, S);
         hipLaunchKernelGGL(hp_heur_stitch_kernel, dim3(T.n_seg_blocks), dim3(64), 0, st, T);
     }
     ApplyDev A{};

@@ -456,6 +456,7 @@ struct Ctx {
     uint32_t n_rows;
     uint32_t tiles;         // 64-entry tiles per variant in the cell table (1 or 2)
     const uint32_t* ctab;   // per-position cell table of the block (hp_astar_dev.h CELL_*), nullptr with HP_NO_CTAB
+    uint32_t cring_off;     // CR (below): byte offset in LDS of the staged window of the cell table, 64 variants x 64 entries x u32
     uint32_t N;
     uint64_t evals, cells;  // per-lane work counters
     uint32_t ev32, cl32;    // ... their 32-bit front end (one sub-solve / one main pop), folded in by flush()
@@ -758,12 +759,20 @@ DEVINL void fast_tile(Ctx& cx, uint32_t cell, uint32_t p, uint32_t off, uint32_t
     }
     px0 = x0; px1 = x1;
 }
-template <bool PROF, int TILES>
+// CR (round 6; BASELINE.json north_star: "the allele matrix packed 2-bit and staged into LDS"): the sub-solver only ever looks at the
+// <= 40 variants of its window (astar_phaser.rs:311-405: problem_size <= max_segment_size), and the heuristic chain moves that window
+// down one variant per step - so the window's rows of the cell table (per variant 64 entries: a row's 2-bit allele + its u8 quality +
+// the ends-here / valid flags, hp_astar_dev.h CELL_*) live in a 64-variant LDS ring that the chain feeds with ONE coalesced 256-byte
+// read per step (solve_segment), and every expansion of the sub-solver - a hundred pops per step, each of which used to read its
+// variant's row from L1 / L2 - takes its row from LDS. 16 KB per wavefront: 8 single-wave workgroups per CU instead of 24, which
+// is what the segment kernel needs anyway (two per SIMD run at the speed of one, profiles/round2/issue_ceiling.txt). The full matrix
+// of a C2 block (188 KB) would not fit; the main search, whose look-back is unbounded, keeps reading the table where it lies.
+template <bool PROF, int TILES, bool CR = false>
 DEVINL void expand_fast(Ctx& cx, const Cur& cur, uint32_t off, uint32_t p, bool bad, uint64_t h_next, Pools& pl,
                         Kids& kd, WaveCounters& wc, FastState& fs, CellCost& cc) {
     const bool two = TILES == 2 && cx.tiles == 2u;   // TILES: what the launch supports, cx.tiles: this block's table
     const uint32_t* row = cx.ctab + ((size_t)p << (two ? 7 : 6)) + lane_id();
-    const uint32_t cell_a = row[0];
+    const uint32_t cell_a = (CR && TILES == 1) ? reinterpret_cast<const uint32_t*>(hp_smem + cx.cring_off)[((p & 63u) << 6) + lane_id()] : row[0];
     const uint32_t cell_b = two ? row[64] : 0u;
     const ExpPre e = expand_begin(cur, off, p, bad, pl);
     seg_stamp<PROF>(wc, 1);
@@ -789,7 +798,7 @@ DEVINL void ringV_set(uint32_t x, uint32_t lo, uint32_t flags) {  // rows per bl
     if (lane_id() == 0) reinterpret_cast<uint32_t*>(hp_smem + LDS_VRING_OFF)[x & 63u] = lo | (flags << 28);
 }
 // astar_subsolver (astar_phaser.rs:311-405). Returns status; outputs (max_cost_so_far, farthest).
-template <bool SUB_LDS, bool PROF, int TILES>
+template <bool SUB_LDS, bool PROF, int TILES, bool CR = false>
 DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t ps, SubHeap<SUB_LDS>& heap,
                         Pools& pl, WaveCounters& wc, uint64_t& est, uint32_t& solved) {
     heap.reset();
@@ -821,7 +830,7 @@ DEVINL int32_t subsolve(Ctx& cx, const SolveParams& prm, uint32_t off, uint32_t 
         seg_stamp<PROF>(wc, 0);       // [0] loop head + LDS ring reads
         CellCost cc;
         const bool collide = (flags & VAR_NOFAST) != 0;   // two rows of this variant on one lane: plane-word path only
-        if (fast_valid && !collide) expand_fast<PROF, TILES>(cx, cur, off, p, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs, cc);
+        if (fast_valid && !collide) expand_fast<PROF, TILES, CR>(cx, cur, off, p, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs, cc);
         else expand<PROF, TILES>(cx, cur, off, p, lo, (flags & HP_VAR_IGNORED) != 0, bcast64(rh), pl, kd, wc, fs, cc);
         // (no capacity check: next_idx <= 4 * visited + 1 <= 4 * max_visits + 1 == cap_sub, see hp_batch_create)
         if (kd.bad && kd.tbase + rdlane(kd.tvec, 0) != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:360
@@ -934,7 +943,7 @@ DEVINL HeurResult heuristic_phase(const BatchDev& B, uint32_t blk, uint32_t slot
     cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
     cx.n_rows = d.n_reads;
     cx.tiles = d.ctab_shift == 7u ? 2u : 1u;
-    cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
+    cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0; cx.cring_off = 0;
     uint64_t* H = B.H + d.h_off;
     Pools subp;
     {
@@ -1019,7 +1028,7 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
     cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
     cx.n_rows = d.n_reads;
     cx.tiles = d.ctab_shift == 7u ? 2u : 1u;
-    cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
+    cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0; cx.cring_off = 0;
     uint64_t* H = B.H + d.h_off;
     Pools mainp;
     {
@@ -1272,9 +1281,10 @@ struct SegBatchDev {
     SegOut* out;
     const uint8_t* run_flag;   // second round: only the segments below a seam the first round's warm-up did not close
     uint32_t warm;             // second round: warm-up length that replaces SegDesc::v0 (0 = first round)
+    uint32_t cring_off;        // CR: where the staged cell-table window lies in LDS (behind the sub-solver's heap)
 };
 
-template <bool SUB_LDS, int TILES>
+template <bool SUB_LDS, int TILES, bool CR>
 DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
     if (S.run_flag && !S.run_flag[seg]) return;
     const BatchDev& B = S.B;
@@ -1293,7 +1303,7 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
     cx.ctab = (d.cell_off != ~0ull) ? B.ctab + d.cell_off : nullptr;
     cx.n_rows = d.n_reads;
     cx.tiles = d.ctab_shift == 7u ? 2u : 1u;
-    cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0;
+    cx.N = N; cx.evals = 0; cx.cells = 0; cx.ev32 = 0; cx.cl32 = 0; cx.cring_off = S.cring_off;
     uint64_t* H = B.H + d.h_off;
     Pools subp;
     {
@@ -1324,9 +1334,12 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
         if (lane == 0) { fl = vflags[v]; l = vlo[v]; }
         fl = bcast32(fl);
         ringV_set(v, l, fl);
+        // (CR: the row of the variant that enters the window - one coalesced read per step of the chain; rows leave the ring by
+        // being overwritten 64 steps later, the window is 40 deep)
+        if (CR && TILES == 1 && cx.ctab != nullptr) reinterpret_cast<uint32_t*>(hp_smem + cx.cring_off)[((v & 63u) << 6) + lane] = cx.ctab[((size_t)v << 6) + lane];
         uint64_t est = 0;
         uint32_t solved = 0;
-        st = subsolve<SUB_LDS, false, TILES>(cx, prm, v, clip, sub, subp, wc, est, solved);
+        st = subsolve<SUB_LDS, false, TILES, CR>(cx, prm, v, clip, sub, subp, wc, est, solved);
         if (st != ST_OK) break;
         if (solved < min(clip, 2u)) { st = ST_INVARIANT; break; }
         const bool bad = (fl & HP_VAR_IGNORED) != 0;
@@ -1359,7 +1372,7 @@ DEVINL void solve_segment(const SegBatchDev& S, uint32_t seg, uint32_t slot) {
 
 // OCC = waves per SIMD the register allocation targets. 6 (80 VGPRs, a few spills) measured equal or faster than
 // the spill-free 4 on every workload tried (throughput batches, a single block, the heavy-tailed mix).
-template <bool SUB_LDS, int OCC, int TILES>
+template <bool SUB_LDS, int OCC, int TILES, bool CR>
 __global__ void __launch_bounds__(64, OCC) hp_heur_seg_kernel(SegBatchDev S) {
     __builtin_amdgcn_s_setprio(3);
     const uint32_t slot = blockIdx.x, G = gridDim.x;
@@ -1367,11 +1380,12 @@ __global__ void __launch_bounds__(64, OCC) hp_heur_seg_kernel(SegBatchDev S) {
         const uint32_t base = round * G;
         if (base >= S.n_segs) break;
         const uint32_t i = base + ((round & 1u) ? (G - 1u - slot) : slot);
-        if (i < S.n_segs) solve_segment<SUB_LDS, TILES>(S, S.seg_order[i], slot);
+        if (i < S.n_segs) solve_segment<SUB_LDS, TILES, CR>(S, S.seg_order[i], slot);
     }
 }
-template __global__ void hp_heur_seg_kernel<true, 6, 1>(SegBatchDev);
-template __global__ void hp_heur_seg_kernel<true, 6, 2>(SegBatchDev);
+template __global__ void hp_heur_seg_kernel<true, 6, 1, false>(SegBatchDev);
+template __global__ void hp_heur_seg_kernel<true, 6, 1, true>(SegBatchDev);
+template __global__ void hp_heur_seg_kernel<true, 6, 2, false>(SegBatchDev);
 
 // Seam verification + offsets, one thread per segmented block (segments of a block are consecutive, bottom first).
 struct StitchDev {

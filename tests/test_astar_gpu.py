@@ -298,6 +298,24 @@ def test_segment_parallel_heuristic_is_exact(monkeypatch, target, warm, warm2):
     check_batch(blocks)
 
 
+@pytest.mark.parametrize("target,warm,warm2", [(64, 64, 160), (64, 8, 160), (32, 48, 160)])
+def test_sub_solver_window_staged_in_lds_is_exact(monkeypatch, target, warm, warm2):
+    """HP_SEG_CRING=1 (BASELINE.json north_star: the allele matrix staged into LDS - here the sub-solver's <= 40-variant window of the
+    per-variant cell table, a 64-variant ring per wavefront that the heuristic chain feeds with one coalesced read per step,
+    reference src/astar_phaser.rs:311-405): same H[], haplotypes, statistics and work counters as the oracle, with seams that close,
+    seams that stay open for the second round, and blocks of coverage 60 in the batch (two tiles per variant: those launches do
+    not stage). Off by default - measured neutral on one block, slower inside a stream (hp_astar.hip launch_segments)."""
+    monkeypatch.setenv("HP_SEG_CRING", "1")
+    monkeypatch.setenv("HP_SEG_TARGET", str(target))
+    monkeypatch.setenv("HP_SEG_WARM", str(warm))
+    monkeypatch.setenv("HP_SEG_WARM2", str(warm2))
+    blocks = [synth_block(n, c, s, e, 0.02, 8300 + i, ignored_permille=ign)[0]
+              for i, (n, c, s, e, ign) in enumerate([(700, 30, 20, 0.01, 0), (513, 30, 20, 0.15, 0), (130, 30, 20, 0.01, 0),
+                                                     (40, 30, 20, 0.01, 0), (1300, 12, 150, 0.03, 30), (2100, 28, 25, 0.02, 0)])]
+    check_batch(blocks)
+    check_batch(blocks + [synth_block(900, 60, 40, 0.05, 0.02, 8399, ignored_permille=20)[0]])
+
+
 def test_single_block_latency_uses_segments(monkeypatch):
     """One 5000-het block alone (BASELINE.json configs[1] as written): the planner segments it by itself."""
     monkeypatch.delenv("HP_SEG_TARGET", raising=False)
