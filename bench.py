@@ -360,7 +360,7 @@ def secondary_own_process(args, which):
     import subprocess
     hets = args.total_hets if which == "hifi" else max(2000, args.total_hets // 3)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--" + which, "--no-resident", "--no-drop-in", "--no-hifi", "--no-deep60", "--no-pcie-probe",
-           "--steps", str(args.steps if which == "hifi" else max(4, args.steps // 2)), "--warmup", str(args.warmup), "--cpu-seconds", str(min(args.cpu_seconds, 3.0)), "--total-hets", str(hets),
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", str(min(args.cpu_seconds, 3.0)), "--total-hets", str(hets),
            "--max-block-hets", str(args.max_block_hets), "--seq-format", args.seq_format, "--depth", str(args.depth), "--host-memory", args.host_memory]
     if which == "deep60":
         cmd += ["--coverage", "60"]

@@ -87,7 +87,7 @@ struct hp::Pipeline {
     bool quit = false;
     // one thread per stage; a seventh only behind the experiment switches HP_STREAM_ROWS_THREADS=2 / HP_STREAM_WFA_THREADS=2 (a second
     // rows or alignment thread: two sets share the stage and still reach the next one in ticket order - measured equal / slower)
-    static constexpr int N_THREADS = 7;
+    static constexpr int N_THREADS = N_STAGES + 7;   // (up to eight threads for the last stage: HP_STREAM_SOLVE_THREADS)
     std::thread th[N_THREADS];
     std::unique_ptr<WorkerPool> pool[N_THREADS];
     void stage_thread(int t);
@@ -178,16 +178,25 @@ hp::Pipeline* hp::pipeline_create(const hp_block_params* p, int device_id, uint3
     // in flight only adds contention.
     const char* wt = std::getenv("HP_STREAM_WFA_THREADS");
     const char* rt = std::getenv("HP_STREAM_ROWS_THREADS");
-    // HP_STREAM_SOLVE_THREADS=2 (round 5): a second thread for the last stage - A* is a latency chain, not issue (3e8 busy cycles per set
-    // against the alignment kernels' 2.3e9), so set k + 1's chain can run beside set k's
-    // Measured (round 5, default bench, three runs a side): 2.15 -> 2.19 M hets/s at depth 6, 2.29 M at depth 7 (one more set in flight
-    // feeds the second chain), 2.34 M with the 48-variant warm-up of hp_astar.hip on top. On by default; =1 switches it off.
+    // HP_STREAM_SOLVE_THREADS=n: n threads for the last stage - A* is a latency chain, not issue (3e8 busy cycles per set against the
+    // alignment kernels' 2.3e9), so set k + 1's chain can run beside set k's.
+    // Measured (round 5, default bench, three runs a side): a second thread 2.15 -> 2.19 M hets/s at depth 6, 2.29 M at depth 7 (one more set
+    // in flight feeds the second chain), 2.34 M with the 48-variant warm-up of hp_astar.hip on top. Round 6: the deep-coverage workload
+    // (hp_synth_reads_deep60: 60x, conflicting rows - the search of its largest block is 0.85 s of ONE wavefront) is bound by exactly this
+    // chain: a set's A* takes 850 ms, the device idles, and the stream's period is 850 ms / threads - as many threads as the stream holds
+    // sets (depth) by default, at most eight; a thread without a set sleeps on the pipeline's condition variable. =1: one thread.
+    // Measured (round 6, three sizes, `gpurun_out/r6_solve`): the default and the HiFi-shaped bench 2.45-2.50 M hets/s at 2, 4 and 7 threads
+    // alike (the third thread never finds a set waiting); deep60 41 k -> 65 k -> 82 k hets/s at 2 / 4 / 7 (14 steps, 0.86 s of them the
+    // first set's way through).
     const char* sv = std::getenv("HP_STREAM_SOLVE_THREADS");
-    int n_threads = Pipeline::N_THREADS;
+    int n_threads = Pipeline::N_STAGES + 1;
     if (rt && std::atoi(rt) >= 2) s->extra_stage = 3;
     else if (wt && std::atoi(wt) >= 2) s->extra_stage = 2;
-    else if (!sv || std::atoi(sv) >= 2) s->extra_stage = 5;
-    else n_threads = Pipeline::N_STAGES;
+    else {
+        const int want = sv ? std::atoi(sv) : (int)depth;
+        s->extra_stage = 5;
+        n_threads = Pipeline::N_STAGES + std::max(0, std::min(want, 8) - 1);
+    }
     s->index = g_pipelines.fetch_add(1);
     for (int k = 0; k < n_threads; ++k) s->th[k] = std::thread([raw, k]() { raw->stage_thread(k); });
     if (status) *status = HP_OK;
