@@ -184,9 +184,9 @@ def fatbin_sha256(path=None):
 
 def measured_traffic(kernels, per_unit_key, units):
     """HBM bytes per launch from the PMC counters: only a measurement taken on THIS build of the library counts
-    (profiles/round5/traffic.json records the sha256 of the .so it was measured on, and of its device code - .hip_fatbin -, which is what must match); otherwise null. `kernels`: names to look
+    (profiles/round6/traffic.json records the sha256 of the .so it was measured on, and of its device code - .hip_fatbin -, which is what must match); otherwise null. `kernels`: names to look
     for, the first one the file holds wins (hp_wfa3_kernel, or hp_wfa2_kernel under HP_WFA_GEN=2)."""
-    for rnd in ("round5", "round4", "round3"):
+    for rnd in ("round6", "round5", "round4", "round3"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
         except Exception:

@@ -75,7 +75,7 @@ for g, unit, n in (("hp_wfa3_kernel", "bytes_per_read", reads), ("hp_wfa2_kernel
         b = (2.0 * tot[(g, "FETCH_SIZE")] + tot[(g, "WRITE_SIZE")]) * 1024.0 / launches
         traffic[g] = {unit: b / n, "hbm_bytes_per_step": b, "FETCH_SIZE_KB_per_step": tot[(g, "FETCH_SIZE")] / launches,
                       "WRITE_SIZE_KB_per_step": tot[(g, "WRITE_SIZE")] / launches, "so_sha256": sha, "fatbin_sha256": fat,
-                      "source": "profiles/round5/path_pmc_summary.txt"}
+                      "source": "profiles/round6/path_pmc_summary.txt"}
         lines.append(f"{g}: HBM traffic (FETCH x 2 + WRITE) = {b / 1e6:.1f} MB per step = {b / n:.0f} {unit.replace('_', ' ')}")
     w, a, wa, wi = (tot.get((g, c)) for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"))
     if w:
