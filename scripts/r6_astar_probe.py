@@ -1,7 +1,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 from hiphase_amd import ResidentBatch, synth_block
-for n, c, s, e in ((2500, 60, 20, 0.15), (4000, 60, 20, 0.15), (2500, 60, 20, 0.25), (2500, 60, 40, 0.15)):
+for n, c, s, e in ((2500, 60, 20, 0.15), (4000, 60, 20, 0.15), (2500, 30, 20, 0.15)):
     blk, _ = synth_block(n, c, s, e, 0.02, 4242)
     for env in ({}, {"HP_NO_SEGMENTS": "1"}):
         for k in ("HP_NO_SEGMENTS",):
