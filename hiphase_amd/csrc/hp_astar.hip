@@ -321,12 +321,12 @@ struct hp_batch {
     std::vector<uint64_t> caller_row_off;
     // host tables that are uploaded with hipMemcpyAsync: they live as long as the batch, so no copy can outlive its source
     std::vector<SegDesc> h_segs;
-    std::vector<uint32_t> h_seg_order, h_sb_first, h_sb_n, h_sb_id, h_junc_block;
+    std::vector<uint32_t> h_seg_order, h_sb_first, h_sb_n, h_sb_id, h_junc_block, h_blk_seg;   // h_blk_seg: per block, [first segment | how many]
     std::vector<uint64_t> h_junc_off;
     uint64_t caller_rows = 0, n_rows_packed = 0, n_junctures = 0;
     bool solved = false;
     // segment-parallel heuristic (large blocks on an otherwise idle GPU)
-    DevBuf d_segs, d_seg_order, d_seg_out, d_seg_off, d_seg_retry, d_sb_first, d_sb_n, d_sb_id, s_seg_pool;
+    DevBuf d_segs, d_seg_order, d_seg_out, d_seg_off, d_seg_retry, d_sb_first, d_sb_n, d_sb_id, s_seg_pool, d_blk_seg;
     uint32_t last_n_segs = 0;
     // second stream + scratch: segmented blocks run beside the sequential pass of all the others
     hipStream_t stream2 = nullptr;
@@ -352,6 +352,19 @@ struct hp_batch {
 namespace {
 
 constexpr uint32_t LDS_SUB_HEAP_MAX_BYTES = 24 * 1024;  // keep >= 6 waves per CU resident (160 KiB LDS)
+
+// Node capacity of a launch's FIRST main search. 6 N + 2048 covers clean data (<= 4 N + 1 nodes); wrong-haplotype cells make the
+// search jump and its frontier grow (15 % of them at 60x: 25-30 nodes a variant), and an attempt that runs out is run again from
+// its start. Scratch that is never touched costs nothing but address space, so a launch gets up to 32 N + 2048 while its slots
+// together stay within 2 GB (104 bytes a node: family record, heap key, a quarter of a chunk record). HP_ASTAR_CAP0=f (test hook):
+// f N + 64, to reach the retries.
+uint32_t first_pass_cap(uint32_t max_n, size_t n_items, uint32_t n_cu) {
+    if (const char* e = std::getenv("HP_ASTAR_CAP0")) return (uint32_t)std::max(1, std::atoi(e)) * max_n + 64;
+    const uint64_t lo = 6ull * max_n + 2048, hi = 32ull * max_n + 2048;
+    const uint64_t slots = std::max<uint64_t>(1, std::min<uint64_t>(n_items, (uint64_t)n_cu * 24));
+    const uint64_t by_mem = (2ull << 30) / slots / 104;
+    return (uint32_t)std::max(lo, std::min(hi, by_mem));
+}
 
 // Plans and launches the segment-parallel heuristic for blocks that would otherwise be the critical path
 // (heavy-tailed block sizes, or few blocks): see hp_astar_dev.h. Blocks whose seams verify get status ST_H_READY
@@ -420,6 +433,11 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
     const size_t sub_pool_bytes = sub_pool_bytes_per_slot(prm);
     int rc;
     if (b->s_seg_pool.bytes < (size_t)slots * sub_pool_bytes && (rc = b->s_seg_pool.alloc((size_t)slots * sub_pool_bytes)) != HP_OK) return rc;
+    // per block (what hp_astar_kernel looks up for a block whose seams stayed open): first segment, then the counts
+    std::vector<uint32_t>& blk_seg = b->h_blk_seg;
+    blk_seg.assign(2 * (size_t)b->n_blocks, 0u);
+    for (size_t t = 0; t < sb_id.size(); ++t) { blk_seg[sb_id[t]] = sb_first[t]; blk_seg[b->n_blocks + sb_id[t]] = sb_n[t]; }
+    if ((rc = upload(b->d_blk_seg, blk_seg, st)) != HP_OK) return rc;
     if ((rc = upload(b->d_segs, segs, st)) || (rc = upload(b->d_seg_order, order, st)) || (rc = upload(b->d_sb_first, sb_first, st)) ||
         (rc = upload(b->d_sb_n, sb_n, st)) || (rc = upload(b->d_sb_id, sb_id, st)))
         return rc;
@@ -529,6 +547,10 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     B.status = b->d_status.as<int32_t>();
     B.sub_pool = sub_pool.as<unsigned char>(); B.main_pool = main_pool.as<unsigned char>();
     B.sub_heap_g = sub_heap.as<uint64_t>(); B.main_heap = main_heap.as<Key>(); B.tracker = tracker.as<uint32_t>();
+    if (b->last_n_segs && !std::getenv("HP_SEG_NO_TAKEOVER")) {   // (HP_SEG_NO_TAKEOVER=1: an unaccepted block walks its whole chain, as until round 6 - A/B switch)
+        B.segs = b->d_segs.as<SegDesc>(); B.seg_out = b->d_seg_out.as<SegOut>();
+        B.blk_seg_first = b->d_blk_seg.as<uint32_t>(); B.blk_seg_n = b->d_blk_seg.as<uint32_t>() + b->n_blocks;
+    }
     B.prm = prm;
     if (verbose) {
         int occ_blocks = -1;
@@ -821,7 +843,9 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     // pass 0: every block, scratch sized generously above the clean-data bound (<= 4N+1 nodes); blocks whose
     // frontier outgrows it (noisy data) keep their finished heuristic and only their main search is re-run
     // with 4x the capacity until it fits (or memory runs out).
-    uint32_t cap_main = 6 * b->max_n + 2048;   // node_index < 2^38 is guaranteed by cap64 <= 0xF0000000 below
+    // (round 6: the first attempt's scratch is sized from a memory budget, not from the clean-data bound alone - first_pass_cap)
+    uint32_t cap_main = first_pass_cap(b->max_n, b->order.size(), b->n_cu);   // node_index < 2^38 is guaranteed by cap64 <= 0xF0000000 below
+    std::vector<uint32_t> blk_cap(b->n_blocks, cap_main);   // the capacity every block's latest attempt ran with
     // Large blocks that would be the critical path get a segment-parallel heuristic on a second stream, beside the
     // ordinary pass over all other blocks; their (short) main search follows on that stream.
     HP_HIP_CHECK(hipEventRecord(b->ev_fork, st));
@@ -837,13 +861,16 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
         for (uint32_t i : b->order) (is_seg[i] ? items_seg : items_seq).push_back(i);
         uint32_t seg_max_n = 0;
         for (uint32_t i : items_seg) seg_max_n = std::max(seg_max_n, b->desc[i].n_vars);
-        rc = launch_pass(b, b->stream2, items_seg, 6 * seg_max_n + 2048, b->g_main_pool, b->g_main_heap, b->g_sub_pool, b->g_sub_heap,
+        const uint32_t cap_seg = first_pass_cap(seg_max_n, items_seg.size(), b->n_cu);
+        for (uint32_t i : items_seg) blk_cap[i] = cap_seg;
+        rc = launch_pass(b, b->stream2, items_seg, cap_seg, b->g_main_pool, b->g_main_heap, b->g_sub_pool, b->g_sub_heap,
                          b->g_tracker, b->g_slots, b->g_cap, b->d_order2);
         if (rc != HP_OK) return rc;
         HP_HIP_CHECK(hipEventRecord(b->ev_join, b->stream2));
         uint32_t seq_max_n = 0;
         for (uint32_t i : items_seq) seq_max_n = std::max(seq_max_n, b->desc[i].n_vars);
-        cap_main = 6 * seq_max_n + 2048;
+        cap_main = first_pass_cap(seq_max_n, items_seq.size(), b->n_cu);
+        for (uint32_t i : items_seq) blk_cap[i] = cap_main;
     }
     if (!items_seq.empty()) {
         rc = launch_pass(b, st, items_seq, cap_main, b->s_main_pool, b->s_main_heap, b->s_sub_pool, b->s_sub_heap,
@@ -861,12 +888,23 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
     for (uint32_t i : b->order) if (status[i] == ST_OVERFLOW_MAIN) retry.push_back(i);
     DevBuf r_main_pool, r_main_heap, r_sub_pool, r_sub_heap, r_tracker, r_items;
     uint32_t r_slots = 0, r_cap = 0;
-    uint64_t cap64 = 6ull * b->max_n + 2048;
+    std::vector<hp_work_counters> ovf_ctr;
     while (!retry.empty()) {
-        cap64 *= 4;
+        // An attempt that ran out of scratch left how far it had come (hp_work_counters.reserved[2] = variants reached): the next
+        // attempt gets what the whole block needs at that rate, with half as much again on top, and never less than twice what
+        // failed. (Until round 6: 4x per attempt - a 2 500-het block at 60x with 15 % wrong cells ran its main search three times,
+        // 15 + 50 + 51 ms.)
+        ovf_ctr.resize(b->n_blocks);
+        if ((rc = fetch_all(b, st, {{ovf_ctr.data(), b->d_counters.p, ovf_ctr.size() * sizeof(hp_work_counters)}})) != HP_OK) return rc;
+        uint64_t cap64 = 0;
+        for (uint32_t i : retry) {
+            const uint64_t n = b->desc[i].n_vars, reached = std::min<uint64_t>(std::max<uint64_t>(ovf_ctr[i].reserved[2], 1), n);
+            const uint64_t est = (uint64_t)blk_cap[i] * n / reached * 3 / 2 + 2048;
+            cap64 = std::max<uint64_t>(cap64, std::min<uint64_t>(std::max<uint64_t>(est, 2ull * blk_cap[i]), 64ull * blk_cap[i]));
+        }
         if (cap64 > 0xF0000000ull) { set_error("search frontier exceeds 2^32 nodes"); return HP_ERR_OOM; }
-        uint32_t rmax = 0;
-        for (uint32_t i : retry) rmax = std::max(rmax, b->desc[i].n_vars);
+        for (uint32_t i : retry) blk_cap[i] = (uint32_t)cap64;
+        if (std::getenv("HP_DEBUG")) { fprintf(stderr, "[hp] %zu blocks ran out of main-search scratch: again with %llu nodes\n", retry.size(), (unsigned long long)cap64); fflush(stderr); }
         HP_HIP_CHECK(hipEventRecord(b->ev0, st));
         rc = launch_pass(b, st, retry, (uint32_t)cap64, r_main_pool, r_main_heap, r_sub_pool, r_sub_heap, r_tracker, r_slots,
                          r_cap, r_items);
@@ -880,6 +918,20 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
         std::vector<uint32_t> again;
         for (uint32_t i : retry) if (status[i] == ST_OVERFLOW_MAIN) again.push_back(i);
         retry.swap(again);
+    }
+    if (std::getenv("HP_DEBUG")) {   // the blocks a solve's time is made of: shader-clock ticks of the heuristic chain and of the main search
+        std::vector<hp_work_counters> ctr(b->n_blocks);
+        if (fetch_all(b, st, {{ctr.data(), b->d_counters.p, ctr.size() * sizeof(hp_work_counters)}}) == HP_OK) {
+            std::vector<uint32_t> by(b->n_blocks);
+            std::iota(by.begin(), by.end(), 0u);
+            std::sort(by.begin(), by.end(), [&](uint32_t x, uint32_t y) { return ctr[x].reserved[0] + ctr[x].reserved[1] > ctr[y].reserved[0] + ctr[y].reserved[1]; });
+            for (size_t k = 0; k < std::min<size_t>(4, by.size()); ++k) {
+                const hp_work_counters& c = ctr[by[k]];
+                fprintf(stderr, "[hp]   block %u: %u hets x %u reads, heuristic chain %.1f M ticks, main search %.1f M ticks (%llu pops), %llu sub-solver pops\n", by[k], b->desc[by[k]].n_vars,
+                        b->desc[by[k]].n_reads, c.reserved[0] / 1e6, c.reserved[1] / 1e6, (unsigned long long)c.main_pops, (unsigned long long)c.sub_pops);
+            }
+            fflush(stderr);
+        }
     }
     if (kernel_ms) *kernel_ms = ms_total;
     g_last_kernel_ms = ms_total;

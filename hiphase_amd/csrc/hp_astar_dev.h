@@ -175,6 +175,12 @@ struct BatchDev {
     uint64_t* sub_heap_g; // [slots][jcap_sub*64] packed sub keys (only when the sub heap does not fit LDS)
     Key* main_heap;       // [slots][jcap_main*64]
     uint32_t* tracker;    // [slots][max_n_vars+1]
+    // what the segment-parallel heuristic left for this launch's blocks (null / 0 segments: none): a block it could not accept
+    // takes over every segment whose seam closes against the true chain (heuristic_phase)
+    const SegDesc* segs;
+    const SegOut* seg_out;
+    const uint32_t* blk_seg_first;   // per block: its first segment (segments of a block are consecutive, bottom first)
+    const uint32_t* blk_seg_n;       // per block: how many
     SolveParams prm;
 };
 

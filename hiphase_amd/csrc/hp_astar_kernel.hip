@@ -26,6 +26,9 @@
 namespace hp {
 
 #define DEVINL __device__ __forceinline__
+#ifndef HP_MAIN_PROF
+#define HP_MAIN_PROF 0   // tuning aid: ticks of the main search by phase, packed over the counters' reserved words
+#endif
 
 // LDS layout (bytes): [0,512) H ring (64 x u64) | [512,768) variant ring (64 x (lo | flags << 28)) | [768,...) sub heap
 // 768 + 11 x 512 B of heap = 6400 B at default parameters = exactly five 1280-byte LDS allocation granules of gfx950
@@ -966,7 +969,42 @@ DEVINL HeurResult heuristic_phase(const BatchDev& B, uint32_t blk, uint32_t slot
         if (lane == 0) H[N] = 0;
         ringH_set(N, 0);
         uint32_t clip = 1;
+        // A block the segment-parallel heuristic ran for and could not accept (a seam stayed open after the long warm-up) is not
+        // walked again from end to end: this chain IS the truth, so at the top of every segment it holds what that segment's
+        // warm-up had to reproduce - the 40-value look-ahead state and the clip. Where they are identical the segment's owned
+        // values are this chain's own (same function of the same inputs) up to the offset: they are taken over, offset applied,
+        // and the chain goes on below the segment; only a segment whose seam is open against the TRUE state is computed here.
+        // (Round 6. Until then one open seam of a hundred cost the block its whole sequential chain: 123 us a variant at 60x.)
+        const uint32_t seg_n = B.blk_seg_n ? B.blk_seg_n[blk] : 0u;
+        const uint32_t seg_0 = seg_n ? B.blk_seg_first[blk] : 0u;
+        uint32_t seg_k = seg_n;   // segments [0, seg_k) lie below the chain's position
         for (uint32_t v = N; v-- > 0;) {
+            if (seg_k > 0 && v + 1 == B.segs[seg_0 + seg_k - 1].b) {
+                seg_k -= 1;
+                const SegDesc sd = B.segs[seg_0 + seg_k];
+                const SegOut& o = B.seg_out[seg_0 + seg_k];
+                const uint64_t hb = ringH_get(sd.b), s00 = o.seam[0];
+                bool cj = true;
+                if (lane >= 1 && lane < SEG_STATE && sd.b + lane <= N)
+                    cj = (o.seam[lane] - s00) == (reinterpret_cast<const uint64_t*>(hp_smem + LDS_HRING_OFF)[(sd.b + lane) & 63u] - hb);
+                if (o.status == ST_OK && o.clip_at_b == clip && __all(cj) && sd.a < sd.b) {
+                    const uint64_t off = hb - s00;
+                    for (uint32_t x = sd.a + lane; x < sd.b; x += 64) {
+                        const uint64_t hx = H[x] + off;
+                        H[x] = hx;
+                        if (x - sd.a < 64u) {   // the chain's rings: the 64 variants above its new position
+                            reinterpret_cast<uint64_t*>(hp_smem + LDS_HRING_OFF)[x & 63u] = hx;
+                            reinterpret_cast<uint32_t*>(hp_smem + LDS_VRING_OFF)[x & 63u] = vlo[x] | ((uint32_t)vflags[x] << 28);
+                        }
+                    }
+                    clip = o.clip_out;
+                    wc.sub_pops += o.ctr.sub_pops;
+                    wc.nodes += o.ctr.nodes_created;
+                    if (lane == 0) { cx.evals += o.ctr.evals; cx.cells += o.ctr.cells; }
+                    v = sd.a;   // (the loop's own v-- moves on to sd.a - 1)
+                    continue;
+                }
+            }
             ringH_set(v, 0);  // heuristic_costs[problem_offset] is still 0 (astar_phaser.rs:320)
             uint32_t fl = 0, l = 0, h = 0;
             if (lane == 0) { fl = vflags[v]; l = vlo[v]; }
@@ -1044,6 +1082,11 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
 
     // ---- main pruned search (astar_phaser.rs:451-633) ---------------------------------------------------
     hp_phase_stats stats{};
+    uint32_t ovf_progress = 0;   // how far the search had come when its scratch ran out: the host sizes the next attempt with it
+#if HP_MAIN_PROF
+    uint64_t mp_prof0 = 0, mp_prof1 = 0, mp_prof2 = 0;
+    const uint64_t mp_rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+#endif
     if (st == ST_OK) {
         MainHeap hq;
         hq.base = B.main_heap + (size_t)slot * prm.jcap_main * 64;
@@ -1095,6 +1138,14 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
         bool fast_valid = fast_ok;
         FastState fs{0, 0, 0, 0};
         uint32_t ring_chunk = NONE32;   // which 64-variant chunk the LDS rings hold
+#if HP_MAIN_PROF
+        uint64_t mp_exp = 0, mp_store = 0, mp_pop = 0, mp_fam = 0, mp_jumps = 0, mp_t = 0;
+#define MP_T0() mp_t = __builtin_readcyclecounter()
+#define MP_ACC(x) { const uint64_t n_ = __builtin_readcyclecounter(); x += n_ - mp_t; mp_t = n_; }
+#else
+#define MP_T0()
+#define MP_ACC(x)
+#endif
 
         while (cur.depth < N) {
             wc.main_pops += 1;
@@ -1109,8 +1160,15 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
                 pruned += 1;
                 if (hq.empty()) { st = ST_INVARIANT; break; }
                 const Key t = hq.top;
+                MP_T0();
                 hq.pop();
+                MP_ACC(mp_pop);
                 cur = cur_from_fam(load_fam(mainp.fam + (key_idx(t) - key_rank(t))), key_rank(t), t.hi >> 24, key_idx(t), 0);
+#if HP_MAIN_PROF
+                if (cur.depth == 0xFFFFFFFFu) break;
+                MP_ACC(mp_fam);
+                mp_jumps += 1;
+#endif
                 fast_valid = false;
                 continue;
             }
@@ -1131,11 +1189,13 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
             Kids kd;
             CellCost cc;
             const bool collide = (fl & VAR_NOFAST) != 0;
+            MP_T0();
             if (fast_valid && !collide) expand_fast<false, TILES>(cx, cur, 0, p, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, fs, cc);
             else expand<false, TILES>(cx, cur, 0, p, l, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, fs, cc);
             cx.flush();
+            MP_ACC(mp_exp);
             wc.nodes += kd.n;
-            if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; break; }
+            if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; ovf_progress = next_expected; break; }
             if (kd.bad && kid_total<0>(kd) != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:529
             const Key k0 = make_key(kid_total<0>(kd), kid_hets<0>(kd), next_idx + kid_rank<0>(kd), kid_rank<0>(kd), kd.depth);
             const Key k1 = kid_valid<1>(kd) ? make_key(kid_total<1>(kd), kid_hets<1>(kd), next_idx + kid_rank<1>(kd), kid_rank<1>(kd), kd.depth) : key_inf();
@@ -1155,6 +1215,7 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
                 const Key q2 = best <= 2 ? k3 : k2;
                 hq.push3(q0 /* never the infinite key unless a lone child */, q1, q2);
             }
+            MP_ACC(mp_store);
             qlen += kd.n;
             // astar_phaser.rs:564-585
             while (trk_total > thr && min_progress < next_expected) {
@@ -1182,15 +1243,27 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
                 fast_valid = fast_ok && !collide;
             } else {
                 fast_valid = false;
+                MP_T0();
                 hq.push(kbest);
                 const Key t = hq.top;
                 hq.pop();
+                MP_ACC(mp_pop);
                 cur = cur_from_fam(load_fam(mainp.fam + (key_idx(t) - key_rank(t))), key_rank(t), t.hi >> 24, key_idx(t), 0);
+#if HP_MAIN_PROF
+                if (cur.depth == 0xFFFFFFFFu) break;   // (never: makes the record's words a dependency of the stamp below)
+                MP_ACC(mp_fam);
+                mp_jumps += 1;
+#endif
             }
             next_idx += kd.n;
-            if (__any(hq.ovf) || mainp.ovf) { st = ST_OVERFLOW_MAIN; break; }
+            if (__any(hq.ovf) || mainp.ovf) { st = ST_OVERFLOW_MAIN; ovf_progress = next_expected; break; }
         }
 
+#if HP_MAIN_PROF
+        mp_prof0 = (mp_exp >> 10) | ((mp_store >> 10) << 32);   // kilo-ticks: expansion | record store + pushes
+        mp_prof1 = mp_jumps;
+        mp_prof2 = (mp_pop >> 10) | ((mp_fam >> 10) << 32);     // kilo-ticks: push + pop of a jump | the popped node's family record
+#endif
         if (st == ST_OK) {
             // ---- emit the solution (astar_phaser.rs:588-628): walk the window chain from the last chunk down
             uint8_t* o1 = B.h1 + d.var_off;
@@ -1248,11 +1321,16 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
         c.sub_pops = wc.sub_pops;
         if (st == ST_OVERFLOW_MAIN) {  // keep only the heuristic phase; the main search will be redone
             c.evals = h_evals; c.cells = h_cells; c.nodes_created = h_nodes;
+            c.reserved[2] = ovf_progress;   // (the attempt that succeeds writes its own counters: reserved[] is zero there)
         } else {
             c.main_pops = wc.main_pops; c.evals = h_evals + m_evals; c.cells = h_cells + m_cells; c.nodes_created = wc.nodes;
         }
         c.reserved[0] = t_heur - t_start;                      // shader-clock cycles spent in the heuristic chain
         c.reserved[1] = __builtin_readcyclecounter() - t_heur;  // ... in the main search + emit
+#if HP_MAIN_PROF
+        c.reserved[2] = mp_prof2; c.sub_pops = mp_prof1; c.reserved[0] = mp_prof0;
+        c.cells = __builtin_amdgcn_s_memrealtime() - mp_rt0;
+#endif
         B.counters[blk] = c;
         B.status[blk] = st;
     }

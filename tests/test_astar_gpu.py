@@ -133,10 +133,35 @@ def test_reference_assert_is_reported():
     assert e2.value.code == -3
 
 
-def test_noisy_default_params_overflow_retry():
-    """C2-noisy shape, small: the frontier outgrows the 4N+64 node pool and the host retries."""
+@pytest.mark.parametrize("cap0", [None, "6", "1"])
+def test_noisy_default_params_overflow_retry(monkeypatch, cap0):
+    """C2-noisy shape, small: the frontier outgrows the node pool of the first attempt and the host retries with a pool sized from
+    how far that attempt came (hp_astar.hip, first_pass_cap and the retry loop of hp_batch_solve). HP_ASTAR_CAP0 = nodes per variant of
+    the first attempt: 6 was every first attempt until round 6 (one retry here), 1 cannot even hold clean data (several); the default
+    is sized from a memory budget."""
+    if cap0 is not None:
+        monkeypatch.setenv("HP_ASTAR_CAP0", cap0)
     blk, _ = synth_block(300, 60, 20, 0.30, 0.02, 13)
+    clean, _ = synth_block(400, 30, 20, 0.01, 0.02, 14)
+    check_batch([blk, clean])
     check_batch([blk])
+
+
+@pytest.mark.parametrize("warm", [("4", "8"), ("8", "24"), ("48", "48")])
+def test_blocks_with_open_seams_take_over_the_segments_that_verify(monkeypatch, warm):
+    """Segment-parallel heuristic (hp_astar_dev.h): with warm-ups this short most seams stay open after both rounds and no block is
+    accepted as a whole. The main kernel's own chain then walks such a block from its end and, at the top of every segment, holds the
+    TRUE look-ahead state: a segment whose warm-up reproduced it is taken over (offset applied, its work counted), any other is
+    computed in place (hp_astar_kernel.hip, heuristic_phase). Heuristic array, work counters, haplotypes and statistics must be the
+    oracle's whichever segments were taken over; HP_SEG_NO_TAKEOVER=1 is the whole sequential chain, same results."""
+    monkeypatch.setenv("HP_SEG_WARM", warm[0])
+    monkeypatch.setenv("HP_SEG_WARM2", warm[1])
+    blocks = [synth_block(n, c, 20, e, 0.02, 900 + i)[0] for i, (n, c, e) in enumerate(
+        [(700, 30, 0.15), (333, 60, 0.10), (64, 30, 0.02), (1000, 30, 0.01), (97, 30, 0.2), (640, 20, 0.05)])]
+    check_batch(blocks)
+    check_batch(blocks[:1])
+    monkeypatch.setenv("HP_SEG_NO_TAKEOVER", "1")
+    check_batch(blocks[:2])
 
 
 def test_batch_many_blocks_mixed():
