@@ -504,7 +504,8 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     prm.max_n_vars = max_n;
     prm.seg_profile = std::getenv("HP_SEG_PROFILE") ? 1u : 0u;   // per-segment s_memtime profile of the sub-solver loop
     const bool verbose = std::getenv("HP_DEBUG") != nullptr;
-    const size_t lds_bytes = LDS_HEAP_OFF + (prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
+    // (at least 1 KB behind the rings: the main search keeps its heaps' roots where the sub-solver's heap lay)
+    const size_t lds_bytes = LDS_HEAP_OFF + std::max<size_t>(1024, prm.sub_heap_in_lds ? (size_t)prm.jcap_sub * 64 * sizeof(uint64_t) : 0);
     // resident waves per CU limited by LDS; one wave per workgroup
     const int occ = prm.sub_heap_in_lds ? 6 : 4;
     uint32_t per_cu = (uint32_t)std::min<size_t>(4 * occ, (160 * 1024) / std::max<size_t>(lds_bytes, 1));

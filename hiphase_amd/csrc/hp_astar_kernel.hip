@@ -280,50 +280,70 @@ template <bool LDS> struct SubHeap {
     }
 };
 
-// (b) main heap: 128-bit keys in HBM scratch. Every level of a sift is a dependent HBM/L2 round trip, so the
-// per-lane heaps are 4-ary: half the levels of a binary heap, the four children of a node are fetched together.
+// (b) main heap: 128-bit keys in HBM scratch, one heap per lane (a key lives in lane node_index % 64, so the up to three
+// children an expansion queues land in three different lanes: one store instruction). Every level of a sift is a dependent
+// HBM / L2 round trip and nothing else runs on this wavefront meanwhile, so the heaps are as flat as the wavefront is wide:
+// 64-ary. A pop concerns ONE lane's heap (the one that holds the minimum) and the whole wavefront works on it: the 64 children
+// of a node are one coalesced 1 KB load (a lane's heap is contiguous), their minimum one DPP reduction - two levels hold 4 161
+// keys, i.e. 266 k keys over the 64 lanes in two round trips. The roots are mirrored in registers, so the minimum over the lanes
+// after a pop costs no load. (Until round 6: 4-ary heaps sifted by their own lane alone - five or six dependent trips a pop and
+// another for the new root, 4 450 shader-clock ticks of a jump's 7 000, scripts/r6_mainprof.py.)
 // Insertion is LAZY: a pushed key is appended behind the lane's heap-ordered prefix (one store, no load) and only the
 // running minimum `top` is updated; the appended keys are sifted into place when the heap order is actually needed - at
 // the next pop or full prune. A dive that never pops from the queue (the common case: the heuristic is exact on clean
 // data) never pays the dependent parent loads of a sift-up; a search that does pop pays exactly what it paid before.
+// Memory order: a heap's entries are written by its own lane and, in a pop, read by all of them: the pop waits for the
+// wavefront's outstanding stores after its own-lane part (workgroup-scope fence = s_waitcnt on a single-wavefront workgroup; the
+// wavefront's accesses go through one L1 in issue order) - by then they are a round trip old and the wait is free.
+// 128-bit lexicographic minimum over the wave and the first lane that holds it (m in scalar registers): one DPP reduction over
+// the high words; the low words only where two lanes tie in the high word (cost and het count equal: uncommon)
+DEVINL uint32_t wave_argmin_key(const Key& k, Key& m) {
+    const uint64_t mh = wave_min_u64_v(k.hi);
+    uint64_t tie = __ballot(k.hi == mh);
+    if (__popcll(tie) > 1) {
+        const uint64_t ml = wave_min_u64_v(k.hi == mh ? k.lo : ~0ull);
+        tie = __ballot(k.hi == mh && k.lo == ml);
+    }
+    const int u = __builtin_ctzll(tie);
+    m.hi = ((uint64_t)rdlane((uint32_t)(k.hi >> 32), u) << 32) | rdlane((uint32_t)k.hi, u);
+    m.lo = ((uint64_t)rdlane((uint32_t)(k.lo >> 32), u) << 32) | rdlane((uint32_t)k.lo, u);
+    return (uint32_t)u;
+}
 struct MainHeap {
     Key* base;
     uint32_t jcap, cnt;
     uint32_t hcnt;   // per lane: entries [0, hcnt) are heap-ordered, [hcnt, cnt) are appended and pending
+    // per lane: entry 0 of the heap-ordered prefix (the infinite key while it is empty) is mirrored in LDS - where the sub-solver's
+    // heap lay during the heuristic phase (1 KB; registers held across the whole search would be spilled in the sub-solver's loop)
+    DEVINL Key root() const {
+        const uint64_t* r = reinterpret_cast<const uint64_t*>(hp_smem + LDS_HEAP_OFF);
+        return Key{r[lane_id()], r[64 + lane_id()]};
+    }
+    DEVINL void set_root(const Key& k) {
+        uint64_t* r = reinterpret_cast<uint64_t*>(hp_smem + LDS_HEAP_OFF);
+        r[lane_id()] = k.hi; r[64 + lane_id()] = k.lo;
+    }
     Key top;
     uint32_t top_lane, ovf;
-    DEVINL Key ld(uint32_t j) const { return base[(size_t)j * 64 + lane_id()]; }
-    DEVINL void st(uint32_t j, const Key& k) { base[(size_t)j * 64 + lane_id()] = k; }
-    DEVINL void reset() { cnt = 0; hcnt = 0; top = key_inf(); top_lane = 0; }
+    DEVINL Key* own() const { return base + (size_t)lane_id() * jcap; }
+    DEVINL Key ld(uint32_t j) const { return own()[j]; }
+    DEVINL void st(uint32_t j, const Key& k) { own()[j] = k; }
+    DEVINL void reset() { cnt = 0; hcnt = 0; set_root(key_inf()); top = key_inf(); top_lane = 0; }
     DEVINL bool empty() const { return (top.hi & top.lo) == ~0ull; }
-    // sift the pending entries of this lane into its heap (every lane runs its own loop)
+    // sift the pending entries of this lane into its heap (every lane runs its own loop: at most two parents above an entry)
     DEVINL void integrate() {
         while (hcnt < cnt) {
             const Key k = ld(hcnt);
             uint32_t j = hcnt;
             while (j > 0) {
-                const uint32_t pj = (j - 1) >> 2;
+                const uint32_t pj = (j - 1) >> 6;
                 const Key pk = ld(pj);
                 if (key_less(k, pk)) { st(j, pk); j = pj; } else break;
             }
             if (j != hcnt) st(j, k);
+            if (j == 0) set_root(k);
             hcnt += 1;
         }
-    }
-    DEVINL void sift_down(uint32_t i, Key k) {
-        for (;;) {
-            const uint32_t c0 = 4 * i + 1;
-            if (c0 >= cnt) break;
-            Key kk[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) kk[u] = (c0 + u < cnt) ? ld(c0 + u) : key_inf();
-            Key ck = kk[0];
-            uint32_t c = c0;
-#pragma unroll
-            for (int u = 1; u < 4; ++u) if (key_less(kk[u], ck)) { ck = kk[u]; c = c0 + u; }
-            if (key_less(ck, k)) { st(i, ck); i = c; } else break;
-        }
-        st(i, k);
     }
     DEVINL void push(const Key& k) {
         const uint32_t tgt = (uint32_t)key_idx(k) & 63u;
@@ -350,9 +370,10 @@ struct MainHeap {
         if (pc && key_less(kc, top)) { top = kc; top_lane = (uint32_t)key_idx(kc) & 63u; }
     }
     // astar_phaser.rs:576-581: every queued node with depth < min_progress gets cost 0. Clearing is a decrease-key,
-    // so each lane scans its heap front to back (independent, coalesced loads) and sifts UP only the entries that
+    // so each lane scans its heap front to back (independent loads) and sifts UP only the entries that
     // are newly cleared — the pop order is a total order on the keys, so the heap's internal layout is free.
     DEVINL void clear_below(uint32_t min_progress) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         integrate();
         for (uint32_t j0 = 0; j0 < cnt; j0 += 4) {
             Key k[4];
@@ -365,30 +386,50 @@ struct MainHeap {
                     c.hi &= 0xFFFFFFull;
                     uint32_t j = j0 + u;
                     while (j > 0) {
-                        const uint32_t pj = (j - 1) >> 2;
+                        const uint32_t pj = (j - 1) >> 6;
                         const Key pk = ld(pj);
                         if (key_less(c, pk)) { st(j, pk); j = pj; } else break;
                     }
                     st(j, c);
+                    if (j == 0) set_root(c);
                 }
             }
         }
         recompute_top();
     }
-    DEVINL void recompute_top() {
-        Key mine = key_inf();
-        if (cnt > 0) mine = ld(0);
-        top = wave_min_key(mine);
-        const uint64_t who = __ballot(cnt > 0 && mine.hi == top.hi && mine.lo == top.lo);
-        top_lane = who ? (uint32_t)__builtin_ctzll(who) : 0;
+    DEVINL void recompute_top() {   // every pending entry has been integrated: the minimum is the least of the lanes' roots
+        top_lane = wave_argmin_key(root(), top);   // (an empty lane's root is the infinite key; all empty: lane 0, as before)
     }
     DEVINL void pop() {
-        integrate();   // the lane minima below are the heap roots
-        if (lane_id() == top_lane) {
-            cnt -= 1;
-            hcnt = cnt;
-            if (cnt > 0) sift_down(0, ld(cnt));
+        integrate();   // the lane minima below are the heap roots (own-lane loads and stores only)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // what follows reads lane T's entries from every lane
+        // the heap of lane `top_lane` loses its root; all 64 lanes sift its last entry down from there
+        const uint32_t T = bcast32(top_lane), lane = lane_id();
+        Key* const heap = base + (size_t)T * jcap;
+        const uint32_t n = bcast32(__builtin_amdgcn_readlane(cnt, T)) - 1u;   // what is left of it
+        Key nroot = key_inf();
+        if (n > 0) {
+            Key k = key_inf();
+            if (lane == 0) k = heap[n];
+            uint32_t i = 0;
+            bool have_k = false;
+            for (;;) {
+                const uint32_t c0 = 64u * i + 1u;
+                if (c0 >= n) break;
+                const Key ck = (c0 + lane < n) ? heap[c0 + lane] : key_inf();
+                if (!have_k) { k = Key{bcast64(k.hi), bcast64(k.lo)}; have_k = true; }
+                Key m;   // (uniform values in scalar registers: the loop's control flow is scalar)
+                const uint32_t u = wave_argmin_key(ck, m);
+                if (!key_less(m, k)) break;
+                if (lane == T) heap[i] = m;
+                if (i == 0) nroot = m;
+                i = c0 + u;
+            }
+            if (!have_k) k = Key{bcast64(k.hi), bcast64(k.lo)};
+            if (lane == T) heap[i] = k;
+            if (i == 0) nroot = k;
         }
+        if (lane == T) { cnt = n; hcnt = n; set_root(nroot); }
         recompute_top();
     }
 };
