@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 T=$1; shift
 for kv in "$@"; do export "$kv"; done
-timeout 600 python bench.py --deep60 --coverage 60 --total-hets 20000 --no-cpu --no-resident --no-drop-in --no-hifi --no-deep60 --no-pcie-probe --steps 40 2>/dev/null | tail -1 > gpurun_out/${T}.json
+timeout 600 python bench.py --deep60 --coverage 60 --total-hets 20000 --no-cpu --no-resident --no-drop-in --no-hifi --no-deep60 --no-pcie-probe --steps 40 $DEEP60_EXTRA 2>/dev/null | tail -1 > gpurun_out/${T}.json
 python - <<EOP
 import json
 d = json.loads(open("gpurun_out/${T}.json").read())
