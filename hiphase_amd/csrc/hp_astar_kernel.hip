@@ -1126,6 +1126,9 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
     uint32_t ovf_progress = 0;   // how far the search had come when its scratch ran out: the host sizes the next attempt with it
 #if HP_MAIN_PROF
     uint64_t mp_prof0 = 0, mp_prof1 = 0, mp_prof2 = 0;
+#if HP_MAIN_PROF == 2
+    uint64_t mp_dv[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     const uint64_t mp_rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
 #endif
     if (st == ST_OK) {
@@ -1187,6 +1190,12 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
 #define MP_T0()
 #define MP_ACC(x)
 #endif
+#if HP_MAIN_PROF == 2   // a dive step by part (the counters' fields carry raw ticks: head, expand, keys, store, push, prune, cur)
+        uint64_t dv[7] = {0, 0, 0, 0, 0, 0, 0}, dv_t = __builtin_readcyclecounter();
+#define DV(i) { const uint64_t n_ = __builtin_readcyclecounter(); dv[i] += n_ - dv_t; dv_t = n_; }
+#else
+#define DV(i)
+#endif
 
         while (cur.depth < N) {
             wc.main_pops += 1;
@@ -1230,11 +1239,13 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
             Kids kd;
             CellCost cc;
             const bool collide = (fl & VAR_NOFAST) != 0;
+            DV(0);
             MP_T0();
             if (fast_valid && !collide) expand_fast<false, TILES>(cx, cur, 0, p, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, fs, cc);
             else expand<false, TILES>(cx, cur, 0, p, l, (fl & HP_VAR_IGNORED) != 0, hn, mainp, kd, wc, fs, cc);
             cx.flush();
             MP_ACC(mp_exp);
+            DV(1);
             wc.nodes += kd.n;
             if (next_idx + kd.n > prm.cap_main) { st = ST_OVERFLOW_MAIN; ovf_progress = next_expected; break; }
             if (kd.bad && kid_total<0>(kd) != cur.total) { st = ST_INVARIANT; break; }  // astar_phaser.rs:529
@@ -1248,8 +1259,13 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
             if (key_less(k2, kbest)) { kbest = k2; best = 2; }
             if (key_less(k3, kbest)) { kbest = k3; best = 3; }
             // push every child except the best one, which is held in registers (it is logically queued)
+#if HP_MAIN_PROF == 2
+            if (kbest.hi == 0x123456789ull) break;   // (never: the keys are a dependency of the stamp)
+#endif
+            DV(2);
             trk_add(kd.depth, kd.n);
             fam_store(mainp.fam, kd, cur, (uint32_t)next_idx);
+            DV(3);
             {   // the (at most three) children other than `best`
                 const Key q0 = best == 0 ? k1 : k0;
                 const Key q1 = best <= 1 ? k2 : k1;
@@ -1257,6 +1273,7 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
                 hq.push3(q0 /* never the infinite key unless a lone child */, q1, q2);
             }
             MP_ACC(mp_store);
+            DV(4);
             qlen += kd.n;
             // astar_phaser.rs:564-585
             while (trk_total > thr && min_progress < next_expected) {
@@ -1275,6 +1292,7 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
                     if (kd.depth < min_progress) kbest.hi &= 0xFFFFFFull;
                 }
             }
+            DV(5);
             if (key_less(kbest, hq.top)) {
                 if (best == 0) { cur = kid_as_cur<0>(kd, next_idx); fast_apply<TILES>(fs, cc, false, true); }
                 else if (best == 1) { cur = kid_as_cur<1>(kd, next_idx); fast_apply<TILES>(fs, cc, true, false); }
@@ -1297,6 +1315,10 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
 #endif
             }
             next_idx += kd.n;
+#if HP_MAIN_PROF == 2
+            if (cur.frozen == 0x123456789abcull && cur.anc1 == 77u) break;   // (never)
+#endif
+            DV(6);
             if (__any(hq.ovf) || mainp.ovf) { st = ST_OVERFLOW_MAIN; ovf_progress = next_expected; break; }
         }
 
@@ -1304,6 +1326,9 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
         mp_prof0 = (mp_exp >> 10) | ((mp_store >> 10) << 32);   // kilo-ticks: expansion | record store + pushes
         mp_prof1 = mp_jumps;
         mp_prof2 = (mp_pop >> 10) | ((mp_fam >> 10) << 32);     // kilo-ticks: push + pop of a jump | the popped node's family record
+#endif
+#if HP_MAIN_PROF == 2
+        for (int i = 0; i < 7; ++i) mp_dv[i] = dv[i];
 #endif
         if (st == ST_OK) {
             // ---- emit the solution (astar_phaser.rs:588-628): walk the window chain from the last chunk down
@@ -1371,6 +1396,9 @@ DEVINL void main_phase(const BatchDev& B, uint32_t blk, uint32_t slot, HeurResul
 #if HP_MAIN_PROF
         c.reserved[2] = mp_prof2; c.sub_pops = mp_prof1; c.reserved[0] = mp_prof0;
         c.cells = __builtin_amdgcn_s_memrealtime() - mp_rt0;
+#endif
+#if HP_MAIN_PROF == 2
+        c.sub_pops = mp_dv[0]; c.evals = mp_dv[1]; c.cells = mp_dv[2]; c.nodes_created = mp_dv[3]; c.reserved[0] = mp_dv[4]; c.reserved[1] = mp_dv[5]; c.reserved[2] = mp_dv[6];
 #endif
         B.counters[blk] = c;
         B.status[blk] = st;
