@@ -495,7 +495,7 @@ int launch_segments(hp_batch* b, hipStream_t st, std::vector<uint32_t>& seg_bloc
 
 int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items, uint32_t cap_main,
                 DevBuf& main_pool, DevBuf& main_heap, DevBuf& sub_pool, DevBuf& sub_heap, DevBuf& tracker,
-                uint32_t& have_slots, uint32_t& have_cap, DevBuf& d_items) {
+                uint32_t& have_slots, uint32_t& have_cap, DevBuf& d_items, bool seg_pass = false) {
     SolveParams prm = b->prm;
     prm.cap_main = cap_main;
     prm.jcap_main = (cap_main + 63) / 64 + 1;
@@ -548,7 +548,10 @@ int launch_pass(hp_batch* b, hipStream_t st, const std::vector<uint32_t>& items,
     B.status = b->d_status.as<int32_t>();
     B.sub_pool = sub_pool.as<unsigned char>(); B.main_pool = main_pool.as<unsigned char>();
     B.sub_heap_g = sub_heap.as<uint64_t>(); B.main_heap = main_heap.as<Key>(); B.tracker = tracker.as<uint32_t>();
-    if (b->last_n_segs && !std::getenv("HP_SEG_NO_TAKEOVER")) {   // (HP_SEG_NO_TAKEOVER=1: an unaccepted block walks its whole chain, as until round 6 - A/B switch)
+    // (only the launch BEHIND the segment kernels, on their stream: the tables are uploaded on that stream, and no other launch has a
+    // block with segments - the ordinary pass on the other stream read them before they had arrived, found by HP_DEV_CACHE_POISON=1.
+    // HP_SEG_NO_TAKEOVER=1: an unaccepted block walks its whole chain, as until round 6 - A/B switch)
+    if (seg_pass && b->last_n_segs && !std::getenv("HP_SEG_NO_TAKEOVER")) {
         B.segs = b->d_segs.as<SegDesc>(); B.seg_out = b->d_seg_out.as<SegOut>();
         B.blk_seg_first = b->d_blk_seg.as<uint32_t>(); B.blk_seg_n = b->d_blk_seg.as<uint32_t>() + b->n_blocks;
     }
@@ -865,7 +868,7 @@ int hp_batch_solve(hp_batch* b, void* stream, float* kernel_ms) {
         const uint32_t cap_seg = first_pass_cap(seg_max_n, items_seg.size(), b->n_cu);
         for (uint32_t i : items_seg) blk_cap[i] = cap_seg;
         rc = launch_pass(b, b->stream2, items_seg, cap_seg, b->g_main_pool, b->g_main_heap, b->g_sub_pool, b->g_sub_heap,
-                         b->g_tracker, b->g_slots, b->g_cap, b->d_order2);
+                         b->g_tracker, b->g_slots, b->g_cap, b->d_order2, true);
         if (rc != HP_OK) return rc;
         HP_HIP_CHECK(hipEventRecord(b->ev_join, b->stream2));
         uint32_t seq_max_n = 0;

@@ -82,6 +82,22 @@ def test_worker_pool_rate_from_cpp():
 
 
 @pytest.mark.timeout(900)
+def test_worker_pool_with_recycled_device_blocks_poisoned():
+    """The same binary with HP_DEV_CACHE_POISON=1 (every block the device-buffer cache hands out is filled with 0xA5 first) and no bar
+    on the rate: merged batches mix blocks that take the segment-parallel heuristic (its tables uploaded on the segment stream) with
+    blocks of the ordinary pass on the other stream. Round 6 had the ordinary pass look a block's segments up in those tables before
+    they had arrived - harmless by luck on fresh memory, a GPU memory fault on poisoned memory; this run is what found it."""
+    import os
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    binp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "coalesce_test")
+    env = dict(os.environ, HP_DEV_CACHE_POISON="1")
+    r = subprocess.run([binp, "64", "12", "0"], capture_output=True, text=True, timeout=400, env=env)
+    assert "bit-identical" in r.stdout and r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("queue_devices", ["3", None])
 def test_worker_pool_through_the_block_entry_over_all_devices(queue_devices):
     """64 std::threads each calling hp_solve_blocks(1, ..., device_id = -1) - what the one-call-site Rust patch does from HiPhase's
